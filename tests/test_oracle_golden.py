@@ -1,0 +1,126 @@
+"""Pins the oracle (CPU restatement) to vectors produced by the reference itself
+(oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser_ref as R
+from oracle import diffusion_ref as D
+from oracle import fill
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def test_g1_schedule_tables_exact(gold):
+    g = gold("g1_schedule.npz")
+    for n in (1000, 50):
+        tb = D.tables(D.linear_betas(n))
+        for name in D.TABLE_NAMES:
+            assert np.array_equal(tb[name], g["n%d.%s" % (n, name)]), name
+    tb = D.tables(D.linear_betas(1000))
+    # known answers probed from the reference
+    assert tb["betas"][0] == 1e-4 and tb["betas"][999] == 0.02
+    assert abs(tb["alphas_cumprod"][999] - 4.035829765375676e-05) < 1e-18
+    assert abs(tb["posterior_log_variance_clipped"][0] - (-9.81672513529567)) < 1e-12
+
+
+@pytest.mark.parametrize("case", ["tiny", "config1", "width"])
+@pytest.mark.parametrize("no_eff", [False, True])
+def test_g2_denoiser_forward(gold, case, no_eff):
+    g = gold("g2_denoiser_fwd.npz")
+    c = fill.CASES[case]
+    tag = "%s.%s" % (case, "full" if no_eff else "lin")
+    p = fill.core_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"])
+    inp = fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"])
+    with torch.no_grad():
+        out, inter = R.denoiser_forward(p, inp["x"], inp["t"], inp["length"], inp["xf_proj"],
+                                        inp["xf_out"], c["H"], c["L"], no_eff=no_eff,
+                                        return_intermediates=True)
+    tol = 1e-3 if no_eff else 2e-6  # the reference's own fp32 floor is 1.9e-4 for no_eff
+    assert rel(out, g[tag + ".out"]) < tol
+    if case != "width":
+        for k in ("sa0", "ca0", "ffn0"):
+            assert rel(inter[k], g[tag + "." + k]) < tol, k
+
+
+@pytest.mark.parametrize("case", ["tiny", "config1"])
+def test_g3_denoiser_backward(gold, case):
+    g = gold("g3_denoiser_bwd.npz")
+    c = fill.CASES[case]
+    tag = case + ".lin"
+    p = {k: v.requires_grad_(True) for k, v in
+         fill.core_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"]).items()}
+    inp = fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"])
+    x, xp, xo = (inp[k].clone().requires_grad_(True) for k in ("x", "xf_proj", "xf_out"))
+    out = R.denoiser_forward(p, x, inp["t"], inp["length"], xp, xo, c["H"], c["L"])
+    r = fill.tensor_for("loss.r." + case, out.shape) * 10.0
+    (out * r).sum().backward()
+    assert rel(x.grad, g[tag + ".dx"]) < 1e-5
+    assert rel(xp.grad, g[tag + ".dxf_proj"]) < 1e-5
+    assert rel(xo.grad, g[tag + ".dxf_out"]) < 1e-5
+    for k in g.files:
+        if k.startswith(tag + ".g."):
+            # key.bias grads are mathematically 0 (column softmax is shift invariant): abs floor
+            a, b = p[k[len(tag) + 3:]].grad.double(), torch.as_tensor(g[k]).double()
+            assert (a - b).norm() <= 1e-5 * b.norm() + 1e-6 * b.numel() ** 0.5, k
+    tot = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in p.values())).item()
+    assert abs(tot - float(g[tag + ".gnorm_core"])) / float(g[tag + ".gnorm_core"]) < 1e-5
+
+
+def test_g4_diffusion_elementwise(gold):
+    g = gold("g4_diffusion.npz")
+    tb = D.tables(D.linear_betas(1000))
+    x, eps, t = torch.tensor(g["x"]), torch.tensor(g["eps"]), torch.tensor(g["t"])
+    z0 = fill.tensor_for("g4.z.0", x.shape) * 10.0
+    z1 = fill.tensor_for("g4.z.1", x.shape) * 10.0
+    assert torch.equal(D.q_sample(tb, x, t, z0), torch.tensor(g["q_sample"]))
+    sample, x0, mean, logv = D.p_step(tb, x, t, eps, z1)
+    assert torch.equal(x0, torch.tensor(g["pred_xstart"]))
+    assert torch.equal(mean, torch.tensor(g["mean"]))
+    assert torch.equal(logv, torch.tensor(g["log_variance"]))
+    assert torch.equal(sample, torch.tensor(g["p_sample"]))
+    assert torch.equal(sample[0], mean[0])  # t == 0: no noise
+    noise = fill.tensor_for("g4.noise", x.shape) * 10
+    mse = ((noise - eps) ** 2).mean(dim=(1, 2))
+    assert rel(mse, g["tl_mse"]) < 1e-6
+
+
+def test_g5_mini_loop(gold):
+    g = gold("g5_loop.npz")
+    c = fill.CASES["tiny"]
+    p = fill.core_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"])
+    inp = fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"])
+    tb = D.tables(D.linear_betas(50))
+    shape = (c["B"], c["T"], c["F"])
+    img = fill.tensor_for("g5.z.0", shape) * 10.0
+    k = 1
+    with torch.no_grad():
+        for i in range(49, -1, -1):
+            t = torch.full((c["B"],), i, dtype=torch.int64)
+            eps = R.denoiser_forward(p, img, t, inp["length"], inp["xf_proj"], inp["xf_out"],
+                                     c["H"], c["L"])
+            z = fill.tensor_for("g5.z.%d" % k, shape) * 10.0
+            k += 1
+            img = D.p_step(tb, img, t, eps, z)[0]
+    assert rel(img, g["final"]) < 1e-4
+
+
+def test_properties_padding_and_permutation():
+    c = fill.CASES["tiny"]
+    p = fill.core_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"])
+    inp = fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"])
+    with torch.no_grad():
+        full = R.denoiser_forward(p, inp["x"], inp["t"], inp["length"], inp["xf_proj"],
+                                  inp["xf_out"], c["H"], c["L"])
+        # padding invariance (interaction_transformer.py:831-854 smoke): sample 1 truncated to its length
+        n = c["lengths"][1]
+        tr = R.denoiser_forward(p, inp["x"][1:2, :n], inp["t"][1:2], torch.tensor([n]),
+                                inp["xf_proj"][1:2], inp["xf_out"][1:2], c["H"], c["L"])
+        assert rel(tr, full[1:2, :n]) < 1e-5
+        perm = torch.tensor([1, 0])
+        pr = R.denoiser_forward(p, inp["x"][perm], inp["t"][perm], inp["length"][perm],
+                                inp["xf_proj"][perm], inp["xf_out"][perm], c["H"], c["L"])
+        assert rel(pr, full[perm]) < 1e-6
