@@ -1,0 +1,487 @@
+// Launch sequences of the denoiser forward / backward over the fused kernels.
+// Reference: MotionTransformer.forward (codes/models/transformer.py:407-426) and the blocks it
+// calls (:60-194); backward is the hand-derived adjoint of exactly that graph (the reference
+// relies on torch autograd).  Host code only: every call enqueues kernels on `stream`, nothing
+// else -- safe under hipGraph capture.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "hig_common.h"
+
+int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+int hig_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+extern "C" int hig_last_error(char* buf, int n) {
+  if (buf && n > 0) {
+    strncpy(buf, g_err, (size_t)n - 1);
+    buf[n - 1] = 0;
+  }
+  return (int)strlen(g_err);
+}
+extern "C" int hig_version(void) { return 100; }
+
+namespace {
+
+__global__ void mul_dsilu_kernel(const float* __restrict__ a, const float* __restrict__ z, int64_t n,
+                                 float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = a[i] * hig_dsilu(z[i]);
+}
+
+inline int64_t al(int64_t floats) { return (floats + 63) & ~(int64_t)63; }  // 256-byte granules
+
+struct Dims {
+  int B, T, F, d, H, ff, L, N, Lt, nf, hd, E;
+  int64_t M, Mt;
+};
+
+int check_dims(const hig_dims* p, Dims& D) {
+  HIG_REQUIRE(p, "null dims");
+  D.B = p->B; D.T = p->T; D.F = p->F; D.d = p->d; D.H = p->H; D.ff = p->ff; D.L = p->L;
+  D.N = p->N; D.Lt = p->Lt; D.nf = p->num_frames;
+  HIG_REQUIRE(D.B > 0 && D.T > 0 && D.F > 0 && D.d > 0 && D.H > 0 && D.ff > 0 && D.L > 0 && D.N > 0 && D.Lt > 0,
+              "hig_dims: every extent must be positive");
+  HIG_REQUIRE(D.d % D.H == 0, "hig_dims: d=%d not divisible by H=%d", D.d, D.H);
+  D.hd = D.d / D.H;
+  D.E = 4 * D.d;
+  HIG_REQUIRE(D.hd == 8 || D.hd == 16 || D.hd == 32 || D.hd == 64 || D.hd == 128,
+              "hig_dims: head dim %d not in {8,16,32,64,128}", D.hd);
+  HIG_REQUIRE(D.d % 4 == 0 && D.ff % 4 == 0 && D.Lt % 4 == 0, "hig_dims: d, ff, Lt must be multiples of 4");
+  HIG_REQUIRE(D.d <= 1024 && D.Lt <= 1024, "hig_dims: d and Lt must be <= 1024");
+  HIG_REQUIRE(D.T <= D.nf, "hig_dims: T=%d exceeds num_frames=%d", D.T, D.nf);
+  if (p->attn_kind != HIG_ATTN_LINEAR)
+    return hig_set_error(HIG_EUNSUPPORTED, "hig: attn_kind=%d (no_eff) kernels are not built yet", p->attn_kind);
+  if (p->prec != HIG_PREC_F32)
+    return hig_set_error(HIG_EUNSUPPORTED, "hig: prec=%d not built yet (HIG_PREC_F32 only)", p->prec);
+  D.M = (int64_t)D.B * D.T;
+  D.Mt = (int64_t)D.B * D.N;
+  return HIG_OK;
+}
+
+// Forward workspace (floats).  Per-layer block repeated L times when training, once otherwise.
+struct FwdLayout {
+  int64_t te, te_h, emb, ss, h0;
+  int64_t layer0, lstride;
+  int64_t st1, qkv, A1, kst1, y1, st2, h1, st3, qc, y2, st4, h2, z1, f1, y3, st5, h3;
+  int64_t total;
+};
+FwdLayout fwd_layout(const Dims& D, int training) {
+  FwdLayout w;
+  int64_t o = 0;
+  auto take = [&](int64_t n) { int64_t r = o; o += al(n); return r; };
+  w.te = take((int64_t)D.B * D.d);
+  w.te_h = take((int64_t)D.B * D.E);
+  w.emb = take((int64_t)D.B * D.E);
+  w.ss = take((int64_t)D.B * 3 * D.L * 2 * D.d);
+  w.h0 = take(D.M * D.d);
+  w.layer0 = o;
+  o = 0;
+  w.st1 = take(D.M * 2);
+  w.qkv = take(D.M * 3 * D.d);
+  w.A1 = take((int64_t)D.B * D.H * D.hd * D.hd);
+  w.kst1 = take((int64_t)D.B * D.d * 2);
+  w.y1 = take(D.M * D.d);
+  w.st2 = take(D.M * 2);
+  w.h1 = take(D.M * D.d);
+  w.st3 = take(D.M * 2);
+  w.qc = take(D.M * D.d);
+  w.y2 = take(D.M * D.d);
+  w.st4 = take(D.M * 2);
+  w.h2 = take(D.M * D.d);
+  w.z1 = take(D.M * D.ff);
+  w.f1 = take(D.M * D.ff);
+  w.y3 = take(D.M * D.d);
+  w.st5 = take(D.M * 2);
+  w.h3 = take(D.M * D.d);
+  w.lstride = training ? o : 0;
+  w.total = w.layer0 + (training ? o * D.L : o);
+  return w;
+}
+
+// Text context (floats): LN stats of xf_out (shared by all layers), then per layer the context
+// matrices + column-softmax stats, and the key/value projections (kept per layer for backward).
+struct TextLayout {
+  int64_t stt, layer0, lstride, Ac, kstc, kv, kv_stride, total;
+};
+TextLayout text_layout(const Dims& D, int training) {
+  TextLayout t;
+  int64_t o = 0;
+  auto take = [&](int64_t n) { int64_t r = o; o += al(n); return r; };
+  t.stt = take(D.Mt * 2);
+  t.layer0 = o;
+  o = 0;
+  t.Ac = take((int64_t)D.B * D.H * D.hd * D.hd);
+  t.kstc = take((int64_t)D.B * D.d * 2);
+  t.lstride = o;
+  t.kv = t.layer0 + t.lstride * D.L;
+  t.kv_stride = training ? al(D.Mt * 2 * D.d) : 0;
+  t.total = t.kv + (training ? t.kv_stride * D.L : al(D.Mt * 2 * D.d));
+  return t;
+}
+
+struct BwdLayout {
+  int64_t dhA, dhB, t1, t2, tff, dqkv, dA, dkv, dxfn, dss, demb, dtmp, dte_h, slabs, slab_floats,
+      colpart, lnpart, total;
+};
+BwdLayout bwd_layout(const Dims& D) {
+  BwdLayout w;
+  int64_t o = 0;
+  auto take = [&](int64_t n) { int64_t r = o; o += al(n); return r; };
+  w.dhA = take(D.M * D.d);
+  w.dhB = take(D.M * D.d);
+  w.t1 = take(D.M * D.d);
+  w.t2 = take(D.M * D.d);
+  w.tff = take(D.M * D.ff);
+  w.dqkv = take(D.M * 3 * D.d);
+  w.dA = take((int64_t)D.B * D.H * D.hd * D.hd);
+  w.dkv = take(D.Mt * 2 * D.d);
+  w.dxfn = take(D.Mt * D.Lt);
+  w.dss = take((int64_t)D.B * 3 * D.L * 2 * D.d);
+  w.demb = take((int64_t)D.B * D.E);
+  w.dtmp = take((int64_t)D.B * D.E);
+  w.dte_h = take((int64_t)D.B * D.E);
+  // split-R slabs: up to 1024 (tile, split) pairs of 128x128 floats, or 16 splits of any output
+  int64_t biggest = 0;
+  const int64_t outs[] = {(int64_t)3 * D.d * D.d, (int64_t)D.d * D.d, (int64_t)D.ff * D.d,
+                          (int64_t)2 * D.d * D.Lt, (int64_t)D.F * D.d, (int64_t)D.B * D.E,
+                          (int64_t)D.E * D.E, (int64_t)D.E * D.d};
+  for (int64_t v : outs) biggest = v > biggest ? v : biggest;
+  w.slab_floats = biggest * 16 > (int64_t)1536 * 128 * 128 ? biggest * 16 : (int64_t)1536 * 128 * 128;
+  w.slabs = take(w.slab_floats);
+  int64_t widest = (int64_t)D.T * D.d;
+  const int64_t wids[] = {(int64_t)3 * D.d, (int64_t)D.ff, (int64_t)D.E, (int64_t)3 * D.L * 2 * D.d, (int64_t)D.F};
+  for (int64_t v : wids) widest = v > widest ? v : widest;
+  w.colpart = take((int64_t)HIG_COLSUM_CHUNKS * widest);
+  int64_t lp = hig_ln_bwd_partial_floats(D.M, D.d, D.T);
+  const int64_t lpt = hig_ln_bwd_partial_floats(D.Mt, D.Lt, D.N);
+  w.lnpart = take(lp > lpt ? lp : lpt);
+  w.total = o;
+  return w;
+}
+
+struct G {  // small builder for gemm descriptors
+  hig_gemm_desc g;
+  G(const float* X, int64_t ldx, int xrs, const float* Y, int64_t ldy, int yrs, float* C, int64_t ldc,
+    int64_t I, int64_t J, int64_t R) {
+    memset(&g, 0, sizeof(g));
+    g.X = X; g.ldx = ldx; g.x_rs = xrs; g.Y = Y; g.ldy = ldy; g.y_rs = yrs; g.C = C; g.ldc = ldc;
+    g.I = (int)I; g.J = (int)J; g.R = (int)R;
+    g.xf = HIG_XF_NONE; g.epi = HIG_EPI_NONE; g.prec = HIG_PREC_F32;
+  }
+  G& epi(int e, const float* bias = nullptr) { g.epi = e; g.bias = bias; return *this; }
+  G& res(const float* r, int64_t ldr) { g.res = r; g.ldr = ldr; return *this; }
+  G& aux(float* a, int64_t lda) { g.aux = a; g.ldaux = lda; return *this; }
+  G& pos(const float* p, int64_t ldp, int T) { g.pos = p; g.ldpos = ldp; g.T = T; return *this; }
+  G& silu(int on_y) { g.xf = HIG_XF_SILU; g.xf_on_y = on_y; return *this; }
+  G& ln(int on_y, const float* stats, const float* gamma, const float* beta) {
+    g.xf = HIG_XF_LN; g.xf_on_y = on_y; g.stats = stats; g.gamma = gamma; g.beta = beta; return *this;
+  }
+  G& mod(const float* ss, int64_t ss_ld, int shift_off, int rows_per_sample) {
+    g.xf = HIG_XF_LN_MOD_SILU; g.ss = ss; g.ss_ld = ss_ld; g.ss_shift_off = shift_off;
+    g.rows_per_sample = rows_per_sample; return *this;
+  }
+};
+
+// Split the reduce range of a weight-gradient GEMM so ~768 workgroups are in flight.
+int wgrad_splits(int64_t I, int64_t J, int64_t R, int64_t slab_floats) {
+  const int bi = (I > 64 && J > 64) ? 128 : 64;
+  const int64_t tiles = ((I + bi - 1) / bi) * ((J + bi - 1) / bi);
+  int64_t s = (768 + tiles - 1) / tiles;
+  const int64_t maxs = R / 256 > 1 ? R / 256 : 1;
+  if (s > maxs) s = maxs;
+  while (s > 1 && s * I * J > slab_floats) --s;
+  if ((I * J) % 4 != 0) s = 1;
+  return (int)(s < 1 ? 1 : s);
+}
+
+inline const float* P(const void* const* t, int idx) { return static_cast<const float*>(t[idx]); }
+inline const float* PL(const void* const* t, int l, int idx) {
+  return static_cast<const float*>(t[HIG_NGLOBAL + l * HIG_NLAYER + idx]);
+}
+inline float* GP(void* const* t, int idx) { return static_cast<float*>(t[idx]); }
+inline float* GL(void* const* t, int l, int idx) {
+  return static_cast<float*>(t[HIG_NGLOBAL + l * HIG_NLAYER + idx]);
+}
+
+}  // namespace
+
+extern "C" int64_t hig_workspace_bytes(const hig_dims* dims, int training) {
+  Dims D;
+  if (check_dims(dims, D) != HIG_OK) return -1;
+  return fwd_layout(D, training).total * 4;
+}
+extern "C" int64_t hig_textctx_bytes(const hig_dims* dims, int training) {
+  Dims D;
+  if (check_dims(dims, D) != HIG_OK) return -1;
+  return text_layout(D, training).total * 4;
+}
+extern "C" int64_t hig_bwd_workspace_bytes(const hig_dims* dims) {
+  Dims D;
+  if (check_dims(dims, D) != HIG_OK) return -1;
+  return bwd_layout(D).total * 4;
+}
+
+extern "C" int hig_text_context(const hig_dims* dims, const void* const* params, const float* xf_out,
+                                void* textctx, int training, hig_stream_t stream) {
+  Dims D;
+  HIG_TRY(check_dims(dims, D));
+  HIG_REQUIRE(params && xf_out && textctx, "hig_text_context: null argument");
+  const TextLayout tl = text_layout(D, training);
+  float* base = static_cast<float*>(textctx);
+  hipStream_t st = hig_stream(stream);
+  float* stt = base + tl.stt;
+  HIG_TRY(hig_rowstats(xf_out, D.Lt, D.Mt, D.Lt, stt, stream));
+  for (int l = 0; l < D.L; ++l) {
+    float* kv = base + tl.kv + tl.kv_stride * l;
+    float* Ac = base + tl.layer0 + tl.lstride * l + tl.Ac;
+    float* kstc = base + tl.layer0 + tl.lstride * l + tl.kstc;
+    // [key; value](LN_text(xf_out))   (transformer.py:146,150)
+    HIG_TRY(hig_gemm_launch(G(xf_out, D.Lt, 0, PL(params, l, HIG_L_CA_KV_W), D.Lt, 0, kv, 2 * D.d, D.Mt, 2 * D.d, D.Lt)
+                                .ln(0, stt, PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B))
+                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_KV_B)).g, 1, nullptr, st));
+    // softmax over the N text tokens (no mask) and A = k^T v   (transformer.py:148,152)
+    HIG_TRY(hig_linattn_ctx(kv, kv + D.d, 2 * D.d, D.B, D.N, D.H, D.hd, nullptr, Ac, kstc, stream));
+  }
+  return HIG_OK;
+}
+
+extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params, const float* x,
+                                const int64_t* t, const int64_t* length, const float* xf_proj,
+                                const void* textctx, float* out, void* workspace, int training,
+                                hig_stream_t stream) {
+  Dims D;
+  HIG_TRY(check_dims(dims, D));
+  HIG_REQUIRE(params && x && t && xf_proj && textctx && out && workspace, "hig_denoiser_fwd: null argument");
+  const FwdLayout w = fwd_layout(D, training);
+  const TextLayout tl = text_layout(D, training);
+  float* ws = static_cast<float*>(workspace);
+  const float* tc = static_cast<const float*>(textctx);
+  hipStream_t st = hig_stream(stream);
+  const int d = D.d, E = D.E;
+  const int64_t M = D.M;
+  const int64_t ss_ld = (int64_t)3 * D.L * 2 * d;
+
+  // K0: emb = time_embed(timestep_embedding(t)) + xf_proj; all 3L scale/shift pairs in ONE GEMM
+  HIG_TRY(hig_timestep_embedding(t, D.B, d, ws + w.te, stream));
+  HIG_TRY(hig_gemm_launch(G(ws + w.te, d, 0, P(params, HIG_P_TE0_W), d, 0, ws + w.te_h, E, D.B, E, d)
+                              .epi(HIG_EPI_BIAS, P(params, HIG_P_TE0_B)).g, 1, nullptr, st));
+  HIG_TRY(hig_gemm_launch(G(ws + w.te_h, E, 0, P(params, HIG_P_TE2_W), E, 0, ws + w.emb, E, D.B, E, E)
+                              .silu(0).epi(HIG_EPI_BIAS_RES, P(params, HIG_P_TE2_B)).res(xf_proj, E).g, 1, nullptr, st));
+  HIG_TRY(hig_gemm_launch(G(ws + w.emb, E, 0, P(params, HIG_P_STY_EMB_W), E, 0, ws + w.ss, ss_ld, D.B, ss_ld, E)
+                              .silu(0).epi(HIG_EPI_BIAS, P(params, HIG_P_STY_EMB_B)).g, 1, nullptr, st));
+  // K1: h0 = joint_embed(x) + sequence_embedding[:T]
+  HIG_TRY(hig_gemm_launch(G(x, D.F, 0, P(params, HIG_P_JOINT_W), D.F, 0, ws + w.h0, d, M, d, D.F)
+                              .epi(HIG_EPI_BIAS_POS, P(params, HIG_P_JOINT_B)).pos(P(params, HIG_P_SEQ_EMB), d, D.T).g,
+                          1, nullptr, st));
+  const float* hin = ws + w.h0;
+  for (int l = 0; l < D.L; ++l) {
+    float* lb = ws + w.layer0 + w.lstride * l;
+    const float* ssl = ws + w.ss + (int64_t)(3 * l) * 2 * d;
+    // ---- self attention -------------------------------------------------------------
+    HIG_TRY(hig_rowstats(hin, d, M, d, lb + w.st1, stream));
+    HIG_TRY(hig_gemm_launch(G(hin, d, 0, PL(params, l, HIG_L_SA_QKV_W), d, 0, lb + w.qkv, 3 * d, M, 3 * d, d)
+                                .ln(0, lb + w.st1, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B))
+                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_SA_QKV_B)).g, 1, nullptr, st));
+    HIG_TRY(hig_linattn_ctx(lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, length,
+                            lb + w.A1, lb + w.kst1, stream));
+    HIG_TRY(hig_linattn_apply(lb + w.qkv, 3 * d, lb + w.A1, lb + w.y1, d, D.B, D.T, D.H, D.hd, stream));
+    HIG_TRY(hig_rowstats(lb + w.y1, d, M, d, lb + w.st2, stream));
+    HIG_TRY(hig_gemm_launch(G(lb + w.y1, d, 0, PL(params, l, HIG_L_SA_STY_OUT_W), d, 0, lb + w.h1, d, M, d, d)
+                                .ln(0, lb + w.st2, PL(params, l, HIG_L_SA_STY_NORM_W), PL(params, l, HIG_L_SA_STY_NORM_B))
+                                .mod(ssl, ss_ld, d, D.T)
+                                .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_SA_STY_OUT_B)).res(hin, d).g, 1, nullptr, st));
+    // ---- cross attention ------------------------------------------------------------
+    HIG_TRY(hig_rowstats(lb + w.h1, d, M, d, lb + w.st3, stream));
+    HIG_TRY(hig_gemm_launch(G(lb + w.h1, d, 0, PL(params, l, HIG_L_CA_Q_W), d, 0, lb + w.qc, d, M, d, d)
+                                .ln(0, lb + w.st3, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B))
+                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).g, 1, nullptr, st));
+    HIG_TRY(hig_linattn_apply(lb + w.qc, d, tc + tl.layer0 + tl.lstride * l + tl.Ac, lb + w.y2, d, D.B, D.T,
+                              D.H, D.hd, stream));
+    HIG_TRY(hig_rowstats(lb + w.y2, d, M, d, lb + w.st4, stream));
+    HIG_TRY(hig_gemm_launch(G(lb + w.y2, d, 0, PL(params, l, HIG_L_CA_STY_OUT_W), d, 0, lb + w.h2, d, M, d, d)
+                                .ln(0, lb + w.st4, PL(params, l, HIG_L_CA_STY_NORM_W), PL(params, l, HIG_L_CA_STY_NORM_B))
+                                .mod(ssl + 2 * d, ss_ld, d, D.T)
+                                .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_CA_STY_OUT_B)).res(lb + w.h1, d).g, 1, nullptr, st));
+    // ---- FFN ------------------------------------------------------------------------
+    HIG_TRY(hig_gemm_launch(G(lb + w.h2, d, 0, PL(params, l, HIG_L_FFN_W1), d, 0, lb + w.f1, D.ff, M, D.ff, d)
+                                .epi(HIG_EPI_BIAS_GELU, PL(params, l, HIG_L_FFN_B1))
+                                .aux(training ? lb + w.z1 : nullptr, D.ff).g, 1, nullptr, st));
+    HIG_TRY(hig_gemm_launch(G(lb + w.f1, D.ff, 0, PL(params, l, HIG_L_FFN_W2), D.ff, 0, lb + w.y3, d, M, d, D.ff)
+                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B2)).g, 1, nullptr, st));
+    HIG_TRY(hig_rowstats(lb + w.y3, d, M, d, lb + w.st5, stream));
+    HIG_TRY(hig_gemm_launch(G(lb + w.y3, d, 0, PL(params, l, HIG_L_FFN_STY_OUT_W), d, 0, lb + w.h3, d, M, d, d)
+                                .ln(0, lb + w.st5, PL(params, l, HIG_L_FFN_STY_NORM_W), PL(params, l, HIG_L_FFN_STY_NORM_B))
+                                .mod(ssl + 4 * d, ss_ld, d, D.T)
+                                .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_FFN_STY_OUT_B)).res(lb + w.h2, d).g, 1, nullptr, st));
+    hin = lb + w.h3;
+  }
+  // K6: out = Linear(d, F)(h_L)
+  HIG_TRY(hig_gemm_launch(G(hin, d, 0, P(params, HIG_P_OUT_W), d, 0, out, D.F, M, D.F, d)
+                              .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT_B)).g, 1, nullptr, st));
+  return HIG_OK;
+}
+
+extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params, const float* x,
+                                const int64_t* t, const int64_t* length, const float* xf_out,
+                                const void* textctx, const void* workspace, const float* dout,
+                                void* const* grads, float* dx, float* dxf_proj, float* dxf_out,
+                                void* bwd_workspace, hig_stream_t stream) {
+  (void)t;
+  Dims D;
+  HIG_TRY(check_dims(dims, D));
+  HIG_REQUIRE(params && x && xf_out && textctx && workspace && dout && grads && dxf_proj && dxf_out && bwd_workspace,
+              "hig_denoiser_bwd: null argument");
+  const FwdLayout w = fwd_layout(D, 1);
+  const TextLayout tl = text_layout(D, 1);
+  const BwdLayout bw = bwd_layout(D);
+  const float* ws = static_cast<const float*>(workspace);
+  const float* tc = static_cast<const float*>(textctx);
+  float* b = static_cast<float*>(bwd_workspace);
+  hipStream_t st = hig_stream(stream);
+  const int d = D.d, E = D.E, ff = D.ff, F = D.F, Lt = D.Lt;
+  const int64_t M = D.M, Mt = D.Mt;
+  const int64_t ss_ld = (int64_t)3 * D.L * 2 * d;
+  float* slabs = b + bw.slabs;
+  float* colp = b + bw.colpart;
+  float* lnp = b + bw.lnpart;
+  float* dss = b + bw.dss;
+
+  auto wgrad = [&](G gd) -> int {  // X, Y both reduce-slow; split over the reduce rows
+    const int s = wgrad_splits(gd.g.I, gd.g.J, gd.g.R, bw.slab_floats);
+    return hig_gemm_launch(gd.g, s, slabs, st);
+  };
+  auto colsum = [&](const float* src, int64_t ld, int64_t rows, int n, float* dst) -> int {
+    return hig_colsum(src, ld, rows, n, dst, colp, stream);
+  };
+  // Backward of one stylization block: h_out = h_in + Lin_out(silu(LN(y)*(1+scale)+shift)).
+  // `dh` is d(h_out); produces dy into `dy_out`, parameter grads, and dss columns of block s.
+  auto sty_bwd = [&](int l, int s, const float* dh, const float* y, const float* stats, int norm_w, int norm_b,
+                     int out_w, int out_b, float* dy_out) -> int {
+    const float* ssl = ws + w.ss + (int64_t)s * 2 * d;
+    HIG_TRY(colsum(dh, d, M, d, GL(grads, l, out_b)));
+    HIG_TRY(wgrad(G(dh, d, 1, y, d, 1, GL(grads, l, out_w), d, d, d, M)
+                      .ln(1, stats, PL(params, l, norm_w), PL(params, l, norm_b)).mod(ssl, ss_ld, d, D.T)));
+    HIG_TRY(hig_gemm_launch(G(dh, d, 0, PL(params, l, out_w), d, 1, b + bw.t1, d, M, d, d).g, 1, nullptr, st));
+    return hig_ln_bwd(b + bw.t1, d, y, d, stats, PL(params, l, norm_w), PL(params, l, norm_b), ssl, ss_ld, d, 1,
+                      nullptr, 0, dy_out, d, M, d, D.T, GL(grads, l, norm_w), GL(grads, l, norm_b),
+                      dss + (int64_t)s * 2 * d, ss_ld, lnp, stream);
+  };
+
+  // ---- output projection ---------------------------------------------------------------
+  const float* hL = ws + w.layer0 + w.lstride * (D.L - 1) + w.h3;
+  HIG_TRY(colsum(dout, F, M, F, GP(grads, HIG_P_OUT_B)));
+  HIG_TRY(wgrad(G(dout, F, 1, hL, d, 1, GP(grads, HIG_P_OUT_W), d, F, d, M)));
+  float* dh = b + bw.dhA;
+  float* dh_alt = b + bw.dhB;
+  HIG_TRY(hig_gemm_launch(G(dout, F, 0, P(params, HIG_P_OUT_W), d, 1, dh, d, M, d, F).g, 1, nullptr, st));
+
+  for (int l = D.L - 1; l >= 0; --l) {
+    const float* lb = ws + w.layer0 + w.lstride * l;
+    const float* hin = l == 0 ? ws + w.h0 : ws + w.layer0 + w.lstride * (l - 1) + w.h3;
+    // ---- FFN --------------------------------------------------------------------------
+    HIG_TRY(sty_bwd(l, 3 * l + 2, dh, lb + w.y3, lb + w.st5, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B,
+                    HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B, b + bw.t2));
+    const float* dy3 = b + bw.t2;
+    HIG_TRY(colsum(dy3, d, M, d, GL(grads, l, HIG_L_FFN_B2)));
+    HIG_TRY(wgrad(G(dy3, d, 1, lb + w.f1, ff, 1, GL(grads, l, HIG_L_FFN_W2), ff, d, ff, M)));
+    HIG_TRY(hig_gemm_launch(G(dy3, d, 0, PL(params, l, HIG_L_FFN_W2), ff, 1, b + bw.tff, ff, M, ff, d)
+                                .epi(HIG_EPI_DGELU).aux(const_cast<float*>(lb + w.z1), ff).g, 1, nullptr, st));
+    const float* dz1 = b + bw.tff;
+    HIG_TRY(colsum(dz1, ff, M, ff, GL(grads, l, HIG_L_FFN_B1)));
+    HIG_TRY(wgrad(G(dz1, ff, 1, lb + w.h2, d, 1, GL(grads, l, HIG_L_FFN_W1), d, ff, d, M)));
+    HIG_TRY(hig_gemm_launch(G(dz1, ff, 0, PL(params, l, HIG_L_FFN_W1), d, 1, dh_alt, d, M, d, ff)
+                                .epi(HIG_EPI_RES).res(dh, d).g, 1, nullptr, st));
+    { float* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h2)
+    // ---- cross attention ---------------------------------------------------------------
+    HIG_TRY(sty_bwd(l, 3 * l + 1, dh, lb + w.y2, lb + w.st4, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B,
+                    HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B, b + bw.t2));
+    const float* Ac = tc + tl.layer0 + tl.lstride * l + tl.Ac;
+    const float* kstc = tc + tl.layer0 + tl.lstride * l + tl.kstc;
+    const float* kv = tc + tl.kv + tl.kv_stride * l;
+    HIG_TRY(hig_linattn_apply_bwd(b + bw.t2, d, lb + w.qc, d, Ac, b + bw.t1, d, b + bw.dA, D.B, D.T, D.H, D.hd, stream));
+    const float* dqc = b + bw.t1;
+    HIG_TRY(colsum(dqc, d, M, d, GL(grads, l, HIG_L_CA_Q_B)));
+    HIG_TRY(wgrad(G(dqc, d, 1, lb + w.h1, d, 1, GL(grads, l, HIG_L_CA_Q_W), d, d, d, M)
+                      .ln(1, lb + w.st3, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B))));
+    HIG_TRY(hig_gemm_launch(G(dqc, d, 0, PL(params, l, HIG_L_CA_Q_W), d, 1, b + bw.t2, d, M, d, d).g, 1, nullptr, st));
+    HIG_TRY(hig_ln_bwd(b + bw.t2, d, lb + w.h1, d, lb + w.st3, PL(params, l, HIG_L_CA_NORM_W),
+                       PL(params, l, HIG_L_CA_NORM_B), nullptr, 0, 0, 0, dh, d, dh_alt, d, M, d, D.T,
+                       GL(grads, l, HIG_L_CA_NORM_W), GL(grads, l, HIG_L_CA_NORM_B), nullptr, 0, lnp, stream));
+    { float* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h1)
+    // text side of this layer: d(A_c) -> d(key,value) -> text_norm -> d(xf_out)
+    HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, kv, kv + d, 2 * d, kstc, nullptr, b + bw.dkv, b + bw.dkv + d, 2 * d, D.B,
+                                D.N, D.H, D.hd, stream));
+    HIG_TRY(colsum(b + bw.dkv, 2 * d, Mt, 2 * d, GL(grads, l, HIG_L_CA_KV_B)));
+    HIG_TRY(wgrad(G(b + bw.dkv, 2 * d, 1, xf_out, Lt, 1, GL(grads, l, HIG_L_CA_KV_W), Lt, 2 * d, Lt, Mt)
+                      .ln(1, tc + tl.stt, PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B))));
+    HIG_TRY(hig_gemm_launch(G(b + bw.dkv, 2 * d, 0, PL(params, l, HIG_L_CA_KV_W), Lt, 1, b + bw.dxfn, Lt, Mt, Lt, 2 * d).g,
+                            1, nullptr, st));
+    HIG_TRY(hig_ln_bwd(b + bw.dxfn, Lt, xf_out, Lt, tc + tl.stt, PL(params, l, HIG_L_CA_TNORM_W),
+                       PL(params, l, HIG_L_CA_TNORM_B), nullptr, 0, 0, 0, l == D.L - 1 ? nullptr : dxf_out, Lt,
+                       dxf_out, Lt, Mt, Lt, D.N, GL(grads, l, HIG_L_CA_TNORM_W), GL(grads, l, HIG_L_CA_TNORM_B),
+                       nullptr, 0, lnp, stream));
+    // ---- self attention ----------------------------------------------------------------
+    HIG_TRY(sty_bwd(l, 3 * l, dh, lb + w.y1, lb + w.st2, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B,
+                    HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B, b + bw.t2));
+    float* dqkv = b + bw.dqkv;
+    HIG_TRY(hig_linattn_apply_bwd(b + bw.t2, d, lb + w.qkv, 3 * d, lb + w.A1, dqkv, 3 * d, b + bw.dA, D.B, D.T, D.H,
+                                  D.hd, stream));
+    HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, lb + w.kst1, length, dqkv + d,
+                                dqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, stream));
+    HIG_TRY(colsum(dqkv, 3 * d, M, 3 * d, GL(grads, l, HIG_L_SA_QKV_B)));
+    HIG_TRY(wgrad(G(dqkv, 3 * d, 1, hin, d, 1, GL(grads, l, HIG_L_SA_QKV_W), d, 3 * d, d, M)
+                      .ln(1, lb + w.st1, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B))));
+    HIG_TRY(hig_gemm_launch(G(dqkv, 3 * d, 0, PL(params, l, HIG_L_SA_QKV_W), d, 1, b + bw.t2, d, M, d, 3 * d).g, 1,
+                            nullptr, st));
+    HIG_TRY(hig_ln_bwd(b + bw.t2, d, hin, d, lb + w.st1, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B),
+                       nullptr, 0, 0, 0, dh, d, dh_alt, d, M, d, D.T, GL(grads, l, HIG_L_SA_NORM_W),
+                       GL(grads, l, HIG_L_SA_NORM_B), nullptr, 0, lnp, stream));
+    { float* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h_in of this layer)
+  }
+
+  // ---- joint_embed + sequence_embedding ------------------------------------------------
+  HIG_TRY(colsum(dh, d, M, d, GP(grads, HIG_P_JOINT_B)));
+  HIG_TRY(wgrad(G(dh, d, 1, x, F, 1, GP(grads, HIG_P_JOINT_W), F, d, F, M)));
+  // d(sequence_embedding)[t] = sum_b dh[b, t, :]  == column sum of dh viewed as (B, T*d)
+  HIG_TRY(colsum(dh, (int64_t)D.T * d, D.B, D.T * d, GP(grads, HIG_P_SEQ_EMB)));
+  if (D.nf > D.T)
+    if (hipMemsetAsync(GP(grads, HIG_P_SEQ_EMB) + (int64_t)D.T * d, 0, (size_t)(D.nf - D.T) * d * 4, st) != hipSuccess)
+      return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+  if (dx)
+    HIG_TRY(hig_gemm_launch(G(dh, d, 0, P(params, HIG_P_JOINT_W), F, 1, dx, F, M, F, d).g, 1, nullptr, st));
+
+  // ---- time / text embedding path ---------------------------------------------------------
+  const float* emb = ws + w.emb;
+  HIG_TRY(colsum(dss, ss_ld, D.B, (int)ss_ld, GP(grads, HIG_P_STY_EMB_B)));
+  HIG_TRY(hig_gemm_launch(G(dss, ss_ld, 1, emb, E, 1, GP(grads, HIG_P_STY_EMB_W), E, ss_ld, E, D.B).silu(1).g, 1, nullptr, st));
+  {
+    G gd(dss, ss_ld, 0, P(params, HIG_P_STY_EMB_W), E, 1, b + bw.dtmp, E, D.B, E, ss_ld);
+    int s = (int)(ss_ld / 1024);
+    if (s > 16) s = 16;
+    HIG_TRY(hig_gemm_launch(gd.g, s < 1 ? 1 : s, slabs, st));
+  }
+  const int64_t nBE = (int64_t)D.B * E;
+  const int eb = (int)((nBE + 255) / 256);
+  hipLaunchKernelGGL(mul_dsilu_kernel, dim3(eb), dim3(256), 0, st, b + bw.dtmp, emb, nBE, b + bw.demb);
+  HIG_CHECK_LAUNCH();
+  if (hipMemcpyAsync(dxf_proj, b + bw.demb, (size_t)nBE * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
+  HIG_TRY(colsum(b + bw.demb, E, D.B, E, GP(grads, HIG_P_TE2_B)));
+  HIG_TRY(hig_gemm_launch(G(b + bw.demb, E, 1, ws + w.te_h, E, 1, GP(grads, HIG_P_TE2_W), E, E, E, D.B).silu(1).g, 1, nullptr, st));
+  HIG_TRY(hig_gemm_launch(G(b + bw.demb, E, 0, P(params, HIG_P_TE2_W), E, 1, b + bw.dtmp, E, D.B, E, E).g, 1, nullptr, st));
+  hipLaunchKernelGGL(mul_dsilu_kernel, dim3(eb), dim3(256), 0, st, b + bw.dtmp, ws + w.te_h, nBE, b + bw.dte_h);
+  HIG_CHECK_LAUNCH();
+  HIG_TRY(colsum(b + bw.dte_h, E, D.B, E, GP(grads, HIG_P_TE0_B)));
+  HIG_TRY(hig_gemm_launch(G(b + bw.dte_h, E, 1, ws + w.te, d, 1, GP(grads, HIG_P_TE0_W), d, E, d, D.B).g, 1, nullptr, st));
+  return HIG_OK;
+}

@@ -1,0 +1,468 @@
+// Fused MFMA GEMM for gfx950 (MI355X):  C[i][j] = epi( sum_r xf(X)[i][r] * Y[j][r] ).
+//
+// One kernel template serves every dense contraction of the denoiser (reference:
+// nn.Linear calls in codes/models/transformer.py:81-85,108-114,144-150,168,418,425 and their
+// autograd backward):
+//   forward   X = activations (reduce-contiguous), Y = nn.Linear weight (out,in)      [RC,RC]
+//   dgrad     X = dC, Y = weight read reduce-slow                                      [RC,RS]
+//   wgrad     X = dC^T, Y = activations^T, both reduce-slow, split over the M rows     [RS,RS]
+// with the LayerNorm / stylization-modulation / SiLU of the reference fused into the operand
+// staging (global -> registers -> transform -> LDS) and bias / GELU / residual / positional
+// embedding fused into the epilogue.
+//
+// CDNA4 mapping: 256 threads = 4 waves (2x2), each wave owns (BI/2 x BJ/2) of the block tile as
+// 32x32 MFMA accumulators.  The MFMA "row" operand is Y (output column j), so each lane ends
+// up holding 4 CONSECUTIVE output columns per accumulator quad -> 16-byte epilogue loads and
+// stores.  Exact-fp32 path: v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD, the fp32 matrix peak of
+// 157 TFLOP/s).  Reduce-contiguous tiles sit in LDS as [row][32+4] (pad = one b128 access, so
+// the 16-lane ds_read_b128 groups are conflict-free); reduce-slow tiles as [32][rows] read with
+// conflict-free ds_read_b32.  Inside a 32-deep K tile the k order is permuted identically for
+// both operands: MFMA step j of group ks uses k = 8*ks + 4*(lane>>5) + j.
+#include "hig_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+constexpr int RC_LD = BK + 4;
+
+struct KArgs {
+  hig_gemm_desc g;
+  int nbj;         // tiles along J
+  int ntiles;      // tiles per split
+  int r_chunk;     // reduce elements per split (multiple of BK)
+  int64_t slab;    // floats between split outputs
+  int vecx, vecy, vecc;  // 16-byte access allowed for X / Y / (C,res,aux)
+};
+
+template <int XF>
+__device__ __forceinline__ float4 xf_apply(float4 v, float mean, float rstd, const float* gamma,
+                                           const float* beta, const float* ssrow, int shift_off,
+                                           int f) {
+  if (XF == HIG_XF_NONE) return v;
+  if (XF == HIG_XF_SILU) {
+    v.x = hig_silu(v.x); v.y = hig_silu(v.y); v.z = hig_silu(v.z); v.w = hig_silu(v.w);
+    return v;
+  }
+  const float4 g4 = *reinterpret_cast<const float4*>(gamma + f);
+  const float4 b4 = *reinterpret_cast<const float4*>(beta + f);
+  v.x = (v.x - mean) * rstd * g4.x + b4.x;
+  v.y = (v.y - mean) * rstd * g4.y + b4.y;
+  v.z = (v.z - mean) * rstd * g4.z + b4.z;
+  v.w = (v.w - mean) * rstd * g4.w + b4.w;
+  if (XF == HIG_XF_LN_MOD_SILU) {
+    const float4 sc = *reinterpret_cast<const float4*>(ssrow + f);
+    const float4 sh = *reinterpret_cast<const float4*>(ssrow + shift_off + f);
+    v.x = hig_silu(v.x * (1.0f + sc.x) + sh.x);
+    v.y = hig_silu(v.y * (1.0f + sc.y) + sh.y);
+    v.z = hig_silu(v.z * (1.0f + sc.z) + sh.z);
+    v.w = hig_silu(v.w * (1.0f + sc.w) + sh.w);
+  }
+  return v;
+}
+
+// Loads one float4 of a reduce-contiguous operand: row `row`, reduce index k..k+3.
+__device__ __forceinline__ float4 ld_rc(const float* base, int64_t ld, int row, int nrows, int k,
+                                        int kend, int vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row < nrows) {
+    const float* p = base + (int64_t)row * ld + k;
+    if (vec && k + 3 < kend) {
+      v = *reinterpret_cast<const float4*>(p);
+    } else {
+      if (k < kend) v.x = p[0];
+      if (k + 1 < kend) v.y = p[1];
+      if (k + 2 < kend) v.z = p[2];
+      if (k + 3 < kend) v.w = p[3];
+    }
+  }
+  return v;
+}
+// Loads one float4 of a reduce-slow operand: reduce index k, rows i..i+3.
+__device__ __forceinline__ float4 ld_rs(const float* base, int64_t ld, int i, int nrows, int k,
+                                        int kend, int vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k < kend) {
+    const float* p = base + (int64_t)k * ld + i;
+    if (vec && i + 3 < nrows) {
+      v = *reinterpret_cast<const float4*>(p);
+    } else {
+      if (i < nrows) v.x = p[0];
+      if (i + 1 < nrows) v.y = p[1];
+      if (i + 2 < nrows) v.z = p[2];
+      if (i + 3 < nrows) v.w = p[3];
+    }
+  }
+  return v;
+}
+
+template <int BI, int BJ, bool X_RS, bool Y_RS, int XF, bool XF_ON_Y, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
+  constexpr int TI = BI / 64, TJ = BJ / 64;
+  constexpr int XP = BI / 32, YP = BJ / 32;
+  constexpr int X_TILE = X_RS ? BK * BI : BI * RC_LD;
+  constexpr int Y_TILE = Y_RS ? BK * BJ : BJ * RC_LD;
+  constexpr int STAGE = X_TILE + Y_TILE;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const hig_gemm_desc& g = a.g;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
+  // contiguous run of tiles so neighbours re-use the same X row panel.
+  int tile;
+  {
+    const int bid = blockIdx.x, q = a.ntiles >> 3, r = a.ntiles & 7, xcd = bid & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int i0 = (tile / a.nbj) * BI, j0 = (tile % a.nbj) * BJ;
+  const int split = blockIdx.y;
+  const int rbeg = split * a.r_chunk;
+  const int rend = min(g.R, rbeg + a.r_chunk);
+  float* __restrict__ C = g.C + (int64_t)split * a.slab;
+
+  // ---- per-thread staging coordinates ------------------------------------------------
+  // RC tile [ROWS][32]: c4 = tid&7, row = (tid>>3) + 32p.   RS tile [32][ROWS]: ROWS/4 float4
+  // per k-row.
+  constexpr int XQ = BI / 4, YQ = BJ / 4;
+  const int x_c4 = X_RS ? (tid % XQ) : (tid & 7);
+  const int x_r = X_RS ? (tid / XQ) : (tid >> 3);
+  constexpr int X_RSTEP = X_RS ? (NTHREADS / XQ) : 32;
+  const int y_c4 = Y_RS ? (tid % YQ) : (tid & 7);
+  const int y_r = Y_RS ? (tid / YQ) : (tid >> 3);
+  constexpr int Y_RSTEP = Y_RS ? (NTHREADS / YQ) : 32;
+
+  // Hoisted per-row transform state for a reduce-contiguous activation operand on X.
+  float xmean[XP], xrstd[XP];
+  const float* xss[XP];
+  if (XF != HIG_XF_NONE && XF != HIG_XF_SILU && !XF_ON_Y && !X_RS) {
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const int m = min(i0 + x_r + 32 * p, g.I - 1);
+      xmean[p] = g.stats[2 * (int64_t)m];
+      xrstd[p] = g.stats[2 * (int64_t)m + 1];
+      xss[p] = (XF == HIG_XF_LN_MOD_SILU) ? g.ss + (int64_t)(m / g.rows_per_sample) * g.ss_ld : nullptr;
+    }
+  }
+
+  float4 xr[XP], yr[YP];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      if (X_RS)
+        xr[p] = ld_rs(g.X, g.ldx, i0 + 4 * x_c4, g.I, k0 + x_r + X_RSTEP * p, rend, a.vecx);
+      else
+        xr[p] = ld_rc(g.X, g.ldx, i0 + x_r + 32 * p, g.I, k0 + 4 * x_c4, rend, a.vecx);
+    }
+#pragma unroll
+    for (int p = 0; p < YP; ++p) {
+      if (Y_RS)
+        yr[p] = ld_rs(g.Y, g.ldy, j0 + 4 * y_c4, g.J, k0 + y_r + Y_RSTEP * p, rend, a.vecy);
+      else
+        yr[p] = ld_rc(g.Y, g.ldy, j0 + y_r + 32 * p, g.J, k0 + 4 * y_c4, rend, a.vecy);
+    }
+  };
+  auto transform = [&](int k0) {
+    if (XF == HIG_XF_NONE) return;
+    if (!XF_ON_Y) {
+      // activation = X, reduce-contiguous: row m fixed per p, features k0+4c4..
+      const int f = k0 + 4 * x_c4;
+      if (f < rend) {  // R % 4 == 0 is required for transformed operands
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+          if (XF == HIG_XF_SILU)
+            xr[p] = xf_apply<XF>(xr[p], 0.f, 0.f, nullptr, nullptr, nullptr, 0, f);
+          else if (i0 + x_r + 32 * p < g.I)
+            xr[p] = xf_apply<XF>(xr[p], xmean[p], xrstd[p], g.gamma, g.beta, xss[p],
+                                 g.ss_shift_off, f);
+        }
+      }
+    } else {
+      // activation = Y, reduce-slow: row m = reduce index, features j0+4c4..
+      const int f = j0 + 4 * y_c4;
+      if (f < g.J) {  // J % 4 == 0 is required for transformed operands
+#pragma unroll
+        for (int p = 0; p < YP; ++p) {
+          const int m = k0 + y_r + Y_RSTEP * p;
+          if (m < rend) {
+            if (XF == HIG_XF_SILU) {
+              yr[p] = xf_apply<XF>(yr[p], 0.f, 0.f, nullptr, nullptr, nullptr, 0, f);
+            } else {
+              const float mean = g.stats[2 * (int64_t)m], rstd = g.stats[2 * (int64_t)m + 1];
+              const float* ssrow =
+                  (XF == HIG_XF_LN_MOD_SILU) ? g.ss + (int64_t)(m / g.rows_per_sample) * g.ss_ld : nullptr;
+              yr[p] = xf_apply<XF>(yr[p], mean, rstd, g.gamma, g.beta, ssrow, g.ss_shift_off, f);
+            }
+          }
+        }
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* sx = smem + buf * STAGE;
+    float* sy = sx + X_TILE;
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      if (X_RS)
+        *reinterpret_cast<float4*>(sx + (x_r + X_RSTEP * p) * BI + 4 * x_c4) = xr[p];
+      else
+        *reinterpret_cast<float4*>(sx + (x_r + 32 * p) * RC_LD + 4 * x_c4) = xr[p];
+    }
+#pragma unroll
+    for (int p = 0; p < YP; ++p) {
+      if (Y_RS)
+        *reinterpret_cast<float4*>(sy + (y_r + Y_RSTEP * p) * BJ + 4 * y_c4) = yr[p];
+      else
+        *reinterpret_cast<float4*>(sy + (y_r + 32 * p) * RC_LD + 4 * y_c4) = yr[p];
+    }
+  };
+
+  f32x16 acc[TJ][TI];
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tj][ti][e] = 0.f;
+
+  const int nk = (rend - rbeg + BK - 1) / BK;
+  if (nk > 0) {
+    load_tiles(rbeg);
+    transform(rbeg);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  const int xrow = wi * (32 * TI) + lr;  // + 32*ti
+  const int yrow = wj * (32 * TJ) + lr;  // + 32*tj
+  for (int kt = 0; kt < nk; ++kt) {
+    const int k_next = rbeg + (kt + 1) * BK;
+    if (kt + 1 < nk) load_tiles(k_next);
+    const float* sx = smem + (kt & 1) * STAGE;
+    const float* sy = sx + X_TILE;
+#pragma unroll
+    for (int ks = 0; ks < BK / 8; ++ks) {
+      float xf[TI][4], yf[TJ][4];
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        if (X_RS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xf[ti][j] = sx[(ks * 8 + 4 * lh + j) * BI + xrow + 32 * ti];
+        } else {
+          const float4 t4 = *reinterpret_cast<const float4*>(sx + (xrow + 32 * ti) * RC_LD + ks * 8 + 4 * lh);
+          xf[ti][0] = t4.x; xf[ti][1] = t4.y; xf[ti][2] = t4.z; xf[ti][3] = t4.w;
+        }
+      }
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        if (Y_RS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) yf[tj][j] = sy[(ks * 8 + 4 * lh + j) * BJ + yrow + 32 * tj];
+        } else {
+          const float4 t4 = *reinterpret_cast<const float4*>(sy + (yrow + 32 * tj) * RC_LD + ks * 8 + 4 * lh);
+          yf[tj][0] = t4.x; yf[tj][1] = t4.y; yf[tj][2] = t4.z; yf[tj][3] = t4.w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+            acc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[tj][j], xf[ti][j], acc[tj][ti], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      transform(k_next);
+      store_tiles((kt + 1) & 1);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds, per accumulator quad q, columns j..j+3 of row i ----------
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) {
+    const int i = i0 + wi * (32 * TI) + 32 * ti + lr;
+    if (i >= g.I) continue;
+    const float* posrow = (EPI == HIG_EPI_BIAS_POS) ? g.pos + (int64_t)(i % g.T) * g.ldpos : nullptr;
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = j0 + wj * (32 * TJ) + 32 * tj + 8 * q + 4 * lh;
+        if (j >= g.J) continue;
+        float v[4] = {acc[tj][ti][4 * q], acc[tj][ti][4 * q + 1], acc[tj][ti][4 * q + 2],
+                      acc[tj][ti][4 * q + 3]};
+        const bool full = a.vecc && (j + 3 < g.J);
+        const int nv = min(4, g.J - j);
+        if (EPI == HIG_EPI_BIAS || EPI == HIG_EPI_BIAS_GELU || EPI == HIG_EPI_BIAS_RES ||
+            EPI == HIG_EPI_BIAS_POS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < nv) v[e] += g.bias[j + e];
+        }
+        if (EPI == HIG_EPI_BIAS_POS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < nv) v[e] += posrow[j + e];
+        }
+        if (EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_RES) {
+          const float* rp = g.res + (int64_t)i * g.ldr + j;
+          if (full) {
+            const float4 r4 = *reinterpret_cast<const float4*>(rp);
+            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (e < nv) v[e] += rp[e];
+          }
+        }
+        if (EPI == HIG_EPI_BIAS_GELU) {
+          if (g.aux) {
+            float* ap = g.aux + (int64_t)i * g.ldaux + j;
+            if (full) {
+              *reinterpret_cast<float4*>(ap) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (e < nv) ap[e] = v[e];
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = hig_gelu(v[e]);
+        }
+        if (EPI == HIG_EPI_DGELU) {
+          const float* ap = g.aux + (int64_t)i * g.ldaux + j;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < nv) v[e] *= hig_dgelu(ap[e]);
+        }
+        float* cp = C + (int64_t)i * g.ldc + j;
+        if (full) {
+          *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < nv) cp[e] = v[e];
+        }
+      }
+    }
+  }
+}
+
+// out[e] = sum_s slabs[s][e]
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit, int64_t slab,
+                                    int64_t n4, float* __restrict__ out) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n4;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    float4 s = reinterpret_cast<const float4*>(slabs)[e];
+    for (int k = 1; k < nsplit; ++k) {
+      const float4 t = reinterpret_cast<const float4*>(slabs + k * slab)[e];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    reinterpret_cast<float4*>(out)[e] = s;
+  }
+}
+
+template <int BI, int BJ, bool X_RS, bool Y_RS, int XF, bool XF_ON_Y, int EPI>
+int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipStream_t st) {
+  KArgs a;
+  a.g = g;
+  const int nbi = (g.I + BI - 1) / BI;
+  a.nbj = (g.J + BJ - 1) / BJ;
+  a.ntiles = nbi * a.nbj;
+  if (splits <= 1) {
+    splits = 1;
+    a.r_chunk = ((g.R + BK - 1) / BK) * BK;
+    a.slab = 0;
+  } else {
+    const int per = (g.R + splits - 1) / splits;
+    a.r_chunk = ((per + BK - 1) / BK) * BK;
+    splits = (g.R + a.r_chunk - 1) / a.r_chunk;
+    a.slab = slab;
+    a.g.C = slabs;
+    a.g.ldc = g.J;  // slabs are dense [I][J]
+  }
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  a.vecx = (g.ldx % 4 == 0) && al16(g.X);
+  a.vecy = (g.ldy % 4 == 0) && al16(g.Y);
+  a.vecc = (a.g.ldc % 4 == 0) && al16(a.g.C) && (a.slab % 4 == 0) &&
+           (!g.res || ((g.ldr % 4 == 0) && al16(g.res))) &&
+           (!g.aux || ((g.ldaux % 4 == 0) && al16(g.aux)));
+  if (a.ntiles > 0 && g.R >= 0)
+    hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI>), dim3(a.ntiles, splits),
+                       dim3(NTHREADS), 0, st, a);
+  HIG_CHECK_LAUNCH();
+  if (splits > 1) {
+    const int64_t n4 = (int64_t)g.I * g.J / 4;
+    const int64_t want = (n4 + 255) / 256;
+    const int blocks = (int)(want > 2048 ? 2048 : want);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, splits, slab, n4, g.C);
+    HIG_CHECK_LAUNCH();
+  }
+  return HIG_OK;
+}
+
+// Tile choice: 128x128 when both extents can fill it, otherwise 64x64 (skinny GEMMs such as the
+// B-row time-embedding MLP are weight-bandwidth bound; smaller tiles keep more CUs streaming).
+template <bool X_RS, bool Y_RS, int XF, bool XF_ON_Y, int EPI>
+int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipStream_t st) {
+  if (g.I > 64 && g.J > 64)
+    return launch<128, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
+  return launch<64, 64, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
+}
+
+}  // namespace
+
+// Internal entry (used by denoiser.hip): splits > 1 routes partial sums over the reduce range
+// through `slabs` (splits x I x J floats) and a deterministic slab reduction.
+int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_t st) {
+  HIG_REQUIRE(g.X && g.Y && g.C, "hig_gemm: null operand");
+  HIG_REQUIRE(g.I >= 0 && g.J >= 0 && g.R >= 0, "hig_gemm: negative extent");
+  if (g.I == 0 || g.J == 0) return HIG_OK;
+  if (g.xf != HIG_XF_NONE) {
+    // transformed operand: features must come in whole float4 quads
+    const int nfeat = g.xf_on_y ? g.J : g.R;
+    HIG_REQUIRE(nfeat % 4 == 0, "hig_gemm: fused transform needs feature count %% 4 == 0 (got %d)", nfeat);
+    if (g.xf != HIG_XF_SILU) HIG_REQUIRE(g.stats && g.gamma && g.beta, "hig_gemm: LN transform needs stats/gamma/beta");
+    if (g.xf == HIG_XF_LN_MOD_SILU) HIG_REQUIRE(g.ss && g.rows_per_sample > 0, "hig_gemm: modulation needs ss");
+  }
+  const int64_t slab = (int64_t)g.I * g.J;
+  if (splits > 1) HIG_REQUIRE(slabs && g.epi == HIG_EPI_NONE && slab % 4 == 0 && g.ldc == g.J,
+                              "hig_gemm: split-R needs slabs, EPI_NONE, dense C");
+#define CASE(xrs, yrs, xfv, ony, epiv)                                                   \
+  if (g.x_rs == xrs && g.y_rs == yrs && g.xf == xfv && (g.xf == HIG_XF_NONE || g.xf_on_y == ony) && \
+      g.epi == epiv)                                                                     \
+    return launch_sized<xrs, yrs, xfv, ony, epiv>(g, splits, slabs, slab, st);
+  // forward (activations x weight^T)
+  CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_NONE)
+  CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_BIAS)
+  CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_BIAS_GELU)
+  CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_BIAS_POS)
+  CASE(0, 0, HIG_XF_LN, 0, HIG_EPI_BIAS)
+  CASE(0, 0, HIG_XF_LN_MOD_SILU, 0, HIG_EPI_BIAS_RES)
+  CASE(0, 0, HIG_XF_SILU, 0, HIG_EPI_BIAS)
+  CASE(0, 0, HIG_XF_SILU, 0, HIG_EPI_BIAS_RES)
+  // dgrad (dC x weight)
+  CASE(0, 1, HIG_XF_NONE, 0, HIG_EPI_NONE)
+  CASE(0, 1, HIG_XF_NONE, 0, HIG_EPI_RES)
+  CASE(0, 1, HIG_XF_NONE, 0, HIG_EPI_DGELU)
+  // wgrad (dC^T x activations)
+  CASE(1, 1, HIG_XF_NONE, 0, HIG_EPI_NONE)
+  CASE(1, 1, HIG_XF_LN, 1, HIG_EPI_NONE)
+  CASE(1, 1, HIG_XF_LN_MOD_SILU, 1, HIG_EPI_NONE)
+  CASE(1, 1, HIG_XF_SILU, 1, HIG_EPI_NONE)
+#undef CASE
+  return hig_set_error(HIG_EUNSUPPORTED, "hig_gemm: combination x_rs=%d y_rs=%d xf=%d on_y=%d epi=%d not built",
+                       g.x_rs, g.y_rs, g.xf, g.xf_on_y, g.epi);
+}
+
+extern "C" int hig_gemm(const hig_gemm_desc* g, hig_stream_t stream) {
+  HIG_REQUIRE(g, "hig_gemm: null descriptor");
+  HIG_REQUIRE(g->prec == HIG_PREC_F32, "hig_gemm: only HIG_PREC_F32 is built in this round");
+  return hig_gemm_launch(*g, 1, nullptr, hig_stream(stream));
+}

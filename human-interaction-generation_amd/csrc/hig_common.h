@@ -1,0 +1,53 @@
+// Internal helpers shared by the HIP translation units of libhig.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hig.h"
+
+int hig_set_error(int code, const char* fmt, ...);
+
+#define HIG_REQUIRE(cond, ...)                                   \
+  do {                                                           \
+    if (!(cond)) return hig_set_error(HIG_EINVAL, __VA_ARGS__);  \
+  } while (0)
+
+#define HIG_CHECK_LAUNCH()                                                                   \
+  do {                                                                                       \
+    hipError_t e__ = hipGetLastError();                                                      \
+    if (e__ != hipSuccess)                                                                   \
+      return hig_set_error(HIG_EHIP, "%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+  } while (0)
+
+#define HIG_TRY(expr)            \
+  do {                           \
+    int rc__ = (expr);           \
+    if (rc__ != HIG_OK) return rc__; \
+  } while (0)
+
+static inline hipStream_t hig_stream(hig_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+__device__ __forceinline__ float hig_silu(float x) { return x / (1.0f + __expf(-x)); }
+// d/dx [x * sigmoid(x)] = s * (1 + x * (1 - s))
+__device__ __forceinline__ float hig_dsilu(float x) {
+  float s = 1.0f / (1.0f + __expf(-x));
+  return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float hig_gelu(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float hig_dgelu(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) +
+         x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,465 @@
+// Linear ("efficient") attention of the reference denoiser, forward and backward.
+// Reference: LinearTemporalSelfAttention / LinearTemporalCrossAttention.forward,
+// codes/models/transformer.py:110-117 and :146-153:
+//     q = softmax over the hd channels of each token           (row softmax)
+//     k = softmax over the tokens, per channel, with -1e6 mask (column softmax)
+//     A[b,h] = k^T v  (hd x hd);   y = q A
+// Masked rows get exp(-1e6 - max) == 0 exactly in fp32 and v*mask == 0, so they are skipped.
+//
+// These contractions are fp32 with hd x hd outputs: on gfx950 the f32 MFMA runs at the VALU
+// rate, so they stay on the VALU with LDS-staged tiles; the kernels are bound by LDS/VALU
+// issue on tiny tiles and by HBM on the (rows x hd) streams.  One workgroup per (sample, head);
+// channel c of head h lives at column h*hd + c of the (rows, d) activation.
+#include "hig_common.h"
+
+namespace {
+
+constexpr int CH = 64;  // rows staged per step
+
+template <int HD> struct Patch {  // register patch of the hd x hd context per thread
+  static constexpr int PC = HD >= 128 ? 8 : HD >= 64 ? 4 : HD >= 32 ? 2 : 1;
+  static constexpr int PL = PC;
+  static constexpr int TL = HD / PL;  // threads along l
+};
+
+// ---------------------------------------------------------------------------------------------
+// ctx: A[b,h][c][l] = sum_r softmax_r(K)[r,c] * V[r,l],  kstat[b][h*HD+c] = (max, sum exp)
+// ---------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void ctx_kernel(const float* __restrict__ K,
+                                                  const float* __restrict__ V, int64_t ld, int rows,
+                                                  int H, const int64_t* __restrict__ length,
+                                                  float* __restrict__ A, float* __restrict__ kstat) {
+  constexpr int LDP = HD + 4;
+  constexpr int PC = Patch<HD>::PC, PL = Patch<HD>::PL, TL = Patch<HD>::TL;
+  constexpr int RG = 256 / HD;
+  __shared__ __attribute__((aligned(16))) float sP[CH * LDP];
+  __shared__ __attribute__((aligned(16))) float sV[CH * LDP];
+  __shared__ float sred[256];
+  __shared__ float smax[HD];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  int len = rows;
+  if (length) len = (int)min<int64_t>(max<int64_t>(length[b], 0), rows);
+  const float* Kb = K + (int64_t)b * rows * ld + h * HD;
+  const float* Vb = V + (int64_t)b * rows * ld + h * HD;
+
+  {  // pass 1: column max over the valid rows
+    const int c = tid % HD, rg = tid / HD;
+    float m = -INFINITY;
+    for (int r = rg; r < len; r += RG) m = fmaxf(m, Kb[(int64_t)r * ld + c]);
+    sred[tid] = m;
+    __syncthreads();
+    if (tid < HD) {
+      for (int g2 = 1; g2 < RG; ++g2) m = fmaxf(m, sred[g2 * HD + tid]);
+      smax[tid] = m;
+    }
+    __syncthreads();
+  }
+
+  const int pc = tid / TL, pl = tid % TL;
+  const int c0 = pc * PC, l0 = pl * PL;
+  const bool active = c0 < HD;
+  float acc[PC][PL], ks[PC];
+#pragma unroll
+  for (int i = 0; i < PC; ++i) {
+    ks[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < PL; ++j) acc[i][j] = 0.f;
+  }
+  for (int r0 = 0; r0 < len; r0 += CH) {
+    for (int idx = tid; idx < CH * HD; idx += 256) {
+      const int rr = idx / HD, cc = idx % HD, r = r0 + rr;
+      float p = 0.f, v = 0.f;
+      if (r < len) {
+        p = __expf(Kb[(int64_t)r * ld + cc] - smax[cc]);
+        v = Vb[(int64_t)r * ld + cc];
+      }
+      sP[rr * LDP + cc] = p;
+      sV[rr * LDP + cc] = v;
+    }
+    __syncthreads();
+    if (active) {
+      const int nr = min(CH, len - r0);
+      for (int rr = 0; rr < nr; ++rr) {
+        float p[PC], v[PL];
+#pragma unroll
+        for (int i = 0; i < PC; ++i) p[i] = sP[rr * LDP + c0 + i];
+#pragma unroll
+        for (int j = 0; j < PL; ++j) v[j] = sV[rr * LDP + l0 + j];
+#pragma unroll
+        for (int i = 0; i < PC; ++i) {
+          ks[i] += p[i];
+#pragma unroll
+          for (int j = 0; j < PL; ++j) acc[i][j] = fmaf(p[i], v[j], acc[i][j]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (active) {
+    float* Ab = A + (int64_t)blockIdx.x * HD * HD;
+#pragma unroll
+    for (int i = 0; i < PC; ++i) {
+      const float inv = ks[i] > 0.f ? 1.0f / ks[i] : 0.f;
+#pragma unroll
+      for (int j = 0; j < PL; ++j) Ab[(c0 + i) * HD + l0 + j] = acc[i][j] * inv;
+      if (pl == 0) {
+        float* st = kstat + ((int64_t)blockIdx.x * HD + c0 + i) * 2;
+        st[0] = len > 0 ? smax[c0 + i] : 0.f;
+        st[1] = len > 0 ? ks[i] : 1.f;
+      }
+    }
+  }
+}
+
+// Stores PER contiguous floats (16-byte vectors when PER allows; callers guarantee alignment).
+template <int PER>
+__device__ __forceinline__ void store_per(float* __restrict__ p, const float* v) {
+  if constexpr (PER % 4 == 0) {
+#pragma unroll
+    for (int e = 0; e < PER; e += 4)
+      *reinterpret_cast<float4*>(p + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) p[e] = v[e];
+  }
+}
+
+// Loads a CH x HD tile of `src` (row r0.., columns of head h) into LDS, zero beyond `rows`.
+template <int HD>
+__device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t ld, int r0,
+                                          int rows, float* __restrict__ dst) {
+  constexpr int LDP = HD + 4;
+  constexpr int Q = HD / 4;
+  for (int idx = threadIdx.x; idx < CH * Q; idx += 256) {
+    const int rr = idx / Q, c4 = idx % Q, r = r0 + rr;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) v = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + 4 * c4);
+    *reinterpret_cast<float4*>(dst + rr * LDP + 4 * c4) = v;
+  }
+}
+
+// In-place softmax over the HD channels of each staged row; thread (rl, part) owns HD/4 values.
+template <int HD>
+__device__ __forceinline__ void row_softmax_tile(float* __restrict__ sQ) {
+  constexpr int LDP = HD + 4, PER = HD / 4;
+  const int rl = threadIdx.x >> 2, part = threadIdx.x & 3;
+  float* p = sQ + rl * LDP + part * PER;
+  float x[PER];
+  float m = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    x[e] = p[e];
+    m = fmaxf(m, x[e]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 1, 64));
+  m = fmaxf(m, __shfl_xor(m, 2, 64));
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    x[e] = __expf(x[e] - m);
+    s += x[e];
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  const float inv = 1.0f / s;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) p[e] = x[e] * inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// apply: Y[r, h*HD + l] = sum_c softmax_c(Q[r, h*HD + :])[c] * A[b,h][c][l]
+// grid = (B*H, ceil(rows / 64))
+// ---------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ Q, int64_t ldq,
+                                                    const float* __restrict__ A,
+                                                    float* __restrict__ Y, int64_t ldy, int rows,
+                                                    int H) {
+  constexpr int LDP = HD + 4, PER = HD / 4;
+  __shared__ __attribute__((aligned(16))) float sA[HD * HD];
+  __shared__ __attribute__((aligned(16))) float sQ[CH * LDP];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int r0 = blockIdx.y * CH;
+  const float* Ab = A + (int64_t)blockIdx.x * HD * HD;
+  for (int idx = tid; idx < HD * HD / 4; idx += 256)
+    reinterpret_cast<float4*>(sA)[idx] = reinterpret_cast<const float4*>(Ab)[idx];
+  load_tile<HD>(Q + (int64_t)b * rows * ldq + h * HD, ldq, r0, rows, sQ);
+  __syncthreads();
+  row_softmax_tile<HD>(sQ);
+  __syncthreads();
+  const int rl = tid >> 2, part = tid & 3;
+  float acc[PER];
+#pragma unroll
+  for (int e = 0; e < PER; ++e) acc[e] = 0.f;
+  const float* qrow = sQ + rl * LDP;
+  for (int c = 0; c < HD; ++c) {
+    const float qc = qrow[c];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) acc[e] = fmaf(qc, sA[c * HD + part * PER + e], acc[e]);
+  }
+  const int r = r0 + rl;
+  if (r < rows) {
+    store_per<PER>(Y + ((int64_t)b * rows + r) * ldy + h * HD + part * PER, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// apply_bwd: dq = dY A^T, dQ = q * (dq - sum_c q dq);  dA[c][l] = sum_r q[r,c] dY[r,l]
+// grid = B*H (each block walks all rows of its sample so dA needs no cross-block sum)
+// ---------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict__ dY, int64_t lddy,
+                                                        const float* __restrict__ Q, int64_t ldq,
+                                                        const float* __restrict__ A,
+                                                        float* __restrict__ dQ, int64_t lddq,
+                                                        float* __restrict__ dA, int rows, int H) {
+  constexpr int LDP = HD + 4, PER = HD / 4;
+  constexpr int PC = Patch<HD>::PC, PL = Patch<HD>::PL, TL = Patch<HD>::TL;
+  __shared__ __attribute__((aligned(16))) float sA[HD * LDP];  // padded: read by rows of c
+  __shared__ __attribute__((aligned(16))) float sQ[CH * LDP];
+  __shared__ __attribute__((aligned(16))) float sD[CH * LDP];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const float* Ab = A + (int64_t)blockIdx.x * HD * HD;
+  for (int idx = tid; idx < HD * HD; idx += 256) sA[(idx / HD) * LDP + idx % HD] = Ab[idx];
+  const int rl = tid >> 2, part = tid & 3;
+  const int pc = tid / TL, pl = tid % TL;
+  const int c0 = pc * PC, l0 = pl * PL;
+  const bool active = c0 < HD;
+  float acc[PC][PL];
+#pragma unroll
+  for (int i = 0; i < PC; ++i)
+#pragma unroll
+    for (int j = 0; j < PL; ++j) acc[i][j] = 0.f;
+
+  for (int r0 = 0; r0 < rows; r0 += CH) {
+    __syncthreads();
+    load_tile<HD>(Q + (int64_t)b * rows * ldq + h * HD, ldq, r0, rows, sQ);
+    load_tile<HD>(dY + (int64_t)b * rows * lddy + h * HD, lddy, r0, rows, sD);
+    __syncthreads();
+    row_softmax_tile<HD>(sQ);
+    __syncthreads();
+    {  // dq for (row rl, channels part*PER ..): dot of the dY row with rows of A
+      const float* dr = sD + rl * LDP;
+      float dq[PER];
+#pragma unroll
+      for (int e = 0; e < PER; ++e) dq[e] = 0.f;
+      for (int l = 0; l < HD; l += 4) {
+        const float4 d4 = *reinterpret_cast<const float4*>(dr + l);
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+          const float4 a4 = *reinterpret_cast<const float4*>(sA + (part * PER + e) * LDP + l);
+          dq[e] += d4.x * a4.x + d4.y * a4.y + d4.z * a4.z + d4.w * a4.w;
+        }
+      }
+      const float* qr = sQ + rl * LDP + part * PER;
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < PER; ++e) s += qr[e] * dq[e];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      const int r = r0 + rl;
+      if (r < rows) {
+        float o[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) o[e] = qr[e] * (dq[e] - s);
+        store_per<PER>(dQ + ((int64_t)b * rows + r) * lddq + h * HD + part * PER, o);
+      }
+    }
+    if (active) {  // dA patch: rows beyond `rows` are zero in sD
+      for (int rr = 0; rr < CH; ++rr) {
+        float p[PC], v[PL];
+#pragma unroll
+        for (int i = 0; i < PC; ++i) p[i] = sQ[rr * LDP + c0 + i];
+#pragma unroll
+        for (int j = 0; j < PL; ++j) v[j] = sD[rr * LDP + l0 + j];
+#pragma unroll
+        for (int i = 0; i < PC; ++i)
+#pragma unroll
+          for (int j = 0; j < PL; ++j) acc[i][j] = fmaf(p[i], v[j], acc[i][j]);
+      }
+    }
+  }
+  if (active) {
+    float* dAb = dA + (int64_t)blockIdx.x * HD * HD;
+#pragma unroll
+    for (int i = 0; i < PC; ++i)
+#pragma unroll
+      for (int j = 0; j < PL; ++j) dAb[(c0 + i) * HD + l0 + j] = acc[i][j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ctx_bwd: with k = exp(K - max)/sum on valid rows:
+//   dV[r,l] = sum_c k[r,c] dA[c][l];  dk[r,c] = sum_l V[r,l] dA[c][l];
+//   dK[r,c] = k[r,c] (dk[r,c] - sum_r' k[r',c] dk[r',c]);  masked rows get 0.
+// grid = B*H.  Pass 1 writes dV and raw dk (into dK) and accumulates the column sums; pass 2
+// finishes dK in place.
+// ---------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void ctx_bwd_kernel(const float* __restrict__ dA,
+                                                      const float* __restrict__ K,
+                                                      const float* __restrict__ V, int64_t ld,
+                                                      const float* __restrict__ kstat,
+                                                      const int64_t* __restrict__ length,
+                                                      float* __restrict__ dK, float* __restrict__ dV,
+                                                      int64_t ldd, int rows, int H) {
+  constexpr int LDP = HD + 4, PER = HD / 4;
+  __shared__ __attribute__((aligned(16))) float sdA[HD * LDP];   // [c][l]
+  __shared__ __attribute__((aligned(16))) float sK[CH * LDP];    // k (normalised)
+  __shared__ __attribute__((aligned(16))) float sV[CH * LDP];
+  __shared__ float smax[HD], sinv[HD], ssum[HD];
+  __shared__ float swsum[4][HD];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  int len = rows;
+  if (length) len = (int)min<int64_t>(max<int64_t>(length[b], 0), rows);
+  const float* dAb = dA + (int64_t)blockIdx.x * HD * HD;
+  for (int idx = tid; idx < HD * HD; idx += 256) sdA[(idx / HD) * LDP + idx % HD] = dAb[idx];
+  if (tid < HD) {
+    const float* st = kstat + ((int64_t)blockIdx.x * HD + tid) * 2;
+    smax[tid] = st[0];
+    sinv[tid] = 1.0f / st[1];
+    ssum[tid] = 0.f;
+  }
+  const float* Kb = K + (int64_t)b * rows * ld + h * HD;
+  const float* Vb = V + (int64_t)b * rows * ld + h * HD;
+  float* dKb = dK + (int64_t)b * rows * ldd + h * HD;
+  float* dVb = dV + (int64_t)b * rows * ldd + h * HD;
+  const int rl = tid >> 2, part = tid & 3;
+  float colsum[PER];
+#pragma unroll
+  for (int e = 0; e < PER; ++e) colsum[e] = 0.f;
+
+  for (int r0 = 0; r0 < rows; r0 += CH) {
+    __syncthreads();
+    for (int idx = tid; idx < CH * HD; idx += 256) {
+      const int rr = idx / HD, cc = idx % HD, r = r0 + rr;
+      float kk = 0.f, v = 0.f;
+      if (r < len) {
+        kk = __expf(Kb[(int64_t)r * ld + cc] - smax[cc]) * sinv[cc];
+        v = Vb[(int64_t)r * ld + cc];
+      }
+      sK[rr * LDP + cc] = kk;
+      sV[rr * LDP + cc] = v;
+    }
+    __syncthreads();
+    const int r = r0 + rl;
+    float dk[PER], dv[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) dk[e] = dv[e] = 0.f;
+    const float* kr = sK + rl * LDP;
+    const float* vr = sV + rl * LDP;
+    for (int x = 0; x < HD; x += 4) {  // dk[c=mine] = sum_l V[r,l] dA[c][l]
+      const float4 v4 = *reinterpret_cast<const float4*>(vr + x);
+#pragma unroll
+      for (int e = 0; e < PER; ++e) {
+        const float4 a4 = *reinterpret_cast<const float4*>(sdA + (part * PER + e) * LDP + x);
+        dk[e] += v4.x * a4.x + v4.y * a4.y + v4.z * a4.z + v4.w * a4.w;
+      }
+    }
+    for (int c = 0; c < HD; ++c) {  // dv[l=mine] = sum_c k[r,c] dA[c][l]
+      const float kc = kr[c];
+#pragma unroll
+      for (int e = 0; e < PER; ++e) dv[e] = fmaf(kc, sdA[c * LDP + part * PER + e], dv[e]);
+    }
+    if (r < rows) {
+      const bool valid = r < len;
+#pragma unroll
+      for (int e = 0; e < PER; ++e) {
+        colsum[e] += kr[part * PER + e] * dk[e];  // k == 0 on masked rows
+        if (!valid) dk[e] = dv[e] = 0.f;
+      }
+      store_per<PER>(dKb + (int64_t)r * ldd + part * PER, dk);
+      store_per<PER>(dVb + (int64_t)r * ldd + part * PER, dv);
+    }
+  }
+  // column sums: lanes with equal `part` hold different rows -> butterfly over lane bits 2..5
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    float s = colsum[e];
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if ((tid & 63) < 4) swsum[tid >> 6][part * PER + e] = s;
+  }
+  __syncthreads();
+  if (tid < HD) ssum[tid] = (swsum[0][tid] + swsum[1][tid]) + (swsum[2][tid] + swsum[3][tid]);
+  __syncthreads();
+  // pass 2: dK = k * (dk - colsum) on valid rows (dk was parked in dK)
+  for (int idx = tid; idx < len * HD; idx += 256) {
+    const int r = idx / HD, cc = idx % HD;
+    const float kk = __expf(Kb[(int64_t)r * ld + cc] - smax[cc]) * sinv[cc];
+    float* p = dKb + (int64_t)r * ldd + cc;
+    *p = kk * (*p - ssum[cc]);
+  }
+}
+
+bool hd_ok(int hd) { return hd == 8 || hd == 16 || hd == 32 || hd == 64 || hd == 128; }
+
+#define HD_SWITCH(hd, STMT)                  \
+  switch (hd) {                              \
+    case 8: { constexpr int HDV = 8; STMT; } break;     \
+    case 16: { constexpr int HDV = 16; STMT; } break;   \
+    case 32: { constexpr int HDV = 32; STMT; } break;   \
+    case 64: { constexpr int HDV = 64; STMT; } break;   \
+    default: { constexpr int HDV = 128; STMT; } break;  \
+  }
+
+}  // namespace
+
+extern "C" int hig_linattn_ctx(const float* K, const float* V, int64_t ld, int32_t B, int32_t rows,
+                               int32_t H, int32_t hd, const int64_t* length, float* A, float* kstat,
+                               hig_stream_t stream) {
+  HIG_REQUIRE(K && V && A && kstat && B > 0 && rows > 0 && H > 0, "hig_linattn_ctx: bad arguments");
+  HIG_REQUIRE(hd_ok(hd), "hig_linattn: head dim %d not in {8,16,32,64,128}", hd);
+  HD_SWITCH(hd, hipLaunchKernelGGL((ctx_kernel<HDV>), dim3(B * H), dim3(256), 0, hig_stream(stream), K, V,
+                                   ld, rows, H, length, A, kstat));
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+extern "C" int hig_linattn_apply(const float* Q, int64_t ldq, const float* A, float* Y, int64_t ldy,
+                                 int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream) {
+  HIG_REQUIRE(Q && A && Y && B > 0 && rows > 0 && H > 0, "hig_linattn_apply: bad arguments");
+  HIG_REQUIRE(hd_ok(hd), "hig_linattn: head dim %d not in {8,16,32,64,128}", hd);
+  HIG_REQUIRE(ldq % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(Y) & 15) == 0,
+              "hig_linattn_apply: Q/Y must be 16-byte aligned");
+  HD_SWITCH(hd, hipLaunchKernelGGL((apply_kernel<HDV>), dim3(B * H, (rows + CH - 1) / CH), dim3(256), 0,
+                                   hig_stream(stream), Q, ldq, A, Y, ldy, rows, H));
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+extern "C" int hig_linattn_apply_bwd(const float* dY, int64_t lddy, const float* Q, int64_t ldq,
+                                     const float* A, float* dQ, int64_t lddq, float* dA, int32_t B,
+                                     int32_t rows, int32_t H, int32_t hd, hig_stream_t stream) {
+  HIG_REQUIRE(dY && Q && A && dQ && dA && B > 0 && rows > 0 && H > 0, "hig_linattn_apply_bwd: bad arguments");
+  HIG_REQUIRE(hd_ok(hd), "hig_linattn: head dim %d not in {8,16,32,64,128}", hd);
+  HIG_REQUIRE(ldq % 4 == 0 && lddy % 4 == 0 && lddq % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(dQ) & 15) == 0,
+              "hig_linattn_apply_bwd: Q/dY/dQ must be 16-byte aligned");
+  HD_SWITCH(hd, hipLaunchKernelGGL((apply_bwd_kernel<HDV>), dim3(B * H), dim3(256), 0, hig_stream(stream), dY,
+                                   lddy, Q, ldq, A, dQ, lddq, dA, rows, H));
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+extern "C" int hig_linattn_ctx_bwd(const float* dA, const float* K, const float* V, int64_t ld,
+                                   const float* kstat, const int64_t* length, float* dK, float* dV,
+                                   int64_t ldd, int32_t B, int32_t rows, int32_t H, int32_t hd,
+                                   hig_stream_t stream) {
+  HIG_REQUIRE(dA && K && V && kstat && dK && dV && B > 0 && rows > 0 && H > 0, "hig_linattn_ctx_bwd: bad arguments");
+  HIG_REQUIRE(hd_ok(hd), "hig_linattn: head dim %d not in {8,16,32,64,128}", hd);
+  HIG_REQUIRE(ldd % 4 == 0 && (reinterpret_cast<uintptr_t>(dK) & 15) == 0 && (reinterpret_cast<uintptr_t>(dV) & 15) == 0,
+              "hig_linattn_ctx_bwd: dK/dV must be 16-byte aligned");
+  HD_SWITCH(hd, hipLaunchKernelGGL((ctx_bwd_kernel<HDV>), dim3(B * H), dim3(256), 0, hig_stream(stream), dA, K,
+                                   V, ld, kstat, length, dK, dV, ldd, rows, H));
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}

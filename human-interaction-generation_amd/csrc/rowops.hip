@@ -1,0 +1,339 @@
+// Row-wise HBM-bound kernels: LayerNorm statistics, LayerNorm / stylization backward with its
+// broadcast reductions, column sums (bias gradients), timestep embedding.
+// Reference arithmetic: nn.LayerNorm (eps 1e-5, biased variance) as used in
+// codes/models/transformer.py:68,94,127-128 and StylizationBlock.forward (:81-85).
+//
+// Mapping: one 64-lane wave per row, lanes stride the row in float4 (16 B/lane, coalesced 1 KiB
+// per wave-instruction); cross-lane sums by DPP/shuffle butterflies; no LDS for the row itself.
+#include "hig_common.h"
+
+namespace {
+
+constexpr int WAVES = 4;
+
+__global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__ x, int64_t ldx,
+                                                       int64_t rows, int n, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  const bool vec = (n % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  float s = 0.f;
+  if (vec) {
+    for (int c = 4 * lane; c < n; c += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(xr + c);
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (int c = lane; c < n; c += 64) s += xr[c];
+  }
+  const float mean = wave_sum(s) / (float)n;
+  float q = 0.f;
+  if (vec) {
+    for (int c = 4 * lane; c < n; c += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(xr + c);
+      const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  } else {
+    for (int c = lane; c < n; c += 64) {
+      const float a = xr[c] - mean;
+      q += a * a;
+    }
+  }
+  const float var = wave_sum(q) / (float)n;
+  if (lane == 0) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rsqrtf(var + 1e-5f);
+  }
+}
+
+// Backward of a = [silu](LN(x) * (1 + scale) + shift).  grid = (samples, splits); wave w of split
+// s owns rows s*4 + w, + 4*splits, ... of its sample.  NIT = ceil(n / 256) float4 per lane.
+template <int NIT, bool MOD_SILU>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(
+    const float* __restrict__ da, int64_t ldda, const float* __restrict__ x, int64_t ldx,
+    const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ ss, int64_t ss_ld, int shift_off, const float* __restrict__ res,
+    int64_t ldr, float* __restrict__ dx, int64_t lddx, int n, int rows_per_sample,
+    float* __restrict__ partial) {
+  __shared__ float red[WAVES][4][64 * 4];  // one NIT slice at a time
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+  const float inv_n = 1.0f / (float)n;
+  float4 g4[NIT], b4[NIT], sc4[NIT], sh4[NIT];
+  float4 a_dg[NIT], a_db[NIT], a_dsc[NIT], a_dsh[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = 4 * lane + 256 * it;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    g4[it] = b4[it] = sc4[it] = sh4[it] = z;
+    a_dg[it] = a_db[it] = a_dsc[it] = a_dsh[it] = z;
+    if (c < n) {
+      g4[it] = *reinterpret_cast<const float4*>(gamma + c);
+      b4[it] = *reinterpret_cast<const float4*>(beta + c);
+      if (MOD_SILU) {
+        sc4[it] = *reinterpret_cast<const float4*>(ss + (int64_t)b * ss_ld + c);
+        sh4[it] = *reinterpret_cast<const float4*>(ss + (int64_t)b * ss_ld + shift_off + c);
+      }
+    }
+  }
+  for (int rl = split * WAVES + wave; rl < rows_per_sample; rl += WAVES * nsplit) {
+    const int64_t row = (int64_t)b * rows_per_sample + rl;
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float4 xh[NIT], dxh[NIT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = 4 * lane + 256 * it;
+      xh[it] = dxh[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < n) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + row * ldx + c);
+        const float4 dav = *reinterpret_cast<const float4*>(da + row * ldda + c);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dav.x, dav.y, dav.z, dav.w};
+        const float gs[4] = {g4[it].x, g4[it].y, g4[it].z, g4[it].w};
+        const float bs[4] = {b4[it].x, b4[it].y, b4[it].z, b4[it].w};
+        const float scs[4] = {sc4[it].x, sc4[it].y, sc4[it].z, sc4[it].w};
+        const float shs[4] = {sh4[it].x, sh4[it].y, sh4[it].z, sh4[it].w};
+        float xho[4], dxo[4], dgo[4], dbo[4], dsco[4], dsho[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xhat = (xs[e] - mean) * rstd;
+          const float nrm = xhat * gs[e] + bs[e];
+          float dn;
+          if (MOD_SILU) {
+            const float u = nrm * (1.0f + scs[e]) + shs[e];
+            const float du = ds[e] * hig_dsilu(u);
+            dsho[e] = du;
+            dsco[e] = du * nrm;
+            dn = du * (1.0f + scs[e]);
+          } else {
+            dsho[e] = dsco[e] = 0.f;
+            dn = ds[e];
+          }
+          dgo[e] = dn * xhat;
+          dbo[e] = dn;
+          xho[e] = xhat;
+          dxo[e] = dn * gs[e];
+          s1 += dxo[e];
+          s2 += dxo[e] * xhat;
+        }
+        xh[it] = make_float4(xho[0], xho[1], xho[2], xho[3]);
+        dxh[it] = make_float4(dxo[0], dxo[1], dxo[2], dxo[3]);
+        a_dg[it].x += dgo[0]; a_dg[it].y += dgo[1]; a_dg[it].z += dgo[2]; a_dg[it].w += dgo[3];
+        a_db[it].x += dbo[0]; a_db[it].y += dbo[1]; a_db[it].z += dbo[2]; a_db[it].w += dbo[3];
+        if (MOD_SILU) {
+          a_dsc[it].x += dsco[0]; a_dsc[it].y += dsco[1]; a_dsc[it].z += dsco[2]; a_dsc[it].w += dsco[3];
+          a_dsh[it].x += dsho[0]; a_dsh[it].y += dsho[1]; a_dsh[it].z += dsho[2]; a_dsh[it].w += dsho[3];
+        }
+      }
+    }
+    s1 = wave_sum(s1) * inv_n;
+    s2 = wave_sum(s2) * inv_n;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = 4 * lane + 256 * it;
+      if (c < n) {
+        float4 o;
+        o.x = rstd * (dxh[it].x - s1 - xh[it].x * s2);
+        o.y = rstd * (dxh[it].y - s1 - xh[it].y * s2);
+        o.z = rstd * (dxh[it].z - s1 - xh[it].z * s2);
+        o.w = rstd * (dxh[it].w - s1 - xh[it].w * s2);
+        if (res) {
+          const float4 r4 = *reinterpret_cast<const float4*>(res + row * ldr + c);
+          o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
+        }
+        *reinterpret_cast<float4*>(dx + row * lddx + c) = o;
+      }
+    }
+  }
+  // cross-wave reduction of the column accumulators -> partial[(b*nsplit+split)][4][n]
+  float* pout = partial + ((int64_t)b * nsplit + split) * 4 * n;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    __syncthreads();
+    *reinterpret_cast<float4*>(&red[wave][0][4 * lane]) = a_dg[it];
+    *reinterpret_cast<float4*>(&red[wave][1][4 * lane]) = a_db[it];
+    *reinterpret_cast<float4*>(&red[wave][2][4 * lane]) = a_dsc[it];
+    *reinterpret_cast<float4*>(&red[wave][3][4 * lane]) = a_dsh[it];
+    __syncthreads();
+    // 4 quantities x 256 columns = 1024 sums, 4 per thread
+    for (int e = threadIdx.x; e < 4 * 256; e += 256) {
+      const int qn = e >> 8, cl = e & 255, c = cl + 256 * it;
+      if (c < n) {
+        float s = red[0][qn][cl];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) s += red[w][qn][cl];
+        pout[(int64_t)qn * n + c] = s;
+      }
+    }
+  }
+}
+
+// out[c] = sum_{r<nr} in[(r*rstride) + c]  (column reduction of small partial tables)
+__global__ void colreduce_kernel(const float* __restrict__ in, int nr, int64_t rstride, int n,
+                                 float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int r = 0; r < nr; ++r) s += in[(int64_t)r * rstride + c];
+  out[c] = s;
+}
+// dss[b][c] = sum_s partial[b][s][2][c];  dss[b][shift_off + c] = sum_s partial[b][s][3][c]
+__global__ void dss_reduce_kernel(const float* __restrict__ partial, int nsplit, int n,
+                                  int shift_off, float* __restrict__ dss, int64_t dss_ld) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (c >= n) return;
+  float s2 = 0.f, s3 = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* p = partial + ((int64_t)b * nsplit + s) * 4 * n;
+    s2 += p[2 * (int64_t)n + c];
+    s3 += p[3 * (int64_t)n + c];
+  }
+  dss[(int64_t)b * dss_ld + c] = s2;
+  dss[(int64_t)b * dss_ld + shift_off + c] = s3;
+}
+
+// partial[chunk][c] = sum over this chunk's rows of x[row][c]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx,
+                                                     int64_t rows, int n, float* __restrict__ partial) {
+  __shared__ float red[WAVES][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 256 + 4 * lane;
+  const int chunk = blockIdx.y, nchunk = gridDim.y;
+  const bool vec = (n % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t r = (int64_t)chunk * WAVES + wave; r < rows; r += (int64_t)WAVES * nchunk) {
+    const float* p = x + r * ldx + c0;
+    if (vec) {
+      if (c0 < n) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    } else {
+      if (c0 < n) s.x += p[0];
+      if (c0 + 1 < n) s.y += p[1];
+      if (c0 + 2 < n) s.z += p[2];
+      if (c0 + 3 < n) s.w += p[3];
+    }
+  }
+  *reinterpret_cast<float4*>(&red[wave][4 * lane]) = s;
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < n) {
+    float t = red[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) t += red[w][threadIdx.x];
+    partial[(int64_t)chunk * n + c] = t;
+  }
+}
+
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int B, int d,
+                                          float* __restrict__ out) {
+  const int half = d / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * d) return;
+  const int b = idx / d, c = idx % d;
+  float v = 0.f;
+  if (c < 2 * half) {
+    const int i = c < half ? c : c - half;
+    // freqs = exp(-ln(10000) * i / half) in fp32, args = float(t) * freqs  (transformer.py:25-28)
+    const float e32 = -9.210340371976184f * (float)i / (float)half;
+    const float freq = (float)exp((double)e32);  // correctly rounded fp32 exp
+    const float arg = (float)t[b] * freq;
+    v = c < half ? cosf(arg) : sinf(arg);
+  }
+  out[idx] = v;
+}
+
+int splits_for(int64_t samples) {
+  int s = 1;
+  while (samples * s < 512 && s < 16) s *= 2;
+  return s;
+}
+
+}  // namespace
+
+extern "C" int hig_rowstats(const float* x, int64_t ldx, int64_t rows, int32_t n, float* stats,
+                            hig_stream_t stream) {
+  HIG_REQUIRE(x && stats && n > 0 && rows >= 0, "hig_rowstats: bad arguments");
+  if (rows == 0) return HIG_OK;
+  hipLaunchKernelGGL(rowstats_kernel, dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(256), 0,
+                     hig_stream(stream), x, ldx, rows, n, stats);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+extern "C" int64_t hig_ln_bwd_partial_floats(int64_t rows, int32_t n, int32_t rows_per_sample) {
+  if (rows_per_sample <= 0) return 0;
+  const int64_t samples = rows / rows_per_sample;
+  return samples * splits_for(samples) * 4 * (int64_t)n;
+}
+
+extern "C" int hig_ln_bwd(const float* da, int64_t ldda, const float* x, int64_t ldx,
+                          const float* stats, const float* gamma, const float* beta,
+                          const float* ss, int64_t ss_ld, int32_t ss_shift_off, int32_t mod_silu,
+                          const float* res, int64_t ldr, float* dx, int64_t lddx, int64_t rows,
+                          int32_t n, int32_t rows_per_sample, float* dgamma, float* dbeta,
+                          float* dss, int64_t dss_ld, float* partial, hig_stream_t stream) {
+  HIG_REQUIRE(da && x && stats && gamma && beta && dx && partial, "hig_ln_bwd: null argument");
+  HIG_REQUIRE(n % 4 == 0 && n <= 1024 && ldda % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0,
+              "hig_ln_bwd: n must be a multiple of 4 and <= 1024 (got %d)", n);
+  HIG_REQUIRE(rows_per_sample > 0 && rows % rows_per_sample == 0, "hig_ln_bwd: rows %% rows_per_sample");
+  HIG_REQUIRE(!mod_silu || (ss && dss), "hig_ln_bwd: modulation needs ss / dss");
+  if (rows == 0) return HIG_OK;
+  const int samples = (int)(rows / rows_per_sample);
+  const int nsplit = splits_for(samples);
+  const int nit = (n + 255) / 256;
+  hipStream_t st = hig_stream(stream);
+  dim3 grid(samples, nsplit);
+#define LNB(NITV, MODV)                                                                          \
+  hipLaunchKernelGGL((ln_bwd_kernel<NITV, MODV>), grid, dim3(256), 0, st, da, ldda, x, ldx, stats, \
+                     gamma, beta, ss, ss_ld, ss_shift_off, res, ldr, dx, lddx, n, rows_per_sample, partial)
+  if (mod_silu) {
+    if (nit == 1) LNB(1, true); else if (nit == 2) LNB(2, true); else LNB(4, true);
+  } else {
+    if (nit == 1) LNB(1, false); else if (nit == 2) LNB(2, false); else LNB(4, false);
+  }
+#undef LNB
+  HIG_CHECK_LAUNCH();
+  const int tb = 128;
+  if (dgamma) {
+    hipLaunchKernelGGL(colreduce_kernel, dim3((n + tb - 1) / tb), dim3(tb), 0, st, partial,
+                       samples * nsplit, (int64_t)4 * n, n, dgamma);
+    HIG_CHECK_LAUNCH();
+  }
+  if (dbeta) {
+    hipLaunchKernelGGL(colreduce_kernel, dim3((n + tb - 1) / tb), dim3(tb), 0, st, partial + n,
+                       samples * nsplit, (int64_t)4 * n, n, dbeta);
+    HIG_CHECK_LAUNCH();
+  }
+  if (mod_silu) {
+    hipLaunchKernelGGL(dss_reduce_kernel, dim3((n + tb - 1) / tb, samples), dim3(tb), 0, st, partial,
+                       nsplit, n, ss_shift_off, dss, dss_ld);
+    HIG_CHECK_LAUNCH();
+  }
+  return HIG_OK;
+}
+
+extern "C" int hig_colsum(const float* x, int64_t ldx, int64_t rows, int32_t n, float* out,
+                          float* partial, hig_stream_t stream) {
+  HIG_REQUIRE(x && out && partial && n > 0, "hig_colsum: bad arguments");
+  hipStream_t st = hig_stream(stream);
+  hipLaunchKernelGGL(colsum_kernel, dim3((n + 255) / 256, HIG_COLSUM_CHUNKS), dim3(256), 0, st, x, ldx,
+                     rows, n, partial);
+  HIG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colreduce_kernel, dim3((n + 127) / 128), dim3(128), 0, st, partial,
+                     HIG_COLSUM_CHUNKS, (int64_t)n, n, out);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+extern "C" int hig_timestep_embedding(const int64_t* t, int32_t B, int32_t d, float* out,
+                                      hig_stream_t s) {
+  HIG_REQUIRE(t && out && B > 0 && d > 0, "hig_timestep_embedding: bad arguments");
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((B * d + 255) / 256), dim3(256), 0, hig_stream(s),
+                     t, B, d, out);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}

@@ -1,0 +1,451 @@
+"""MI355X-native `MotionTransformer`: same constructor, attributes, state-dict keys and call
+signature as the reference module (codes/models/transformer.py:288-426), with the per-timestep
+denoiser math running in hand-written HIP kernels behind the C ABI of include/hig.h.
+
+What stays on stock PyTorch ops (boundary): `encode_text` -- CLIP (frozen,
+stubbed when the `clip` package is absent) and the 4-layer text TransformerEncoder head.
+
+There is no CPU execution path: calling the module on host tensors, or without libhig.so, raises.
+"""
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from .. import _lib
+
+try:  # the real OpenAI CLIP when installed (transformer.py:10), else the deterministic stand-in
+    import clip  # type: ignore
+except Exception:  # pragma: no cover - depends on the environment
+    from . import stub_clip as clip
+
+
+def timestep_embedding(timesteps, dim, max_period=10000):
+    """Sinusoidal embedding, cos first (transformer.py:15-32).  Device tensors go through the
+    HIP kernel; kept as a module-level function because reference callers import it."""
+    if timesteps.is_cuda:
+        t = timesteps.long().contiguous()
+        out = torch.empty(t.shape[0], dim, device=t.device, dtype=torch.float32)
+        _lib.check(_lib.lib().hig_timestep_embedding(_lib.ptr(t), t.shape[0], dim, _lib.ptr(out),
+                                                    _lib.stream_ptr()))
+        return out
+    raise RuntimeError("timestep_embedding: ROCm device tensor required (no CPU fallback)")
+
+
+def set_requires_grad(nets, requires_grad=False):
+    """transformer.py:35-48."""
+    if not isinstance(nets, list):
+        nets = [nets]
+    for net in nets:
+        if net is not None:
+            for param in net.parameters():
+                param.requires_grad = requires_grad
+
+
+def zero_module(module):
+    """transformer.py:51-57."""
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+# --- parameter containers: same submodule / key names as the reference; math lives in HIP -----
+class StylizationBlock(nn.Module):
+    """Parameters of transformer.py:60-73 (emb_layers.1, norm, out_layers.2 [zero-init])."""
+
+    def __init__(self, latent_dim, time_embed_dim, dropout):
+        super().__init__()
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(time_embed_dim, 2 * latent_dim))
+        self.norm = nn.LayerNorm(latent_dim)
+        self.out_layers = nn.Sequential(nn.SiLU(), nn.Dropout(p=dropout),
+                                        zero_module(nn.Linear(latent_dim, latent_dim)))
+
+
+class _SelfAttention(nn.Module):
+    """Parameters of (Linear)TemporalSelfAttention, transformer.py:91-99 / 198-206."""
+
+    def __init__(self, latent_dim, num_head, dropout, time_embed_dim):
+        super().__init__()
+        self.num_head = num_head
+        self.norm = nn.LayerNorm(latent_dim)
+        self.query = nn.Linear(latent_dim, latent_dim)
+        self.key = nn.Linear(latent_dim, latent_dim)
+        self.value = nn.Linear(latent_dim, latent_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.proj_out = StylizationBlock(latent_dim, time_embed_dim, dropout)
+
+
+class _CrossAttention(nn.Module):
+    """Parameters of (Linear)TemporalCrossAttention, transformer.py:124-133 / 231-240."""
+
+    def __init__(self, latent_dim, text_latent_dim, num_head, dropout, time_embed_dim):
+        super().__init__()
+        self.num_head = num_head
+        self.norm = nn.LayerNorm(latent_dim)
+        self.text_norm = nn.LayerNorm(text_latent_dim)
+        self.query = nn.Linear(latent_dim, latent_dim)
+        self.key = nn.Linear(text_latent_dim, latent_dim)
+        self.value = nn.Linear(text_latent_dim, latent_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.proj_out = StylizationBlock(latent_dim, time_embed_dim, dropout)
+
+
+class FFN(nn.Module):
+    """Parameters of transformer.py:157-165 (linear2 zero-init)."""
+
+    def __init__(self, latent_dim, ffn_dim, dropout, time_embed_dim):
+        super().__init__()
+        self.linear1 = nn.Linear(latent_dim, ffn_dim)
+        self.linear2 = zero_module(nn.Linear(ffn_dim, latent_dim))
+        self.activation = nn.GELU()
+        self.dropout = nn.Dropout(dropout)
+        self.proj_out = StylizationBlock(latent_dim, time_embed_dim, dropout)
+
+
+class _DecoderLayer(nn.Module):
+    """transformer.py:173-194 / 264-285: sa_block -> ca_block -> ffn."""
+
+    def __init__(self, latent_dim, text_latent_dim, time_embed_dim, ffn_dim, num_head, dropout):
+        super().__init__()
+        self.sa_block = _SelfAttention(latent_dim, num_head, dropout, time_embed_dim)
+        self.ca_block = _CrossAttention(latent_dim, text_latent_dim, num_head, dropout, time_embed_dim)
+        self.ffn = FFN(latent_dim, ffn_dim, dropout, time_embed_dim)
+
+
+def _core_param_order(model):
+    """(global table, per-layer tables) as lists of parameter groups in hig.h table order.
+    A group with several parameters must be laid out contiguously (fused GEMM operand)."""
+    blocks = list(model.temporal_decoder_blocks)
+    stys = [s for b in blocks for s in (b.sa_block.proj_out, b.ca_block.proj_out, b.ffn.proj_out)]
+    glob = [
+        [model.sequence_embedding],
+        [model.joint_embed.weight], [model.joint_embed.bias],
+        [model.time_embed[0].weight], [model.time_embed[0].bias],
+        [model.time_embed[2].weight], [model.time_embed[2].bias],
+        [s.emb_layers[1].weight for s in stys], [s.emb_layers[1].bias for s in stys],
+        [model.out.weight], [model.out.bias],
+    ]
+    layers = []
+    for b in blocks:
+        sa, ca, ff = b.sa_block, b.ca_block, b.ffn
+        layers.append([
+            [sa.norm.weight], [sa.norm.bias],
+            [sa.query.weight, sa.key.weight, sa.value.weight], [sa.query.bias, sa.key.bias, sa.value.bias],
+            [sa.proj_out.norm.weight], [sa.proj_out.norm.bias],
+            [sa.proj_out.out_layers[2].weight], [sa.proj_out.out_layers[2].bias],
+            [ca.norm.weight], [ca.norm.bias], [ca.text_norm.weight], [ca.text_norm.bias],
+            [ca.query.weight], [ca.query.bias],
+            [ca.key.weight, ca.value.weight], [ca.key.bias, ca.value.bias],
+            [ca.proj_out.norm.weight], [ca.proj_out.norm.bias],
+            [ca.proj_out.out_layers[2].weight], [ca.proj_out.out_layers[2].bias],
+            [ff.linear1.weight], [ff.linear1.bias], [ff.linear2.weight], [ff.linear2.bias],
+            [ff.proj_out.norm.weight], [ff.proj_out.norm.bias],
+            [ff.proj_out.out_layers[2].weight], [ff.proj_out.out_layers[2].bias],
+        ])
+    assert len(glob) == _lib.NGLOBAL and all(len(l) == _lib.NLAYER for l in layers)
+    return glob, layers
+
+
+class _FlatParams:
+    """One contiguous fp32 device buffer holding every denoiser-core parameter (and a twin for
+    gradients) so that (a) q/k/v, key/value and the 3L stylization `emb_layers` matrices are
+    single fused-GEMM operands, (b) the RCCL all-reduce and the fused clip+Adam see ONE buffer.
+    The nn.Parameters become views into it; state-dict names/shapes are untouched."""
+
+    ALIGN = 64  # floats (256 B)
+
+    def __init__(self, model):
+        glob, layers = _core_param_order(model)
+        groups = glob + [g for l in layers for g in l]
+        self.params = [p for g in groups for p in g]
+        dev = self.params[0].device
+        assert all(p.device == dev and p.dtype == torch.float32 for p in self.params)
+        offs, o = [], 0
+        self.group_offsets = []
+        for g in groups:
+            o = (o + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            self.group_offsets.append(o)
+            for p in g:
+                offs.append(o)
+                o += p.numel()
+        self.numel = (o + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.offsets = offs
+        self.flat = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for p, off in zip(self.params, offs):
+                view = self.flat[off:off + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+        self.grad = None
+        self.grad_views = None
+        self._ptr_key = None
+        self._ptable = None
+        self._gtable = None
+
+    def table(self, base_ptr):
+        n = len(self.group_offsets)
+        arr = (C.c_void_p * n)()
+        for i, off in enumerate(self.group_offsets):
+            arr[i] = base_ptr + 4 * off
+        return arr
+
+    def param_table(self):
+        key = self.flat.data_ptr()
+        if self._ptr_key != key:
+            self._ptable, self._ptr_key = self.table(key), key
+        return self._ptable
+
+    def ensure_grad(self):
+        if self.grad is None:
+            self.grad = torch.zeros_like(self.flat)
+            self.grad_views = [self.grad[o:o + p.numel()].view(p.shape)
+                               for p, o in zip(self.params, self.offsets)]
+            self._gtable = self.table(self.grad.data_ptr())
+        return self._gtable
+
+    def valid(self):
+        base, end = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.numel
+        return all(p.is_cuda and base <= p.data_ptr() < end for p in self.params[:3] + self.params[-3:]) \
+            and all(p.data_ptr() == base + 4 * o for p, o in zip(self.params[:8], self.offsets[:8]))
+
+
+class _WorkspacePool:
+    """Scratch buffers keyed by (kind, bytes).  A forward that needs its activations kept for
+    backward holds its buffer until backward returns it."""
+
+    def __init__(self):
+        self.free = {}
+
+    def take(self, kind, nbytes, device):
+        lst = self.free.setdefault((kind, nbytes, str(device)), [])
+        if lst:
+            return lst.pop()
+        return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+    def give(self, kind, buf, device):
+        self.free.setdefault((kind, buf.numel(), str(device)), []).append(buf)
+
+
+class _DenoiserFn(torch.autograd.Function):
+    """Autograd boundary: forward = hig_text_context + hig_denoiser_fwd(training=1),
+    backward = hig_denoiser_bwd.  Parameter gradients come back as copies of the views of the
+    flat gradient buffer (the fused trainer path reads the flat buffer directly instead)."""
+
+    @staticmethod
+    def forward(ctx, model, x, t, length, xf_proj, xf_out, *params):
+        out, saved = model._launch_forward(x, t, length, xf_proj, xf_out, training=True)
+        ctx.model, ctx.saved = model, saved
+        ctx.save_for_backward(x, t, length, xf_out)
+        ctx.need = (x.requires_grad, xf_proj.requires_grad, xf_out.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model = ctx.model
+        x, t, length, xf_out = ctx.saved_tensors
+        dx, dxp, dxo = model._launch_backward(x, t, length, xf_out, ctx.saved, dout.contiguous(),
+                                              want_dx=ctx.need[0])
+        ctx.saved = None
+        pg = tuple(g.clone() for g in model._flat.grad_views)
+        return (None, dx if ctx.need[0] else None, None, None, dxp if ctx.need[1] else None,
+                dxo if ctx.need[2] else None) + pg
+
+
+class MotionTransformer(nn.Module):
+    """Drop-in for the reference class (transformer.py:288-426)."""
+
+    def __init__(self, input_feats, num_frames=240, latent_dim=512, ff_size=1024, num_layers=8,
+                 num_heads=8, dropout=0, activation="gelu", num_text_layers=4, text_latent_dim=256,
+                 text_ff_size=2048, text_num_heads=4, no_clip=False, no_eff=False, **kargs):
+        super().__init__()
+        if dropout != 0:
+            # every reference tool uses the constructor default p=0; the fused
+            # kernels implement exactly that
+            raise NotImplementedError("dropout != 0 is not supported by the fused denoiser")
+        self.num_frames = num_frames
+        self.latent_dim = latent_dim
+        self.ff_size = ff_size
+        self.num_layers = num_layers
+        self.num_heads = num_heads
+        self.dropout = dropout
+        self.activation = activation
+        self.input_feats = input_feats
+        self.time_embed_dim = latent_dim * 4
+        self.text_latent_dim = text_latent_dim
+        self.no_eff = no_eff
+        self.sequence_embedding = nn.Parameter(torch.randn(num_frames, latent_dim))
+
+        # Text transformer (stock torch ops; transformer.py:318-340)
+        self.clip, _ = clip.load('ViT-B/32', "cpu")
+        if no_clip:
+            self.clip.initialize_parameters()
+        else:
+            set_requires_grad(self.clip, False)
+        if text_latent_dim != 512:
+            self.text_pre_proj = nn.Linear(512, text_latent_dim)
+        else:
+            self.text_pre_proj = nn.Identity()
+        layer = nn.TransformerEncoderLayer(d_model=text_latent_dim, nhead=text_num_heads,
+                                           dim_feedforward=text_ff_size, dropout=dropout,
+                                           activation=activation)
+        self.textTransEncoder = nn.TransformerEncoder(layer, num_layers=num_text_layers,
+                                                      enable_nested_tensor=False)
+        self.text_ln = nn.LayerNorm(text_latent_dim)
+        self.text_proj = nn.Sequential(nn.Linear(text_latent_dim, self.time_embed_dim))
+
+        # Denoiser core (parameters only; the math is in libhig.so)
+        self.joint_embed = nn.Linear(self.input_feats, self.latent_dim)
+        self.time_embed = nn.Sequential(
+            nn.Linear(self.latent_dim, self.time_embed_dim),
+            nn.SiLU(),
+            nn.Linear(self.time_embed_dim, self.time_embed_dim),
+        )
+        self.temporal_decoder_blocks = nn.ModuleList(
+            _DecoderLayer(latent_dim, text_latent_dim, self.time_embed_dim, ff_size, num_heads, dropout)
+            for _ in range(num_layers))
+        self.out = zero_module(nn.Linear(self.latent_dim, self.input_feats))
+
+        self._flat = None
+        self._pool = _WorkspacePool()
+        self._textctx_cache = None
+
+    # ---- nn.Module plumbing -------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._flat = None            # .to()/.cuda()/.float() re-home parameters: re-flatten lazily
+        self._textctx_cache = None
+        return r
+
+    def flat_params(self):
+        """Flat fp32 buffer aliasing every core parameter (built on first use on the device)."""
+        if self._flat is None or not self._flat.valid():
+            if not self.out.weight.is_cuda:
+                raise RuntimeError("MotionTransformer: parameters must live on a ROCm device "
+                                   "(call .to('cuda')); there is no CPU fallback")
+            self._flat = _FlatParams(self)
+        return self._flat
+
+    def core_parameters(self):
+        return list(self.flat_params().params)
+
+    # ---- reference API ------------------------------------------------------------------
+    def encode_text(self, text, device):
+        """transformer.py:380-397."""
+        with torch.no_grad():
+            text = clip.tokenize(text, truncate=True).to(device)
+            x = self.clip.token_embedding(text).type(self.clip.dtype)
+            x = x + self.clip.positional_embedding.type(self.clip.dtype)
+            x = x.permute(1, 0, 2)
+            x = self.clip.transformer(x)
+            x = self.clip.ln_final(x).type(self.clip.dtype)
+        x = self.text_pre_proj(x)
+        xf_out = self.textTransEncoder(x)
+        xf_out = self.text_ln(xf_out)
+        xf_proj = self.text_proj(xf_out[text.argmax(dim=-1), torch.arange(xf_out.shape[1])])
+        xf_out = xf_out.permute(1, 0, 2)
+        return xf_proj, xf_out
+
+    def generate_src_mask(self, T, length):
+        """(B, T) float CPU mask, mask[i, j] = j < length[i] (transformer.py:399-405); the
+        trainer calls this directly (ddpm_trainer.py:116-119).  The kernels build their own
+        mask from `length` on the device."""
+        length = torch.as_tensor(length).detach().to("cpu", torch.int64).view(-1)
+        return (torch.arange(T)[None, :] < length[:, None]).float()
+
+    def dims(self, B, T, N):
+        return _lib.Dims(B=B, T=T, F=self.input_feats, d=self.latent_dim, H=self.num_heads,
+                         ff=self.ff_size, L=self.num_layers, N=N, Lt=self.text_latent_dim,
+                         num_frames=self.num_frames,
+                         attn_kind=_lib.ATTN_FULL if self.no_eff else _lib.ATTN_LINEAR,
+                         prec=_lib.PREC_F32)
+
+    def forward(self, x, timesteps, length=None, text=None, xf_proj=None, xf_out=None):
+        """x: (B, T, F) -> (B, T, F)   (transformer.py:407-426)."""
+        B, T = x.shape[0], x.shape[1]
+        if xf_proj is None or xf_out is None:
+            xf_proj, xf_out = self.encode_text(text, x.device)
+        if not x.is_cuda:
+            raise RuntimeError("MotionTransformer.forward: ROCm device tensors required "
+                               "(no CPU fallback; the CPU restatement lives in oracle/ for tests only)")
+        assert x.shape[2] == self.input_feats and T <= self.num_frames
+        dev = x.device
+        x = x.float().contiguous()
+        t = timesteps.to(dev).long().contiguous()
+        assert t.shape == (B,)
+        if length is None:
+            length = torch.full((B,), T, dtype=torch.int64, device=dev)
+        else:
+            length = torch.as_tensor(length).to(dev).long().contiguous()
+        xf_proj = xf_proj.float().contiguous()
+        xf_out = xf_out.float().contiguous()
+        fp = self.flat_params()
+        needs_grad = torch.is_grad_enabled() and (
+            x.requires_grad or xf_proj.requires_grad or xf_out.requires_grad
+            or any(p.requires_grad for p in fp.params))
+        if needs_grad:
+            return _DenoiserFn.apply(self, x, t, length, xf_proj, xf_out, *fp.params)
+        out, _ = self._launch_forward(x, t, length, xf_proj, xf_out, training=False)
+        return out
+
+    # ---- launches -----------------------------------------------------------------------
+    def _text_context(self, dims, xf_out, training):
+        """Cross-attention text side (all layers).  Cached on (storage, version) of xf_out and the
+        parameter version, so the 1000-step sampling loop computes it once (it is step-invariant)."""
+        fp = self.flat_params()
+        key = (xf_out.data_ptr(), xf_out._version, tuple(xf_out.shape), fp.flat.data_ptr(),
+               fp.flat._version, bool(training))
+        if not training and self._textctx_cache is not None and self._textctx_cache[0] == key:
+            return self._textctx_cache[1]
+        L = _lib.lib()
+        nbytes = L.hig_textctx_bytes(C.byref(dims), int(training))
+        if nbytes < 0:
+            raise RuntimeError("libhig: " + _lib.last_error())
+        buf = (self._pool.take("textctx_t", nbytes, xf_out.device) if training
+               else torch.empty(nbytes, dtype=torch.uint8, device=xf_out.device))
+        _lib.check(L.hig_text_context(C.byref(dims), fp.param_table(), _lib.ptr(xf_out), _lib.ptr(buf),
+                                      int(training), _lib.stream_ptr()))
+        if not training:
+            self._textctx_cache = (key, buf, xf_out)  # keep xf_out alive so the key stays unique
+        return buf
+
+    def _launch_forward(self, x, t, length, xf_proj, xf_out, training):
+        B, T, N = x.shape[0], x.shape[1], xf_out.shape[1]
+        assert xf_out.shape == (B, N, self.text_latent_dim) and xf_proj.shape == (B, self.time_embed_dim)
+        L = _lib.lib()
+        fp = self.flat_params()
+        dims = self.dims(B, T, N)
+        nbytes = L.hig_workspace_bytes(C.byref(dims), int(training))
+        if nbytes < 0:
+            raise RuntimeError("libhig: " + _lib.last_error())
+        textctx = self._text_context(dims, xf_out, training)
+        ws = self._pool.take("fwd_t" if training else "fwd_i", nbytes, x.device)
+        out = torch.empty(B, T, self.input_feats, device=x.device, dtype=torch.float32)
+        _lib.check(L.hig_denoiser_fwd(C.byref(dims), fp.param_table(), _lib.ptr(x), _lib.ptr(t),
+                                      _lib.ptr(length), _lib.ptr(xf_proj), _lib.ptr(textctx), _lib.ptr(out),
+                                      _lib.ptr(ws), int(training), _lib.stream_ptr()))
+        if not training:
+            self._pool.give("fwd_i", ws, x.device)
+            return out, None
+        return out, (dims, ws, textctx)
+
+    def _launch_backward(self, x, t, length, xf_out, saved, dout, want_dx=False):
+        dims, ws, textctx = saved
+        L = _lib.lib()
+        fp = self.flat_params()
+        gtable = fp.ensure_grad()
+        B, T, N = dims.B, dims.T, dims.N
+        dev = x.device
+        nb = L.hig_bwd_workspace_bytes(C.byref(dims))
+        bws = self._pool.take("bwd", nb, dev)
+        dx = torch.empty_like(x) if want_dx else None
+        dxp = torch.empty(B, self.time_embed_dim, device=dev, dtype=torch.float32)
+        dxo = torch.empty(B, N, self.text_latent_dim, device=dev, dtype=torch.float32)
+        _lib.check(L.hig_denoiser_bwd(C.byref(dims), fp.param_table(), _lib.ptr(x), _lib.ptr(t),
+                                      _lib.ptr(length), _lib.ptr(xf_out), _lib.ptr(textctx), _lib.ptr(ws),
+                                      _lib.ptr(dout), gtable, _lib.ptr(dx), _lib.ptr(dxp), _lib.ptr(dxo),
+                                      _lib.ptr(bws), _lib.stream_ptr()))
+        self._pool.give("bwd", bws, dev)
+        self._pool.give("fwd_t", ws, dev)
+        self._pool.give("textctx_t", textctx, dev)
+        return dx, dxp, dxo

@@ -1,0 +1,257 @@
+"""MI355X-native `DDPMTrainer`: the reference trainer's public surface
+(codes/trainers/ddpm_trainer.py:29-266) over the HIP denoiser.
+
+Two ways to take a training step:
+  * `forward(batch)` + `update()` -- the reference's own sequence (autograd, torch Adam,
+    clip_grad_norm_), kept so existing driver code runs unchanged;
+  * `train_step_fused(...)` -- the MI355X path: explicit forward/backward launches, masked-MSE,
+    ONE flat-buffer RCCL all-reduce and a fused clip+Adam kernel, hipGraph-capturable.
+"""
+import time
+from collections import OrderedDict
+from os.path import join as pjoin
+
+import torch
+import torch.distributed as dist
+import torch.optim as optim
+from torch.nn.utils import clip_grad_norm_
+
+from .. import _lib
+from ..models.gaussian_diffusion import (GaussianDiffusion, LossType, ModelMeanType, ModelVarType,
+                                         create_named_schedule_sampler, get_named_beta_schedule)
+from ..parallel import FlatGradAllReduce, ShardedSampler
+
+
+def _core(encoder):
+    return getattr(encoder, "module", encoder)
+
+
+class DDPMTrainer(object):
+
+    def __init__(self, args, encoder):
+        self.opt = args
+        self.device = args.device
+        self.encoder = encoder
+        self.multi = False
+        self.diffusion_steps = args.diffusion_steps
+        sampler = 'uniform'
+        beta_scheduler = 'linear'
+        betas = get_named_beta_schedule(beta_scheduler, self.diffusion_steps)
+        self.diffusion = GaussianDiffusion(
+            betas=betas,
+            model_mean_type=ModelMeanType.EPSILON,
+            model_var_type=ModelVarType.FIXED_SMALL,
+            loss_type=LossType.MSE
+        )
+        self.sampler = create_named_schedule_sampler(sampler, self.diffusion)
+        self.sampler_name = sampler
+        if args.is_train:
+            self.mse_criterion = torch.nn.MSELoss(reduction='none')
+        self.to(self.device)
+        self._fused = None
+
+    @staticmethod
+    def zero_grad(opt_list):
+        for opt in opt_list:
+            opt.zero_grad()
+
+    @staticmethod
+    def clip_norm(network_list):
+        for network in network_list:
+            clip_grad_norm_(network.parameters(), 0.5)
+
+    @staticmethod
+    def step(opt_list):
+        for opt in opt_list:
+            opt.step()
+
+    def forward(self, batch_data, eval_mode=False):
+        """ddpm_trainer.py:97-119."""
+        caption, motions, m_lens = batch_data
+        motions = motions.detach().to(self.device).float()
+        self.caption = caption
+        self.motions = motions
+        x_start = motions
+        B, T = x_start.shape[:2]
+        cur_len = torch.LongTensor([min(T, int(m_len)) for m_len in m_lens]).to(self.device)
+        t, _ = self.sampler.sample(B, x_start.device)
+        output = self.diffusion.training_losses(
+            model=self.encoder,
+            x_start=x_start,
+            t=t,
+            model_kwargs={"text": caption, "length": cur_len}
+        )
+        self.real_noise = output['target']
+        self.fake_noise = output['pred']
+        self.src_mask = _core(self.encoder).generate_src_mask(T, cur_len).to(x_start.device)
+
+    def generate_batch(self, caption, m_lens, dim_pose):
+        """ddpm_trainer.py:121-150: text encoded once, then the (graph-captured) sampling loop."""
+        xf_proj, xf_out = _core(self.encoder).encode_text(caption, self.device)
+        B = len(caption)
+        T = min(int(m_lens.max()), _core(self.encoder).num_frames)
+        output = self.diffusion.p_sample_loop(
+            self.encoder,
+            (B, T, dim_pose),
+            clip_denoised=False,
+            progress=True,
+            model_kwargs={
+                'xf_proj': xf_proj,
+                'xf_out': xf_out,
+                'length': m_lens
+            })
+        return output
+
+    def generate(self, caption, m_lens, dim_pose, batch_size=1024):
+        """ddpm_trainer.py:152-170."""
+        N = len(caption)
+        cur_idx = 0
+        self.encoder.eval()
+        all_output = []
+        while cur_idx < N:
+            if cur_idx + batch_size >= N:
+                batch_caption = caption[cur_idx:]
+                batch_m_lens = m_lens[cur_idx:]
+            else:
+                batch_caption = caption[cur_idx: cur_idx + batch_size]
+                batch_m_lens = m_lens[cur_idx: cur_idx + batch_size]
+            output = self.generate_batch(batch_caption, batch_m_lens, dim_pose)
+            B = output.shape[0]
+            for i in range(B):
+                all_output.append(output[i])
+            cur_idx += batch_size
+        return all_output
+
+    def backward_G(self):
+        """ddpm_trainer.py:172-178."""
+        loss_mot_rec = self.mse_criterion(self.fake_noise, self.real_noise).mean(dim=-1)
+        loss_mot_rec = (loss_mot_rec * self.src_mask).sum() / self.src_mask.sum()
+        self.loss_mot_rec = loss_mot_rec
+        loss_logs = OrderedDict({})
+        loss_logs['loss_mot_rec'] = self.loss_mot_rec.item()
+        return loss_logs
+
+    def update(self):
+        """ddpm_trainer.py:180-187."""
+        self.zero_grad([self.opt_encoder])
+        loss_logs = self.backward_G()
+        self.loss_mot_rec.backward()
+        self.clip_norm([self.encoder])
+        self.step([self.opt_encoder])
+        return loss_logs
+
+    def to(self, device):
+        if self.opt.is_train:
+            self.mse_criterion.to(device)
+        self.encoder = self.encoder.to(device)
+
+    def train_mode(self):
+        self.encoder.train()
+
+    def eval_mode(self):
+        self.encoder.eval()
+
+    def save(self, file_name, ep, total_it):
+        """ddpm_trainer.py:200-211: keys opt_encoder / ep / total_it / encoder."""
+        state = {
+            'opt_encoder': self.opt_encoder.state_dict(),
+            'ep': ep,
+            'total_it': total_it,
+            'encoder': _core(self.encoder).state_dict(),
+        }
+        torch.save(state, file_name)
+
+    def load(self, model_dir):
+        checkpoint = torch.load(model_dir, map_location=self.device)
+        if self.opt.is_train:
+            self.opt_encoder.load_state_dict(checkpoint['opt_encoder'])
+        _core(self.encoder).load_state_dict(checkpoint['encoder'], strict=True)
+        return checkpoint['ep'], checkpoint.get('total_it', 0)
+
+    def train(self, train_dataset, rank, world_size):
+        """ddpm_trainer.py:220-266 (epoch loop, logging, checkpoint cadence)."""
+        self.to(self.device)
+        self.opt_encoder = optim.Adam(self.encoder.parameters(), lr=self.opt.lr)
+        it = 0
+        cur_epoch = 0
+        if self.opt.is_continue:
+            model_dir = pjoin(self.opt.model_dir, 'latest.tar')
+            cur_epoch, it = self.load(model_dir)
+        start_time = time.time()
+        sampler = ShardedSampler(len(train_dataset), rank, world_size, shuffle=True)
+        train_loader = torch.utils.data.DataLoader(
+            train_dataset, batch_size=self.opt.batch_size, sampler=sampler, drop_last=True,
+            num_workers=getattr(self.opt, "num_workers", 4), shuffle=False)
+        logs = OrderedDict()
+        for epoch in range(cur_epoch, self.opt.num_epochs):
+            self.train_mode()
+            for i, batch_data in enumerate(train_loader):
+                self.forward(batch_data)
+                log_dict = self.update()
+                for k, v in log_dict.items():
+                    logs[k] = logs.get(k, 0) + v
+                it += 1
+                if it % self.opt.log_every == 0 and rank == 0:
+                    mean_loss = OrderedDict({tag: value / self.opt.log_every for tag, value in logs.items()})
+                    logs = OrderedDict()
+                    msg = ' '.join('%s: %.4f' % kv for kv in mean_loss.items())
+                    print('epoch: %3d niter: %6d inner_iter: %4d %.0fs %s'
+                          % (epoch, it, i, time.time() - start_time, msg))
+                if it % self.opt.save_latest == 0 and rank == 0:
+                    self.save(pjoin(self.opt.model_dir, 'latest.tar'), epoch, it)
+            if rank == 0:
+                self.save(pjoin(self.opt.model_dir, 'latest.tar'), epoch, it)
+            if epoch % self.opt.save_every_e == 0 and rank == 0:
+                self.save(pjoin(self.opt.model_dir, 'ckpt_e%03d.tar' % (epoch)), epoch, total_it=it)
+
+    # ------------------------------------------------------------------------------------------
+    # MI355X fused step
+    # ------------------------------------------------------------------------------------------
+    def fused_state(self):
+        """Flat Adam moments, loss / norm scalars and scratch for the fused step (lazy)."""
+        if self._fused is None:
+            core = _core(self.encoder)
+            fp = core.flat_params()
+            fp.ensure_grad()
+            dev = fp.flat.device
+            self._fused = {
+                "m": torch.zeros_like(fp.flat), "v": torch.zeros_like(fp.flat),
+                "scratch": torch.zeros(_lib.NORM_BLOCKS, device=dev, dtype=torch.float32),
+                "mse_scratch": torch.zeros(_lib.NORM_BLOCKS, device=dev, dtype=torch.float32),
+                "loss": torch.zeros(1, device=dev, dtype=torch.float32),
+                "gnorm": torch.zeros(1, device=dev, dtype=torch.float32),
+                "step": torch.zeros(1, device=dev, dtype=torch.int32),
+                "allreduce": FlatGradAllReduce(),
+            }
+        return self._fused
+
+    def train_step_fused(self, x_start, t, length, xf_proj, xf_out, noise=None, lr=None):
+        """One DDPM training step on device tensors, reference semantics
+        (ddpm_trainer.py:97-119,172-187) for the denoiser-core parameters:
+          x_t = q_sample(x0, t, noise); pred = denoiser(x_t, t); loss = masked MSE(pred, noise);
+          backward; grads = all_reduce(grads) / world; clip_grad_norm_(0.5); Adam.
+        No host synchronisation: the loss stays on the device (`fused_state()['loss']`)."""
+        core = _core(self.encoder)
+        L = _lib.lib()
+        st = self.fused_state()
+        fp = core.flat_params()
+        B, T, F = x_start.shape
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        x_t = self.diffusion.q_sample(x_start, t, noise=noise)
+        pred, saved = core._launch_forward(x_t, t, length, xf_proj, xf_out, training=True)
+        dpred = torch.empty_like(pred)
+        _lib.check(L.hig_masked_mse(_lib.ptr(pred), _lib.ptr(noise), _lib.ptr(length), B, T, F,
+                                    _lib.ptr(st["loss"]), _lib.ptr(dpred), _lib.ptr(st["mse_scratch"]),
+                                    _lib.stream_ptr()))
+        core._launch_backward(x_t, t, length, xf_out, saved, dpred, want_dx=False)
+        world = st["allreduce"](fp.grad)                       # sum over ranks (RCCL, xGMI)
+        n = fp.numel
+        _lib.check(L.hig_sumsq_partial(_lib.ptr(fp.grad), n, 1.0 / world, _lib.ptr(st["scratch"]),
+                                       _lib.stream_ptr()))
+        _lib.check(L.hig_clip_adam(_lib.ptr(fp.flat), _lib.ptr(fp.grad), _lib.ptr(st["m"]), _lib.ptr(st["v"]),
+                                   n, float(lr if lr is not None else self.opt.lr), 0.9, 0.999, 1e-8, 0.5,
+                                   1.0 / world, _lib.ptr(st["scratch"]), _lib.ptr(st["gnorm"]),
+                                   _lib.ptr(st["step"]), _lib.stream_ptr()))
+        core._textctx_cache = None  # parameters changed under the cached text context
+        return st["loss"]

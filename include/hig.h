@@ -1,0 +1,262 @@
+/*
+ * hig.h -- C ABI of the MI355X-native motion-diffusion denoiser hot path (libhig.so).
+ *
+ * The reference (line/Human-Interaction-Generation) has no FFI layer: the boundary it exposes
+ * is the Python object API (MotionTransformer / GaussianDiffusion / DDPMTrainer).  This ABI is
+ * what sits UNDER our mirror of that API; every entry point cites the reference code whose
+ * arithmetic it replaces.  Conventions:
+ *   - extern "C", plain pointers and sizes; returns 0 (HIG_OK) or a negative HIG_E* code;
+ *     never throws, never exits; hig_last_error() holds the message of the last failure
+ *     on the calling thread.
+ *   - The caller owns every buffer.  The library allocates no device memory, frees nothing,
+ *     keeps no reference past return.  All device pointers must be valid on the current HIP
+ *     device (hipSetDevice is the caller's job).
+ *   - Every launch goes on the `stream` argument (a hipStream_t passed as void*).  No
+ *     synchronisation, allocation, blocking copy or host read-back happens inside, so any
+ *     call sequence can be captured into a hipGraph.
+ *   - Matrices are row-major fp32 unless stated; nn.Linear weights are (out, in).
+ */
+#ifndef HIG_H
+#define HIG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIG_OK 0
+#define HIG_EINVAL (-1)
+#define HIG_EHIP (-2)
+#define HIG_EUNSUPPORTED (-3)
+
+#define HIG_ATTN_LINEAR 0 /* LinearTemporal*Attention, transformer.py:89-155 (default) */
+#define HIG_ATTN_FULL 1   /* Temporal*Attention (no_eff=True), transformer.py:196-262 */
+
+/* GEMM compute modes */
+#define HIG_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate */
+#define HIG_PREC_BF16X3 1 /* split-bf16 (hi*hi + hi*lo + lo*hi) on v_mfma_f32_32x32x16_bf16 */
+#define HIG_PREC_BF16 2   /* single bf16 product, fp32 accumulate */
+
+typedef void* hig_stream_t; /* hipStream_t */
+
+int hig_version(void);
+/* Copies the calling thread's last error message (NUL terminated) into buf; returns its length. */
+int hig_last_error(char* buf, int n);
+
+/* ------------------------------------------------------------------------------------------
+ * Problem description.  Mirrors the constructor arguments of MotionTransformer
+ * (transformer.py:289-304) plus the call-time batch shape.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hig_dims {
+  int32_t B;          /* samples in the batch */
+  int32_t T;          /* motion frames per sample (<= num_frames) */
+  int32_t F;          /* input_feats */
+  int32_t d;          /* latent_dim */
+  int32_t H;          /* num_heads (d % H == 0, head dim multiple of 4, <= 128) */
+  int32_t ff;         /* ff_size */
+  int32_t L;          /* num_layers */
+  int32_t N;          /* text tokens (77) */
+  int32_t Lt;         /* text_latent_dim */
+  int32_t num_frames; /* rows of sequence_embedding */
+  int32_t attn_kind;  /* HIG_ATTN_* */
+  int32_t prec;       /* HIG_PREC_* */
+} hig_dims;
+
+/* Parameter table: an array of device pointers, HIG_NGLOBAL global entries followed by
+ * HIG_NLAYER entries per decoder layer, in the order below.  The same table layout is used
+ * for gradients.  Three groups must be CONTIGUOUS in memory so one GEMM covers them:
+ *   SA_QKV_W = [query.weight; key.weight; value.weight]  (3d, d)   SA_QKV_B (3d)
+ *   CA_KV_W  = [key.weight; value.weight]                (2d, Lt)  CA_KV_B  (2d)
+ *   STY_EMB_W= the 3L `emb_layers.1.weight` matrices stacked in (layer, sa|ca|ffn) order
+ *              (3L*2d, E); STY_EMB_B likewise (3L*2d).
+ * Names are the reference's state-dict keys. */
+enum {
+  HIG_P_SEQ_EMB = 0, /* sequence_embedding (num_frames, d) */
+  HIG_P_JOINT_W,     /* joint_embed.weight (d, F) */
+  HIG_P_JOINT_B,
+  HIG_P_TE0_W, /* time_embed.0 (E, d) */
+  HIG_P_TE0_B,
+  HIG_P_TE2_W, /* time_embed.2 (E, E) */
+  HIG_P_TE2_B,
+  HIG_P_STY_EMB_W,
+  HIG_P_STY_EMB_B,
+  HIG_P_OUT_W, /* out.weight (F, d) */
+  HIG_P_OUT_B,
+  HIG_NGLOBAL
+};
+enum {
+  HIG_L_SA_NORM_W = 0,
+  HIG_L_SA_NORM_B,
+  HIG_L_SA_QKV_W,
+  HIG_L_SA_QKV_B,
+  HIG_L_SA_STY_NORM_W,
+  HIG_L_SA_STY_NORM_B,
+  HIG_L_SA_STY_OUT_W, /* proj_out.out_layers.2 (d, d) */
+  HIG_L_SA_STY_OUT_B,
+  HIG_L_CA_NORM_W,
+  HIG_L_CA_NORM_B,
+  HIG_L_CA_TNORM_W, /* ca_block.text_norm (Lt) */
+  HIG_L_CA_TNORM_B,
+  HIG_L_CA_Q_W,
+  HIG_L_CA_Q_B,
+  HIG_L_CA_KV_W,
+  HIG_L_CA_KV_B,
+  HIG_L_CA_STY_NORM_W,
+  HIG_L_CA_STY_NORM_B,
+  HIG_L_CA_STY_OUT_W,
+  HIG_L_CA_STY_OUT_B,
+  HIG_L_FFN_W1, /* ffn.linear1 (ff, d) */
+  HIG_L_FFN_B1,
+  HIG_L_FFN_W2, /* ffn.linear2 (d, ff) */
+  HIG_L_FFN_B2,
+  HIG_L_FFN_STY_NORM_W,
+  HIG_L_FFN_STY_NORM_B,
+  HIG_L_FFN_STY_OUT_W,
+  HIG_L_FFN_STY_OUT_B,
+  HIG_NLAYER
+};
+
+/* Bytes of scratch the forward needs.  training != 0 keeps every layer's activations for
+ * hig_denoiser_bwd; training == 0 reuses one layer's buffers for all layers. */
+int64_t hig_workspace_bytes(const hig_dims* dims, int training);
+/* Bytes for the step-invariant cross-attention text context (all L layers). */
+int64_t hig_textctx_bytes(const hig_dims* dims, int training);
+
+/* Cross-attention text side for all L layers: text_norm, key/value projections, softmax over
+ * the N text tokens, A = k^T v (transformer.py:146-152).  Step-invariant during sampling, so
+ * p_sample_loop calls it once and passes `textctx` to every hig_denoiser_fwd. */
+int hig_text_context(const hig_dims* dims, const void* const* params, const float* xf_out,
+                     void* textctx, int training, hig_stream_t stream);
+
+/* MotionTransformer.forward with text embeddings supplied (transformer.py:407-426):
+ * x (B,T,F), t (B) int64, length (B) int64 or NULL (= all T), xf_proj (B,4d), out (B,T,F). */
+int hig_denoiser_fwd(const hig_dims* dims, const void* const* params, const float* x,
+                     const int64_t* t, const int64_t* length, const float* xf_proj,
+                     const void* textctx, float* out, void* workspace, int training,
+                     hig_stream_t stream);
+
+/* Backward of hig_denoiser_fwd(training=1) for d(out) = dout.  Writes (does not accumulate)
+ * every entry of `grads` (same table layout as params; NULL entries are skipped is NOT
+ * supported -- all must be valid), dx (B,T,F) or NULL, dxf_proj (B,4d), dxf_out (B,N,Lt). */
+int hig_denoiser_bwd(const hig_dims* dims, const void* const* params, const float* x,
+                     const int64_t* t, const int64_t* length, const float* xf_out,
+                     const void* textctx, const void* workspace, const float* dout,
+                     void* const* grads, float* dx, float* dxf_proj, float* dxf_out,
+                     void* bwd_workspace, hig_stream_t stream);
+int64_t hig_bwd_workspace_bytes(const hig_dims* dims);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel entry points (unit-testable pieces of the above).
+ * ---------------------------------------------------------------------------------------- */
+
+/* Generic fused GEMM  C[i][j] = epi( sum_r xf(X)[i][r] * Y[j][r] ).
+ * x_rs / y_rs: 0 = operand stored reduce-contiguous (X[i*ldx + r]); 1 = reduce-slow
+ * (X[r*ldx + i]).  xf_* select the prologue applied to the ACTIVATION operand (X when
+ * xf_on_y == 0, Y otherwise) -- the fused LayerNorm / stylization modulation / SiLU of
+ * StylizationBlock.forward (transformer.py:81-85) and the pre-attention norms. */
+#define HIG_XF_NONE 0
+#define HIG_XF_LN 1          /* (x-mean)*rstd*gamma+beta */
+#define HIG_XF_LN_MOD_SILU 2 /* silu(LN(x)*(1+scale)+shift), scale/shift per sample */
+#define HIG_XF_SILU 3
+#define HIG_EPI_NONE 0
+#define HIG_EPI_BIAS 1
+#define HIG_EPI_BIAS_GELU 2 /* out = gelu(acc+bias); aux (if set) receives acc+bias */
+#define HIG_EPI_BIAS_RES 3  /* out = res + acc + bias */
+#define HIG_EPI_BIAS_POS 4  /* out = acc + bias + pos[i % T] (joint_embed + sequence_embedding) */
+#define HIG_EPI_RES 5       /* out = res + acc */
+#define HIG_EPI_DGELU 6     /* out = acc * gelu'(aux) */
+typedef struct hig_gemm_desc {
+  const float* X; int64_t ldx; int32_t x_rs;
+  const float* Y; int64_t ldy; int32_t y_rs;
+  float* C; int64_t ldc;
+  int32_t I, J, R;
+  int32_t xf, xf_on_y, epi, prec;
+  const float* bias;                 /* [J] */
+  const float* res; int64_t ldr;     /* [I][J] */
+  float* aux; int64_t ldaux;         /* [I][J] */
+  const float* stats;                /* [rows][2] mean, rstd of the activation rows */
+  const float* gamma; const float* beta; /* [features] */
+  const float* ss; int64_t ss_ld; int32_t ss_shift_off; int32_t rows_per_sample;
+  const float* pos; int64_t ldpos; int32_t T;
+} hig_gemm_desc;
+int hig_gemm(const hig_gemm_desc* g, hig_stream_t stream);
+
+/* Row statistics for LayerNorm: stats[m] = (mean, rstd) of x[m, :n], eps = 1e-5, biased var. */
+int hig_rowstats(const float* x, int64_t ldx, int64_t rows, int32_t n, float* stats,
+                 hig_stream_t stream);
+
+/* Linear ("efficient") attention pieces, transformer.py:110-117 / 146-153.  Channel c of
+ * head h lives at column h*hd + c.
+ * ctx: k = softmax over the `len[b]` leading rows of each sample (masked rows contribute 0),
+ *      A[b,h] = k^T v; kstat[b][col] = (column max, column sum of exp).
+ * apply: y = softmax_hd(Q) . A[b,h]. */
+int hig_linattn_ctx(const float* K, const float* V, int64_t ld, int32_t B, int32_t rows,
+                    int32_t H, int32_t hd, const int64_t* length, float* A, float* kstat,
+                    hig_stream_t stream);
+int hig_linattn_apply(const float* Q, int64_t ldq, const float* A, float* Y, int64_t ldy,
+                      int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
+int hig_linattn_apply_bwd(const float* dY, int64_t lddy, const float* Q, int64_t ldq,
+                          const float* A, float* dQ, int64_t lddq, float* dA, int32_t B,
+                          int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
+int hig_linattn_ctx_bwd(const float* dA, const float* K, const float* V, int64_t ld,
+                        const float* kstat, const int64_t* length, float* dK, float* dV,
+                        int64_t ldd, int32_t B, int32_t rows, int32_t H, int32_t hd,
+                        hig_stream_t stream);
+
+/* Backward of y = [silu](LN(x)*(1+scale)+shift) w.r.t. x for upstream gradient da, plus the
+ * reductions for gamma/beta (over all rows) and scale/shift (per sample):
+ *   dx = (res ? res : 0) + LNbwd(...).  partial: [rows/rows_per_sample * splits][4][n]. */
+int hig_ln_bwd(const float* da, int64_t ldda, const float* x, int64_t ldx, const float* stats,
+               const float* gamma, const float* beta, const float* ss, int64_t ss_ld,
+               int32_t ss_shift_off, int32_t mod_silu, const float* res, int64_t ldr,
+               float* dx, int64_t lddx, int64_t rows, int32_t n, int32_t rows_per_sample,
+               float* dgamma, float* dbeta, float* dss, int64_t dss_ld, float* partial,
+               hig_stream_t stream);
+int64_t hig_ln_bwd_partial_floats(int64_t rows, int32_t n, int32_t rows_per_sample);
+
+/* out[j] = sum_i x[i][j]  (bias gradients).  partial: [HIG_COLSUM_CHUNKS][n] floats. */
+#define HIG_COLSUM_CHUNKS 64
+int hig_colsum(const float* x, int64_t ldx, int64_t rows, int32_t n, float* out, float* partial,
+               hig_stream_t stream);
+
+/* timestep_embedding (transformer.py:15-32): out[b] = [cos(t*f), sin(t*f)], fp32. */
+int hig_timestep_embedding(const int64_t* t, int32_t B, int32_t d, float* out, hig_stream_t s);
+
+/* ------------------------------------------------------------------------------------------
+ * DDPM arithmetic (gaussian_diffusion.py).  `tab` is a device table of 6 x nsteps fp32 rows:
+ * sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod, sqrt_recip_alphas_cumprod,
+ * sqrt_recipm1_alphas_cumprod, posterior_mean_coef1, posterior_mean_coef2, followed by
+ * posterior_log_variance_clipped (7 rows), each float64-computed then cast like
+ * _extract_into_tensor(...).float() (gaussian_diffusion.py:1137-1150).
+ * ---------------------------------------------------------------------------------------- */
+#define HIG_TAB_ROWS 7
+/* q_sample, gaussian_diffusion.py:399-417: xt = sqrt_ac[t]*x0 + sqrt_1m_ac[t]*noise */
+int hig_q_sample(const float* x0, const float* noise, const int64_t* t, const float* tab,
+                 int32_t nsteps, int32_t B, int64_t per_sample, float* xt, hig_stream_t s);
+/* p_sample (EPSILON / FIXED_SMALL, clip_denoised=False), gaussian_diffusion.py:443-544,606-666:
+ * x_prev = coef1*x0hat + coef2*x + [t!=0]*exp(0.5*logvar)*z;  may run in place (x_prev == x). */
+int hig_p_sample_step(const float* x, const float* eps, const float* z, const int64_t* t,
+                      const float* tab, int32_t nsteps, int32_t B, int64_t per_sample,
+                      float* x_prev, float* pred_xstart /* nullable */, hig_stream_t s);
+/* t[b] -= 1 on the device (the sampling loop's step counter, graph-replayable). */
+int hig_dec_timesteps(int64_t* t, int32_t B, hig_stream_t s);
+/* DDPMTrainer.backward_G (ddpm_trainer.py:172-178): loss = sum_bt mask*mean_f (p-t)^2 / sum mask
+ * with mask[b][t] = t < length[b];  dpred = d loss / d pred.  scratch: 2*B floats + loss. */
+int hig_masked_mse(const float* pred, const float* target, const int64_t* length, int32_t B,
+                   int32_t T, int32_t F, float* loss /* device scalar */, float* dpred,
+                   float* scratch, hig_stream_t s);
+/* clip_grad_norm_(0.5) + Adam (ddpm_trainer.py:184-185,222) on a flat fp32 buffer:
+ * g *= inv_world (DDP mean); gnorm = ||g||; g *= min(1, max_norm/(gnorm+1e-6)); Adam step.
+ * `state`: device {float gnorm_out; int32 step} ; scratch: HIG_NORM_BLOCKS floats. */
+#define HIG_NORM_BLOCKS 1024
+int hig_sumsq_partial(const float* g, int64_t n, float inv_world, float* scratch, hig_stream_t s);
+int hig_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                  float b2, float eps, float max_norm, float inv_world, const float* scratch,
+                  float* gnorm_out, int32_t* step_dev, hig_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIG_H */

@@ -1,0 +1,338 @@
+"""Per-kernel parity: every C-ABI entry point of libhig.so against a plain PyTorch fp32/fp64 CPU
+statement of the same op (for floating point the tolerance is written at each assert).
+All tests need the MI355X: run through `gpurun -- python -m pytest tests -m gpu`."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import hig_amd  # noqa: E402
+from hig_amd import _lib  # noqa: E402
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+_KEEP = []  # device tensors created inline must outlive the launch that reads them
+
+
+def P(t):
+    if t is None:
+        return None
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        del _KEEP[:128]
+    return t.data_ptr()
+
+
+def gemm(X, Y, I, J, R, x_rs=0, y_rs=0, xf=0, xf_on_y=0, epi=0, bias=None, res=None, aux=None,
+         stats=None, gamma=None, beta=None, ss=None, ss_shift_off=0, rows_per_sample=0, pos=None, T=0):
+    out = torch.full((I, J), float("nan"), device=DEV)
+    d = _lib.GemmDesc()
+    d.X, d.ldx, d.x_rs = P(X), X.stride(0), x_rs
+    d.Y, d.ldy, d.y_rs = P(Y), Y.stride(0), y_rs
+    d.C, d.ldc = P(out), J
+    d.I, d.J, d.R = I, J, R
+    d.xf, d.xf_on_y, d.epi, d.prec = xf, xf_on_y, epi, _lib.PREC_F32
+    d.bias = P(bias)
+    if res is not None:
+        d.res, d.ldr = P(res), res.stride(0)
+    if aux is not None:
+        d.aux, d.ldaux = P(aux), aux.stride(0)
+    d.stats, d.gamma, d.beta = P(stats), P(gamma), P(beta)
+    if ss is not None:
+        d.ss, d.ss_ld, d.ss_shift_off, d.rows_per_sample = P(ss), ss.stride(0), ss_shift_off, rows_per_sample
+    if pos is not None:
+        d.pos, d.ldpos, d.T = P(pos), pos.stride(0), T
+    _lib.check(_lib.lib().hig_gemm(C.byref(d), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return out
+
+
+def stats_of(x):
+    m = x.mean(-1)
+    v = x.var(-1, unbiased=False)
+    return torch.stack([m, torch.rsqrt(v + 1e-5)], -1).contiguous()
+
+
+@pytest.mark.parametrize("I,J,R", [(128, 128, 32), (130, 150, 150), (64, 64, 512), (300, 1536, 512), (2, 2048, 64)])
+def test_gemm_forward_bias(I, J, R):
+    X, Y, b = rnd(I, R), rnd(J, R, seed=1), rnd(J, seed=2)
+    out = gemm(X.to(DEV), Y.to(DEV), I, J, R, epi=_lib.EPI_BIAS, bias=b.to(DEV))
+    ref = X.double() @ Y.double().T + b.double()
+    assert rel(out, ref) < 2e-6  # fp32 MFMA, fp32 accumulate
+
+
+def test_gemm_exact_small_integers():
+    # integer-valued operands: the fp32 MFMA path must be EXACT (catches layout / k-order bugs)
+    I, J, R = 192, 160, 96
+    g = torch.Generator().manual_seed(3)
+    X = torch.randint(-4, 5, (I, R), generator=g).float()
+    Y = torch.randint(-4, 5, (J, R), generator=g).float()  # asymmetric
+    out = gemm(X.to(DEV), Y.to(DEV), I, J, R)
+    assert torch.equal(out.cpu(), X @ Y.T)
+
+
+def test_gemm_ln_prologue_and_gelu_epilogue():
+    I, J, R = 200, 96, 128
+    X, Y, b = rnd(I, R, scale=2.0) + 0.5, rnd(J, R, seed=1, scale=0.1), rnd(J, seed=2)
+    g, be = 1 + 0.1 * rnd(R, seed=3), 0.1 * rnd(R, seed=4)
+    out = gemm(X.to(DEV), Y.to(DEV), I, J, R, xf=_lib.XF_LN, epi=_lib.EPI_BIAS, bias=b.to(DEV),
+               stats=stats_of(X).to(DEV), gamma=g.to(DEV), beta=be.to(DEV))
+    ref = F.linear(F.layer_norm(X.double(), (R,), g.double(), be.double()), Y.double(), b.double())
+    assert rel(out, ref) < 5e-6
+    aux = torch.zeros(I, J, device=DEV)
+    out = gemm(X.to(DEV), Y.to(DEV), I, J, R, epi=_lib.EPI_BIAS_GELU, bias=b.to(DEV), aux=aux)
+    z = F.linear(X.double(), Y.double(), b.double())
+    assert rel(aux, z) < 2e-6 and rel(out, F.gelu(z)) < 5e-6
+
+
+def test_gemm_stylization_prologue_residual():
+    B, T, d, J = 3, 50, 64, 64
+    I, R = B * T, d
+    X, Y, b = rnd(I, R), rnd(J, R, seed=1, scale=0.2), rnd(J, seed=2)
+    g, be = 1 + 0.1 * rnd(R, seed=3), 0.1 * rnd(R, seed=4)
+    ss = rnd(B, 6 * d, seed=5, scale=0.5)   # block 1 of 3: scale at [2d,3d), shift at [3d,4d)
+    res = rnd(I, J, seed=6)
+    out = gemm(X.to(DEV), Y.to(DEV), I, J, R, xf=_lib.XF_LN_MOD_SILU, epi=_lib.EPI_BIAS_RES,
+               bias=b.to(DEV), res=res.to(DEV), stats=stats_of(X).to(DEV), gamma=g.to(DEV),
+               beta=be.to(DEV), ss=ss.to(DEV)[:, 2 * d:], ss_shift_off=d, rows_per_sample=T)
+    n = F.layer_norm(X.double(), (R,), g.double(), be.double()).view(B, T, d)
+    u = n * (1 + ss.double()[:, None, 2 * d:3 * d]) + ss.double()[:, None, 3 * d:4 * d]
+    ref = res.double() + F.linear(F.silu(u).view(I, d), Y.double(), b.double())
+    assert rel(out, ref) < 5e-6
+
+
+def test_gemm_silu_prologue_and_pos_epilogue():
+    I, J, R, T = 96, 80, 64, 32
+    X, Y, b = rnd(I, R), rnd(J, R, seed=1), rnd(J, seed=2)
+    out = gemm(X.to(DEV), Y.to(DEV), I, J, R, xf=_lib.XF_SILU, epi=_lib.EPI_BIAS, bias=b.to(DEV))
+    assert rel(out, F.linear(F.silu(X.double()), Y.double(), b.double())) < 5e-6
+    pos = rnd(40, J, seed=7)
+    out = gemm(X.to(DEV), Y.to(DEV), I, J, R, epi=_lib.EPI_BIAS_POS, bias=b.to(DEV), pos=pos.to(DEV), T=T)
+    ref = F.linear(X.double(), Y.double(), b.double()) + pos.double()[:T].repeat(I // T, 1)
+    assert rel(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("I,J,R", [(200, 150, 64), (128, 128, 1536), (70, 512, 150)])
+def test_gemm_dgrad(I, J, R):
+    dC, W = rnd(I, R), rnd(R, J, seed=1)          # W is (out=R, in=J): dA = dC @ W
+    out = gemm(dC.to(DEV), W.to(DEV), I, J, R, y_rs=1)
+    assert rel(out, dC.double() @ W.double()) < 2e-6
+    res = rnd(I, J, seed=2)
+    out = gemm(dC.to(DEV), W.to(DEV), I, J, R, y_rs=1, epi=_lib.EPI_RES, res=res.to(DEV))
+    assert rel(out, res.double() + dC.double() @ W.double()) < 2e-6
+    z = rnd(I, J, seed=3)
+    zd = z.double().requires_grad_(True)
+    F.gelu(zd).backward(dC.double() @ W.double())
+    out = gemm(dC.to(DEV), W.to(DEV), I, J, R, y_rs=1, epi=_lib.EPI_DGELU, aux=z.to(DEV))
+    assert rel(out, zd.grad) < 5e-6
+
+
+def test_gemm_wgrad_with_fused_activation_recompute():
+    B, T, d, n_out = 2, 70, 64, 96
+    M = B * T
+    dC, y = rnd(M, n_out), rnd(M, d, seed=1)
+    out = gemm(dC.to(DEV), y.to(DEV), n_out, d, M, x_rs=1, y_rs=1)
+    assert rel(out, dC.double().T @ y.double()) < 2e-6
+    g, be = 1 + 0.1 * rnd(d, seed=3), 0.1 * rnd(d, seed=4)
+    ss = rnd(B, 2 * d, seed=5, scale=0.5)
+    n = F.layer_norm(y.double(), (d,), g.double(), be.double())
+    out = gemm(dC.to(DEV), y.to(DEV), n_out, d, M, x_rs=1, y_rs=1, xf=_lib.XF_LN, xf_on_y=1,
+               stats=stats_of(y).to(DEV), gamma=g.to(DEV), beta=be.to(DEV))
+    assert rel(out, dC.double().T @ n) < 5e-6
+    a = F.silu(n.view(B, T, d) * (1 + ss.double()[:, None, :d]) + ss.double()[:, None, d:]).view(M, d)
+    out = gemm(dC.to(DEV), y.to(DEV), n_out, d, M, x_rs=1, y_rs=1, xf=_lib.XF_LN_MOD_SILU, xf_on_y=1,
+               stats=stats_of(y).to(DEV), gamma=g.to(DEV), beta=be.to(DEV), ss=ss.to(DEV),
+               ss_shift_off=d, rows_per_sample=T)
+    assert rel(out, dC.double().T @ a) < 5e-6
+    out = gemm(dC.to(DEV), y.to(DEV), n_out, d, M, x_rs=1, y_rs=1, xf=_lib.XF_SILU, xf_on_y=1)
+    assert rel(out, dC.double().T @ F.silu(y.double())) < 5e-6
+
+
+@pytest.mark.parametrize("rows,n", [(7, 64), (1000, 512), (33, 1024), (5, 150), (77 * 2, 256)])
+def test_rowstats(rows, n):
+    x = rnd(rows, n, scale=3.0) + 1.5
+    st = torch.zeros(rows, 2, device=DEV)
+    _lib.check(_lib.lib().hig_rowstats(P(x.to(DEV)), n, rows, n, P(st), _lib.stream_ptr()))
+    assert rel(st, stats_of(x.double())) < 1e-6
+
+
+@pytest.mark.parametrize("mod", [0, 1])
+@pytest.mark.parametrize("B,T,n", [(2, 16, 64), (3, 50, 512), (2, 77, 256), (2, 9, 1024)])
+def test_ln_bwd(mod, B, T, n):
+    M = B * T
+    x = rnd(M, n, scale=2.0) + 0.3
+    da, g, be = rnd(M, n, seed=1), 1 + 0.1 * rnd(n, seed=2), 0.1 * rnd(n, seed=3)
+    ss = rnd(B, 2 * n, seed=4, scale=0.5)
+    res = rnd(M, n, seed=5)
+    xd, gd, bd, ssd = (v.double().requires_grad_(True) for v in (x, g, be, ss))
+    nrm = F.layer_norm(xd, (n,), gd, bd)
+    if mod:
+        a = F.silu(nrm.view(B, T, n) * (1 + ssd[:, None, :n]) + ssd[:, None, n:]).view(M, n)
+    else:
+        a = nrm
+    a.backward(da.double())
+    L = _lib.lib()
+    npart = L.hig_ln_bwd_partial_floats(M, n, T)
+    part = torch.zeros(npart, device=DEV)
+    dx, dg, db = torch.zeros(M, n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    dss = torch.zeros(B, 2 * n, device=DEV)
+    xg, ssg, resg = x.to(DEV), ss.to(DEV), res.to(DEV)
+    _lib.check(L.hig_ln_bwd(P(da.to(DEV)), n, P(xg), n, P(stats_of(x).to(DEV)), P(g.to(DEV)), P(be.to(DEV)),
+                            P(ssg) if mod else None, 2 * n, n, mod, P(resg), n, P(dx), n, M, n, T, P(dg), P(db),
+                            P(dss) if mod else None, 2 * n, P(part), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert rel(dx, res.double() + xd.grad) < 1e-5
+    assert rel(dg, gd.grad) < 1e-5 and rel(db, bd.grad) < 1e-5
+    if mod:
+        assert rel(dss, ssd.grad) < 1e-5
+
+
+@pytest.mark.parametrize("rows,n", [(1000, 512), (64, 24576 // 8), (77, 150), (3, 5)])
+def test_colsum(rows, n):
+    x = rnd(rows, n)
+    out = torch.zeros(n, device=DEV)
+    part = torch.zeros(_lib.COLSUM_CHUNKS * n, device=DEV)
+    _lib.check(_lib.lib().hig_colsum(P(x.to(DEV)), n, rows, n, P(out), P(part), _lib.stream_ptr()))
+    assert rel(out, x.double().sum(0)) < 1e-6
+
+
+def _linattn_ref(Q, K, V, lengths, H):
+    B, T, D = Q.shape
+    mask = (torch.arange(T)[None] < lengths[:, None]).double().unsqueeze(-1)
+    q = F.softmax(Q.view(B, T, H, -1), dim=-1)
+    k = F.softmax((K + (1 - mask) * -1000000).view(B, T, H, -1), dim=1)
+    v = (V * mask).view(B, T, H, -1)
+    A = torch.einsum("bnhd,bnhl->bhdl", k, v)
+    y = torch.einsum("bnhd,bhdl->bnhl", q, A).reshape(B, T, D)
+    return y, A
+
+
+@pytest.mark.parametrize("B,T,H,hd,lens", [(2, 16, 8, 8, (16, 9)), (2, 60, 8, 16, (60, 41)),
+                                           (3, 196, 8, 64, (196, 77, 1)), (2, 300, 2, 128, (300, 123)),
+                                           (2, 70, 4, 32, (70, 64))])
+def test_linear_attention_forward_backward(B, T, H, hd, lens):
+    d = H * hd
+    qkv = rnd(B * T, 3 * d, scale=1.5)
+    dy = rnd(B * T, d, seed=1)
+    lengths = torch.tensor(lens)
+    qd = qkv.double().view(B, T, 3 * d).requires_grad_(True)
+    y_ref, A_ref = _linattn_ref(qd[..., :d], qd[..., d:2 * d], qd[..., 2 * d:], lengths, H)
+    y_ref.backward(dy.double().view(B, T, d))
+    L = _lib.lib()
+    g = qkv.to(DEV)
+    A = torch.zeros(B, H, hd, hd, device=DEV)
+    kst = torch.zeros(B, d, 2, device=DEV)
+    y = torch.zeros(B * T, d, device=DEV)
+    lg = lengths.to(DEV)
+    s = _lib.stream_ptr()
+    _lib.check(L.hig_linattn_ctx(g.data_ptr() + 4 * d, g.data_ptr() + 8 * d, 3 * d, B, T, H, hd, P(lg), P(A), P(kst), s))
+    _lib.check(L.hig_linattn_apply(P(g), 3 * d, P(A), P(y), d, B, T, H, hd, s))
+    torch.cuda.synchronize()
+    assert rel(A, A_ref) < 5e-6      # fp32 exp/sum vs fp64
+    assert rel(y, y_ref.reshape(B * T, d)) < 5e-6
+    dqkv = torch.full((B * T, 3 * d), float("nan"), device=DEV)
+    dA = torch.zeros(B, H, hd, hd, device=DEV)
+    _lib.check(L.hig_linattn_apply_bwd(P(dy.to(DEV)), d, P(g), 3 * d, P(A), P(dqkv), 3 * d, P(dA), B, T, H, hd, s))
+    _lib.check(L.hig_linattn_ctx_bwd(P(dA), g.data_ptr() + 4 * d, g.data_ptr() + 8 * d, 3 * d, P(kst), P(lg),
+                                     dqkv.data_ptr() + 4 * d, dqkv.data_ptr() + 8 * d, 3 * d, B, T, H, hd, s))
+    torch.cuda.synchronize()
+    ref = qd.grad.view(B * T, 3 * d)
+    assert rel(dqkv[:, :d], ref[:, :d]) < 2e-5
+    assert rel(dqkv[:, 2 * d:], ref[:, 2 * d:]) < 2e-5
+    # dK is a difference of near-equal terms (column softmax): absolute floor relative to dV scale
+    err = (dqkv[:, d:2 * d].double().cpu() - ref[:, d:2 * d]).norm()
+    assert err < 2e-5 * ref[:, 2 * d:].norm() + 2e-5 * ref[:, d:2 * d].norm()
+
+
+def test_timestep_embedding_matches_reference_formula():
+    from oracle import denoiser_ref as R
+    t = torch.tensor([0, 1, 7, 500, 999])
+    for d in (64, 128, 512):
+        out = torch.zeros(len(t), d, device=DEV)
+        _lib.check(_lib.lib().hig_timestep_embedding(P(t.to(DEV)), len(t), d, P(out), _lib.stream_ptr()))
+        ref = R.timestep_embedding(t, d)
+        assert (out.cpu() - ref).abs().max() < 2e-4  # |arg| <= 999: one fp32 ulp of arg is 6e-5
+
+
+def test_ddpm_elementwise_against_golden(gold):
+    from oracle import diffusion_ref as D
+    from oracle import fill
+    g = gold("g4_diffusion.npz")
+    gd = hig_amd.GaussianDiffusion(
+        betas=hig_amd.models.gaussian_diffusion.get_named_beta_schedule("linear", 1000),
+        model_mean_type=hig_amd.models.gaussian_diffusion.ModelMeanType.EPSILON,
+        model_var_type=hig_amd.models.gaussian_diffusion.ModelVarType.FIXED_SMALL,
+        loss_type=hig_amd.models.gaussian_diffusion.LossType.MSE)
+    x, eps, t = (torch.tensor(g[k]).to(DEV) for k in ("x", "eps", "t"))
+    z0 = (fill.tensor_for("g4.z.0", x.shape) * 10.0).to(DEV)
+    z1 = (fill.tensor_for("g4.z.1", x.shape) * 10.0).to(DEV)
+    xt = gd.q_sample(x, t, noise=z0)
+    assert rel(xt, torch.tensor(g["q_sample"])) < 1e-6
+    B = x.shape[0]
+    sample, pred = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(_lib.lib().hig_p_sample_step(P(x), P(eps), P(z1), P(t), P(gd.device_table(x.device)), 1000, B,
+                                            x.numel() // B, P(sample), P(pred), _lib.stream_ptr()))
+    assert rel(pred, torch.tensor(g["pred_xstart"])) < 1e-6
+    assert rel(sample, torch.tensor(g["p_sample"])) < 1e-6
+    # t == 0 row: no noise
+    assert rel(sample[0], torch.tensor(g["mean"])[0]) < 1e-6
+    # device table equals the float64 tables cast to fp32
+    tb = D.tables(D.linear_betas(1000))
+    tab = gd.device_table(x.device).cpu().numpy()
+    assert np.array_equal(tab[6], tb["posterior_log_variance_clipped"].astype(np.float32))
+    assert np.array_equal(tab[0], tb["sqrt_alphas_cumprod"].astype(np.float32))
+
+
+def test_masked_mse_and_grad():
+    B, T, Fd = 3, 20, 150
+    pred, tgt = rnd(B, T, Fd), rnd(B, T, Fd, seed=1)
+    lens = torch.tensor([20, 7, 1])
+    pd = pred.double().requires_grad_(True)
+    mask = (torch.arange(T)[None] < lens[:, None]).double()
+    loss_ref = (((pd - tgt.double()) ** 2).mean(-1) * mask).sum() / mask.sum()
+    loss_ref.backward()
+    loss, dp = torch.zeros(1, device=DEV), torch.zeros(B, T, Fd, device=DEV)
+    scr = torch.zeros(_lib.NORM_BLOCKS, device=DEV)
+    _lib.check(_lib.lib().hig_masked_mse(P(pred.to(DEV)), P(tgt.to(DEV)), P(lens.to(DEV)), B, T, Fd, P(loss),
+                                         P(dp), P(scr), _lib.stream_ptr()))
+    assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())
+    assert rel(dp, pd.grad) < 1e-6
+
+
+def test_clip_adam_matches_torch():
+    n = 100003
+    p0, g = rnd(n), rnd(n, seed=1, scale=0.01)
+    ref = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.Adam([ref], lr=2e-4)
+    p, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    scr, gn = torch.zeros(_lib.NORM_BLOCKS, device=DEV), torch.zeros(1, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    L = _lib.lib()
+    for it in range(3):
+        gi = g * (it + 1) * (40.0 if it == 1 else 1.0)   # step 1 is above the 0.5 clip threshold
+        ref.grad = gi.double() / 2                        # world = 2: mean of the summed gradient
+        tot = torch.nn.utils.clip_grad_norm_([ref], 0.5)
+        opt.step()
+        gg = gi.to(DEV)
+        _lib.check(L.hig_sumsq_partial(P(gg), n, 0.5, P(scr), _lib.stream_ptr()))
+        _lib.check(L.hig_clip_adam(P(p), P(gg), P(m), P(v), n, 2e-4, 0.9, 0.999, 1e-8, 0.5, 0.5, P(scr), P(gn),
+                                   P(step), _lib.stream_ptr()))
+        assert abs(gn.item() - tot.item()) < 1e-5 * tot.item()
+        assert rel(p, ref.data) < 1e-6
+    assert step.item() == 3
