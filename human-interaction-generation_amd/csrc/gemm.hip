@@ -98,7 +98,22 @@ __device__ __forceinline__ float4 ld_rs(const float* base, int64_t ld, int i, in
   return v;
 }
 
-template <int BI, int BJ, bool X_RS, bool Y_RS, int XF, bool XF_ON_Y, int EPI>
+// Branch-free loads for the common case (16-byte aligned operand, k-tile entirely inside the
+// reduce range): out-of-range ROWS are clamped to the last valid row instead of being zeroed --
+// they only feed accumulator rows/columns the epilogue never stores -- so a tile's loads issue
+// back to back with no control flow and no use before the MFMA block.  (A guarded load makes
+// hipcc branch around it and wait vmcnt(0) each time, serialising the whole tile fetch.)
+__device__ __forceinline__ float4 ld_rc_fast(const float* base, int64_t ld, int row, int nrows, int k) {
+  return *reinterpret_cast<const float4*>(base + (int64_t)min(row, nrows - 1) * ld + k);
+}
+__device__ __forceinline__ float4 ld_rs_fast(const float* base, int64_t ld, int i, int nrows, int k) {
+  return *reinterpret_cast<const float4*>(base + (int64_t)k * ld + min(i, nrows - 4));
+}
+
+// FAST = every operand 16-byte aligned and the reduce extent a multiple of BK: the tile fetch
+// is a straight run of clamped float4 loads (chosen on the host; the general kernel keeps the
+// guarded loads for odd shapes such as F = 150).
+template <int BI, int BJ, bool X_RS, bool Y_RS, int XF, bool XF_ON_Y, int EPI, bool FAST>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
   constexpr int TI = BI / 64, TJ = BJ / 64;
   constexpr int XP = BI / 32, YP = BJ / 32;
@@ -154,17 +169,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
   auto load_tiles = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
-      if (X_RS)
-        xr[p] = ld_rs(g.X, g.ldx, i0 + 4 * x_c4, g.I, k0 + x_r + X_RSTEP * p, rend, a.vecx);
-      else
-        xr[p] = ld_rc(g.X, g.ldx, i0 + x_r + 32 * p, g.I, k0 + 4 * x_c4, rend, a.vecx);
+      if (FAST) {
+        if (X_RS)
+          xr[p] = ld_rs_fast(g.X, g.ldx, i0 + 4 * x_c4, g.I, k0 + x_r + X_RSTEP * p);
+        else
+          xr[p] = ld_rc_fast(g.X, g.ldx, i0 + x_r + 32 * p, g.I, k0 + 4 * x_c4);
+      } else {
+        if (X_RS)
+          xr[p] = ld_rs(g.X, g.ldx, i0 + 4 * x_c4, g.I, k0 + x_r + X_RSTEP * p, rend, a.vecx);
+        else
+          xr[p] = ld_rc(g.X, g.ldx, i0 + x_r + 32 * p, g.I, k0 + 4 * x_c4, rend, a.vecx);
+      }
     }
 #pragma unroll
     for (int p = 0; p < YP; ++p) {
-      if (Y_RS)
-        yr[p] = ld_rs(g.Y, g.ldy, j0 + 4 * y_c4, g.J, k0 + y_r + Y_RSTEP * p, rend, a.vecy);
-      else
-        yr[p] = ld_rc(g.Y, g.ldy, j0 + y_r + 32 * p, g.J, k0 + 4 * y_c4, rend, a.vecy);
+      if (FAST) {
+        if (Y_RS)
+          yr[p] = ld_rs_fast(g.Y, g.ldy, j0 + 4 * y_c4, g.J, k0 + y_r + Y_RSTEP * p);
+        else
+          yr[p] = ld_rc_fast(g.Y, g.ldy, j0 + y_r + 32 * p, g.J, k0 + 4 * y_c4);
+      } else {
+        if (Y_RS)
+          yr[p] = ld_rs(g.Y, g.ldy, j0 + 4 * y_c4, g.J, k0 + y_r + Y_RSTEP * p, rend, a.vecy);
+        else
+          yr[p] = ld_rc(g.Y, g.ldy, j0 + y_r + 32 * p, g.J, k0 + 4 * y_c4, rend, a.vecy);
+      }
     }
   };
   auto transform = [&](int k0) {
@@ -393,9 +422,16 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
   a.vecc = (a.g.ldc % 4 == 0) && al16(a.g.C) && (a.slab % 4 == 0) &&
            (!g.res || ((g.ldr % 4 == 0) && al16(g.res))) &&
            (!g.aux || ((g.ldaux % 4 == 0) && al16(g.aux)));
-  if (a.ntiles > 0 && g.R >= 0)
-    hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI>), dim3(a.ntiles, splits),
-                       dim3(NTHREADS), 0, st, a);
+  const bool fast = a.vecx && a.vecy && (g.R % BK == 0) && g.R > 0 &&
+                    (!X_RS || (g.I % 4 == 0 && g.I >= 4)) && (!Y_RS || (g.J % 4 == 0 && g.J >= 4));
+  if (a.ntiles > 0 && g.R >= 0) {
+    if (fast)
+      hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, true>), dim3(a.ntiles, splits),
+                         dim3(NTHREADS), 0, st, a);
+    else
+      hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, false>), dim3(a.ntiles, splits),
+                         dim3(NTHREADS), 0, st, a);
+  }
   HIG_CHECK_LAUNCH();
   if (splits > 1) {
     const int64_t n4 = (int64_t)g.I * g.J / 4;

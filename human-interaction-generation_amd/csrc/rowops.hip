@@ -170,14 +170,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   }
 }
 
-// out[c] = sum_{r<nr} in[(r*rstride) + c]  (column reduction of small partial tables)
-__global__ void colreduce_kernel(const float* __restrict__ in, int nr, int64_t rstride, int n,
-                                 float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
-  float s = 0.f;
-  for (int r = 0; r < nr; ++r) s += in[(int64_t)r * rstride + c];
-  out[c] = s;
+// out[c] = sum_{r<nr} in[(r*rstride) + c]  (column reduction of small partial tables).
+// 64 columns x 16 row lanes per block; 4 independent accumulators keep 4 loads in flight.
+__global__ __launch_bounds__(1024) void colreduce_kernel(const float* __restrict__ in, int nr,
+                                                         int64_t rstride, int n, float* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < n) {
+    int r = ry;
+    for (; r + 48 < nr; r += 64) {
+      s0 += in[(int64_t)r * rstride + c];
+      s1 += in[(int64_t)(r + 16) * rstride + c];
+      s2 += in[(int64_t)(r + 32) * rstride + c];
+      s3 += in[(int64_t)(r + 48) * rstride + c];
+    }
+    for (; r < nr; r += 16) s0 += in[(int64_t)r * rstride + c];
+  }
+  red[ry][cx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ry == 0 && c < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cx];
+    out[c] = t;
+  }
 }
 // dss[b][c] = sum_s partial[b][s][2][c];  dss[b][shift_off + c] = sum_s partial[b][s][3][c]
 __global__ void dss_reduce_kernel(const float* __restrict__ partial, int nsplit, int n,
@@ -299,12 +317,12 @@ extern "C" int hig_ln_bwd(const float* da, int64_t ldda, const float* x, int64_t
   HIG_CHECK_LAUNCH();
   const int tb = 128;
   if (dgamma) {
-    hipLaunchKernelGGL(colreduce_kernel, dim3((n + tb - 1) / tb), dim3(tb), 0, st, partial,
+    hipLaunchKernelGGL(colreduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial,
                        samples * nsplit, (int64_t)4 * n, n, dgamma);
     HIG_CHECK_LAUNCH();
   }
   if (dbeta) {
-    hipLaunchKernelGGL(colreduce_kernel, dim3((n + tb - 1) / tb), dim3(tb), 0, st, partial + n,
+    hipLaunchKernelGGL(colreduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial + n,
                        samples * nsplit, (int64_t)4 * n, n, dbeta);
     HIG_CHECK_LAUNCH();
   }
@@ -323,7 +341,7 @@ extern "C" int hig_colsum(const float* x, int64_t ldx, int64_t rows, int32_t n, 
   hipLaunchKernelGGL(colsum_kernel, dim3((n + 255) / 256, HIG_COLSUM_CHUNKS), dim3(256), 0, st, x, ldx,
                      rows, n, partial);
   HIG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colreduce_kernel, dim3((n + 127) / 128), dim3(128), 0, st, partial,
+  hipLaunchKernelGGL(colreduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial,
                      HIG_COLSUM_CHUNKS, (int64_t)n, n, out);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
