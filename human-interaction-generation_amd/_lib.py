@@ -25,7 +25,7 @@ COLSUM_CHUNKS = 64
 SYMBOLS = (
     "hig_version", "hig_last_error", "hig_workspace_bytes", "hig_textctx_bytes",
     "hig_bwd_workspace_bytes", "hig_text_context", "hig_denoiser_fwd", "hig_denoiser_bwd",
-    "hig_gemm", "hig_rowstats", "hig_linattn_ctx", "hig_linattn_apply", "hig_linattn_apply_bwd",
+    "hig_gemm", "hig_rowstats", "hig_ln_mod_silu", "hig_linattn_ctx", "hig_linattn_apply", "hig_linattn_apply_bwd",
     "hig_linattn_ctx_bwd", "hig_ln_bwd", "hig_ln_bwd_partial_floats", "hig_colsum",
     "hig_timestep_embedding", "hig_q_sample", "hig_p_sample_step", "hig_dec_timesteps",
     "hig_masked_mse", "hig_sumsq_partial", "hig_clip_adam",
@@ -80,6 +80,7 @@ def lib():
         L.hig_denoiser_bwd.argtypes = [C.POINTER(Dims)] + [vp] * 14
         L.hig_gemm.argtypes = [C.POINTER(GemmDesc), vp]
         L.hig_rowstats.argtypes = [vp, i64, i64, i32, vp, vp]
+        L.hig_ln_mod_silu.argtypes = [vp, i64, i64, i32, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp]
         L.hig_linattn_ctx.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp]
         L.hig_linattn_apply.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]
         L.hig_linattn_apply_bwd.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp]

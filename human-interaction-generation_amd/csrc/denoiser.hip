@@ -72,7 +72,7 @@ int check_dims(const hig_dims* p, Dims& D) {
 struct FwdLayout {
   int64_t te, te_h, emb, ss, h0;
   int64_t layer0, lstride;
-  int64_t st1, qkv, A1, kst1, y1, st2, h1, st3, qc, y2, st4, h2, z1, f1, y3, st5, h3;
+  int64_t st1, qkv, A1, kst1, y1, st2, a1, h1, st3, qc, y2, st4, a2, h2, z1, f1, y3, st5, a3, h3;
   int64_t total;
 };
 FwdLayout fwd_layout(const Dims& D, int training) {
@@ -92,16 +92,19 @@ FwdLayout fwd_layout(const Dims& D, int training) {
   w.kst1 = take((int64_t)D.B * D.d * 2);
   w.y1 = take(D.M * D.d);
   w.st2 = take(D.M * 2);
+  w.a1 = take(D.M * D.d);
   w.h1 = take(D.M * D.d);
   w.st3 = take(D.M * 2);
   w.qc = take(D.M * D.d);
   w.y2 = take(D.M * D.d);
   w.st4 = take(D.M * 2);
+  w.a2 = take(D.M * D.d);
   w.h2 = take(D.M * D.d);
   w.z1 = take(D.M * D.ff);
   w.f1 = take(D.M * D.ff);
   w.y3 = take(D.M * D.d);
   w.st5 = take(D.M * 2);
+  w.a3 = take(D.M * D.d);
   w.h3 = take(D.M * D.d);
   w.lstride = training ? o : 0;
   w.total = w.layer0 + (training ? o * D.L : o);
@@ -295,10 +298,9 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
     HIG_TRY(hig_linattn_ctx(lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, length,
                             lb + w.A1, lb + w.kst1, stream));
     HIG_TRY(hig_linattn_apply(lb + w.qkv, 3 * d, lb + w.A1, lb + w.y1, d, D.B, D.T, D.H, D.hd, stream));
-    HIG_TRY(hig_rowstats(lb + w.y1, d, M, d, lb + w.st2, stream));
-    HIG_TRY(hig_gemm_launch(G(lb + w.y1, d, 0, PL(params, l, HIG_L_SA_STY_OUT_W), d, 0, lb + w.h1, d, M, d, d)
-                                .ln(0, lb + w.st2, PL(params, l, HIG_L_SA_STY_NORM_W), PL(params, l, HIG_L_SA_STY_NORM_B))
-                                .mod(ssl, ss_ld, d, D.T)
+    HIG_TRY(hig_ln_mod_silu(lb + w.y1, d, M, d, PL(params, l, HIG_L_SA_STY_NORM_W), PL(params, l, HIG_L_SA_STY_NORM_B),
+                            ssl, ss_ld, d, D.T, lb + w.a1, d, lb + w.st2, stream));
+    HIG_TRY(hig_gemm_launch(G(lb + w.a1, d, 0, PL(params, l, HIG_L_SA_STY_OUT_W), d, 0, lb + w.h1, d, M, d, d)
                                 .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_SA_STY_OUT_B)).res(hin, d).g, 1, nullptr, st));
     // ---- cross attention ------------------------------------------------------------
     HIG_TRY(hig_rowstats(lb + w.h1, d, M, d, lb + w.st3, stream));
@@ -307,10 +309,9 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
                                 .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).g, 1, nullptr, st));
     HIG_TRY(hig_linattn_apply(lb + w.qc, d, tc + tl.layer0 + tl.lstride * l + tl.Ac, lb + w.y2, d, D.B, D.T,
                               D.H, D.hd, stream));
-    HIG_TRY(hig_rowstats(lb + w.y2, d, M, d, lb + w.st4, stream));
-    HIG_TRY(hig_gemm_launch(G(lb + w.y2, d, 0, PL(params, l, HIG_L_CA_STY_OUT_W), d, 0, lb + w.h2, d, M, d, d)
-                                .ln(0, lb + w.st4, PL(params, l, HIG_L_CA_STY_NORM_W), PL(params, l, HIG_L_CA_STY_NORM_B))
-                                .mod(ssl + 2 * d, ss_ld, d, D.T)
+    HIG_TRY(hig_ln_mod_silu(lb + w.y2, d, M, d, PL(params, l, HIG_L_CA_STY_NORM_W), PL(params, l, HIG_L_CA_STY_NORM_B),
+                            ssl + 2 * d, ss_ld, d, D.T, lb + w.a2, d, lb + w.st4, stream));
+    HIG_TRY(hig_gemm_launch(G(lb + w.a2, d, 0, PL(params, l, HIG_L_CA_STY_OUT_W), d, 0, lb + w.h2, d, M, d, d)
                                 .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_CA_STY_OUT_B)).res(lb + w.h1, d).g, 1, nullptr, st));
     // ---- FFN ------------------------------------------------------------------------
     HIG_TRY(hig_gemm_launch(G(lb + w.h2, d, 0, PL(params, l, HIG_L_FFN_W1), d, 0, lb + w.f1, D.ff, M, D.ff, d)
@@ -318,10 +319,9 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
                                 .aux(training ? lb + w.z1 : nullptr, D.ff).g, 1, nullptr, st));
     HIG_TRY(hig_gemm_launch(G(lb + w.f1, D.ff, 0, PL(params, l, HIG_L_FFN_W2), D.ff, 0, lb + w.y3, d, M, d, D.ff)
                                 .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B2)).g, 1, nullptr, st));
-    HIG_TRY(hig_rowstats(lb + w.y3, d, M, d, lb + w.st5, stream));
-    HIG_TRY(hig_gemm_launch(G(lb + w.y3, d, 0, PL(params, l, HIG_L_FFN_STY_OUT_W), d, 0, lb + w.h3, d, M, d, d)
-                                .ln(0, lb + w.st5, PL(params, l, HIG_L_FFN_STY_NORM_W), PL(params, l, HIG_L_FFN_STY_NORM_B))
-                                .mod(ssl + 4 * d, ss_ld, d, D.T)
+    HIG_TRY(hig_ln_mod_silu(lb + w.y3, d, M, d, PL(params, l, HIG_L_FFN_STY_NORM_W), PL(params, l, HIG_L_FFN_STY_NORM_B),
+                            ssl + 4 * d, ss_ld, d, D.T, lb + w.a3, d, lb + w.st5, stream));
+    HIG_TRY(hig_gemm_launch(G(lb + w.a3, d, 0, PL(params, l, HIG_L_FFN_STY_OUT_W), d, 0, lb + w.h3, d, M, d, d)
                                 .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_FFN_STY_OUT_B)).res(lb + w.h2, d).g, 1, nullptr, st));
     hin = lb + w.h3;
   }
@@ -365,12 +365,11 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
   };
   // Backward of one stylization block: h_out = h_in + Lin_out(silu(LN(y)*(1+scale)+shift)).
   // `dh` is d(h_out); produces dy into `dy_out`, parameter grads, and dss columns of block s.
-  auto sty_bwd = [&](int l, int s, const float* dh, const float* y, const float* stats, int norm_w, int norm_b,
-                     int out_w, int out_b, float* dy_out) -> int {
+  auto sty_bwd = [&](int l, int s, const float* dh, const float* y, const float* a_saved, const float* stats,
+                     int norm_w, int norm_b, int out_w, int out_b, float* dy_out) -> int {
     const float* ssl = ws + w.ss + (int64_t)s * 2 * d;
     HIG_TRY(colsum(dh, d, M, d, GL(grads, l, out_b)));
-    HIG_TRY(wgrad(G(dh, d, 1, y, d, 1, GL(grads, l, out_w), d, d, d, M)
-                      .ln(1, stats, PL(params, l, norm_w), PL(params, l, norm_b)).mod(ssl, ss_ld, d, D.T)));
+    HIG_TRY(wgrad(G(dh, d, 1, a_saved, d, 1, GL(grads, l, out_w), d, d, d, M)));
     HIG_TRY(hig_gemm_launch(G(dh, d, 0, PL(params, l, out_w), d, 1, b + bw.t1, d, M, d, d).g, 1, nullptr, st));
     return hig_ln_bwd(b + bw.t1, d, y, d, stats, PL(params, l, norm_w), PL(params, l, norm_b), ssl, ss_ld, d, 1,
                       nullptr, 0, dy_out, d, M, d, D.T, GL(grads, l, norm_w), GL(grads, l, norm_b),
@@ -389,7 +388,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
     const float* lb = ws + w.layer0 + w.lstride * l;
     const float* hin = l == 0 ? ws + w.h0 : ws + w.layer0 + w.lstride * (l - 1) + w.h3;
     // ---- FFN --------------------------------------------------------------------------
-    HIG_TRY(sty_bwd(l, 3 * l + 2, dh, lb + w.y3, lb + w.st5, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B,
+    HIG_TRY(sty_bwd(l, 3 * l + 2, dh, lb + w.y3, lb + w.a3, lb + w.st5, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B,
                     HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B, b + bw.t2));
     const float* dy3 = b + bw.t2;
     HIG_TRY(colsum(dy3, d, M, d, GL(grads, l, HIG_L_FFN_B2)));
@@ -403,7 +402,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                                 .epi(HIG_EPI_RES).res(dh, d).g, 1, nullptr, st));
     { float* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h2)
     // ---- cross attention ---------------------------------------------------------------
-    HIG_TRY(sty_bwd(l, 3 * l + 1, dh, lb + w.y2, lb + w.st4, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B,
+    HIG_TRY(sty_bwd(l, 3 * l + 1, dh, lb + w.y2, lb + w.a2, lb + w.st4, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B,
                     HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B, b + bw.t2));
     const float* Ac = tc + tl.layer0 + tl.lstride * l + tl.Ac;
     const float* kstc = tc + tl.layer0 + tl.lstride * l + tl.kstc;
@@ -431,7 +430,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                        dxf_out, Lt, Mt, Lt, D.N, GL(grads, l, HIG_L_CA_TNORM_W), GL(grads, l, HIG_L_CA_TNORM_B),
                        nullptr, 0, lnp, stream));
     // ---- self attention ----------------------------------------------------------------
-    HIG_TRY(sty_bwd(l, 3 * l, dh, lb + w.y1, lb + w.st2, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B,
+    HIG_TRY(sty_bwd(l, 3 * l, dh, lb + w.y1, lb + w.a1, lb + w.st2, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B,
                     HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B, b + bw.t2));
     float* dqkv = b + bw.dqkv;
     HIG_TRY(hig_linattn_apply_bwd(b + bw.t2, d, lb + w.qkv, 3 * d, lb + w.A1, dqkv, 3 * d, b + bw.dA, D.B, D.T, D.H,

@@ -18,6 +18,8 @@
 // the 16-lane ds_read_b128 groups are conflict-free); reduce-slow tiles as [32][rows] read with
 // conflict-free ds_read_b32.  Inside a 32-deep K tile the k order is permuted identically for
 // both operands: MFMA step j of group ks uses k = 8*ks + 4*(lane>>5) + j.
+#include <stdlib.h>
+
 #include "hig_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -443,13 +445,35 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
   return HIG_OK;
 }
 
-// Tile choice: 128x128 when both extents can fill it, otherwise 64x64 (skinny GEMMs such as the
-// B-row time-embedding MLP are weight-bandwidth bound; smaller tiles keep more CUs streaming).
+// Tile choice.  fp32 MFMA is slow enough (64 cycles per 32x32x2) that every tile shape is
+// MFMA-bound, so what matters is how evenly ceil(I/BI)*ceil(J/BJ) tiles spread over 256 CUs:
+// M = 12544 = 2^8 * 49 gives 3.06 128x128 tiles per CU for N = 1024 (4 rounds, 77 % balance)
+// but 12.25 64x64 tiles (13 rounds, 94 %).  Pick the shape with the smallest
+// rounds x tile-area x overhead; smaller tiles pay a little more prologue/epilogue/LDS traffic.
 template <bool X_RS, bool Y_RS, int XF, bool XF_ON_Y, int EPI>
 int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipStream_t st) {
-  if (g.I > 64 && g.J > 64)
-    return launch<128, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
-  return launch<64, 64, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
+  if (splits > 1 || X_RS) {  // weight gradients: split-R already supplies the parallelism
+    if (g.I > 64 && g.J > 64) return launch<128, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
+    return launch<64, 64, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
+  }
+  struct Cand { int bi, bj; double ovh; };
+  const Cand cands[4] = {{128, 128, 1.00}, {64, 128, 1.02}, {128, 64, 1.03}, {64, 64, 1.04}};
+  int best = 0;
+  double best_cost = 1e300;
+  static const int forced = getenv("HIG_GEMM_TILE") ? atoi(getenv("HIG_GEMM_TILE")) : -1;  // tuning knob
+  for (int c = 0; c < 4 && forced < 0; ++c) {
+    const int64_t tiles = (int64_t)((g.I + cands[c].bi - 1) / cands[c].bi) * ((g.J + cands[c].bj - 1) / cands[c].bj);
+    const int64_t rounds = (tiles + 255) / 256;
+    const double cost = (double)rounds * cands[c].bi * cands[c].bj * cands[c].ovh;
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  if (forced >= 0) best = forced;
+  switch (best) {
+    case 0: return launch<128, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
+    case 1: return launch<64, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
+    case 2: return launch<128, 64, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
+    default: return launch<64, 64, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
+  }
 }
 
 }  // namespace
@@ -479,6 +503,7 @@ int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_
   CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_BIAS)
   CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_BIAS_GELU)
   CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_BIAS_POS)
+  CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_BIAS_RES)
   CASE(0, 0, HIG_XF_LN, 0, HIG_EPI_BIAS)
   CASE(0, 0, HIG_XF_LN_MOD_SILU, 0, HIG_EPI_BIAS_RES)
   CASE(0, 0, HIG_XF_SILU, 0, HIG_EPI_BIAS)

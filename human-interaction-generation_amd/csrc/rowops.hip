@@ -48,6 +48,63 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__
   }
 }
 
+// Fused StylizationBlock front half (transformer.py:81-84 + the SiLU of out_layers):
+//   a[m] = silu( LN(x[m]) * (1 + scale[b(m)]) + shift[b(m)] ),  stats[m] = (mean, rstd)
+// One wave per row, the row stays in registers between the statistics and the transform, so x
+// is read once and a written once (the GEMM that consumes `a` is then a plain contraction: the
+// per-element exp/rcp of the SiLU is paid once per element instead of once per N-tile column).
+template <int NIT>
+__global__ __launch_bounds__(256) void ln_mod_silu_kernel(
+    const float* __restrict__ x, int64_t ldx, int64_t rows, int n, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ ss, int64_t ss_ld, int shift_off,
+    int rows_per_sample, float* __restrict__ a, int64_t lda, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  float4 v[NIT];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = 4 * lane + 256 * it;
+    v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < n) v[it] = *reinterpret_cast<const float4*>(xr + c);
+    s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+  }
+  const float mean = wave_sum(s) / (float)n;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = 4 * lane + 256 * it;
+    if (c < n) {
+      const float d0 = v[it].x - mean, d1 = v[it].y - mean, d2 = v[it].z - mean, d3 = v[it].w - mean;
+      q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)n + 1e-5f);
+  if (lane == 0) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rstd;
+  }
+  const float* ssrow = ss + (row / rows_per_sample) * ss_ld;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = 4 * lane + 256 * it;
+    if (c < n) {
+      const float4 g4 = *reinterpret_cast<const float4*>(gamma + c);
+      const float4 b4 = *reinterpret_cast<const float4*>(beta + c);
+      const float4 sc = *reinterpret_cast<const float4*>(ssrow + c);
+      const float4 sh = *reinterpret_cast<const float4*>(ssrow + shift_off + c);
+      float4 o;
+      o.x = hig_silu(((v[it].x - mean) * rstd * g4.x + b4.x) * (1.0f + sc.x) + sh.x);
+      o.y = hig_silu(((v[it].y - mean) * rstd * g4.y + b4.y) * (1.0f + sc.y) + sh.y);
+      o.z = hig_silu(((v[it].z - mean) * rstd * g4.z + b4.z) * (1.0f + sc.z) + sh.z);
+      o.w = hig_silu(((v[it].w - mean) * rstd * g4.w + b4.w) * (1.0f + sc.w) + sh.w);
+      *reinterpret_cast<float4*>(a + row * lda + c) = o;
+    }
+  }
+}
+
 // Backward of a = [silu](LN(x) * (1 + scale) + shift).  grid = (samples, splits); wave w of split
 // s owns rows s*4 + w, + 4*splits, ... of its sample.  NIT = ceil(n / 256) float4 per lane.
 template <int NIT, bool MOD_SILU>
@@ -278,6 +335,25 @@ extern "C" int hig_rowstats(const float* x, int64_t ldx, int64_t rows, int32_t n
   if (rows == 0) return HIG_OK;
   hipLaunchKernelGGL(rowstats_kernel, dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(256), 0,
                      hig_stream(stream), x, ldx, rows, n, stats);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+extern "C" int hig_ln_mod_silu(const float* x, int64_t ldx, int64_t rows, int32_t n, const float* gamma,
+                               const float* beta, const float* ss, int64_t ss_ld, int32_t ss_shift_off,
+                               int32_t rows_per_sample, float* a, int64_t lda, float* stats,
+                               hig_stream_t stream) {
+  HIG_REQUIRE(x && gamma && beta && ss && a && stats && rows >= 0, "hig_ln_mod_silu: null argument");
+  HIG_REQUIRE(n > 0 && n % 4 == 0 && n <= 1024 && ldx % 4 == 0 && lda % 4 == 0 && rows_per_sample > 0,
+              "hig_ln_mod_silu: n must be a multiple of 4 and <= 1024 (got %d)", n);
+  if (rows == 0) return HIG_OK;
+  const dim3 grid((unsigned)((rows + WAVES - 1) / WAVES));
+  const int nit = (n + 255) / 256;
+#define LMS(NITV)                                                                                      \
+  hipLaunchKernelGGL((ln_mod_silu_kernel<NITV>), grid, dim3(256), 0, hig_stream(stream), x, ldx, rows, n, \
+                     gamma, beta, ss, ss_ld, ss_shift_off, rows_per_sample, a, lda, stats)
+  if (nit == 1) LMS(1); else if (nit == 2) LMS(2); else LMS(4);
+#undef LMS
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

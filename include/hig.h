@@ -187,6 +187,13 @@ int hig_gemm(const hig_gemm_desc* g, hig_stream_t stream);
 int hig_rowstats(const float* x, int64_t ldx, int64_t rows, int32_t n, float* stats,
                  hig_stream_t stream);
 
+/* Front half of StylizationBlock.forward (transformer.py:81-84) fused with the SiLU of its
+ * out_layers and with the LayerNorm statistics:  a = silu(LN(x)*(1+scale)+shift), stats = (mean, rstd).
+ * scale = ss[b][0..n), shift = ss[b][ss_shift_off ..), b = row / rows_per_sample. */
+int hig_ln_mod_silu(const float* x, int64_t ldx, int64_t rows, int32_t n, const float* gamma,
+                    const float* beta, const float* ss, int64_t ss_ld, int32_t ss_shift_off,
+                    int32_t rows_per_sample, float* a, int64_t lda, float* stats, hig_stream_t stream);
+
 /* Linear ("efficient") attention pieces, transformer.py:110-117 / 146-153.  Channel c of
  * head h lives at column h*hd + c.
  * ctx: k = softmax over the `len[b]` leading rows of each sample (masked rows contribute 0),

@@ -172,6 +172,20 @@ def test_rowstats(rows, n):
     assert rel(st, stats_of(x.double())) < 1e-6
 
 
+@pytest.mark.parametrize("B,T,n", [(2, 16, 64), (3, 50, 512), (2, 9, 1024), (5, 7, 256)])
+def test_ln_mod_silu_rows(B, T, n):
+    M = B * T
+    x = rnd(M, n, scale=2.0) + 0.3
+    g, be, ss = 1 + 0.1 * rnd(n, seed=2), 0.1 * rnd(n, seed=3), rnd(B, 6 * n, seed=4, scale=0.5)
+    a, st = torch.zeros(M, n, device=DEV), torch.zeros(M, 2, device=DEV)
+    ssg = ss.to(DEV)
+    _lib.check(_lib.lib().hig_ln_mod_silu(P(x.to(DEV)), n, M, n, P(g.to(DEV)), P(be.to(DEV)),
+                                          ssg.data_ptr() + 4 * 2 * n, 6 * n, n, T, P(a), n, P(st), _lib.stream_ptr()))
+    nrm = F.layer_norm(x.double(), (n,), g.double(), be.double()).view(B, T, n)
+    ref = F.silu(nrm * (1 + ss.double()[:, None, 2 * n:3 * n]) + ss.double()[:, None, 3 * n:4 * n]).view(M, n)
+    assert rel(a, ref) < 2e-6 and rel(st, stats_of(x.double())) < 1e-6
+
+
 @pytest.mark.parametrize("mod", [0, 1])
 @pytest.mark.parametrize("B,T,n", [(2, 16, 64), (3, 50, 512), (2, 77, 256), (2, 9, 1024)])
 def test_ln_bwd(mod, B, T, n):

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Launches the FFN linear1 GEMM (M=12544, K=512, N=1024, bias+GELU) a few times so that
+`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) can price its HBM traffic."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from tools.gemm_bench import run  # noqa: E402
+from hig_amd import _lib  # noqa: E402
+
+if __name__ == "__main__":
+    # evict: stream 1 GiB through the caches so the GEMM reads from HBM, not the 256 MiB MALL
+    junk = torch.empty(256 << 20, device="cuda")
+    for _ in range(3):
+        junk.fill_(1.0)
+        ms, tf = run(12544, 1024, 512, _lib.XF_NONE, _lib.EPI_BIAS_GELU, reps=1)
+    print("ffn1 %.3f ms %.1f TF" % (ms, tf))
