@@ -167,8 +167,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
     }
   }
 
-  float4 xr[XP], yr[YP];
-  auto load_tiles = [&](int k0) {
+  // Two register sets for operand staging: tile k+2 is fetched while tile k is multiplied and
+  // tile k+1 (fetched one iteration ago) is written to LDS in the MIDDLE of the MFMA block, so
+  // the barrier that closes the iteration never waits on a global load or a fresh LDS write --
+  // only on wave skew.  (With the write placed right before the barrier every wave idled for
+  // the slowest wave's fetch+write each k-tile: MfmaUtil 46-57 %.)
+  float4 xrA[XP], yrA[YP], xrB[XP], yrB[YP];
+  auto load_tiles = [&](float4 (&xr)[XP], float4 (&yr)[YP], int k0) {
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
       if (FAST) {
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
       }
     }
   };
-  auto transform = [&](int k0) {
+  auto transform = [&](float4 (&xr)[XP], float4 (&yr)[YP], int k0) {
     if (XF == HIG_XF_NONE) return;
     if (!XF_ON_Y) {
       // activation = X, reduce-contiguous: row m fixed per p, features k0+4c4..
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
       }
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](const float4 (&xr)[XP], const float4 (&yr)[YP], int buf) {
     float* sx = smem + buf * STAGE;
     float* sy = sx + X_TILE;
 #pragma unroll
@@ -261,23 +266,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[tj][ti][e] = 0.f;
 
-  const int nk = (rend - rbeg + BK - 1) / BK;
-  if (nk > 0) {
-    load_tiles(rbeg);
-    transform(rbeg);
-    store_tiles(0);
-  }
-  __syncthreads();
-
   const int xrow = wi * (32 * TI) + lr;  // + 32*ti
   const int yrow = wj * (32 * TJ) + lr;  // + 32*tj
-  for (int kt = 0; kt < nk; ++kt) {
-    const int k_next = rbeg + (kt + 1) * BK;
-    if (kt + 1 < nk) load_tiles(k_next);
-    const float* sx = smem + (kt & 1) * STAGE;
+  // MFMA over k-groups [ks0, ks1) of the staged tile in LDS buffer `buf`
+  auto mfma_part = [&](int buf, int ks0, int ks1) {
+    const float* sx = smem + buf * STAGE;
     const float* sy = sx + X_TILE;
 #pragma unroll
-    for (int ks = 0; ks < BK / 8; ++ks) {
+    for (int ks = ks0; ks < ks1; ++ks) {
       float xf[TI][4], yf[TJ][4];
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti) {
@@ -307,11 +303,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
           for (int ti = 0; ti < TI; ++ti)
             acc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[tj][j], xf[ti][j], acc[tj][ti], 0, 0, 0);
     }
+  };
+  // One k-tile: `nxt` holds tile kt+1 (fetched an iteration ago), `ld` receives tile kt+2.
+  auto iteration = [&](int kt, int nk, int buf, float4 (&xn)[XP], float4 (&yn)[YP], float4 (&xl)[XP],
+                       float4 (&yl)[YP]) {
+    if (kt + 2 < nk) load_tiles(xl, yl, rbeg + (kt + 2) * BK);
+    mfma_part(buf, 0, BK / 16);
     if (kt + 1 < nk) {
-      transform(k_next);
-      store_tiles((kt + 1) & 1);
+      transform(xn, yn, rbeg + (kt + 1) * BK);
+      store_tiles(xn, yn, buf ^ 1);
     }
+    mfma_part(buf, BK / 16, BK / 8);
     __syncthreads();
+  };
+
+  const int nk = (rend - rbeg + BK - 1) / BK;
+  if (nk > 0) {
+    load_tiles(xrA, yrA, rbeg);
+    if (nk > 1) load_tiles(xrB, yrB, rbeg + BK);
+    transform(xrA, yrA, rbeg);
+    store_tiles(xrA, yrA, 0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    iteration(kt, nk, 0, xrB, yrB, xrA, yrA);
+    if (kt + 1 < nk) iteration(kt + 1, nk, 1, xrA, yrA, xrB, yrB);
   }
 
   // ---- epilogue: lane holds, per accumulator quad q, columns j..j+3 of row i ----------
