@@ -50,7 +50,7 @@ def build_model(c, device):
     g = torch.Generator().manual_seed(0)
     with torch.no_grad():
         for name, p in m.named_parameters():
-            if name.startswith("out.") or ".linear2." in name or ".out_layers.2." in name:
+            if name.startswith("out.") or ".ffn.linear2." in name or ".out_layers.2." in name:
                 p.copy_(torch.randn(p.shape, generator=g) * 0.02)  # un-zero the zero_module tensors
     return m.to(device)
 

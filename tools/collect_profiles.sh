@@ -1,0 +1,15 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): bench line + rocprofv3 kernel trace of the same command +
+# separate PMC passes for the dominant kernel (FFN linear1 GEMM).  Writes under gpurun_out/$1/.
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $O/bench_under_rocprof.json 2> $O/trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/tools/ffn_gemm_pmc.py > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/tools/ffn_gemm_pmc.py > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- python3 $R/tools/ffn_gemm_pmc.py > $O/pmc_sq.log 2>&1
+cat $O/bench.json
