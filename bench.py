@@ -117,10 +117,25 @@ def ffn_gemm_roofline(c, device, reps=30):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * M * K * Nn
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,RC,RC,XF_NONE,EPI_BIAS_GELU> (FFN linear1)",
+    return {"bound": "mfma",
+            "kernel": "gemm_f32_kernel<64,64,X_RS=0,Y_RS=0,XF_NONE,EPI_BIAS_GELU,FAST> (FFN linear1: M=%d K=%d N=%d)" % (M, K, Nn),
             "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic_bytes(),
             "flops_per_launch": flops, "avg_launch_ms": round(ms, 4)}
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the FFN GEMM from the committed rocprofv3 PMC passes
+    ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, profiles/rNN_ffn_gemm_pmc.json; counters cannot be
+    read from inside the timed process).  None when no profile has been committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ffn_gemm_pmc.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1])).get("traffic_bytes")
+    except Exception:
+        return None
 
 
 def cpu_baseline(c, model, inp, gpu_out):
