@@ -41,7 +41,7 @@ __global__ void mul_dsilu_kernel(const float* __restrict__ a, const float* __res
 inline int64_t al(int64_t floats) { return (floats + 63) & ~(int64_t)63; }  // 256-byte granules
 
 struct Dims {
-  int B, T, F, d, H, ff, L, N, Lt, nf, hd, E;
+  int B, T, F, d, H, ff, L, N, Lt, nf, hd, E, prec;
   int64_t M, Mt;
 };
 
@@ -61,8 +61,9 @@ int check_dims(const hig_dims* p, Dims& D) {
   HIG_REQUIRE(D.T <= D.nf, "hig_dims: T=%d exceeds num_frames=%d", D.T, D.nf);
   if (p->attn_kind != HIG_ATTN_LINEAR)
     return hig_set_error(HIG_EUNSUPPORTED, "hig: attn_kind=%d (no_eff) kernels are not built yet", p->attn_kind);
-  if (p->prec != HIG_PREC_F32)
-    return hig_set_error(HIG_EUNSUPPORTED, "hig: prec=%d not built yet (HIG_PREC_F32 only)", p->prec);
+  if (p->prec != HIG_PREC_F32 && p->prec != HIG_PREC_BF16X3 && p->prec != HIG_PREC_BF16)
+    return hig_set_error(HIG_EINVAL, "hig: unknown prec=%d", p->prec);
+  D.prec = p->prec;
   D.M = (int64_t)D.B * D.T;
   D.Mt = (int64_t)D.B * D.N;
   return HIG_OK;
@@ -181,6 +182,7 @@ struct G {  // small builder for gemm descriptors
     g.I = (int)I; g.J = (int)J; g.R = (int)R;
     g.xf = HIG_XF_NONE; g.epi = HIG_EPI_NONE; g.prec = HIG_PREC_F32;
   }
+  G& prec(int p) { g.prec = p; return *this; }  // forward products: HIG_PREC_* of the plan
   G& epi(int e, const float* bias = nullptr) { g.epi = e; g.bias = bias; return *this; }
   G& res(const float* r, int64_t ldr) { g.res = r; g.ldr = ldr; return *this; }
   G& aux(float* a, int64_t lda) { g.aux = a; g.ldaux = lda; return *this; }
@@ -251,7 +253,7 @@ extern "C" int hig_text_context(const hig_dims* dims, const void* const* params,
     // [key; value](LN_text(xf_out))   (transformer.py:146,150)
     HIG_TRY(hig_gemm_launch(G(xf_out, D.Lt, 0, PL(params, l, HIG_L_CA_KV_W), D.Lt, 0, kv, 2 * D.d, D.Mt, 2 * D.d, D.Lt)
                                 .ln(0, stt, PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B))
-                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_KV_B)).g, 1, nullptr, st));
+                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_KV_B)).prec(D.prec).g, 1, nullptr, st));
     // softmax over the N text tokens (no mask) and A = k^T v   (transformer.py:148,152)
     HIG_TRY(hig_linattn_ctx(kv, kv + D.d, 2 * D.d, D.B, D.N, D.H, D.hd, nullptr, Ac, kstc, stream));
   }
@@ -277,14 +279,14 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
   // K0: emb = time_embed(timestep_embedding(t)) + xf_proj; all 3L scale/shift pairs in ONE GEMM
   HIG_TRY(hig_timestep_embedding(t, D.B, d, ws + w.te, stream));
   HIG_TRY(hig_gemm_launch(G(ws + w.te, d, 0, P(params, HIG_P_TE0_W), d, 0, ws + w.te_h, E, D.B, E, d)
-                              .epi(HIG_EPI_BIAS, P(params, HIG_P_TE0_B)).g, 1, nullptr, st));
+                              .epi(HIG_EPI_BIAS, P(params, HIG_P_TE0_B)).prec(D.prec).g, 1, nullptr, st));
   HIG_TRY(hig_gemm_launch(G(ws + w.te_h, E, 0, P(params, HIG_P_TE2_W), E, 0, ws + w.emb, E, D.B, E, E)
-                              .silu(0).epi(HIG_EPI_BIAS_RES, P(params, HIG_P_TE2_B)).res(xf_proj, E).g, 1, nullptr, st));
+                              .silu(0).epi(HIG_EPI_BIAS_RES, P(params, HIG_P_TE2_B)).res(xf_proj, E).prec(D.prec).g, 1, nullptr, st));
   HIG_TRY(hig_gemm_launch(G(ws + w.emb, E, 0, P(params, HIG_P_STY_EMB_W), E, 0, ws + w.ss, ss_ld, D.B, ss_ld, E)
-                              .silu(0).epi(HIG_EPI_BIAS, P(params, HIG_P_STY_EMB_B)).g, 1, nullptr, st));
+                              .silu(0).epi(HIG_EPI_BIAS, P(params, HIG_P_STY_EMB_B)).prec(D.prec).g, 1, nullptr, st));
   // K1: h0 = joint_embed(x) + sequence_embedding[:T]
   HIG_TRY(hig_gemm_launch(G(x, D.F, 0, P(params, HIG_P_JOINT_W), D.F, 0, ws + w.h0, d, M, d, D.F)
-                              .epi(HIG_EPI_BIAS_POS, P(params, HIG_P_JOINT_B)).pos(P(params, HIG_P_SEQ_EMB), d, D.T).g,
+                              .epi(HIG_EPI_BIAS_POS, P(params, HIG_P_JOINT_B)).pos(P(params, HIG_P_SEQ_EMB), d, D.T).prec(D.prec).g,
                           1, nullptr, st));
   const float* hin = ws + w.h0;
   for (int l = 0; l < D.L; ++l) {
@@ -294,40 +296,40 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
     HIG_TRY(hig_rowstats(hin, d, M, d, lb + w.st1, stream));
     HIG_TRY(hig_gemm_launch(G(hin, d, 0, PL(params, l, HIG_L_SA_QKV_W), d, 0, lb + w.qkv, 3 * d, M, 3 * d, d)
                                 .ln(0, lb + w.st1, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B))
-                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_SA_QKV_B)).g, 1, nullptr, st));
+                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_SA_QKV_B)).prec(D.prec).g, 1, nullptr, st));
     HIG_TRY(hig_linattn_ctx(lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, length,
                             lb + w.A1, lb + w.kst1, stream));
     HIG_TRY(hig_linattn_apply(lb + w.qkv, 3 * d, lb + w.A1, lb + w.y1, d, D.B, D.T, D.H, D.hd, stream));
     HIG_TRY(hig_ln_mod_silu(lb + w.y1, d, M, d, PL(params, l, HIG_L_SA_STY_NORM_W), PL(params, l, HIG_L_SA_STY_NORM_B),
                             ssl, ss_ld, d, D.T, lb + w.a1, d, lb + w.st2, stream));
     HIG_TRY(hig_gemm_launch(G(lb + w.a1, d, 0, PL(params, l, HIG_L_SA_STY_OUT_W), d, 0, lb + w.h1, d, M, d, d)
-                                .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_SA_STY_OUT_B)).res(hin, d).g, 1, nullptr, st));
+                                .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_SA_STY_OUT_B)).res(hin, d).prec(D.prec).g, 1, nullptr, st));
     // ---- cross attention ------------------------------------------------------------
     HIG_TRY(hig_rowstats(lb + w.h1, d, M, d, lb + w.st3, stream));
     HIG_TRY(hig_gemm_launch(G(lb + w.h1, d, 0, PL(params, l, HIG_L_CA_Q_W), d, 0, lb + w.qc, d, M, d, d)
                                 .ln(0, lb + w.st3, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B))
-                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).g, 1, nullptr, st));
+                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).prec(D.prec).g, 1, nullptr, st));
     HIG_TRY(hig_linattn_apply(lb + w.qc, d, tc + tl.layer0 + tl.lstride * l + tl.Ac, lb + w.y2, d, D.B, D.T,
                               D.H, D.hd, stream));
     HIG_TRY(hig_ln_mod_silu(lb + w.y2, d, M, d, PL(params, l, HIG_L_CA_STY_NORM_W), PL(params, l, HIG_L_CA_STY_NORM_B),
                             ssl + 2 * d, ss_ld, d, D.T, lb + w.a2, d, lb + w.st4, stream));
     HIG_TRY(hig_gemm_launch(G(lb + w.a2, d, 0, PL(params, l, HIG_L_CA_STY_OUT_W), d, 0, lb + w.h2, d, M, d, d)
-                                .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_CA_STY_OUT_B)).res(lb + w.h1, d).g, 1, nullptr, st));
+                                .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_CA_STY_OUT_B)).res(lb + w.h1, d).prec(D.prec).g, 1, nullptr, st));
     // ---- FFN ------------------------------------------------------------------------
     HIG_TRY(hig_gemm_launch(G(lb + w.h2, d, 0, PL(params, l, HIG_L_FFN_W1), d, 0, lb + w.f1, D.ff, M, D.ff, d)
                                 .epi(HIG_EPI_BIAS_GELU, PL(params, l, HIG_L_FFN_B1))
-                                .aux(training ? lb + w.z1 : nullptr, D.ff).g, 1, nullptr, st));
+                                .aux(training ? lb + w.z1 : nullptr, D.ff).prec(D.prec).g, 1, nullptr, st));
     HIG_TRY(hig_gemm_launch(G(lb + w.f1, D.ff, 0, PL(params, l, HIG_L_FFN_W2), D.ff, 0, lb + w.y3, d, M, d, D.ff)
-                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B2)).g, 1, nullptr, st));
+                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B2)).prec(D.prec).g, 1, nullptr, st));
     HIG_TRY(hig_ln_mod_silu(lb + w.y3, d, M, d, PL(params, l, HIG_L_FFN_STY_NORM_W), PL(params, l, HIG_L_FFN_STY_NORM_B),
                             ssl + 4 * d, ss_ld, d, D.T, lb + w.a3, d, lb + w.st5, stream));
     HIG_TRY(hig_gemm_launch(G(lb + w.a3, d, 0, PL(params, l, HIG_L_FFN_STY_OUT_W), d, 0, lb + w.h3, d, M, d, d)
-                                .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_FFN_STY_OUT_B)).res(lb + w.h2, d).g, 1, nullptr, st));
+                                .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_FFN_STY_OUT_B)).res(lb + w.h2, d).prec(D.prec).g, 1, nullptr, st));
     hin = lb + w.h3;
   }
   // K6: out = Linear(d, F)(h_L)
   HIG_TRY(hig_gemm_launch(G(hin, d, 0, P(params, HIG_P_OUT_W), d, 0, out, D.F, M, D.F, d)
-                              .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT_B)).g, 1, nullptr, st));
+                              .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT_B)).prec(D.prec).g, 1, nullptr, st));
   return HIG_OK;
 }
 

@@ -23,12 +23,16 @@
 #include "hig_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int BK = 32;
 constexpr int NTHREADS = 256;
 constexpr int RC_LD = BK + 4;
+constexpr int BF_LD = BK + 8;  // bf16 elements per LDS row in the bf16 modes (80 bytes)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct KArgs {
   hig_gemm_desc g;
@@ -40,9 +44,9 @@ struct KArgs {
 };
 
 template <int XF>
-__device__ __forceinline__ float4 xf_apply(float4 v, float mean, float rstd, const float* gamma,
-                                           const float* beta, const float* ssrow, int shift_off,
-                                           int f) {
+__device__ __forceinline__ f32x4 xf_apply(f32x4 v, float mean, float rstd, const float* gamma,
+                                          const float* beta, const float* ssrow, int shift_off,
+                                          int f) {
   if (XF == HIG_XF_NONE) return v;
   if (XF == HIG_XF_SILU) {
     v.x = hig_silu(v.x); v.y = hig_silu(v.y); v.z = hig_silu(v.z); v.w = hig_silu(v.w);
@@ -115,12 +119,25 @@ __device__ __forceinline__ float4 ld_rs_fast(const float* base, int64_t ld, int 
 // FAST = every operand 16-byte aligned and the reduce extent a multiple of BK: the tile fetch
 // is a straight run of clamped float4 loads (chosen on the host; the general kernel keeps the
 // guarded loads for odd shapes such as F = 150).
-template <int BI, int BJ, bool X_RS, bool Y_RS, int XF, bool XF_ON_Y, int EPI, bool FAST>
+//
+// PREC selects the product arithmetic (reduce-contiguous operands only for PREC != F32):
+//   HIG_PREC_F32     v_mfma_f32_32x32x2_f32, exact fp32 products
+//   HIG_PREC_BF16X3  each fp32 operand is split x = hi + lo (bf16 each, lo = bf16(x - hi)) while it
+//                    is staged into LDS; a*b ~= ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16
+//                    (3 MFMAs at 16x the fp32 MFMA rate, relative error ~2^-16 per product,
+//                    fp32 accumulate)
+//   HIG_PREC_BF16    ah*bh only
+// LDS image for the bf16 modes: per operand a hi plane (and a lo plane) of [rows][32+8] bf16 --
+// 80-byte rows keep the 16-lane ds_read_b128 groups conflict-free; one 16-byte read is one MFMA
+// operand (8 consecutive k of one row).
+template <int BI, int BJ, bool X_RS, bool Y_RS, int XF, bool XF_ON_Y, int EPI, bool FAST, int PREC>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
+  static_assert(PREC == HIG_PREC_F32 || (!X_RS && !Y_RS), "bf16 modes need reduce-contiguous operands");
   constexpr int TI = BI / 64, TJ = BJ / 64;
   constexpr int XP = BI / 32, YP = BJ / 32;
-  constexpr int X_TILE = X_RS ? BK * BI : BI * RC_LD;
-  constexpr int Y_TILE = Y_RS ? BK * BJ : BJ * RC_LD;
+  constexpr int NPLANE = PREC == HIG_PREC_BF16X3 ? 2 : 1;
+  constexpr int X_TILE = PREC != HIG_PREC_F32 ? BI * (BF_LD / 2) * NPLANE : (X_RS ? BK * BI : BI * RC_LD);
+  constexpr int Y_TILE = PREC != HIG_PREC_F32 ? BJ * (BF_LD / 2) * NPLANE : (Y_RS ? BK * BJ : BJ * RC_LD);
   constexpr int STAGE = X_TILE + Y_TILE;
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
@@ -167,43 +184,60 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
     }
   }
 
-  // Two register sets for operand staging: tile k+2 is fetched while tile k is multiplied and
-  // tile k+1 (fetched one iteration ago) is written to LDS in the MIDDLE of the MFMA block, so
-  // the barrier that closes the iteration never waits on a global load or a fresh LDS write --
-  // only on wave skew.  (With the write placed right before the barrier every wave idled for
-  // the slowest wave's fetch+write each k-tile: MfmaUtil 46-57 %.)
-  float4 xrA[XP], yrA[YP], xrB[XP], yrB[YP];
-  auto load_tiles = [&](float4 (&xr)[XP], float4 (&yr)[YP], int k0) {
+  // Operand staging registers (global -> registers -> [transform] -> LDS); see `iteration`.
+  // native vector type (not HIP's float4 struct): keeps the arrays in registers (SROA)
+  f32x4 xr[XP], yr[YP];
+  // FAST path: per-thread source pointers live in registers for the whole kernel and advance by
+  // one k-tile per fetch (no per-load address temporaries for the compiler to alias with the
+  // staging registers).  Out-of-range rows are clamped (see ld_*_fast).
+  const float* xptr[XP];
+  const float* yptr[YP];
+  if (FAST) {
+#pragma unroll
+    for (int p = 0; p < XP; ++p)
+      xptr[p] = X_RS ? g.X + (int64_t)(rbeg + x_r + X_RSTEP * p) * g.ldx + min(i0 + 4 * x_c4, g.I - 4)
+                     : g.X + (int64_t)min(i0 + x_r + 32 * p, g.I - 1) * g.ldx + rbeg + 4 * x_c4;
+#pragma unroll
+    for (int p = 0; p < YP; ++p)
+      yptr[p] = Y_RS ? g.Y + (int64_t)(rbeg + y_r + Y_RSTEP * p) * g.ldy + min(j0 + 4 * y_c4, g.J - 4)
+                     : g.Y + (int64_t)min(j0 + y_r + 32 * p, g.J - 1) * g.ldy + rbeg + 4 * y_c4;
+  }
+  const int64_t xstep = X_RS ? (int64_t)BK * g.ldx : BK;
+  const int64_t ystep = Y_RS ? (int64_t)BK * g.ldy : BK;
+  auto load_tiles = [&](int k0) {
+    if (FAST) {  // tiles are fetched in order: the pointers already sit at k0
+#pragma unroll
+      for (int p = 0; p < XP; ++p) {
+        xr[p] = *reinterpret_cast<const f32x4*>(xptr[p]);
+        xptr[p] += xstep;
+      }
+#pragma unroll
+      for (int p = 0; p < YP; ++p) {
+        yr[p] = *reinterpret_cast<const f32x4*>(yptr[p]);
+        yptr[p] += ystep;
+      }
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
-      if (FAST) {
-        if (X_RS)
-          xr[p] = ld_rs_fast(g.X, g.ldx, i0 + 4 * x_c4, g.I, k0 + x_r + X_RSTEP * p);
-        else
-          xr[p] = ld_rc_fast(g.X, g.ldx, i0 + x_r + 32 * p, g.I, k0 + 4 * x_c4);
-      } else {
-        if (X_RS)
-          xr[p] = ld_rs(g.X, g.ldx, i0 + 4 * x_c4, g.I, k0 + x_r + X_RSTEP * p, rend, a.vecx);
-        else
-          xr[p] = ld_rc(g.X, g.ldx, i0 + x_r + 32 * p, g.I, k0 + 4 * x_c4, rend, a.vecx);
-      }
+      float4 t4;
+      if (X_RS)
+        t4 = ld_rs(g.X, g.ldx, i0 + 4 * x_c4, g.I, k0 + x_r + X_RSTEP * p, rend, a.vecx);
+      else
+        t4 = ld_rc(g.X, g.ldx, i0 + x_r + 32 * p, g.I, k0 + 4 * x_c4, rend, a.vecx);
+      xr[p] = f32x4{t4.x, t4.y, t4.z, t4.w};
     }
 #pragma unroll
     for (int p = 0; p < YP; ++p) {
-      if (FAST) {
-        if (Y_RS)
-          yr[p] = ld_rs_fast(g.Y, g.ldy, j0 + 4 * y_c4, g.J, k0 + y_r + Y_RSTEP * p);
-        else
-          yr[p] = ld_rc_fast(g.Y, g.ldy, j0 + y_r + 32 * p, g.J, k0 + 4 * y_c4);
-      } else {
-        if (Y_RS)
-          yr[p] = ld_rs(g.Y, g.ldy, j0 + 4 * y_c4, g.J, k0 + y_r + Y_RSTEP * p, rend, a.vecy);
-        else
-          yr[p] = ld_rc(g.Y, g.ldy, j0 + y_r + 32 * p, g.J, k0 + 4 * y_c4, rend, a.vecy);
-      }
+      float4 t4;
+      if (Y_RS)
+        t4 = ld_rs(g.Y, g.ldy, j0 + 4 * y_c4, g.J, k0 + y_r + Y_RSTEP * p, rend, a.vecy);
+      else
+        t4 = ld_rc(g.Y, g.ldy, j0 + y_r + 32 * p, g.J, k0 + 4 * y_c4, rend, a.vecy);
+      yr[p] = f32x4{t4.x, t4.y, t4.z, t4.w};
     }
   };
-  auto transform = [&](float4 (&xr)[XP], float4 (&yr)[YP], int k0) {
+  auto transform = [&](int k0) {
     if (XF == HIG_XF_NONE) return;
     if (!XF_ON_Y) {
       // activation = X, reduce-contiguous: row m fixed per p, features k0+4c4..
@@ -239,22 +273,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
       }
     }
   };
-  auto store_tiles = [&](const float4 (&xr)[XP], const float4 (&yr)[YP], int buf) {
+  auto split_store = [&](__bf16* plane0, int rows, int row, int c4, const f32x4 v) {
+    // hi = bf16(v) (RNE), lo = bf16(v - hi): 8-byte stores into the hi / lo planes
+    bf16x4 hi = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    *reinterpret_cast<bf16x4*>(plane0 + row * BF_LD + 4 * c4) = hi;
+    if (PREC == HIG_PREC_BF16X3) {
+      bf16x4 lo = {(__bf16)(v.x - (float)hi[0]), (__bf16)(v.y - (float)hi[1]), (__bf16)(v.z - (float)hi[2]),
+                   (__bf16)(v.w - (float)hi[3])};
+      *reinterpret_cast<bf16x4*>(plane0 + rows * BF_LD + row * BF_LD + 4 * c4) = lo;
+    }
+  };
+  auto store_tiles = [&](int buf) {
     float* sx = smem + buf * STAGE;
     float* sy = sx + X_TILE;
+    if (PREC != HIG_PREC_F32) {
+#pragma unroll
+      for (int p = 0; p < XP; ++p) split_store(reinterpret_cast<__bf16*>(sx), BI, x_r + 32 * p, x_c4, xr[p]);
+#pragma unroll
+      for (int p = 0; p < YP; ++p) split_store(reinterpret_cast<__bf16*>(sy), BJ, y_r + 32 * p, y_c4, yr[p]);
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
       if (X_RS)
-        *reinterpret_cast<float4*>(sx + (x_r + X_RSTEP * p) * BI + 4 * x_c4) = xr[p];
+        *reinterpret_cast<f32x4*>(sx + (x_r + X_RSTEP * p) * BI + 4 * x_c4) = xr[p];
       else
-        *reinterpret_cast<float4*>(sx + (x_r + 32 * p) * RC_LD + 4 * x_c4) = xr[p];
+        *reinterpret_cast<f32x4*>(sx + (x_r + 32 * p) * RC_LD + 4 * x_c4) = xr[p];
     }
 #pragma unroll
     for (int p = 0; p < YP; ++p) {
       if (Y_RS)
-        *reinterpret_cast<float4*>(sy + (y_r + Y_RSTEP * p) * BJ + 4 * y_c4) = yr[p];
+        *reinterpret_cast<f32x4*>(sy + (y_r + Y_RSTEP * p) * BJ + 4 * y_c4) = yr[p];
       else
-        *reinterpret_cast<float4*>(sy + (y_r + 32 * p) * RC_LD + 4 * y_c4) = yr[p];
+        *reinterpret_cast<f32x4*>(sy + (y_r + 32 * p) * RC_LD + 4 * y_c4) = yr[p];
     }
   };
 
@@ -272,6 +323,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
   auto mfma_part = [&](int buf, int ks0, int ks1) {
     const float* sx = smem + buf * STAGE;
     const float* sy = sx + X_TILE;
+    if (PREC != HIG_PREC_F32) {
+      // here a "k-group" is one 16-deep bf16 MFMA step; lane: row lr, k = 16*ks + 8*lh .. +7
+      const __bf16* bx = reinterpret_cast<const __bf16*>(sx);
+      const __bf16* by = reinterpret_cast<const __bf16*>(sy);
+#pragma unroll
+      for (int ks = ks0; ks < ks1; ++ks) {
+        bf16x8 xh[TI], xl[TI], yh[TJ], yl[TJ];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+          const __bf16* pp = bx + (xrow + 32 * ti) * BF_LD + 16 * ks + 8 * lh;
+          xh[ti] = *reinterpret_cast<const bf16x8*>(pp);
+          if (PREC == HIG_PREC_BF16X3) xl[ti] = *reinterpret_cast<const bf16x8*>(pp + BI * BF_LD);
+        }
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+          const __bf16* pp = by + (yrow + 32 * tj) * BF_LD + 16 * ks + 8 * lh;
+          yh[tj] = *reinterpret_cast<const bf16x8*>(pp);
+          if (PREC == HIG_PREC_BF16X3) yl[tj] = *reinterpret_cast<const bf16x8*>(pp + BJ * BF_LD);
+        }
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti) {
+            if (PREC == HIG_PREC_BF16X3) {  // small cross terms first, then the leading term
+              acc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[tj], xh[ti], acc[tj][ti], 0, 0, 0);
+              acc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[tj], xl[ti], acc[tj][ti], 0, 0, 0);
+            }
+            acc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[tj], xh[ti], acc[tj][ti], 0, 0, 0);
+          }
+      }
+      return;
+    }
 #pragma unroll
     for (int ks = ks0; ks < ks1; ++ks) {
       float xf[TI][4], yf[TJ][4];
@@ -304,30 +387,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
             acc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[tj][j], xf[ti][j], acc[tj][ti], 0, 0, 0);
     }
   };
-  // One k-tile: `nxt` holds tile kt+1 (fetched an iteration ago), `ld` receives tile kt+2.
-  auto iteration = [&](int kt, int nk, int buf, float4 (&xn)[XP], float4 (&yn)[YP], float4 (&xl)[XP],
-                       float4 (&yl)[YP]) {
-    if (kt + 2 < nk) load_tiles(xl, yl, rbeg + (kt + 2) * BK);
-    mfma_part(buf, 0, BK / 16);
+  // One k-tile.  On entry the staging registers hold tile kt+1, fetched at the start of the
+  // PREVIOUS iteration (a whole MFMA block ago).  Order: (1) transform + write them to the other
+  // LDS buffer (free since the barrier that ended iteration kt-1), (2) re-issue the same
+  // registers as the fetch of tile kt+2, (3) the MFMA block on the current buffer, (4) barrier.
+  // The only global-memory wait is on loads that had a full MFMA block to land, the LDS writes
+  // have a full MFMA block before the barrier, and one register set suffices.
+  auto iteration = [&](int kt, int nk, int buf) {
+    constexpr int NG = PREC != HIG_PREC_F32 ? BK / 16 : BK / 8;  // k-groups per tile
     if (kt + 1 < nk) {
-      transform(xn, yn, rbeg + (kt + 1) * BK);
-      store_tiles(xn, yn, buf ^ 1);
+      transform(rbeg + (kt + 1) * BK);
+      store_tiles(buf ^ 1);
     }
-    mfma_part(buf, BK / 16, BK / 8);
+    if (kt + 2 < nk) load_tiles(rbeg + (kt + 2) * BK);
+    mfma_part(buf, 0, NG);
     __syncthreads();
   };
 
   const int nk = (rend - rbeg + BK - 1) / BK;
   if (nk > 0) {
-    load_tiles(xrA, yrA, rbeg);
-    if (nk > 1) load_tiles(xrB, yrB, rbeg + BK);
-    transform(xrA, yrA, rbeg);
-    store_tiles(xrA, yrA, 0);
+    load_tiles(rbeg);
+    transform(rbeg);
+    store_tiles(0);
+    if (nk > 1) load_tiles(rbeg + BK);
   }
   __syncthreads();
   for (int kt = 0; kt < nk; kt += 2) {
-    iteration(kt, nk, 0, xrB, yrB, xrA, yrA);
-    if (kt + 1 < nk) iteration(kt + 1, nk, 1, xrA, yrA, xrB, yrB);
+    iteration(kt, nk, 0);
+    if (kt + 1 < nk) iteration(kt + 1, nk, 1);
   }
 
   // ---- epilogue: lane holds, per accumulator quad q, columns j..j+3 of row i ----------
@@ -443,12 +530,28 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
   const bool fast = a.vecx && a.vecy && (g.R % BK == 0) && g.R > 0 &&
                     (!X_RS || (g.I % 4 == 0 && g.I >= 4)) && (!Y_RS || (g.J % 4 == 0 && g.J >= 4));
   if (a.ntiles > 0 && g.R >= 0) {
+    // the bf16 product modes exist for aligned reduce-contiguous operands; anything else
+    // (F = 150 projections, dgrad / wgrad layouts) runs the exact fp32 kernel
+    if constexpr (!X_RS && !Y_RS) {
+      if (fast && g.prec == HIG_PREC_BF16X3) {
+        hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, true, HIG_PREC_BF16X3>),
+                           dim3(a.ntiles, splits), dim3(NTHREADS), 0, st, a);
+        HIG_CHECK_LAUNCH();
+        return HIG_OK;
+      }
+      if (fast && g.prec == HIG_PREC_BF16) {
+        hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, true, HIG_PREC_BF16>),
+                           dim3(a.ntiles, splits), dim3(NTHREADS), 0, st, a);
+        HIG_CHECK_LAUNCH();
+        return HIG_OK;
+      }
+    }
     if (fast)
-      hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, true>), dim3(a.ntiles, splits),
-                         dim3(NTHREADS), 0, st, a);
+      hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, true, HIG_PREC_F32>),
+                         dim3(a.ntiles, splits), dim3(NTHREADS), 0, st, a);
     else
-      hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, false>), dim3(a.ntiles, splits),
-                         dim3(NTHREADS), 0, st, a);
+      hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, false, HIG_PREC_F32>),
+                         dim3(a.ntiles, splits), dim3(NTHREADS), 0, st, a);
   }
   HIG_CHECK_LAUNCH();
   if (splits > 1) {
@@ -473,7 +576,11 @@ int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab,
     return launch<64, 64, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
   }
   struct Cand { int bi, bj; double ovh; };
-  const Cand cands[4] = {{128, 128, 1.00}, {64, 128, 1.02}, {128, 64, 1.03}, {64, 64, 1.04}};
+  // measured (tools/gemm_bench.py): with 64-cycle fp32 MFMAs small tiles cost almost nothing;
+  // with the 16x faster bf16 MFMAs the extra LDS/L2 traffic of small tiles shows (x1.1-1.2)
+  const bool bf = g.prec != HIG_PREC_F32;
+  const Cand cands[4] = {{128, 128, 1.00}, {64, 128, bf ? 1.10 : 1.02}, {128, 64, bf ? 1.12 : 1.03},
+                         {64, 64, bf ? 1.20 : 1.04}};
   int best = 0;
   double best_cost = 1e300;
   static const int forced = getenv("HIG_GEMM_TILE") ? atoi(getenv("HIG_GEMM_TILE")) : -1;  // tuning knob
@@ -514,6 +621,10 @@ int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_
   if (g.x_rs == xrs && g.y_rs == yrs && g.xf == xfv && (g.xf == HIG_XF_NONE || g.xf_on_y == ony) && \
       g.epi == epiv)                                                                     \
     return launch_sized<xrs, yrs, xfv, ony, epiv>(g, splits, slabs, slab, st);
+#ifdef HIG_GEMM_PROBE  // compile-time aid: build a single combination
+  CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_BIAS_GELU)
+  return HIG_EUNSUPPORTED;
+#endif
   // forward (activations x weight^T)
   CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_NONE)
   CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_BIAS)
@@ -540,6 +651,7 @@ int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_
 
 extern "C" int hig_gemm(const hig_gemm_desc* g, hig_stream_t stream) {
   HIG_REQUIRE(g, "hig_gemm: null descriptor");
-  HIG_REQUIRE(g->prec == HIG_PREC_F32, "hig_gemm: only HIG_PREC_F32 is built in this round");
+  HIG_REQUIRE(g->prec == HIG_PREC_F32 || g->prec == HIG_PREC_BF16X3 || g->prec == HIG_PREC_BF16,
+              "hig_gemm: unknown prec %d", g->prec);
   return hig_gemm_launch(*g, 1, nullptr, hig_stream(stream));
 }

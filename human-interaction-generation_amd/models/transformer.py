@@ -306,6 +306,10 @@ class MotionTransformer(nn.Module):
             for _ in range(num_layers))
         self.out = zero_module(nn.Linear(self.latent_dim, self.input_feats))
 
+        # product arithmetic of the forward GEMMs: "f32" (exact fp32 MFMA, default), "bf16x3"
+        # (split-bf16, ~1e-5 relative, 16x-rate MFMA) or "bf16"; HIG_PREC overrides the default
+        import os
+        self.precision = kargs.get("precision", os.environ.get("HIG_PREC", "f32"))
         self._flat = None
         self._pool = _WorkspacePool()
         self._textctx_cache = None
@@ -358,7 +362,7 @@ class MotionTransformer(nn.Module):
                          ff=self.ff_size, L=self.num_layers, N=N, Lt=self.text_latent_dim,
                          num_frames=self.num_frames,
                          attn_kind=_lib.ATTN_FULL if self.no_eff else _lib.ATTN_LINEAR,
-                         prec=_lib.PREC_F32)
+                         prec={"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16": _lib.PREC_BF16}[self.precision])
 
     def forward(self, x, timesteps, length=None, text=None, xf_proj=None, xf_out=None):
         """x: (B, T, F) -> (B, T, F)   (transformer.py:407-426)."""
@@ -394,7 +398,7 @@ class MotionTransformer(nn.Module):
         parameter version, so the 1000-step sampling loop computes it once (it is step-invariant)."""
         fp = self.flat_params()
         key = (xf_out.data_ptr(), xf_out._version, tuple(xf_out.shape), fp.flat.data_ptr(),
-               fp.flat._version, bool(training))
+               fp.flat._version, bool(training), self.precision)
         if not training and self._textctx_cache is not None and self._textctx_cache[0] == key:
             return self._textctx_cache[1]
         L = _lib.lib()

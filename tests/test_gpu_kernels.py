@@ -40,14 +40,15 @@ def P(t):
 
 
 def gemm(X, Y, I, J, R, x_rs=0, y_rs=0, xf=0, xf_on_y=0, epi=0, bias=None, res=None, aux=None,
-         stats=None, gamma=None, beta=None, ss=None, ss_shift_off=0, rows_per_sample=0, pos=None, T=0):
+         stats=None, gamma=None, beta=None, ss=None, ss_shift_off=0, rows_per_sample=0, pos=None, T=0,
+         prec=0):
     out = torch.full((I, J), float("nan"), device=DEV)
     d = _lib.GemmDesc()
     d.X, d.ldx, d.x_rs = P(X), X.stride(0), x_rs
     d.Y, d.ldy, d.y_rs = P(Y), Y.stride(0), y_rs
     d.C, d.ldc = P(out), J
     d.I, d.J, d.R = I, J, R
-    d.xf, d.xf_on_y, d.epi, d.prec = xf, xf_on_y, epi, _lib.PREC_F32
+    d.xf, d.xf_on_y, d.epi, d.prec = xf, xf_on_y, epi, prec
     d.bias = P(bias)
     if res is not None:
         d.res, d.ldr = P(res), res.stride(0)
@@ -75,6 +76,30 @@ def test_gemm_forward_bias(I, J, R):
     out = gemm(X.to(DEV), Y.to(DEV), I, J, R, epi=_lib.EPI_BIAS, bias=b.to(DEV))
     ref = X.double() @ Y.double().T + b.double()
     assert rel(out, ref) < 2e-6  # fp32 MFMA, fp32 accumulate
+
+
+@pytest.mark.parametrize("I,J,R", [(256, 256, 512), (12544 // 8, 1024, 512), (300, 1536, 512), (70, 64, 2048)])
+def test_gemm_split_bf16_modes(I, J, R):
+    """HIG_PREC_BF16X3: hi/lo split of both operands, 3 bf16 MFMAs, fp32 accumulate -> ~2^-16
+    per product; HIG_PREC_BF16: single product (bf16 rounding of the operands)."""
+    X, Y, b = rnd(I, R), rnd(J, R, seed=1), rnd(J, seed=2)
+    ref = X.double() @ Y.double().T + b.double()
+    out3 = gemm(X.to(DEV), Y.to(DEV), I, J, R, epi=_lib.EPI_BIAS, bias=b.to(DEV), prec=_lib.PREC_BF16X3)
+    assert rel(out3, ref) < 2e-5
+    out1 = gemm(X.to(DEV), Y.to(DEV), I, J, R, epi=_lib.EPI_BIAS, bias=b.to(DEV), prec=_lib.PREC_BF16)
+    assert 1e-4 < rel(out1, ref) < 1e-2
+    # bf16-representable small integers are exact in both modes
+    g = torch.Generator().manual_seed(5)
+    Xi = torch.randint(-8, 9, (I, R), generator=g).float()
+    Yi = torch.randint(-8, 9, (J, R), generator=g).float()
+    for prec in (_lib.PREC_BF16X3, _lib.PREC_BF16):
+        assert torch.equal(gemm(Xi.to(DEV), Yi.to(DEV), I, J, R, prec=prec).cpu(), Xi @ Yi.T)
+    # fused prologue + epilogue still apply
+    gm, be = 1 + 0.1 * rnd(R, seed=3), 0.1 * rnd(R, seed=4)
+    out = gemm(X.to(DEV), Y.to(DEV), I, J, R, xf=_lib.XF_LN, epi=_lib.EPI_BIAS, bias=b.to(DEV),
+               stats=stats_of(X).to(DEV), gamma=gm.to(DEV), beta=be.to(DEV), prec=_lib.PREC_BF16X3)
+    refln = F.linear(F.layer_norm(X.double(), (R,), gm.double(), be.double()), Y.double(), b.double())
+    assert rel(out, refln) < 2e-5
 
 
 def test_gemm_exact_small_integers():

@@ -23,7 +23,7 @@ def run(M, N, K, xf, epi, reps=20):
     ss = torch.randn(M // 196 + 1, 2 * K, device=dev) * 0.1
     d = _lib.GemmDesc()
     d.X, d.ldx, d.Y, d.ldy, d.C, d.ldc = X.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), N
-    d.I, d.J, d.R, d.xf, d.epi, d.prec = M, N, K, xf, epi, 0
+    d.I, d.J, d.R, d.xf, d.epi, d.prec = M, N, K, xf, epi, int(os.environ.get("PREC", 0))
     d.bias, d.res, d.ldr = b.data_ptr(), res.data_ptr(), N
     d.stats, d.gamma, d.beta = st.data_ptr(), g.data_ptr(), be.data_ptr()
     d.ss, d.ss_ld, d.ss_shift_off, d.rows_per_sample = ss.data_ptr(), 2 * K, K, 196
@@ -49,5 +49,5 @@ if __name__ == "__main__":
               ("ffn2 bias", 512, 1024, _lib.XF_NONE, _lib.EPI_BIAS)]
     for name, N, K, xf, epi in shapes:
         ms, tf = run(M, N, K, xf, epi)
-        print("tile=%s M=%d %-14s N=%4d K=%4d  %.3f ms  %.1f TFLOP/s" %
-              (os.environ.get("HIG_GEMM_TILE", "auto"), M, name, N, K, ms, tf))
+        print("prec=%s tile=%s M=%d %-14s N=%4d K=%4d  %.3f ms  %.1f TFLOP/s" %
+              (os.environ.get("PREC", "0"), os.environ.get("HIG_GEMM_TILE", "auto"), M, name, N, K, ms, tf))

@@ -1,0 +1,95 @@
+// Micro-probe (tuning aid): how close can a wave-level loop get to the fp32 MFMA peak when we add,
+// one at a time, the ingredients of the GEMM main loop?  hipcc --offload-arch=gfx950 -O3.
+//   variant 0: bare v_mfma_f32_32x32x2_f32 chain(s)
+//   variant 1: + 2 ds_read_b128 per 4 MFMAs (operands from LDS)
+//   variant 2: + one __syncthreads per 16 MFMAs
+//   variant 3: + 4 global_load_dwordx4 + 4 ds_write_b128 per 16 MFMAs (full staging traffic)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int VARIANT, int NACC>
+__global__ __launch_bounds__(256) void probe(const float* __restrict__ g, float* __restrict__ out, int iters) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2 * 64 * 36];
+  const int tid = threadIdx.x, lane = tid & 63;
+  f32x16 acc[NACC];
+  for (int a = 0; a < NACC; ++a)
+    for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+  for (int i = tid; i < 2 * 2 * 64 * 36; i += 256) (&lds[0][0])[i] = (float)(i & 7);
+  __syncthreads();
+  float4 stage[4];
+  const float* gp = g + (size_t)blockIdx.x * 4096 + tid * 4;
+  float xa = 1.0f + lane, xb = 0.5f;
+  for (int it = 0; it < iters; ++it) {
+    const float* sx = lds[it & 1];
+    if (VARIANT >= 3) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) stage[p] = *reinterpret_cast<const float4*>(gp + ((it * 4 + p) & 63) * 1024);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float xf[4], yf[4];
+      if (VARIANT >= 1) {
+        const float4 a4 = *reinterpret_cast<const float4*>(sx + (lane & 31) * 36 + ks * 8 + 4 * (lane >> 5));
+        const float4 b4 = *reinterpret_cast<const float4*>(sx + 64 * 36 + (lane & 31) * 36 + ks * 8 + 4 * (lane >> 5));
+        xf[0] = a4.x; xf[1] = a4.y; xf[2] = a4.z; xf[3] = a4.w;
+        yf[0] = b4.x; yf[1] = b4.y; yf[2] = b4.z; yf[3] = b4.w;
+      } else {
+        xf[0] = xf[1] = xf[2] = xf[3] = xa;
+        yf[0] = yf[1] = yf[2] = yf[3] = xb;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[j], xf[j], acc[a], 0, 0, 0);
+    }
+    if (VARIANT >= 3) {
+      float* dst = lds[(it + 1) & 1];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(dst + ((tid >> 3) + 32 * p) * 36 + 4 * (tid & 7)) = stage[p];
+    }
+    if (VARIANT >= 2) __syncthreads();
+  }
+  float s = 0.f;
+  for (int a = 0; a < NACC; ++a)
+    for (int e = 0; e < 16; ++e) s += acc[a][e];
+  out[(size_t)blockIdx.x * 256 + tid] = s;
+}
+
+template <int V, int NACC>
+void run(const char* name, int blocks, const float* g, float* out) {
+  const int iters = 2000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL((probe<V, NACC>), dim3(blocks), dim3(256), 0, 0, g, out, 10);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((probe<V, NACC>), dim3(blocks), dim3(256), 0, 0, g, out, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double flops = (double)blocks * 4 /*waves*/ * iters * 16 * NACC * 4096.0;
+  printf("%-34s blocks=%5d acc/wave=%d  %.3f ms  %.1f TFLOP/s\n", name, blocks, NACC, ms, flops / ms / 1e9);
+}
+
+int main() {
+  float *g, *out;
+  hipMalloc(&g, (size_t)4096 * 4096 * 4);
+  hipMemset(g, 0, (size_t)4096 * 4096 * 4);
+  hipMalloc(&out, (size_t)4096 * 256 * 4);
+  for (int bpc = 1; bpc <= 4; ++bpc) {
+    const int blocks = 256 * bpc;
+    printf("--- %d block(s) of 4 waves per CU\n", bpc);
+    run<0, 1>("bare mfma", blocks, g, out);
+    run<0, 4>("bare mfma", blocks, g, out);
+    run<1, 1>("+ds_read_b128", blocks, g, out);
+    run<1, 4>("+ds_read_b128", blocks, g, out);
+    run<2, 1>("+barrier/16 mfma", blocks, g, out);
+    run<2, 4>("+barrier/64 mfma", blocks, g, out);
+    run<3, 1>("+global load + ds_write", blocks, g, out);
+    run<3, 4>("+global load + ds_write", blocks, g, out);
+  }
+  return 0;
+}
