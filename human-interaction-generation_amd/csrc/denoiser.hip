@@ -41,7 +41,7 @@ __global__ void mul_dsilu_kernel(const float* __restrict__ a, const float* __res
 inline int64_t al(int64_t floats) { return (floats + 63) & ~(int64_t)63; }  // 256-byte granules
 
 struct Dims {
-  int B, T, F, d, H, ff, L, N, Lt, nf, hd, E, prec;
+  int B, T, F, d, H, ff, L, N, Lt, nf, hd, E, prec, full;
   int64_t M, Mt;
 };
 
@@ -59,8 +59,11 @@ int check_dims(const hig_dims* p, Dims& D) {
   HIG_REQUIRE(D.d % 4 == 0 && D.ff % 4 == 0 && D.Lt % 4 == 0, "hig_dims: d, ff, Lt must be multiples of 4");
   HIG_REQUIRE(D.d <= 1024 && D.Lt <= 1024, "hig_dims: d and Lt must be <= 1024");
   HIG_REQUIRE(D.T <= D.nf, "hig_dims: T=%d exceeds num_frames=%d", D.T, D.nf);
-  if (p->attn_kind != HIG_ATTN_LINEAR)
-    return hig_set_error(HIG_EUNSUPPORTED, "hig: attn_kind=%d (no_eff) kernels are not built yet", p->attn_kind);
+  HIG_REQUIRE(p->attn_kind == HIG_ATTN_LINEAR || p->attn_kind == HIG_ATTN_FULL, "hig_dims: unknown attn_kind=%d",
+              p->attn_kind);
+  D.full = p->attn_kind == HIG_ATTN_FULL;
+  if (D.full && D.hd > 64)
+    return hig_set_error(HIG_EUNSUPPORTED, "hig: full (no_eff) attention supports head dim <= 64 (got %d)", D.hd);
   if (p->prec != HIG_PREC_F32 && p->prec != HIG_PREC_BF16X3 && p->prec != HIG_PREC_BF16)
     return hig_set_error(HIG_EINVAL, "hig: unknown prec=%d", p->prec);
   D.prec = p->prec;
@@ -73,7 +76,7 @@ int check_dims(const hig_dims* p, Dims& D) {
 struct FwdLayout {
   int64_t te, te_h, emb, ss, h0;
   int64_t layer0, lstride;
-  int64_t st1, qkv, A1, kst1, y1, st2, a1, h1, st3, qc, y2, st4, a2, h2, z1, f1, y3, st5, a3, h3;
+  int64_t st1, qkv, A1, kst1, lse1, y1, st2, a1, h1, st3, qc, lse2, y2, st4, a2, h2, z1, f1, y3, st5, a3, h3;
   int64_t total;
 };
 FwdLayout fwd_layout(const Dims& D, int training) {
@@ -91,12 +94,14 @@ FwdLayout fwd_layout(const Dims& D, int training) {
   w.qkv = take(D.M * 3 * D.d);
   w.A1 = take((int64_t)D.B * D.H * D.hd * D.hd);
   w.kst1 = take((int64_t)D.B * D.d * 2);
+  w.lse1 = take((int64_t)D.B * D.H * D.T);  // full attention: log-sum-exp per (b, h, query)
   w.y1 = take(D.M * D.d);
   w.st2 = take(D.M * 2);
   w.a1 = take(D.M * D.d);
   w.h1 = take(D.M * D.d);
   w.st3 = take(D.M * 2);
   w.qc = take(D.M * D.d);
+  w.lse2 = take((int64_t)D.B * D.H * D.T);
   w.y2 = take(D.M * D.d);
   w.st4 = take(D.M * 2);
   w.a2 = take(D.M * D.d);
@@ -128,13 +133,16 @@ TextLayout text_layout(const Dims& D, int training) {
   t.kstc = take((int64_t)D.B * D.d * 2);
   t.lstride = o;
   t.kv = t.layer0 + t.lstride * D.L;
-  t.kv_stride = training ? al(D.Mt * 2 * D.d) : 0;
-  t.total = t.kv + (training ? t.kv_stride * D.L : al(D.Mt * 2 * D.d));
+  // linear attention needs key/value only to build A_c (kept per layer just for backward);
+  // full attention reads them at every step
+  const bool keep = training || D.full;
+  t.kv_stride = keep ? al(D.Mt * 2 * D.d) : 0;
+  t.total = t.kv + (keep ? t.kv_stride * D.L : al(D.Mt * 2 * D.d));
   return t;
 }
 
 struct BwdLayout {
-  int64_t dhA, dhB, t1, t2, tff, dqkv, dA, dkv, dxfn, dss, demb, dtmp, dte_h, slabs, slab_floats,
+  int64_t dhA, dhB, t1, t2, tff, dqkv, dA, delta, dkv, dxfn, dss, demb, dtmp, dte_h, slabs, slab_floats,
       colpart, lnpart, total;
 };
 BwdLayout bwd_layout(const Dims& D) {
@@ -148,6 +156,7 @@ BwdLayout bwd_layout(const Dims& D) {
   w.tff = take(D.M * D.ff);
   w.dqkv = take(D.M * 3 * D.d);
   w.dA = take((int64_t)D.B * D.H * D.hd * D.hd);
+  w.delta = take((int64_t)D.B * D.H * D.T);
   w.dkv = take(D.Mt * 2 * D.d);
   w.dxfn = take(D.Mt * D.Lt);
   w.dss = take((int64_t)D.B * 3 * D.L * 2 * D.d);
@@ -254,8 +263,9 @@ extern "C" int hig_text_context(const hig_dims* dims, const void* const* params,
     HIG_TRY(hig_gemm_launch(G(xf_out, D.Lt, 0, PL(params, l, HIG_L_CA_KV_W), D.Lt, 0, kv, 2 * D.d, D.Mt, 2 * D.d, D.Lt)
                                 .ln(0, stt, PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B))
                                 .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_KV_B)).prec(D.prec).g, 1, nullptr, st));
-    // softmax over the N text tokens (no mask) and A = k^T v   (transformer.py:148,152)
-    HIG_TRY(hig_linattn_ctx(kv, kv + D.d, 2 * D.d, D.B, D.N, D.H, D.hd, nullptr, Ac, kstc, stream));
+    // linear attention: softmax over the N text tokens (no mask) and A = k^T v (transformer.py:148,152);
+    // full attention (:253-259) consumes key/value directly
+    if (!D.full) HIG_TRY(hig_linattn_ctx(kv, kv + D.d, 2 * D.d, D.B, D.N, D.H, D.hd, nullptr, Ac, kstc, stream));
   }
   return HIG_OK;
 }
@@ -297,9 +307,14 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
     HIG_TRY(hig_gemm_launch(G(hin, d, 0, PL(params, l, HIG_L_SA_QKV_W), d, 0, lb + w.qkv, 3 * d, M, 3 * d, d)
                                 .ln(0, lb + w.st1, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B))
                                 .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_SA_QKV_B)).prec(D.prec).g, 1, nullptr, st));
-    HIG_TRY(hig_linattn_ctx(lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, length,
-                            lb + w.A1, lb + w.kst1, stream));
-    HIG_TRY(hig_linattn_apply(lb + w.qkv, 3 * d, lb + w.A1, lb + w.y1, d, D.B, D.T, D.H, D.hd, stream));
+    if (D.full) {
+      HIG_TRY(hig_fullattn_fwd(lb + w.qkv, 3 * d, lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, D.B, D.T, D.T, D.H, D.hd,
+                               length, lb + w.y1, d, lb + w.lse1, stream));
+    } else {
+      HIG_TRY(hig_linattn_ctx(lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, length,
+                              lb + w.A1, lb + w.kst1, stream));
+      HIG_TRY(hig_linattn_apply(lb + w.qkv, 3 * d, lb + w.A1, lb + w.y1, d, D.B, D.T, D.H, D.hd, stream));
+    }
     HIG_TRY(hig_ln_mod_silu(lb + w.y1, d, M, d, PL(params, l, HIG_L_SA_STY_NORM_W), PL(params, l, HIG_L_SA_STY_NORM_B),
                             ssl, ss_ld, d, D.T, lb + w.a1, d, lb + w.st2, stream));
     HIG_TRY(hig_gemm_launch(G(lb + w.a1, d, 0, PL(params, l, HIG_L_SA_STY_OUT_W), d, 0, lb + w.h1, d, M, d, d)
@@ -309,8 +324,14 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
     HIG_TRY(hig_gemm_launch(G(lb + w.h1, d, 0, PL(params, l, HIG_L_CA_Q_W), d, 0, lb + w.qc, d, M, d, d)
                                 .ln(0, lb + w.st3, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B))
                                 .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).prec(D.prec).g, 1, nullptr, st));
-    HIG_TRY(hig_linattn_apply(lb + w.qc, d, tc + tl.layer0 + tl.lstride * l + tl.Ac, lb + w.y2, d, D.B, D.T,
-                              D.H, D.hd, stream));
+    if (D.full) {
+      const float* kvl = tc + tl.kv + tl.kv_stride * l;
+      HIG_TRY(hig_fullattn_fwd(lb + w.qc, d, kvl, kvl + d, 2 * d, D.B, D.T, D.N, D.H, D.hd, nullptr, lb + w.y2, d,
+                               lb + w.lse2, stream));
+    } else {
+      HIG_TRY(hig_linattn_apply(lb + w.qc, d, tc + tl.layer0 + tl.lstride * l + tl.Ac, lb + w.y2, d, D.B, D.T,
+                                D.H, D.hd, stream));
+    }
     HIG_TRY(hig_ln_mod_silu(lb + w.y2, d, M, d, PL(params, l, HIG_L_CA_STY_NORM_W), PL(params, l, HIG_L_CA_STY_NORM_B),
                             ssl + 2 * d, ss_ld, d, D.T, lb + w.a2, d, lb + w.st4, stream));
     HIG_TRY(hig_gemm_launch(G(lb + w.a2, d, 0, PL(params, l, HIG_L_CA_STY_OUT_W), d, 0, lb + w.h2, d, M, d, d)
@@ -409,7 +430,12 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
     const float* Ac = tc + tl.layer0 + tl.lstride * l + tl.Ac;
     const float* kstc = tc + tl.layer0 + tl.lstride * l + tl.kstc;
     const float* kv = tc + tl.kv + tl.kv_stride * l;
-    HIG_TRY(hig_linattn_apply_bwd(b + bw.t2, d, lb + w.qc, d, Ac, b + bw.t1, d, b + bw.dA, D.B, D.T, D.H, D.hd, stream));
+    if (D.full)
+      HIG_TRY(hig_fullattn_bwd(b + bw.t2, d, lb + w.y2, d, lb + w.qc, d, kv, kv + d, 2 * d, D.B, D.T, D.N, D.H, D.hd,
+                               nullptr, lb + w.lse2, b + bw.delta, b + bw.t1, d, b + bw.dkv, b + bw.dkv + d, 2 * d,
+                               stream));
+    else
+      HIG_TRY(hig_linattn_apply_bwd(b + bw.t2, d, lb + w.qc, d, Ac, b + bw.t1, d, b + bw.dA, D.B, D.T, D.H, D.hd, stream));
     const float* dqc = b + bw.t1;
     HIG_TRY(colsum(dqc, d, M, d, GL(grads, l, HIG_L_CA_Q_B)));
     HIG_TRY(wgrad(G(dqc, d, 1, lb + w.h1, d, 1, GL(grads, l, HIG_L_CA_Q_W), d, d, d, M)
@@ -420,8 +446,9 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                        GL(grads, l, HIG_L_CA_NORM_W), GL(grads, l, HIG_L_CA_NORM_B), nullptr, 0, lnp, stream));
     { float* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h1)
     // text side of this layer: d(A_c) -> d(key,value) -> text_norm -> d(xf_out)
-    HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, kv, kv + d, 2 * d, kstc, nullptr, b + bw.dkv, b + bw.dkv + d, 2 * d, D.B,
-                                D.N, D.H, D.hd, stream));
+    if (!D.full)
+      HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, kv, kv + d, 2 * d, kstc, nullptr, b + bw.dkv, b + bw.dkv + d, 2 * d, D.B,
+                                  D.N, D.H, D.hd, stream));
     HIG_TRY(colsum(b + bw.dkv, 2 * d, Mt, 2 * d, GL(grads, l, HIG_L_CA_KV_B)));
     HIG_TRY(wgrad(G(b + bw.dkv, 2 * d, 1, xf_out, Lt, 1, GL(grads, l, HIG_L_CA_KV_W), Lt, 2 * d, Lt, Mt)
                       .ln(1, tc + tl.stt, PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B))));
@@ -435,10 +462,16 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
     HIG_TRY(sty_bwd(l, 3 * l, dh, lb + w.y1, lb + w.a1, lb + w.st2, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B,
                     HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B, b + bw.t2));
     float* dqkv = b + bw.dqkv;
-    HIG_TRY(hig_linattn_apply_bwd(b + bw.t2, d, lb + w.qkv, 3 * d, lb + w.A1, dqkv, 3 * d, b + bw.dA, D.B, D.T, D.H,
-                                  D.hd, stream));
-    HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, lb + w.kst1, length, dqkv + d,
-                                dqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, stream));
+    if (D.full) {
+      HIG_TRY(hig_fullattn_bwd(b + bw.t2, d, lb + w.y1, d, lb + w.qkv, 3 * d, lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d,
+                               D.B, D.T, D.T, D.H, D.hd, length, lb + w.lse1, b + bw.delta, dqkv, 3 * d, dqkv + d,
+                               dqkv + 2 * d, 3 * d, stream));
+    } else {
+      HIG_TRY(hig_linattn_apply_bwd(b + bw.t2, d, lb + w.qkv, 3 * d, lb + w.A1, dqkv, 3 * d, b + bw.dA, D.B, D.T, D.H,
+                                    D.hd, stream));
+      HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, lb + w.kst1, length, dqkv + d,
+                                  dqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, stream));
+    }
     HIG_TRY(colsum(dqkv, 3 * d, M, 3 * d, GL(grads, l, HIG_L_SA_QKV_B)));
     HIG_TRY(wgrad(G(dqkv, 3 * d, 1, hin, d, 1, GL(grads, l, HIG_L_SA_QKV_W), d, 3 * d, d, M)
                       .ln(1, lb + w.st1, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B))));

@@ -225,16 +225,11 @@ class DDPMTrainer(object):
             }
         return self._fused
 
-    def train_step_fused(self, x_start, t, length, xf_proj, xf_out, noise=None, lr=None):
-        """One DDPM training step on device tensors, reference semantics
-        (ddpm_trainer.py:97-119,172-187) for the denoiser-core parameters:
-          x_t = q_sample(x0, t, noise); pred = denoiser(x_t, t); loss = masked MSE(pred, noise);
-          backward; grads = all_reduce(grads) / world; clip_grad_norm_(0.5); Adam.
-        No host synchronisation: the loss stays on the device (`fused_state()['loss']`)."""
+    def _fused_fwd_bwd(self, x_start, t, length, xf_proj, xf_out, noise):
+        """q_sample -> denoiser forward -> masked MSE -> denoiser backward into the flat gradient."""
         core = _core(self.encoder)
         L = _lib.lib()
         st = self.fused_state()
-        fp = core.flat_params()
         B, T, F = x_start.shape
         if noise is None:
             noise = torch.randn_like(x_start)
@@ -245,7 +240,13 @@ class DDPMTrainer(object):
                                     _lib.ptr(st["loss"]), _lib.ptr(dpred), _lib.ptr(st["mse_scratch"]),
                                     _lib.stream_ptr()))
         core._launch_backward(x_t, t, length, xf_out, saved, dpred, want_dx=False)
-        world = st["allreduce"](fp.grad)                       # sum over ranks (RCCL, xGMI)
+
+    def _fused_clip_adam(self, world, lr):
+        """g /= world; clip_grad_norm_(0.5); Adam -- one norm pass + one update pass over the flat buffers."""
+        core = _core(self.encoder)
+        L = _lib.lib()
+        st = self.fused_state()
+        fp = core.flat_params()
         n = fp.numel
         _lib.check(L.hig_sumsq_partial(_lib.ptr(fp.grad), n, 1.0 / world, _lib.ptr(st["scratch"]),
                                        _lib.stream_ptr()))
@@ -254,4 +255,79 @@ class DDPMTrainer(object):
                                    1.0 / world, _lib.ptr(st["scratch"]), _lib.ptr(st["gnorm"]),
                                    _lib.ptr(st["step"]), _lib.stream_ptr()))
         core._textctx_cache = None  # parameters changed under the cached text context
+
+    def train_step_fused(self, x_start, t, length, xf_proj, xf_out, noise=None, lr=None):
+        """One DDPM training step on device tensors, reference semantics
+        (ddpm_trainer.py:97-119,172-187) for the denoiser-core parameters:
+          x_t = q_sample(x0, t, noise); pred = denoiser(x_t, t); loss = masked MSE(pred, noise);
+          backward; grads = all_reduce(grads) / world; clip_grad_norm_(0.5); Adam.
+        No host synchronisation: the loss stays on the device (`fused_state()['loss']`)."""
+        st = self.fused_state()
+        self._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise)
+        world = st["allreduce"](_core(self.encoder).flat_params().grad)      # sum over ranks (RCCL, xGMI)
+        self._fused_clip_adam(world, lr)
+        return st["loss"]
+
+    def train_step_captured(self, x_start, t, length, xf_proj, xf_out, noise=None, lr=None):
+        """The same step as hipGraphs.  Captured once per batch shape: graph A = q_sample + forward
+        + loss + backward, graph B = clip + Adam; the RCCL all-reduce of the flat gradient runs
+        between them on the same stream (world == 1: A and B are one graph).  Inputs are copied
+        into static device buffers, so the host cost per step is two graph launches whatever the
+        ~600 kernels inside; `t` arrives from the host sampler through the same staging copy
+        (the reference draws it with numpy, gaussian_diffusion.py:47-62)."""
+        st = self.fused_state()
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        key = (tuple(x_start.shape), tuple(xf_out.shape), noise is None, world, lr)
+        cap = st.setdefault("graphs", {}).get(key)
+        if cap is None:
+            static = {"x0": x_start.clone(), "t": t.clone(), "length": length.clone(),
+                      "xf_proj": xf_proj.clone(), "xf_out": xf_out.clone(),
+                      "noise": None if noise is None else noise.clone()}
+
+            def part_a():
+                self._fused_fwd_bwd(static["x0"], static["t"], static["length"], static["xf_proj"],
+                                    static["xf_out"], static["noise"])
+
+            # warm-up (allocations, workspace pools) on a side stream, as torch.cuda.graph requires;
+            # it runs a real step, so restore parameters / moments / step counter afterwards
+            core = _core(self.encoder)
+            fp = core.flat_params()
+            keep = (fp.flat.clone(), st["m"].clone(), st["v"].clone(), st["step"].clone())
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                part_a()
+                self._fused_clip_adam(1, lr)
+            torch.cuda.current_stream().wait_stream(s)
+            with torch.no_grad():
+                fp.flat.copy_(keep[0])
+                st["m"].copy_(keep[1])
+                st["v"].copy_(keep[2])
+                st["step"].copy_(keep[3])
+            ga, gb = torch.cuda.CUDAGraph(), None
+            if world == 1:
+                with torch.cuda.graph(ga):
+                    part_a()
+                    self._fused_clip_adam(1, lr)
+            else:
+                with torch.cuda.graph(ga):
+                    part_a()
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, pool=ga.pool()):
+                    self._fused_clip_adam(world, lr)
+            cap = st["graphs"][key] = (static, ga, gb)
+        static, ga, gb = cap
+        with torch.no_grad():
+            static["x0"].copy_(x_start)
+            static["t"].copy_(t)
+            static["length"].copy_(length)
+            static["xf_proj"].copy_(xf_proj)
+            static["xf_out"].copy_(xf_out)
+            if noise is not None:
+                static["noise"].copy_(noise)
+        ga.replay()
+        if gb is not None:
+            st["allreduce"](_core(self.encoder).flat_params().grad)
+            gb.replay()
+        _core(self.encoder)._textctx_cache = None
         return st["loss"]

@@ -212,6 +212,20 @@ int hig_linattn_ctx_bwd(const float* dA, const float* K, const float* V, int64_t
                         int64_t ldd, int32_t B, int32_t rows, int32_t H, int32_t hd,
                         hig_stream_t stream);
 
+/* Full softmax attention (no_eff=True), transformer.py:208-227 / 242-262, flash-style (no T x T
+ * matrix in memory).  S = q.k/sqrt(hd) (+ -100000 on query rows n >= qlen[b]: the reference puts
+ * its mask on the QUERY axis; qlen == NULL for cross attention), W = softmax over the Tk keys,
+ * Y = W V; lse[b,h,n] = log sum_m exp(S[n,m]) is kept for the backward, `delta` is scratch
+ * (B*H*Tq floats).  Head dim in {8,16,32,64}. */
+int hig_fullattn_fwd(const float* Q, int64_t ldq, const float* K, const float* V, int64_t ldk,
+                     int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t hd, const int64_t* qlen,
+                     float* Y, int64_t ldy, float* lse, hig_stream_t stream);
+int hig_fullattn_bwd(const float* dY, int64_t lddy, const float* Y, int64_t ldy, const float* Q,
+                     int64_t ldq, const float* K, const float* V, int64_t ldk, int32_t B, int32_t Tq,
+                     int32_t Tk, int32_t H, int32_t hd, const int64_t* qlen, const float* lse,
+                     float* delta, float* dQ, int64_t lddq, float* dK, float* dV, int64_t lddk,
+                     hig_stream_t stream);
+
 /* Backward of y = [silu](LN(x)*(1+scale)+shift) w.r.t. x for upstream gradient da, plus the
  * reductions for gamma/beta (over all rows) and scale/shift (per sample):
  *   dx = (res ? res : 0) + LNbwd(...).  partial: [rows/rows_per_sample * splits][4][n]. */

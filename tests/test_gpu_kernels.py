@@ -299,6 +299,46 @@ def test_linear_attention_forward_backward(B, T, H, hd, lens):
     assert err < 2e-5 * ref[:, 2 * d:].norm() + 2e-5 * ref[:, d:2 * d].norm()
 
 
+@pytest.mark.parametrize("B,Tq,Tk,H,hd,lens", [(2, 16, 16, 8, 8, (16, 9)), (2, 60, 60, 8, 16, (60, 41)),
+                                                (2, 196, 196, 4, 64, (196, 77)), (2, 70, 77, 4, 32, None),
+                                                (1, 130, 77, 2, 64, None)])
+def test_full_attention_forward_backward(B, Tq, Tk, H, hd, lens):
+    """no_eff attention (transformer.py:208-227,242-262) incl. the query-axis -1e5 mask, vs fp64."""
+    d = H * hd
+    q, kv, dy = rnd(B * Tq, d, scale=1.5), rnd(B * Tk, 2 * d, seed=1, scale=1.5), rnd(B * Tq, d, seed=2)
+    qd = q.double().view(B, Tq, H, hd).requires_grad_(True)
+    kvd = kv.double().view(B, Tk, 2 * d).requires_grad_(True)
+    kd, vd = kvd[..., :d].reshape(B, Tk, H, hd), kvd[..., d:].reshape(B, Tk, H, hd)
+    att = torch.einsum("bnhd,bmhd->bnmh", qd, kd) / math.sqrt(hd)
+    valid = torch.ones(B, Tq, dtype=torch.bool)
+    if lens is not None:
+        valid = torch.arange(Tq)[None] < torch.tensor(lens)[:, None]
+        # fp32 semantics of the reference: logits + (-1e5) rounded to fp32 on padded QUERY rows
+        att = torch.where(valid[:, :, None, None], att, (att.float() + (-100000.0)).double() + 0 * att)
+    w = torch.softmax(att, dim=2)
+    y_ref = torch.einsum("bnmh,bmhd->bnhd", w, vd).reshape(B, Tq, d)
+    (y_ref * dy.double().view(B, Tq, d) * valid[..., None]).sum().backward()
+    L, s = _lib.lib(), _lib.stream_ptr()
+    qg, kvg = q.to(DEV), kv.to(DEV)
+    lg = None if lens is None else torch.tensor(lens).to(DEV)
+    y = torch.full((B * Tq, d), float("nan"), device=DEV)
+    lse = torch.zeros(B * H * Tq, device=DEV)
+    _lib.check(L.hig_fullattn_fwd(P(qg), d, P(kvg), kvg.data_ptr() + 4 * d, 2 * d, B, Tq, Tk, H, hd, P(lg), P(y), d, P(lse), s))
+    torch.cuda.synchronize()
+    vm = valid.reshape(-1)
+    assert rel(y[vm.to(DEV)], y_ref.reshape(B * Tq, d)[vm]) < 5e-6
+    if lens is not None and (~vm).any():   # padded query rows: logits quantised to 2^-7 by the -1e5 offset
+        assert rel(y[(~vm).to(DEV)], y_ref.reshape(B * Tq, d)[~vm]) < 2e-2
+    dyg = (dy * vm[:, None]).to(DEV)
+    dq, dkv = torch.full((B * Tq, d), float("nan"), device=DEV), torch.full((B * Tk, 2 * d), float("nan"), device=DEV)
+    delta = torch.zeros(B * H * Tq, device=DEV)
+    _lib.check(L.hig_fullattn_bwd(P(dyg), d, P(y), d, P(qg), d, P(kvg), kvg.data_ptr() + 4 * d, 2 * d, B, Tq, Tk, H, hd,
+                                  P(lg), P(lse), P(delta), P(dq), d, P(dkv), dkv.data_ptr() + 4 * d, 2 * d, s))
+    torch.cuda.synchronize()
+    assert rel(dq, qd.grad.reshape(B * Tq, d)) < 2e-5
+    assert rel(dkv, kvd.grad.reshape(B * Tk, 2 * d)) < 2e-5
+
+
 def test_timestep_embedding_matches_reference_formula():
     from oracle import denoiser_ref as R
     t = torch.tensor([0, 1, 7, 500, 999])
