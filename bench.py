@@ -250,12 +250,16 @@ def main():
             trainer.train_step_fused(inp["x0"], inp["t"], inp["length"], inp["xf_proj"], inp["xf_out"], noise=noise)
 
         ksteps = max(3, min(a.steps, 10))
-        el_t = timed(train_step, ksteps, 2, world)
-        extra["train_step"] = {"frames_per_s": round(B * T * ksteps * world / el_t, 1),
-                               "ms_per_step": round(el_t / ksteps * 1e3, 3), "steps": ksteps,
-                               "what": "q_sample+fwd+masked-MSE+bwd+%sclip(0.5)+Adam, B=64/GPU, fp32"
-                                       % ("RCCL all-reduce(%.0f MB)+" % (model.flat_params().numel * 4 / 1e6)
-                                          if world > 1 else "")}
+        for mode in ("f32", "bf16x3"):
+            model.precision = mode
+            el_t = timed(train_step, ksteps, 2, world)
+            extra["train_step_" + mode] = {
+                "frames_per_s": round(B * T * ksteps * world / el_t, 1),
+                "ms_per_step": round(el_t / ksteps * 1e3, 3), "steps": ksteps,
+                "what": "q_sample+fwd+masked-MSE+bwd+%sclip(0.5)+Adam, B=64/GPU, %s GEMM products, fp32 "
+                        "accumulate/storage/optimizer" % ("RCCL all-reduce(%.0f MB)+" % (model.flat_params().numel * 4 / 1e6)
+                                                          if world > 1 else "", mode)}
+        model.precision = "f32"
         model.eval()
         if world == 1:
             # ---- DDPM sampling, hipGraph replay, B=32 (BASELINE config 3 shape, fp32 here) ----

@@ -26,7 +26,7 @@ SYMBOLS = (
     "hig_version", "hig_last_error", "hig_workspace_bytes", "hig_textctx_bytes",
     "hig_bwd_workspace_bytes", "hig_text_context", "hig_denoiser_fwd", "hig_denoiser_bwd",
     "hig_gemm", "hig_rowstats", "hig_ln_mod_silu", "hig_linattn_ctx", "hig_linattn_apply", "hig_linattn_apply_bwd",
-    "hig_linattn_ctx_bwd", "hig_fullattn_fwd", "hig_fullattn_bwd", "hig_ln_bwd", "hig_ln_bwd_partial_floats", "hig_colsum",
+    "hig_linattn_ctx_bwd", "hig_fullattn_fwd", "hig_fullattn_bwd", "hig_ln_bwd", "hig_ln_bwd_partial_floats", "hig_transpose", "hig_colsum",
     "hig_timestep_embedding", "hig_q_sample", "hig_p_sample_step", "hig_dec_timesteps",
     "hig_masked_mse", "hig_sumsq_partial", "hig_clip_adam",
 )
@@ -92,6 +92,7 @@ def lib():
                                  i64, i32, i32, vp, vp, vp, i64, vp, vp]
         L.hig_ln_bwd_partial_floats.restype = i64
         L.hig_ln_bwd_partial_floats.argtypes = [i64, i32, i32]
+        L.hig_transpose.argtypes = [vp, i64, i32, i32, vp, i64, vp, vp, vp, vp]
         L.hig_colsum.argtypes = [vp, i64, i64, i32, vp, vp, vp]
         L.hig_timestep_embedding.argtypes = [vp, i32, i32, vp, vp]
         L.hig_q_sample.argtypes = [vp, vp, vp, vp, i32, i32, i64, vp, vp]

@@ -143,7 +143,7 @@ TextLayout text_layout(const Dims& D, int training) {
 
 struct BwdLayout {
   int64_t dhA, dhB, t1, t2, tff, dqkv, dA, delta, dkv, dxfn, dss, demb, dtmp, dte_h, slabs, slab_floats,
-      colpart, lnpart, total;
+      colpart, lnpart, wT, tA, tB, total;
 };
 BwdLayout bwd_layout(const Dims& D) {
   BwdLayout w;
@@ -178,6 +178,13 @@ BwdLayout bwd_layout(const Dims& D) {
   int64_t lp = hig_ln_bwd_partial_floats(D.M, D.d, D.T);
   const int64_t lpt = hig_ln_bwd_partial_floats(D.Mt, D.Lt, D.N);
   w.lnpart = take(lp > lpt ? lp : lpt);
+  // one layer's transposed weights (reduce-contiguous operands for the data-gradient GEMMs)
+  w.wT = take((int64_t)7 * D.d * D.d + (int64_t)2 * D.d * D.ff + (int64_t)2 * D.d * D.Lt);
+  // transposed dC / activation operands of the weight-gradient GEMMs (bf16 product modes)
+  const int64_t mrows = D.M > D.Mt ? D.M : D.Mt;
+  const int64_t wide = 3 * D.d > D.ff ? 3 * D.d : D.ff;
+  w.tA = take(wide * mrows);
+  w.tB = take((int64_t)(D.ff > D.d ? (D.ff > D.Lt ? D.ff : D.Lt) : (D.d > D.Lt ? D.d : D.Lt)) * mrows);
   w.total = o;
   return w;
 }
@@ -383,17 +390,43 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
     const int s = wgrad_splits(gd.g.I, gd.g.J, gd.g.R, bw.slab_floats);
     return hig_gemm_launch(gd.g, s, slabs, st);
   };
+  // dW[n][k] = sum_m dC[m][n] * act[m][k]  (act optionally LayerNorm'ed on the fly).
+  // exact-fp32 mode: both operands read reduce-slow straight from their row-major buffers.
+  // bf16 product modes: both are transposed first (LN fused into the transpose) so the GEMM gets
+  // reduce-contiguous operands -- the layout the bf16 MFMA fragments need.
+  auto wgrad_act = [&](const float* dC, int n_out, const float* act, int k_in, float* out, int64_t rows,
+                       const float* stats, const float* gamma, const float* beta) -> int {
+    if (D.prec != HIG_PREC_F32 && rows % 32 == 0) {
+      float* ta = b + bw.tA;
+      float* tb = b + bw.tB;
+      HIG_TRY(hig_transpose(dC, n_out, (int)rows, n_out, ta, rows, nullptr, nullptr, nullptr, stream));
+      HIG_TRY(hig_transpose(act, k_in, (int)rows, k_in, tb, rows, stats, gamma, beta, stream));
+      return wgrad(G(ta, rows, 0, tb, rows, 0, out, k_in, n_out, k_in, rows).prec(D.prec));
+    }
+    G gd(dC, n_out, 1, act, k_in, 1, out, k_in, n_out, k_in, rows);
+    if (stats) gd.ln(1, stats, gamma, beta);
+    return wgrad(gd);
+  };
+  // W (out, in) row-major -> W^T (in, out): the data-gradient GEMM dA = dC . W then reads both
+  // operands reduce-contiguous (fast tile fetch, b128 LDS fragments, bf16 modes available)
+  float* wT = b + bw.wT;
+  const int64_t o_sty3 = 0, o_w2t = o_sty3 + (int64_t)d * d, o_w1t = o_w2t + (int64_t)d * ff,
+                o_sty2 = o_w1t + (int64_t)d * ff, o_caq = o_sty2 + (int64_t)d * d, o_kv = o_caq + (int64_t)d * d,
+                o_sty1 = o_kv + (int64_t)2 * d * Lt, o_qkv = o_sty1 + (int64_t)d * d;
+  auto wtrans = [&](const float* W, int out_f, int in_f, int64_t off) -> int {
+    return hig_transpose(W, in_f, out_f, in_f, wT + off, out_f, nullptr, nullptr, nullptr, stream);
+  };
   auto colsum = [&](const float* src, int64_t ld, int64_t rows, int n, float* dst) -> int {
     return hig_colsum(src, ld, rows, n, dst, colp, stream);
   };
   // Backward of one stylization block: h_out = h_in + Lin_out(silu(LN(y)*(1+scale)+shift)).
   // `dh` is d(h_out); produces dy into `dy_out`, parameter grads, and dss columns of block s.
   auto sty_bwd = [&](int l, int s, const float* dh, const float* y, const float* a_saved, const float* stats,
-                     int norm_w, int norm_b, int out_w, int out_b, float* dy_out) -> int {
+                     int norm_w, int norm_b, int out_w, int out_b, int64_t wt_off, float* dy_out) -> int {
     const float* ssl = ws + w.ss + (int64_t)s * 2 * d;
     HIG_TRY(colsum(dh, d, M, d, GL(grads, l, out_b)));
-    HIG_TRY(wgrad(G(dh, d, 1, a_saved, d, 1, GL(grads, l, out_w), d, d, d, M)));
-    HIG_TRY(hig_gemm_launch(G(dh, d, 0, PL(params, l, out_w), d, 1, b + bw.t1, d, M, d, d).g, 1, nullptr, st));
+    HIG_TRY(wgrad_act(dh, d, a_saved, d, GL(grads, l, out_w), M, nullptr, nullptr, nullptr));
+    HIG_TRY(hig_gemm_launch(G(dh, d, 0, wT + wt_off, d, 0, b + bw.t1, d, M, d, d).prec(D.prec).g, 1, nullptr, st));
     return hig_ln_bwd(b + bw.t1, d, y, d, stats, PL(params, l, norm_w), PL(params, l, norm_b), ssl, ss_ld, d, 1,
                       nullptr, 0, dy_out, d, M, d, D.T, GL(grads, l, norm_w), GL(grads, l, norm_b),
                       dss + (int64_t)s * 2 * d, ss_ld, lnp, stream);
@@ -410,23 +443,31 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
   for (int l = D.L - 1; l >= 0; --l) {
     const float* lb = ws + w.layer0 + w.lstride * l;
     const float* hin = l == 0 ? ws + w.h0 : ws + w.layer0 + w.lstride * (l - 1) + w.h3;
+    HIG_TRY(wtrans(PL(params, l, HIG_L_FFN_STY_OUT_W), d, d, o_sty3));
+    HIG_TRY(wtrans(PL(params, l, HIG_L_FFN_W2), d, ff, o_w2t));
+    HIG_TRY(wtrans(PL(params, l, HIG_L_FFN_W1), ff, d, o_w1t));
+    HIG_TRY(wtrans(PL(params, l, HIG_L_CA_STY_OUT_W), d, d, o_sty2));
+    HIG_TRY(wtrans(PL(params, l, HIG_L_CA_Q_W), d, d, o_caq));
+    HIG_TRY(wtrans(PL(params, l, HIG_L_CA_KV_W), 2 * d, Lt, o_kv));
+    HIG_TRY(wtrans(PL(params, l, HIG_L_SA_STY_OUT_W), d, d, o_sty1));
+    HIG_TRY(wtrans(PL(params, l, HIG_L_SA_QKV_W), 3 * d, d, o_qkv));
     // ---- FFN --------------------------------------------------------------------------
     HIG_TRY(sty_bwd(l, 3 * l + 2, dh, lb + w.y3, lb + w.a3, lb + w.st5, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B,
-                    HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B, b + bw.t2));
+                    HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B, o_sty3, b + bw.t2));
     const float* dy3 = b + bw.t2;
     HIG_TRY(colsum(dy3, d, M, d, GL(grads, l, HIG_L_FFN_B2)));
-    HIG_TRY(wgrad(G(dy3, d, 1, lb + w.f1, ff, 1, GL(grads, l, HIG_L_FFN_W2), ff, d, ff, M)));
-    HIG_TRY(hig_gemm_launch(G(dy3, d, 0, PL(params, l, HIG_L_FFN_W2), ff, 1, b + bw.tff, ff, M, ff, d)
+    HIG_TRY(wgrad_act(dy3, d, lb + w.f1, ff, GL(grads, l, HIG_L_FFN_W2), M, nullptr, nullptr, nullptr));
+    HIG_TRY(hig_gemm_launch(G(dy3, d, 0, wT + o_w2t, d, 0, b + bw.tff, ff, M, ff, d).prec(D.prec)
                                 .epi(HIG_EPI_DGELU).aux(const_cast<float*>(lb + w.z1), ff).g, 1, nullptr, st));
     const float* dz1 = b + bw.tff;
     HIG_TRY(colsum(dz1, ff, M, ff, GL(grads, l, HIG_L_FFN_B1)));
-    HIG_TRY(wgrad(G(dz1, ff, 1, lb + w.h2, d, 1, GL(grads, l, HIG_L_FFN_W1), d, ff, d, M)));
-    HIG_TRY(hig_gemm_launch(G(dz1, ff, 0, PL(params, l, HIG_L_FFN_W1), d, 1, dh_alt, d, M, d, ff)
+    HIG_TRY(wgrad_act(dz1, ff, lb + w.h2, d, GL(grads, l, HIG_L_FFN_W1), M, nullptr, nullptr, nullptr));
+    HIG_TRY(hig_gemm_launch(G(dz1, ff, 0, wT + o_w1t, ff, 0, dh_alt, d, M, d, ff).prec(D.prec)
                                 .epi(HIG_EPI_RES).res(dh, d).g, 1, nullptr, st));
     { float* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h2)
     // ---- cross attention ---------------------------------------------------------------
     HIG_TRY(sty_bwd(l, 3 * l + 1, dh, lb + w.y2, lb + w.a2, lb + w.st4, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B,
-                    HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B, b + bw.t2));
+                    HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B, o_sty2, b + bw.t2));
     const float* Ac = tc + tl.layer0 + tl.lstride * l + tl.Ac;
     const float* kstc = tc + tl.layer0 + tl.lstride * l + tl.kstc;
     const float* kv = tc + tl.kv + tl.kv_stride * l;
@@ -438,9 +479,9 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
       HIG_TRY(hig_linattn_apply_bwd(b + bw.t2, d, lb + w.qc, d, Ac, b + bw.t1, d, b + bw.dA, D.B, D.T, D.H, D.hd, stream));
     const float* dqc = b + bw.t1;
     HIG_TRY(colsum(dqc, d, M, d, GL(grads, l, HIG_L_CA_Q_B)));
-    HIG_TRY(wgrad(G(dqc, d, 1, lb + w.h1, d, 1, GL(grads, l, HIG_L_CA_Q_W), d, d, d, M)
-                      .ln(1, lb + w.st3, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B))));
-    HIG_TRY(hig_gemm_launch(G(dqc, d, 0, PL(params, l, HIG_L_CA_Q_W), d, 1, b + bw.t2, d, M, d, d).g, 1, nullptr, st));
+    HIG_TRY(wgrad_act(dqc, d, lb + w.h1, d, GL(grads, l, HIG_L_CA_Q_W), M, lb + w.st3, PL(params, l, HIG_L_CA_NORM_W),
+                      PL(params, l, HIG_L_CA_NORM_B)));
+    HIG_TRY(hig_gemm_launch(G(dqc, d, 0, wT + o_caq, d, 0, b + bw.t2, d, M, d, d).prec(D.prec).g, 1, nullptr, st));
     HIG_TRY(hig_ln_bwd(b + bw.t2, d, lb + w.h1, d, lb + w.st3, PL(params, l, HIG_L_CA_NORM_W),
                        PL(params, l, HIG_L_CA_NORM_B), nullptr, 0, 0, 0, dh, d, dh_alt, d, M, d, D.T,
                        GL(grads, l, HIG_L_CA_NORM_W), GL(grads, l, HIG_L_CA_NORM_B), nullptr, 0, lnp, stream));
@@ -450,9 +491,9 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
       HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, kv, kv + d, 2 * d, kstc, nullptr, b + bw.dkv, b + bw.dkv + d, 2 * d, D.B,
                                   D.N, D.H, D.hd, stream));
     HIG_TRY(colsum(b + bw.dkv, 2 * d, Mt, 2 * d, GL(grads, l, HIG_L_CA_KV_B)));
-    HIG_TRY(wgrad(G(b + bw.dkv, 2 * d, 1, xf_out, Lt, 1, GL(grads, l, HIG_L_CA_KV_W), Lt, 2 * d, Lt, Mt)
-                      .ln(1, tc + tl.stt, PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B))));
-    HIG_TRY(hig_gemm_launch(G(b + bw.dkv, 2 * d, 0, PL(params, l, HIG_L_CA_KV_W), Lt, 1, b + bw.dxfn, Lt, Mt, Lt, 2 * d).g,
+    HIG_TRY(wgrad_act(b + bw.dkv, 2 * d, xf_out, Lt, GL(grads, l, HIG_L_CA_KV_W), Mt, tc + tl.stt,
+                      PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B)));
+    HIG_TRY(hig_gemm_launch(G(b + bw.dkv, 2 * d, 0, wT + o_kv, 2 * d, 0, b + bw.dxfn, Lt, Mt, Lt, 2 * d).prec(D.prec).g,
                             1, nullptr, st));
     HIG_TRY(hig_ln_bwd(b + bw.dxfn, Lt, xf_out, Lt, tc + tl.stt, PL(params, l, HIG_L_CA_TNORM_W),
                        PL(params, l, HIG_L_CA_TNORM_B), nullptr, 0, 0, 0, l == D.L - 1 ? nullptr : dxf_out, Lt,
@@ -460,7 +501,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                        nullptr, 0, lnp, stream));
     // ---- self attention ----------------------------------------------------------------
     HIG_TRY(sty_bwd(l, 3 * l, dh, lb + w.y1, lb + w.a1, lb + w.st2, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B,
-                    HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B, b + bw.t2));
+                    HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B, o_sty1, b + bw.t2));
     float* dqkv = b + bw.dqkv;
     if (D.full) {
       HIG_TRY(hig_fullattn_bwd(b + bw.t2, d, lb + w.y1, d, lb + w.qkv, 3 * d, lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d,
@@ -473,9 +514,9 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                                   dqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, stream));
     }
     HIG_TRY(colsum(dqkv, 3 * d, M, 3 * d, GL(grads, l, HIG_L_SA_QKV_B)));
-    HIG_TRY(wgrad(G(dqkv, 3 * d, 1, hin, d, 1, GL(grads, l, HIG_L_SA_QKV_W), d, 3 * d, d, M)
-                      .ln(1, lb + w.st1, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B))));
-    HIG_TRY(hig_gemm_launch(G(dqkv, 3 * d, 0, PL(params, l, HIG_L_SA_QKV_W), d, 1, b + bw.t2, d, M, d, 3 * d).g, 1,
+    HIG_TRY(wgrad_act(dqkv, 3 * d, hin, d, GL(grads, l, HIG_L_SA_QKV_W), M, lb + w.st1, PL(params, l, HIG_L_SA_NORM_W),
+                      PL(params, l, HIG_L_SA_NORM_B)));
+    HIG_TRY(hig_gemm_launch(G(dqkv, 3 * d, 0, wT + o_qkv, 3 * d, 0, b + bw.t2, d, M, d, 3 * d).prec(D.prec).g, 1,
                             nullptr, st));
     HIG_TRY(hig_ln_bwd(b + bw.t2, d, hin, d, lb + w.st1, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B),
                        nullptr, 0, 0, 0, dh, d, dh_alt, d, M, d, D.T, GL(grads, l, HIG_L_SA_NORM_W),

@@ -531,27 +531,27 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
                     (!X_RS || (g.I % 4 == 0 && g.I >= 4)) && (!Y_RS || (g.J % 4 == 0 && g.J >= 4));
   if (a.ntiles > 0 && g.R >= 0) {
     // the bf16 product modes exist for aligned reduce-contiguous operands; anything else
-    // (F = 150 projections, dgrad / wgrad layouts) runs the exact fp32 kernel
+    // (F = 150 projections, reduce-slow dgrad / wgrad layouts) runs the exact fp32 kernel
+    bool launched = false;
     if constexpr (!X_RS && !Y_RS) {
       if (fast && g.prec == HIG_PREC_BF16X3) {
         hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, true, HIG_PREC_BF16X3>),
                            dim3(a.ntiles, splits), dim3(NTHREADS), 0, st, a);
-        HIG_CHECK_LAUNCH();
-        return HIG_OK;
-      }
-      if (fast && g.prec == HIG_PREC_BF16) {
+        launched = true;
+      } else if (fast && g.prec == HIG_PREC_BF16) {
         hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, true, HIG_PREC_BF16>),
                            dim3(a.ntiles, splits), dim3(NTHREADS), 0, st, a);
-        HIG_CHECK_LAUNCH();
-        return HIG_OK;
+        launched = true;
       }
     }
-    if (fast)
-      hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, true, HIG_PREC_F32>),
-                         dim3(a.ntiles, splits), dim3(NTHREADS), 0, st, a);
-    else
-      hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, false, HIG_PREC_F32>),
-                         dim3(a.ntiles, splits), dim3(NTHREADS), 0, st, a);
+    if (!launched) {
+      if (fast)
+        hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, true, HIG_PREC_F32>),
+                           dim3(a.ntiles, splits), dim3(NTHREADS), 0, st, a);
+      else
+        hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, false, HIG_PREC_F32>),
+                           dim3(a.ntiles, splits), dim3(NTHREADS), 0, st, a);
+    }
   }
   HIG_CHECK_LAUNCH();
   if (splits > 1) {
@@ -631,6 +631,8 @@ int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_
   CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_BIAS_GELU)
   CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_BIAS_POS)
   CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_BIAS_RES)
+  CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_RES)    // dgrad through a transposed weight copy
+  CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_DGELU)
   CASE(0, 0, HIG_XF_LN, 0, HIG_EPI_BIAS)
   CASE(0, 0, HIG_XF_LN_MOD_SILU, 0, HIG_EPI_BIAS_RES)
   CASE(0, 0, HIG_XF_SILU, 0, HIG_EPI_BIAS)

@@ -303,6 +303,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// dst[c][r] = [LN](src[r][c])   (64x64 tiles through LDS; both sides coalesced).
+// Used to give the weight-gradient / data-gradient GEMMs reduce-contiguous operands.
+template <bool LN>
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int64_t lds_, int rows,
+                                                        int cols, float* __restrict__ dst, int64_t ldd,
+                                                        const float* __restrict__ stats,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta) {
+  __shared__ float tile[64][65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) {
+      v = src[(int64_t)r * lds_ + c];
+      if (LN) v = (v - stats[2 * (int64_t)r]) * stats[2 * (int64_t)r + 1] * gamma[c] + beta[c];
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) dst[(int64_t)c * ldd + r] = tile[tx][i];
+  }
+}
+
 __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int B, int d,
                                           float* __restrict__ out) {
   const int half = d / 2;
@@ -419,6 +446,22 @@ extern "C" int hig_colsum(const float* x, int64_t ldx, int64_t rows, int32_t n, 
   HIG_CHECK_LAUNCH();
   hipLaunchKernelGGL(colreduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial,
                      HIG_COLSUM_CHUNKS, (int64_t)n, n, out);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+extern "C" int hig_transpose(const float* src, int64_t ld, int32_t rows, int32_t cols, float* dst, int64_t ldd,
+                             const float* stats, const float* gamma, const float* beta, hig_stream_t stream) {
+  HIG_REQUIRE(src && dst && rows > 0 && cols > 0, "hig_transpose: bad arguments");
+  const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  if (stats) {
+    HIG_REQUIRE(gamma && beta, "hig_transpose: LayerNorm needs gamma/beta");
+    hipLaunchKernelGGL((transpose_kernel<true>), grid, dim3(256), 0, hig_stream(stream), src, ld, rows, cols, dst,
+                       ldd, stats, gamma, beta);
+  } else {
+    hipLaunchKernelGGL((transpose_kernel<false>), grid, dim3(256), 0, hig_stream(stream), src, ld, rows, cols, dst,
+                       ldd, stats, gamma, beta);
+  }
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

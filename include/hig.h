@@ -237,6 +237,11 @@ int hig_ln_bwd(const float* da, int64_t ldda, const float* x, int64_t ldx, const
                hig_stream_t stream);
 int64_t hig_ln_bwd_partial_floats(int64_t rows, int32_t n, int32_t rows_per_sample);
 
+/* dst[c][r] = src[r][c], optionally with LayerNorm applied to the source rows first
+ * (stats = (mean, rstd) per source row, gamma/beta per source column; NULL = plain transpose). */
+int hig_transpose(const float* src, int64_t ld, int32_t rows, int32_t cols, float* dst, int64_t ldd,
+                  const float* stats, const float* gamma, const float* beta, hig_stream_t stream);
+
 /* out[j] = sum_i x[i][j]  (bias gradients).  partial: [HIG_COLSUM_CHUNKS][n] floats. */
 #define HIG_COLSUM_CHUNKS 64
 int hig_colsum(const float* x, int64_t ldx, int64_t rows, int32_t n, float* out, float* partial,

@@ -242,6 +242,21 @@ def test_ln_bwd(mod, B, T, n):
         assert rel(dss, ssd.grad) < 1e-5
 
 
+@pytest.mark.parametrize("rows,cols,ln", [(130, 70, False), (12544 // 4, 512, True), (64, 64, False), (77, 256, True)])
+def test_transpose_with_optional_layernorm(rows, cols, ln):
+    x = rnd(rows, cols, scale=2.0) + 0.5
+    g, be = 1 + 0.1 * rnd(cols, seed=2), 0.1 * rnd(cols, seed=3)
+    out = torch.full((cols, rows), float("nan"), device=DEV)
+    _lib.check(_lib.lib().hig_transpose(P(x.to(DEV)), cols, rows, cols, P(out), rows,
+                                        P(stats_of(x).to(DEV)) if ln else None, P(g.to(DEV)) if ln else None,
+                                        P(be.to(DEV)) if ln else None, _lib.stream_ptr()))
+    ref = F.layer_norm(x.double(), (cols,), g.double(), be.double()) if ln else x.double()
+    if ln:
+        assert rel(out, ref.T) < 2e-6
+    else:
+        assert torch.equal(out.cpu(), x.T)
+
+
 @pytest.mark.parametrize("rows,n", [(1000, 512), (64, 24576 // 8), (77, 150), (3, 5)])
 def test_colsum(rows, n):
     x = rnd(rows, n)
