@@ -19,14 +19,14 @@ XF_NONE, XF_LN, XF_LN_MOD_SILU, XF_SILU = 0, 1, 2, 3
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_BIAS_POS, EPI_RES, EPI_DGELU = range(7)
 TAB_ROWS = 7
 NORM_BLOCKS = 1024
-COLSUM_CHUNKS = 64
+COLSUM_CHUNKS = 512
 
 # every symbol include/hig.h declares (checked by the CPU test-suite)
 SYMBOLS = (
     "hig_version", "hig_last_error", "hig_workspace_bytes", "hig_textctx_bytes",
     "hig_bwd_workspace_bytes", "hig_text_context", "hig_denoiser_fwd", "hig_denoiser_bwd",
     "hig_gemm", "hig_rowstats", "hig_ln_mod_silu", "hig_linattn_ctx", "hig_linattn_apply", "hig_linattn_apply_bwd",
-    "hig_linattn_ctx_bwd", "hig_fullattn_fwd", "hig_fullattn_bwd", "hig_ln_bwd", "hig_ln_bwd_partial_floats", "hig_transpose", "hig_colsum",
+    "hig_linattn_ctx_bwd", "hig_linattn_bwd_scratch_floats", "hig_fullattn_fwd", "hig_fullattn_bwd", "hig_ln_bwd", "hig_ln_bwd_partial_floats", "hig_transpose", "hig_colsum", "hig_colsum_chunks",
     "hig_timestep_embedding", "hig_q_sample", "hig_p_sample_step", "hig_dec_timesteps",
     "hig_masked_mse", "hig_sumsq_partial", "hig_clip_adam",
 )
@@ -83,8 +83,10 @@ def lib():
         L.hig_ln_mod_silu.argtypes = [vp, i64, i64, i32, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp]
         L.hig_linattn_ctx.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp]
         L.hig_linattn_apply.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]
-        L.hig_linattn_apply_bwd.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp]
-        L.hig_linattn_ctx_bwd.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+        L.hig_linattn_bwd_scratch_floats.restype = i64
+        L.hig_linattn_bwd_scratch_floats.argtypes = [i32, i32, i32, i32]
+        L.hig_linattn_apply_bwd.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, vp]
+        L.hig_linattn_ctx_bwd.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]
         L.hig_fullattn_fwd.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, vp, vp, i64, vp, vp]
         L.hig_fullattn_bwd.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, vp, vp,
                                        vp, vp, i64, vp, vp, i64, vp]
@@ -93,6 +95,7 @@ def lib():
         L.hig_ln_bwd_partial_floats.restype = i64
         L.hig_ln_bwd_partial_floats.argtypes = [i64, i32, i32]
         L.hig_transpose.argtypes = [vp, i64, i32, i32, vp, i64, vp, vp, vp, vp]
+        L.hig_colsum_chunks.argtypes = [i64]
         L.hig_colsum.argtypes = [vp, i64, i64, i32, vp, vp, vp]
         L.hig_timestep_embedding.argtypes = [vp, i32, i32, vp, vp]
         L.hig_q_sample.argtypes = [vp, vp, vp, vp, i32, i32, i64, vp, vp]

@@ -143,7 +143,7 @@ TextLayout text_layout(const Dims& D, int training) {
 
 struct BwdLayout {
   int64_t dhA, dhB, t1, t2, tff, dqkv, dA, delta, dkv, dxfn, dss, demb, dtmp, dte_h, slabs, slab_floats,
-      colpart, lnpart, wT, tA, tB, total;
+      colpart, lnpart, wT, tA, tB, attn, total;
 };
 BwdLayout bwd_layout(const Dims& D) {
   BwdLayout w;
@@ -171,10 +171,15 @@ BwdLayout bwd_layout(const Dims& D) {
   for (int64_t v : outs) biggest = v > biggest ? v : biggest;
   w.slab_floats = biggest * 16 > (int64_t)1536 * 128 * 128 ? biggest * 16 : (int64_t)1536 * 128 * 128;
   w.slabs = take(w.slab_floats);
-  int64_t widest = (int64_t)D.T * D.d;
-  const int64_t wids[] = {(int64_t)3 * D.d, (int64_t)D.ff, (int64_t)D.E, (int64_t)3 * D.L * 2 * D.d, (int64_t)D.F};
-  for (int64_t v : wids) widest = v > widest ? v : widest;
-  w.colpart = take((int64_t)HIG_COLSUM_CHUNKS * widest);
+  // column-sum partials: [chunks(rows)][n] for every (rows, n) the backward reduces
+  int64_t colp = 0;
+  const int64_t uses[][2] = {{D.M, 3 * D.d}, {D.M, D.ff}, {D.M, D.F}, {D.Mt, 2 * D.d}, {D.B, D.E},
+                             {D.B, (int64_t)3 * D.L * 2 * D.d}, {D.B, (int64_t)D.T * D.d}};
+  for (auto& u : uses) {
+    const int64_t v = (int64_t)hig_colsum_chunks(u[0]) * u[1];
+    colp = v > colp ? v : colp;
+  }
+  w.colpart = take(colp);
   int64_t lp = hig_ln_bwd_partial_floats(D.M, D.d, D.T);
   const int64_t lpt = hig_ln_bwd_partial_floats(D.Mt, D.Lt, D.N);
   w.lnpart = take(lp > lpt ? lp : lpt);
@@ -185,6 +190,9 @@ BwdLayout bwd_layout(const Dims& D) {
   const int64_t wide = 3 * D.d > D.ff ? 3 * D.d : D.ff;
   w.tA = take(wide * mrows);
   w.tB = take((int64_t)(D.ff > D.d ? (D.ff > D.Lt ? D.ff : D.Lt) : (D.d > D.Lt ? D.d : D.Lt)) * mrows);
+  const int64_t as1 = hig_linattn_bwd_scratch_floats(D.B, D.T, D.H, D.hd);
+  const int64_t as2 = hig_linattn_bwd_scratch_floats(D.B, D.N, D.H, D.hd);
+  w.attn = take(as1 > as2 ? as1 : as2);
   w.total = o;
   return w;
 }
@@ -476,7 +484,8 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                                nullptr, lb + w.lse2, b + bw.delta, b + bw.t1, d, b + bw.dkv, b + bw.dkv + d, 2 * d,
                                stream));
     else
-      HIG_TRY(hig_linattn_apply_bwd(b + bw.t2, d, lb + w.qc, d, Ac, b + bw.t1, d, b + bw.dA, D.B, D.T, D.H, D.hd, stream));
+      HIG_TRY(hig_linattn_apply_bwd(b + bw.t2, d, lb + w.qc, d, Ac, b + bw.t1, d, b + bw.dA, D.B, D.T, D.H, D.hd,
+                                    b + bw.attn, stream));
     const float* dqc = b + bw.t1;
     HIG_TRY(colsum(dqc, d, M, d, GL(grads, l, HIG_L_CA_Q_B)));
     HIG_TRY(wgrad_act(dqc, d, lb + w.h1, d, GL(grads, l, HIG_L_CA_Q_W), M, lb + w.st3, PL(params, l, HIG_L_CA_NORM_W),
@@ -489,7 +498,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
     // text side of this layer: d(A_c) -> d(key,value) -> text_norm -> d(xf_out)
     if (!D.full)
       HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, kv, kv + d, 2 * d, kstc, nullptr, b + bw.dkv, b + bw.dkv + d, 2 * d, D.B,
-                                  D.N, D.H, D.hd, stream));
+                                  D.N, D.H, D.hd, b + bw.attn, stream));
     HIG_TRY(colsum(b + bw.dkv, 2 * d, Mt, 2 * d, GL(grads, l, HIG_L_CA_KV_B)));
     HIG_TRY(wgrad_act(b + bw.dkv, 2 * d, xf_out, Lt, GL(grads, l, HIG_L_CA_KV_W), Mt, tc + tl.stt,
                       PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B)));
@@ -509,9 +518,9 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                                dqkv + 2 * d, 3 * d, stream));
     } else {
       HIG_TRY(hig_linattn_apply_bwd(b + bw.t2, d, lb + w.qkv, 3 * d, lb + w.A1, dqkv, 3 * d, b + bw.dA, D.B, D.T, D.H,
-                                    D.hd, stream));
+                                    D.hd, b + bw.attn, stream));
       HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, lb + w.kst1, length, dqkv + d,
-                                  dqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, stream));
+                                  dqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, b + bw.attn, stream));
     }
     HIG_TRY(colsum(dqkv, 3 * d, M, 3 * d, GL(grads, l, HIG_L_SA_QKV_B)));
     HIG_TRY(wgrad_act(dqkv, 3 * d, hin, d, GL(grads, l, HIG_L_SA_QKV_W), M, lb + w.st1, PL(params, l, HIG_L_SA_NORM_W),

@@ -208,14 +208,16 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ Q,
 
 // ---------------------------------------------------------------------------------------------
 // apply_bwd: dq = dY A^T, dQ = q * (dq - sum_c q dq);  dA[c][l] = sum_r q[r,c] dY[r,l]
-// grid = B*H (each block walks all rows of its sample so dA needs no cross-block sum)
+// grid = (B*H, row chunks): each block owns 64 rows and writes its dA contribution to
+// dApart[(bh * nchunk + chunk)]; chunk_sum_kernel adds the chunks in a fixed order (no atomics:
+// bitwise reproducible)
 // ---------------------------------------------------------------------------------------------
 template <int HD>
 __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict__ dY, int64_t lddy,
                                                         const float* __restrict__ Q, int64_t ldq,
                                                         const float* __restrict__ A,
                                                         float* __restrict__ dQ, int64_t lddq,
-                                                        float* __restrict__ dA, int rows, int H) {
+                                                        float* __restrict__ dApart, int rows, int H) {
   constexpr int LDP = HD + 4, PER = HD / 4;
   constexpr int PC = Patch<HD>::PC, PL = Patch<HD>::PL, TL = Patch<HD>::TL;
   __shared__ __attribute__((aligned(16))) float sA[HD * LDP];  // padded: read by rows of c
@@ -235,7 +237,8 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int j = 0; j < PL; ++j) acc[i][j] = 0.f;
 
-  for (int r0 = 0; r0 < rows; r0 += CH) {
+  {
+    const int r0 = blockIdx.y * CH;
     __syncthreads();
     load_tile<HD>(Q + (int64_t)b * rows * ldq + h * HD, ldq, r0, rows, sQ);
     load_tile<HD>(dY + (int64_t)b * rows * lddy + h * HD, lddy, r0, rows, sD);
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict_
     }
   }
   if (active) {
-    float* dAb = dA + (int64_t)blockIdx.x * HD * HD;
+    float* dAb = dApart + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * HD * HD;
 #pragma unroll
     for (int i = 0; i < PC; ++i)
 #pragma unroll
@@ -292,12 +295,29 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict_
   }
 }
 
+// out[g][e] = sum_{c < nchunk} part[(g * nchunk + c)][e]   (e < n, n % 4 == 0)
+__global__ void chunk_sum_kernel(const float* __restrict__ part, int nchunk, int64_t n, int64_t groups,
+                                 float* __restrict__ out) {
+  const int64_t total4 = groups * n / 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t g = (i * 4) / n, e = (i * 4) % n;
+    const float* p = part + (g * nchunk) * n + e;
+    float4 s = *reinterpret_cast<const float4*>(p);
+    for (int c = 1; c < nchunk; ++c) {
+      const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)c * n);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    *reinterpret_cast<float4*>(out + g * n + e) = s;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // ctx_bwd: with k = exp(K - max)/sum on valid rows:
 //   dV[r,l] = sum_c k[r,c] dA[c][l];  dk[r,c] = sum_l V[r,l] dA[c][l];
 //   dK[r,c] = k[r,c] (dk[r,c] - sum_r' k[r',c] dk[r',c]);  masked rows get 0.
-// grid = B*H.  Pass 1 writes dV and raw dk (into dK) and accumulates the column sums; pass 2
-// finishes dK in place.
+// Two launches, both grid = (B*H, row chunks): pass 1 writes dV, parks raw dk in dK and writes
+// the chunk's column sums of k*dk; pass 2 adds the chunks' column sums and finishes dK in place.
 // ---------------------------------------------------------------------------------------------
 template <int HD>
 __global__ __launch_bounds__(256) void ctx_bwd_kernel(const float* __restrict__ dA,
@@ -306,12 +326,13 @@ __global__ __launch_bounds__(256) void ctx_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ kstat,
                                                       const int64_t* __restrict__ length,
                                                       float* __restrict__ dK, float* __restrict__ dV,
-                                                      int64_t ldd, int rows, int H) {
+                                                      int64_t ldd, int rows, int H,
+                                                      float* __restrict__ colpart) {
   constexpr int LDP = HD + 4, PER = HD / 4;
   __shared__ __attribute__((aligned(16))) float sdA[HD * LDP];   // [c][l]
   __shared__ __attribute__((aligned(16))) float sK[CH * LDP];    // k (normalised)
   __shared__ __attribute__((aligned(16))) float sV[CH * LDP];
-  __shared__ float smax[HD], sinv[HD], ssum[HD];
+  __shared__ float smax[HD], sinv[HD];
   __shared__ float swsum[4][HD];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -323,7 +344,6 @@ __global__ __launch_bounds__(256) void ctx_bwd_kernel(const float* __restrict__ 
     const float* st = kstat + ((int64_t)blockIdx.x * HD + tid) * 2;
     smax[tid] = st[0];
     sinv[tid] = 1.0f / st[1];
-    ssum[tid] = 0.f;
   }
   const float* Kb = K + (int64_t)b * rows * ld + h * HD;
   const float* Vb = V + (int64_t)b * rows * ld + h * HD;
@@ -333,8 +353,8 @@ __global__ __launch_bounds__(256) void ctx_bwd_kernel(const float* __restrict__ 
   float colsum[PER];
 #pragma unroll
   for (int e = 0; e < PER; ++e) colsum[e] = 0.f;
-
-  for (int r0 = 0; r0 < rows; r0 += CH) {
+  {
+    const int r0 = blockIdx.y * CH;
     __syncthreads();
     for (int idx = tid; idx < CH * HD; idx += 256) {
       const int rr = idx / HD, cc = idx % HD, r = r0 + rr;
@@ -377,7 +397,7 @@ __global__ __launch_bounds__(256) void ctx_bwd_kernel(const float* __restrict__ 
       store_per<PER>(dVb + (int64_t)r * ldd + part * PER, dv);
     }
   }
-  // column sums: lanes with equal `part` hold different rows -> butterfly over lane bits 2..5
+  // column sums of this chunk: lanes with equal `part` hold different rows -> butterfly over lane bits 2..5
 #pragma unroll
   for (int e = 0; e < PER; ++e) {
     float s = colsum[e];
@@ -388,11 +408,37 @@ __global__ __launch_bounds__(256) void ctx_bwd_kernel(const float* __restrict__ 
     if ((tid & 63) < 4) swsum[tid >> 6][part * PER + e] = s;
   }
   __syncthreads();
-  if (tid < HD) ssum[tid] = (swsum[0][tid] + swsum[1][tid]) + (swsum[2][tid] + swsum[3][tid]);
+  if (tid < HD)
+    colpart[((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * HD + tid] =
+        (swsum[0][tid] + swsum[1][tid]) + (swsum[2][tid] + swsum[3][tid]);
+}
+
+// pass 2: dK[r,c] = k[r,c] * (dk[r,c] - sum_chunks colpart[chunk][c]) on valid rows
+template <int HD>
+__global__ __launch_bounds__(256) void ctx_bwd_finish_kernel(const float* __restrict__ K, int64_t ld,
+                                                             const float* __restrict__ kstat,
+                                                             const int64_t* __restrict__ length,
+                                                             float* __restrict__ dK, int64_t ldd, int rows,
+                                                             int H, const float* __restrict__ colpart) {
+  __shared__ float smax[HD], sinv[HD], ssum[HD];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  int len = rows;
+  if (length) len = (int)min<int64_t>(max<int64_t>(length[b], 0), rows);
+  if (tid < HD) {
+    const float* st = kstat + ((int64_t)blockIdx.x * HD + tid) * 2;
+    smax[tid] = st[0];
+    sinv[tid] = 1.0f / st[1];
+    float s = 0.f;
+    for (int c = 0; c < (int)gridDim.y; ++c) s += colpart[((int64_t)blockIdx.x * gridDim.y + c) * HD + tid];
+    ssum[tid] = s;
+  }
   __syncthreads();
-  // pass 2: dK = k * (dk - colsum) on valid rows (dk was parked in dK)
-  for (int idx = tid; idx < len * HD; idx += 256) {
-    const int r = idx / HD, cc = idx % HD;
+  const float* Kb = K + (int64_t)b * rows * ld + h * HD;
+  float* dKb = dK + (int64_t)b * rows * ldd + h * HD;
+  const int r0 = blockIdx.y * CH, r1 = min(r0 + CH, len);
+  for (int idx = tid; idx < (r1 - r0) * HD; idx += 256) {
+    const int r = r0 + idx / HD, cc = idx % HD;
     const float kk = __expf(Kb[(int64_t)r * ld + cc] - smax[cc]) * sinv[cc];
     float* p = dKb + (int64_t)r * ldd + cc;
     *p = kk * (*p - ssum[cc]);
@@ -436,16 +482,29 @@ extern "C" int hig_linattn_apply(const float* Q, int64_t ldq, const float* A, fl
   return HIG_OK;
 }
 
+extern "C" int64_t hig_linattn_bwd_scratch_floats(int32_t B, int32_t rows, int32_t H, int32_t hd) {
+  const int64_t nchunk = (rows + CH - 1) / CH;
+  return (int64_t)B * H * nchunk * ((int64_t)hd * hd + hd);
+}
+
 extern "C" int hig_linattn_apply_bwd(const float* dY, int64_t lddy, const float* Q, int64_t ldq,
                                      const float* A, float* dQ, int64_t lddq, float* dA, int32_t B,
-                                     int32_t rows, int32_t H, int32_t hd, hig_stream_t stream) {
-  HIG_REQUIRE(dY && Q && A && dQ && dA && B > 0 && rows > 0 && H > 0, "hig_linattn_apply_bwd: bad arguments");
+                                     int32_t rows, int32_t H, int32_t hd, float* scratch,
+                                     hig_stream_t stream) {
+  HIG_REQUIRE(dY && Q && A && dQ && dA && scratch && B > 0 && rows > 0 && H > 0,
+              "hig_linattn_apply_bwd: bad arguments");
   HIG_REQUIRE(hd_ok(hd), "hig_linattn: head dim %d not in {8,16,32,64,128}", hd);
   HIG_REQUIRE(ldq % 4 == 0 && lddy % 4 == 0 && lddq % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0 &&
                   (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(dQ) & 15) == 0,
               "hig_linattn_apply_bwd: Q/dY/dQ must be 16-byte aligned");
-  HD_SWITCH(hd, hipLaunchKernelGGL((apply_bwd_kernel<HDV>), dim3(B * H), dim3(256), 0, hig_stream(stream), dY,
-                                   lddy, Q, ldq, A, dQ, lddq, dA, rows, H));
+  const int nchunk = (rows + CH - 1) / CH;
+  HD_SWITCH(hd, hipLaunchKernelGGL((apply_bwd_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream),
+                                   dY, lddy, Q, ldq, A, dQ, lddq, scratch, rows, H));
+  HIG_CHECK_LAUNCH();
+  const int64_t n = (int64_t)hd * hd, groups = (int64_t)B * H;
+  const int64_t want = (groups * n / 4 + 255) / 256;
+  hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)(want > 2048 ? 2048 : want)), dim3(256), 0, hig_stream(stream),
+                     scratch, nchunk, n, groups, dA);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
@@ -453,13 +512,18 @@ extern "C" int hig_linattn_apply_bwd(const float* dY, int64_t lddy, const float*
 extern "C" int hig_linattn_ctx_bwd(const float* dA, const float* K, const float* V, int64_t ld,
                                    const float* kstat, const int64_t* length, float* dK, float* dV,
                                    int64_t ldd, int32_t B, int32_t rows, int32_t H, int32_t hd,
-                                   hig_stream_t stream) {
-  HIG_REQUIRE(dA && K && V && kstat && dK && dV && B > 0 && rows > 0 && H > 0, "hig_linattn_ctx_bwd: bad arguments");
+                                   float* scratch, hig_stream_t stream) {
+  HIG_REQUIRE(dA && K && V && kstat && dK && dV && scratch && B > 0 && rows > 0 && H > 0,
+              "hig_linattn_ctx_bwd: bad arguments");
   HIG_REQUIRE(hd_ok(hd), "hig_linattn: head dim %d not in {8,16,32,64,128}", hd);
   HIG_REQUIRE(ldd % 4 == 0 && (reinterpret_cast<uintptr_t>(dK) & 15) == 0 && (reinterpret_cast<uintptr_t>(dV) & 15) == 0,
               "hig_linattn_ctx_bwd: dK/dV must be 16-byte aligned");
-  HD_SWITCH(hd, hipLaunchKernelGGL((ctx_bwd_kernel<HDV>), dim3(B * H), dim3(256), 0, hig_stream(stream), dA, K,
-                                   V, ld, kstat, length, dK, dV, ldd, rows, H));
+  const int nchunk = (rows + CH - 1) / CH;
+  HD_SWITCH(hd, hipLaunchKernelGGL((ctx_bwd_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream), dA,
+                                   K, V, ld, kstat, length, dK, dV, ldd, rows, H, scratch));
+  HIG_CHECK_LAUNCH();
+  HD_SWITCH(hd, hipLaunchKernelGGL((ctx_bwd_finish_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0,
+                                   hig_stream(stream), K, ld, kstat, length, dK, ldd, rows, H, scratch));
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

@@ -437,15 +437,23 @@ extern "C" int hig_ln_bwd(const float* da, int64_t ldda, const float* x, int64_t
   return HIG_OK;
 }
 
+extern "C" int hig_colsum_chunks(int64_t rows) {
+  // enough row chunks to fill the chip (each chunk = one workgroup per 256 columns), at least
+  // 16 rows per chunk
+  int64_t c = rows / 16;
+  return (int)(c < 1 ? 1 : (c > HIG_COLSUM_CHUNKS ? HIG_COLSUM_CHUNKS : c));
+}
+
 extern "C" int hig_colsum(const float* x, int64_t ldx, int64_t rows, int32_t n, float* out,
                           float* partial, hig_stream_t stream) {
   HIG_REQUIRE(x && out && partial && n > 0, "hig_colsum: bad arguments");
   hipStream_t st = hig_stream(stream);
-  hipLaunchKernelGGL(colsum_kernel, dim3((n + 255) / 256, HIG_COLSUM_CHUNKS), dim3(256), 0, st, x, ldx,
+  const int chunks = hig_colsum_chunks(rows);
+  hipLaunchKernelGGL(colsum_kernel, dim3((n + 255) / 256, chunks), dim3(256), 0, st, x, ldx,
                      rows, n, partial);
   HIG_CHECK_LAUNCH();
   hipLaunchKernelGGL(colreduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial,
-                     HIG_COLSUM_CHUNKS, (int64_t)n, n, out);
+                     chunks, (int64_t)n, n, out);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

@@ -204,13 +204,17 @@ int hig_linattn_ctx(const float* K, const float* V, int64_t ld, int32_t B, int32
                     hig_stream_t stream);
 int hig_linattn_apply(const float* Q, int64_t ldq, const float* A, float* Y, int64_t ldy,
                       int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
+/* The backward kernels split each sample's rows into 64-row chunks (one workgroup each) and
+ * combine the chunks' partial sums in a fixed order; `scratch` holds those partials
+ * (hig_linattn_bwd_scratch_floats(B, rows, H, hd) floats). */
+int64_t hig_linattn_bwd_scratch_floats(int32_t B, int32_t rows, int32_t H, int32_t hd);
 int hig_linattn_apply_bwd(const float* dY, int64_t lddy, const float* Q, int64_t ldq,
                           const float* A, float* dQ, int64_t lddq, float* dA, int32_t B,
-                          int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
+                          int32_t rows, int32_t H, int32_t hd, float* scratch, hig_stream_t stream);
 int hig_linattn_ctx_bwd(const float* dA, const float* K, const float* V, int64_t ld,
                         const float* kstat, const int64_t* length, float* dK, float* dV,
                         int64_t ldd, int32_t B, int32_t rows, int32_t H, int32_t hd,
-                        hig_stream_t stream);
+                        float* scratch, hig_stream_t stream);
 
 /* Full softmax attention (no_eff=True), transformer.py:208-227 / 242-262, flash-style (no T x T
  * matrix in memory).  S = q.k/sqrt(hd) (+ -100000 on query rows n >= qlen[b]: the reference puts
@@ -242,8 +246,10 @@ int64_t hig_ln_bwd_partial_floats(int64_t rows, int32_t n, int32_t rows_per_samp
 int hig_transpose(const float* src, int64_t ld, int32_t rows, int32_t cols, float* dst, int64_t ldd,
                   const float* stats, const float* gamma, const float* beta, hig_stream_t stream);
 
-/* out[j] = sum_i x[i][j]  (bias gradients).  partial: [HIG_COLSUM_CHUNKS][n] floats. */
-#define HIG_COLSUM_CHUNKS 64
+/* out[j] = sum_i x[i][j]  (bias gradients).  partial: [hig_colsum_chunks(rows)][n] floats
+ * (at most HIG_COLSUM_CHUNKS row chunks). */
+#define HIG_COLSUM_CHUNKS 512
+int hig_colsum_chunks(int64_t rows);
 int hig_colsum(const float* x, int64_t ldx, int64_t rows, int32_t n, float* out, float* partial,
                hig_stream_t stream);
 
