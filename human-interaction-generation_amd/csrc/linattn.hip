@@ -113,6 +113,13 @@ __global__ __launch_bounds__(256) void ctx_kernel(const float* __restrict__ K,
   }
 }
 
+// LDS column swizzle for [hd][hd+4] context tiles whose rows are read as "row = part*PER + e" by
+// the 4 lanes of a token row: rows PER apart are a multiple of 64 banks apart for every legal row
+// stride, i.e. a 4-way conflict on each ds_read_b128.  XOR-ing the column with 4*part (a whole
+// 16-byte quad) puts the four lanes on four different quads of the bank row.
+template <int HD>
+__device__ __forceinline__ int swz(int row_group) { return (4 * row_group) & (HD - 1); }
+
 // Stores PER contiguous floats (16-byte vectors when PER allows; callers guarantee alignment).
 template <int PER>
 __device__ __forceinline__ void store_per(float* __restrict__ p, const float* v) {
@@ -226,7 +233,10 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict_
   const int tid = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const float* Ab = A + (int64_t)blockIdx.x * HD * HD;
-  for (int idx = tid; idx < HD * HD; idx += 256) sA[(idx / HD) * LDP + idx % HD] = Ab[idx];
+  for (int idx = tid; idx < HD * HD; idx += 256) {
+    const int c = idx / HD;
+    sA[c * LDP + ((idx % HD) ^ swz<HD>(c / PER))] = Ab[idx];
+  }
   const int rl = tid >> 2, part = tid & 3;
   const int pc = tid / TL, pl = tid % TL;
   const int c0 = pc * PC, l0 = pl * PL;
@@ -250,11 +260,12 @@ __global__ __launch_bounds__(256) void apply_bwd_kernel(const float* __restrict_
       float dq[PER];
 #pragma unroll
       for (int e = 0; e < PER; ++e) dq[e] = 0.f;
+      const int sw = swz<HD>(part);
       for (int l = 0; l < HD; l += 4) {
-        const float4 d4 = *reinterpret_cast<const float4*>(dr + l);
+        const float4 d4 = *reinterpret_cast<const float4*>(dr + l);  // logical columns l..l+3
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
-          const float4 a4 = *reinterpret_cast<const float4*>(sA + (part * PER + e) * LDP + l);
+          const float4 a4 = *reinterpret_cast<const float4*>(sA + (part * PER + e) * LDP + (l ^ sw));
           dq[e] += d4.x * a4.x + d4.y * a4.y + d4.z * a4.z + d4.w * a4.w;
         }
       }
@@ -339,7 +350,10 @@ __global__ __launch_bounds__(256) void ctx_bwd_kernel(const float* __restrict__ 
   int len = rows;
   if (length) len = (int)min<int64_t>(max<int64_t>(length[b], 0), rows);
   const float* dAb = dA + (int64_t)blockIdx.x * HD * HD;
-  for (int idx = tid; idx < HD * HD; idx += 256) sdA[(idx / HD) * LDP + idx % HD] = dAb[idx];
+  for (int idx = tid; idx < HD * HD; idx += 256) {
+    const int c = idx / HD;
+    sdA[c * LDP + ((idx % HD) ^ swz<HD>(c / PER))] = dAb[idx];  // column-swizzled, see swz()
+  }
   if (tid < HD) {
     const float* st = kstat + ((int64_t)blockIdx.x * HD + tid) * 2;
     smax[tid] = st[0];
@@ -373,18 +387,30 @@ __global__ __launch_bounds__(256) void ctx_bwd_kernel(const float* __restrict__ 
     for (int e = 0; e < PER; ++e) dk[e] = dv[e] = 0.f;
     const float* kr = sK + rl * LDP;
     const float* vr = sV + rl * LDP;
+    const int sw = swz<HD>(part);
     for (int x = 0; x < HD; x += 4) {  // dk[c=mine] = sum_l V[r,l] dA[c][l]
-      const float4 v4 = *reinterpret_cast<const float4*>(vr + x);
+      const float4 v4 = *reinterpret_cast<const float4*>(vr + x);  // logical columns x..x+3
 #pragma unroll
       for (int e = 0; e < PER; ++e) {
-        const float4 a4 = *reinterpret_cast<const float4*>(sdA + (part * PER + e) * LDP + x);
+        const float4 a4 = *reinterpret_cast<const float4*>(sdA + (part * PER + e) * LDP + (x ^ sw));
         dk[e] += v4.x * a4.x + v4.y * a4.y + v4.z * a4.z + v4.w * a4.w;
       }
     }
     for (int c = 0; c < HD; ++c) {  // dv[l=mine] = sum_c k[r,c] dA[c][l]
       const float kc = kr[c];
+      const float* arow = sdA + c * LDP;
+      const int swc = swz<HD>(c / PER);
+      if constexpr (PER % 4 == 0) {
 #pragma unroll
-      for (int e = 0; e < PER; ++e) dv[e] = fmaf(kc, sdA[c * LDP + part * PER + e], dv[e]);
+        for (int e = 0; e < PER; e += 4) {
+          const float4 a4 = *reinterpret_cast<const float4*>(arow + ((part * PER + e) ^ swc));
+          dv[e] = fmaf(kc, a4.x, dv[e]); dv[e + 1] = fmaf(kc, a4.y, dv[e + 1]);
+          dv[e + 2] = fmaf(kc, a4.z, dv[e + 2]); dv[e + 3] = fmaf(kc, a4.w, dv[e + 3]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) dv[e] = fmaf(kc, arow[(part * PER + e) ^ swc], dv[e]);
+      }
     }
     if (r < rows) {
       const bool valid = r < len;
