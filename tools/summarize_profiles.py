@@ -15,8 +15,8 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(src, pattern), recursive=True)
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
+    return f[-1] if f else None  # newest run (gpurun merges successive runs into one directory)
 
 
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.json"))
