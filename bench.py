@@ -191,11 +191,17 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)   # (several ranks may share a GPU only in the gloo self-test below)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("HIG_DIST_BACKEND", "nccl")  # "nccl" == RCCL over xGMI; gloo: 1-GPU self-test
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import hig_amd
     from hig_amd.parallel import broadcast_parameters

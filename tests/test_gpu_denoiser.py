@@ -208,6 +208,36 @@ def test_backward_with_split_bf16_products(gold):
             assert rel(named[k[len(tag) + 3:]].grad, g[k]) < 1e-3, k
 
 
+def test_config5_shape_head_dim_128_long_sequence():
+    """BASELINE config 5 geometry at small batch/depth: T=300, d=1024, H=8 (hd=128), ff=1024.
+    Exercises the hd=128 linear-attention templates, NIT=4 row kernels and E=4096 GEMMs; forward
+    and backward against the CPU oracle."""
+    c = dict(B=2, T=300, F=150, d=1024, H=8, L=2, ff=1024, N=77, Lt=256, num_frames=300,
+             lengths=(300, 173), t=(12, 901))
+    m = build(c).train()
+    inp, gi = case_inputs(c)
+    x = gi["x"].clone().requires_grad_(True)
+    out = m(x, gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+    r = (fill.tensor_for("loss.r.c5", out.shape) * 10.0).to(DEV)
+    (out * r).sum().backward()
+    p = {k: v.requires_grad_(True) for k, v in
+         fill.core_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"]).items()}
+    xr = inp["x"].clone().requires_grad_(True)
+    ref = R.denoiser_forward(p, xr, inp["t"], inp["length"], inp["xf_proj"], inp["xf_out"], c["H"], c["L"])
+    (ref * r.cpu()).sum().backward()
+    assert rel(out, ref) < 2e-5 and rel(x.grad, xr.grad) < 1e-4
+    named = dict(m.named_parameters())
+    for k in ("out.weight", "temporal_decoder_blocks.0.sa_block.query.weight",
+              "temporal_decoder_blocks.0.sa_block.key.weight", "temporal_decoder_blocks.1.ca_block.value.weight",
+              "temporal_decoder_blocks.1.ffn.linear1.weight", "temporal_decoder_blocks.0.sa_block.proj_out.emb_layers.1.weight",
+              "sequence_embedding"):
+        assert rel(named[k].grad, p[k].grad) < 2e-4, k
+    m.precision = "bf16"
+    with torch.no_grad():
+        o16 = m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+    assert 1e-4 < rel(o16, ref) < 3e-2
+
+
 def test_properties_padding_permutation_zero_init():
     c = fill.CASES["config1"]
     m = build(c).eval()
