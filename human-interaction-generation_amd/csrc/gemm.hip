@@ -69,39 +69,21 @@ __device__ __forceinline__ f32x4 xf_apply(f32x4 v, float mean, float rstd, const
   return v;
 }
 
-// Loads one float4 of a reduce-contiguous operand: row `row`, reduce index k..k+3.
+// General (unaligned / ragged) operands -- e.g. the F = 150 pose tensor, whose 600-byte rows rule out
+// 16-byte loads: four 4-byte loads per quad at CLAMPED addresses (always in bounds, no control flow,
+// lanes still sweep each row contiguously), the out-of-range reduce indices are zeroed later, when
+// the registers are written to LDS (`mask_tiles`), so nothing waits on these loads early either.
 __device__ __forceinline__ float4 ld_rc(const float* base, int64_t ld, int row, int nrows, int k,
-                                        int kend, int vec) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (row < nrows) {
-    const float* p = base + (int64_t)row * ld + k;
-    if (vec && k + 3 < kend) {
-      v = *reinterpret_cast<const float4*>(p);
-    } else {
-      if (k < kend) v.x = p[0];
-      if (k + 1 < kend) v.y = p[1];
-      if (k + 2 < kend) v.z = p[2];
-      if (k + 3 < kend) v.w = p[3];
-    }
-  }
-  return v;
+                                        int kend) {
+  const float* p = base + (int64_t)min(row, nrows - 1) * ld;
+  const int kl = kend - 1;
+  return make_float4(p[min(k, kl)], p[min(k + 1, kl)], p[min(k + 2, kl)], p[min(k + 3, kl)]);
 }
-// Loads one float4 of a reduce-slow operand: reduce index k, rows i..i+3.
 __device__ __forceinline__ float4 ld_rs(const float* base, int64_t ld, int i, int nrows, int k,
-                                        int kend, int vec) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (k < kend) {
-    const float* p = base + (int64_t)k * ld + i;
-    if (vec && i + 3 < nrows) {
-      v = *reinterpret_cast<const float4*>(p);
-    } else {
-      if (i < nrows) v.x = p[0];
-      if (i + 1 < nrows) v.y = p[1];
-      if (i + 2 < nrows) v.z = p[2];
-      if (i + 3 < nrows) v.w = p[3];
-    }
-  }
-  return v;
+                                        int kend) {
+  const float* p = base + (int64_t)min(k, kend - 1) * ld;
+  const int il = nrows - 1;
+  return make_float4(p[min(i, il)], p[min(i + 1, il)], p[min(i + 2, il)], p[min(i + 3, il)]);
 }
 
 // Branch-free loads for the common case (16-byte aligned operand, k-tile entirely inside the
@@ -222,19 +204,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
     for (int p = 0; p < XP; ++p) {
       float4 t4;
       if (X_RS)
-        t4 = ld_rs(g.X, g.ldx, i0 + 4 * x_c4, g.I, k0 + x_r + X_RSTEP * p, rend, a.vecx);
+        t4 = ld_rs(g.X, g.ldx, i0 + 4 * x_c4, g.I, k0 + x_r + X_RSTEP * p, rend);
       else
-        t4 = ld_rc(g.X, g.ldx, i0 + x_r + 32 * p, g.I, k0 + 4 * x_c4, rend, a.vecx);
+        t4 = ld_rc(g.X, g.ldx, i0 + x_r + 32 * p, g.I, k0 + 4 * x_c4, rend);
       xr[p] = f32x4{t4.x, t4.y, t4.z, t4.w};
     }
 #pragma unroll
     for (int p = 0; p < YP; ++p) {
       float4 t4;
       if (Y_RS)
-        t4 = ld_rs(g.Y, g.ldy, j0 + 4 * y_c4, g.J, k0 + y_r + Y_RSTEP * p, rend, a.vecy);
+        t4 = ld_rs(g.Y, g.ldy, j0 + 4 * y_c4, g.J, k0 + y_r + Y_RSTEP * p, rend);
       else
-        t4 = ld_rc(g.Y, g.ldy, j0 + y_r + 32 * p, g.J, k0 + 4 * y_c4, rend, a.vecy);
+        t4 = ld_rc(g.Y, g.ldy, j0 + y_r + 32 * p, g.J, k0 + 4 * y_c4, rend);
       yr[p] = f32x4{t4.x, t4.y, t4.z, t4.w};
+    }
+  };
+  // general path only: zero what the clamped loads fetched beyond the reduce range of tile k0
+  auto mask_tiles = [&](int k0) {
+    if (FAST) return;
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      if (X_RS) {
+        if (k0 + x_r + X_RSTEP * p >= rend) xr[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        const int k = k0 + 4 * x_c4;
+        if (k >= rend) xr[p].x = 0.f;
+        if (k + 1 >= rend) xr[p].y = 0.f;
+        if (k + 2 >= rend) xr[p].z = 0.f;
+        if (k + 3 >= rend) xr[p].w = 0.f;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < YP; ++p) {
+      if (Y_RS) {
+        if (k0 + y_r + Y_RSTEP * p >= rend) yr[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        const int k = k0 + 4 * y_c4;
+        if (k >= rend) yr[p].x = 0.f;
+        if (k + 1 >= rend) yr[p].y = 0.f;
+        if (k + 2 >= rend) yr[p].z = 0.f;
+        if (k + 3 >= rend) yr[p].w = 0.f;
+      }
     }
   };
   auto transform = [&](int k0) {
@@ -396,6 +406,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
   auto iteration = [&](int kt, int nk, int buf) {
     constexpr int NG = PREC != HIG_PREC_F32 ? BK / 16 : BK / 8;  // k-groups per tile
     if (kt + 1 < nk) {
+      mask_tiles(rbeg + (kt + 1) * BK);
       transform(rbeg + (kt + 1) * BK);
       store_tiles(buf ^ 1);
     }
@@ -407,6 +418,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
   const int nk = (rend - rbeg + BK - 1) / BK;
   if (nk > 0) {
     load_tiles(rbeg);
+    mask_tiles(rbeg);
     transform(rbeg);
     store_tiles(0);
     if (nk > 1) load_tiles(rbeg + BK);
