@@ -131,12 +131,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
 
   // XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
   // contiguous run of tiles so neighbours re-use the same X row panel.
-  int tile;
-  {
-    const int bid = blockIdx.x, q = a.ntiles >> 3, r = a.ntiles & 7, xcd = bid & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int i0 = (tile / a.nbj) * BI, j0 = (tile % a.nbj) * BJ;
+  // The kernel is PERSISTENT over tiles: block b walks linear ids b, b + gridDim.x, ... (gridDim.x
+  // is a multiple of 8, so a block keeps its XCD), and fetches the first k-tile of its next tile
+  // before the epilogue of the current one -- no per-tile launch gap, no exposed prologue latency.
+  int i0 = 0, j0 = 0;
+  auto tile_coords = [&](int lin) {
+    const int q = a.ntiles >> 3, r = a.ntiles & 7, xcd = lin & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    i0 = (tile / a.nbj) * BI;
+    j0 = (tile % a.nbj) * BJ;
+  };
   const int split = blockIdx.y;
   const int rbeg = split * a.r_chunk;
   const int rend = min(g.R, rbeg + a.r_chunk);
@@ -156,15 +160,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
   // Hoisted per-row transform state for a reduce-contiguous activation operand on X.
   float xmean[XP], xrstd[XP];
   const float* xss[XP];
-  if (XF != HIG_XF_NONE && XF != HIG_XF_SILU && !XF_ON_Y && !X_RS) {
+  auto setup_row_state = [&]() {
+    if (XF != HIG_XF_NONE && XF != HIG_XF_SILU && !XF_ON_Y && !X_RS) {
 #pragma unroll
-    for (int p = 0; p < XP; ++p) {
-      const int m = min(i0 + x_r + 32 * p, g.I - 1);
-      xmean[p] = g.stats[2 * (int64_t)m];
-      xrstd[p] = g.stats[2 * (int64_t)m + 1];
-      xss[p] = (XF == HIG_XF_LN_MOD_SILU) ? g.ss + (int64_t)(m / g.rows_per_sample) * g.ss_ld : nullptr;
+      for (int p = 0; p < XP; ++p) {
+        const int m = min(i0 + x_r + 32 * p, g.I - 1);
+        xmean[p] = g.stats[2 * (int64_t)m];
+        xrstd[p] = g.stats[2 * (int64_t)m + 1];
+        xss[p] = (XF == HIG_XF_LN_MOD_SILU) ? g.ss + (int64_t)(m / g.rows_per_sample) * g.ss_ld : nullptr;
+      }
     }
-  }
+  };
 
   // Operand staging registers (global -> registers -> [transform] -> LDS); see `iteration`.
   // native vector type (not HIP's float4 struct): keeps the arrays in registers (SROA)
@@ -174,16 +180,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
   // staging registers).  Out-of-range rows are clamped (see ld_*_fast).
   const float* xptr[XP];
   const float* yptr[YP];
-  if (FAST) {
+  auto setup_pointers = [&]() {
+    if (FAST) {
 #pragma unroll
-    for (int p = 0; p < XP; ++p)
-      xptr[p] = X_RS ? g.X + (int64_t)(rbeg + x_r + X_RSTEP * p) * g.ldx + min(i0 + 4 * x_c4, g.I - 4)
-                     : g.X + (int64_t)min(i0 + x_r + 32 * p, g.I - 1) * g.ldx + rbeg + 4 * x_c4;
+      for (int p = 0; p < XP; ++p)
+        xptr[p] = X_RS ? g.X + (int64_t)(rbeg + x_r + X_RSTEP * p) * g.ldx + min(i0 + 4 * x_c4, g.I - 4)
+                       : g.X + (int64_t)min(i0 + x_r + 32 * p, g.I - 1) * g.ldx + rbeg + 4 * x_c4;
 #pragma unroll
-    for (int p = 0; p < YP; ++p)
-      yptr[p] = Y_RS ? g.Y + (int64_t)(rbeg + y_r + Y_RSTEP * p) * g.ldy + min(j0 + 4 * y_c4, g.J - 4)
-                     : g.Y + (int64_t)min(j0 + y_r + 32 * p, g.J - 1) * g.ldy + rbeg + 4 * y_c4;
-  }
+      for (int p = 0; p < YP; ++p)
+        yptr[p] = Y_RS ? g.Y + (int64_t)(rbeg + y_r + Y_RSTEP * p) * g.ldy + min(j0 + 4 * y_c4, g.J - 4)
+                       : g.Y + (int64_t)min(j0 + y_r + 32 * p, g.J - 1) * g.ldy + rbeg + 4 * y_c4;
+    }
+  };
   const int64_t xstep = X_RS ? (int64_t)BK * g.ldx : BK;
   const int64_t ystep = Y_RS ? (int64_t)BK * g.ldy : BK;
   auto load_tiles = [&](int k0) {
@@ -320,12 +328,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
   };
 
   f32x16 acc[TJ][TI];
-#pragma unroll
-  for (int tj = 0; tj < TJ; ++tj)
-#pragma unroll
-    for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[tj][ti][e] = 0.f;
 
   const int xrow = wi * (32 * TI) + lr;  // + 32*ti
   const int yrow = wj * (32 * TJ) + lr;  // + 32*tj
@@ -416,30 +418,52 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
   };
 
   const int nk = (rend - rbeg + BK - 1) / BK;
-  if (nk > 0) {
-    load_tiles(rbeg);
-    mask_tiles(rbeg);
-    transform(rbeg);
-    store_tiles(0);
-    if (nk > 1) load_tiles(rbeg + BK);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    iteration(kt, nk, 0);
-    if (kt + 1 < nk) iteration(kt + 1, nk, 1);
-  }
+  bool prefetched = false;
+  for (int lin = blockIdx.x; lin < a.ntiles; lin += gridDim.x) {
+    if (!prefetched) {  // first tile of this block: nothing in flight yet
+      tile_coords(lin);
+      setup_pointers();
+      if (nk > 0) load_tiles(rbeg);
+    }
+    setup_row_state();
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[tj][ti][e] = 0.f;
+    if (nk > 0) {
+      mask_tiles(rbeg);
+      transform(rbeg);
+      store_tiles(0);
+      if (nk > 1) load_tiles(rbeg + BK);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      iteration(kt, nk, 0);
+      if (kt + 1 < nk) iteration(kt + 1, nk, 1);
+    }
+    // epilogue coordinates of THIS tile, then start fetching the next one (the staging registers
+    // and both LDS buffers are free: the main loop ended on a barrier)
+    const int ei0 = i0, ej0 = j0;
+    prefetched = lin + (int)gridDim.x < a.ntiles;
+    if (prefetched) {
+      tile_coords(lin + gridDim.x);
+      setup_pointers();
+      if (nk > 0) load_tiles(rbeg);
+    }
 
   // ---- epilogue: lane holds, per accumulator quad q, columns j..j+3 of row i ----------
 #pragma unroll
   for (int ti = 0; ti < TI; ++ti) {
-    const int i = i0 + wi * (32 * TI) + 32 * ti + lr;
+    const int i = ei0 + wi * (32 * TI) + 32 * ti + lr;
     if (i >= g.I) continue;
     const float* posrow = (EPI == HIG_EPI_BIAS_POS) ? g.pos + (int64_t)(i % g.T) * g.ldpos : nullptr;
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int j = j0 + wj * (32 * TJ) + 32 * tj + 8 * q + 4 * lh;
+        const int j = ej0 + wj * (32 * TJ) + 32 * tj + 8 * q + 4 * lh;
         if (j >= g.J) continue;
         float v[4] = {acc[tj][ti][4 * q], acc[tj][ti][4 * q + 1], acc[tj][ti][4 * q + 2],
                       acc[tj][ti][4 * q + 3]};
@@ -498,6 +522,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
       }
     }
   }
+  }  // persistent tile loop
 }
 
 // out[e] = sum_s slabs[s][e]
@@ -539,6 +564,17 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
   a.vecc = (a.g.ldc % 4 == 0) && al16(a.g.C) && (a.slab % 4 == 0) &&
            (!g.res || ((g.ldr % 4 == 0) && al16(g.res))) &&
            (!g.aux || ((g.ldaux % 4 == 0) && al16(g.aux)));
+  // persistent grid: as many workgroups as fit on the chip at once (LDS-limited), rounded to the 8 XCDs
+  constexpr int kStage = ((X_RS ? BK * BI : BI * RC_LD) + (Y_RS ? BK * BJ : BJ * RC_LD));
+  constexpr int kLdsF32 = 2 * kStage * 4;
+  constexpr int kLdsBf3 = 2 * (BI + BJ) * (BF_LD / 2) * 2 * 4;
+  const int lds_bytes = (g.prec == HIG_PREC_BF16X3 && !X_RS && !Y_RS) ? kLdsBf3 : kLdsF32;
+  int per_cu = 160 * 1024 / lds_bytes;
+  per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+  const int max_vgpr_blocks = (BI * BJ >= 128 * 128) ? 2 : 4;   // 128x128: <=256 VGPRs -> 2 waves/SIMD
+  if (per_cu > max_vgpr_blocks) per_cu = max_vgpr_blocks;
+  int gridx = 256 * per_cu;
+  if (gridx > a.ntiles) gridx = a.ntiles;
   const bool fast = a.vecx && a.vecy && (g.R % BK == 0) && g.R > 0 &&
                     (!X_RS || (g.I % 4 == 0 && g.I >= 4)) && (!Y_RS || (g.J % 4 == 0 && g.J >= 4));
   if (a.ntiles > 0 && g.R >= 0) {
@@ -548,21 +584,21 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
     if constexpr (!X_RS && !Y_RS) {
       if (fast && g.prec == HIG_PREC_BF16X3) {
         hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, true, HIG_PREC_BF16X3>),
-                           dim3(a.ntiles, splits), dim3(NTHREADS), 0, st, a);
+                           dim3(gridx, splits), dim3(NTHREADS), 0, st, a);
         launched = true;
       } else if (fast && g.prec == HIG_PREC_BF16) {
         hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, true, HIG_PREC_BF16>),
-                           dim3(a.ntiles, splits), dim3(NTHREADS), 0, st, a);
+                           dim3(gridx, splits), dim3(NTHREADS), 0, st, a);
         launched = true;
       }
     }
     if (!launched) {
       if (fast)
         hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, true, HIG_PREC_F32>),
-                           dim3(a.ntiles, splits), dim3(NTHREADS), 0, st, a);
+                           dim3(gridx, splits), dim3(NTHREADS), 0, st, a);
       else
         hipLaunchKernelGGL((gemm_f32_kernel<BI, BJ, X_RS, Y_RS, XF, XF_ON_Y, EPI, false, HIG_PREC_F32>),
-                           dim3(a.ntiles, splits), dim3(NTHREADS), 0, st, a);
+                           dim3(gridx, splits), dim3(NTHREADS), 0, st, a);
     }
   }
   HIG_CHECK_LAUNCH();

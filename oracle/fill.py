@@ -84,6 +84,37 @@ def core_param_shapes(F, d, ff, L, Lt, num_frames):
     return s
 
 
+def interaction_param_shapes(F, d, ff, L, Lt, num_frames, no_cross_attn=False):
+    """Denoiser core of MotionInteractionTransformer (interaction_transformer.py:459-507): the
+    single-person core + joint_embed2, out2 and one int_ca_block per layer."""
+    s = core_param_shapes(F, d, ff, L, Lt, num_frames)
+    E = 4 * d
+    s["joint_embed2.weight"] = (d, 4)
+    s["joint_embed2.bias"] = (d,)
+    s["out2.weight"] = (F, d)
+    s["out2.bias"] = (F,)
+    if not no_cross_attn:
+        for l in range(L):
+            b = "temporal_decoder_blocks.%d.int_ca_block" % l
+            s[b + ".norm.weight"] = (d,)
+            s[b + ".norm.bias"] = (d,)
+            for nm in ("query", "key", "value"):
+                s[b + "." + nm + ".weight"] = (d, d)
+                s[b + "." + nm + ".bias"] = (d,)
+            s[b + ".proj_out.emb_layers.1.weight"] = (2 * d, E)
+            s[b + ".proj_out.emb_layers.1.bias"] = (2 * d,)
+            s[b + ".proj_out.norm.weight"] = (d,)
+            s[b + ".proj_out.norm.bias"] = (d,)
+            s[b + ".proj_out.out_layers.2.weight"] = (d, d)
+            s[b + ".proj_out.out_layers.2.bias"] = (d,)
+    return s
+
+
+def interaction_params(F, d, ff, L, Lt, num_frames, dtype=torch.float32, no_cross_attn=False):
+    return {k: tensor_for(k, v, dtype)
+            for k, v in interaction_param_shapes(F, d, ff, L, Lt, num_frames, no_cross_attn).items()}
+
+
 def core_params(F, d, ff, L, Lt, num_frames, dtype=torch.float32):
     return {k: tensor_for(k, v, dtype) for k, v in core_param_shapes(F, d, ff, L, Lt, num_frames).items()}
 
@@ -99,6 +130,14 @@ def inputs(B, T, F, d, N, Lt, lengths, t_values, dtype=torch.float32):
         "length": torch.tensor(list(lengths), dtype=torch.int64),
     }
 
+
+# two-person cases: B = number of PAIRS (the model batch is 2B); lengths/t are per pair
+ICASES = {
+    "tiny2": dict(B=2, T=16, F=12, d=64, H=8, L=2, ff=128, N=77, Lt=32, num_frames=20,
+                  lengths=(16, 9), t=(3, 987)),
+    "config1x2": dict(B=2, T=61, F=150, d=128, H=8, L=3, ff=1024, N=77, Lt=256, num_frames=60,
+                      lengths=(61, 41), t=(0, 500)),
+}
 
 CASES = {
     # name: dict(B,T,F,d,H,L,ff,N,Lt,num_frames,lengths,t)

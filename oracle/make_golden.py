@@ -259,6 +259,105 @@ def g6():
     np.savez_compressed(os.path.join(GOLD, "g6_trainer.npz"), **out)
 
 
+def build_ref_interaction(c, **kw):
+    from models.interaction_transformer import MotionInteractionTransformer
+    m = MotionInteractionTransformer(input_feats=c["F"], num_frames=c["num_frames"], latent_dim=c["d"],
+                                     ff_size=c["ff"], num_layers=c["L"], num_heads=c["H"],
+                                     text_latent_dim=c["Lt"], **kw)
+    m.load_state_dict(fill.fill_state_dict(m.state_dict()), strict=True)
+    return m.eval()
+
+
+def interaction_inputs(c):
+    """(2B, ...) inputs: both persons share t / length / text of their pair (mul_ddpm_trainer.py:113-127)."""
+    B = c["B"]
+    inp = fill.inputs(2 * B, c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"] * 2, c["t"] * 2)
+    return inp
+
+
+def g8_interaction():
+    out = {}
+    for cname, c in fill.ICASES.items():
+        for nca in (False, True):
+            tag = cname + (".nocross" if nca else "")
+            m = build_ref_interaction(c, no_cross_attn=nca)
+            inp = interaction_inputs(c)
+            x = inp["x"].clone().requires_grad_(True)
+            xp = inp["xf_proj"].clone().requires_grad_(True)
+            xo = inp["xf_out"].clone().requires_grad_(True)
+            y = m(x, inp["t"], length=inp["length"], xf_proj=xp, xf_out=xo)
+            out[tag + ".out"] = y.detach().numpy()
+            if nca:
+                continue
+            r = fill.tensor_for("loss.r." + cname, y.shape) * 10.0
+            (y * r).sum().backward()
+            out[tag + ".dx"] = x.grad.numpy()
+            out[tag + ".dxf_proj"] = xp.grad.numpy()
+            out[tag + ".dxf_out"] = xo.grad.numpy()
+            named = dict(m.named_parameters())
+            L = c["L"] - 1
+            for pn in ("joint_embed2.weight", "joint_embed2.bias", "out2.weight", "out2.bias", "out.bias",
+                       "joint_embed.bias", "temporal_decoder_blocks.0.int_ca_block.norm.weight",
+                       "temporal_decoder_blocks.0.int_ca_block.query.bias",
+                       "temporal_decoder_blocks.0.int_ca_block.value.bias",
+                       "temporal_decoder_blocks.%d.int_ca_block.proj_out.norm.bias" % L,
+                       "temporal_decoder_blocks.%d.int_ca_block.proj_out.out_layers.2.bias" % L,
+                       "temporal_decoder_blocks.%d.int_ca_block.proj_out.emb_layers.1.bias" % L,
+                       "temporal_decoder_blocks.0.sa_block.value.bias", "temporal_decoder_blocks.0.ffn.linear1.bias"):
+                out[tag + ".g." + pn] = named[pn].grad.numpy()
+            core = fill.interaction_param_shapes(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"])
+            tot = torch.sqrt(sum((named[k].grad.double() ** 2).sum() for k in core))
+            out[tag + ".gnorm_core"] = np.float64(tot.item())
+    # state-dict key / shape contract of the two-person module (tiny)
+    m = build_ref_interaction(fill.ICASES["tiny2"])
+    for k, v in m.state_dict().items():
+        out["keys." + k] = np.array(v.shape, dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "g8_interaction.npz"), **out)
+
+
+def g9_mul_trainer():
+    """One DDPMMulTrainer.forward + update in PIT mode (no label file) with injected t / noise."""
+    import trainers.mul_ddpm_trainer as tr
+    c = fill.ICASES["config1x2"]
+    m = build_ref_interaction(c).train()
+    args = types.SimpleNamespace(device=torch.device("cpu"), diffusion_steps=1000, is_train=True, lr=2e-4,
+                                 batch_size=c["B"], num_epochs=1, log_every=50, save_latest=500, save_every_e=5,
+                                 is_continue=False, model_dir="/tmp", multi=True, label_path=None, cap_id=False)
+    trainer = tr.DDPMMulTrainer(args, m)
+    trainer.opt_encoder = torch.optim.Adam(m.parameters(), lr=args.lr)
+    B, T, Fd = c["B"], c["T"], c["F"]
+    motion1 = fill.tensor_for("g9.motion1", (B, T, Fd)) * 10
+    motion2 = fill.tensor_for("g9.motion2", (B, T, Fd)) * 10
+    cap1 = ["a person shakes hands with another person", "one pushes the other"]
+    cap2 = ["a person receives a handshake", "one is pushed by the other"]
+    t_fixed = torch.tensor(c["t"])
+    trainer.sampler.sample = lambda bs, dev: (t_fixed.to(dev), torch.ones(bs))
+    captured = {}
+    real_clip = tr.clip_grad_norm_
+
+    def spy(params, max_norm):
+        captured["gnorm"] = float(real_clip(params, max_norm))
+        return captured["gnorm"]
+
+    tr.clip_grad_norm_ = spy
+    undo = _patch_noise(_NoiseFeed("g9.noise"))
+    try:
+        trainer.forward((cap1, cap2, motion1, motion2, torch.tensor(c["lengths"]), None))
+        logs = trainer.update()
+    finally:
+        undo()
+        tr.clip_grad_norm_ = real_clip
+    sd = m.state_dict()
+    out = {"loss_mot_rec": np.float64(logs["loss_mot_rec"]), "gnorm": np.float64(captured["gnorm"]),
+           "src_mask": trainer.src_mask.numpy(), "fake_noise": trainer.fake_noise.detach().numpy()}
+    for pn in ("out.bias", "out2.bias", "out2.weight", "joint_embed2.bias",
+               "temporal_decoder_blocks.0.int_ca_block.query.bias",
+               "temporal_decoder_blocks.2.int_ca_block.proj_out.out_layers.2.bias",
+               "temporal_decoder_blocks.2.ffn.linear2.bias", "text_ln.weight"):
+        out["p." + pn] = sd[pn].numpy()
+    np.savez_compressed(os.path.join(GOLD, "g9_mul_trainer.npz"), **out)
+
+
 def g7_state_dict_keys():
     """Key/shape contract of the reference module (tiny config) for the round-trip test."""
     c = fill.CASES["tiny"]
@@ -272,6 +371,9 @@ if __name__ == "__main__":
     install_stubs()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    for fn in (g1, g2_g3, g4, g5, g6, g7_state_dict_keys):
+    only = sys.argv[1:]
+    for fn in (g1, g2_g3, g4, g5, g6, g7_state_dict_keys, g8_interaction, g9_mul_trainer):
+        if only and fn.__name__ not in only:
+            continue
         fn()
         print("wrote", fn.__name__)

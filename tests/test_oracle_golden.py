@@ -124,3 +124,48 @@ def test_properties_padding_and_permutation():
         pr = R.denoiser_forward(p, inp["x"][perm], inp["t"][perm], inp["length"][perm],
                                 inp["xf_proj"][perm], inp["xf_out"][perm], c["H"], c["L"])
         assert rel(pr, full[perm]) < 1e-6
+
+
+# ---- two-person path -----------------------------------------------------------
+from oracle import interaction_ref as IR  # noqa: E402
+
+
+def _iinputs(c):
+    B = c["B"]
+    return fill.inputs(2 * B, c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"] * 2, c["t"] * 2)
+
+
+@pytest.mark.parametrize("case", ["tiny2", "config1x2"])
+def test_g8_interaction_forward_backward(gold, case):
+    g = gold("g8_interaction.npz")
+    c = fill.ICASES[case]
+    inp = _iinputs(c)
+    for nca in (True, False):
+        tag = case + (".nocross" if nca else "")
+        p = {k: v.requires_grad_(True) for k, v in
+             fill.interaction_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"], no_cross_attn=nca).items()}
+        x, xp, xo = (inp[k].clone().requires_grad_(True) for k in ("x", "xf_proj", "xf_out"))
+        out = IR.interaction_forward(p, x, inp["t"], inp["length"], xp, xo, c["H"], c["L"], no_cross_attn=nca)
+        assert rel(out, g[tag + ".out"]) < 2e-6
+    r = fill.tensor_for("loss.r." + case, out.shape) * 10.0
+    (out * r).sum().backward()
+    assert rel(x.grad, g[case + ".dx"]) < 1e-5 and rel(xp.grad, g[case + ".dxf_proj"]) < 1e-5
+    assert rel(xo.grad, g[case + ".dxf_out"]) < 1e-5
+    for k in g.files:
+        if k.startswith(case + ".g."):
+            a, b = p[k[len(case) + 3:]].grad.double(), torch.as_tensor(g[k]).double()
+            assert (a - b).norm() <= 1e-5 * b.norm() + 1e-6 * b.numel() ** 0.5, k
+    tot = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in p.values())).item()
+    assert abs(tot - float(g[case + ".gnorm_core"])) / float(g[case + ".gnorm_core"]) < 1e-5
+
+
+def test_pit_loss_symmetry():
+    """PIT loss (mul_ddpm_trainer.py:234-243): swapping the caption assignment groups leaves it unchanged."""
+    n, T, Fd = 8, 5, 6
+    pred, tgt = fill.tensor_for("pit.pred", (n, T, Fd)), fill.tensor_for("pit.tgt", (n, T, Fd))
+    mask = torch.ones(n, T)
+    a = IR.pit_loss(pred, tgt, mask)
+    perm = torch.tensor([2, 3, 0, 1, 6, 7, 4, 5])   # (m1|c1, m1|c2, m2|c2, m2|c1) -> swap c1 <-> c2 groups
+    b = IR.pit_loss(pred[perm], tgt[perm], mask)
+    assert torch.allclose(a, b)
+    assert IR.pit_loss(pred, tgt, mask) <= IR.labelled_loss(pred, tgt, mask) * 2 + 1e-6
