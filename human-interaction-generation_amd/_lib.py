@@ -11,8 +11,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhig.so")
 
-NGLOBAL = 11
-NLAYER = 28
+NGLOBAL = 15
+NLAYER = 36
 ATTN_LINEAR, ATTN_FULL = 0, 1
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 XF_NONE, XF_LN, XF_LN_MOD_SILU, XF_SILU = 0, 1, 2, 3
@@ -34,7 +34,7 @@ SYMBOLS = (
 
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("B", "T", "F", "d", "H", "ff", "L", "N", "Lt", "num_frames", "attn_kind", "prec")]
+                ("B", "T", "F", "d", "H", "ff", "L", "N", "Lt", "num_frames", "attn_kind", "prec", "two_person")]
 
 
 class GemmDesc(C.Structure):
@@ -51,7 +51,7 @@ class GemmDesc(C.Structure):
         ("gamma", C.c_void_p), ("beta", C.c_void_p),
         ("ss", C.c_void_p), ("ss_ld", C.c_int64), ("ss_shift_off", C.c_int32),
         ("rows_per_sample", C.c_int32),
-        ("pos", C.c_void_p), ("ldpos", C.c_int64), ("T", C.c_int32),
+        ("pos", C.c_void_p), ("ldpos", C.c_int64), ("T", C.c_int32), ("pos_shift", C.c_int32),
     ]
 
 

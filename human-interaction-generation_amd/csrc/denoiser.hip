@@ -38,10 +38,26 @@ __global__ void mul_dsilu_kernel(const float* __restrict__ a, const float* __res
     out[i] = a[i] * hig_dsilu(z[i]);
 }
 
+// out[b] = in[(b + B/2) % B]  (the partner's sequence length, two-person model)
+__global__ void swap_halves_i64_kernel(const int64_t* __restrict__ in, int B, int64_t fill, int64_t* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) out[b] = in ? in[(b + B / 2) % B] : fill;
+}
+// Copies row (b, 0, :) of buf [B][T][n] to tok0 [B][n] (if tok0) and zeroes it in buf (if zero).
+__global__ void tok0_kernel(float* __restrict__ buf, int64_t sample_stride, int B, int n, float* __restrict__ tok0,
+                            int zero) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * n) return;
+  const int b = idx / n, c = idx % n;
+  float* p = buf + (int64_t)b * sample_stride + c;
+  if (tok0) tok0[idx] = *p;
+  if (zero) *p = 0.f;
+}
+
 inline int64_t al(int64_t floats) { return (floats + 63) & ~(int64_t)63; }  // 256-byte granules
 
 struct Dims {
-  int B, T, F, d, H, ff, L, N, Lt, nf, hd, E, prec, full;
+  int B, T, F, d, H, ff, L, N, Lt, nf, hd, E, prec, full, two, nsty;
   int64_t M, Mt;
 };
 
@@ -58,7 +74,6 @@ int check_dims(const hig_dims* p, Dims& D) {
               "hig_dims: head dim %d not in {8,16,32,64,128}", D.hd);
   HIG_REQUIRE(D.d % 4 == 0 && D.ff % 4 == 0 && D.Lt % 4 == 0, "hig_dims: d, ff, Lt must be multiples of 4");
   HIG_REQUIRE(D.d <= 1024 && D.Lt <= 1024, "hig_dims: d and Lt must be <= 1024");
-  HIG_REQUIRE(D.T <= D.nf, "hig_dims: T=%d exceeds num_frames=%d", D.T, D.nf);
   HIG_REQUIRE(p->attn_kind == HIG_ATTN_LINEAR || p->attn_kind == HIG_ATTN_FULL, "hig_dims: unknown attn_kind=%d",
               p->attn_kind);
   D.full = p->attn_kind == HIG_ATTN_FULL;
@@ -67,6 +82,16 @@ int check_dims(const hig_dims* p, Dims& D) {
   if (p->prec != HIG_PREC_F32 && p->prec != HIG_PREC_BF16X3 && p->prec != HIG_PREC_BF16)
     return hig_set_error(HIG_EINVAL, "hig: unknown prec=%d", p->prec);
   D.prec = p->prec;
+  HIG_REQUIRE(p->two_person >= 0 && p->two_person <= 2, "hig_dims: two_person must be 0, 1 or 2");
+  D.two = p->two_person;
+  D.nsty = D.two == 1 ? 4 : 3;  // stylization blocks per layer: sa, ca, [int_ca], ffn
+  if (D.two) {
+    HIG_REQUIRE(D.B % 2 == 0 && D.T >= 2 && D.F >= 4, "hig_dims: two-person needs even B, T >= 2, F >= 4");
+    HIG_REQUIRE(D.T - 1 <= D.nf, "hig_dims: T-1=%d exceeds num_frames=%d", D.T - 1, D.nf);
+    if (D.full) return hig_set_error(HIG_EUNSUPPORTED, "hig: the two-person model is built for linear attention only");
+  } else {
+    HIG_REQUIRE(D.T <= D.nf, "hig_dims: T=%d exceeds num_frames=%d", D.T, D.nf);
+  }
   D.M = (int64_t)D.B * D.T;
   D.Mt = (int64_t)D.B * D.N;
   return HIG_OK;
@@ -74,9 +99,10 @@ int check_dims(const hig_dims* p, Dims& D) {
 
 // Forward workspace (floats).  Per-layer block repeated L times when training, once otherwise.
 struct FwdLayout {
-  int64_t te, te_h, emb, ss, h0;
+  int64_t te, te_h, emb, ss, h0, lenp;
   int64_t layer0, lstride;
   int64_t st1, qkv, A1, kst1, lse1, y1, st2, a1, h1, st3, qc, lse2, y2, st4, a2, h2, z1, f1, y3, st5, a3, h3;
+  int64_t st6, iqkv, Ai, ksti, y4, st7, a4, h2b;  // two-person interaction attention block
   int64_t total;
 };
 FwdLayout fwd_layout(const Dims& D, int training) {
@@ -86,8 +112,9 @@ FwdLayout fwd_layout(const Dims& D, int training) {
   w.te = take((int64_t)D.B * D.d);
   w.te_h = take((int64_t)D.B * D.E);
   w.emb = take((int64_t)D.B * D.E);
-  w.ss = take((int64_t)D.B * 3 * D.L * 2 * D.d);
+  w.ss = take((int64_t)D.B * D.nsty * D.L * 2 * D.d);
   w.h0 = take(D.M * D.d);
+  w.lenp = take((int64_t)D.B * 2);  // int64 lengths with the two halves swapped (partner's mask)
   w.layer0 = o;
   o = 0;
   w.st1 = take(D.M * 2);
@@ -112,6 +139,17 @@ FwdLayout fwd_layout(const Dims& D, int training) {
   w.st5 = take(D.M * 2);
   w.a3 = take(D.M * D.d);
   w.h3 = take(D.M * D.d);
+  w.st6 = w.iqkv = w.Ai = w.ksti = w.y4 = w.st7 = w.a4 = w.h2b = 0;
+  if (D.two == 1) {
+    w.st6 = take(D.M * 2);
+    w.iqkv = take(D.M * 3 * D.d);
+    w.Ai = take((int64_t)D.B * D.H * D.hd * D.hd);
+    w.ksti = take((int64_t)D.B * D.d * 2);
+    w.y4 = take(D.M * D.d);
+    w.st7 = take(D.M * 2);
+    w.a4 = take(D.M * D.d);
+    w.h2b = take(D.M * D.d);
+  }
   w.lstride = training ? o : 0;
   w.total = w.layer0 + (training ? o * D.L : o);
   return w;
@@ -143,7 +181,7 @@ TextLayout text_layout(const Dims& D, int training) {
 
 struct BwdLayout {
   int64_t dhA, dhB, t1, t2, tff, dqkv, dA, delta, dkv, dxfn, dss, demb, dtmp, dte_h, slabs, slab_floats,
-      colpart, lnpart, wT, tA, tB, attn, total;
+      colpart, lnpart, wT, tA, tB, attn, tok0, doutm, postmp, total;
 };
 BwdLayout bwd_layout(const Dims& D) {
   BwdLayout w;
@@ -159,7 +197,7 @@ BwdLayout bwd_layout(const Dims& D) {
   w.delta = take((int64_t)D.B * D.H * D.T);
   w.dkv = take(D.Mt * 2 * D.d);
   w.dxfn = take(D.Mt * D.Lt);
-  w.dss = take((int64_t)D.B * 3 * D.L * 2 * D.d);
+  w.dss = take((int64_t)D.B * D.nsty * D.L * 2 * D.d);
   w.demb = take((int64_t)D.B * D.E);
   w.dtmp = take((int64_t)D.B * D.E);
   w.dte_h = take((int64_t)D.B * D.E);
@@ -174,7 +212,7 @@ BwdLayout bwd_layout(const Dims& D) {
   // column-sum partials: [chunks(rows)][n] for every (rows, n) the backward reduces
   int64_t colp = 0;
   const int64_t uses[][2] = {{D.M, 3 * D.d}, {D.M, D.ff}, {D.M, D.F}, {D.Mt, 2 * D.d}, {D.B, D.E},
-                             {D.B, (int64_t)3 * D.L * 2 * D.d}, {D.B, (int64_t)D.T * D.d}};
+                             {D.B, (int64_t)D.nsty * D.L * 2 * D.d}, {D.B, (int64_t)D.T * D.d}};
   for (auto& u : uses) {
     const int64_t v = (int64_t)hig_colsum_chunks(u[0]) * u[1];
     colp = v > colp ? v : colp;
@@ -184,7 +222,7 @@ BwdLayout bwd_layout(const Dims& D) {
   const int64_t lpt = hig_ln_bwd_partial_floats(D.Mt, D.Lt, D.N);
   w.lnpart = take(lp > lpt ? lp : lpt);
   // one layer's transposed weights (reduce-contiguous operands for the data-gradient GEMMs)
-  w.wT = take((int64_t)7 * D.d * D.d + (int64_t)2 * D.d * D.ff + (int64_t)2 * D.d * D.Lt);
+  w.wT = take((int64_t)11 * D.d * D.d + (int64_t)2 * D.d * D.ff + (int64_t)2 * D.d * D.Lt);
   // transposed dC / activation operands of the weight-gradient GEMMs (bf16 product modes)
   const int64_t mrows = D.M > D.Mt ? D.M : D.Mt;
   const int64_t wide = 3 * D.d > D.ff ? 3 * D.d : D.ff;
@@ -193,6 +231,9 @@ BwdLayout bwd_layout(const Dims& D) {
   const int64_t as1 = hig_linattn_bwd_scratch_floats(D.B, D.T, D.H, D.hd);
   const int64_t as2 = hig_linattn_bwd_scratch_floats(D.B, D.N, D.H, D.hd);
   w.attn = take(as1 > as2 ? as1 : as2);
+  w.tok0 = take((int64_t)D.B * D.d);       // two-person: init-pose rows of d(h0)
+  w.doutm = take(D.two ? D.M * D.F : 0);   // two-person: d(out) with the init-pose rows zeroed
+  w.postmp = take(D.two ? (int64_t)D.T * D.d : 0);
   w.total = o;
   return w;
 }
@@ -299,7 +340,8 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
   hipStream_t st = hig_stream(stream);
   const int d = D.d, E = D.E;
   const int64_t M = D.M;
-  const int64_t ss_ld = (int64_t)3 * D.L * 2 * d;
+  const int64_t ss_ld = (int64_t)D.nsty * D.L * 2 * d;
+  const int Bp = D.B / 2;  // pairs (two-person)
 
   // K0: emb = time_embed(timestep_embedding(t)) + xf_proj; all 3L scale/shift pairs in ONE GEMM
   HIG_TRY(hig_timestep_embedding(t, D.B, d, ws + w.te, stream));
@@ -310,13 +352,27 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
   HIG_TRY(hig_gemm_launch(G(ws + w.emb, E, 0, P(params, HIG_P_STY_EMB_W), E, 0, ws + w.ss, ss_ld, D.B, ss_ld, E)
                               .silu(0).epi(HIG_EPI_BIAS, P(params, HIG_P_STY_EMB_B)).prec(D.prec).g, 1, nullptr, st));
   // K1: h0 = joint_embed(x) + sequence_embedding[:T]
-  HIG_TRY(hig_gemm_launch(G(x, D.F, 0, P(params, HIG_P_JOINT_W), D.F, 0, ws + w.h0, d, M, d, D.F)
-                              .epi(HIG_EPI_BIAS_POS, P(params, HIG_P_JOINT_B)).pos(P(params, HIG_P_SEQ_EMB), d, D.T).prec(D.prec).g,
-                          1, nullptr, st));
+  {
+    G ge(x, D.F, 0, P(params, HIG_P_JOINT_W), D.F, 0, ws + w.h0, d, M, d, D.F);
+    ge.epi(HIG_EPI_BIAS_POS, P(params, HIG_P_JOINT_B)).pos(P(params, HIG_P_SEQ_EMB), d, D.T).prec(D.prec);
+    ge.g.pos_shift = D.two ? 1 : 0;  // two-person: frame t >= 1 gets sequence_embedding[t-1] (:595)
+    HIG_TRY(hig_gemm_launch(ge.g, 1, nullptr, st));
+  }
+  const int64_t* len_partner = nullptr;
+  if (D.two) {
+    // token 0 is the init-pose row: joint_embed2 on its first 4 features, no positional term (:596)
+    HIG_TRY(hig_gemm_launch(G(x, (int64_t)D.T * D.F, 0, P(params, HIG_P_JOINT2_W), 4, 0, ws + w.h0, (int64_t)D.T * d,
+                              D.B, d, 4).epi(HIG_EPI_BIAS, P(params, HIG_P_JOINT2_B)).g, 1, nullptr, st));
+    int64_t* lp = reinterpret_cast<int64_t*>(ws + w.lenp);
+    hipLaunchKernelGGL(swap_halves_i64_kernel, dim3((D.B + 255) / 256), dim3(256), 0, st, length, D.B, (int64_t)D.T, lp);
+    HIG_CHECK_LAUNCH();
+    len_partner = lp;
+  }
   const float* hin = ws + w.h0;
   for (int l = 0; l < D.L; ++l) {
     float* lb = ws + w.layer0 + w.lstride * l;
-    const float* ssl = ws + w.ss + (int64_t)(3 * l) * 2 * d;
+    const float* ssl = ws + w.ss + (int64_t)(D.nsty * l) * 2 * d;
+    const float* ss_ffn = ssl + (int64_t)(D.nsty - 1) * 2 * d;
     // ---- self attention -------------------------------------------------------------
     HIG_TRY(hig_rowstats(hin, d, M, d, lb + w.st1, stream));
     HIG_TRY(hig_gemm_launch(G(hin, d, 0, PL(params, l, HIG_L_SA_QKV_W), d, 0, lb + w.qkv, 3 * d, M, 3 * d, d)
@@ -351,21 +407,46 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
                             ssl + 2 * d, ss_ld, d, D.T, lb + w.a2, d, lb + w.st4, stream));
     HIG_TRY(hig_gemm_launch(G(lb + w.a2, d, 0, PL(params, l, HIG_L_CA_STY_OUT_W), d, 0, lb + w.h2, d, M, d, d)
                                 .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_CA_STY_OUT_B)).res(lb + w.h1, d).prec(D.prec).g, 1, nullptr, st));
+    const float* hffn = lb + w.h2;
+    if (D.two == 1) {
+      // ---- person <-> person linear cross attention (interaction_transformer.py:181-205): queries from
+      // the own stream, key/value from the partner's (same LayerNorm on both), key softmax masked with
+      // the consumer's length, value unmasked (masked rows carry k == 0 anyway)
+      HIG_TRY(hig_rowstats(lb + w.h2, d, M, d, lb + w.st6, stream));
+      HIG_TRY(hig_gemm_launch(G(lb + w.h2, d, 0, PL(params, l, HIG_L_INT_QKV_W), d, 0, lb + w.iqkv, 3 * d, M, 3 * d, d)
+                                  .ln(0, lb + w.st6, PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B))
+                                  .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_INT_QKV_B)).prec(D.prec).g, 1, nullptr, st));
+      HIG_TRY(hig_linattn_ctx(lb + w.iqkv + d, lb + w.iqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, len_partner,
+                              lb + w.Ai, lb + w.ksti, stream));
+      const int64_t halfA = (int64_t)Bp * D.H * D.hd * D.hd, halfM = (int64_t)Bp * D.T;
+      HIG_TRY(hig_linattn_apply(lb + w.iqkv, 3 * d, lb + w.Ai + halfA, lb + w.y4, d, Bp, D.T, D.H, D.hd, stream));
+      HIG_TRY(hig_linattn_apply(lb + w.iqkv + halfM * 3 * d, 3 * d, lb + w.Ai, lb + w.y4 + halfM * d, d, Bp, D.T, D.H,
+                                D.hd, stream));
+      HIG_TRY(hig_ln_mod_silu(lb + w.y4, d, M, d, PL(params, l, HIG_L_INT_STY_NORM_W), PL(params, l, HIG_L_INT_STY_NORM_B),
+                              ssl + 4 * d, ss_ld, d, D.T, lb + w.a4, d, lb + w.st7, stream));
+      HIG_TRY(hig_gemm_launch(G(lb + w.a4, d, 0, PL(params, l, HIG_L_INT_STY_OUT_W), d, 0, lb + w.h2b, d, M, d, d)
+                                  .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_INT_STY_OUT_B)).res(lb + w.h2, d).prec(D.prec).g,
+                              1, nullptr, st));
+      hffn = lb + w.h2b;
+    }
     // ---- FFN ------------------------------------------------------------------------
-    HIG_TRY(hig_gemm_launch(G(lb + w.h2, d, 0, PL(params, l, HIG_L_FFN_W1), d, 0, lb + w.f1, D.ff, M, D.ff, d)
+    HIG_TRY(hig_gemm_launch(G(hffn, d, 0, PL(params, l, HIG_L_FFN_W1), d, 0, lb + w.f1, D.ff, M, D.ff, d)
                                 .epi(HIG_EPI_BIAS_GELU, PL(params, l, HIG_L_FFN_B1))
                                 .aux(training ? lb + w.z1 : nullptr, D.ff).prec(D.prec).g, 1, nullptr, st));
     HIG_TRY(hig_gemm_launch(G(lb + w.f1, D.ff, 0, PL(params, l, HIG_L_FFN_W2), D.ff, 0, lb + w.y3, d, M, d, D.ff)
                                 .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B2)).prec(D.prec).g, 1, nullptr, st));
     HIG_TRY(hig_ln_mod_silu(lb + w.y3, d, M, d, PL(params, l, HIG_L_FFN_STY_NORM_W), PL(params, l, HIG_L_FFN_STY_NORM_B),
-                            ssl + 4 * d, ss_ld, d, D.T, lb + w.a3, d, lb + w.st5, stream));
+                            ss_ffn, ss_ld, d, D.T, lb + w.a3, d, lb + w.st5, stream));
     HIG_TRY(hig_gemm_launch(G(lb + w.a3, d, 0, PL(params, l, HIG_L_FFN_STY_OUT_W), d, 0, lb + w.h3, d, M, d, d)
-                                .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_FFN_STY_OUT_B)).res(lb + w.h2, d).prec(D.prec).g, 1, nullptr, st));
+                                .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_FFN_STY_OUT_B)).res(hffn, d).prec(D.prec).g, 1, nullptr, st));
     hin = lb + w.h3;
   }
   // K6: out = Linear(d, F)(h_L)
   HIG_TRY(hig_gemm_launch(G(hin, d, 0, P(params, HIG_P_OUT_W), d, 0, out, D.F, M, D.F, d)
                               .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT_B)).prec(D.prec).g, 1, nullptr, st));
+  if (D.two)  // init-pose rows go through out2 instead (:613-614)
+    HIG_TRY(hig_gemm_launch(G(hin, (int64_t)D.T * d, 0, P(params, HIG_P_OUT2_W), d, 0, out, (int64_t)D.T * D.F, D.B, D.F, d)
+                                .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT2_B)).g, 1, nullptr, st));
   return HIG_OK;
 }
 
@@ -388,7 +469,8 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
   hipStream_t st = hig_stream(stream);
   const int d = D.d, E = D.E, ff = D.ff, F = D.F, Lt = D.Lt;
   const int64_t M = D.M, Mt = D.Mt;
-  const int64_t ss_ld = (int64_t)3 * D.L * 2 * d;
+  const int64_t ss_ld = (int64_t)D.nsty * D.L * 2 * d;
+  const int Bp = D.B / 2;
   float* slabs = b + bw.slabs;
   float* colp = b + bw.colpart;
   float* lnp = b + bw.lnpart;
@@ -420,7 +502,8 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
   float* wT = b + bw.wT;
   const int64_t o_sty3 = 0, o_w2t = o_sty3 + (int64_t)d * d, o_w1t = o_w2t + (int64_t)d * ff,
                 o_sty2 = o_w1t + (int64_t)d * ff, o_caq = o_sty2 + (int64_t)d * d, o_kv = o_caq + (int64_t)d * d,
-                o_sty1 = o_kv + (int64_t)2 * d * Lt, o_qkv = o_sty1 + (int64_t)d * d;
+                o_sty1 = o_kv + (int64_t)2 * d * Lt, o_qkv = o_sty1 + (int64_t)d * d,
+                o_isty = o_qkv + (int64_t)3 * d * d, o_iqkv = o_isty + (int64_t)d * d;
   auto wtrans = [&](const float* W, int out_f, int in_f, int64_t off) -> int {
     return hig_transpose(W, in_f, out_f, in_f, wT + off, out_f, nullptr, nullptr, nullptr, stream);
   };
@@ -442,11 +525,27 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
 
   // ---- output projection ---------------------------------------------------------------
   const float* hL = ws + w.layer0 + w.lstride * (D.L - 1) + w.h3;
-  HIG_TRY(colsum(dout, F, M, F, GP(grads, HIG_P_OUT_B)));
-  HIG_TRY(wgrad(G(dout, F, 1, hL, d, 1, GP(grads, HIG_P_OUT_W), d, F, d, M)));
   float* dh = b + bw.dhA;
   float* dh_alt = b + bw.dhB;
-  HIG_TRY(hig_gemm_launch(G(dout, F, 0, P(params, HIG_P_OUT_W), d, 1, dh, d, M, d, F).g, 1, nullptr, st));
+  const float* dout_m = dout;  // rows that went through `out`
+  if (D.two) {
+    // init-pose rows went through out2 (:613): separate them from the `out` adjoint
+    float* dm = b + bw.doutm;
+    if (hipMemcpyAsync(dm, dout, (size_t)M * F * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
+    hipLaunchKernelGGL(tok0_kernel, dim3((D.B * F + 255) / 256), dim3(256), 0, st, dm, (int64_t)D.T * F, D.B, F,
+                       (float*)nullptr, 1);
+    HIG_CHECK_LAUNCH();
+    dout_m = dm;
+    HIG_TRY(colsum(dout, (int64_t)D.T * F, D.B, F, GP(grads, HIG_P_OUT2_B)));
+    HIG_TRY(wgrad(G(dout, (int64_t)D.T * F, 1, hL, (int64_t)D.T * d, 1, GP(grads, HIG_P_OUT2_W), d, F, d, D.B)));
+  }
+  HIG_TRY(colsum(dout_m, F, M, F, GP(grads, HIG_P_OUT_B)));
+  HIG_TRY(wgrad(G(dout_m, F, 1, hL, d, 1, GP(grads, HIG_P_OUT_W), d, F, d, M)));
+  HIG_TRY(hig_gemm_launch(G(dout_m, F, 0, P(params, HIG_P_OUT_W), d, 1, dh, d, M, d, F).g, 1, nullptr, st));
+  if (D.two)  // the out-GEMM left exact zeros in the init-pose rows of dh; fill them from out2
+    HIG_TRY(hig_gemm_launch(G(dout, (int64_t)D.T * F, 0, P(params, HIG_P_OUT2_W), d, 1, dh, (int64_t)D.T * d, D.B, d, F).g,
+                            1, nullptr, st));
 
   for (int l = D.L - 1; l >= 0; --l) {
     const float* lb = ws + w.layer0 + w.lstride * l;
@@ -459,8 +558,13 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
     HIG_TRY(wtrans(PL(params, l, HIG_L_CA_KV_W), 2 * d, Lt, o_kv));
     HIG_TRY(wtrans(PL(params, l, HIG_L_SA_STY_OUT_W), d, d, o_sty1));
     HIG_TRY(wtrans(PL(params, l, HIG_L_SA_QKV_W), 3 * d, d, o_qkv));
+    if (D.two == 1) {
+      HIG_TRY(wtrans(PL(params, l, HIG_L_INT_STY_OUT_W), d, d, o_isty));
+      HIG_TRY(wtrans(PL(params, l, HIG_L_INT_QKV_W), 3 * d, d, o_iqkv));
+    }
+    const float* hffn = D.two == 1 ? lb + w.h2b : lb + w.h2;
     // ---- FFN --------------------------------------------------------------------------
-    HIG_TRY(sty_bwd(l, 3 * l + 2, dh, lb + w.y3, lb + w.a3, lb + w.st5, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B,
+    HIG_TRY(sty_bwd(l, D.nsty * l + D.nsty - 1, dh, lb + w.y3, lb + w.a3, lb + w.st5, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B,
                     HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B, o_sty3, b + bw.t2));
     const float* dy3 = b + bw.t2;
     HIG_TRY(colsum(dy3, d, M, d, GL(grads, l, HIG_L_FFN_B2)));
@@ -469,12 +573,36 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                                 .epi(HIG_EPI_DGELU).aux(const_cast<float*>(lb + w.z1), ff).g, 1, nullptr, st));
     const float* dz1 = b + bw.tff;
     HIG_TRY(colsum(dz1, ff, M, ff, GL(grads, l, HIG_L_FFN_B1)));
-    HIG_TRY(wgrad_act(dz1, ff, lb + w.h2, d, GL(grads, l, HIG_L_FFN_W1), M, nullptr, nullptr, nullptr));
+    HIG_TRY(wgrad_act(dz1, ff, hffn, d, GL(grads, l, HIG_L_FFN_W1), M, nullptr, nullptr, nullptr));
     HIG_TRY(hig_gemm_launch(G(dz1, ff, 0, wT + o_w1t, ff, 0, dh_alt, d, M, d, ff).prec(D.prec)
                                 .epi(HIG_EPI_RES).res(dh, d).g, 1, nullptr, st));
-    { float* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h2)
+    { float* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h2), or d(h2b) in the interaction model
+    if (D.two == 1) {
+      // ---- person <-> person cross attention ------------------------------------------------
+      HIG_TRY(sty_bwd(l, D.nsty * l + 2, dh, lb + w.y4, lb + w.a4, lb + w.st7, HIG_L_INT_STY_NORM_W, HIG_L_INT_STY_NORM_B,
+                      HIG_L_INT_STY_OUT_W, HIG_L_INT_STY_OUT_B, o_isty, b + bw.t2));
+      const int64_t* len_partner = reinterpret_cast<const int64_t*>(ws + w.lenp);
+      const int64_t halfA = (int64_t)Bp * D.H * D.hd * D.hd, halfM = (int64_t)Bp * D.T;
+      float* dqkv = b + bw.dqkv;
+      // consumer sample s read the context of producer (s + B/2) % B: route d(A) back the same way
+      HIG_TRY(hig_linattn_apply_bwd(b + bw.t2, d, lb + w.iqkv, 3 * d, lb + w.Ai + halfA, dqkv, 3 * d, b + bw.dA + halfA,
+                                    Bp, D.T, D.H, D.hd, b + bw.attn, stream));
+      HIG_TRY(hig_linattn_apply_bwd(b + bw.t2 + halfM * d, d, lb + w.iqkv + halfM * 3 * d, 3 * d, lb + w.Ai,
+                                    dqkv + halfM * 3 * d, 3 * d, b + bw.dA, Bp, D.T, D.H, D.hd, b + bw.attn, stream));
+      HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, lb + w.iqkv + d, lb + w.iqkv + 2 * d, 3 * d, lb + w.ksti, len_partner,
+                                  dqkv + d, dqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, b + bw.attn, stream));
+      HIG_TRY(colsum(dqkv, 3 * d, M, 3 * d, GL(grads, l, HIG_L_INT_QKV_B)));
+      HIG_TRY(wgrad_act(dqkv, 3 * d, lb + w.h2, d, GL(grads, l, HIG_L_INT_QKV_W), M, lb + w.st6,
+                        PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B)));
+      HIG_TRY(hig_gemm_launch(G(dqkv, 3 * d, 0, wT + o_iqkv, 3 * d, 0, b + bw.t2, d, M, d, 3 * d).prec(D.prec).g, 1,
+                              nullptr, st));
+      HIG_TRY(hig_ln_bwd(b + bw.t2, d, lb + w.h2, d, lb + w.st6, PL(params, l, HIG_L_INT_NORM_W),
+                         PL(params, l, HIG_L_INT_NORM_B), nullptr, 0, 0, 0, dh, d, dh_alt, d, M, d, D.T,
+                         GL(grads, l, HIG_L_INT_NORM_W), GL(grads, l, HIG_L_INT_NORM_B), nullptr, 0, lnp, stream));
+      { float* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h2)
+    }
     // ---- cross attention ---------------------------------------------------------------
-    HIG_TRY(sty_bwd(l, 3 * l + 1, dh, lb + w.y2, lb + w.a2, lb + w.st4, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B,
+    HIG_TRY(sty_bwd(l, D.nsty * l + 1, dh, lb + w.y2, lb + w.a2, lb + w.st4, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B,
                     HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B, o_sty2, b + bw.t2));
     const float* Ac = tc + tl.layer0 + tl.lstride * l + tl.Ac;
     const float* kstc = tc + tl.layer0 + tl.lstride * l + tl.kstc;
@@ -509,7 +637,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                        dxf_out, Lt, Mt, Lt, D.N, GL(grads, l, HIG_L_CA_TNORM_W), GL(grads, l, HIG_L_CA_TNORM_B),
                        nullptr, 0, lnp, stream));
     // ---- self attention ----------------------------------------------------------------
-    HIG_TRY(sty_bwd(l, 3 * l, dh, lb + w.y1, lb + w.a1, lb + w.st2, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B,
+    HIG_TRY(sty_bwd(l, D.nsty * l, dh, lb + w.y1, lb + w.a1, lb + w.st2, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B,
                     HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B, o_sty1, b + bw.t2));
     float* dqkv = b + bw.dqkv;
     if (D.full) {
@@ -534,15 +662,36 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
   }
 
   // ---- joint_embed + sequence_embedding ------------------------------------------------
+  if (D.two) {
+    // init-pose rows came from joint_embed2 (no positional term): move them aside, leaving zeros so the
+    // joint_embed / sequence_embedding adjoints below see only the motion rows
+    hipLaunchKernelGGL(tok0_kernel, dim3((D.B * d + 255) / 256), dim3(256), 0, st, dh, (int64_t)D.T * d, D.B, d,
+                       b + bw.tok0, 1);
+    HIG_CHECK_LAUNCH();
+    HIG_TRY(colsum(b + bw.tok0, d, D.B, d, GP(grads, HIG_P_JOINT2_B)));
+    HIG_TRY(wgrad(G(b + bw.tok0, d, 1, x, (int64_t)D.T * F, 1, GP(grads, HIG_P_JOINT2_W), 4, d, 4, D.B)));
+  }
   HIG_TRY(colsum(dh, d, M, d, GP(grads, HIG_P_JOINT_B)));
   HIG_TRY(wgrad(G(dh, d, 1, x, F, 1, GP(grads, HIG_P_JOINT_W), F, d, F, M)));
   // d(sequence_embedding)[t] = sum_b dh[b, t, :]  == column sum of dh viewed as (B, T*d)
-  HIG_TRY(colsum(dh, (int64_t)D.T * d, D.B, D.T * d, GP(grads, HIG_P_SEQ_EMB)));
-  if (D.nf > D.T)
-    if (hipMemsetAsync(GP(grads, HIG_P_SEQ_EMB) + (int64_t)D.T * d, 0, (size_t)(D.nf - D.T) * d * 4, st) != hipSuccess)
+  const int Tpos = D.two ? D.T - 1 : D.T;  // rows of sequence_embedding that were used
+  if (D.two) {  // frame t used row t-1
+    HIG_TRY(colsum(dh, (int64_t)D.T * d, D.B, D.T * d, b + bw.postmp));
+    if (hipMemcpyAsync(GP(grads, HIG_P_SEQ_EMB), b + bw.postmp + d, (size_t)Tpos * d * 4, hipMemcpyDeviceToDevice, st) !=
+        hipSuccess)
+      return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
+  } else {
+    HIG_TRY(colsum(dh, (int64_t)D.T * d, D.B, D.T * d, GP(grads, HIG_P_SEQ_EMB)));
+  }
+  if (D.nf > Tpos)
+    if (hipMemsetAsync(GP(grads, HIG_P_SEQ_EMB) + (int64_t)Tpos * d, 0, (size_t)(D.nf - Tpos) * d * 4, st) != hipSuccess)
       return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
-  if (dx)
+  if (dx) {
     HIG_TRY(hig_gemm_launch(G(dh, d, 0, P(params, HIG_P_JOINT_W), F, 1, dx, F, M, F, d).g, 1, nullptr, st));
+    if (D.two)  // d(x[:, 0, :4]) through joint_embed2; the other features of the init-pose row are unused
+      HIG_TRY(hig_gemm_launch(G(b + bw.tok0, d, 0, P(params, HIG_P_JOINT2_W), 4, 1, dx, (int64_t)D.T * F, D.B, 4, d).g, 1,
+                              nullptr, st));
+  }
 
   // ---- time / text embedding path ---------------------------------------------------------
   const float* emb = ws + w.emb;

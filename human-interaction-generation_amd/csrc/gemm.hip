@@ -458,7 +458,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
   for (int ti = 0; ti < TI; ++ti) {
     const int i = ei0 + wi * (32 * TI) + 32 * ti + lr;
     if (i >= g.I) continue;
-    const float* posrow = (EPI == HIG_EPI_BIAS_POS) ? g.pos + (int64_t)(i % g.T) * g.ldpos : nullptr;
+    const float* posrow = nullptr;
+    if (EPI == HIG_EPI_BIAS_POS) {
+      const int tp = (i % g.T) - g.pos_shift;
+      if (tp >= 0) posrow = g.pos + (int64_t)tp * g.ldpos;
+    }
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
 #pragma unroll
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
           for (int e = 0; e < 4; ++e)
             if (e < nv) v[e] += g.bias[j + e];
         }
-        if (EPI == HIG_EPI_BIAS_POS) {
+        if (EPI == HIG_EPI_BIAS_POS && posrow) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (e < nv) v[e] += posrow[j + e];

@@ -115,9 +115,16 @@ class _DecoderLayer(nn.Module):
 
 def _core_param_order(model):
     """(global table, per-layer tables) as lists of parameter groups in hig.h table order.
-    A group with several parameters must be laid out contiguously (fused GEMM operand)."""
+    A group with several parameters must be laid out contiguously (fused GEMM operand); an empty
+    group is a NULL table entry (the two-person entries of a single-person model)."""
     blocks = list(model.temporal_decoder_blocks)
-    stys = [s for b in blocks for s in (b.sa_block.proj_out, b.ca_block.proj_out, b.ffn.proj_out)]
+
+    def sty_blocks(b):  # stylization order the kernels index `ss` with: sa, ca, [int_ca], ffn
+        ic = [b.int_ca_block.proj_out] if hasattr(b, "int_ca_block") else []
+        return [b.sa_block.proj_out, b.ca_block.proj_out] + ic + [b.ffn.proj_out]
+
+    stys = [s for b in blocks for s in sty_blocks(b)]
+    two = hasattr(model, "joint_embed2")
     glob = [
         [model.sequence_embedding],
         [model.joint_embed.weight], [model.joint_embed.bias],
@@ -125,11 +132,13 @@ def _core_param_order(model):
         [model.time_embed[2].weight], [model.time_embed[2].bias],
         [s.emb_layers[1].weight for s in stys], [s.emb_layers[1].bias for s in stys],
         [model.out.weight], [model.out.bias],
+        [model.joint_embed2.weight] if two else [], [model.joint_embed2.bias] if two else [],
+        [model.out2.weight] if two else [], [model.out2.bias] if two else [],
     ]
     layers = []
     for b in blocks:
         sa, ca, ff = b.sa_block, b.ca_block, b.ffn
-        layers.append([
+        lay = [
             [sa.norm.weight], [sa.norm.bias],
             [sa.query.weight, sa.key.weight, sa.value.weight], [sa.query.bias, sa.key.bias, sa.value.bias],
             [sa.proj_out.norm.weight], [sa.proj_out.norm.bias],
@@ -142,7 +151,18 @@ def _core_param_order(model):
             [ff.linear1.weight], [ff.linear1.bias], [ff.linear2.weight], [ff.linear2.bias],
             [ff.proj_out.norm.weight], [ff.proj_out.norm.bias],
             [ff.proj_out.out_layers[2].weight], [ff.proj_out.out_layers[2].bias],
-        ])
+        ]
+        if hasattr(b, "int_ca_block"):
+            ic = b.int_ca_block
+            lay += [
+                [ic.norm.weight], [ic.norm.bias],
+                [ic.query.weight, ic.key.weight, ic.value.weight], [ic.query.bias, ic.key.bias, ic.value.bias],
+                [ic.proj_out.norm.weight], [ic.proj_out.norm.bias],
+                [ic.proj_out.out_layers[2].weight], [ic.proj_out.out_layers[2].bias],
+            ]
+        else:
+            lay += [[] for _ in range(8)]
+        layers.append(lay)
     assert len(glob) == _lib.NGLOBAL and all(len(l) == _lib.NLAYER for l in layers)
     return glob, layers
 
@@ -165,7 +185,7 @@ class _FlatParams:
         self.group_offsets = []
         for g in groups:
             o = (o + self.ALIGN - 1) // self.ALIGN * self.ALIGN
-            self.group_offsets.append(o)
+            self.group_offsets.append(o if g else None)
             for p in g:
                 offs.append(o)
                 o += p.numel()
@@ -187,7 +207,7 @@ class _FlatParams:
         n = len(self.group_offsets)
         arr = (C.c_void_p * n)()
         for i, off in enumerate(self.group_offsets):
-            arr[i] = base_ptr + 4 * off
+            arr[i] = None if off is None else base_ptr + 4 * off
         return arr
 
     def param_table(self):
@@ -373,6 +393,11 @@ class MotionTransformer(nn.Module):
             raise RuntimeError("MotionTransformer.forward: ROCm device tensors required "
                                "(no CPU fallback; the CPU restatement lives in oracle/ for tests only)")
         assert x.shape[2] == self.input_feats and T <= self.num_frames
+        return self._run(x, timesteps, length, xf_proj, xf_out)
+
+    def _run(self, x, timesteps, length, xf_proj, xf_out):
+        """Normalise the inputs and launch (through autograd when anything requires grad)."""
+        B, T = x.shape[0], x.shape[1]
         dev = x.device
         x = x.float().contiguous()
         t = timesteps.to(dev).long().contiguous()

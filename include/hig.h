@@ -62,6 +62,11 @@ typedef struct hig_dims {
   int32_t num_frames; /* rows of sequence_embedding */
   int32_t attn_kind;  /* HIG_ATTN_* */
   int32_t prec;       /* HIG_PREC_* */
+  int32_t two_person; /* 0: MotionTransformer.  1: MotionInteractionTransformer (interaction_transformer.py
+                         :397-616): B = 2 x pairs, x = [person1; person2], token 0 of every sample is the
+                         init-pose row (joint_embed2 on its first 4 features, out2), and each layer has the
+                         person<->person linear cross-attention `int_ca_block` (:167-207).
+                         2: the same with no_cross_attn=True (no int_ca_block). */
 } hig_dims;
 
 /* Parameter table: an array of device pointers, HIG_NGLOBAL global entries followed by
@@ -70,7 +75,8 @@ typedef struct hig_dims {
  *   SA_QKV_W = [query.weight; key.weight; value.weight]  (3d, d)   SA_QKV_B (3d)
  *   CA_KV_W  = [key.weight; value.weight]                (2d, Lt)  CA_KV_B  (2d)
  *   STY_EMB_W= the 3L `emb_layers.1.weight` matrices stacked in (layer, sa|ca|ffn) order
- *              (3L*2d, E); STY_EMB_B likewise (3L*2d).
+ *              (3L*2d, E); STY_EMB_B likewise (3L*2d).  With two_person == 1 there are 4 per
+ *              layer, in (sa|ca|int_ca|ffn) order.
  * Names are the reference's state-dict keys. */
 enum {
   HIG_P_SEQ_EMB = 0, /* sequence_embedding (num_frames, d) */
@@ -84,6 +90,11 @@ enum {
   HIG_P_STY_EMB_B,
   HIG_P_OUT_W, /* out.weight (F, d) */
   HIG_P_OUT_B,
+  /* two-person model only (NULL otherwise) */
+  HIG_P_JOINT2_W, /* joint_embed2.weight (d, 4) */
+  HIG_P_JOINT2_B,
+  HIG_P_OUT2_W,   /* out2.weight (F, d) */
+  HIG_P_OUT2_B,
   HIG_NGLOBAL
 };
 enum {
@@ -115,6 +126,15 @@ enum {
   HIG_L_FFN_STY_NORM_B,
   HIG_L_FFN_STY_OUT_W,
   HIG_L_FFN_STY_OUT_B,
+  /* two-person model with interaction attention only (NULL otherwise) */
+  HIG_L_INT_NORM_W, /* int_ca_block.norm (d): applied to the own AND the partner stream */
+  HIG_L_INT_NORM_B,
+  HIG_L_INT_QKV_W,  /* [query; key; value] (3d, d), contiguous */
+  HIG_L_INT_QKV_B,
+  HIG_L_INT_STY_NORM_W,
+  HIG_L_INT_STY_NORM_B,
+  HIG_L_INT_STY_OUT_W,
+  HIG_L_INT_STY_OUT_B,
   HIG_NLAYER
 };
 
@@ -180,6 +200,7 @@ typedef struct hig_gemm_desc {
   const float* gamma; const float* beta; /* [features] */
   const float* ss; int64_t ss_ld; int32_t ss_shift_off; int32_t rows_per_sample;
   const float* pos; int64_t ldpos; int32_t T;
+  int32_t pos_shift;                 /* EPI_BIAS_POS adds pos[(i % T) - pos_shift]; rows with a negative index get none */
 } hig_gemm_desc;
 int hig_gemm(const hig_gemm_desc* g, hig_stream_t stream);
 

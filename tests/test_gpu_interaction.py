@@ -1,0 +1,221 @@
+"""Two-person path on the MI355X: MotionInteractionTransformer / DDPMMulTrainer over the
+HIP kernels against goldens produced by the reference itself (g8, g9) and the CPU oracle."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import hig_amd  # noqa: E402
+from oracle import fill  # noqa: E402
+from oracle import interaction_ref as IR  # noqa: E402
+from test_gpu_denoiser import _NoiseFeed, _patch, make_diffusion, rel  # noqa: E402
+
+DEV = "cuda"
+
+
+def build(c, **kw):
+    m = hig_amd.MotionInteractionTransformer(input_feats=c["F"], num_frames=c["num_frames"], latent_dim=c["d"],
+                                             ff_size=c["ff"], num_layers=c["L"], num_heads=c["H"],
+                                             text_latent_dim=c["Lt"], **kw)
+    m.load_state_dict(fill.fill_state_dict(m.state_dict()), strict=True)
+    return m.to(DEV)
+
+
+def case_inputs(c):
+    inp = fill.inputs(2 * c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"] * 2, c["t"] * 2)
+    return inp, {k: v.to(DEV) for k, v in inp.items()}
+
+
+@pytest.mark.parametrize("case", ["tiny2", "config1x2"])
+@pytest.mark.parametrize("nocross", [False, True])
+def test_forward_matches_reference_golden(gold, case, nocross):
+    g = gold("g8_interaction.npz")
+    c = fill.ICASES[case]
+    m = build(c, no_cross_attn=nocross).eval()
+    _, gi = case_inputs(c)
+    with torch.no_grad():
+        out = m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+    assert out.shape == (2 * c["B"], c["T"], c["F"])
+    ref = torch.tensor(g[case + (".nocross" if nocross else "") + ".out"])
+    assert rel(out, ref) < 2e-5
+    assert rel(out[:, 0], ref[:, 0]) < 2e-5      # init-pose rows (out2 head)
+
+
+def test_state_dict_contract(gold):
+    g = gold("g8_interaction.npz")
+    c = fill.ICASES["tiny2"]
+    sd = build(c).state_dict()
+    keys = [k[5:] for k in g.files if k.startswith("keys.")]
+    assert list(sd) == keys
+    assert all(tuple(sd[k].shape) == tuple(g["keys." + k]) for k in keys)
+
+
+@pytest.mark.parametrize("case", ["tiny2", "config1x2"])
+def test_backward_matches_reference_golden(gold, case):
+    g = gold("g8_interaction.npz")
+    c = fill.ICASES[case]
+    m = build(c).train()
+    _, gi = case_inputs(c)
+    x, xp, xo = (gi[k].clone().requires_grad_(True) for k in ("x", "xf_proj", "xf_out"))
+    out = m(x, gi["t"], length=gi["length"], xf_proj=xp, xf_out=xo)
+    r = (fill.tensor_for("loss.r." + case, out.shape) * 10.0).to(DEV)
+    (out * r).sum().backward()
+    assert rel(x.grad, g[case + ".dx"]) < 1e-4
+    assert rel(x.grad[:, 0, :4], g[case + ".dx"][:, 0, :4]) < 1e-4       # through joint_embed2
+    assert x.grad[:, 0, 4:].abs().max().item() == 0.0                     # unused init-pose features
+    assert rel(xp.grad, g[case + ".dxf_proj"]) < 1e-4
+    assert rel(xo.grad, g[case + ".dxf_out"]) < 1e-4
+    named = dict(m.named_parameters())
+    gnorm = float(g[case + ".gnorm_core"])
+    for k in g.files:
+        if k.startswith(case + ".g."):
+            pn = k[len(case) + 3:]
+            ref = torch.tensor(g[k])
+            err = (named[pn].grad.cpu() - ref).norm().item()
+            assert err < 2e-4 * ref.norm().item() + 1e-7 * gnorm, (pn, err, ref.norm().item())
+    core = fill.interaction_param_shapes(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"])
+    tot = torch.sqrt(sum((named[k].grad.double() ** 2).sum() for k in core)).item()
+    assert abs(tot - gnorm) / gnorm < 1e-4
+
+
+def test_all_gradients_against_oracle_autograd():
+    """Every core parameter gradient (not just the golden subset) against torch autograd of the oracle."""
+    c = fill.ICASES["tiny2"]
+    m = build(c).train()
+    inp, gi = case_inputs(c)
+    x = gi["x"].clone().requires_grad_(True)
+    out = m(x, gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+    r = fill.tensor_for("loss.r.oracle", out.shape) * 10.0
+    (out * r.to(DEV)).sum().backward()
+    p = {k: v.double().requires_grad_(True) for k, v in
+         fill.interaction_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"]).items()}
+    ref = IR.interaction_forward(p, inp["x"].double(), inp["t"], inp["length"], inp["xf_proj"].double(),
+                                 inp["xf_out"].double(), c["H"], c["L"])
+    assert rel(out, ref) < 1e-5
+    (ref * r.double()).sum().backward()
+    named = dict(m.named_parameters())
+    for k, v in p.items():
+        gr = named[k].grad.cpu().double()
+        scale = v.grad.norm().item()
+        if k == "sequence_embedding":
+            assert gr[c["T"] - 1:].abs().max().item() == 0.0      # rows >= T-1 are never read
+        assert (gr - v.grad).norm().item() <= 2e-4 * scale + 1e-5, (k, (gr - v.grad).norm().item(), scale)
+
+
+def test_swapping_the_two_persons_swaps_the_outputs():
+    """Size-independent property at a production-like size: the model is symmetric in the two
+    persons, so model(cat[x2, x1]) == swap(model(cat[x1, x2])) when both share text / t / length."""
+    c = dict(B=16, T=100, F=150, d=512, H=8, L=4, ff=1024, N=77, Lt=256, num_frames=196)
+    m = build(c).eval()
+    B = c["B"]
+    lengths = [c["T"] - (7 * i) % 60 for i in range(B)]
+    inp = fill.inputs(2 * B, c["T"], c["F"], c["d"], c["N"], c["Lt"], lengths * 2, [(37 * i) % 1000 for i in range(B)] * 2)
+    gi = {k: v.to(DEV) for k, v in inp.items()}
+    for k in ("xf_proj", "xf_out"):      # same conditioning for both persons of a pair
+        gi[k] = torch.cat([gi[k][:B], gi[k][:B]])
+    with torch.no_grad():
+        a = m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+        xs = torch.cat([gi["x"][B:], gi["x"][:B]])
+        b = m(xs, gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+    assert torch.isfinite(a).all() and a.abs().max() > 0
+    assert rel(torch.cat([b[B:], b[:B]]), a) < 1e-6
+    # ...and it is a real interaction: changing person 2 changes person 1's output
+    with torch.no_grad():
+        x2 = gi["x"].clone()
+        x2[B:] += 1.0
+        c2 = m(x2, gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+    assert rel(c2[:B], a[:B]) > 1e-4
+    # against the oracle on the first pairs of the same batch (pairs are independent)
+    p = fill.interaction_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"])
+    sel = [0, 1, B, B + 1]
+    ref = IR.interaction_forward(p, inp["x"][sel], inp["t"][sel], inp["length"][sel], gi["xf_proj"][sel].cpu(),
+                                 gi["xf_out"][sel].cpu(), c["H"], c["L"])
+    assert rel(a[sel], ref) < 2e-5
+
+
+def test_split_bf16_products_keep_parity(gold):
+    g = gold("g8_interaction.npz")
+    c = fill.ICASES["config1x2"]
+    m = build(c, precision="bf16x3").train()
+    _, gi = case_inputs(c)
+    x = gi["x"].clone().requires_grad_(True)
+    out = m(x, gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+    assert rel(out, g["config1x2.out"]) < 5e-5
+    r = (fill.tensor_for("loss.r.config1x2", out.shape) * 10.0).to(DEV)
+    (out * r).sum().backward()
+    assert rel(x.grad, g["config1x2.dx"]) < 2e-4
+
+
+def _trainer(c, m, label_path=None):
+    args = types.SimpleNamespace(device=torch.device(DEV), diffusion_steps=1000, is_train=True, lr=2e-4,
+                                 batch_size=c["B"], num_epochs=1, log_every=50, save_latest=500, save_every_e=5,
+                                 is_continue=False, model_dir="/tmp", multi=True, label_path=label_path, cap_id=False)
+    return hig_amd.DDPMMulTrainer(args, m)
+
+
+CAP1 = ["a person shakes hands with another person", "one pushes the other"]
+CAP2 = ["a person receives a handshake", "one is pushed by the other"]
+
+
+def test_pit_trainer_step_matches_reference_golden(gold):
+    """DDPMMulTrainer.forward + update in PIT mode (forward_twice, min over caption assignments) == G9."""
+    import hig_amd.trainers.ddpm_trainer as tr
+    g = gold("g9_mul_trainer.npz")
+    c = fill.ICASES["config1x2"]
+    m = build(c).train()
+    trainer = _trainer(c, m)
+    trainer.opt_encoder = torch.optim.Adam(m.parameters(), lr=2e-4)
+    B, T, Fd = c["B"], c["T"], c["F"]
+    motion1 = fill.tensor_for("g9.motion1", (B, T, Fd)) * 10
+    motion2 = fill.tensor_for("g9.motion2", (B, T, Fd)) * 10
+    t_fixed = torch.tensor(c["t"])
+    trainer.sampler.sample = lambda bs, dev: (t_fixed.to(dev), torch.ones(bs))
+    captured = {}
+    real_clip = tr.clip_grad_norm_
+
+    def spy(params, max_norm):
+        captured["gnorm"] = float(real_clip(params, max_norm))
+        return captured["gnorm"]
+
+    tr.clip_grad_norm_ = spy
+    undo = _patch(_NoiseFeed("g9.noise", DEV))
+    try:
+        trainer.forward((CAP1, CAP2, motion1, motion2, torch.tensor(c["lengths"]), None))
+        logs = trainer.update()
+    finally:
+        undo()
+        tr.clip_grad_norm_ = real_clip
+    assert trainer.fake_noise.shape == (4 * B, T, Fd)
+    assert rel(trainer.fake_noise, g["fake_noise"]) < 5e-5
+    assert np.array_equal(trainer.src_mask.cpu().numpy(), g["src_mask"])
+    assert abs(logs["loss_mot_rec"] - float(g["loss_mot_rec"])) < 1e-4 * float(g["loss_mot_rec"])
+    assert abs(captured["gnorm"] - float(g["gnorm"])) < 2e-4 * float(g["gnorm"])
+    sd = m.state_dict()
+    for k in g.files:
+        if k.startswith("p."):
+            assert (sd[k[2:]].cpu() - torch.tensor(g[k])).abs().max().item() < 2e-5, k
+
+
+def test_labelled_trainer_loss_and_generate():
+    """with_label branch (no forward_twice) against the oracle's loss; then a short sampling run."""
+    c = fill.ICASES["config1x2"]
+    m = build(c).train()
+    trainer = _trainer(c, m, label_path="labels/")
+    trainer.opt_encoder = torch.optim.Adam(m.parameters(), lr=2e-4)
+    B, T, Fd = c["B"], c["T"], c["F"]
+    motion1 = fill.tensor_for("lab.motion1", (B, T, Fd)) * 10
+    motion2 = fill.tensor_for("lab.motion2", (B, T, Fd)) * 10
+    trainer.forward((CAP1, CAP2, motion1, motion2, torch.tensor(c["lengths"]), None))
+    assert trainer.fake_noise.shape == (2 * B, T, Fd)
+    logs = trainer.update()
+    ref = IR.labelled_loss(trainer.fake_noise.detach().cpu(), trainer.real_noise.cpu(), trainer.src_mask.cpu())
+    assert abs(logs["loss_mot_rec"] - ref.item()) < 1e-5 * ref.item()
+    # sampling: 50-step schedule, hipGraph loop, both persons come back as (motion1, motion2) pairs
+    trainer.diffusion = make_diffusion(50)
+    outs = trainer.generate(CAP1, CAP2, torch.tensor([T, 40]), Fd)
+    Tg = min(T, c["num_frames"])
+    assert len(outs) == B and all(len(o) == 2 and o[0].shape == (Tg, Fd) for o in outs)
+    assert all(torch.isfinite(o[0]).all() and torch.isfinite(o[1]).all() for o in outs)
