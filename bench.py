@@ -292,6 +292,34 @@ def main():
                     "what": "hipGraph p_sample_loop B=32 T=196, %s products: %d steps measured (capture "
                             "included), scaled x%d to 1000" % (mode, nst, scale)}
             model.precision = "f32"
+            # ---- two-person denoiser: 32 pairs x 91 tokens x 263 features, fwd and fwd+bwd ----
+            torch.manual_seed(0)
+            c2 = dict(c, B=64, T=91, F=263)
+            m2 = hig_amd.MotionInteractionTransformer(input_feats=c2["F"], num_frames=196, latent_dim=c2["d"],
+                                                      ff_size=c2["ff"], num_layers=c2["L"], num_heads=c2["H"],
+                                                      text_latent_dim=c2["Lt"])
+            with torch.no_grad():
+                for name, p in m2.named_parameters():
+                    if name.startswith("out") or ".ffn.linear2." in name or ".out_layers.2." in name:
+                        p.copy_(torch.randn(p.shape) * 0.02)
+            m2 = m2.to(device)
+            i2 = make_inputs(c2, device, rank)
+
+            def fwd2():
+                with torch.no_grad():
+                    return m2(i2["x"], i2["t"], length=i2["length"], xf_proj=i2["xf_proj"], xf_out=i2["xf_out"])
+
+            def fwdbwd2():
+                out, saved = m2._launch_forward(i2["x"], i2["t"], i2["length"], i2["xf_proj"], i2["xf_out"], training=True)
+                m2._launch_backward(i2["x"], i2["t"], i2["length"], i2["xf_out"], saved, i2["x0"], want_dx=False)
+
+            k2 = max(5, a.steps // 2)
+            e_f, e_fb = timed(fwd2, k2, 2, 1), timed(fwdbwd2, k2, 2, 1)
+            extra["two_person"] = {
+                "fwd_frames_per_s": round(c2["B"] * c2["T"] * k2 / e_f, 1), "fwd_ms": round(e_f / k2 * 1e3, 3),
+                "fwd_bwd_frames_per_s": round(c2["B"] * c2["T"] * k2 / e_fb, 1), "fwd_bwd_ms": round(e_fb / k2 * 1e3, 3),
+                "what": "MotionInteractionTransformer, 32 pairs (model batch 64) x 91 tokens x 263 features, d=512 L=8, "
+                        "f32 products; frames = person-tokens"}
     if rank == 0:
         res["roofline"] = ffn_gemm_roofline(c, device)
         if not a.no_cpu_baseline and world == 1:

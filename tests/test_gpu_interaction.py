@@ -219,3 +219,27 @@ def test_labelled_trainer_loss_and_generate():
     Tg = min(T, c["num_frames"])
     assert len(outs) == B and all(len(o) == 2 and o[0].shape == (Tg, Fd) for o in outs)
     assert all(torch.isfinite(o[0]).all() and torch.isfinite(o[1]).all() for o in outs)
+
+
+def test_cap_id_mode_class_embeddings_single_text_token():
+    """cap_id=True: captions are class ids, the text context is ONE token per sample (N=1,
+    interaction_transformer.py:558-563); forward + backward against the oracle."""
+    c = fill.ICASES["tiny2"]
+    m = build(c, cap_id=True).train()
+    assert not hasattr(m, "clip") and m.cap_embedding.shape == (43, c["Lt"])
+    inp, gi = case_inputs(c)
+    ids = [torch.tensor([3, 41], device=DEV), torch.tensor([4, 40], device=DEV)]
+    x = gi["x"].clone().requires_grad_(True)
+    out = m(x, gi["t"], length=gi["length"], text=ids)
+    r = fill.tensor_for("loss.r.capid", out.shape) * 10.0
+    (out * r.to(DEV)).sum().backward()
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    emb = sd["cap_embedding"][torch.cat(ids).cpu()]
+    xf_proj = torch.nn.functional.linear(emb, sd["text_proj.0.weight"], sd["text_proj.0.bias"])
+    xr = inp["x"].double().requires_grad_(True)
+    ref = IR.interaction_forward(sd, xr, inp["t"], inp["length"], xf_proj, emb.unsqueeze(1), c["H"], c["L"])
+    assert rel(out, ref) < 1e-5
+    (ref * r.double()).sum().backward()
+    assert rel(x.grad, xr.grad) < 1e-4
+    assert rel(m.cap_embedding.grad, sd["cap_embedding"].grad) < 1e-4          # through xf_out AND xf_proj
+    assert rel(m.text_proj[0].weight.grad, sd["text_proj.0.weight"].grad) < 1e-4
