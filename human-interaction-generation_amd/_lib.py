@@ -29,12 +29,21 @@ SYMBOLS = (
     "hig_linattn_ctx_bwd", "hig_linattn_bwd_scratch_floats", "hig_fullattn_fwd", "hig_fullattn_bwd", "hig_ln_bwd", "hig_ln_bwd_partial_floats", "hig_transpose", "hig_colsum", "hig_colsum_chunks",
     "hig_timestep_embedding", "hig_q_sample", "hig_p_sample_step", "hig_dec_timesteps",
     "hig_masked_mse", "hig_sumsq_partial", "hig_clip_adam",
+    "hig_text_head_workspace_bytes", "hig_text_head_bwd_workspace_bytes", "hig_text_head_fwd", "hig_text_head_bwd",
+    "hig_layernorm", "hig_gather_rows", "hig_scatter_add_rows",
 )
 
 
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("B", "T", "F", "d", "H", "ff", "L", "N", "Lt", "num_frames", "attn_kind", "prec", "two_person")]
+
+
+class TextDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "N", "W", "Lt", "H", "ff", "L", "E", "prec")]
+
+
+T_NGLOBAL, T_NLAYER = 6, 12
 
 
 class GemmDesc(C.Structure):
@@ -104,6 +113,15 @@ def lib():
         L.hig_masked_mse.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
         L.hig_sumsq_partial.argtypes = [vp, i64, f32, vp, vp]
         L.hig_clip_adam.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, vp, vp, vp]
+        L.hig_text_head_workspace_bytes.restype = i64
+        L.hig_text_head_workspace_bytes.argtypes = [C.POINTER(TextDims), C.c_int]
+        L.hig_text_head_bwd_workspace_bytes.restype = i64
+        L.hig_text_head_bwd_workspace_bytes.argtypes = [C.POINTER(TextDims)]
+        L.hig_text_head_fwd.argtypes = [C.POINTER(TextDims), vp, vp, vp, vp, vp, vp, C.c_int, vp]
+        L.hig_text_head_bwd.argtypes = [C.POINTER(TextDims)] + [vp] * 11
+        L.hig_layernorm.argtypes = [vp, i64, i64, i32, vp, vp, vp, i64, vp, vp]
+        L.hig_gather_rows.argtypes = [vp, i64, i32, i32, vp, i32, vp, i64, vp]
+        L.hig_scatter_add_rows.argtypes = [vp, i64, i32, i32, vp, i32, vp, i64, vp]
         _lib = L
     return _lib
 

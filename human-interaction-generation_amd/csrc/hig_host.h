@@ -1,0 +1,49 @@
+// Host-side helpers shared by the orchestration translation units (denoiser.hip, texthead.hip).
+#pragma once
+#include <string.h>
+
+#include "hig_common.h"
+
+int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_t st);
+
+namespace {
+
+inline int64_t al(int64_t floats) { return (floats + 63) & ~(int64_t)63; }  // 256-byte granules
+
+struct G {  // small builder for gemm descriptors
+  hig_gemm_desc g;
+  G(const float* X, int64_t ldx, int xrs, const float* Y, int64_t ldy, int yrs, float* C, int64_t ldc,
+    int64_t I, int64_t J, int64_t R) {
+    memset(&g, 0, sizeof(g));
+    g.X = X; g.ldx = ldx; g.x_rs = xrs; g.Y = Y; g.ldy = ldy; g.y_rs = yrs; g.C = C; g.ldc = ldc;
+    g.I = (int)I; g.J = (int)J; g.R = (int)R;
+    g.xf = HIG_XF_NONE; g.epi = HIG_EPI_NONE; g.prec = HIG_PREC_F32;
+  }
+  G& prec(int p) { g.prec = p; return *this; }  // forward products: HIG_PREC_* of the plan
+  G& epi(int e, const float* bias = nullptr) { g.epi = e; g.bias = bias; return *this; }
+  G& res(const float* r, int64_t ldr) { g.res = r; g.ldr = ldr; return *this; }
+  G& aux(float* a, int64_t lda) { g.aux = a; g.ldaux = lda; return *this; }
+  G& pos(const float* p, int64_t ldp, int T) { g.pos = p; g.ldpos = ldp; g.T = T; return *this; }
+  G& silu(int on_y) { g.xf = HIG_XF_SILU; g.xf_on_y = on_y; return *this; }
+  G& ln(int on_y, const float* stats, const float* gamma, const float* beta) {
+    g.xf = HIG_XF_LN; g.xf_on_y = on_y; g.stats = stats; g.gamma = gamma; g.beta = beta; return *this;
+  }
+  G& mod(const float* ss, int64_t ss_ld, int shift_off, int rows_per_sample) {
+    g.xf = HIG_XF_LN_MOD_SILU; g.ss = ss; g.ss_ld = ss_ld; g.ss_shift_off = shift_off;
+    g.rows_per_sample = rows_per_sample; return *this;
+  }
+};
+
+// Split the reduce range of a weight-gradient GEMM so ~768 workgroups are in flight.
+inline int wgrad_splits(int64_t I, int64_t J, int64_t R, int64_t slab_floats) {
+  const int bi = (I > 64 && J > 64) ? 128 : 64;
+  const int64_t tiles = ((I + bi - 1) / bi) * ((J + bi - 1) / bi);
+  int64_t s = (768 + tiles - 1) / tiles;
+  const int64_t maxs = R / 256 > 1 ? R / 256 : 1;
+  if (s > maxs) s = maxs;
+  while (s > 1 && s * I * J > slab_floats) --s;
+  if ((I * J) % 4 != 0) s = 1;
+  return (int)(s < 1 ? 1 : s);
+}
+
+}  // namespace

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void rowstats_kernel(const float* __restrict__
 // One wave per row, the row stays in registers between the statistics and the transform, so x
 // is read once and a written once (the GEMM that consumes `a` is then a plain contraction: the
 // per-element exp/rcp of the SiLU is paid once per element instead of once per N-tile column).
-template <int NIT>
+template <int NIT, bool MOD>
 __global__ __launch_bounds__(256) void ln_mod_silu_kernel(
     const float* __restrict__ x, int64_t ldx, int64_t rows, int n, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ ss, int64_t ss_ld, int shift_off,
@@ -85,6 +85,23 @@ __global__ __launch_bounds__(256) void ln_mod_silu_kernel(
   if (lane == 0) {
     stats[2 * row] = mean;
     stats[2 * row + 1] = rstd;
+  }
+  if (!MOD) {  // plain LayerNorm (text head): a = LN(x) * gamma + beta
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = 4 * lane + 256 * it;
+      if (c < n) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 b4 = *reinterpret_cast<const float4*>(beta + c);
+        float4 o;
+        o.x = (v[it].x - mean) * rstd * g4.x + b4.x;
+        o.y = (v[it].y - mean) * rstd * g4.y + b4.y;
+        o.z = (v[it].z - mean) * rstd * g4.z + b4.z;
+        o.w = (v[it].w - mean) * rstd * g4.w + b4.w;
+        *reinterpret_cast<float4*>(a + row * lda + c) = o;
+      }
+    }
+    return;
   }
   const float* ssrow = ss + (row / rows_per_sample) * ss_ld;
 #pragma unroll
@@ -377,10 +394,63 @@ extern "C" int hig_ln_mod_silu(const float* x, int64_t ldx, int64_t rows, int32_
   const dim3 grid((unsigned)((rows + WAVES - 1) / WAVES));
   const int nit = (n + 255) / 256;
 #define LMS(NITV)                                                                                      \
-  hipLaunchKernelGGL((ln_mod_silu_kernel<NITV>), grid, dim3(256), 0, hig_stream(stream), x, ldx, rows, n, \
+  hipLaunchKernelGGL((ln_mod_silu_kernel<NITV, true>), grid, dim3(256), 0, hig_stream(stream), x, ldx, rows, n, \
                      gamma, beta, ss, ss_ld, ss_shift_off, rows_per_sample, a, lda, stats)
   if (nit == 1) LMS(1); else if (nit == 2) LMS(2); else LMS(4);
 #undef LMS
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+extern "C" int hig_layernorm(const float* x, int64_t ldx, int64_t rows, int32_t n, const float* gamma,
+                             const float* beta, float* y, int64_t ldy, float* stats, hig_stream_t stream) {
+  HIG_REQUIRE(x && gamma && beta && y && stats && rows >= 0, "hig_layernorm: null argument");
+  HIG_REQUIRE(n > 0 && n % 4 == 0 && n <= 1024 && ldx % 4 == 0 && ldy % 4 == 0,
+              "hig_layernorm: n must be a multiple of 4 and <= 1024 (got %d)", n);
+  if (rows == 0) return HIG_OK;
+  const dim3 grid((unsigned)((rows + WAVES - 1) / WAVES));
+  const int nit = (n + 255) / 256;
+#define LNF(NITV)                                                                                          \
+  hipLaunchKernelGGL((ln_mod_silu_kernel<NITV, false>), grid, dim3(256), 0, hig_stream(stream), x, ldx, rows, n, \
+                     gamma, beta, (const float*)nullptr, (int64_t)0, 0, 1, y, ldy, stats)
+  if (nit == 1) LNF(1); else if (nit == 2) LNF(2); else LNF(4);
+#undef LNF
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+namespace {
+// dst[b][:] = src[b*rows_per_sample + idx[b]][:]   (EOT-token gather of encode_text, transformer.py:395)
+__global__ void gather_rows_kernel(const float* __restrict__ src, int64_t ld, int rows_per_sample,
+                                   const int64_t* __restrict__ idx, int n, float* __restrict__ dst, int64_t ldd) {
+  const int b = blockIdx.x;
+  const int64_t r = (int64_t)b * rows_per_sample + idx[b];
+  for (int c = threadIdx.x; c < n; c += blockDim.x) dst[(int64_t)b * ldd + c] = src[r * ld + c];
+}
+// dst[b*rows_per_sample + idx[b]][:] += src[b][:]   (its adjoint; one row per sample, no collisions)
+__global__ void scatter_add_rows_kernel(const float* __restrict__ src, int64_t ld, int rows_per_sample,
+                                        const int64_t* __restrict__ idx, int n, float* __restrict__ dst, int64_t ldd) {
+  const int b = blockIdx.x;
+  const int64_t r = (int64_t)b * rows_per_sample + idx[b];
+  for (int c = threadIdx.x; c < n; c += blockDim.x) dst[r * ldd + c] += src[(int64_t)b * ld + c];
+}
+}  // namespace
+
+extern "C" int hig_gather_rows(const float* src, int64_t ld, int32_t B, int32_t rows_per_sample, const int64_t* idx,
+                               int32_t n, float* dst, int64_t ldd, hig_stream_t stream) {
+  HIG_REQUIRE(src && idx && dst && B >= 0 && n > 0 && rows_per_sample > 0, "hig_gather_rows: bad argument");
+  if (B == 0) return HIG_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(B), dim3(256), 0, hig_stream(stream), src, ld, rows_per_sample, idx, n,
+                     dst, ldd);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+extern "C" int hig_scatter_add_rows(const float* src, int64_t ld, int32_t B, int32_t rows_per_sample,
+                                    const int64_t* idx, int32_t n, float* dst, int64_t ldd, hig_stream_t stream) {
+  HIG_REQUIRE(src && idx && dst && B >= 0 && n > 0 && rows_per_sample > 0, "hig_scatter_add_rows: bad argument");
+  if (B == 0) return HIG_OK;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(B), dim3(256), 0, hig_stream(stream), src, ld, rows_per_sample, idx,
+                     n, dst, ldd);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

@@ -122,6 +122,7 @@ class MotionInteractionTransformer(MotionTransformer):
         self.out2 = zero_module(nn.Linear(self.latent_dim, self.input_feats))
 
         self.precision = kargs.get("precision", os.environ.get("HIG_PREC", "f32"))
+        self.text_head = kargs.get("text_head", os.environ.get("HIG_TEXT_HEAD", "hip"))
         self._flat = None
         self._pool = _WorkspacePool()
         self._textctx_cache = None
@@ -160,12 +161,7 @@ class MotionInteractionTransformer(MotionTransformer):
         x = x.permute(1, 0, 2)
         x = self.clip.transformer(x)
         x = self.clip.ln_final(x).type(self.clip.d_type)
-        x = self.text_pre_proj(x)
-        xf_out = self.textTransEncoder(x)
-        xf_out = self.text_ln(xf_out)
-        xf_proj = self.text_proj(xf_out[text.argmax(dim=-1), torch.arange(xf_out.shape[1])])
-        xf_out = xf_out.permute(1, 0, 2)
-        return xf_proj, xf_out
+        return self._text_head(text, x)
 
     def get_class_embedding(self, text):
         """:558-563: caption ids -> learned class embeddings (cap_id models)."""

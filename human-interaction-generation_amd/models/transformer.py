@@ -272,6 +272,28 @@ class _DenoiserFn(torch.autograd.Function):
                 dxo if ctx.need[2] else None) + pg
 
 
+class _TextHeadFn(torch.autograd.Function):
+    """Autograd boundary of the text head (hig_text_head_fwd / _bwd): CLIP features (B, N, W) and the
+    EOT indices in, (xf_proj, xf_out) out; the parameters are passed so autograd routes their
+    gradients (one flat scratch buffer per backward, returned as views)."""
+
+    @staticmethod
+    def forward(ctx, model, clip_out, eot, *params):
+        xf_proj, xf_out, saved = model._launch_text_head(clip_out, eot, training=True)
+        ctx.model, ctx.saved = model, saved
+        ctx.save_for_backward(clip_out, eot, xf_out)
+        ctx.need_clip = clip_out.requires_grad
+        return xf_proj, xf_out
+
+    @staticmethod
+    def backward(ctx, dxf_proj, dxf_out):
+        clip_out, eot, xf_out = ctx.saved_tensors
+        grads, dclip = ctx.model._launch_text_head_backward(clip_out, eot, xf_out, ctx.saved, dxf_out, dxf_proj,
+                                                           ctx.need_clip)
+        ctx.saved = None
+        return (None, dclip, None) + tuple(grads)
+
+
 class MotionTransformer(nn.Module):
     """Drop-in for the reference class (transformer.py:288-426)."""
 
@@ -330,6 +352,8 @@ class MotionTransformer(nn.Module):
         # (split-bf16, ~1e-5 relative, 16x-rate MFMA) or "bf16"; HIG_PREC overrides the default
         import os
         self.precision = kargs.get("precision", os.environ.get("HIG_PREC", "f32"))
+        # "hip": the text head runs through hig_text_head_fwd/_bwd; "torch": stock PyTorch-ROCm ops
+        self.text_head = kargs.get("text_head", os.environ.get("HIG_TEXT_HEAD", "hip"))
         self._flat = None
         self._pool = _WorkspacePool()
         self._textctx_cache = None
@@ -354,8 +378,8 @@ class MotionTransformer(nn.Module):
         return list(self.flat_params().params)
 
     # ---- reference API ------------------------------------------------------------------
-    def encode_text(self, text, device):
-        """transformer.py:380-397."""
+    def _clip_features(self, text, device):
+        """Frozen CLIP text tower up to ln_final (transformer.py:381-388): tokens + (L, B, 512)."""
         with torch.no_grad():
             text = clip.tokenize(text, truncate=True).to(device)
             x = self.clip.token_embedding(text).type(self.clip.dtype)
@@ -363,11 +387,37 @@ class MotionTransformer(nn.Module):
             x = x.permute(1, 0, 2)
             x = self.clip.transformer(x)
             x = self.clip.ln_final(x).type(self.clip.dtype)
+        return text, x
+
+    def _text_head_torch(self, text, x):
+        """transformer.py:389-397 on stock torch ops (`text_head="torch"`)."""
         x = self.text_pre_proj(x)
         xf_out = self.textTransEncoder(x)
         xf_out = self.text_ln(xf_out)
         xf_proj = self.text_proj(xf_out[text.argmax(dim=-1), torch.arange(xf_out.shape[1])])
         xf_out = xf_out.permute(1, 0, 2)
+        return xf_proj, xf_out
+
+    def encode_text(self, text, device):
+        """transformer.py:380-397.  CLIP stays on its own (frozen / stubbed) ops; the trainable head
+        after it -- text_pre_proj, the post-norm encoder, text_ln, EOT gather, text_proj -- runs in
+        the HIP kernels."""
+        text, x = self._clip_features(text, device)
+        return self._text_head(text, x)
+
+    def _text_head(self, text, x):
+        """tokens (B, N) + CLIP features (N, B, W) -> xf_proj (B, E), xf_out (B, N, Lt)."""
+        if self.text_head == "torch":
+            return self._text_head_torch(text, x)
+        if not x.is_cuda:
+            raise RuntimeError("encode_text: ROCm device required (no CPU fallback); pass text_head='torch' "
+                               "to run the text head on stock PyTorch ops")
+        clip_out = x.permute(1, 0, 2).float().contiguous()
+        eot = text.argmax(dim=-1).contiguous()
+        tp = self._text_params()
+        if torch.is_grad_enabled() and (clip_out.requires_grad or any(p.requires_grad for p in tp)):
+            return _TextHeadFn.apply(self, clip_out, eot, *tp)
+        xf_proj, xf_out, _ = self._launch_text_head(clip_out, eot, training=False)
         return xf_proj, xf_out
 
     def generate_src_mask(self, T, length):
@@ -478,3 +528,78 @@ class MotionTransformer(nn.Module):
         self._pool.give("fwd_t", ws, dev)
         self._pool.give("textctx_t", textctx, dev)
         return dx, dxp, dxo
+
+
+    # ---- text head (hig_text_head_*) -------------------------------------------------------
+    def _text_params(self):
+        """Text-head parameters in hig.h table order (HIG_T_*, then HIG_TL_* per layer)."""
+        pre = self.text_pre_proj
+        glob = [getattr(pre, "weight", None), getattr(pre, "bias", None), self.text_ln.weight, self.text_ln.bias,
+                self.text_proj[0].weight, self.text_proj[0].bias]
+        lay = []
+        for l in self.textTransEncoder.layers:
+            lay += [l.self_attn.in_proj_weight, l.self_attn.in_proj_bias, l.self_attn.out_proj.weight,
+                    l.self_attn.out_proj.bias, l.norm1.weight, l.norm1.bias, l.linear1.weight, l.linear1.bias,
+                    l.linear2.weight, l.linear2.bias, l.norm2.weight, l.norm2.bias]
+        assert len(glob) == _lib.T_NGLOBAL and len(lay) == _lib.T_NLAYER * len(self.textTransEncoder.layers)
+        self._text_slots = [p is not None for p in glob + lay]
+        return [p for p in glob + lay if p is not None]
+
+    def _text_dims(self, B, N, W):
+        l0 = self.textTransEncoder.layers[0]
+        return _lib.TextDims(B=B, N=N, W=W, Lt=self.text_latent_dim, H=l0.self_attn.num_heads,
+                             ff=l0.linear1.out_features, L=len(self.textTransEncoder.layers), E=self.time_embed_dim,
+                             prec={"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16": _lib.PREC_BF16}[self.precision])
+
+    def _text_table(self, tensors):
+        """c_void_p table with NULL in the slots of an Identity text_pre_proj."""
+        arr = (C.c_void_p * len(self._text_slots))()
+        it = iter(tensors)
+        for i, present in enumerate(self._text_slots):
+            arr[i] = next(it).data_ptr() if present else None
+        return arr
+
+    def _launch_text_head(self, clip_out, eot, training):
+        B, N, W = clip_out.shape
+        L = _lib.lib()
+        tp = self._text_params()
+        for p in tp:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise RuntimeError("text head: parameters must be contiguous fp32 ROCm tensors")
+        dims = self._text_dims(B, N, W)
+        nbytes = L.hig_text_head_workspace_bytes(C.byref(dims), int(training))
+        if nbytes < 0:
+            raise RuntimeError("libhig: %s (text_head='torch' selects stock PyTorch ops)" % _lib.last_error())
+        dev = clip_out.device
+        ws = self._pool.take("txt_t" if training else "txt_i", nbytes, dev)
+        xf_out = torch.empty(B, N, self.text_latent_dim, device=dev, dtype=torch.float32)
+        xf_proj = torch.empty(B, self.time_embed_dim, device=dev, dtype=torch.float32)
+        _lib.check(L.hig_text_head_fwd(C.byref(dims), self._text_table(tp), _lib.ptr(clip_out), _lib.ptr(eot),
+                                       _lib.ptr(xf_out), _lib.ptr(xf_proj), _lib.ptr(ws), int(training),
+                                       _lib.stream_ptr()))
+        if not training:
+            self._pool.give("txt_i", ws, dev)
+            return xf_proj, xf_out, None
+        return xf_proj, xf_out, (dims, ws)
+
+    def _launch_text_head_backward(self, clip_out, eot, xf_out, saved, dxf_out, dxf_proj, want_dclip):
+        dims, ws = saved
+        L = _lib.lib()
+        tp = self._text_params()
+        dev = clip_out.device
+        offs, o = [], 0
+        for p in tp:
+            offs.append(o)
+            o += (p.numel() + 63) // 64 * 64
+        gflat = torch.empty(o, device=dev, dtype=torch.float32)
+        grads = [gflat[off:off + p.numel()].view(p.shape) for p, off in zip(tp, offs)]
+        dclip = torch.empty_like(clip_out) if want_dclip else None
+        bws = self._pool.take("txt_bwd", L.hig_text_head_bwd_workspace_bytes(C.byref(dims)), dev)
+        _lib.check(L.hig_text_head_bwd(
+            C.byref(dims), self._text_table(tp), _lib.ptr(clip_out), _lib.ptr(eot), _lib.ptr(xf_out), _lib.ptr(ws),
+            _lib.ptr(None if dxf_out is None else dxf_out.contiguous()),
+            _lib.ptr(None if dxf_proj is None else dxf_proj.contiguous()),
+            self._text_table(grads), _lib.ptr(dclip), _lib.ptr(bws), _lib.stream_ptr()))
+        self._pool.give("txt_bwd", bws, dev)
+        self._pool.give("txt_t", ws, dev)
+        return grads, dclip

@@ -168,6 +168,48 @@ int hig_denoiser_bwd(const hig_dims* dims, const void* const* params, const floa
 int64_t hig_bwd_workspace_bytes(const hig_dims* dims);
 
 /* ------------------------------------------------------------------------------------------
+ * Text head: the trainable part of MotionTransformer.encode_text after CLIP
+ * (transformer.py:324-340, 389-397): text_pre_proj -> L_text post-norm nn.TransformerEncoderLayer
+ * (self-attention over the N tokens, no mask, 1/sqrt(hd) scaling; FFN with exact GELU; dropout 0)
+ * -> text_ln -> xf_out; xf_proj = text_proj(xf_out[b, eot[b]]).  Batch-first (B, N, .) rows.
+ * Parameter table: HIG_T_* then HIG_TL_* per layer, nn.MultiheadAttention / nn.Linear layouts.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hig_text_dims {
+  int32_t B, N, W;  /* samples, tokens (77), CLIP width (512) */
+  int32_t Lt, H, ff, L, E; /* text_latent_dim, text_num_heads, text_ff_size, num_text_layers, 4*latent_dim */
+  int32_t prec;     /* HIG_PREC_* of the GEMM products */
+} hig_text_dims;
+enum {
+  HIG_T_PRE_W = 0, HIG_T_PRE_B, /* text_pre_proj (Lt, W); both NULL = nn.Identity (needs W == Lt) */
+  HIG_T_LN_W, HIG_T_LN_B,       /* text_ln */
+  HIG_T_PROJ_W, HIG_T_PROJ_B,   /* text_proj.0 (E, Lt) */
+  HIG_T_NGLOBAL
+};
+enum {
+  HIG_TL_IN_W = 0, HIG_TL_IN_B,   /* self_attn.in_proj_weight (3Lt, Lt) / in_proj_bias */
+  HIG_TL_OUT_W, HIG_TL_OUT_B,     /* self_attn.out_proj */
+  HIG_TL_N1_W, HIG_TL_N1_B,       /* norm1 */
+  HIG_TL_FF1_W, HIG_TL_FF1_B,     /* linear1 (ff, Lt) */
+  HIG_TL_FF2_W, HIG_TL_FF2_B,     /* linear2 (Lt, ff) */
+  HIG_TL_N2_W, HIG_TL_N2_B,       /* norm2 */
+  HIG_TL_NLAYER
+};
+int64_t hig_text_head_workspace_bytes(const hig_text_dims* dims, int training);
+int64_t hig_text_head_bwd_workspace_bytes(const hig_text_dims* dims);
+/* clip_out (B, N, W): CLIP's ln_final output, batch-first; eot[b] = index of the EOT token
+ * (text.argmax(-1), transformer.py:395).  Writes xf_out (B, N, Lt) and xf_proj (B, E).
+ * training != 0 keeps every layer's activations in `workspace` for hig_text_head_bwd. */
+int hig_text_head_fwd(const hig_text_dims* dims, const void* const* params, const float* clip_out,
+                      const int64_t* eot, float* xf_out, float* xf_proj, void* workspace, int training,
+                      hig_stream_t stream);
+/* Adjoint for upstream d(xf_out), d(xf_proj) (either may be NULL = zero).  Writes (not accumulates)
+ * every parameter gradient through `grads` (same table order) and d(clip_out) if dclip != NULL. */
+int hig_text_head_bwd(const hig_text_dims* dims, const void* const* params, const float* clip_out,
+                      const int64_t* eot, const float* xf_out, const void* workspace, const float* dxf_out,
+                      const float* dxf_proj, void* const* grads, float* dclip, void* bwd_workspace,
+                      hig_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel entry points (unit-testable pieces of the above).
  * ---------------------------------------------------------------------------------------- */
 
@@ -214,6 +256,15 @@ int hig_rowstats(const float* x, int64_t ldx, int64_t rows, int32_t n, float* st
 int hig_ln_mod_silu(const float* x, int64_t ldx, int64_t rows, int32_t n, const float* gamma,
                     const float* beta, const float* ss, int64_t ss_ld, int32_t ss_shift_off,
                     int32_t rows_per_sample, float* a, int64_t lda, float* stats, hig_stream_t stream);
+
+/* Plain LayerNorm y = LN(x)*gamma+beta (eps 1e-5) that also returns stats = (mean, rstd) per row. */
+int hig_layernorm(const float* x, int64_t ldx, int64_t rows, int32_t n, const float* gamma,
+                  const float* beta, float* y, int64_t ldy, float* stats, hig_stream_t stream);
+/* dst[b][:n] = src[b*rows_per_sample + idx[b]][:n] and its adjoint dst[...] += src[b]. */
+int hig_gather_rows(const float* src, int64_t ld, int32_t B, int32_t rows_per_sample, const int64_t* idx,
+                    int32_t n, float* dst, int64_t ldd, hig_stream_t stream);
+int hig_scatter_add_rows(const float* src, int64_t ld, int32_t B, int32_t rows_per_sample,
+                         const int64_t* idx, int32_t n, float* dst, int64_t ldd, hig_stream_t stream);
 
 /* Linear ("efficient") attention pieces, transformer.py:110-117 / 146-153.  Channel c of
  * head h lives at column h*hd + c.

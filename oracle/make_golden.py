@@ -358,6 +358,42 @@ def g9_mul_trainer():
     np.savez_compressed(os.path.join(GOLD, "g9_mul_trainer.npz"), **out)
 
 
+TEXT_CAPTIONS = ["a person shakes hands with another person", "two people hug", "one pushes the other away and "
+                 "then they both walk in a circle while waving their arms above their heads slowly", "bow"]
+
+
+def g10_text_head():
+    """The reference's own encode_text (stub CLIP + its torch text head): outputs and gradients."""
+    out = {}
+    for cname in ("tiny", "config1"):
+        c = fill.CASES[cname]
+        m = build_ref_model(c, False).train()
+        xf_proj, xf_out = m.encode_text(TEXT_CAPTIONS, "cpu")
+        out[cname + ".xf_proj"] = xf_proj.detach().numpy()
+        out[cname + ".xf_out"] = xf_out.detach().numpy()
+        r1 = fill.tensor_for("g10.r1." + cname, xf_proj.shape) * 10.0
+        r2 = fill.tensor_for("g10.r2." + cname, xf_out.shape) * 10.0
+        ((xf_proj * r1).sum() + (xf_out * r2).sum()).backward()
+        named = dict(m.named_parameters())
+        L = len(m.textTransEncoder.layers) - 1
+        sq = 0.0
+        for k, v in named.items():
+            if k.startswith("text"):
+                sq += float((v.grad.double() ** 2).sum())
+        out[cname + ".gnorm_text"] = np.float64(sq ** 0.5)
+        for pn in ("text_pre_proj.weight", "text_pre_proj.bias", "text_ln.weight", "text_ln.bias", "text_proj.0.weight",
+                   "text_proj.0.bias", "textTransEncoder.layers.0.self_attn.in_proj_weight",
+                   "textTransEncoder.layers.0.self_attn.in_proj_bias",
+                   "textTransEncoder.layers.%d.self_attn.out_proj.weight" % L,
+                   "textTransEncoder.layers.0.norm1.weight", "textTransEncoder.layers.%d.norm2.bias" % L,
+                   "textTransEncoder.layers.0.linear1.bias", "textTransEncoder.layers.%d.linear2.weight" % L):
+            g = named[pn].grad
+            if cname == "config1" and g.numel() > 70000:
+                g = g[:64, :64]            # keep the fixture small: a corner block is enough next to gnorm
+            out[cname + ".g." + pn] = g.numpy()
+    np.savez_compressed(os.path.join(GOLD, "g10_text_head.npz"), **out)
+
+
 def g7_state_dict_keys():
     """Key/shape contract of the reference module (tiny config) for the round-trip test."""
     c = fill.CASES["tiny"]
@@ -372,7 +408,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for fn in (g1, g2_g3, g4, g5, g6, g7_state_dict_keys, g8_interaction, g9_mul_trainer):
+    for fn in (g1, g2_g3, g4, g5, g6, g7_state_dict_keys, g8_interaction, g9_mul_trainer, g10_text_head):
         if only and fn.__name__ not in only:
             continue
         fn()

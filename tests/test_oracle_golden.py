@@ -169,3 +169,45 @@ def test_pit_loss_symmetry():
     b = IR.pit_loss(pred[perm], tgt[perm], mask)
     assert torch.allclose(a, b)
     assert IR.pit_loss(pred, tgt, mask) <= IR.labelled_loss(pred, tgt, mask) * 2 + 1e-6
+
+
+# ---- text head ---------------------------------------------------------------------
+from oracle import text_head_ref as TH  # noqa: E402
+
+TEXT_CAPTIONS = ["a person shakes hands with another person", "two people hug", "one pushes the other away and "
+                 "then they both walk in a circle while waving their arms above their heads slowly", "bow"]
+
+
+def text_case(case):
+    """Stub-CLIP features of the golden captions + name-seeded text-head parameters."""
+    import hig_amd
+    from hig_amd.models import stub_clip
+    c = fill.CASES[case]
+    m = hig_amd.MotionTransformer(c["F"], num_frames=c["num_frames"], latent_dim=c["d"], ff_size=c["ff"],
+                                  num_layers=c["L"], num_heads=c["H"], text_latent_dim=c["Lt"], text_head="torch")
+    sd = fill.fill_state_dict(m.state_dict())
+    tokens, x = m._clip_features(TEXT_CAPTIONS, "cpu")
+    assert tokens.argmax(-1).tolist() == [len(s.split()) + 1 for s in TEXT_CAPTIONS] and stub_clip.EOT == 49407
+    p = {k: v for k, v in sd.items() if k.startswith("text")}
+    return c, p, x.permute(1, 0, 2).contiguous(), tokens.argmax(-1)
+
+
+@pytest.mark.parametrize("case", ["tiny", "config1"])
+def test_g10_text_head_forward_backward(gold, case):
+    g = gold("g10_text_head.npz")
+    c, p, clip_out, eot = text_case(case)
+    p = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xf_proj, xf_out = TH.text_head_forward(p, clip_out, eot, 4, 4)
+    assert rel(xf_proj, g[case + ".xf_proj"]) < 2e-6 and rel(xf_out, g[case + ".xf_out"]) < 2e-6
+    r1 = fill.tensor_for("g10.r1." + case, xf_proj.shape) * 10.0
+    r2 = fill.tensor_for("g10.r2." + case, xf_out.shape) * 10.0
+    ((xf_proj * r1).sum() + (xf_out * r2).sum()).backward()
+    tot = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in p.values())).item()
+    assert abs(tot - float(g[case + ".gnorm_text"])) < 1e-5 * tot
+    for k in g.files:
+        if k.startswith(case + ".g."):
+            ref = torch.tensor(g[k])
+            got = p[k[len(case) + 3:]].grad
+            if got.shape != ref.shape:
+                got = got[:64, :64]
+            assert (got - ref).norm().item() < 2e-5 * ref.norm().item() + 1e-7 * tot, k
