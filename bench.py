@@ -320,6 +320,27 @@ def main():
                 "fwd_bwd_frames_per_s": round(c2["B"] * c2["T"] * k2 / e_fb, 1), "fwd_bwd_ms": round(e_fb / k2 * 1e3, 3),
                 "what": "MotionInteractionTransformer, 32 pairs (model batch 64) x 91 tokens x 263 features, d=512 L=8, "
                         "f32 products; frames = person-tokens"}
+            # ---- text head: encode_text after CLIP, fwd+bwd, HIP vs stock torch ops ----
+            caps = ["a person walks towards another person and shakes hands number %d" % i for i in range(B)]
+            th = {}
+            for mode in ("hip", "torch"):
+                model.text_head = mode
+                model.train()
+                tok, feat = model._clip_features(caps, device)
+
+                def text_step():
+                    xp, xo = model._text_head(tok, feat)
+                    (xp.sum() + xo.sum()).backward()
+
+                e_t = timed(text_step, k2, 2, 1)
+                th[mode] = round(e_t / k2 * 1e3, 3)
+            model.text_head = "hip"
+            model.eval()
+            model.zero_grad(set_to_none=True)
+            extra["text_head"] = {"fwd_bwd_ms_hip": th["hip"], "fwd_bwd_ms_stock_torch": th["torch"],
+                                  "what": "text_pre_proj + 4-layer encoder (77 tokens, d=256, ff=2048) + text_ln + "
+                                          "text_proj, fwd+bwd at B=64, fp32: hig_text_head_* vs nn.TransformerEncoder "
+                                          "on PyTorch-ROCm"}
     if rank == 0:
         res["roofline"] = ffn_gemm_roofline(c, device)
         if not a.no_cpu_baseline and world == 1:

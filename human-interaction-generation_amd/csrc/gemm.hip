@@ -577,8 +577,10 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
   per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
   const int max_vgpr_blocks = (BI * BJ >= 128 * 128) ? 2 : 4;   // 128x128: <=256 VGPRs -> 2 waves/SIMD
   if (per_cu > max_vgpr_blocks) per_cu = max_vgpr_blocks;
+  static const int forced_per_cu = getenv("HIG_GEMM_PERCU") ? atoi(getenv("HIG_GEMM_PERCU")) : -1;  // tuning knob
+  if (forced_per_cu > 0) per_cu = forced_per_cu;
   int gridx = 256 * per_cu;
-  if (gridx > a.ntiles) gridx = a.ntiles;
+  if (gridx > a.ntiles || forced_per_cu == 0) gridx = a.ntiles;   // 0: one workgroup per tile
   const bool fast = a.vecx && a.vecy && (g.R % BK == 0) && g.R > 0 &&
                     (!X_RS || (g.I % 4 == 0 && g.I >= 4)) && (!Y_RS || (g.J % 4 == 0 && g.J >= 4));
   if (a.ntiles > 0 && g.R >= 0) {

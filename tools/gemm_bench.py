@@ -15,6 +15,9 @@ def run(M, N, K, xf, epi, reps=20):
     dev = "cuda"
     X = torch.randn(M, K, device=dev)
     W = torch.randn(N, K, device=dev) * 0.05
+    if os.environ.get("ZERO"):   # data-dependent power: zero operands show the clock give-back
+        X.zero_()
+        W.zero_()
     b = torch.randn(N, device=dev)
     out = torch.empty(M, N, device=dev)
     res = torch.randn(M, N, device=dev)

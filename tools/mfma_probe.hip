@@ -4,13 +4,15 @@
 //   variant 1: + 2 ds_read_b128 per 4 MFMAs (operands from LDS)
 //   variant 2: + one __syncthreads per 16 MFMAs
 //   variant 3: + 4 global_load_dwordx4 + 4 ds_write_b128 per 16 MFMAs (full staging traffic)
+//   variant 4: variant 2 + the 4 global loads only (consumed by a VALU add, no LDS write)
+//   variant 5: variant 2 + the 4 ds_write_b128 only (constant registers, no global load)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int VARIANT, int NACC>
-__global__ __launch_bounds__(256) void probe(const float* __restrict__ g, float* __restrict__ out, int iters) {
+__global__ __launch_bounds__(256) void probe(const float* __restrict__ g, float* __restrict__ out, int iters, int bmask) {
   __shared__ __attribute__((aligned(16))) float lds[2][2 * 64 * 36];
   const int tid = threadIdx.x, lane = tid & 63;
   f32x16 acc[NACC];
@@ -19,11 +21,13 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ g, float*
   for (int i = tid; i < 2 * 2 * 64 * 36; i += 256) (&lds[0][0])[i] = (float)(i & 7);
   __syncthreads();
   float4 stage[4];
-  const float* gp = g + (size_t)blockIdx.x * 4096 + tid * 4;
+  float sink = 0.f;
+  for (int p = 0; p < 4; ++p) stage[p] = make_float4(tid, 1.f, 2.f, 3.f);
+  const float* gp = g + (size_t)(blockIdx.x & bmask) * 4096 + tid * 4;  // bmask small: every block re-reads the same L2-resident rows
   float xa = 1.0f + lane, xb = 0.5f;
   for (int it = 0; it < iters; ++it) {
     const float* sx = lds[it & 1];
-    if (VARIANT >= 3) {
+    if (VARIANT == 3 || VARIANT == 4) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) stage[p] = *reinterpret_cast<const float4*>(gp + ((it * 4 + p) & 63) * 1024);
     }
@@ -44,28 +48,32 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ g, float*
 #pragma unroll
         for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[j], xf[j], acc[a], 0, 0, 0);
     }
-    if (VARIANT >= 3) {
+    if (VARIANT == 3 || VARIANT == 5) {
       float* dst = lds[(it + 1) & 1];
 #pragma unroll
       for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(dst + ((tid >> 3) + 32 * p) * 36 + 4 * (tid & 7)) = stage[p];
     }
+    if (VARIANT == 4) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) sink += stage[p].x + stage[p].w;
+    }
     if (VARIANT >= 2) __syncthreads();
   }
-  float s = 0.f;
+  float s = sink;
   for (int a = 0; a < NACC; ++a)
     for (int e = 0; e < 16; ++e) s += acc[a][e];
   out[(size_t)blockIdx.x * 256 + tid] = s;
 }
 
 template <int V, int NACC>
-void run(const char* name, int blocks, const float* g, float* out) {
+void run(const char* name, int blocks, const float* g, float* out, int bmask = 0xffff) {
   const int iters = 2000;
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL((probe<V, NACC>), dim3(blocks), dim3(256), 0, 0, g, out, 10);
+  hipLaunchKernelGGL((probe<V, NACC>), dim3(blocks), dim3(256), 0, 0, g, out, 10, bmask);
   hipEventRecord(e0);
-  hipLaunchKernelGGL((probe<V, NACC>), dim3(blocks), dim3(256), 0, 0, g, out, iters);
+  hipLaunchKernelGGL((probe<V, NACC>), dim3(blocks), dim3(256), 0, 0, g, out, iters, bmask);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -90,6 +98,10 @@ int main() {
     run<2, 4>("+barrier/64 mfma", blocks, g, out);
     run<3, 1>("+global load + ds_write", blocks, g, out);
     run<3, 4>("+global load + ds_write", blocks, g, out);
+    run<4, 1>("+global load only", blocks, g, out);
+    run<5, 1>("+ds_write only", blocks, g, out);
+    run<4, 1>("+global load only, L2-resident", blocks, g, out, 15);
+    run<3, 1>("+global load + ds_write, L2-res.", blocks, g, out, 15);
   }
   return 0;
 }
