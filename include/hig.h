@@ -210,6 +210,18 @@ int hig_text_head_bwd(const hig_text_dims* dims, const void* const* params, cons
                       hig_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Input pipeline: batch assembly from a device-resident bank of motions.
+ * Reference arithmetic: Text2MotionMulDataset.__getitem__, datasets/mul_dataset.py:203-209.
+ * out[r][t][:] = normalise(bank[seq_off[r] + frame_ix[r][t] * F ...]):  token 0 (the init-pose row)
+ * is (x - init_mean) / init_std on its first 4 features and raw elsewhere; tokens >= 1 are
+ * (x - mean) / std.  stats = [mean F | std F | init_mean 4 | init_std 4], float (stats_f64 == 0) or
+ * double (numpy's promotion when the saved statistics are float64): bit-identical to numpy either way.
+ * ---------------------------------------------------------------------------------------- */
+int hig_gather_frames(const float* bank, const int64_t* seq_off, const int32_t* frame_ix,
+                      const void* stats, int32_t stats_f64, int32_t rows, int32_t T, int32_t F,
+                      float* out, hig_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel entry points (unit-testable pieces of the above).
  * ---------------------------------------------------------------------------------------- */
 

@@ -394,6 +394,38 @@ def g10_text_head():
     np.savez_compressed(os.path.join(GOLD, "g10_text_head.npz"), **out)
 
 
+def g11_dataset():
+    """The reference's own Text2MotionMulDataset on the synthetic files of oracle/synth_dataset.py:
+    the feat_bias-adjusted statistics and __getitem__ outputs under a fixed `random` seed."""
+    import random
+    import tempfile
+    from oracle import synth_dataset as SD
+    from datasets.mul_dataset import Text2MotionMulDataset
+    out = {}
+    for tag, sdt, with_label in (("f32", np.float32, False), ("f64", np.float64, True)):
+        with tempfile.TemporaryDirectory() as root:
+            opt = SD.write(root)
+            mean, std = SD.stats(sdt)
+            ds = Text2MotionMulDataset(opt, mean.copy(), std.copy(), opt.split_file, times=2,
+                                       label_path=opt.label_path if with_label else None)
+            out[tag + ".mean_saved"] = np.load(os.path.join(opt.meta_dir, "mean.npy"))
+            out[tag + ".std_saved"] = np.load(os.path.join(opt.meta_dir, "std.npy"))
+            out[tag + ".names"] = np.array(list(ds.name_list))
+            out[tag + ".len"] = np.int64(len(ds))
+            random.seed(1234)
+            for i in range(len(ds)):
+                c1, c2, m1, m2, ml, fid = ds[i]
+                for nm, m in (("m1", np.asarray(m1)), ("m2", np.asarray(m2))):
+                    # bit-exact probes instead of the whole (91, 263) array: six full rows, every 37th
+                    # column, and an order-independent checksum of the raw bits
+                    out["%s.%d.%s.rows" % (tag, i, nm)] = m[[0, 1, 2, 45, 89, 90]]
+                    out["%s.%d.%s.cols" % (tag, i, nm)] = m[:, ::37]
+                    out["%s.%d.%s.bits" % (tag, i, nm)] = np.uint64(m.view(np.uint32).astype(np.uint64).sum())
+                    out["%s.%d.%s.shape" % (tag, i, nm)] = np.array(m.shape)
+                out["%s.%d.meta" % (tag, i)] = np.array([c1, c2, str(ml), fid])
+    np.savez_compressed(os.path.join(GOLD, "g11_dataset.npz"), **out)
+
+
 def g7_state_dict_keys():
     """Key/shape contract of the reference module (tiny config) for the round-trip test."""
     c = fill.CASES["tiny"]
@@ -408,7 +440,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for fn in (g1, g2_g3, g4, g5, g6, g7_state_dict_keys, g8_interaction, g9_mul_trainer, g10_text_head):
+    for fn in (g1, g2_g3, g4, g5, g6, g7_state_dict_keys, g8_interaction, g9_mul_trainer, g10_text_head, g11_dataset):
         if only and fn.__name__ not in only:
             continue
         fn()
