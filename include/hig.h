@@ -222,6 +222,19 @@ int hig_gather_frames(const float* bank, const int64_t* seq_off, const int32_t* 
                       float* out, hig_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Post-sampling joint recovery: de-normalise a generated motion and integrate it to
+ * world-space joint positions.  Reference: tools/visualization.py:146-152 (x * std + mean, init row on
+ * 4 features), utils/motion_process.py:362-382 recover_root_rot_pos, :418-462 recover_from_ric2
+ * (one person; both persons are rows of the same call), utils/quaternion.py qinv / qrot.
+ * motion (rows, T + 1, F): T body frames + one init-state row [x, z, quat_w, quat_y, ...], first
+ * (init_first = 1, the sampler's token order) or last (0, recover_from_ric2's order).
+ * stats = [mean F | std F | init_mean 4 | init_std 4] floats, or NULL if already de-normalised.
+ * pos (rows, T, joints, 3).
+ * ---------------------------------------------------------------------------------------- */
+int hig_recover_joints(const float* motion, const float* stats, int32_t rows, int32_t T, int32_t F,
+                       int32_t joints, int32_t init_first, float* pos, hig_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel entry points (unit-testable pieces of the above).
  * ---------------------------------------------------------------------------------------- */
 

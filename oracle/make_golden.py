@@ -426,6 +426,27 @@ def g11_dataset():
     np.savez_compressed(os.path.join(GOLD, "g11_dataset.npz"), **out)
 
 
+def g12_recover():
+    """The reference's own recover_from_ric2 / recover_root_rot_pos on seeded inputs."""
+    np.float = float          # numpy >= 1.24 dropped the alias the reference's utils still use
+    from utils.motion_process import recover_from_ric2, recover_root_rot_pos
+    out = {}
+    B, T, Fd, J = 3, 90, 263, 22
+    d1 = fill.tensor_for("g12.data1", (B, T + 1, Fd)) * 10.0
+    d2 = fill.tensor_for("g12.data2", (B, T + 1, Fd)) * 10.0
+    for d in (d1, d2):
+        d[..., 0] *= 0.05          # angular velocity (rad / frame)
+        d[:, -1, 2:4] = torch.nn.functional.normalize(d[:, -1, 2:4], dim=-1)   # init quaternion (w, y)
+    # the reference broadcasts the init quaternion as (B, 4) against (B, T, J, 4), which only lines up
+    # for B == 1 (how its plotting code calls it): one sample at a time
+    ps = [recover_from_ric2(d1[b:b + 1].clone(), d2[b:b + 1].clone(), J) for b in range(B)]
+    out["pos1"] = torch.cat([p[0] for p in ps]).numpy()
+    out["pos2"] = torch.cat([p[1] for p in ps]).numpy()
+    q, r = recover_root_rot_pos(d1[:, :-1].clone())
+    out["quat"], out["rpos"] = q.numpy(), r.numpy()
+    np.savez_compressed(os.path.join(GOLD, "g12_recover.npz"), **out)
+
+
 def g7_state_dict_keys():
     """Key/shape contract of the reference module (tiny config) for the round-trip test."""
     c = fill.CASES["tiny"]
@@ -440,7 +461,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for fn in (g1, g2_g3, g4, g5, g6, g7_state_dict_keys, g8_interaction, g9_mul_trainer, g10_text_head, g11_dataset):
+    for fn in (g1, g2_g3, g4, g5, g6, g7_state_dict_keys, g8_interaction, g9_mul_trainer, g10_text_head, g11_dataset, g12_recover):
         if only and fn.__name__ not in only:
             continue
         fn()
