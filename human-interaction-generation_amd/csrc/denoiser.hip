@@ -101,6 +101,7 @@ struct FwdLayout {
   int64_t layer0, lstride;
   int64_t st1, qkv, A1, kst1, lse1, y1, st2, a1, h1, st3, qc, lse2, y2, st4, a2, h2, z1, f1, y3, st5, a3, h3;
   int64_t st6, iqkv, Ai, ksti, y4, st7, a4, h2b;  // two-person interaction attention block
+  int64_t xn1, xn2, xn3;  // LayerNorm outputs feeding the q/k/v GEMMs (kept: wgrad operands)
   int64_t total;
 };
 FwdLayout fwd_layout(const Dims& D, int training) {
@@ -116,6 +117,7 @@ FwdLayout fwd_layout(const Dims& D, int training) {
   w.layer0 = o;
   o = 0;
   w.st1 = take(D.M * 2);
+  w.xn1 = take(D.M * D.d);
   w.qkv = take(D.M * 3 * D.d);
   w.A1 = take((int64_t)D.B * D.H * D.hd * D.hd);
   w.kst1 = take((int64_t)D.B * D.d * 2);
@@ -125,6 +127,7 @@ FwdLayout fwd_layout(const Dims& D, int training) {
   w.a1 = take(D.M * D.d);
   w.h1 = take(D.M * D.d);
   w.st3 = take(D.M * 2);
+  w.xn2 = take(D.M * D.d);
   w.qc = take(D.M * D.d);
   w.lse2 = take((int64_t)D.B * D.H * D.T);
   w.y2 = take(D.M * D.d);
@@ -137,9 +140,10 @@ FwdLayout fwd_layout(const Dims& D, int training) {
   w.st5 = take(D.M * 2);
   w.a3 = take(D.M * D.d);
   w.h3 = take(D.M * D.d);
-  w.st6 = w.iqkv = w.Ai = w.ksti = w.y4 = w.st7 = w.a4 = w.h2b = 0;
+  w.st6 = w.iqkv = w.Ai = w.ksti = w.y4 = w.st7 = w.a4 = w.h2b = w.xn3 = 0;
   if (D.two == 1) {
     w.st6 = take(D.M * 2);
+    w.xn3 = take(D.M * D.d);
     w.iqkv = take(D.M * 3 * D.d);
     w.Ai = take((int64_t)D.B * D.H * D.hd * D.hd);
     w.ksti = take((int64_t)D.B * D.d * 2);
@@ -336,9 +340,11 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
     const float* ssl = ws + w.ss + (int64_t)(D.nsty * l) * 2 * d;
     const float* ss_ffn = ssl + (int64_t)(D.nsty - 1) * 2 * d;
     // ---- self attention -------------------------------------------------------------
-    HIG_TRY(hig_rowstats(hin, d, M, d, lb + w.st1, stream));
-    HIG_TRY(hig_gemm_launch(G(hin, d, 0, PL(params, l, HIG_L_SA_QKV_W), d, 0, lb + w.qkv, 3 * d, M, 3 * d, d)
-                                .ln(0, lb + w.st1, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B))
+    // LayerNorm as its own row kernel: the GEMM then stages plain operands (a fused LN prologue cost
+    // the q/k/v GEMM 258 -> 207 us at config 2, the row pass 13 us; profiles/r01_notes.md)
+    HIG_TRY(hig_layernorm(hin, d, M, d, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B), lb + w.xn1, d,
+                          lb + w.st1, stream));
+    HIG_TRY(hig_gemm_launch(G(lb + w.xn1, d, 0, PL(params, l, HIG_L_SA_QKV_W), d, 0, lb + w.qkv, 3 * d, M, 3 * d, d)
                                 .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_SA_QKV_B)).prec(D.prec).g, 1, nullptr, st));
     if (D.full) {
       HIG_TRY(hig_fullattn_fwd(lb + w.qkv, 3 * d, lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, D.B, D.T, D.T, D.H, D.hd,
@@ -353,9 +359,9 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
     HIG_TRY(hig_gemm_launch(G(lb + w.a1, d, 0, PL(params, l, HIG_L_SA_STY_OUT_W), d, 0, lb + w.h1, d, M, d, d)
                                 .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_SA_STY_OUT_B)).res(hin, d).prec(D.prec).g, 1, nullptr, st));
     // ---- cross attention ------------------------------------------------------------
-    HIG_TRY(hig_rowstats(lb + w.h1, d, M, d, lb + w.st3, stream));
-    HIG_TRY(hig_gemm_launch(G(lb + w.h1, d, 0, PL(params, l, HIG_L_CA_Q_W), d, 0, lb + w.qc, d, M, d, d)
-                                .ln(0, lb + w.st3, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B))
+    HIG_TRY(hig_layernorm(lb + w.h1, d, M, d, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B),
+                          lb + w.xn2, d, lb + w.st3, stream));
+    HIG_TRY(hig_gemm_launch(G(lb + w.xn2, d, 0, PL(params, l, HIG_L_CA_Q_W), d, 0, lb + w.qc, d, M, d, d)
                                 .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).prec(D.prec).g, 1, nullptr, st));
     if (D.full) {
       const float* kvl = tc + tl.kv + tl.kv_stride * l;
@@ -374,9 +380,9 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
       // ---- person <-> person linear cross attention (interaction_transformer.py:181-205): queries from
       // the own stream, key/value from the partner's (same LayerNorm on both), key softmax masked with
       // the consumer's length, value unmasked (masked rows carry k == 0 anyway)
-      HIG_TRY(hig_rowstats(lb + w.h2, d, M, d, lb + w.st6, stream));
-      HIG_TRY(hig_gemm_launch(G(lb + w.h2, d, 0, PL(params, l, HIG_L_INT_QKV_W), d, 0, lb + w.iqkv, 3 * d, M, 3 * d, d)
-                                  .ln(0, lb + w.st6, PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B))
+      HIG_TRY(hig_layernorm(lb + w.h2, d, M, d, PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B),
+                            lb + w.xn3, d, lb + w.st6, stream));
+      HIG_TRY(hig_gemm_launch(G(lb + w.xn3, d, 0, PL(params, l, HIG_L_INT_QKV_W), d, 0, lb + w.iqkv, 3 * d, M, 3 * d, d)
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_INT_QKV_B)).prec(D.prec).g, 1, nullptr, st));
       HIG_TRY(hig_linattn_ctx(lb + w.iqkv + d, lb + w.iqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, len_partner,
                               lb + w.Ai, lb + w.ksti, stream));
@@ -554,8 +560,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
       HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, lb + w.iqkv + d, lb + w.iqkv + 2 * d, 3 * d, lb + w.ksti, len_partner,
                                   dqkv + d, dqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, b + bw.attn, stream));
       HIG_TRY(colsum(dqkv, 3 * d, M, 3 * d, GL(grads, l, HIG_L_INT_QKV_B)));
-      HIG_TRY(wgrad_act(dqkv, 3 * d, lb + w.h2, d, GL(grads, l, HIG_L_INT_QKV_W), M, lb + w.st6,
-                        PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B)));
+      HIG_TRY(wgrad_act(dqkv, 3 * d, lb + w.xn3, d, GL(grads, l, HIG_L_INT_QKV_W), M, nullptr, nullptr, nullptr));
       HIG_TRY(hig_gemm_launch(G(dqkv, 3 * d, 0, wT + o_iqkv, 3 * d, 0, b + bw.t2, d, M, d, 3 * d).prec(D.prec).g, 1,
                               nullptr, st));
       HIG_TRY(hig_ln_bwd(b + bw.t2, d, lb + w.h2, d, lb + w.st6, PL(params, l, HIG_L_INT_NORM_W),
@@ -578,8 +583,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                                     b + bw.attn, stream));
     const float* dqc = b + bw.t1;
     HIG_TRY(colsum(dqc, d, M, d, GL(grads, l, HIG_L_CA_Q_B)));
-    HIG_TRY(wgrad_act(dqc, d, lb + w.h1, d, GL(grads, l, HIG_L_CA_Q_W), M, lb + w.st3, PL(params, l, HIG_L_CA_NORM_W),
-                      PL(params, l, HIG_L_CA_NORM_B)));
+    HIG_TRY(wgrad_act(dqc, d, lb + w.xn2, d, GL(grads, l, HIG_L_CA_Q_W), M, nullptr, nullptr, nullptr));
     HIG_TRY(hig_gemm_launch(G(dqc, d, 0, wT + o_caq, d, 0, b + bw.t2, d, M, d, d).prec(D.prec).g, 1, nullptr, st));
     HIG_TRY(hig_ln_bwd(b + bw.t2, d, lb + w.h1, d, lb + w.st3, PL(params, l, HIG_L_CA_NORM_W),
                        PL(params, l, HIG_L_CA_NORM_B), nullptr, 0, 0, 0, dh, d, dh_alt, d, M, d, D.T,
@@ -613,8 +617,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                                   dqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, b + bw.attn, stream));
     }
     HIG_TRY(colsum(dqkv, 3 * d, M, 3 * d, GL(grads, l, HIG_L_SA_QKV_B)));
-    HIG_TRY(wgrad_act(dqkv, 3 * d, hin, d, GL(grads, l, HIG_L_SA_QKV_W), M, lb + w.st1, PL(params, l, HIG_L_SA_NORM_W),
-                      PL(params, l, HIG_L_SA_NORM_B)));
+    HIG_TRY(wgrad_act(dqkv, 3 * d, lb + w.xn1, d, GL(grads, l, HIG_L_SA_QKV_W), M, nullptr, nullptr, nullptr));
     HIG_TRY(hig_gemm_launch(G(dqkv, 3 * d, 0, wT + o_qkv, 3 * d, 0, b + bw.t2, d, M, d, 3 * d).prec(D.prec).g, 1,
                             nullptr, st));
     HIG_TRY(hig_ln_bwd(b + bw.t2, d, hin, d, lb + w.st1, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B),

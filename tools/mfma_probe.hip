@@ -12,13 +12,18 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int VARIANT, int NACC>
-__global__ __launch_bounds__(256) void probe(const float* __restrict__ g, float* __restrict__ out, int iters, int bmask) {
+__global__ __launch_bounds__(256) void probe(const float* __restrict__ g, float* __restrict__ out, int iters, int bmask, int rnd) {
   __shared__ __attribute__((aligned(16))) float lds[2][2 * 64 * 36];
   const int tid = threadIdx.x, lane = tid & 63;
   f32x16 acc[NACC];
   for (int a = 0; a < NACC; ++a)
     for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
-  for (int i = tid; i < 2 * 2 * 64 * 36; i += 256) (&lds[0][0])[i] = (float)(i & 7);
+  // rnd != 0: operands with random mantissas / signs (data-dependent power -> clock); else small integers
+  for (int i = tid; i < 2 * 2 * 64 * 36; i += 256) {
+    unsigned h = (unsigned)i * 2654435761u + (unsigned)blockIdx.x * 40503u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    (&lds[0][0])[i] = rnd ? ((float)(int)(h & 0xffffff) - 8388608.0f) * (1.0f / 8388608.0f) : (float)(i & 7);
+  }
   __syncthreads();
   float4 stage[4];
   float sink = 0.f;
@@ -66,14 +71,14 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ g, float*
 }
 
 template <int V, int NACC>
-void run(const char* name, int blocks, const float* g, float* out, int bmask = 0xffff) {
+void run(const char* name, int blocks, const float* g, float* out, int bmask = 0xffff, int rnd = 0) {
   const int iters = 2000;
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL((probe<V, NACC>), dim3(blocks), dim3(256), 0, 0, g, out, 10, bmask);
+  hipLaunchKernelGGL((probe<V, NACC>), dim3(blocks), dim3(256), 0, 0, g, out, 10, bmask, rnd);
   hipEventRecord(e0);
-  hipLaunchKernelGGL((probe<V, NACC>), dim3(blocks), dim3(256), 0, 0, g, out, iters, bmask);
+  hipLaunchKernelGGL((probe<V, NACC>), dim3(blocks), dim3(256), 0, 0, g, out, iters, bmask, rnd);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -100,6 +105,8 @@ int main() {
     run<3, 4>("+global load + ds_write", blocks, g, out);
     run<4, 1>("+global load only", blocks, g, out);
     run<5, 1>("+ds_write only", blocks, g, out);
+    run<2, 1>("+barrier, RANDOM operands", blocks, g, out, 0xffff, 1);
+    run<2, 4>("+barrier, RANDOM operands", blocks, g, out, 0xffff, 1);
     run<4, 1>("+global load only, L2-resident", blocks, g, out, 15);
     run<3, 1>("+global load + ds_write, L2-res.", blocks, g, out, 15);
   }
