@@ -214,6 +214,142 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ Q,
 }
 
 // ---------------------------------------------------------------------------------------------
+// hd = 64 forward kernels on the matrix cores.  The 64 x 64 contractions are small GEMMs; on the
+// VALU they were LDS-read bound (8 ds_read_b32 per 16 FMAs), 30 / 42 us per launch at config 2
+// against ~12 us of HBM time.  v_mfma_f32_32x32x2_f32: 4 waves = the 2 x 2 grid of 32 x 32 output
+// blocks; operand k order inside an 8-group is k = 8*ks + 4*(lane>>5) + j for both operands (as in
+// gemm.hip), the MFMA "row" operand is the one indexed by the OUTPUT COLUMN so that a lane ends up
+// with 4 consecutive output columns per accumulator quad (16-byte stores).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Y tile (64 rows) = softmax_c(Q tile) . A[b,h]
+__global__ __launch_bounds__(256) void apply_mfma64_kernel(const float* __restrict__ Q, int64_t ldq,
+                                                           const float* __restrict__ A,
+                                                           float* __restrict__ Y, int64_t ldy, int rows,
+                                                           int H) {
+  constexpr int HD = 64, LDP = HD + 4;
+  __shared__ __attribute__((aligned(16))) float sA[HD * HD];    // [c][l]: reduce index major
+  __shared__ __attribute__((aligned(16))) float sQ[CH * LDP];   // [row][c]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int r0 = blockIdx.y * CH;
+  const float* Ab = A + (int64_t)blockIdx.x * HD * HD;
+  for (int idx = tid; idx < HD * HD / 4; idx += 256)
+    reinterpret_cast<float4*>(sA)[idx] = reinterpret_cast<const float4*>(Ab)[idx];
+  load_tile<HD>(Q + (int64_t)b * rows * ldq + h * HD, ldq, r0, rows, sQ);
+  __syncthreads();
+  row_softmax_tile<HD>(sQ);
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const float* qrow = sQ + (wi * 32 + lr) * LDP + 4 * lh;
+  const float* acol = sA + (4 * lh) * HD + wj * 32 + lr;
+#pragma unroll
+  for (int ks = 0; ks < HD / 8; ++ks) {
+    const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * ks);
+    const float a0 = acol[(8 * ks + 0) * HD], a1 = acol[(8 * ks + 1) * HD], a2 = acol[(8 * ks + 2) * HD],
+                a3 = acol[(8 * ks + 3) * HD];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q4.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q4.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, q4.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, q4.w, acc, 0, 0, 0);
+  }
+  const int r = r0 + wi * 32 + lr;
+  if (r < rows) {
+    float* yp = Y + ((int64_t)b * rows + r) * ldy + h * HD + wj * 32 + 4 * lh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(yp + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+  }
+}
+
+// A[b,h][c][l] = sum_r softmax_r(K)[r,c] V[r,l]  (+ kstat), one workgroup per (sample, head)
+__global__ __launch_bounds__(256) void ctx_mfma64_kernel(const float* __restrict__ K, const float* __restrict__ V,
+                                                         int64_t ld, int rows, int H,
+                                                         const int64_t* __restrict__ length, float* __restrict__ A,
+                                                         float* __restrict__ kstat) {
+  constexpr int HD = 64, LDP = HD + 4, RG = 256 / HD;
+  __shared__ __attribute__((aligned(16))) float sP[CH * LDP];   // [r][c] = exp(K - colmax)
+  __shared__ __attribute__((aligned(16))) float sV[CH * LDP];   // [r][l]
+  __shared__ float sred[256];
+  __shared__ float smax[HD];
+  __shared__ float ssum[HD];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  int len = rows;
+  if (length) len = (int)min<int64_t>(max<int64_t>(length[b], 0), rows);
+  const float* Kb = K + (int64_t)b * rows * ld + h * HD;
+  const float* Vb = V + (int64_t)b * rows * ld + h * HD;
+  const int c = tid % HD, rg = tid / HD;
+  {  // pass 1: column max over the valid rows
+    float m = -INFINITY;
+    for (int r = rg; r < len; r += RG) m = fmaxf(m, Kb[(int64_t)r * ld + c]);
+    sred[tid] = m;
+    __syncthreads();
+    if (tid < HD) {
+      for (int g2 = 1; g2 < RG; ++g2) m = fmaxf(m, sred[g2 * HD + tid]);
+      smax[tid] = m;
+    }
+    __syncthreads();
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  float ks = 0.f;                     // this thread's share of sum_r exp(K[r][c] - max[c])
+  const float cm = smax[c];
+  const float* pcol = sP + (4 * lh) * LDP + wi * 32 + lr;
+  const float* vcol = sV + (4 * lh) * LDP + wj * 32 + lr;
+  for (int r0 = 0; r0 < len; r0 += CH) {
+#pragma unroll 4
+    for (int rr = rg; rr < CH; rr += RG) {   // thread owns column c of rows rg, rg + 4, ...
+      const int r = r0 + rr;
+      float p = 0.f, v = 0.f;
+      if (r < len) {
+        p = __expf(Kb[(int64_t)r * ld + c] - cm);
+        v = Vb[(int64_t)r * ld + c];
+      }
+      ks += p;
+      sP[rr * LDP + c] = p;
+      sV[rr * LDP + c] = v;
+    }
+    __syncthreads();
+    const int nk = (min(CH, len - r0) + 7) / 8;   // 8-row groups holding valid rows (the rest are zeros)
+    for (int g = 0; g < nk; ++g) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vcol[(8 * g + j) * LDP], pcol[(8 * g + j) * LDP], acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  sred[tid] = ks;
+  __syncthreads();
+  if (tid < HD) {
+    float t = 0.f;
+    for (int g2 = 0; g2 < RG; ++g2) t += sred[g2 * HD + tid];
+    ssum[tid] = t;
+    float* st = kstat + ((int64_t)blockIdx.x * HD + tid) * 2;
+    st[0] = len > 0 ? smax[tid] : 0.f;
+    st[1] = len > 0 ? t : 1.f;
+  }
+  __syncthreads();
+  // lane holds row (channel c) = wi*32 + lr, columns l = wj*32 + 8q + 4lh + e
+  const int cc = wi * 32 + lr;
+  const float sum = ssum[cc];
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+  float* ap = A + (int64_t)blockIdx.x * HD * HD + cc * HD + wj * 32 + 4 * lh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<float4*>(ap + 8 * q) =
+        make_float4(acc[4 * q] * inv, acc[4 * q + 1] * inv, acc[4 * q + 2] * inv, acc[4 * q + 3] * inv);
+}
+
+// ---------------------------------------------------------------------------------------------
 // apply_bwd: dq = dY A^T, dQ = q * (dq - sum_c q dq);  dA[c][l] = sum_r q[r,c] dY[r,l]
 // grid = (B*H, row chunks): each block owns 64 rows and writes its dA contribution to
 // dApart[(bh * nchunk + chunk)]; chunk_sum_kernel adds the chunks in a fixed order (no atomics:
@@ -489,8 +625,12 @@ extern "C" int hig_linattn_ctx(const float* K, const float* V, int64_t ld, int32
                                hig_stream_t stream) {
   HIG_REQUIRE(K && V && A && kstat && B > 0 && rows > 0 && H > 0, "hig_linattn_ctx: bad arguments");
   HIG_REQUIRE(hd_ok(hd), "hig_linattn: head dim %d not in {8,16,32,64,128}", hd);
-  HD_SWITCH(hd, hipLaunchKernelGGL((ctx_kernel<HDV>), dim3(B * H), dim3(256), 0, hig_stream(stream), K, V,
-                                   ld, rows, H, length, A, kstat));
+  if (hd == 64)
+    hipLaunchKernelGGL(ctx_mfma64_kernel, dim3(B * H), dim3(256), 0, hig_stream(stream), K, V, ld, rows, H, length, A,
+                       kstat);
+  else
+    HD_SWITCH(hd, hipLaunchKernelGGL((ctx_kernel<HDV>), dim3(B * H), dim3(256), 0, hig_stream(stream), K, V,
+                                     ld, rows, H, length, A, kstat));
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
@@ -502,8 +642,12 @@ extern "C" int hig_linattn_apply(const float* Q, int64_t ldq, const float* A, fl
   HIG_REQUIRE(ldq % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0 &&
                   (reinterpret_cast<uintptr_t>(Y) & 15) == 0,
               "hig_linattn_apply: Q/Y must be 16-byte aligned");
-  HD_SWITCH(hd, hipLaunchKernelGGL((apply_kernel<HDV>), dim3(B * H, (rows + CH - 1) / CH), dim3(256), 0,
-                                   hig_stream(stream), Q, ldq, A, Y, ldy, rows, H));
+  if (hd == 64)
+    hipLaunchKernelGGL(apply_mfma64_kernel, dim3(B * H, (rows + CH - 1) / CH), dim3(256), 0, hig_stream(stream), Q, ldq,
+                       A, Y, ldy, rows, H);
+  else
+    HD_SWITCH(hd, hipLaunchKernelGGL((apply_kernel<HDV>), dim3(B * H, (rows + CH - 1) / CH), dim3(256), 0,
+                                     hig_stream(stream), Q, ldq, A, Y, ldy, rows, H));
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
