@@ -24,6 +24,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef HIG_GEMM_NT
+#define HIG_GEMM_NT 1
+#endif
 
 namespace {
 
@@ -96,6 +99,18 @@ __device__ __forceinline__ float4 ld_rc_fast(const float* base, int64_t ld, int 
 }
 __device__ __forceinline__ float4 ld_rs_fast(const float* base, int64_t ld, int i, int nrows, int k) {
   return *reinterpret_cast<const float4*>(base + (int64_t)k * ld + min(i, nrows - 4));
+}
+
+// Output tiles are written once and read by a LATER kernel: a non-temporal 16-byte store keeps them
+// from evicting the X row panels / W that the other column tiles of this XCD still re-read from L2
+// (HIG_GEMM_NT=0 restores plain stores; measured in profiles/r01_notes.md).
+__device__ __forceinline__ void st_stream(float* p, const float (&v)[4]) {
+  const f32x4 x = {v[0], v[1], v[2], v[3]};
+#if HIG_GEMM_NT
+  __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<f32x4*>(p) = x;
+#endif
 }
 
 // FAST = every operand 16-byte aligned and the reduce extent a multiple of BK: the tile fetch
@@ -499,7 +514,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
           if (g.aux) {
             float* ap = g.aux + (int64_t)i * g.ldaux + j;
             if (full) {
-              *reinterpret_cast<float4*>(ap) = make_float4(v[0], v[1], v[2], v[3]);
+              st_stream(ap, v);
             } else {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
@@ -517,7 +532,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
         }
         float* cp = C + (int64_t)i * g.ldc + j;
         if (full) {
-          *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+          st_stream(cp, v);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)

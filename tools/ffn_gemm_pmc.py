@@ -10,9 +10,11 @@ from tools.gemm_bench import run  # noqa: E402
 from hig_amd import _lib  # noqa: E402
 
 if __name__ == "__main__":
-    # evict: stream 1 GiB through the caches so the GEMM reads from HBM, not the 256 MiB MALL
-    junk = torch.empty(256 << 20, device="cuda")
-    for _ in range(3):
-        junk.fill_(1.0)
-        ms, tf = run(12544, 1024, 512, _lib.XF_NONE, _lib.EPI_BIAS_GELU, reps=1)
+    # evict with a READ sweep of 1 GiB: the caches end up full of CLEAN junk lines, so the GEMM reads from
+    # HBM (not the 256 MiB MALL) and no write-back of somebody else's dirty lines is billed to it
+    junk = torch.ones(256 << 20, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(6):     # every profiled launch starts cold: one GEMM per sweep, no warm-up launches
+        junk.sum().item()
+        ms, tf = run(12544, 1024, 512, _lib.XF_NONE, _lib.EPI_BIAS_GELU, reps=1, warm=0)
     print("ffn1 %.3f ms %.1f TF" % (ms, tf))

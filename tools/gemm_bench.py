@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hig_amd import _lib  # noqa: E402
 
 
-def run(M, N, K, xf, epi, reps=20):
+def run(M, N, K, xf, epi, reps=20, warm=3):
     dev = "cuda"
     X = torch.randn(M, K, device=dev)
     W = torch.randn(N, K, device=dev) * 0.05
@@ -31,7 +31,7 @@ def run(M, N, K, xf, epi, reps=20):
     d.stats, d.gamma, d.beta = st.data_ptr(), g.data_ptr(), be.data_ptr()
     d.ss, d.ss_ld, d.ss_shift_off, d.rows_per_sample = ss.data_ptr(), 2 * K, K, 196
     L = _lib.lib()
-    for _ in range(3):
+    for _ in range(warm):
         _lib.check(L.hig_gemm(C.byref(d), _lib.stream_ptr()))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
