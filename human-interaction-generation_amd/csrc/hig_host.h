@@ -1,5 +1,6 @@
 // Host-side helpers shared by the orchestration translation units (denoiser.hip, texthead.hip).
 #pragma once
+#include <stdlib.h>
 #include <string.h>
 
 #include "hig_common.h"
@@ -34,11 +35,14 @@ struct G {  // small builder for gemm descriptors
   }
 };
 
-// Split the reduce range of a weight-gradient GEMM so ~768 workgroups are in flight.
+// Split the reduce range of a weight-gradient GEMM so that tiles x splits fills, but does not exceed, the
+// 512 workgroups that are resident at once (2 per CU: 64 KB of LDS each) -- one more would start a second,
+// nearly empty round (768 in flight cost the training step 0.6 ms; profiles/r01_notes.md).
 inline int wgrad_splits(int64_t I, int64_t J, int64_t R, int64_t slab_floats) {
   const int bi = (I > 64 && J > 64) ? 128 : 64;
   const int64_t tiles = ((I + bi - 1) / bi) * ((J + bi - 1) / bi);
-  int64_t s = (768 + tiles - 1) / tiles;
+  static const int target = getenv("HIG_WGRAD_TARGET") ? atoi(getenv("HIG_WGRAD_TARGET")) : 512;  // tuning knob
+  int64_t s = target / tiles;
   const int64_t maxs = R / 256 > 1 ? R / 256 : 1;
   if (s > maxs) s = maxs;
   while (s > 1 && s * I * J > slab_floats) --s;
