@@ -30,7 +30,7 @@ SYMBOLS = (
     "hig_timestep_embedding", "hig_q_sample", "hig_p_sample_step", "hig_dec_timesteps",
     "hig_masked_mse", "hig_sumsq_partial", "hig_clip_adam",
     "hig_text_head_workspace_bytes", "hig_text_head_bwd_workspace_bytes", "hig_text_head_fwd", "hig_text_head_bwd",
-    "hig_layernorm", "hig_gather_rows", "hig_scatter_add_rows", "hig_gather_frames", "hig_recover_joints",
+    "hig_layernorm", "hig_gather_rows", "hig_scatter_add_rows", "hig_gather_frames", "hig_recover_joints", "hig_transpose_batch",
 )
 
 
@@ -122,6 +122,7 @@ def lib():
         L.hig_layernorm.argtypes = [vp, i64, i64, i32, vp, vp, vp, i64, vp, vp]
         L.hig_gather_rows.argtypes = [vp, i64, i32, i32, vp, i32, vp, i64, vp]
         L.hig_scatter_add_rows.argtypes = [vp, i64, i32, i32, vp, i32, vp, i64, vp]
+        L.hig_transpose_batch.argtypes = [i32, vp, vp, vp, vp, vp]
         L.hig_recover_joints.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
         L.hig_gather_frames.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
         _lib = L

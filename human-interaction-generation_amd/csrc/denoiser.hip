@@ -472,9 +472,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                 o_sty2 = o_w1t + (int64_t)d * ff, o_caq = o_sty2 + (int64_t)d * d, o_kv = o_caq + (int64_t)d * d,
                 o_sty1 = o_kv + (int64_t)2 * d * Lt, o_qkv = o_sty1 + (int64_t)d * d,
                 o_isty = o_qkv + (int64_t)3 * d * d, o_iqkv = o_isty + (int64_t)d * d;
-  auto wtrans = [&](const float* W, int out_f, int in_f, int64_t off) -> int {
-    return hig_transpose(W, in_f, out_f, in_f, wT + off, out_f, nullptr, nullptr, nullptr, stream);
-  };
+  constexpr int TRB_N = 12;
   auto colsum = [&](const float* src, int64_t ld, int64_t rows, int n, float* dst) -> int {
     return hig_colsum(src, ld, rows, n, dst, colp, stream);
   };
@@ -518,17 +516,27 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
   for (int l = D.L - 1; l >= 0; --l) {
     const float* lb = ws + w.layer0 + w.lstride * l;
     const float* hin = l == 0 ? ws + w.h0 : ws + w.layer0 + w.lstride * (l - 1) + w.h3;
-    HIG_TRY(wtrans(PL(params, l, HIG_L_FFN_STY_OUT_W), d, d, o_sty3));
-    HIG_TRY(wtrans(PL(params, l, HIG_L_FFN_W2), d, ff, o_w2t));
-    HIG_TRY(wtrans(PL(params, l, HIG_L_FFN_W1), ff, d, o_w1t));
-    HIG_TRY(wtrans(PL(params, l, HIG_L_CA_STY_OUT_W), d, d, o_sty2));
-    HIG_TRY(wtrans(PL(params, l, HIG_L_CA_Q_W), d, d, o_caq));
-    HIG_TRY(wtrans(PL(params, l, HIG_L_CA_KV_W), 2 * d, Lt, o_kv));
-    HIG_TRY(wtrans(PL(params, l, HIG_L_SA_STY_OUT_W), d, d, o_sty1));
-    HIG_TRY(wtrans(PL(params, l, HIG_L_SA_QKV_W), 3 * d, d, o_qkv));
-    if (D.two == 1) {
-      HIG_TRY(wtrans(PL(params, l, HIG_L_INT_STY_OUT_W), d, d, o_isty));
-      HIG_TRY(wtrans(PL(params, l, HIG_L_INT_QKV_W), 3 * d, d, o_iqkv));
+    {  // all W -> W^T copies of this layer in one launch
+      const float* srcs[TRB_N];
+      float* dsts[TRB_N];
+      int32_t rws[TRB_N], cls[TRB_N];
+      int n = 0;
+      auto add = [&](int idx, int out_f, int in_f, int64_t off) {
+        srcs[n] = PL(params, l, idx); dsts[n] = wT + off; rws[n] = out_f; cls[n] = in_f; ++n;
+      };
+      add(HIG_L_FFN_STY_OUT_W, d, d, o_sty3);
+      add(HIG_L_FFN_W2, d, ff, o_w2t);
+      add(HIG_L_FFN_W1, ff, d, o_w1t);
+      add(HIG_L_CA_STY_OUT_W, d, d, o_sty2);
+      add(HIG_L_CA_Q_W, d, d, o_caq);
+      add(HIG_L_CA_KV_W, 2 * d, Lt, o_kv);
+      add(HIG_L_SA_STY_OUT_W, d, d, o_sty1);
+      add(HIG_L_SA_QKV_W, 3 * d, d, o_qkv);
+      if (D.two == 1) {
+        add(HIG_L_INT_STY_OUT_W, d, d, o_isty);
+        add(HIG_L_INT_QKV_W, 3 * d, d, o_iqkv);
+      }
+      HIG_TRY(hig_transpose_batch(n, srcs, dsts, rws, cls, stream));
     }
     const float* hffn = D.two == 1 ? lb + w.h2b : lb + w.h2;
     // ---- FFN --------------------------------------------------------------------------

@@ -347,6 +347,38 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
   }
 }
 
+// Several dense transposes in ONE launch (all the W -> W^T of a decoder layer's backward: eight to ten
+// 1-4 MB matrices cost ~10 us each as separate launches, mostly launch + tail).  The descriptors travel
+// by value in the kernel arguments; block -> (matrix, 64x64 tile) through a prefix table.
+constexpr int TRB_MAX = 12;
+struct TrBatch {
+  const float* src[TRB_MAX];
+  float* dst[TRB_MAX];
+  int rows[TRB_MAX], cols[TRB_MAX];
+  int tile0[TRB_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const TrBatch b) {
+  __shared__ float tile[64][65];
+  int m = 0;
+  while (m + 1 < b.n && (int)blockIdx.x >= b.tile0[m + 1]) ++m;
+  const int rows = b.rows[m], cols = b.cols[m];
+  const int lt = blockIdx.x - b.tile0[m], tcn = (cols + 63) / 64;
+  const int c0 = (lt % tcn) * 64, r0 = (lt / tcn) * 64;
+  const float* __restrict__ src = b.src[m];
+  float* __restrict__ dst = b.dst[m];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? src[(int64_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) dst[(int64_t)c * rows + r] = tile[tx][i];
+  }
+}
+
 __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int B, int d,
                                           float* __restrict__ out) {
   const int half = d / 2;
@@ -540,6 +572,26 @@ extern "C" int hig_transpose(const float* src, int64_t ld, int32_t rows, int32_t
     hipLaunchKernelGGL((transpose_kernel<false>), grid, dim3(256), 0, hig_stream(stream), src, ld, rows, cols, dst,
                        ldd, stats, gamma, beta);
   }
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+extern "C" int hig_transpose_batch(int32_t n, const float* const* srcs, float* const* dsts, const int32_t* rows,
+                                   const int32_t* cols, hig_stream_t stream) {
+  HIG_REQUIRE(n >= 0 && n <= TRB_MAX && (n == 0 || (srcs && dsts && rows && cols)),
+              "hig_transpose_batch: 0 <= n <= %d matrices", TRB_MAX);
+  if (n == 0) return HIG_OK;
+  TrBatch b;
+  b.n = n;
+  int t = 0;
+  for (int m = 0; m < n; ++m) {
+    HIG_REQUIRE(srcs[m] && dsts[m] && rows[m] > 0 && cols[m] > 0, "hig_transpose_batch: bad matrix %d", m);
+    b.src[m] = srcs[m]; b.dst[m] = dsts[m]; b.rows[m] = rows[m]; b.cols[m] = cols[m];
+    b.tile0[m] = t;
+    t += ((rows[m] + 63) / 64) * ((cols[m] + 63) / 64);
+  }
+  b.tile0[n] = t;
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(t), dim3(256), 0, hig_stream(stream), b);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

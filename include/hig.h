@@ -343,6 +343,11 @@ int64_t hig_ln_bwd_partial_floats(int64_t rows, int32_t n, int32_t rows_per_samp
 int hig_transpose(const float* src, int64_t ld, int32_t rows, int32_t cols, float* dst, int64_t ldd,
                   const float* stats, const float* gamma, const float* beta, hig_stream_t stream);
 
+/* n <= 12 dense transposes in one launch: dsts[m] (cols x rows) = srcs[m] (rows x cols)^T.  The pointer
+ * and extent arrays are HOST arrays read before return (the W -> W^T copies of one layer's backward). */
+int hig_transpose_batch(int32_t n, const float* const* srcs, float* const* dsts, const int32_t* rows,
+                        const int32_t* cols, hig_stream_t stream);
+
 /* out[j] = sum_i x[i][j]  (bias gradients).  partial: [hig_colsum_chunks(rows)][n] floats
  * (at most HIG_COLSUM_CHUNKS row chunks). */
 #define HIG_COLSUM_CHUNKS 512

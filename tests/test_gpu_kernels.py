@@ -431,3 +431,21 @@ def test_clip_adam_matches_torch():
         assert abs(gn.item() - tot.item()) < 1e-5 * tot.item()
         assert rel(p, ref.data) < 1e-6
     assert step.item() == 3
+
+
+def test_transpose_batch_matches_torch():
+    """Several W -> W^T copies in one launch (ragged extents, up to 12 matrices)."""
+    import ctypes as C
+    shapes = [(512, 512), (1024, 512), (150, 512), (70, 33), (1, 5), (1536, 512), (64, 64)]
+    src = [torch.randn(r, c, device=DEV) for r, c in shapes]
+    dst = [torch.full((c, r), float("nan"), device=DEV) for r, c in shapes]
+    n = len(shapes)
+    srcs = (C.c_void_p * n)(*[t.data_ptr() for t in src])
+    dsts = (C.c_void_p * n)(*[t.data_ptr() for t in dst])
+    rows = (C.c_int32 * n)(*[r for r, _ in shapes])
+    cols = (C.c_int32 * n)(*[c for _, c in shapes])
+    _lib.check(_lib.lib().hig_transpose_batch(n, srcs, dsts, rows, cols, _lib.stream_ptr()))
+    for a, b in zip(src, dst):
+        assert torch.equal(b, a.t())
+    with pytest.raises(RuntimeError, match="matrices"):
+        _lib.check(_lib.lib().hig_transpose_batch(13, srcs, dsts, rows, cols, _lib.stream_ptr()))
