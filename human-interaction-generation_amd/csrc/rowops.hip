@@ -246,8 +246,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
 
 // out[c] = sum_{r<nr} in[(r*rstride) + c]  (column reduction of small partial tables).
 // 64 columns x 16 row lanes per block; 4 independent accumulators keep 4 loads in flight.
+// Columns [0, n_first) go to `out`, columns [n_first, n) to `out2` (two gradients from one partial table).
 __global__ __launch_bounds__(1024) void colreduce_kernel(const float* __restrict__ in, int nr,
-                                                         int64_t rstride, int n, float* __restrict__ out) {
+                                                         int64_t rstride, int n, float* __restrict__ out,
+                                                         int n_first = 1 << 30, float* __restrict__ out2 = nullptr) {
   __shared__ float red[16][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(1024) void colreduce_kernel(const float* __restrict
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][cx];
-    out[c] = t;
+    if (c < n_first) out[c] = t; else out2[c - n_first] = t;
   }
 }
 // dss[b][c] = sum_s partial[b][s][2][c];  dss[b][shift_off + c] = sum_s partial[b][s][3][c]
@@ -521,14 +523,17 @@ extern "C" int hig_ln_bwd(const float* da, int64_t ldda, const float* x, int64_t
 #undef LNB
   HIG_CHECK_LAUNCH();
   const int tb = 128;
-  if (dgamma) {
-    hipLaunchKernelGGL(colreduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial,
-                       samples * nsplit, (int64_t)4 * n, n, dgamma);
+  if (dgamma && dbeta) {   // partial rows are [dgamma n | dbeta n | ...]: both in one launch
+    hipLaunchKernelGGL(colreduce_kernel, dim3((2 * n + 63) / 64), dim3(1024), 0, st, partial,
+                       samples * nsplit, (int64_t)4 * n, 2 * n, dgamma, n, dbeta);
     HIG_CHECK_LAUNCH();
-  }
-  if (dbeta) {
+  } else if (dgamma) {
+    hipLaunchKernelGGL(colreduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial,
+                       samples * nsplit, (int64_t)4 * n, n, dgamma, 1 << 30, (float*)nullptr);
+    HIG_CHECK_LAUNCH();
+  } else if (dbeta) {
     hipLaunchKernelGGL(colreduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial + n,
-                       samples * nsplit, (int64_t)4 * n, n, dbeta);
+                       samples * nsplit, (int64_t)4 * n, n, dbeta, 1 << 30, (float*)nullptr);
     HIG_CHECK_LAUNCH();
   }
   if (mod_silu) {
