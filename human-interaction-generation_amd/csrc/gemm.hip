@@ -25,7 +25,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef HIG_GEMM_NT
-#define HIG_GEMM_NT 1
+#define HIG_GEMM_NT 0
 #endif
 
 namespace {
@@ -101,9 +101,10 @@ __device__ __forceinline__ float4 ld_rs_fast(const float* base, int64_t ld, int 
   return *reinterpret_cast<const float4*>(base + (int64_t)k * ld + min(i, nrows - 4));
 }
 
-// Output tiles are written once and read by a LATER kernel: a non-temporal 16-byte store keeps them
-// from evicting the X row panels / W that the other column tiles of this XCD still re-read from L2
-// (HIG_GEMM_NT=0 restores plain stores; measured in profiles/r01_notes.md).
+// Output tile store.  -DHIG_GEMM_NT=1 makes it non-temporal: that keeps the tile from evicting the X row
+// panels / W the other column tiles of the XCD re-read (FFN1 fetch 61 -> 43 MB), but the NEXT kernel then
+// finds its input in the Infinity Cache instead of L2, and the whole path gets slower (forward 7.26 ->
+// 7.38 ms, bf16 products 3.9 -> 5.0 ms; profiles/r01_notes.md) -- so plain stores are the default.
 __device__ __forceinline__ void st_stream(float* p, const float (&v)[4]) {
   const f32x4 x = {v[0], v[1], v[2], v[3]};
 #if HIG_GEMM_NT
