@@ -607,6 +607,195 @@ __global__ __launch_bounds__(256) void ctx_bwd_finish_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// hd = 64 backward kernels on the matrix cores (same grids, outputs and scratch as the VALU versions
+// above; 4 waves = the 2 x 2 grid of 32 x 32 blocks of each 64 x 64 product, lane layout as in
+// apply_mfma64_kernel: row = w_i*32 + (lane & 31), columns = w_j*32 + 8q + 4*(lane >> 5) + e).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void zero16(f32x16& a) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) a[e] = 0.f;
+}
+// acc += X . Y^T with X[row][k] and Y[col][k] both k-contiguous tiles ([.][LDP]): 8 k-groups of 8
+__device__ __forceinline__ void mma_rc_rc(f32x16& acc, const float* xrow, const float* yrow) {
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const float4 x4 = *reinterpret_cast<const float4*>(xrow + 8 * ks);
+    const float4 y4 = *reinterpret_cast<const float4*>(yrow + 8 * ks);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y4.x, x4.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y4.y, x4.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y4.z, x4.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y4.w, x4.w, acc, 0, 0, 0);
+  }
+}
+// acc += X . Y^T with X[row][k] k-contiguous and Y given k-major (ycol -> element [k][col], stride LDP)
+__device__ __forceinline__ void mma_rc_rs(f32x16& acc, const float* xrow, const float* ycol, int ldp) {
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const float4 x4 = *reinterpret_cast<const float4*>(xrow + 8 * ks);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ycol[(8 * ks + 0) * ldp], x4.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ycol[(8 * ks + 1) * ldp], x4.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ycol[(8 * ks + 2) * ldp], x4.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ycol[(8 * ks + 3) * ldp], x4.w, acc, 0, 0, 0);
+  }
+}
+// acc += X^T . Y with both tiles k-major (xcol -> [k][row], ycol -> [k][col])
+__device__ __forceinline__ void mma_rs_rs(f32x16& acc, const float* xcol, const float* ycol, int ldp) {
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ycol[(8 * ks + j) * ldp], xcol[(8 * ks + j) * ldp], acc, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void apply_bwd_mfma64_kernel(const float* __restrict__ dY, int64_t lddy,
+                                                               const float* __restrict__ Q, int64_t ldq,
+                                                               const float* __restrict__ A,
+                                                               float* __restrict__ dQ, int64_t lddq,
+                                                               float* __restrict__ dApart, int rows, int H) {
+  constexpr int HD = 64, LDP = HD + 4;
+  __shared__ __attribute__((aligned(16))) float sA[HD * LDP];   // [c][l]
+  __shared__ __attribute__((aligned(16))) float sQ[CH * LDP];   // softmax(Q) [r][c]
+  __shared__ __attribute__((aligned(16))) float sD[CH * LDP];   // dY [r][l]
+  __shared__ float srow[2][CH];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int r0 = blockIdx.y * CH;
+  const float* Ab = A + (int64_t)blockIdx.x * HD * HD;
+  for (int idx = tid; idx < HD * HD / 4; idx += 256) {
+    const int c = idx / (HD / 4), l4 = idx % (HD / 4);
+    *reinterpret_cast<float4*>(sA + c * LDP + 4 * l4) = reinterpret_cast<const float4*>(Ab)[idx];
+  }
+  load_tile<HD>(Q + (int64_t)b * rows * ldq + h * HD, ldq, r0, rows, sQ);
+  load_tile<HD>(dY + (int64_t)b * rows * lddy + h * HD, lddy, r0, rows, sD);
+  __syncthreads();
+  row_softmax_tile<HD>(sQ);
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
+  // dq_pre[r][c] = sum_l dY[r][l] A[c][l]
+  f32x16 dq;
+  zero16(dq);
+  mma_rc_rc(dq, sD + (wi * 32 + lr) * LDP + 4 * lh, sA + (wj * 32 + lr) * LDP + 4 * lh);
+  // dA[c][l] = sum_r q[r][c] dY[r][l]
+  f32x16 da;
+  zero16(da);
+  mma_rs_rs(da, sQ + (4 * lh) * LDP + wi * 32 + lr, sD + (4 * lh) * LDP + wj * 32 + lr, LDP);
+  {
+    float* dAb = dApart + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * HD * HD + (wi * 32 + lr) * HD + wj * 32 + 4 * lh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(dAb + 8 * q) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
+  }
+  // softmax Jacobian over the 64 channels of a row: the row lives in 2 lanes (lh) x 2 waves (wj)
+  const int rl = wi * 32 + lr;
+  float4 qv[4];
+  float part = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    qv[q] = *reinterpret_cast<const float4*>(sQ + rl * LDP + wj * 32 + 8 * q + 4 * lh);
+    part += qv[q].x * dq[4 * q] + qv[q].y * dq[4 * q + 1] + qv[q].z * dq[4 * q + 2] + qv[q].w * dq[4 * q + 3];
+  }
+  part += __shfl_xor(part, 32, 64);
+  if (lh == 0) srow[wj][rl] = part;
+  __syncthreads();
+  const float sdot = srow[0][rl] + srow[1][rl];
+  const int r = r0 + rl;
+  if (r < rows) {
+    float* op = dQ + ((int64_t)b * rows + r) * lddq + h * HD + wj * 32 + 4 * lh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(op + 8 * q) =
+          make_float4(qv[q].x * (dq[4 * q] - sdot), qv[q].y * (dq[4 * q + 1] - sdot), qv[q].z * (dq[4 * q + 2] - sdot),
+                      qv[q].w * (dq[4 * q + 3] - sdot));
+  }
+}
+
+__global__ __launch_bounds__(256) void ctx_bwd_mfma64_kernel(const float* __restrict__ dA, const float* __restrict__ K,
+                                                             const float* __restrict__ V, int64_t ld,
+                                                             const float* __restrict__ kstat,
+                                                             const int64_t* __restrict__ length,
+                                                             float* __restrict__ dK, float* __restrict__ dV, int64_t ldd,
+                                                             int rows, int H, float* __restrict__ colpart) {
+  constexpr int HD = 64, LDP = HD + 4;
+  __shared__ __attribute__((aligned(16))) float sdA[HD * LDP];   // [c][l]
+  __shared__ __attribute__((aligned(16))) float sK[CH * LDP];    // k (normalised) [r][c]
+  __shared__ __attribute__((aligned(16))) float sV[CH * LDP];    // [r][l]; later k * dk [r][c]
+  __shared__ float smax[HD], sinv[HD];
+  __shared__ float swsum[4][HD];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  int len = rows;
+  if (length) len = (int)min<int64_t>(max<int64_t>(length[b], 0), rows);
+  const float* dAb = dA + (int64_t)blockIdx.x * HD * HD;
+  for (int idx = tid; idx < HD * HD / 4; idx += 256) {
+    const int c = idx / (HD / 4), l4 = idx % (HD / 4);
+    *reinterpret_cast<float4*>(sdA + c * LDP + 4 * l4) = reinterpret_cast<const float4*>(dAb)[idx];
+  }
+  if (tid < HD) {
+    const float* st = kstat + ((int64_t)blockIdx.x * HD + tid) * 2;
+    smax[tid] = st[0];
+    sinv[tid] = 1.0f / st[1];
+  }
+  const float* Kb = K + (int64_t)b * rows * ld + h * HD;
+  const float* Vb = V + (int64_t)b * rows * ld + h * HD;
+  const int r0 = blockIdx.y * CH;
+  __syncthreads();
+  for (int idx = tid; idx < CH * HD; idx += 256) {
+    const int rr = idx / HD, cc = idx % HD, r = r0 + rr;
+    float kk = 0.f, v = 0.f;
+    if (r < len) {
+      kk = __expf(Kb[(int64_t)r * ld + cc] - smax[cc]) * sinv[cc];
+      v = Vb[(int64_t)r * ld + cc];
+    }
+    sK[rr * LDP + cc] = kk;
+    sV[rr * LDP + cc] = v;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
+  const int rl = wi * 32 + lr;
+  // dV[r][l] = sum_c k[r][c] dA[c][l]
+  f32x16 dv;
+  zero16(dv);
+  mma_rc_rs(dv, sK + rl * LDP + 4 * lh, sdA + (4 * lh) * LDP + wj * 32 + lr, LDP);
+  // dk[r][c] = sum_l V[r][l] dA[c][l]
+  f32x16 dk;
+  zero16(dk);
+  mma_rc_rc(dk, sV + rl * LDP + 4 * lh, sdA + (wj * 32 + lr) * LDP + 4 * lh);
+  const int r = r0 + rl;
+  if (r < rows) {   // rows in [len, rows) carry k == 0 and V == 0 in LDS, so both products are exact zeros
+    float* kp = dK + ((int64_t)b * rows + r) * ldd + h * HD + wj * 32 + 4 * lh;
+    float* vp = dV + ((int64_t)b * rows + r) * ldd + h * HD + wj * 32 + 4 * lh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<float4*>(kp + 8 * q) = make_float4(dk[4 * q], dk[4 * q + 1], dk[4 * q + 2], dk[4 * q + 3]);
+      *reinterpret_cast<float4*>(vp + 8 * q) = make_float4(dv[4 * q], dv[4 * q + 1], dv[4 * q + 2], dv[4 * q + 3]);
+    }
+  }
+  __syncthreads();   // every wave is done reading sV
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {   // k * dk into sV ([r][c]) for the column sums of this chunk
+    const int c = wj * 32 + 8 * q + 4 * lh;
+    const float4 k4 = *reinterpret_cast<const float4*>(sK + rl * LDP + c);
+    *reinterpret_cast<float4*>(sV + rl * LDP + c) =
+        make_float4(k4.x * dk[4 * q], k4.y * dk[4 * q + 1], k4.z * dk[4 * q + 2], k4.w * dk[4 * q + 3]);
+  }
+  __syncthreads();
+  {
+    const int c = tid % HD, rg = tid / HD;
+    float t = 0.f;
+#pragma unroll
+    for (int rr = rg; rr < CH; rr += 4) t += sV[rr * LDP + c];
+    swsum[rg][c] = t;
+  }
+  __syncthreads();
+  if (tid < HD)
+    colpart[((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * HD + tid] =
+        (swsum[0][tid] + swsum[1][tid]) + (swsum[2][tid] + swsum[3][tid]);
+}
+
 bool hd_ok(int hd) { return hd == 8 || hd == 16 || hd == 32 || hd == 64 || hd == 128; }
 
 #define HD_SWITCH(hd, STMT)                  \
@@ -668,8 +857,12 @@ extern "C" int hig_linattn_apply_bwd(const float* dY, int64_t lddy, const float*
                   (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(dQ) & 15) == 0,
               "hig_linattn_apply_bwd: Q/dY/dQ must be 16-byte aligned");
   const int nchunk = (rows + CH - 1) / CH;
-  HD_SWITCH(hd, hipLaunchKernelGGL((apply_bwd_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream),
-                                   dY, lddy, Q, ldq, A, dQ, lddq, scratch, rows, H));
+  if (hd == 64)
+    hipLaunchKernelGGL(apply_bwd_mfma64_kernel, dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream), dY, lddy, Q, ldq,
+                       A, dQ, lddq, scratch, rows, H);
+  else
+    HD_SWITCH(hd, hipLaunchKernelGGL((apply_bwd_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream),
+                                     dY, lddy, Q, ldq, A, dQ, lddq, scratch, rows, H));
   HIG_CHECK_LAUNCH();
   const int64_t n = (int64_t)hd * hd, groups = (int64_t)B * H;
   const int64_t want = (groups * n / 4 + 255) / 256;
@@ -689,8 +882,12 @@ extern "C" int hig_linattn_ctx_bwd(const float* dA, const float* K, const float*
   HIG_REQUIRE(ldd % 4 == 0 && (reinterpret_cast<uintptr_t>(dK) & 15) == 0 && (reinterpret_cast<uintptr_t>(dV) & 15) == 0,
               "hig_linattn_ctx_bwd: dK/dV must be 16-byte aligned");
   const int nchunk = (rows + CH - 1) / CH;
-  HD_SWITCH(hd, hipLaunchKernelGGL((ctx_bwd_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream), dA,
-                                   K, V, ld, kstat, length, dK, dV, ldd, rows, H, scratch));
+  if (hd == 64)
+    hipLaunchKernelGGL(ctx_bwd_mfma64_kernel, dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream), dA, K, V, ld, kstat,
+                       length, dK, dV, ldd, rows, H, scratch);
+  else
+    HD_SWITCH(hd, hipLaunchKernelGGL((ctx_bwd_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream), dA,
+                                     K, V, ld, kstat, length, dK, dV, ldd, rows, H, scratch));
   HIG_CHECK_LAUNCH();
   HD_SWITCH(hd, hipLaunchKernelGGL((ctx_bwd_finish_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0,
                                    hig_stream(stream), K, ld, kstat, length, dK, ldd, rows, H, scratch));
