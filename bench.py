@@ -320,6 +320,29 @@ def main():
                 "fwd_bwd_frames_per_s": round(c2["B"] * c2["T"] * k2 / e_fb, 1), "fwd_bwd_ms": round(e_fb / k2 * 1e3, 3),
                 "what": "MotionInteractionTransformer, 32 pairs (model batch 64) x 91 tokens x 263 features, d=512 L=8, "
                         "f32 products; frames = person-tokens"}
+            # ---- BASELINE config 5 shape: long sequence, wide model (hd = 128), bf16 products ----
+            c5 = dict(c, B=32, T=300, d=1024, L=12, H=8, ff=1024)
+            m5 = build_model(c5, device).eval()
+            i5 = make_inputs(c5, device, rank)
+
+            def fwd5():
+                with torch.no_grad():
+                    return m5(i5["x"], i5["t"], length=i5["length"], xf_proj=i5["xf_proj"], xf_out=i5["xf_out"])
+
+            r5 = {}
+            for mode in ("f32", "bf16"):
+                m5.precision = mode
+                e5 = timed(fwd5, 5, 2, 1)
+                r5[mode] = (e5 / 5 * 1e3, fwd5().double())
+            extra["config5_long_sequence"] = {
+                "fwd_ms_f32": round(r5["f32"][0], 3), "fwd_ms_bf16": round(r5["bf16"][0], 3),
+                "frames_per_s_bf16": round(c5["B"] * c5["T"] / r5["bf16"][0] * 1e3, 1),
+                "fwd_tflops_f32": round(flops_per_frame_fwd(c5) * c5["B"] * c5["T"] / r5["f32"][0] / 1e9, 1),
+                "rel_l2_bf16_vs_f32": float("%.2e" % ((r5["bf16"][1] - r5["f32"][1]).norm() / r5["f32"][1].norm()).item()),
+                "what": "MotionTransformer forward B=32 T=300 d=1024 L=12 H=8 (head dim 128) ff=1024: f32 and bf16 products, "
+                        "fp32 storage"}
+            del m5, i5, r5
+            torch.cuda.empty_cache()
             # ---- text head: encode_text after CLIP, fwd+bwd, HIP vs stock torch ops ----
             caps = ["a person walks towards another person and shakes hands number %d" % i for i in range(B)]
             th = {}

@@ -214,21 +214,40 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ Q,
 }
 
 // ---------------------------------------------------------------------------------------------
-// hd = 64 forward kernels on the matrix cores.  The 64 x 64 contractions are small GEMMs; on the
-// VALU they were LDS-read bound (8 ds_read_b32 per 16 FMAs), 30 / 42 us per launch at config 2
-// against ~12 us of HBM time.  v_mfma_f32_32x32x2_f32: 4 waves = the 2 x 2 grid of 32 x 32 output
-// blocks; operand k order inside an 8-group is k = 8*ks + 4*(lane>>5) + j for both operands (as in
-// gemm.hip), the MFMA "row" operand is the one indexed by the OUTPUT COLUMN so that a lane ends up
-// with 4 consecutive output columns per accumulator quad (16-byte stores).
+// hd = 64 / 128 forward kernels on the matrix cores.  The hd x hd contractions are small GEMMs; on
+// the VALU they were LDS-read bound (hd = 64: 30 / 42 us per launch at config 2 against ~12 us of HBM
+// time; hd = 128: 127 / 110 us at config 5).  v_mfma_f32_32x32x2_f32: 4 waves in a 2 x 2 grid, each
+// owning (rows/2) x (cols/2) of the product as 32 x 32 accumulator blocks; operand k order inside an
+// 8-group is k = 8*ks + 4*(lane>>5) + j for both operands (as in gemm.hip); the MFMA "row" operand is
+// the one indexed by the OUTPUT COLUMN so that a lane ends up with 4 consecutive output columns per
+// accumulator quad (16-byte stores): row = base_i + (lane & 31), columns = base_j + 8q + 4*(lane>>5) + e.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+__device__ __forceinline__ void zero16(f32x16& a) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) a[e] = 0.f;
+}
+__device__ __forceinline__ f32x16 mfma4(f32x16 acc, float y0, float y1, float y2, float y3, float4 x) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, x.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y1, x.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y2, x.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y3, x.w, acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ void store16(float* p, const f32x16& a, float scale = 1.0f) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<float4*>(p + 8 * q) =
+        make_float4(a[4 * q] * scale, a[4 * q + 1] * scale, a[4 * q + 2] * scale, a[4 * q + 3] * scale);
+}
+
 // Y tile (64 rows) = softmax_c(Q tile) . A[b,h]
-__global__ __launch_bounds__(256) void apply_mfma64_kernel(const float* __restrict__ Q, int64_t ldq,
-                                                           const float* __restrict__ A,
-                                                           float* __restrict__ Y, int64_t ldy, int rows,
-                                                           int H) {
-  constexpr int HD = 64, LDP = HD + 4;
+template <int HD>
+__global__ __launch_bounds__(256) void apply_mfma_kernel(const float* __restrict__ Q, int64_t ldq,
+                                                         const float* __restrict__ A,
+                                                         float* __restrict__ Y, int64_t ldy, int rows, int H) {
+  constexpr int LDP = HD + 4, TJ = HD / 64;
   __shared__ __attribute__((aligned(16))) float sA[HD * HD];    // [c][l]: reduce index major
   __shared__ __attribute__((aligned(16))) float sQ[CH * LDP];   // [row][c]
   const int tid = threadIdx.x;
@@ -243,36 +262,35 @@ __global__ __launch_bounds__(256) void apply_mfma64_kernel(const float* __restri
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
-  f32x16 acc;
+  f32x16 acc[TJ];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int tj = 0; tj < TJ; ++tj) zero16(acc[tj]);
   const float* qrow = sQ + (wi * 32 + lr) * LDP + 4 * lh;
-  const float* acol = sA + (4 * lh) * HD + wj * 32 + lr;
-#pragma unroll
+  const float* acol = sA + (4 * lh) * HD + wj * (HD / 2) + lr;
+#pragma unroll 4
   for (int ks = 0; ks < HD / 8; ++ks) {
     const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * ks);
-    const float a0 = acol[(8 * ks + 0) * HD], a1 = acol[(8 * ks + 1) * HD], a2 = acol[(8 * ks + 2) * HD],
-                a3 = acol[(8 * ks + 3) * HD];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q4.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q4.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, q4.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, q4.w, acc, 0, 0, 0);
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const float* ap = acol + (8 * ks) * HD + 32 * tj;
+      acc[tj] = mfma4(acc[tj], ap[0], ap[HD], ap[2 * HD], ap[3 * HD], q4);
+    }
   }
   const int r = r0 + wi * 32 + lr;
   if (r < rows) {
-    float* yp = Y + ((int64_t)b * rows + r) * ldy + h * HD + wj * 32 + 4 * lh;
+    float* yp = Y + ((int64_t)b * rows + r) * ldy + h * HD + wj * (HD / 2) + 4 * lh;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<float4*>(yp + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    for (int tj = 0; tj < TJ; ++tj) store16(yp + 32 * tj, acc[tj]);
   }
 }
 
 // A[b,h][c][l] = sum_r softmax_r(K)[r,c] V[r,l]  (+ kstat), one workgroup per (sample, head)
-__global__ __launch_bounds__(256) void ctx_mfma64_kernel(const float* __restrict__ K, const float* __restrict__ V,
-                                                         int64_t ld, int rows, int H,
-                                                         const int64_t* __restrict__ length, float* __restrict__ A,
-                                                         float* __restrict__ kstat) {
-  constexpr int HD = 64, LDP = HD + 4, RG = 256 / HD;
+template <int HD>
+__global__ __launch_bounds__(256) void ctx_mfma_kernel(const float* __restrict__ K, const float* __restrict__ V,
+                                                       int64_t ld, int rows, int H,
+                                                       const int64_t* __restrict__ length, float* __restrict__ A,
+                                                       float* __restrict__ kstat) {
+  constexpr int LDP = HD + 4, RG = 256 / HD, TB = HD / 64;   // TB x TB accumulator blocks per wave
   __shared__ __attribute__((aligned(16))) float sP[CH * LDP];   // [r][c] = exp(K - colmax)
   __shared__ __attribute__((aligned(16))) float sV[CH * LDP];   // [r][l]
   __shared__ float sred[256];
@@ -298,16 +316,18 @@ __global__ __launch_bounds__(256) void ctx_mfma64_kernel(const float* __restrict
   }
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
-  f32x16 acc;
+  f32x16 acc[TB][TB];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int ti = 0; ti < TB; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TB; ++tj) zero16(acc[ti][tj]);
   float ks = 0.f;                     // this thread's share of sum_r exp(K[r][c] - max[c])
   const float cm = smax[c];
-  const float* pcol = sP + (4 * lh) * LDP + wi * 32 + lr;
-  const float* vcol = sV + (4 * lh) * LDP + wj * 32 + lr;
+  const float* pcol = sP + (4 * lh) * LDP + wi * (HD / 2) + lr;
+  const float* vcol = sV + (4 * lh) * LDP + wj * (HD / 2) + lr;
   for (int r0 = 0; r0 < len; r0 += CH) {
 #pragma unroll 4
-    for (int rr = rg; rr < CH; rr += RG) {   // thread owns column c of rows rg, rg + 4, ...
+    for (int rr = rg; rr < CH; rr += RG) {   // thread owns column c of rows rg, rg + RG, ...
       const int r = r0 + rr;
       float p = 0.f, v = 0.f;
       if (r < len) {
@@ -322,8 +342,19 @@ __global__ __launch_bounds__(256) void ctx_mfma64_kernel(const float* __restrict
     const int nk = (min(CH, len - r0) + 7) / 8;   // 8-row groups holding valid rows (the rest are zeros)
     for (int g = 0; g < nk; ++g) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vcol[(8 * g + j) * LDP], pcol[(8 * g + j) * LDP], acc, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        float pv[TB], vv[TB];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+          pv[t] = pcol[(8 * g + j) * LDP + 32 * t];
+          vv[t] = vcol[(8 * g + j) * LDP + 32 * t];
+        }
+#pragma unroll
+        for (int ti = 0; ti < TB; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TB; ++tj)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[tj], pv[ti], acc[ti][tj], 0, 0, 0);
+      }
     }
     __syncthreads();
   }
@@ -338,15 +369,15 @@ __global__ __launch_bounds__(256) void ctx_mfma64_kernel(const float* __restrict
     st[1] = len > 0 ? t : 1.f;
   }
   __syncthreads();
-  // lane holds row (channel c) = wi*32 + lr, columns l = wj*32 + 8q + 4lh + e
-  const int cc = wi * 32 + lr;
-  const float sum = ssum[cc];
-  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-  float* ap = A + (int64_t)blockIdx.x * HD * HD + cc * HD + wj * 32 + 4 * lh;
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-    *reinterpret_cast<float4*>(ap + 8 * q) =
-        make_float4(acc[4 * q] * inv, acc[4 * q + 1] * inv, acc[4 * q + 2] * inv, acc[4 * q + 3] * inv);
+  for (int ti = 0; ti < TB; ++ti) {
+    const int cc = wi * (HD / 2) + 32 * ti + lr;      // lane's context row (channel c)
+    const float sum = ssum[cc];
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    float* ap = A + (int64_t)blockIdx.x * HD * HD + cc * HD + wj * (HD / 2) + 4 * lh;
+#pragma unroll
+    for (int tj = 0; tj < TB; ++tj) store16(ap + 32 * tj, acc[ti][tj], inv);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -608,57 +639,21 @@ __global__ __launch_bounds__(256) void ctx_bwd_finish_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// hd = 64 backward kernels on the matrix cores (same grids, outputs and scratch as the VALU versions
-// above; 4 waves = the 2 x 2 grid of 32 x 32 blocks of each 64 x 64 product, lane layout as in
-// apply_mfma64_kernel: row = w_i*32 + (lane & 31), columns = w_j*32 + 8q + 4*(lane >> 5) + e).
+// hd = 64 / 128 backward kernels on the matrix cores (same grids, outputs and scratch as the VALU
+// versions above; lane layout as in apply_mfma_kernel).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void zero16(f32x16& a) {
-#pragma unroll
-  for (int e = 0; e < 16; ++e) a[e] = 0.f;
-}
-// acc += X . Y^T with X[row][k] and Y[col][k] both k-contiguous tiles ([.][LDP]): 8 k-groups of 8
-__device__ __forceinline__ void mma_rc_rc(f32x16& acc, const float* xrow, const float* yrow) {
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    const float4 x4 = *reinterpret_cast<const float4*>(xrow + 8 * ks);
-    const float4 y4 = *reinterpret_cast<const float4*>(yrow + 8 * ks);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y4.x, x4.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y4.y, x4.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y4.z, x4.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y4.w, x4.w, acc, 0, 0, 0);
-  }
-}
-// acc += X . Y^T with X[row][k] k-contiguous and Y given k-major (ycol -> element [k][col], stride LDP)
-__device__ __forceinline__ void mma_rc_rs(f32x16& acc, const float* xrow, const float* ycol, int ldp) {
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    const float4 x4 = *reinterpret_cast<const float4*>(xrow + 8 * ks);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ycol[(8 * ks + 0) * ldp], x4.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ycol[(8 * ks + 1) * ldp], x4.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ycol[(8 * ks + 2) * ldp], x4.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ycol[(8 * ks + 3) * ldp], x4.w, acc, 0, 0, 0);
-  }
-}
-// acc += X^T . Y with both tiles k-major (xcol -> [k][row], ycol -> [k][col])
-__device__ __forceinline__ void mma_rs_rs(f32x16& acc, const float* xcol, const float* ycol, int ldp) {
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ycol[(8 * ks + j) * ldp], xcol[(8 * ks + j) * ldp], acc, 0, 0, 0);
-  }
-}
-
-__global__ __launch_bounds__(256) void apply_bwd_mfma64_kernel(const float* __restrict__ dY, int64_t lddy,
-                                                               const float* __restrict__ Q, int64_t ldq,
-                                                               const float* __restrict__ A,
-                                                               float* __restrict__ dQ, int64_t lddq,
-                                                               float* __restrict__ dApart, int rows, int H) {
-  constexpr int HD = 64, LDP = HD + 4;
-  __shared__ __attribute__((aligned(16))) float sA[HD * LDP];   // [c][l]
-  __shared__ __attribute__((aligned(16))) float sQ[CH * LDP];   // softmax(Q) [r][c]
-  __shared__ __attribute__((aligned(16))) float sD[CH * LDP];   // dY [r][l]
-  __shared__ float srow[2][CH];
+template <int HD>
+__global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const float* __restrict__ dY, int64_t lddy,
+                                                             const float* __restrict__ Q, int64_t ldq,
+                                                             const float* __restrict__ A,
+                                                             float* __restrict__ dQ, int64_t lddq,
+                                                             float* __restrict__ dApart, int rows, int H) {
+  constexpr int LDP = HD + 4, TB = HD / 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                    // [c][l]            HD * LDP
+  float* sQ = sA + HD * LDP;           // softmax(Q) [r][c] CH * LDP
+  float* sD = sQ + CH * LDP;           // dY [r][l]         CH * LDP
+  float* srow = sD + CH * LDP;         // [2][CH]
   const int tid = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int r0 = blockIdx.y * CH;
@@ -674,56 +669,100 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma64_kernel(const float* __re
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
-  // dq_pre[r][c] = sum_l dY[r][l] A[c][l]
-  f32x16 dq;
-  zero16(dq);
-  mma_rc_rc(dq, sD + (wi * 32 + lr) * LDP + 4 * lh, sA + (wj * 32 + lr) * LDP + 4 * lh);
-  // dA[c][l] = sum_r q[r][c] dY[r][l]
-  f32x16 da;
-  zero16(da);
-  mma_rs_rs(da, sQ + (4 * lh) * LDP + wi * 32 + lr, sD + (4 * lh) * LDP + wj * 32 + lr, LDP);
-  {
-    float* dAb = dApart + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * HD * HD + (wi * 32 + lr) * HD + wj * 32 + 4 * lh;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<float4*>(dAb + 8 * q) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
-  }
-  // softmax Jacobian over the 64 channels of a row: the row lives in 2 lanes (lh) x 2 waves (wj)
   const int rl = wi * 32 + lr;
-  float4 qv[4];
+  // dq_pre[r][c] = sum_l dY[r][l] A[c][l]   (64 x HD, reduce over HD)
+  f32x16 dq[TB];
+#pragma unroll
+  for (int tj = 0; tj < TB; ++tj) zero16(dq[tj]);
+  {
+    const float* xrow = sD + rl * LDP + 4 * lh;
+    const float* yrow = sA + (wj * (HD / 2) + lr) * LDP + 4 * lh;
+#pragma unroll 4
+    for (int ks = 0; ks < HD / 8; ++ks) {
+      const float4 x4 = *reinterpret_cast<const float4*>(xrow + 8 * ks);
+#pragma unroll
+      for (int tj = 0; tj < TB; ++tj) {
+        const float4 y4 = *reinterpret_cast<const float4*>(yrow + 32 * tj * LDP + 8 * ks);
+        dq[tj] = mfma4(dq[tj], y4.x, y4.y, y4.z, y4.w, x4);
+      }
+    }
+  }
+  // dA[c][l] = sum_r q[r][c] dY[r][l]   (HD x HD, reduce over the 64 rows)
+  {
+    f32x16 da[TB][TB];
+#pragma unroll
+    for (int ti = 0; ti < TB; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TB; ++tj) zero16(da[ti][tj]);
+    const float* xcol = sQ + (4 * lh) * LDP + wi * (HD / 2) + lr;
+    const float* ycol = sD + (4 * lh) * LDP + wj * (HD / 2) + lr;
+#pragma unroll 2
+    for (int ks = 0; ks < CH / 8; ++ks) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float xv[TB], yv[TB];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+          xv[t] = xcol[(8 * ks + j) * LDP + 32 * t];
+          yv[t] = ycol[(8 * ks + j) * LDP + 32 * t];
+        }
+#pragma unroll
+        for (int ti = 0; ti < TB; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TB; ++tj)
+            da[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv[tj], xv[ti], da[ti][tj], 0, 0, 0);
+      }
+    }
+    float* dAb = dApart + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * HD * HD;
+#pragma unroll
+    for (int ti = 0; ti < TB; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TB; ++tj)
+        store16(dAb + (wi * (HD / 2) + 32 * ti + lr) * HD + wj * (HD / 2) + 32 * tj + 4 * lh, da[ti][tj]);
+  }
+  // softmax Jacobian over the HD channels of a row: the row lives in 2 lanes (lh) x 2 waves (wj)
   float part = 0.f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    qv[q] = *reinterpret_cast<const float4*>(sQ + rl * LDP + wj * 32 + 8 * q + 4 * lh);
-    part += qv[q].x * dq[4 * q] + qv[q].y * dq[4 * q + 1] + qv[q].z * dq[4 * q + 2] + qv[q].w * dq[4 * q + 3];
-  }
+  for (int tj = 0; tj < TB; ++tj)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 qv = *reinterpret_cast<const float4*>(sQ + rl * LDP + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh);
+      part += qv.x * dq[tj][4 * q] + qv.y * dq[tj][4 * q + 1] + qv.z * dq[tj][4 * q + 2] + qv.w * dq[tj][4 * q + 3];
+    }
   part += __shfl_xor(part, 32, 64);
-  if (lh == 0) srow[wj][rl] = part;
+  if (lh == 0) srow[wj * CH + rl] = part;
   __syncthreads();
-  const float sdot = srow[0][rl] + srow[1][rl];
+  const float sdot = srow[rl] + srow[CH + rl];
   const int r = r0 + rl;
   if (r < rows) {
-    float* op = dQ + ((int64_t)b * rows + r) * lddq + h * HD + wj * 32 + 4 * lh;
+    float* op = dQ + ((int64_t)b * rows + r) * lddq + h * HD + wj * (HD / 2) + 4 * lh;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<float4*>(op + 8 * q) =
-          make_float4(qv[q].x * (dq[4 * q] - sdot), qv[q].y * (dq[4 * q + 1] - sdot), qv[q].z * (dq[4 * q + 2] - sdot),
-                      qv[q].w * (dq[4 * q + 3] - sdot));
+    for (int tj = 0; tj < TB; ++tj)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 qv = *reinterpret_cast<const float4*>(sQ + rl * LDP + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh);
+        *reinterpret_cast<float4*>(op + 32 * tj + 8 * q) =
+            make_float4(qv.x * (dq[tj][4 * q] - sdot), qv.y * (dq[tj][4 * q + 1] - sdot),
+                        qv.z * (dq[tj][4 * q + 2] - sdot), qv.w * (dq[tj][4 * q + 3] - sdot));
+      }
   }
 }
 
-__global__ __launch_bounds__(256) void ctx_bwd_mfma64_kernel(const float* __restrict__ dA, const float* __restrict__ K,
-                                                             const float* __restrict__ V, int64_t ld,
-                                                             const float* __restrict__ kstat,
-                                                             const int64_t* __restrict__ length,
-                                                             float* __restrict__ dK, float* __restrict__ dV, int64_t ldd,
-                                                             int rows, int H, float* __restrict__ colpart) {
-  constexpr int HD = 64, LDP = HD + 4;
-  __shared__ __attribute__((aligned(16))) float sdA[HD * LDP];   // [c][l]
-  __shared__ __attribute__((aligned(16))) float sK[CH * LDP];    // k (normalised) [r][c]
-  __shared__ __attribute__((aligned(16))) float sV[CH * LDP];    // [r][l]; later k * dk [r][c]
-  __shared__ float smax[HD], sinv[HD];
-  __shared__ float swsum[4][HD];
+template <int HD>
+__global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restrict__ dA, const float* __restrict__ K,
+                                                           const float* __restrict__ V, int64_t ld,
+                                                           const float* __restrict__ kstat,
+                                                           const int64_t* __restrict__ length,
+                                                           float* __restrict__ dK, float* __restrict__ dV, int64_t ldd,
+                                                           int rows, int H, float* __restrict__ colpart) {
+  constexpr int LDP = HD + 4, TB = HD / 64, RG = 256 / HD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sdA = smem;                   // [c][l]                      HD * LDP
+  float* sK = sdA + HD * LDP;          // k (normalised) [r][c]       CH * LDP
+  float* sV = sK + CH * LDP;           // [r][l]; later k * dk [r][c] CH * LDP
+  float* smax = sV + CH * LDP;         // [HD]
+  float* sinv = smax + HD;             // [HD]
+  float* swsum = sinv + HD;            // [RG][HD]
   const int tid = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   int len = rows;
@@ -756,44 +795,81 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma64_kernel(const float* __rest
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
   const int rl = wi * 32 + lr;
-  // dV[r][l] = sum_c k[r][c] dA[c][l]
-  f32x16 dv;
-  zero16(dv);
-  mma_rc_rs(dv, sK + rl * LDP + 4 * lh, sdA + (4 * lh) * LDP + wj * 32 + lr, LDP);
-  // dk[r][c] = sum_l V[r][l] dA[c][l]
-  f32x16 dk;
-  zero16(dk);
-  mma_rc_rc(dk, sV + rl * LDP + 4 * lh, sdA + (wj * 32 + lr) * LDP + 4 * lh);
+  f32x16 dv[TB], dk[TB];
+#pragma unroll
+  for (int tj = 0; tj < TB; ++tj) {
+    zero16(dv[tj]);
+    zero16(dk[tj]);
+  }
+  {
+    const float* krow = sK + rl * LDP + 4 * lh;                          // X of dV: k[r][c], reduce over c
+    const float* acol = sdA + (4 * lh) * LDP + wj * (HD / 2) + lr;       // Y of dV: dA[c][l] by rows of c
+    const float* vrow = sV + rl * LDP + 4 * lh;                          // X of dk: V[r][l], reduce over l
+    const float* arow = sdA + (wj * (HD / 2) + lr) * LDP + 4 * lh;       // Y of dk: dA[c][l] by rows of c
+#pragma unroll 2
+    for (int ks = 0; ks < HD / 8; ++ks) {
+      const float4 k4 = *reinterpret_cast<const float4*>(krow + 8 * ks);
+      const float4 v4 = *reinterpret_cast<const float4*>(vrow + 8 * ks);
+#pragma unroll
+      for (int tj = 0; tj < TB; ++tj) {
+        const float* ap = acol + (8 * ks) * LDP + 32 * tj;
+        dv[tj] = mfma4(dv[tj], ap[0], ap[LDP], ap[2 * LDP], ap[3 * LDP], k4);
+        const float4 a4 = *reinterpret_cast<const float4*>(arow + 32 * tj * LDP + 8 * ks);
+        dk[tj] = mfma4(dk[tj], a4.x, a4.y, a4.z, a4.w, v4);
+      }
+    }
+  }
   const int r = r0 + rl;
   if (r < rows) {   // rows in [len, rows) carry k == 0 and V == 0 in LDS, so both products are exact zeros
-    float* kp = dK + ((int64_t)b * rows + r) * ldd + h * HD + wj * 32 + 4 * lh;
-    float* vp = dV + ((int64_t)b * rows + r) * ldd + h * HD + wj * 32 + 4 * lh;
+    float* kp = dK + ((int64_t)b * rows + r) * ldd + h * HD + wj * (HD / 2) + 4 * lh;
+    float* vp = dV + ((int64_t)b * rows + r) * ldd + h * HD + wj * (HD / 2) + 4 * lh;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      *reinterpret_cast<float4*>(kp + 8 * q) = make_float4(dk[4 * q], dk[4 * q + 1], dk[4 * q + 2], dk[4 * q + 3]);
-      *reinterpret_cast<float4*>(vp + 8 * q) = make_float4(dv[4 * q], dv[4 * q + 1], dv[4 * q + 2], dv[4 * q + 3]);
+    for (int tj = 0; tj < TB; ++tj) {
+      store16(kp + 32 * tj, dk[tj]);
+      store16(vp + 32 * tj, dv[tj]);
     }
   }
   __syncthreads();   // every wave is done reading sV
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {   // k * dk into sV ([r][c]) for the column sums of this chunk
-    const int c = wj * 32 + 8 * q + 4 * lh;
-    const float4 k4 = *reinterpret_cast<const float4*>(sK + rl * LDP + c);
-    *reinterpret_cast<float4*>(sV + rl * LDP + c) =
-        make_float4(k4.x * dk[4 * q], k4.y * dk[4 * q + 1], k4.z * dk[4 * q + 2], k4.w * dk[4 * q + 3]);
-  }
+  for (int tj = 0; tj < TB; ++tj)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {   // k * dk into sV ([r][c]) for the column sums of this chunk
+      const int cc = wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh;
+      const float4 k4 = *reinterpret_cast<const float4*>(sK + rl * LDP + cc);
+      *reinterpret_cast<float4*>(sV + rl * LDP + cc) =
+          make_float4(k4.x * dk[tj][4 * q], k4.y * dk[tj][4 * q + 1], k4.z * dk[tj][4 * q + 2], k4.w * dk[tj][4 * q + 3]);
+    }
   __syncthreads();
   {
-    const int c = tid % HD, rg = tid / HD;
+    const int cc = tid % HD, rg = tid / HD;
     float t = 0.f;
-#pragma unroll
-    for (int rr = rg; rr < CH; rr += 4) t += sV[rr * LDP + c];
-    swsum[rg][c] = t;
+#pragma unroll 4
+    for (int rr = rg; rr < CH; rr += RG) t += sV[rr * LDP + cc];
+    swsum[rg * HD + cc] = t;
   }
   __syncthreads();
-  if (tid < HD)
-    colpart[((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * HD + tid] =
-        (swsum[0][tid] + swsum[1][tid]) + (swsum[2][tid] + swsum[3][tid]);
+  if (tid < HD) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < RG; ++g) t += swsum[g * HD + tid];
+    colpart[((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * HD + tid] = t;
+  }
+}
+
+template <int HD> constexpr size_t attn_bwd_lds_bytes() {
+  return sizeof(float) * ((size_t)HD * (HD + 4) + 2 * (size_t)CH * (HD + 4) + 2 * CH + 2 * HD + (256 / HD) * HD);
+}
+// hd = 128 needs 135 KB of dynamic LDS (of the 160 KB per CU): raise the per-kernel limit once.
+int allow_big_lds() {
+  static const int rc = [] {
+    const int bytes = (int)attn_bwd_lds_bytes<128>();
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&apply_bwd_mfma_kernel<128>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&ctx_bwd_mfma_kernel<128>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : 1;
+  }();
+  return rc;
 }
 
 bool hd_ok(int hd) { return hd == 8 || hd == 16 || hd == 32 || hd == 64 || hd == 128; }
@@ -815,7 +891,10 @@ extern "C" int hig_linattn_ctx(const float* K, const float* V, int64_t ld, int32
   HIG_REQUIRE(K && V && A && kstat && B > 0 && rows > 0 && H > 0, "hig_linattn_ctx: bad arguments");
   HIG_REQUIRE(hd_ok(hd), "hig_linattn: head dim %d not in {8,16,32,64,128}", hd);
   if (hd == 64)
-    hipLaunchKernelGGL(ctx_mfma64_kernel, dim3(B * H), dim3(256), 0, hig_stream(stream), K, V, ld, rows, H, length, A,
+    hipLaunchKernelGGL(ctx_mfma_kernel<64>, dim3(B * H), dim3(256), 0, hig_stream(stream), K, V, ld, rows, H, length, A,
+                       kstat);
+  else if (hd == 128)
+    hipLaunchKernelGGL(ctx_mfma_kernel<128>, dim3(B * H), dim3(256), 0, hig_stream(stream), K, V, ld, rows, H, length, A,
                        kstat);
   else
     HD_SWITCH(hd, hipLaunchKernelGGL((ctx_kernel<HDV>), dim3(B * H), dim3(256), 0, hig_stream(stream), K, V,
@@ -832,8 +911,11 @@ extern "C" int hig_linattn_apply(const float* Q, int64_t ldq, const float* A, fl
                   (reinterpret_cast<uintptr_t>(Y) & 15) == 0,
               "hig_linattn_apply: Q/Y must be 16-byte aligned");
   if (hd == 64)
-    hipLaunchKernelGGL(apply_mfma64_kernel, dim3(B * H, (rows + CH - 1) / CH), dim3(256), 0, hig_stream(stream), Q, ldq,
+    hipLaunchKernelGGL(apply_mfma_kernel<64>, dim3(B * H, (rows + CH - 1) / CH), dim3(256), 0, hig_stream(stream), Q, ldq,
                        A, Y, ldy, rows, H);
+  else if (hd == 128)
+    hipLaunchKernelGGL(apply_mfma_kernel<128>, dim3(B * H, (rows + CH - 1) / CH), dim3(256), 0, hig_stream(stream), Q,
+                       ldq, A, Y, ldy, rows, H);
   else
     HD_SWITCH(hd, hipLaunchKernelGGL((apply_kernel<HDV>), dim3(B * H, (rows + CH - 1) / CH), dim3(256), 0,
                                      hig_stream(stream), Q, ldq, A, Y, ldy, rows, H));
@@ -858,8 +940,11 @@ extern "C" int hig_linattn_apply_bwd(const float* dY, int64_t lddy, const float*
               "hig_linattn_apply_bwd: Q/dY/dQ must be 16-byte aligned");
   const int nchunk = (rows + CH - 1) / CH;
   if (hd == 64)
-    hipLaunchKernelGGL(apply_bwd_mfma64_kernel, dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream), dY, lddy, Q, ldq,
-                       A, dQ, lddq, scratch, rows, H);
+    hipLaunchKernelGGL(apply_bwd_mfma_kernel<64>, dim3(B * H, nchunk), dim3(256), attn_bwd_lds_bytes<64>(),
+                       hig_stream(stream), dY, lddy, Q, ldq, A, dQ, lddq, scratch, rows, H);
+  else if (hd == 128 && allow_big_lds() == 0)
+    hipLaunchKernelGGL(apply_bwd_mfma_kernel<128>, dim3(B * H, nchunk), dim3(256), attn_bwd_lds_bytes<128>(),
+                       hig_stream(stream), dY, lddy, Q, ldq, A, dQ, lddq, scratch, rows, H);
   else
     HD_SWITCH(hd, hipLaunchKernelGGL((apply_bwd_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream),
                                      dY, lddy, Q, ldq, A, dQ, lddq, scratch, rows, H));
@@ -883,8 +968,11 @@ extern "C" int hig_linattn_ctx_bwd(const float* dA, const float* K, const float*
               "hig_linattn_ctx_bwd: dK/dV must be 16-byte aligned");
   const int nchunk = (rows + CH - 1) / CH;
   if (hd == 64)
-    hipLaunchKernelGGL(ctx_bwd_mfma64_kernel, dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream), dA, K, V, ld, kstat,
-                       length, dK, dV, ldd, rows, H, scratch);
+    hipLaunchKernelGGL(ctx_bwd_mfma_kernel<64>, dim3(B * H, nchunk), dim3(256), attn_bwd_lds_bytes<64>(),
+                       hig_stream(stream), dA, K, V, ld, kstat, length, dK, dV, ldd, rows, H, scratch);
+  else if (hd == 128 && allow_big_lds() == 0)
+    hipLaunchKernelGGL(ctx_bwd_mfma_kernel<128>, dim3(B * H, nchunk), dim3(256), attn_bwd_lds_bytes<128>(),
+                       hig_stream(stream), dA, K, V, ld, kstat, length, dK, dV, ldd, rows, H, scratch);
   else
     HD_SWITCH(hd, hipLaunchKernelGGL((ctx_bwd_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream), dA,
                                      K, V, ld, kstat, length, dK, dV, ldd, rows, H, scratch));
