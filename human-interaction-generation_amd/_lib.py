@@ -30,7 +30,7 @@ SYMBOLS = (
     "hig_timestep_embedding", "hig_q_sample", "hig_p_sample_step", "hig_dec_timesteps",
     "hig_masked_mse", "hig_sumsq_partial", "hig_clip_adam",
     "hig_text_head_workspace_bytes", "hig_text_head_bwd_workspace_bytes", "hig_text_head_fwd", "hig_text_head_bwd",
-    "hig_layernorm", "hig_gather_rows", "hig_scatter_add_rows", "hig_gather_frames", "hig_recover_joints", "hig_transpose_batch",
+    "hig_layernorm", "hig_gather_rows", "hig_scatter_add_rows", "hig_gather_frames", "hig_recover_joints", "hig_transpose_batch", "hig_linattn_ctx_scratch_floats",
 )
 
 
@@ -90,7 +90,9 @@ def lib():
         L.hig_gemm.argtypes = [C.POINTER(GemmDesc), vp]
         L.hig_rowstats.argtypes = [vp, i64, i64, i32, vp, vp]
         L.hig_ln_mod_silu.argtypes = [vp, i64, i64, i32, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp]
-        L.hig_linattn_ctx.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp]
+        L.hig_linattn_ctx.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+        L.hig_linattn_ctx_scratch_floats.restype = i64
+        L.hig_linattn_ctx_scratch_floats.argtypes = [i32, i32, i32, i32]
         L.hig_linattn_apply.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]
         L.hig_linattn_bwd_scratch_floats.restype = i64
         L.hig_linattn_bwd_scratch_floats.argtypes = [i32, i32, i32, i32]

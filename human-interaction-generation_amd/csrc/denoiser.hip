@@ -97,7 +97,7 @@ int check_dims(const hig_dims* p, Dims& D) {
 
 // Forward workspace (floats).  Per-layer block repeated L times when training, once otherwise.
 struct FwdLayout {
-  int64_t te, te_h, emb, ss, h0, lenp;
+  int64_t te, te_h, emb, ss, h0, lenp, cscr;
   int64_t layer0, lstride;
   int64_t st1, qkv, A1, kst1, lse1, y1, st2, a1, h1, st3, qc, lse2, y2, st4, a2, h2, z1, f1, y3, st5, a3, h3;
   int64_t st6, iqkv, Ai, ksti, y4, st7, a4, h2b;  // two-person interaction attention block
@@ -114,6 +114,7 @@ FwdLayout fwd_layout(const Dims& D, int training) {
   w.ss = take((int64_t)D.B * D.nsty * D.L * 2 * D.d);
   w.h0 = take(D.M * D.d);
   w.lenp = take((int64_t)D.B * 2);  // int64 lengths with the two halves swapped (partner's mask)
+  w.cscr = take(hig_linattn_ctx_scratch_floats(D.B, D.T, D.H, D.hd));   // chunk partials of the context build
   w.layer0 = o;
   o = 0;
   w.st1 = take(D.M * 2);
@@ -160,13 +161,14 @@ FwdLayout fwd_layout(const Dims& D, int training) {
 // Text context (floats): LN stats of xf_out (shared by all layers), then per layer the context
 // matrices + column-softmax stats, and the key/value projections (kept per layer for backward).
 struct TextLayout {
-  int64_t stt, layer0, lstride, Ac, kstc, kv, kv_stride, total;
+  int64_t stt, cscr, layer0, lstride, Ac, kstc, kv, kv_stride, total;
 };
 TextLayout text_layout(const Dims& D, int training) {
   TextLayout t;
   int64_t o = 0;
   auto take = [&](int64_t n) { int64_t r = o; o += al(n); return r; };
   t.stt = take(D.Mt * 2);
+  t.cscr = take(hig_linattn_ctx_scratch_floats(D.B, D.N, D.H, D.hd));
   t.layer0 = o;
   o = 0;
   t.Ac = take((int64_t)D.B * D.H * D.hd * D.hd);
@@ -287,7 +289,8 @@ extern "C" int hig_text_context(const hig_dims* dims, const void* const* params,
                                 .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_KV_B)).prec(D.prec).g, 1, nullptr, st));
     // linear attention: softmax over the N text tokens (no mask) and A = k^T v (transformer.py:148,152);
     // full attention (:253-259) consumes key/value directly
-    if (!D.full) HIG_TRY(hig_linattn_ctx(kv, kv + D.d, 2 * D.d, D.B, D.N, D.H, D.hd, nullptr, Ac, kstc, stream));
+    if (!D.full)
+      HIG_TRY(hig_linattn_ctx(kv, kv + D.d, 2 * D.d, D.B, D.N, D.H, D.hd, nullptr, Ac, kstc, base + tl.cscr, stream));
   }
   return HIG_OK;
 }
@@ -351,7 +354,7 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
                                length, lb + w.y1, d, lb + w.lse1, stream));
     } else {
       HIG_TRY(hig_linattn_ctx(lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, length,
-                              lb + w.A1, lb + w.kst1, stream));
+                              lb + w.A1, lb + w.kst1, ws + w.cscr, stream));
       HIG_TRY(hig_linattn_apply(lb + w.qkv, 3 * d, lb + w.A1, lb + w.y1, d, D.B, D.T, D.H, D.hd, stream));
     }
     HIG_TRY(hig_ln_mod_silu(lb + w.y1, d, M, d, PL(params, l, HIG_L_SA_STY_NORM_W), PL(params, l, HIG_L_SA_STY_NORM_B),
@@ -385,7 +388,7 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
       HIG_TRY(hig_gemm_launch(G(lb + w.xn3, d, 0, PL(params, l, HIG_L_INT_QKV_W), d, 0, lb + w.iqkv, 3 * d, M, 3 * d, d)
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_INT_QKV_B)).prec(D.prec).g, 1, nullptr, st));
       HIG_TRY(hig_linattn_ctx(lb + w.iqkv + d, lb + w.iqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, len_partner,
-                              lb + w.Ai, lb + w.ksti, stream));
+                              lb + w.Ai, lb + w.ksti, ws + w.cscr, stream));
       const int64_t halfA = (int64_t)Bp * D.H * D.hd * D.hd, halfM = (int64_t)Bp * D.T;
       HIG_TRY(hig_linattn_apply(lb + w.iqkv, 3 * d, lb + w.Ai + halfA, lb + w.y4, d, Bp, D.T, D.H, D.hd, stream));
       HIG_TRY(hig_linattn_apply(lb + w.iqkv + halfM * 3 * d, 3 * d, lb + w.Ai, lb + w.y4 + halfM * d, d, Bp, D.T, D.H,

@@ -380,6 +380,146 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const float* __restrict__
   }
 }
 
+// ctx over row chunks in parallel (online softmax): workgroup (b,h,chunk j) uses the column max m_j of ITS
+// 64 rows and writes the unnormalised partial  A_j[c][l] = sum_r exp(K[r][c] - m_j[c]) V[r][l],  m_j and
+// s_j[c] = sum_r exp(K[r][c] - m_j[c]);  ctx_combine_kernel merges them:  m = max_j m_j,
+// A = sum_j exp(m_j - m) A_j / sum_j exp(m_j - m) s_j.   part layout per (bh, chunk): [HD*HD | m HD | s HD].
+template <int HD>
+__global__ __launch_bounds__(256) void ctx_part_mfma_kernel(const float* __restrict__ K, const float* __restrict__ V,
+                                                            int64_t ld, int rows, int H,
+                                                            const int64_t* __restrict__ length,
+                                                            float* __restrict__ part) {
+  constexpr int LDP = HD + 4, RG = 256 / HD, TB = HD / 64, PER = CH / RG;
+  __shared__ __attribute__((aligned(16))) float sP[CH * LDP];
+  __shared__ __attribute__((aligned(16))) float sV[CH * LDP];
+  __shared__ float sred[256];
+  __shared__ float smax[HD];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  int len = rows;
+  if (length) len = (int)min<int64_t>(max<int64_t>(length[b], 0), rows);
+  const int r0 = blockIdx.y * CH;
+  const int nvalid = max(0, min(CH, len - r0));
+  const float* Kb = K + ((int64_t)b * rows + r0) * ld + h * HD;
+  const float* Vb = V + ((int64_t)b * rows + r0) * ld + h * HD;
+  const int c = tid % HD, rg = tid / HD;
+  float kreg[PER], vreg[PER];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {       // one pass over HBM: the thread keeps its 64/RG rows of column c
+    const int rr = rg + RG * i;
+    kreg[i] = rr < nvalid ? Kb[(int64_t)rr * ld + c] : -INFINITY;
+    vreg[i] = rr < nvalid ? Vb[(int64_t)rr * ld + c] : 0.f;
+    m = fmaxf(m, kreg[i]);
+  }
+  sred[tid] = m;
+  __syncthreads();
+  if (tid < HD) {
+    for (int g2 = 1; g2 < RG; ++g2) m = fmaxf(m, sred[g2 * HD + tid]);
+    smax[tid] = m;
+  }
+  __syncthreads();
+  const float cm = smax[c];
+  float ks = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int rr = rg + RG * i;
+    const float pe = rr < nvalid ? __expf(kreg[i] - cm) : 0.f;
+    ks += pe;
+    sP[rr * LDP + c] = pe;
+    sV[rr * LDP + c] = vreg[i];
+  }
+  __syncthreads();
+  sred[tid] = ks;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
+  f32x16 acc[TB][TB];
+#pragma unroll
+  for (int ti = 0; ti < TB; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TB; ++tj) zero16(acc[ti][tj]);
+  const float* pcol = sP + (4 * lh) * LDP + wi * (HD / 2) + lr;
+  const float* vcol = sV + (4 * lh) * LDP + wj * (HD / 2) + lr;
+  const int nk = (nvalid + 7) / 8;
+  for (int g = 0; g < nk; ++g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float pv[TB], vv[TB];
+#pragma unroll
+      for (int t = 0; t < TB; ++t) {
+        pv[t] = pcol[(8 * g + j) * LDP + 32 * t];
+        vv[t] = vcol[(8 * g + j) * LDP + 32 * t];
+      }
+#pragma unroll
+      for (int ti = 0; ti < TB; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TB; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[tj], pv[ti], acc[ti][tj], 0, 0, 0);
+    }
+  }
+  float* pb = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (HD * HD + 2 * HD);
+#pragma unroll
+  for (int ti = 0; ti < TB; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TB; ++tj)
+      store16(pb + (wi * (HD / 2) + 32 * ti + lr) * HD + wj * (HD / 2) + 32 * tj + 4 * lh, acc[ti][tj]);
+  __syncthreads();
+  if (tid < HD) {
+    float t = 0.f;
+    for (int g2 = 0; g2 < RG; ++g2) t += sred[g2 * HD + tid];
+    pb[HD * HD + tid] = smax[tid];
+    pb[HD * HD + HD + tid] = t;
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void ctx_combine_kernel(const float* __restrict__ part, int nchunk,
+                                                          float* __restrict__ A, float* __restrict__ kstat) {
+  constexpr int PS = HD * HD + 2 * HD;
+  __shared__ float sw[16][HD];        // weight of chunk j for channel c (nchunk <= 16 per pass)
+  __shared__ float sinv[HD];
+  const int tid = threadIdx.x;
+  const float* pb = part + (int64_t)blockIdx.x * nchunk * PS;
+  float* Ab = A + (int64_t)blockIdx.x * HD * HD;
+  float gm = -INFINITY, gs = 0.f;
+  if (tid < HD) {
+    for (int j = 0; j < nchunk; ++j) gm = fmaxf(gm, pb[(int64_t)j * PS + HD * HD + tid]);
+    for (int j = 0; j < nchunk; ++j) {
+      const float mj = pb[(int64_t)j * PS + HD * HD + tid];
+      const float wj = mj == -INFINITY ? 0.f : __expf(mj - gm);
+      gs += wj * pb[(int64_t)j * PS + HD * HD + HD + tid];
+    }
+    sinv[tid] = gs > 0.f ? 1.0f / gs : 0.f;
+    float* st = kstat + ((int64_t)blockIdx.x * HD + tid) * 2;
+    st[0] = gs > 0.f ? gm : 0.f;
+    st[1] = gs > 0.f ? gs : 1.f;
+  }
+  for (int j0 = 0; j0 < nchunk; j0 += 16) {
+    const int nj = min(16, nchunk - j0);
+    __syncthreads();
+    if (tid < HD)
+      for (int j = 0; j < nj; ++j) {
+        const float mj = pb[(int64_t)(j0 + j) * PS + HD * HD + tid];
+        sw[j][tid] = mj == -INFINITY ? 0.f : __expf(mj - gm);
+      }
+    __syncthreads();
+    for (int idx = tid; idx < HD * HD / 4; idx += 256) {
+      const int c = (idx * 4) / HD;
+      float4 a = j0 == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(Ab)[idx];
+      for (int j = 0; j < nj; ++j) {
+        const float4 t = reinterpret_cast<const float4*>(pb + (int64_t)(j0 + j) * PS)[idx];
+        const float wv = sw[j][c];
+        a.x += wv * t.x; a.y += wv * t.y; a.z += wv * t.z; a.w += wv * t.w;
+      }
+      if (j0 + nj >= nchunk) {
+        const float inv = sinv[c];
+        a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
+      }
+      reinterpret_cast<float4*>(Ab)[idx] = a;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // apply_bwd: dq = dY A^T, dQ = q * (dq - sum_c q dq);  dA[c][l] = sum_r q[r,c] dY[r,l]
 // grid = (B*H, row chunks): each block owns 64 rows and writes its dA contribution to
@@ -885,11 +1025,33 @@ bool hd_ok(int hd) { return hd == 8 || hd == 16 || hd == 32 || hd == 64 || hd ==
 
 }  // namespace
 
+extern "C" int64_t hig_linattn_ctx_scratch_floats(int32_t B, int32_t rows, int32_t H, int32_t hd) {
+  const int64_t nchunk = (rows + CH - 1) / CH;
+  return (int64_t)B * H * nchunk * ((int64_t)hd * hd + 2 * hd);
+}
+
 extern "C" int hig_linattn_ctx(const float* K, const float* V, int64_t ld, int32_t B, int32_t rows,
                                int32_t H, int32_t hd, const int64_t* length, float* A, float* kstat,
-                               hig_stream_t stream) {
+                               float* scratch, hig_stream_t stream) {
   HIG_REQUIRE(K && V && A && kstat && B > 0 && rows > 0 && H > 0, "hig_linattn_ctx: bad arguments");
   HIG_REQUIRE(hd_ok(hd), "hig_linattn: head dim %d not in {8,16,32,64,128}", hd);
+  const int nchunk = (rows + CH - 1) / CH;
+  if (scratch && nchunk > 1 && (hd == 64 || hd == 128)) {
+    // row chunks in parallel + a merge: 4-5x the workgroups of the one-per-(sample, head) kernel
+    if (hd == 64) {
+      hipLaunchKernelGGL(ctx_part_mfma_kernel<64>, dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream), K, V, ld,
+                         rows, H, length, scratch);
+      hipLaunchKernelGGL(ctx_combine_kernel<64>, dim3(B * H), dim3(256), 0, hig_stream(stream), scratch, nchunk, A,
+                         kstat);
+    } else {
+      hipLaunchKernelGGL(ctx_part_mfma_kernel<128>, dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream), K, V, ld,
+                         rows, H, length, scratch);
+      hipLaunchKernelGGL(ctx_combine_kernel<128>, dim3(B * H), dim3(256), 0, hig_stream(stream), scratch, nchunk, A,
+                         kstat);
+    }
+    HIG_CHECK_LAUNCH();
+    return HIG_OK;
+  }
   if (hd == 64)
     hipLaunchKernelGGL(ctx_mfma_kernel<64>, dim3(B * H), dim3(256), 0, hig_stream(stream), K, V, ld, rows, H, length, A,
                        kstat);

@@ -298,7 +298,10 @@ int hig_scatter_add_rows(const float* src, int64_t ld, int32_t B, int32_t rows_p
  * apply: y = softmax_hd(Q) . A[b,h]. */
 int hig_linattn_ctx(const float* K, const float* V, int64_t ld, int32_t B, int32_t rows,
                     int32_t H, int32_t hd, const int64_t* length, float* A, float* kstat,
-                    hig_stream_t stream);
+                    float* scratch, hig_stream_t stream);
+/* scratch (optional, hig_linattn_ctx_scratch_floats(B, rows, H, hd) floats): with it, hd 64 / 128 contexts
+ * are built from 64-row chunks in parallel (online softmax) and merged; NULL = one workgroup per (b, h). */
+int64_t hig_linattn_ctx_scratch_floats(int32_t B, int32_t rows, int32_t H, int32_t hd);
 int hig_linattn_apply(const float* Q, int64_t ldq, const float* A, float* Y, int64_t ldy,
                       int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
 /* The backward kernels split each sample's rows into 64-row chunks (one workgroup each) and

@@ -295,7 +295,14 @@ def test_linear_attention_forward_backward(B, T, H, hd, lens):
     y = torch.zeros(B * T, d, device=DEV)
     lg = lengths.to(DEV)
     s = _lib.stream_ptr()
-    _lib.check(L.hig_linattn_ctx(g.data_ptr() + 4 * d, g.data_ptr() + 8 * d, 3 * d, B, T, H, hd, P(lg), P(A), P(kst), s))
+    # with scratch: chunk-parallel build (hd 64 / 128, more than one 64-row chunk); without: one workgroup per (b, h)
+    for use_scratch in (True, False):
+        scr = torch.zeros(L.hig_linattn_ctx_scratch_floats(B, T, H, hd), device=DEV) if use_scratch else None
+        A.zero_()
+        kst.zero_()
+        _lib.check(L.hig_linattn_ctx(g.data_ptr() + 4 * d, g.data_ptr() + 8 * d, 3 * d, B, T, H, hd, P(lg), P(A), P(kst),
+                                     P(scr), s))
+        assert rel(A, A_ref) < 1e-5, (use_scratch, rel(A, A_ref))
     _lib.check(L.hig_linattn_apply(P(g), 3 * d, P(A), P(y), d, B, T, H, hd, s))
     torch.cuda.synchronize()
     assert rel(A, A_ref) < 5e-6      # fp32 exp/sum vs fp64
