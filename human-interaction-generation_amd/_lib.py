@@ -30,7 +30,7 @@ SYMBOLS = (
     "hig_timestep_embedding", "hig_q_sample", "hig_p_sample_step", "hig_dec_timesteps",
     "hig_masked_mse", "hig_sumsq_partial", "hig_clip_adam",
     "hig_text_head_workspace_bytes", "hig_text_head_bwd_workspace_bytes", "hig_text_head_fwd", "hig_text_head_bwd",
-    "hig_layernorm", "hig_gather_rows", "hig_scatter_add_rows", "hig_gather_frames", "hig_recover_joints", "hig_transpose_batch", "hig_linattn_ctx_scratch_floats",
+    "hig_layernorm", "hig_gather_rows", "hig_scatter_add_rows", "hig_gather_frames", "hig_recover_joints", "hig_transpose_batch", "hig_linattn_ctx_scratch_floats", "hig_pair_mse",
 )
 
 
@@ -113,6 +113,7 @@ def lib():
         L.hig_p_sample_step.argtypes = [vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, vp]
         L.hig_dec_timesteps.argtypes = [vp, i32, vp]
         L.hig_masked_mse.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+        L.hig_pair_mse.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
         L.hig_sumsq_partial.argtypes = [vp, i64, f32, vp, vp]
         L.hig_clip_adam.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, vp, vp, vp]
         L.hig_text_head_workspace_bytes.restype = i64

@@ -187,6 +187,98 @@ int stream_blocks(int64_t total) {
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
+// ---- two-person losses (DDPMMulTrainer.backward_G, mul_ddpm_trainer.py:223-247) ------------------------
+// Row r of the model batch, token t: l[r][t] = mean_f (pred - target)^2 over all F features, except the
+// init-pose token t == 0 which is scored on its first 4 features only.  rowloss[r] = sum_{t < len[r]} l[r][t].
+__global__ __launch_bounds__(256) void pair_rowloss_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                           const int64_t* __restrict__ length, int R, int T, int F,
+                                                           float* __restrict__ rowloss) {
+  __shared__ float wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x;
+  int64_t l = length ? length[r] : T;
+  l = l < 0 ? 0 : (l > T ? T : l);
+  float acc = 0.f;
+  for (int t = wave; t < (int)l; t += 4) {
+    const int nf = t == 0 ? 4 : F;
+    const float* p = pred + ((int64_t)r * T + t) * F;
+    const float* q = target + ((int64_t)r * T + t) * F;
+    float sq = 0.f;
+    for (int f = lane; f < nf; f += 64) {
+      const float dlt = p[f] - q[f];
+      sq += dlt * dlt;
+    }
+    sq = wave_sum(sq);
+    acc += sq / (float)nf;
+  }
+  if (lane == 0) wsum[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) rowloss[r] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+// One block.  pit == 0: loss = sum_r rowloss / sum(mask), every row active.  pit == 1 (rows = [m1|c1, m1|c2,
+// m2|c2, m2|c1], R = 4P): S0[p] = L[p] + L[2P + p], S1[p] = L[P + p] + L[3P + p]; loss = sum_p min(S0, S1) /
+// (sum(mask) / 2); only the rows of the cheaper caption assignment of each pair get a gradient (ties: the first).
+// rowscale[r] = d loss / d rowloss[r].
+__global__ __launch_bounds__(256) void pair_select_kernel(const float* __restrict__ rowloss,
+                                                          const int64_t* __restrict__ length, int R, int T, int pit,
+                                                          float* __restrict__ loss, float* __restrict__ rowscale) {
+  __shared__ float red[256];
+  __shared__ float scnt;
+  float cnt = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    int64_t l = length ? length[r] : T;
+    cnt += (float)(l < 0 ? 0 : (l > T ? T : l));
+  }
+  red[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scnt = red[0];
+  __syncthreads();
+  const float denom = pit ? scnt * 0.5f : scnt;
+  float part = 0.f;
+  if (pit) {
+    const int P = R / 4;
+    for (int p = threadIdx.x; p < P; p += 256) {
+      const float s0 = rowloss[p] + rowloss[2 * P + p], s1 = rowloss[P + p] + rowloss[3 * P + p];
+      const bool first = s0 <= s1;
+      part += first ? s0 : s1;
+      rowscale[p] = rowscale[2 * P + p] = first ? 1.0f / denom : 0.f;
+      rowscale[P + p] = rowscale[3 * P + p] = first ? 0.f : 1.0f / denom;
+    }
+  } else {
+    for (int r = threadIdx.x; r < R; r += 256) {
+      part += rowloss[r];
+      rowscale[r] = 1.0f / denom;
+    }
+  }
+  __syncthreads();
+  red[threadIdx.x] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0] / denom;
+}
+__global__ __launch_bounds__(256) void pair_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                        const int64_t* __restrict__ length,
+                                                        const float* __restrict__ rowscale, int R, int T, int F,
+                                                        float* __restrict__ dpred) {
+  const int64_t n = (int64_t)R * T * F;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % F);
+    const int64_t rt = i / F;
+    const int t = (int)(rt % T), r = (int)(rt / T);
+    const int64_t l = length ? length[r] : T;
+    float g = 0.f;
+    if (t < l && (t > 0 || f < 4)) g = rowscale[r] * 2.0f * (pred[i] - target[i]) / (float)(t == 0 ? 4 : F);
+    dpred[i] = g;
+  }
+}
+
 }  // namespace
 
 extern "C" int hig_q_sample(const float* x0, const float* noise, const int64_t* t, const float* tab,
@@ -214,6 +306,26 @@ extern "C" int hig_dec_timesteps(int64_t* t, int32_t B, hig_stream_t s) {
   HIG_REQUIRE(t && B > 0, "hig_dec_timesteps: bad arguments");
   hipLaunchKernelGGL(dec_t_kernel, dim3((B + 255) / 256), dim3(256), 0, hig_stream(s), t, B);
   HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+extern "C" int hig_pair_mse(const float* pred, const float* target, const int64_t* length, int32_t R, int32_t T,
+                            int32_t F, int32_t pit, float* loss, float* dpred, float* scratch, hig_stream_t s) {
+  HIG_REQUIRE(pred && target && loss && scratch && R > 0 && T > 0 && F >= 4, "hig_pair_mse: bad arguments");
+  HIG_REQUIRE(!pit || R % 4 == 0, "hig_pair_mse: PIT needs 4 groups of rows (got %d rows)", R);
+  float* rowloss = scratch;          // [R]
+  float* rowscale = scratch + R;     // [R]
+  hipLaunchKernelGGL(pair_rowloss_kernel, dim3(R), dim3(256), 0, hig_stream(s), pred, target, length, R, T, F, rowloss);
+  HIG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(pair_select_kernel, dim3(1), dim3(256), 0, hig_stream(s), rowloss, length, R, T, pit, loss,
+                     rowscale);
+  HIG_CHECK_LAUNCH();
+  if (dpred) {
+    const int64_t n = (int64_t)R * T * F;
+    hipLaunchKernelGGL(pair_grad_kernel, dim3(stream_blocks(n)), dim3(256), 0, hig_stream(s), pred, target, length,
+                       rowscale, R, T, F, dpred);
+    HIG_CHECK_LAUNCH();
+  }
   return HIG_OK;
 }
 

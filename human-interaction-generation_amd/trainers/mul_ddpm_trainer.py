@@ -12,6 +12,7 @@ from collections import Counter, OrderedDict
 import numpy as np
 import torch
 
+from .. import _lib
 from .ddpm_trainer import DDPMTrainer, _core
 
 
@@ -79,6 +80,41 @@ class DDPMMulTrainer(DDPMTrainer):
             loss_mot_rec = per_assign.view(2, rows // 4).min(dim=0).values.sum() / (self.src_mask.sum() / 2)
         self.loss_mot_rec = loss_mot_rec
         return OrderedDict({'loss_mot_rec': self.loss_mot_rec.item()})
+
+    # ---- MI355X fused step (inherits train_step_fused / train_step_captured) ---------------------
+    def _fused_fwd_bwd(self, x_start, t, length, xf_proj, xf_out, noise):
+        """Two-person version of the fused forward/backward: x_start = cat([motion1, motion2]) (2B, T, F),
+        t (B,) or (2B,), length (B,) per pair.  PIT mode (no label file): the noised motions run twice,
+        rows [m1|c1, m1|c2, m2|c2, m2|c1] -- xf_proj / xf_out must hold the 4B text embeddings in that
+        order (2B rows [c1 | c2] with a label file) -- and `hig_pair_mse` picks the cheaper caption
+        assignment per pair (mul_ddpm_trainer.py:96-131, 223-247)."""
+        if not self.multi:
+            return super()._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise)
+        core = _core(self.encoder)
+        L = _lib.lib()
+        st = self.fused_state()
+        B2, T, F = x_start.shape
+        B = B2 // 2
+        t2 = t if t.numel() == B2 else torch.cat([t, t])
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        x_t = self.diffusion.q_sample(x_start, t2, noise=noise)
+        pit = not self.with_label
+        if pit:   # gaussian_diffusion.py:996-1001 (forward_twice)
+            x_t = torch.cat([x_t[:B], x_t[:B], x_t[B:], x_t[B:]])
+            noise = torch.cat([noise[:B], noise[:B], noise[B:], noise[B:]])
+            t2 = torch.cat([t2, t2])
+        rows = x_t.shape[0]
+        len_rows = torch.cat([length] * (rows // B)).contiguous()
+        assert xf_proj.shape[0] == rows and xf_out.shape[0] == rows, "text embeddings must cover the model batch"
+        pred, saved = core._launch_forward(x_t, t2, len_rows, xf_proj, xf_out, training=True)
+        dpred = torch.empty_like(pred)
+        scr = st.get("pair_scratch")
+        if scr is None or scr.numel() < 2 * rows:
+            scr = st["pair_scratch"] = torch.zeros(2 * rows, device=pred.device, dtype=torch.float32)
+        _lib.check(L.hig_pair_mse(_lib.ptr(pred), _lib.ptr(noise.contiguous()), _lib.ptr(len_rows), rows, T, F, int(pit),
+                                  _lib.ptr(st["loss"]), _lib.ptr(dpred), _lib.ptr(scr), _lib.stream_ptr()))
+        core._launch_backward(x_t, t2, len_rows, xf_out, saved, dpred, want_dx=False)
 
     # ---- sampling ---------------------------------------------------------------------------
     def generate_batch(self, caption1, caption2, m_lens, dim_pose):

@@ -388,6 +388,12 @@ int hig_masked_mse(const float* pred, const float* target, const int64_t* length
  * g *= inv_world (DDP mean); gnorm = ||g||; g *= min(1, max_norm/(gnorm+1e-6)); Adam step.
  * `state`: device {float gnorm_out; int32 step} ; scratch: HIG_NORM_BLOCKS floats. */
 #define HIG_NORM_BLOCKS 1024
+/* Two-person losses of DDPMMulTrainer.backward_G (mul_ddpm_trainer.py:223-247): per-token MSE with the
+ * init-pose token (t == 0) scored on its first 4 features, masked by length[r].  pit == 0: the labelled loss
+ * sum / sum(mask).  pit == 1: rows are [m1|c1, m1|c2, m2|c2, m2|c1] (R = 4 x pairs); per pair the cheaper of the
+ * two caption assignments, / (sum(mask) / 2).  dpred (optional) = d loss / d pred.  scratch: 2 R floats. */
+int hig_pair_mse(const float* pred, const float* target, const int64_t* length, int32_t R, int32_t T,
+                 int32_t F, int32_t pit, float* loss, float* dpred, float* scratch, hig_stream_t s);
 int hig_sumsq_partial(const float* g, int64_t n, float inv_world, float* scratch, hig_stream_t s);
 int hig_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
                   float b2, float eps, float max_norm, float inv_world, const float* scratch,

@@ -243,3 +243,53 @@ def test_cap_id_mode_class_embeddings_single_text_token():
     assert rel(x.grad, xr.grad) < 1e-4
     assert rel(m.cap_embedding.grad, sd["cap_embedding"].grad) < 1e-4          # through xf_out AND xf_proj
     assert rel(m.text_proj[0].weight.grad, sd["text_proj.0.weight"].grad) < 1e-4
+
+
+@pytest.mark.parametrize("with_label", [False, True])
+def test_fused_two_person_step_equals_reference_sequence(with_label):
+    """DDPMMulTrainer.train_step_fused (hig_pair_mse + flat clip+Adam) == training_losses(forward_twice) +
+    backward_G + clip + Adam through autograd, on the core parameters; then the captured step == the fused one."""
+    c = fill.ICASES["config1x2"]
+    B, T, Fd = c["B"], c["T"], c["F"]
+    rows = 2 * B if with_label else 4 * B
+    x0 = (fill.tensor_for("fused2.x0", (2 * B, T, Fd)) * 10).to(DEV)
+    noise = (fill.tensor_for("fused2.noise", x0.shape) * 10).to(DEV)
+    tt = torch.tensor(c["t"], device=DEV)
+    length = torch.tensor(c["lengths"], device=DEV)
+    xf_proj = (fill.tensor_for("fused2.xp", (rows, 4 * c["d"])) * 10).to(DEV)
+    xf_out = (fill.tensor_for("fused2.xo", (rows, c["N"], c["Lt"])) * 10).to(DEV)
+    label = "labels/" if with_label else None
+    # reference sequence through autograd, core parameters only
+    m1 = build(c).train()
+    tr1 = _trainer(c, m1, label_path=label)
+    opt = torch.optim.Adam(m1.core_parameters(), lr=2e-4)
+    len_rows = torch.cat([length] * (rows // B))
+    out = tr1.diffusion.training_losses(m1, x0, torch.cat([tt, tt]), noise=noise, forward_twice=not with_label,
+                                        model_kwargs={"xf_proj": xf_proj, "xf_out": xf_out, "length": len_rows})
+    tr1.real_noise, tr1.fake_noise = out["target"], out["pred"]
+    tr1.src_mask = m1.generate_src_mask(T, len_rows).to(DEV)
+    tr1.backward_G()
+    tr1.loss_mot_rec.backward()
+    gn = torch.nn.utils.clip_grad_norm_(m1.core_parameters(), 0.5)
+    opt.step()
+    oracle = (IR.labelled_loss if with_label else IR.pit_loss)(out["pred"].detach().cpu(), out["target"].cpu(),
+                                                              tr1.src_mask.cpu())
+    assert abs(tr1.loss_mot_rec.item() - oracle.item()) < 1e-5 * oracle.item()
+    # fused
+    m2 = build(c).train()
+    tr2 = _trainer(c, m2, label_path=label)
+    l2 = tr2.train_step_fused(x0, tt, length, xf_proj, xf_out, noise=noise)
+    st = tr2.fused_state()
+    assert abs(l2.item() - tr1.loss_mot_rec.item()) < 1e-5 * abs(l2.item())
+    assert abs(st["gnorm"].item() - gn.item()) < 1e-4 * gn.item()
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        # Adam's first step is lr * g / (|g| + eps): elements whose gradient is within rounding of 1e-8 move by a
+        # visibly different fraction of lr = 2e-4 (key.bias: its true gradient is zero, pure rounding noise)
+        assert (a - b).abs().max().item() < 5e-6, k
+    # captured
+    m3 = build(c).train()
+    tr3 = _trainer(c, m3, label_path=label)
+    l3 = tr3.train_step_captured(x0, tt, length, xf_proj, xf_out, noise=noise)
+    assert abs(l3.item() - l2.item()) <= 1e-6 * abs(l2.item())
+    for (k, a), (_, b) in zip(m2.state_dict().items(), m3.state_dict().items()):
+        assert torch.equal(a, b), k
