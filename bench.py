@@ -315,11 +315,27 @@ def main():
 
             k2 = max(5, a.steps // 2)
             e_f, e_fb = timed(fwd2, k2, 2, 1), timed(fwdbwd2, k2, 2, 1)
+            # PIT training step (what tools/train.py runs): 16 pairs -> 64 model rows [m1|c1, m1|c2, m2|c2, m2|c1]
+            args2 = types.SimpleNamespace(device=device, diffusion_steps=1000, is_train=True, lr=2e-4, batch_size=16,
+                                          num_epochs=1, log_every=50, save_latest=500, save_every_e=5, is_continue=False,
+                                          model_dir="/tmp", multi=True, label_path=None, cap_id=False)
+            tr2 = hig_amd.DDPMMulTrainer(args2, m2.train())
+            x0p, tp, lp = i2["x0"][:32].contiguous(), i2["t"][:16].contiguous(), i2["length"][:16].contiguous()
+            nz2 = torch.randn_like(x0p)
+
+            def pit_step():
+                tr2.train_step_captured(x0p, tp, lp, i2["xf_proj"], i2["xf_out"], noise=nz2)
+
+            e_pit = timed(pit_step, k2, 2, 1)
+            m2.eval()
             extra["two_person"] = {
+                "pit_train_step_ms": round(e_pit / k2 * 1e3, 3),
+                "pit_train_pairs_per_s": round(16 * k2 / e_pit, 1),
                 "fwd_frames_per_s": round(c2["B"] * c2["T"] * k2 / e_f, 1), "fwd_ms": round(e_f / k2 * 1e3, 3),
                 "fwd_bwd_frames_per_s": round(c2["B"] * c2["T"] * k2 / e_fb, 1), "fwd_bwd_ms": round(e_fb / k2 * 1e3, 3),
                 "what": "MotionInteractionTransformer, 32 pairs (model batch 64) x 91 tokens x 263 features, d=512 L=8, "
-                        "f32 products; frames = person-tokens"}
+                        "f32 products; frames = person-tokens.  pit_train_step: 16 pairs run twice (64 rows), q_sample + "
+                        "fwd + PIT loss + bwd + clip + Adam as one hipGraph"}
             # ---- BASELINE config 5 shape: long sequence, wide model (hd = 128), bf16 products ----
             c5 = dict(c, B=32, T=300, d=1024, L=12, H=8, ff=1024)
             m5 = build_model(c5, device).eval()
