@@ -507,3 +507,40 @@ def test_checkpoint_roundtrip_and_reference_keys(gold, tmp_path):
         a = m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
         b = m2(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("no_eff", [False, True])
+def test_edge_cases_empty_sample_single_frame_batch_of_one(no_eff):
+    """Ragged extremes against the oracle, forward and backward: a sample with length 0 (every key masked),
+    length 1, T not a multiple of anything, a single frame (T = 1), batch of one, lengths given past T."""
+    base = dict(F=12, d=64, H=8, L=2, ff=128, N=77, Lt=32, num_frames=70)
+    for (B, T, lens) in ((3, 67, (0, 1, 67)), (1, 1, (1,)), (2, 5, (9, 2))):
+        c = dict(base, B=B, T=T)
+        m = build(c, no_eff=no_eff).train()
+        inp = fill.inputs(B, T, c["F"], c["d"], c["N"], c["Lt"], lens, (0, 999, 431)[:B])
+        gi = {k: v.to(DEV) for k, v in inp.items()}
+        x = gi["x"].clone().requires_grad_(True)
+        out = m(x, gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+        r = fill.tensor_for("edge.r.%d.%d" % (B, T), out.shape) * 10.0
+        (out * r.to(DEV)).sum().backward()
+        p = {k: v.double().requires_grad_(True) for k, v in
+             fill.core_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"]).items()}
+        xr = inp["x"].double().requires_grad_(True)
+        ref = R.denoiser_forward(p, xr, inp["t"], inp["length"], inp["xf_proj"].double(), inp["xf_out"].double(),
+                                 c["H"], c["L"], no_eff=no_eff)
+        assert torch.isfinite(out).all()
+        if no_eff:
+            # padded QUERY rows of the full-attention variant carry logits quantised by the reference's -1e5 offset
+            # (App. B-3): gate the valid rows, and the rest loosely
+            for b, n in enumerate(lens):
+                n = min(n, T)
+                if n:
+                    assert rel(out[b, :n], ref[b, :n]) < 1e-3, (B, T, b)
+            continue
+        assert rel(out, ref) < 1e-5, (B, T, rel(out, ref))
+        (ref * r.double()).sum().backward()
+        assert rel(x.grad, xr.grad) < 1e-4
+        named = dict(m.named_parameters())
+        for k in ("temporal_decoder_blocks.0.sa_block.value.weight", "temporal_decoder_blocks.1.ffn.linear1.bias",
+                  "sequence_embedding", "out.weight"):
+            assert (named[k].grad.cpu().double() - p[k].grad).norm() <= 1e-4 * p[k].grad.norm() + 1e-9, (k, B, T)
