@@ -171,14 +171,17 @@ class _FlatParams:
     """One contiguous fp32 device buffer holding every denoiser-core parameter (and a twin for
     gradients) so that (a) q/k/v, key/value and the 3L stylization `emb_layers` matrices are
     single fused-GEMM operands, (b) the RCCL all-reduce and the fused clip+Adam see ONE buffer.
-    The nn.Parameters become views into it; state-dict names/shapes are untouched."""
+    The nn.Parameters become views into it; state-dict names/shapes are untouched.
+    The text-head parameters (when the model has a HIP text head) follow the core in the same
+    buffer -- `[0, core_numel)` core, `[core_numel, numel)` text head -- so the fused training step
+    can update everything that is trainable with one all-reduce and one clip+Adam."""
 
     ALIGN = 64  # floats (256 B)
 
     def __init__(self, model):
         glob, layers = _core_param_order(model)
         groups = glob + [g for l in layers for g in l]
-        self.params = [p for g in groups for p in g]
+        self.params = [p for g in groups for p in g]          # denoiser core, hig.h table order
         dev = self.params[0].device
         assert all(p.device == dev and p.dtype == torch.float32 for p in self.params)
         offs, o = [], 0
@@ -189,11 +192,20 @@ class _FlatParams:
             for p in g:
                 offs.append(o)
                 o += p.numel()
-        self.numel = (o + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.core_numel = (o + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.offsets = offs
+        # text head (HIG_T_* / HIG_TL_* order), one aligned group per tensor
+        self.text_params = list(model._text_params()) if model._has_hip_text_head() else []
+        if not all(p.device == dev and p.dtype == torch.float32 for p in self.text_params):
+            self.text_params = []
+        self.text_offsets, o = [], self.core_numel
+        for p in self.text_params:
+            self.text_offsets.append(o)
+            o += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.numel = o
         self.flat = torch.zeros(self.numel, device=dev, dtype=torch.float32)
         with torch.no_grad():
-            for p, off in zip(self.params, offs):
+            for p, off in zip(self.params + self.text_params, offs + self.text_offsets):
                 view = self.flat[off:off + p.numel()].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
@@ -224,10 +236,20 @@ class _FlatParams:
             self._gtable = self.table(self.grad.data_ptr())
         return self._gtable
 
+    def text_grad_table(self, slots):
+        """Pointer table (HIG_T_* order, NULL where `slots` is False) into the flat GRADIENT buffer."""
+        self.ensure_grad()
+        arr = (C.c_void_p * len(slots))()
+        it = iter(self.text_offsets)
+        for i, present in enumerate(slots):
+            arr[i] = self.grad.data_ptr() + 4 * next(it) if present else None
+        return arr
+
     def valid(self):
         base, end = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.numel
         return all(p.is_cuda and base <= p.data_ptr() < end for p in self.params[:3] + self.params[-3:]) \
-            and all(p.data_ptr() == base + 4 * o for p, o in zip(self.params[:8], self.offsets[:8]))
+            and all(p.data_ptr() == base + 4 * o for p, o in zip(self.params[:8], self.offsets[:8])) \
+            and all(p.data_ptr() == base + 4 * o for p, o in zip(self.text_params, self.text_offsets))
 
 
 class _WorkspacePool:
@@ -531,6 +553,13 @@ class MotionTransformer(nn.Module):
 
 
     # ---- text head (hig_text_head_*) -------------------------------------------------------
+    def _has_hip_text_head(self):
+        """True when this model owns a text head the HIP kernels cover (not cap_id, head dim in 8..64)."""
+        if getattr(self, "text_head", "hip") != "hip" or not hasattr(self, "textTransEncoder"):
+            return False
+        l0 = self.textTransEncoder.layers[0]
+        return self.text_latent_dim // l0.self_attn.num_heads in (8, 16, 32, 64)
+
     def _text_params(self):
         """Text-head parameters in hig.h table order (HIG_T_*, then HIG_TL_* per layer)."""
         pre = self.text_pre_proj
@@ -582,24 +611,33 @@ class MotionTransformer(nn.Module):
             return xf_proj, xf_out, None
         return xf_proj, xf_out, (dims, ws)
 
-    def _launch_text_head_backward(self, clip_out, eot, xf_out, saved, dxf_out, dxf_proj, want_dclip):
+    def _launch_text_head_backward(self, clip_out, eot, xf_out, saved, dxf_out, dxf_proj, want_dclip,
+                                   into_flat=False):
+        """into_flat: write the parameter gradients into the flat gradient buffer (fused training step)
+        instead of a fresh scratch buffer (autograd path)."""
         dims, ws = saved
         L = _lib.lib()
         tp = self._text_params()
         dev = clip_out.device
-        offs, o = [], 0
-        for p in tp:
-            offs.append(o)
-            o += (p.numel() + 63) // 64 * 64
-        gflat = torch.empty(o, device=dev, dtype=torch.float32)
-        grads = [gflat[off:off + p.numel()].view(p.shape) for p, off in zip(tp, offs)]
+        if into_flat:
+            fp = self.flat_params()
+            assert len(fp.text_params) == len(tp), "text head is not part of the flat parameter buffer"
+            grads, gtable = None, fp.text_grad_table(self._text_slots)
+        else:
+            offs, o = [], 0
+            for p in tp:
+                offs.append(o)
+                o += (p.numel() + 63) // 64 * 64
+            gflat = torch.empty(o, device=dev, dtype=torch.float32)
+            grads = [gflat[off:off + p.numel()].view(p.shape) for p, off in zip(tp, offs)]
+            gtable = self._text_table(grads)
         dclip = torch.empty_like(clip_out) if want_dclip else None
         bws = self._pool.take("txt_bwd", L.hig_text_head_bwd_workspace_bytes(C.byref(dims)), dev)
         _lib.check(L.hig_text_head_bwd(
             C.byref(dims), self._text_table(tp), _lib.ptr(clip_out), _lib.ptr(eot), _lib.ptr(xf_out), _lib.ptr(ws),
             _lib.ptr(None if dxf_out is None else dxf_out.contiguous()),
             _lib.ptr(None if dxf_proj is None else dxf_proj.contiguous()),
-            self._text_table(grads), _lib.ptr(dclip), _lib.ptr(bws), _lib.stream_ptr()))
+            gtable, _lib.ptr(dclip), _lib.ptr(bws), _lib.stream_ptr()))
         self._pool.give("txt_bwd", bws, dev)
         self._pool.give("txt_t", ws, dev)
         return grads, dclip

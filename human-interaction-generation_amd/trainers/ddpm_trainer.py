@@ -186,8 +186,12 @@ class DDPMTrainer(object):
         for epoch in range(cur_epoch, self.opt.num_epochs):
             self.train_mode()
             for i, batch_data in enumerate(train_loader):
-                self.forward(batch_data)
-                log_dict = self.update()
+                if getattr(self.opt, "fused_step", False):
+                    # MI355X path: the same update as forward() + update(), as one captured hipGraph
+                    log_dict = OrderedDict({'loss_mot_rec': self.train_fused_batch(batch_data).item()})
+                else:
+                    self.forward(batch_data)
+                    log_dict = self.update()
                 for k, v in log_dict.items():
                     logs[k] = logs.get(k, 0) + v
                 it += 1
@@ -225,12 +229,29 @@ class DDPMTrainer(object):
             }
         return self._fused
 
-    def _fused_fwd_bwd(self, x_start, t, length, xf_proj, xf_out, noise):
-        """q_sample -> denoiser forward -> masked MSE -> denoiser backward into the flat gradient."""
+    def _text_forward(self, clip_out, eot):
+        """Text head of the fused step: CLIP features (B, N, W) + EOT indices -> xf_proj, xf_out and the saved
+        activations `_text_backward` needs."""
+        core = _core(self.encoder)
+        xf_proj, xf_out, tsaved = core._launch_text_head(clip_out, eot, training=True)
+        return xf_proj, xf_out, (clip_out, eot, xf_out, tsaved)
+
+    def _text_backward(self, tstate, dxf_proj, dxf_out):
+        clip_out, eot, xf_out, tsaved = tstate
+        _core(self.encoder)._launch_text_head_backward(clip_out, eot, xf_out, tsaved, dxf_out, dxf_proj,
+                                                       want_dclip=False, into_flat=True)
+
+    def _fused_fwd_bwd(self, x_start, t, length, xf_proj, xf_out, noise, clip_out=None, eot=None):
+        """q_sample -> [text head] -> denoiser forward -> masked MSE -> denoiser backward [-> text head backward]
+        into the flat gradient.  With `clip_out` / `eot` the text embeddings are computed here and the text
+        head is trained too (the reference's full update); otherwise xf_proj / xf_out are inputs."""
         core = _core(self.encoder)
         L = _lib.lib()
         st = self.fused_state()
         B, T, F = x_start.shape
+        tstate = None
+        if clip_out is not None:
+            xf_proj, xf_out, tstate = self._text_forward(clip_out, eot)
         if noise is None:
             noise = torch.randn_like(x_start)
         x_t = self.diffusion.q_sample(x_start, t, noise=noise)
@@ -239,15 +260,25 @@ class DDPMTrainer(object):
         _lib.check(L.hig_masked_mse(_lib.ptr(pred), _lib.ptr(noise), _lib.ptr(length), B, T, F,
                                     _lib.ptr(st["loss"]), _lib.ptr(dpred), _lib.ptr(st["mse_scratch"]),
                                     _lib.stream_ptr()))
-        core._launch_backward(x_t, t, length, xf_out, saved, dpred, want_dx=False)
+        _, dxp, dxo = core._launch_backward(x_t, t, length, xf_out, saved, dpred, want_dx=False)
+        if tstate is not None:
+            self._text_backward(tstate, dxp, dxo)
 
-    def _fused_clip_adam(self, world, lr):
+    def _fused_numel(self, with_text):
+        """Floats of the flat buffers one fused step covers: the core, or core + text head."""
+        fp = _core(self.encoder).flat_params()
+        if with_text and not fp.text_params:
+            raise RuntimeError("this model's text head is not on the HIP path (text_head='torch', cap_id or an "
+                               "unsupported head dim): the fused step cannot train it")
+        return fp.numel if with_text else fp.core_numel
+
+    def _fused_clip_adam(self, world, lr, with_text=False):
         """g /= world; clip_grad_norm_(0.5); Adam -- one norm pass + one update pass over the flat buffers."""
         core = _core(self.encoder)
         L = _lib.lib()
         st = self.fused_state()
         fp = core.flat_params()
-        n = fp.numel
+        n = self._fused_numel(with_text)
         _lib.check(L.hig_sumsq_partial(_lib.ptr(fp.grad), n, 1.0 / world, _lib.ptr(st["scratch"]),
                                        _lib.stream_ptr()))
         _lib.check(L.hig_clip_adam(_lib.ptr(fp.flat), _lib.ptr(fp.grad), _lib.ptr(st["m"]), _lib.ptr(st["v"]),
@@ -256,37 +287,70 @@ class DDPMTrainer(object):
                                    _lib.ptr(st["step"]), _lib.stream_ptr()))
         core._textctx_cache = None  # parameters changed under the cached text context
 
-    def train_step_fused(self, x_start, t, length, xf_proj, xf_out, noise=None, lr=None):
-        """One DDPM training step on device tensors, reference semantics
-        (ddpm_trainer.py:97-119,172-187) for the denoiser-core parameters:
+    def train_step_fused(self, x_start, t, length, xf_proj=None, xf_out=None, noise=None, lr=None, clip_out=None,
+                         eot=None):
+        """One DDPM training step on device tensors, reference semantics (ddpm_trainer.py:97-119,172-187):
           x_t = q_sample(x0, t, noise); pred = denoiser(x_t, t); loss = masked MSE(pred, noise);
           backward; grads = all_reduce(grads) / world; clip_grad_norm_(0.5); Adam.
+        With text embeddings (`xf_proj`, `xf_out`) the denoiser-core parameters are updated; with CLIP features
+        (`clip_out` (B, N, W) batch-first, `eot` (B,), see MotionTransformer._clip_features) the text head runs
+        inside the step and EVERY trainable parameter is updated -- the reference's full update.
         No host synchronisation: the loss stays on the device (`fused_state()['loss']`)."""
         st = self.fused_state()
-        self._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise)
-        world = st["allreduce"](_core(self.encoder).flat_params().grad)      # sum over ranks (RCCL, xGMI)
-        self._fused_clip_adam(world, lr)
+        with_text = clip_out is not None
+        n = self._fused_numel(with_text)
+        self._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise, clip_out=clip_out, eot=eot)
+        world = st["allreduce"](_core(self.encoder).flat_params().grad[:n])      # sum over ranks (RCCL, xGMI)
+        self._fused_clip_adam(world, lr, with_text)
         return st["loss"]
 
-    def train_step_captured(self, x_start, t, length, xf_proj, xf_out, noise=None, lr=None):
-        """The same step as hipGraphs.  Captured once per batch shape: graph A = q_sample + forward
-        + loss + backward, graph B = clip + Adam; the RCCL all-reduce of the flat gradient runs
-        between them on the same stream (world == 1: A and B are one graph).  Inputs are copied
-        into static device buffers, so the host cost per step is two graph launches whatever the
-        ~600 kernels inside; `t` arrives from the host sampler through the same staging copy
-        (the reference draws it with numpy, gaussian_diffusion.py:47-62)."""
+    def train_fused_batch(self, batch_data, captured=True, noise=None):
+        """forward(batch) + update() of the reference (ddpm_trainer.py:97-119,180-187) as ONE fused step over every
+        trainable parameter: batch -> device, t ~ sampler, CLIP features -> train_step_captured / _fused."""
+        caption, motions, m_lens = batch_data
+        x_start = motions.detach().to(self.device).float().contiguous()
+        B, T = x_start.shape[:2]
+        cur_len = torch.LongTensor([min(T, int(m_len)) for m_len in m_lens]).to(self.device)
+        t, _ = self.sampler.sample(B, x_start.device)
+        clip_out, eot = self.clip_inputs(caption)
+        step = self.train_step_captured if captured else self.train_step_fused
+        return step(x_start, t, cur_len, noise=noise, clip_out=clip_out, eot=eot)
+
+    def clip_inputs(self, caption):
+        """Captions -> (clip_out (B, N, W) batch-first fp32, eot (B,)) for `train_step_fused(clip_out=...)`: the
+        frozen CLIP tower on its own ops, outside the fused / captured region."""
+        core = _core(self.encoder)
+        tokens, feat = core._clip_features(caption, self.device)
+        return feat.permute(1, 0, 2).float().contiguous(), tokens.argmax(dim=-1).contiguous()
+
+    def train_step_captured(self, x_start, t, length, xf_proj=None, xf_out=None, noise=None, lr=None, clip_out=None,
+                            eot=None):
+        """The same step as hipGraphs.  Captured once per batch shape: graph A = q_sample [+ text head] + forward
+        + loss + backward, graph B = clip + Adam; the RCCL all-reduce of the flat gradient runs between them on
+        the same stream (world == 1: A and B are one graph).  Inputs are copied into static device buffers, so
+        the host cost per step is two graph launches whatever the ~600 kernels inside; `t` arrives from the
+        host sampler through the same staging copy (the reference draws it with numpy,
+        gaussian_diffusion.py:47-62).  Text inputs as in `train_step_fused`: embeddings, or CLIP features."""
         st = self.fused_state()
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        key = (tuple(x_start.shape), tuple(xf_out.shape), noise is None, world, lr)
+        with_text = clip_out is not None
+        text_in = (clip_out, eot) if with_text else (xf_proj, xf_out)
+        n = self._fused_numel(with_text)
+        key = (tuple(x_start.shape), tuple(text_in[0].shape), tuple(text_in[1].shape), with_text, noise is None,
+               world, lr)
         cap = st.setdefault("graphs", {}).get(key)
         if cap is None:
             static = {"x0": x_start.clone(), "t": t.clone(), "length": length.clone(),
-                      "xf_proj": xf_proj.clone(), "xf_out": xf_out.clone(),
+                      "ta": text_in[0].clone(), "tb": text_in[1].clone(),
                       "noise": None if noise is None else noise.clone()}
 
             def part_a():
-                self._fused_fwd_bwd(static["x0"], static["t"], static["length"], static["xf_proj"],
-                                    static["xf_out"], static["noise"])
+                if with_text:
+                    self._fused_fwd_bwd(static["x0"], static["t"], static["length"], None, None, static["noise"],
+                                        clip_out=static["ta"], eot=static["tb"])
+                else:
+                    self._fused_fwd_bwd(static["x0"], static["t"], static["length"], static["ta"], static["tb"],
+                                        static["noise"])
 
             # warm-up (allocations, workspace pools) on a side stream, as torch.cuda.graph requires;
             # it runs a real step, so restore parameters / moments / step counter afterwards
@@ -297,7 +361,7 @@ class DDPMTrainer(object):
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 part_a()
-                self._fused_clip_adam(1, lr)
+                self._fused_clip_adam(1, lr, with_text)
             torch.cuda.current_stream().wait_stream(s)
             with torch.no_grad():
                 fp.flat.copy_(keep[0])
@@ -308,26 +372,26 @@ class DDPMTrainer(object):
             if world == 1:
                 with torch.cuda.graph(ga):
                     part_a()
-                    self._fused_clip_adam(1, lr)
+                    self._fused_clip_adam(1, lr, with_text)
             else:
                 with torch.cuda.graph(ga):
                     part_a()
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb, pool=ga.pool()):
-                    self._fused_clip_adam(world, lr)
+                    self._fused_clip_adam(world, lr, with_text)
             cap = st["graphs"][key] = (static, ga, gb)
         static, ga, gb = cap
         with torch.no_grad():
             static["x0"].copy_(x_start)
             static["t"].copy_(t)
             static["length"].copy_(length)
-            static["xf_proj"].copy_(xf_proj)
-            static["xf_out"].copy_(xf_out)
+            static["ta"].copy_(text_in[0])
+            static["tb"].copy_(text_in[1])
             if noise is not None:
                 static["noise"].copy_(noise)
         ga.replay()
         if gb is not None:
-            st["allreduce"](_core(self.encoder).flat_params().grad)
+            st["allreduce"](_core(self.encoder).flat_params().grad[:n])
             gb.replay()
         _core(self.encoder)._textctx_cache = None
         return st["loss"]

@@ -82,17 +82,20 @@ class DDPMMulTrainer(DDPMTrainer):
         return OrderedDict({'loss_mot_rec': self.loss_mot_rec.item()})
 
     # ---- MI355X fused step (inherits train_step_fused / train_step_captured) ---------------------
-    def _fused_fwd_bwd(self, x_start, t, length, xf_proj, xf_out, noise):
+    def _fused_fwd_bwd(self, x_start, t, length, xf_proj, xf_out, noise, clip_out=None, eot=None):
         """Two-person version of the fused forward/backward: x_start = cat([motion1, motion2]) (2B, T, F),
         t (B,) or (2B,), length (B,) per pair.  PIT mode (no label file): the noised motions run twice,
         rows [m1|c1, m1|c2, m2|c2, m2|c1] -- xf_proj / xf_out must hold the 4B text embeddings in that
         order (2B rows [c1 | c2] with a label file) -- and `hig_pair_mse` picks the cheaper caption
         assignment per pair (mul_ddpm_trainer.py:96-131, 223-247)."""
         if not self.multi:
-            return super()._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise)
+            return super()._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise, clip_out=clip_out, eot=eot)
         core = _core(self.encoder)
         L = _lib.lib()
         st = self.fused_state()
+        tstate = None
+        if clip_out is not None:     # CLIP features of the model batch's captions (4B rows in PIT mode)
+            xf_proj, xf_out, tstate = self._text_forward(clip_out, eot)
         B2, T, F = x_start.shape
         B = B2 // 2
         t2 = t if t.numel() == B2 else torch.cat([t, t])
@@ -114,7 +117,23 @@ class DDPMMulTrainer(DDPMTrainer):
             scr = st["pair_scratch"] = torch.zeros(2 * rows, device=pred.device, dtype=torch.float32)
         _lib.check(L.hig_pair_mse(_lib.ptr(pred), _lib.ptr(noise.contiguous()), _lib.ptr(len_rows), rows, T, F, int(pit),
                                   _lib.ptr(st["loss"]), _lib.ptr(dpred), _lib.ptr(scr), _lib.stream_ptr()))
-        core._launch_backward(x_t, t2, len_rows, xf_out, saved, dpred, want_dx=False)
+        _, dxp, dxo = core._launch_backward(x_t, t2, len_rows, xf_out, saved, dpred, want_dx=False)
+        if tstate is not None:
+            self._text_backward(tstate, dxp, dxo)
+
+    def train_fused_batch(self, batch_data, captured=True, noise=None):
+        """forward(batch) + update() of the reference (mul_ddpm_trainer.py:90-161, 251-258) as one fused step."""
+        if not self.multi:
+            return super().train_fused_batch(batch_data, captured, noise)
+        caption, caption1, caption2, x_start, cur_len, B, T = self._pair_inputs(batch_data)
+        if not self.with_label:
+            caption = caption + caption2 + caption1
+        t, _ = self.sampler.sample(B, x_start.device)
+        if self.cap_id:
+            raise NotImplementedError("cap_id models take class embeddings, not the text head: use forward()/update()")
+        clip_out, eot = self.clip_inputs(caption)
+        step = self.train_step_captured if captured else self.train_step_fused
+        return step(x_start.contiguous(), t, cur_len, noise=noise, clip_out=clip_out, eot=eot)
 
     # ---- sampling ---------------------------------------------------------------------------
     def generate_batch(self, caption1, caption2, m_lens, dim_pose):

@@ -115,3 +115,47 @@ def test_identity_pre_proj_and_split_bf16():
     m.precision = "bf16x3"
     got = m.encode_text(TEXT_CAPTIONS, DEV)
     assert rel(got[0], ref[0]) < 5e-5 and rel(got[1], ref[1]) < 5e-5
+
+
+def test_fused_step_with_text_head_equals_full_reference_update():
+    """train_fused_batch (text head inside the fused / captured step, one clip+Adam over core + text parameters)
+    == the reference sequence forward() + update() with torch's Adam over EVERY trainable parameter."""
+    import types
+    import hig_amd.models.gaussian_diffusion as gdm
+    from test_gpu_denoiser import _NoiseFeed, _patch
+    c = fill.CASES["config1"]
+    motions = fill.tensor_for("fts.motions", (c["B"], c["T"], c["F"])) * 10
+    batch = (TEXT_CAPTIONS[:2], motions, torch.tensor(c["lengths"]))
+    t_fixed = torch.tensor(c["t"])
+    res = {}
+    for mode in ("reference", "fused", "captured"):
+        m = build(c).train()
+        args = types.SimpleNamespace(device=torch.device(DEV), diffusion_steps=1000, is_train=True, lr=2e-4,
+                                     batch_size=c["B"], num_epochs=1, log_every=50, save_latest=500, save_every_e=5,
+                                     is_continue=False, model_dir="/tmp")
+        tr = hig_amd.DDPMTrainer(args, m)
+        tr.sampler.sample = lambda bs, dev: (t_fixed.to(dev), torch.ones(bs))
+        noise = (fill.tensor_for("fts.noise", motions.shape) * 10).to(DEV)
+        if mode == "reference":
+            tr.opt_encoder = torch.optim.Adam(m.parameters(), lr=2e-4)
+            undo = _patch(type("F", (), {"randn": None, "randn_like": staticmethod(lambda x, **_: noise)})())
+            try:
+                tr.forward(batch)
+                loss = tr.update()["loss_mot_rec"]
+            finally:
+                undo()
+        else:
+            loss = tr.train_fused_batch(batch, captured=(mode == "captured"), noise=noise).item()
+            fp = m.flat_params()
+            assert len(fp.text_params) == 6 + 12 * 4 and fp.numel > fp.core_numel
+        res[mode] = (loss, {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if not k.startswith("clip.")})
+    for mode in ("fused", "captured"):
+        assert abs(res[mode][0] - res["reference"][0]) < 1e-5 * abs(res["reference"][0]), mode
+        moved = 0
+        for k, v in res["reference"][1].items():
+            # Adam's first step moves by lr * g / (|g| + eps): only gradients within rounding of 1e-8 can differ visibly
+            assert (res[mode][1][k] - v).abs().max().item() < 5e-6, (mode, k)
+            moved += int(k.startswith("text") and (v - fill.tensor_for(k, v.shape)).abs().max().item() > 1e-5)
+        assert moved >= 50, moved              # the text head really was trained
+    for k, v in res["fused"][1].items():
+        assert torch.equal(res["captured"][1][k], v), k
