@@ -266,6 +266,19 @@ def main():
                         "accumulate/storage/optimizer" % ("RCCL all-reduce(%.0f MB)+" % (model.flat_params().numel * 4 / 1e6)
                                                           if world > 1 else "", mode)}
         model.precision = "f32"
+        # the reference's FULL update (text head trained too), as captured hipGraph(s): CLIP features in
+        caps = ["a person walks towards another person and shakes hands number %d" % i for i in range(B)]
+        clip_out, eot = trainer.clip_inputs(caps)
+
+        def full_step():
+            trainer.train_step_captured(inp["x0"], inp["t"], inp["length"], noise=noise, clip_out=clip_out, eot=eot)
+
+        el_f = timed(full_step, ksteps, 2, world)
+        extra["train_step_full_f32"] = {
+            "frames_per_s": round(B * T * ksteps * world / el_f, 1), "ms_per_step": round(el_f / ksteps * 1e3, 3),
+            "what": "as train_step_f32 plus the text head forward/backward inside the step and its %.1f M parameters in "
+                    "the same all-reduce / clip / Adam; hipGraph replay" % (
+                        (model.flat_params().numel - model.flat_params().core_numel) / 1e6)}
         model.eval()
         if world == 1:
             # ---- DDPM sampling, hipGraph replay, B=32 (BASELINE config 3 shape, fp32 here) ----

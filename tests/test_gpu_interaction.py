@@ -293,3 +293,26 @@ def test_fused_two_person_step_equals_reference_sequence(with_label):
     assert abs(l3.item() - l2.item()) <= 1e-6 * abs(l2.item())
     for (k, a), (_, b) in zip(m2.state_dict().items(), m3.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_pit_fused_batch_with_text_head_matches_reference_golden(gold):
+    """train_fused_batch (PIT mode, text head inside the captured step) reproduces the reference's own
+    DDPMMulTrainer.forward + update (golden g9): loss, pre-clip gradient norm, updated parameters."""
+    g = gold("g9_mul_trainer.npz")
+    c = fill.ICASES["config1x2"]
+    m = build(c).train()
+    trainer = _trainer(c, m)
+    B, T, Fd = c["B"], c["T"], c["F"]
+    motion1 = fill.tensor_for("g9.motion1", (B, T, Fd)) * 10
+    motion2 = fill.tensor_for("g9.motion2", (B, T, Fd)) * 10
+    t_fixed = torch.tensor(c["t"])
+    trainer.sampler.sample = lambda bs, dev: (t_fixed.to(dev), torch.ones(bs))
+    noise = (fill.tensor_for("g9.noise.0", (2 * B, T, Fd)) * 10).to(DEV)
+    loss = trainer.train_fused_batch((CAP1, CAP2, motion1, motion2, torch.tensor(c["lengths"]), None), noise=noise)
+    st = trainer.fused_state()
+    assert abs(loss.item() - float(g["loss_mot_rec"])) < 1e-4 * float(g["loss_mot_rec"])
+    assert abs(st["gnorm"].item() - float(g["gnorm"])) < 2e-4 * float(g["gnorm"])
+    sd = m.state_dict()
+    for k in g.files:
+        if k.startswith("p."):
+            assert (sd[k[2:]].cpu() - torch.tensor(g[k])).abs().max().item() < 2e-5, k
