@@ -128,3 +128,39 @@ def test_device_bank_feeds_the_two_person_trainer(tmp_path):
         tr.forward(bank.make_batch(list(range(start, start + 4))))
         logs = tr.update()
     assert tr.fake_noise.shape == (16, 91, 263) and np.isfinite(logs["loss_mot_rec"])
+
+
+@pytest.mark.gpu
+def test_end_to_end_two_person_pipeline(tmp_path):
+    """Disk -> HBM-resident bank -> captured PIT training steps (text head inside) -> hipGraph sampling ->
+    world-space joints: the whole two-person path of tools/train.py + tools/visualization.py on the device."""
+    import types
+    from hig_amd.models import gaussian_diffusion as gdm
+    from hig_amd.utils.motion_process import generated_to_joints
+    _, ds = make(tmp_path, "f32")
+    bank = DeviceMotionBank(ds, "cuda")
+    torch.manual_seed(0)
+    m = hig_amd.MotionInteractionTransformer(263, num_frames=90, latent_dim=64, ff_size=128, num_layers=2, num_heads=8,
+                                             text_latent_dim=32).to("cuda")
+    args = types.SimpleNamespace(device=torch.device("cuda"), diffusion_steps=1000, is_train=True, lr=2e-3, batch_size=4,
+                                 num_epochs=1, log_every=50, save_latest=500, save_every_e=5, is_continue=False,
+                                 model_dir=str(tmp_path), multi=True, label_path=None, cap_id=False)
+    tr = hig_amd.DDPMMulTrainer(args, m)
+    random.seed(11)
+    tr.train_mode()
+    losses = []
+    for it in range(40):
+        items = [(4 * it + k) % len(ds) for k in range(4)]
+        losses.append(tr.train_fused_batch(bank.make_batch(items)).item())
+    assert all(np.isfinite(losses))
+    assert abs(losses[0] - 1.0) < 0.1            # zero-initialised output head: the first loss is E[noise^2]
+    assert np.mean(losses[-5:]) < 0.9 * losses[0]  # and it trains
+    assert tr.fused_state()["step"].item() == 40
+    # sampling (50-step schedule, hipGraph loop) and joint recovery, all on the device
+    tr.diffusion = hig_amd.GaussianDiffusion(betas=gdm.get_named_beta_schedule("linear", 50),
+                                             model_mean_type=gdm.ModelMeanType.EPSILON,
+                                             model_var_type=gdm.ModelVarType.FIXED_SMALL, loss_type=gdm.LossType.MSE)
+    out = tr.generate_batch(["one pushes the other"], ["one is pushed by the other"], torch.tensor([91]), 263)
+    assert out.shape == (2, 90, 263) or out.shape == (2, 91, 263)
+    joints = generated_to_joints(out, ds.mean, ds.std, ds.init_mean, ds.init_std, joints_num=22)
+    assert joints.shape == (2, out.shape[1] - 1, 22, 3) and torch.isfinite(joints).all()
