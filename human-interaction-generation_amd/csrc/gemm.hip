@@ -27,6 +27,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef HIG_GEMM_NT
 #define HIG_GEMM_NT 0
 #endif
+#ifndef HIG_GEMM_LDS_EPI
+#define HIG_GEMM_LDS_EPI 1
+#endif
 
 namespace {
 
@@ -469,6 +472,54 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
       if (nk > 0) load_tiles(rbeg);
     }
 
+#if HIG_GEMM_LDS_EPI
+  // ---- epilogue through LDS: the accumulator layout (a lane = one row x 4 columns per quad) would write
+  // 32-byte pieces of 32 different rows per store instruction; staging the tile in LDS (free here: the main
+  // loop ended on a barrier and the next tile's first k-tile waits in registers) lets every instruction
+  // read `res` / `aux` and write C as whole 16-byte-per-lane rows (BJ * 4 contiguous bytes per row).
+  constexpr int CLD = BJ + 4;
+  if constexpr (2 * STAGE >= BI * CLD)      // (tiles whose staging buffers are smaller keep the direct epilogue)
+  if (a.vecc && ej0 + BJ <= g.J) {
+    float* sC = smem;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(sC + (wi * (32 * TI) + 32 * ti + lr) * CLD + wj * (32 * TJ) + 32 * tj + 8 * q + 4 * lh) =
+              f32x4{acc[tj][ti][4 * q], acc[tj][ti][4 * q + 1], acc[tj][ti][4 * q + 2], acc[tj][ti][4 * q + 3]};
+    __syncthreads();
+    constexpr int Q4 = BJ / 4, RPP = NTHREADS / Q4;     // float4 per row, rows per pass
+    const int c4 = tid % Q4, rr0 = tid / Q4;
+    const int j = ej0 + 4 * c4;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == HIG_EPI_BIAS || EPI == HIG_EPI_BIAS_GELU || EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_POS)
+      b4 = *reinterpret_cast<const f32x4*>(g.bias + j);
+#pragma unroll 4
+    for (int rr = rr0; rr < BI; rr += RPP) {
+      const int i = ei0 + rr;
+      if (i >= g.I) break;
+      f32x4 v = *reinterpret_cast<const f32x4*>(sC + rr * CLD + 4 * c4) + b4;
+      if (EPI == HIG_EPI_BIAS_POS) {
+        const int tp = (i % g.T) - g.pos_shift;
+        if (tp >= 0) v += *reinterpret_cast<const f32x4*>(g.pos + (int64_t)tp * g.ldpos + j);
+      }
+      if (EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_RES) v += *reinterpret_cast<const f32x4*>(g.res + (int64_t)i * g.ldr + j);
+      if (EPI == HIG_EPI_BIAS_GELU) {
+        if (g.aux) *reinterpret_cast<f32x4*>(g.aux + (int64_t)i * g.ldaux + j) = v;
+        v = f32x4{hig_gelu(v.x), hig_gelu(v.y), hig_gelu(v.z), hig_gelu(v.w)};
+      }
+      if (EPI == HIG_EPI_DGELU) {
+        const f32x4 z = *reinterpret_cast<const f32x4*>(g.aux + (int64_t)i * g.ldaux + j);
+        v = f32x4{v.x * hig_dgelu(z.x), v.y * hig_dgelu(z.y), v.z * hig_dgelu(z.z), v.w * hig_dgelu(z.w)};
+      }
+      *reinterpret_cast<f32x4*>(C + (int64_t)i * g.ldc + j) = v;
+    }
+    __syncthreads();   // the next tile's store_tiles() reuses this LDS
+    continue;
+  }
+#endif
   // ---- epilogue: lane holds, per accumulator quad q, columns j..j+3 of row i ----------
 #pragma unroll
   for (int ti = 0; ti < TI; ++ti) {

@@ -70,6 +70,55 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ g, float*
   out[(size_t)blockIdx.x * 256 + tid] = s;
 }
 
+// BK = 64 shape of the same loop: 8 global_load_dwordx4 + 8 ds_write_b128 + 16 ds_read_b128 + 32 MFMAs
+// (one accumulator) per barrier; 69.6 KB of LDS -> 2 workgroups per CU.
+__global__ __launch_bounds__(256) void probe_bk64(const float* __restrict__ g, float* __restrict__ out, int iters, int bmask) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2 * 64 * 68];
+  const int tid = threadIdx.x, lane = tid & 63;
+  f32x16 acc;
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int i = tid; i < 2 * 2 * 64 * 68; i += 256) (&lds[0][0])[i] = (float)(i & 7);
+  __syncthreads();
+  float4 stage[8];
+  const float* gp = g + (size_t)(blockIdx.x & bmask) * 4096 + tid * 4;
+  for (int it = 0; it < iters; ++it) {
+    const float* sx = lds[it & 1];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) stage[p] = *reinterpret_cast<const float4*>(gp + ((it * 8 + p) & 63) * 1024);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const float4 a4 = *reinterpret_cast<const float4*>(sx + (lane & 31) * 68 + ks * 8 + 4 * (lane >> 5));
+      const float4 b4 = *reinterpret_cast<const float4*>(sx + 64 * 68 + (lane & 31) * 68 + ks * 8 + 4 * (lane >> 5));
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.x, a4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.y, a4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.z, a4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.w, a4.w, acc, 0, 0, 0);
+    }
+    float* dst = lds[(it + 1) & 1];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) *reinterpret_cast<float4*>(dst + ((tid >> 4) + 16 * p) * 68 + 4 * (tid & 15)) = stage[p];
+    __syncthreads();
+  }
+  float s = 0.f;
+  for (int e = 0; e < 16; ++e) s += acc[e];
+  out[(size_t)blockIdx.x * 256 + tid] = s;
+}
+void run_bk64(int blocks, const float* g, float* out, int bmask) {
+  const int iters = 1000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL(probe_bk64, dim3(blocks), dim3(256), 0, 0, g, out, 10, bmask);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(probe_bk64, dim3(blocks), dim3(256), 0, 0, g, out, iters, bmask);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double flops = (double)blocks * 4 * iters * 32 * 4096.0;
+  printf("%-34s blocks=%5d acc/wave=1  %.3f ms  %.1f TFLOP/s\n", bmask == 15 ? "BK=64 loop, L2-resident" : "BK=64 loop", blocks, ms, flops / ms / 1e9);
+}
+
 template <int V, int NACC>
 void run(const char* name, int blocks, const float* g, float* out, int bmask = 0xffff, int rnd = 0) {
   const int iters = 2000;
@@ -109,6 +158,10 @@ int main() {
     run<2, 4>("+barrier, RANDOM operands", blocks, g, out, 0xffff, 1);
     run<4, 1>("+global load only, L2-resident", blocks, g, out, 15);
     run<3, 1>("+global load + ds_write, L2-res.", blocks, g, out, 15);
+    if (bpc <= 2) {
+      run_bk64(blocks, g, out, 0xffff);
+      run_bk64(blocks, g, out, 15);
+    }
   }
   return 0;
 }
