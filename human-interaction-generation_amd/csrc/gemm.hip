@@ -519,6 +519,54 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
     __syncthreads();   // the next tile's store_tiles() reuses this LDS
     continue;
   }
+  // tiles too large for one pass (128-row tiles of the bf16 modes, whose staging buffers are small): the two
+  // 64-row halves -- one wave row each -- go through LDS in turn
+  if constexpr (2 * STAGE < BI * CLD && TI == 2 && 2 * STAGE >= (BI / 2) * CLD)
+  if (a.vecc && ej0 + BJ <= g.J) {
+    float* sC = smem;
+    constexpr int Q4 = BJ / 4, RPP = NTHREADS / Q4, PROWS = BI / 2;
+    const int c4 = tid % Q4, rr0 = tid / Q4;
+    const int j = ej0 + 4 * c4;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == HIG_EPI_BIAS || EPI == HIG_EPI_BIAS_GELU || EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_POS)
+      b4 = *reinterpret_cast<const f32x4*>(g.bias + j);
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      if (wi == ps) {
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *reinterpret_cast<f32x4*>(sC + (32 * ti + lr) * CLD + wj * (32 * TJ) + 32 * tj + 8 * q + 4 * lh) =
+                  f32x4{acc[tj][ti][4 * q], acc[tj][ti][4 * q + 1], acc[tj][ti][4 * q + 2], acc[tj][ti][4 * q + 3]};
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int rr = rr0; rr < PROWS; rr += RPP) {
+        const int i = ei0 + ps * PROWS + rr;
+        if (i >= g.I) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(sC + rr * CLD + 4 * c4) + b4;
+        if (EPI == HIG_EPI_BIAS_POS) {
+          const int tp = (i % g.T) - g.pos_shift;
+          if (tp >= 0) v += *reinterpret_cast<const f32x4*>(g.pos + (int64_t)tp * g.ldpos + j);
+        }
+        if (EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_RES) v += *reinterpret_cast<const f32x4*>(g.res + (int64_t)i * g.ldr + j);
+        if (EPI == HIG_EPI_BIAS_GELU) {
+          if (g.aux) *reinterpret_cast<f32x4*>(g.aux + (int64_t)i * g.ldaux + j) = v;
+          v = f32x4{hig_gelu(v.x), hig_gelu(v.y), hig_gelu(v.z), hig_gelu(v.w)};
+        }
+        if (EPI == HIG_EPI_DGELU) {
+          const f32x4 z = *reinterpret_cast<const f32x4*>(g.aux + (int64_t)i * g.ldaux + j);
+          v = f32x4{v.x * hig_dgelu(z.x), v.y * hig_dgelu(z.y), v.z * hig_dgelu(z.z), v.w * hig_dgelu(z.w)};
+        }
+        *reinterpret_cast<f32x4*>(C + (int64_t)i * g.ldc + j) = v;
+      }
+      __syncthreads();
+    }
+    continue;
+  }
 #endif
   // ---- epilogue: lane holds, per accumulator quad q, columns j..j+3 of row i ----------
 #pragma unroll
