@@ -361,7 +361,7 @@ class GaussianDiffusion:
             img.copy_(img0)
             t_dev.fill_(self.num_timesteps - 1)
             graph = th.cuda.CUDAGraph()
-            with th.cuda.graph(graph):
+            with th.cuda.graph(graph, capture_error_mode="thread_local"):
                 step()
             # capture does not execute: state is still (img0, N-1)
             for _ in range(self.num_timesteps):

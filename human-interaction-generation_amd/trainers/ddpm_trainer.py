@@ -368,16 +368,17 @@ class DDPMTrainer(object):
                 st["m"].copy_(keep[1])
                 st["v"].copy_(keep[2])
                 st["step"].copy_(keep[3])
+            # thread_local: other threads (the RCCL watchdog polls its events) may call into HIP while we capture
             ga, gb = torch.cuda.CUDAGraph(), None
             if world == 1:
-                with torch.cuda.graph(ga):
+                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                     part_a()
                     self._fused_clip_adam(1, lr, with_text)
             else:
-                with torch.cuda.graph(ga):
+                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                     part_a()
                 gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, pool=ga.pool()):
+                with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
                     self._fused_clip_adam(world, lr, with_text)
             cap = st["graphs"][key] = (static, ga, gb)
         static, ga, gb = cap
