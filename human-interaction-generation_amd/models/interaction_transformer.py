@@ -77,7 +77,7 @@ class MotionInteractionTransformer(MotionTransformer):
         self.no_eff = False
         self.no_cross_attn = no_cross_attn
 
-        # Text side (stock torch ops; :421-462)
+        # Text side: CLIP / class embeddings + the parameter containers of the text head (:421-462)
         if self.cap_id:
             self.cap_embedding = nn.Parameter(torch.randn(43, text_latent_dim))
             self.text_proj = nn.Sequential(nn.Linear(text_latent_dim, self.time_embed_dim))

@@ -2,8 +2,10 @@
 signature as the reference module (codes/models/transformer.py:288-426), with the per-timestep
 denoiser math running in hand-written HIP kernels behind the C ABI of include/hig.h.
 
-What stays on stock PyTorch ops (boundary): `encode_text` -- CLIP (frozen,
-stubbed when the `clip` package is absent) and the 4-layer text TransformerEncoder head.
+`encode_text`: CLIP itself (frozen; stubbed when the `clip` package is absent) runs on
+its own PyTorch ops; the trainable head behind it -- text_pre_proj, the 4-layer post-norm encoder, text_ln,
+the EOT gather and text_proj -- goes through hig_text_head_fwd / _bwd (`text_head="torch"` keeps it on stock
+ops, e.g. for head dims the kernels do not cover).  The nn.Modules of the head are parameter containers.
 
 There is no CPU execution path: calling the module on host tensors, or without libhig.so, raises.
 """
@@ -340,7 +342,7 @@ class MotionTransformer(nn.Module):
         self.no_eff = no_eff
         self.sequence_embedding = nn.Parameter(torch.randn(num_frames, latent_dim))
 
-        # Text transformer (stock torch ops; transformer.py:318-340)
+        # Text side: CLIP + the parameter containers of the text head (transformer.py:318-340)
         self.clip, _ = clip.load('ViT-B/32', "cpu")
         if no_clip:
             self.clip.initialize_parameters()
