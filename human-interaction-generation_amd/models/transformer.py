@@ -254,6 +254,9 @@ class _FlatParams:
             and all(p.data_ptr() == base + 4 * o for p, o in zip(self.text_params, self.text_offsets))
 
 
+_POISON = __import__("os").environ.get("HIG_POISON", "0") == "1"
+
+
 class _WorkspacePool:
     """Scratch buffers keyed by (kind, bytes).  A forward that needs its activations kept for
     backward holds its buffer until backward returns it."""
@@ -263,9 +266,10 @@ class _WorkspacePool:
 
     def take(self, kind, nbytes, device):
         lst = self.free.setdefault((kind, nbytes, str(device)), [])
-        if lst:
-            return lst.pop()
-        return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+        buf = lst.pop() if lst else torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+        if _POISON:   # debugging aid (HIG_POISON=1): every scratch byte starts as NaN, so a kernel that reads
+            buf.fill_(0xFF)   # workspace it did not write first shows up as NaN in the outputs
+        return buf
 
     def give(self, kind, buf, device):
         self.free.setdefault((kind, buf.numel(), str(device)), []).append(buf)
