@@ -544,3 +544,45 @@ def test_edge_cases_empty_sample_single_frame_batch_of_one(no_eff):
         for k in ("temporal_decoder_blocks.0.sa_block.value.weight", "temporal_decoder_blocks.1.ffn.linear1.bias",
                   "sequence_embedding", "out.weight"):
             assert (named[k].grad.cpu().double() - p[k].grad).norm() <= 1e-4 * p[k].grad.norm() + 1e-9, (k, B, T)
+
+
+@pytest.mark.parametrize("two_person", [False, True])
+def test_workspaces_are_not_overrun(two_person):
+    """Every scratch buffer the library asks for (sizes from hig_*_bytes) is handed out inside a larger
+    sentinel-filled allocation; after forward + backward (+ text head) the guard bands must be intact."""
+    guards = []
+
+    def guarded_take(kind, nbytes, device):
+        pad = 4096
+        big = torch.full((int(nbytes) + 2 * pad,), 0xA5, dtype=torch.uint8, device=device)
+        guards.append((kind, big, pad, int(nbytes)))
+        return big[pad:pad + max(int(nbytes), 16)]
+
+    if two_person:
+        c = fill.ICASES["config1x2"]
+        m = hig_amd.MotionInteractionTransformer(input_feats=c["F"], num_frames=c["num_frames"], latent_dim=c["d"],
+                                                 ff_size=c["ff"], num_layers=c["L"], num_heads=c["H"],
+                                                 text_latent_dim=c["Lt"])
+        m.load_state_dict(fill.fill_state_dict(m.state_dict()), strict=True)
+        m = m.to(DEV).train()
+        inp = fill.inputs(2 * c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"] * 2, c["t"] * 2)
+    else:
+        c = fill.CASES["config1"]
+        m = build(c).train()
+        inp = fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"])
+    gi = {k: v.to(DEV) for k, v in inp.items()}
+    m._pool.take = guarded_take
+    m._pool.give = lambda *a, **k: None
+    caps = ["two people shake hands", "one pushes the other", "they hug", "a person waves"][:gi["x"].shape[0]]
+    xf_proj, xf_out = m.encode_text(caps, DEV)                      # text head forward (training workspace)
+    x = gi["x"].clone().requires_grad_(True)
+    out = m(x, gi["t"], length=gi["length"], xf_proj=xf_proj, xf_out=xf_out)
+    out.square().mean().backward()                                   # denoiser backward + text head backward
+    with torch.no_grad():
+        m(gi["x"], gi["t"], length=gi["length"], xf_proj=xf_proj.detach(), xf_out=xf_out.detach())   # inference workspaces
+    torch.cuda.synchronize()
+    kinds = {k for k, *_ in guards}
+    assert {"fwd_t", "bwd", "textctx_t", "txt_t", "txt_bwd", "fwd_i"} <= kinds, kinds
+    for kind, big, pad, n in guards:
+        assert bool((big[:pad] == 0xA5).all()) and bool((big[pad + max(n, 16):] == 0xA5).all()), kind
+    assert torch.isfinite(x.grad).all()
