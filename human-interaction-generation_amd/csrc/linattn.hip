@@ -10,6 +10,8 @@
 // rate, so they stay on the VALU with LDS-staged tiles; the kernels are bound by LDS/VALU
 // issue on tiny tiles and by HBM on the (rows x hd) streams.  One workgroup per (sample, head);
 // channel c of head h lives at column h*hd + c of the (rows, d) activation.
+#include <stdlib.h>
+
 #include "hig_common.h"
 
 namespace {
@@ -247,40 +249,61 @@ template <int HD>
 __global__ __launch_bounds__(256) void apply_mfma_kernel(const float* __restrict__ Q, int64_t ldq,
                                                          const float* __restrict__ A,
                                                          float* __restrict__ Y, int64_t ldy, int rows, int H) {
-  constexpr int LDP = HD + 4, TJ = HD / 64;
+  constexpr int LDP = HD + 4, TJ = HD / 64, Q4 = HD / 4, NPRE = CH * Q4 / 256;
   __shared__ __attribute__((aligned(16))) float sA[HD * HD];    // [c][l]: reduce index major
   __shared__ __attribute__((aligned(16))) float sQ[CH * LDP];   // [row][c]
   const int tid = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const int r0 = blockIdx.y * CH;
+  const int nchunk = (rows + CH - 1) / CH;
+  const float* Qb = Q + (int64_t)b * rows * ldq + h * HD;
+  // A workgroup walks chunks blockIdx.y, blockIdx.y + gridDim.y, ...: A[b,h] is staged once, and the next Q tile
+  // is requested into registers before the softmax / MFMA of the current one (no exposed load per chunk).
+  float4 pre[NPRE];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = tid + 256 * i, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
+      pre[i] = r < rows ? *reinterpret_cast<const float4*>(Qb + (int64_t)r * ldq + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  fetch(blockIdx.y * CH);
   const float* Ab = A + (int64_t)blockIdx.x * HD * HD;
   for (int idx = tid; idx < HD * HD / 4; idx += 256)
     reinterpret_cast<float4*>(sA)[idx] = reinterpret_cast<const float4*>(Ab)[idx];
-  load_tile<HD>(Q + (int64_t)b * rows * ldq + h * HD, ldq, r0, rows, sQ);
-  __syncthreads();
-  row_softmax_tile<HD>(sQ);
-  __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
-  f32x16 acc[TJ];
-#pragma unroll
-  for (int tj = 0; tj < TJ; ++tj) zero16(acc[tj]);
   const float* qrow = sQ + (wi * 32 + lr) * LDP + 4 * lh;
   const float* acol = sA + (4 * lh) * HD + wj * (HD / 2) + lr;
-#pragma unroll 4
-  for (int ks = 0; ks < HD / 8; ++ks) {
-    const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * ks);
+  for (int chunk = blockIdx.y; chunk < nchunk; chunk += gridDim.y) {
+    const int r0 = chunk * CH;
 #pragma unroll
-    for (int tj = 0; tj < TJ; ++tj) {
-      const float* ap = acol + (8 * ks) * HD + 32 * tj;
-      acc[tj] = mfma4(acc[tj], ap[0], ap[HD], ap[2 * HD], ap[3 * HD], q4);
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = tid + 256 * i;
+      *reinterpret_cast<float4*>(sQ + (idx / Q4) * LDP + 4 * (idx % Q4)) = pre[i];
     }
-  }
-  const int r = r0 + wi * 32 + lr;
-  if (r < rows) {
-    float* yp = Y + ((int64_t)b * rows + r) * ldy + h * HD + wj * (HD / 2) + 4 * lh;
+    __syncthreads();
+    if (chunk + (int)gridDim.y < nchunk) fetch((chunk + gridDim.y) * CH);
+    row_softmax_tile<HD>(sQ);
+    __syncthreads();
+    f32x16 acc[TJ];
 #pragma unroll
-    for (int tj = 0; tj < TJ; ++tj) store16(yp + 32 * tj, acc[tj]);
+    for (int tj = 0; tj < TJ; ++tj) zero16(acc[tj]);
+#pragma unroll 4
+    for (int ks = 0; ks < HD / 8; ++ks) {
+      const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * ks);
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        const float* ap = acol + (8 * ks) * HD + 32 * tj;
+        acc[tj] = mfma4(acc[tj], ap[0], ap[HD], ap[2 * HD], ap[3 * HD], q4);
+      }
+    }
+    const int r = r0 + wi * 32 + lr;
+    if (r < rows) {
+      float* yp = Y + ((int64_t)b * rows + r) * ldy + h * HD + wj * (HD / 2) + 4 * lh;
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) store16(yp + 32 * tj, acc[tj]);
+    }
+    __syncthreads();   // sQ is rewritten by the next chunk
   }
 }
 
@@ -1072,12 +1095,20 @@ extern "C" int hig_linattn_apply(const float* Q, int64_t ldq, const float* A, fl
   HIG_REQUIRE(ldq % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0 &&
                   (reinterpret_cast<uintptr_t>(Y) & 15) == 0,
               "hig_linattn_apply: Q/Y must be 16-byte aligned");
+  // chunk-walking workgroups: enough of them to fill the chip (~4 per CU), each staging A[b,h] once
+  const int nchunk_a = (rows + CH - 1) / CH;
+  // (hd = 128 keeps 97 KB of LDS per workgroup = one per CU: fewer, longer-lived workgroups; measured with
+  // tools/attn_time.py: 61 -> 47 us at config 5, neutral at hd = 64)
+  static const int apply_target = getenv("HIG_APPLY_WGS") ? atoi(getenv("HIG_APPLY_WGS")) : 0;   // tuning knob
+  const int target = apply_target > 0 ? apply_target : (hd == 128 ? 512 : 1024);
+  int gy = (target + B * H - 1) / (B * H);
+  gy = gy < 1 ? 1 : (gy > nchunk_a ? nchunk_a : gy);
   if (hd == 64)
-    hipLaunchKernelGGL(apply_mfma_kernel<64>, dim3(B * H, (rows + CH - 1) / CH), dim3(256), 0, hig_stream(stream), Q, ldq,
-                       A, Y, ldy, rows, H);
+    hipLaunchKernelGGL(apply_mfma_kernel<64>, dim3(B * H, gy), dim3(256), 0, hig_stream(stream), Q, ldq, A, Y, ldy, rows,
+                       H);
   else if (hd == 128)
-    hipLaunchKernelGGL(apply_mfma_kernel<128>, dim3(B * H, (rows + CH - 1) / CH), dim3(256), 0, hig_stream(stream), Q,
-                       ldq, A, Y, ldy, rows, H);
+    hipLaunchKernelGGL(apply_mfma_kernel<128>, dim3(B * H, gy), dim3(256), 0, hig_stream(stream), Q, ldq, A, Y, ldy,
+                       rows, H);
   else
     HD_SWITCH(hd, hipLaunchKernelGGL((apply_kernel<HDV>), dim3(B * H, (rows + CH - 1) / CH), dim3(256), 0,
                                      hig_stream(stream), Q, ldq, A, Y, ldy, rows, H));
