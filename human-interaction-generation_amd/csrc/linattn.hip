@@ -925,7 +925,7 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
   float* sV = sK + CH * LDP;           // [r][l]; later k * dk [r][c] CH * LDP
   float* smax = sV + CH * LDP;         // [HD]
   float* sinv = smax + HD;             // [HD]
-  float* swsum = sinv + HD;            // [RG][HD]
+  float* swsum = sK;                   // [RG][HD], over sK once k * dk has been formed (keeps the kernel at 3 per CU)
   const int tid = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   int len = rows;
@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
       *reinterpret_cast<float4*>(sV + rl * LDP + cc) =
           make_float4(k4.x * dk[tj][4 * q], k4.y * dk[tj][4 * q + 1], k4.z * dk[tj][4 * q + 2], k4.w * dk[tj][4 * q + 3]);
     }
-  __syncthreads();
+  __syncthreads();   // k * dk complete in sV, nobody reads sK any more
   {
     const int cc = tid % HD, rg = tid / HD;
     float t = 0.f;
@@ -1019,8 +1019,10 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
   }
 }
 
+// three [.][HD + 4] tiles + 2 * max(CH, HD) floats of small arrays: 52.7 KB at hd = 64, i.e. three
+// workgroups per CU within the 1280-byte LDS allocation granule (54.3 KB would leave only two)
 template <int HD> constexpr size_t attn_bwd_lds_bytes() {
-  return sizeof(float) * ((size_t)HD * (HD + 4) + 2 * (size_t)CH * (HD + 4) + 2 * CH + 2 * HD + (256 / HD) * HD);
+  return sizeof(float) * ((size_t)HD * (HD + 4) + 2 * (size_t)CH * (HD + 4) + 2 * (HD > CH ? HD : CH));
 }
 // hd = 128 needs 135 KB of dynamic LDS (of the 160 KB per CU): raise the per-kernel limit once.
 int allow_big_lds() {
