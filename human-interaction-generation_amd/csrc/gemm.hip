@@ -759,6 +759,14 @@ int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab,
     const double cost = (double)rounds * cands[c].bi * cands[c].bj * cands[c].ovh;
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
+  if (bf && forced < 0) {
+    // bf16 products: the MFMA part is short, so per-tile latency and the number of workgroups in flight decide.
+    // Measured (tools/fwd_time.py, B = 32 / 64): mixed 64x128 / 128x64 tiles are the worst choice, 128x128 wins
+    // once it yields enough tiles to occupy the chip, 64x64 below that.
+    static const int thr = getenv("HIG_BF_THR") ? atoi(getenv("HIG_BF_THR")) : 300;   // tuning knob
+    const int64_t t128 = (int64_t)((g.I + 127) / 128) * ((g.J + 127) / 128);
+    best = t128 >= thr ? 0 : 3;
+  }
   if (forced >= 0) best = forced;
   switch (best) {
     case 0: return launch<128, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs one named workload a few times (for `rocprofv3 --kernel-trace --stats -- python3 tools/profile_case.py CASE`).
-CASE: two_fwd | two_fwdbwd | text | fwd | fwdbwd | c5_fwd | c5_fwdbwd (HIG_PREC selects the products)   (env STEPS = iterations, default 6)."""
+CASE: two_fwd | two_fwdbwd | text | fwd | fwdbwd | c5_fwd | c5_fwdbwd | c3_fwd (HIG_PREC selects the products)   (env STEPS = iterations, default 6)."""
 import os
 import sys
 
@@ -28,6 +28,8 @@ if __name__ == "__main__":
     else:
         if case.startswith("c5"):          # BASELINE config 5 shape (hd = 128)
             c.update(B=32, T=300, d=1024, L=12, H=8, ff=1024)
+        if case.startswith("c3"):          # BASELINE config 3 shape (sampling batch)
+            c.update(B=32)
         m = bench.build_model(c, dev)
         m.precision = os.environ.get("HIG_PREC", "f32")
     i = bench.make_inputs(c, dev, 0)
