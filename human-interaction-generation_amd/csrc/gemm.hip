@@ -759,6 +759,15 @@ int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab,
     const double cost = (double)rounds * cands[c].bi * cands[c].bj * cands[c].ovh;
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
+  // exact-fp32 products: 64x64 tiles (four co-resident workgroups per CU) were never beaten by a larger tile on the
+  // model's shapes -- B = 32 / 64 forwards, tools/fwd_time.py with HIG_GEMM_TILE forced: 4.07 / 6.90 ms against
+  // 4.19-4.67 / 7.5-7.6 ms -- the round-counting model above mis-ranks them by a few per cent, so it only
+  // breaks ties for shapes with at most one tile per CU
+  static const int f32_rule = getenv("HIG_F32_TILE_RULE") ? atoi(getenv("HIG_F32_TILE_RULE")) : 1;   // tuning knob
+  if (!bf && forced < 0 && f32_rule) {
+    const int64_t t64 = (int64_t)((g.I + 63) / 64) * ((g.J + 63) / 64);
+    if (t64 > 256) best = 3;
+  }
   if (bf && forced < 0) {
     // bf16 products: the MFMA part is short, so per-tile latency and the number of workgroups in flight decide.
     // Measured (tools/fwd_time.py, B = 32 / 64): mixed 64x128 / 128x64 tiles are the worst choice, 128x128 wins
