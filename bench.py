@@ -124,6 +124,51 @@ def ffn_gemm_roofline(c, device, reps=30):
             "flops_per_launch": flops, "avg_launch_ms": round(ms, 4)}
 
 
+def hbm_kernel_rooflines(c, device, reps=30):
+    """HBM-bound kernels of the path through the C ABI: achieved GB/s = algorithmic bytes (each operand read or
+    written once) / launch time measured with HIP events on the launch stream; peak 8 TB/s."""
+    from hig_amd import _lib
+    L, s = _lib.lib(), _lib.stream_ptr()
+    B, T, H, d = c["B"], c["T"], c["H"], c["d"]
+    hd, M = d // H, c["B"] * c["T"]
+    P = lambda t: t.data_ptr()
+    qkv = torch.randn(M, 3 * d, device=device)
+    y, a = torch.empty(M, d, device=device), torch.empty(M, d, device=device)
+    dy = torch.randn(M, d, device=device)
+    A = torch.randn(B, H, hd, hd, device=device) * 0.1
+    kst, st = torch.zeros(B, d, 2, device=device), torch.empty(M, 2, device=device)
+    scr = torch.zeros(L.hig_linattn_ctx_scratch_floats(B, T, H, hd), device=device)
+    bscr = torch.zeros(L.hig_linattn_bwd_scratch_floats(B, T, H, hd), device=device)
+    dqkv, dA = torch.empty_like(qkv), torch.empty_like(A)
+    lg = torch.full((B,), T, dtype=torch.int64, device=device)
+    g, be = torch.ones(d, device=device), torch.zeros(d, device=device)
+    ss = torch.randn(B, 2 * d, device=device) * 0.1
+    stream_mb = M * d * 4 / 1e6
+    cases = {
+        "linattn_ctx (k^T v)": (2 * stream_mb, lambda: L.hig_linattn_ctx(P(qkv) + 4 * d, P(qkv) + 8 * d, 3 * d, B, T, H, hd, P(lg), P(A), P(kst), P(scr), s)),
+        "linattn_apply (q A)": (2 * stream_mb, lambda: L.hig_linattn_apply(P(qkv), 3 * d, P(A), P(y), d, B, T, H, hd, s)),
+        "linattn_apply_bwd": (3 * stream_mb, lambda: L.hig_linattn_apply_bwd(P(dy), d, P(qkv), 3 * d, P(A), P(dqkv), 3 * d, P(dA), B, T, H, hd, P(bscr), s)),
+        "linattn_ctx_bwd": (4 * stream_mb, lambda: L.hig_linattn_ctx_bwd(P(dA), P(qkv) + 4 * d, P(qkv) + 8 * d, 3 * d, P(kst), P(lg), P(dqkv) + 4 * d, P(dqkv) + 8 * d, 3 * d, B, T, H, hd, P(bscr), s)),
+        "ln_mod_silu (stylization front)": (2 * stream_mb, lambda: L.hig_ln_mod_silu(P(y), d, M, d, P(g), P(be), P(ss), 2 * d, d, T, P(a), d, P(st), s)),
+        "layernorm": (2 * stream_mb, lambda: L.hig_layernorm(P(y), d, M, d, P(g), P(be), P(a), d, P(st), s)),
+    }
+    out = {}
+    for name, (mb, fn) in cases.items():
+        for _ in range(3):
+            _lib.check(fn())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            _lib.check(fn())
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        out[name] = {"us": round(us, 1), "algorithmic_MB": round(mb, 1), "GB_per_s": round(mb / us * 1e3, 0),
+                     "frac_of_8TB_s": round(mb / us * 1e3 / 8000.0, 3)}
+    return out
+
+
 def pmc_traffic_bytes():
     """HBM bytes per launch of the FFN GEMM from the committed rocprofv3 PMC passes
     ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, profiles/rNN_ffn_gemm_pmc.json; counters cannot be
@@ -394,6 +439,8 @@ def main():
                                           "text_proj, fwd+bwd at B=64, fp32: hig_text_head_* vs nn.TransformerEncoder "
                                           "on PyTorch-ROCm"}
     if rank == 0:
+        if not a.no_extra and world == 1:
+            extra["hbm_bound_kernels"] = hbm_kernel_rooflines(c, device)
         res["roofline"] = ffn_gemm_roofline(c, device)
         if not a.no_cpu_baseline and world == 1:
             gpu_out = fwd()
