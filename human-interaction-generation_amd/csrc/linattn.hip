@@ -412,10 +412,10 @@ __global__ __launch_bounds__(256) void ctx_part_mfma_kernel(const float* __restr
                                                             int64_t ld, int rows, int H,
                                                             const int64_t* __restrict__ length,
                                                             float* __restrict__ part) {
-  constexpr int LDP = HD + 4, RG = 256 / HD, TB = HD / 64, PER = CH / RG;
+  constexpr int LDP = HD + 4, TB = HD / 64, Q4 = HD / 4, NRG = 256 / Q4, PER = CH / NRG;
   __shared__ __attribute__((aligned(16))) float sP[CH * LDP];
   __shared__ __attribute__((aligned(16))) float sV[CH * LDP];
-  __shared__ float sred[256];
+  __shared__ __attribute__((aligned(16))) float sred[NRG * HD];   // per row-group column maxima, then column sums
   __shared__ float smax[HD];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -425,35 +425,45 @@ __global__ __launch_bounds__(256) void ctx_part_mfma_kernel(const float* __restr
   const int nvalid = max(0, min(CH, len - r0));
   const float* Kb = K + ((int64_t)b * rows + r0) * ld + h * HD;
   const float* Vb = V + ((int64_t)b * rows + r0) * ld + h * HD;
-  const int c = tid % HD, rg = tid / HD;
-  float kreg[PER], vreg[PER];
-  float m = -INFINITY;
+  // one pass over HBM, 16 bytes per lane: thread = 4 channels (c4) of rows rgrp, rgrp + NRG, ...
+  const int c4 = tid % Q4, rgrp = tid / Q4;
+  float4 kreg[PER], vreg[PER];
+  float4 m4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {       // one pass over HBM: the thread keeps its 64/RG rows of column c
-    const int rr = rg + RG * i;
-    kreg[i] = rr < nvalid ? Kb[(int64_t)rr * ld + c] : -INFINITY;
-    vreg[i] = rr < nvalid ? Vb[(int64_t)rr * ld + c] : 0.f;
-    m = fmaxf(m, kreg[i]);
+  for (int i = 0; i < PER; ++i) {
+    const int rr = rgrp + NRG * i;
+    if (rr < nvalid) {
+      kreg[i] = *reinterpret_cast<const float4*>(Kb + (int64_t)rr * ld + 4 * c4);
+      vreg[i] = *reinterpret_cast<const float4*>(Vb + (int64_t)rr * ld + 4 * c4);
+    } else {
+      kreg[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      vreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    m4.x = fmaxf(m4.x, kreg[i].x); m4.y = fmaxf(m4.y, kreg[i].y);
+    m4.z = fmaxf(m4.z, kreg[i].z); m4.w = fmaxf(m4.w, kreg[i].w);
   }
-  sred[tid] = m;
+  *reinterpret_cast<float4*>(sred + rgrp * HD + 4 * c4) = m4;
   __syncthreads();
   if (tid < HD) {
-    for (int g2 = 1; g2 < RG; ++g2) m = fmaxf(m, sred[g2 * HD + tid]);
+    float m = sred[tid];
+    for (int g2 = 1; g2 < NRG; ++g2) m = fmaxf(m, sred[g2 * HD + tid]);
     smax[tid] = m;
   }
   __syncthreads();
-  const float cm = smax[c];
-  float ks = 0.f;
+  const float4 cm = *reinterpret_cast<const float4*>(smax + 4 * c4);
+  float4 ks4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int rr = rg + RG * i;
-    const float pe = rr < nvalid ? __expf(kreg[i] - cm) : 0.f;
-    ks += pe;
-    sP[rr * LDP + c] = pe;
-    sV[rr * LDP + c] = vreg[i];
+    const int rr = rgrp + NRG * i;
+    float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rr < nvalid)
+      pe = make_float4(__expf(kreg[i].x - cm.x), __expf(kreg[i].y - cm.y), __expf(kreg[i].z - cm.z), __expf(kreg[i].w - cm.w));
+    ks4.x += pe.x; ks4.y += pe.y; ks4.z += pe.z; ks4.w += pe.w;
+    *reinterpret_cast<float4*>(sP + rr * LDP + 4 * c4) = pe;
+    *reinterpret_cast<float4*>(sV + rr * LDP + 4 * c4) = vreg[i];
   }
+  *reinterpret_cast<float4*>(sred + rgrp * HD + 4 * c4) = ks4;   // (the maxima were consumed before the barrier above)
   __syncthreads();
-  sred[tid] = ks;
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
   f32x16 acc[TB][TB];
@@ -486,10 +496,9 @@ __global__ __launch_bounds__(256) void ctx_part_mfma_kernel(const float* __restr
 #pragma unroll
     for (int tj = 0; tj < TB; ++tj)
       store16(pb + (wi * (HD / 2) + 32 * ti + lr) * HD + wj * (HD / 2) + 32 * tj + 4 * lh, acc[ti][tj]);
-  __syncthreads();
   if (tid < HD) {
     float t = 0.f;
-    for (int g2 = 0; g2 < RG; ++g2) t += sred[g2 * HD + tid];
+    for (int g2 = 0; g2 < NRG; ++g2) t += sred[g2 * HD + tid];
     pb[HD * HD + tid] = smax[tid];
     pb[HD * HD + HD + tid] = t;
   }
@@ -944,15 +953,19 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
   const float* Vb = V + (int64_t)b * rows * ld + h * HD;
   const int r0 = blockIdx.y * CH;
   __syncthreads();
-  for (int idx = tid; idx < CH * HD; idx += 256) {
-    const int rr = idx / HD, cc = idx % HD, r = r0 + rr;
-    float kk = 0.f, v = 0.f;
+  for (int idx = tid; idx < CH * (HD / 4); idx += 256) {   // 16 bytes per lane
+    const int rr = idx / (HD / 4), c4 = idx % (HD / 4), r = r0 + rr;
+    float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), v = kk;
     if (r < len) {
-      kk = __expf(Kb[(int64_t)r * ld + cc] - smax[cc]) * sinv[cc];
-      v = Vb[(int64_t)r * ld + cc];
+      const float4 k4 = *reinterpret_cast<const float4*>(Kb + (int64_t)r * ld + 4 * c4);
+      const float4 mx = *reinterpret_cast<const float4*>(smax + 4 * c4);
+      const float4 iv = *reinterpret_cast<const float4*>(sinv + 4 * c4);
+      kk = make_float4(__expf(k4.x - mx.x) * iv.x, __expf(k4.y - mx.y) * iv.y, __expf(k4.z - mx.z) * iv.z,
+                       __expf(k4.w - mx.w) * iv.w);
+      v = *reinterpret_cast<const float4*>(Vb + (int64_t)r * ld + 4 * c4);
     }
-    sK[rr * LDP + cc] = kk;
-    sV[rr * LDP + cc] = v;
+    *reinterpret_cast<float4*>(sK + rr * LDP + 4 * c4) = kk;
+    *reinterpret_cast<float4*>(sV + rr * LDP + 4 * c4) = v;
   }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
