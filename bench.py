@@ -148,7 +148,7 @@ def hbm_kernel_rooflines(c, device, reps=30):
         "linattn_ctx (k^T v)": (2 * stream_mb, lambda: L.hig_linattn_ctx(P(qkv) + 4 * d, P(qkv) + 8 * d, 3 * d, B, T, H, hd, P(lg), P(A), P(kst), P(scr), s)),
         "linattn_apply (q A)": (2 * stream_mb, lambda: L.hig_linattn_apply(P(qkv), 3 * d, P(A), P(y), d, B, T, H, hd, s)),
         "linattn_apply_bwd": (3 * stream_mb, lambda: L.hig_linattn_apply_bwd(P(dy), d, P(qkv), 3 * d, P(A), P(dqkv), 3 * d, P(dA), B, T, H, hd, P(bscr), s)),
-        "linattn_ctx_bwd": (4 * stream_mb, lambda: L.hig_linattn_ctx_bwd(P(dA), P(qkv) + 4 * d, P(qkv) + 8 * d, 3 * d, P(kst), P(lg), P(dqkv) + 4 * d, P(dqkv) + 8 * d, 3 * d, B, T, H, hd, P(bscr), s)),
+        "linattn_ctx_bwd": (4 * stream_mb, lambda: L.hig_linattn_ctx_bwd(P(dA), P(A), P(qkv) + 4 * d, P(qkv) + 8 * d, 3 * d, P(kst), P(lg), P(dqkv) + 4 * d, P(dqkv) + 8 * d, 3 * d, B, T, H, hd, P(bscr), s)),
         "ln_mod_silu (stylization front)": (2 * stream_mb, lambda: L.hig_ln_mod_silu(P(y), d, M, d, P(g), P(be), P(ss), 2 * d, d, T, P(a), d, P(st), s)),
         "layernorm": (2 * stream_mb, lambda: L.hig_layernorm(P(y), d, M, d, P(g), P(be), P(a), d, P(st), s)),
     }

@@ -97,7 +97,7 @@ def lib():
         L.hig_linattn_bwd_scratch_floats.restype = i64
         L.hig_linattn_bwd_scratch_floats.argtypes = [i32, i32, i32, i32]
         L.hig_linattn_apply_bwd.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, vp]
-        L.hig_linattn_ctx_bwd.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]
+        L.hig_linattn_ctx_bwd.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]
         L.hig_fullattn_fwd.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, vp, vp, i64, vp, vp]
         L.hig_fullattn_bwd.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, vp, vp,
                                        vp, vp, i64, vp, vp, i64, vp]

@@ -568,7 +568,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                                     Bp, D.T, D.H, D.hd, b + bw.attn, stream));
       HIG_TRY(hig_linattn_apply_bwd(b + bw.t2 + halfM * d, d, lb + w.iqkv + halfM * 3 * d, 3 * d, lb + w.Ai,
                                     dqkv + halfM * 3 * d, 3 * d, b + bw.dA, Bp, D.T, D.H, D.hd, b + bw.attn, stream));
-      HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, lb + w.iqkv + d, lb + w.iqkv + 2 * d, 3 * d, lb + w.ksti, len_partner,
+      HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, lb + w.Ai, lb + w.iqkv + d, lb + w.iqkv + 2 * d, 3 * d, lb + w.ksti, len_partner,
                                   dqkv + d, dqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, b + bw.attn, stream));
       HIG_TRY(colsum(dqkv, 3 * d, M, 3 * d, GL(grads, l, HIG_L_INT_QKV_B)));
       HIG_TRY(wgrad_act(dqkv, 3 * d, lb + w.xn3, d, GL(grads, l, HIG_L_INT_QKV_W), M, nullptr, nullptr, nullptr));
@@ -602,7 +602,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
     { float* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h1)
     // text side of this layer: d(A_c) -> d(key,value) -> text_norm -> d(xf_out)
     if (!D.full)
-      HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, kv, kv + d, 2 * d, kstc, nullptr, b + bw.dkv, b + bw.dkv + d, 2 * d, D.B,
+      HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, Ac, kv, kv + d, 2 * d, kstc, nullptr, b + bw.dkv, b + bw.dkv + d, 2 * d, D.B,
                                   D.N, D.H, D.hd, b + bw.attn, stream));
     HIG_TRY(colsum(b + bw.dkv, 2 * d, Mt, 2 * d, GL(grads, l, HIG_L_CA_KV_B)));
     HIG_TRY(wgrad_act(b + bw.dkv, 2 * d, xf_out, Lt, GL(grads, l, HIG_L_CA_KV_W), Mt, tc + tl.stt,
@@ -624,7 +624,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
     } else {
       HIG_TRY(hig_linattn_apply_bwd(b + bw.t2, d, lb + w.qkv, 3 * d, lb + w.A1, dqkv, 3 * d, b + bw.dA, D.B, D.T, D.H,
                                     D.hd, b + bw.attn, stream));
-      HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, lb + w.kst1, length, dqkv + d,
+      HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, lb + w.A1, lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, lb + w.kst1, length, dqkv + d,
                                   dqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, b + bw.attn, stream));
     }
     HIG_TRY(colsum(dqkv, 3 * d, M, 3 * d, GL(grads, l, HIG_L_SA_QKV_B)));

@@ -920,29 +920,40 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const float* __rest
   }
 }
 
+// Single pass: the column term of the column-softmax Jacobian,  S[c] = sum_r k[r][c] dk[r][c],  needs no pass over
+// the rows:  dk[r][c] = sum_l V[r][l] dA[c][l]  gives  S[c] = sum_l dA[c][l] (sum_r k[r][c] V[r][l]) = sum_l dA[c][l] A[c][l],
+// a row-wise dot of the two hd x hd matrices the workgroup already stages -- so dK is finished here.
 template <int HD>
-__global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restrict__ dA, const float* __restrict__ K,
-                                                           const float* __restrict__ V, int64_t ld,
-                                                           const float* __restrict__ kstat,
+__global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restrict__ dA, const float* __restrict__ A,
+                                                           const float* __restrict__ K, const float* __restrict__ V,
+                                                           int64_t ld, const float* __restrict__ kstat,
                                                            const int64_t* __restrict__ length,
                                                            float* __restrict__ dK, float* __restrict__ dV, int64_t ldd,
-                                                           int rows, int H, float* __restrict__ colpart) {
-  constexpr int LDP = HD + 4, TB = HD / 64, RG = 256 / HD;
+                                                           int rows, int H) {
+  constexpr int LDP = HD + 4, TB = HD / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sdA = smem;                   // [c][l]                      HD * LDP
   float* sK = sdA + HD * LDP;          // k (normalised) [r][c]       CH * LDP
-  float* sV = sK + CH * LDP;           // [r][l]; later k * dk [r][c] CH * LDP
-  float* smax = sV + CH * LDP;         // [HD]
+  float* sV = sK + CH * LDP;           // [r][l]                      CH * LDP
+  float* smax = sV + CH * LDP;         // [HD]; after the staging loop: S[c]
   float* sinv = smax + HD;             // [HD]
-  float* swsum = sK;                   // [RG][HD], over sK once k * dk has been formed (keeps the kernel at 3 per CU)
   const int tid = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   int len = rows;
   if (length) len = (int)min<int64_t>(max<int64_t>(length[b], 0), rows);
   const float* dAb = dA + (int64_t)blockIdx.x * HD * HD;
+  const float* Ab = A + (int64_t)blockIdx.x * HD * HD;
   for (int idx = tid; idx < HD * HD / 4; idx += 256) {
     const int c = idx / (HD / 4), l4 = idx % (HD / 4);
-    *reinterpret_cast<float4*>(sdA + c * LDP + 4 * l4) = reinterpret_cast<const float4*>(dAb)[idx];
+    const float4 d4 = reinterpret_cast<const float4*>(dAb)[idx];
+    const float4 a4 = reinterpret_cast<const float4*>(Ab)[idx];
+    *reinterpret_cast<float4*>(sdA + c * LDP + 4 * l4) = d4;
+    const float pr = d4.x * a4.x + d4.y * a4.y + d4.z * a4.z + d4.w * a4.w;
+    // HD / 4 consecutive threads (16 or 32 lanes of one wave) hold one row of this sweep: reduce inside the group
+    float t = pr;
+#pragma unroll
+    for (int o = HD / 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (l4 == 0) sK[c] = t;          // sK is free until the staging loop below: park S there
   }
   if (tid < HD) {
     const float* st = kstat + ((int64_t)blockIdx.x * HD + tid) * 2;
@@ -952,6 +963,18 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
   const float* Kb = K + (int64_t)b * rows * ld + h * HD;
   const float* Vb = V + (int64_t)b * rows * ld + h * HD;
   const int r0 = blockIdx.y * CH;
+  __syncthreads();
+  float scol[TB][4][4];   // S[c] for the lane's columns (read before sK is overwritten)
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
+  const int rl = wi * 32 + lr;
+#pragma unroll
+  for (int tj = 0; tj < TB; ++tj)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 s4 = *reinterpret_cast<const float4*>(sK + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh);
+      scol[tj][q][0] = s4.x; scol[tj][q][1] = s4.y; scol[tj][q][2] = s4.z; scol[tj][q][3] = s4.w;
+    }
   __syncthreads();
   for (int idx = tid; idx < CH * (HD / 4); idx += 256) {   // 16 bytes per lane
     const int rr = idx / (HD / 4), c4 = idx % (HD / 4), r = r0 + rr;
@@ -968,9 +991,6 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
     *reinterpret_cast<float4*>(sV + rr * LDP + 4 * c4) = v;
   }
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
-  const int rl = wi * 32 + lr;
   f32x16 dv[TB], dk[TB];
 #pragma unroll
   for (int tj = 0; tj < TB; ++tj) {
@@ -996,39 +1016,20 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
     }
   }
   const int r = r0 + rl;
-  if (r < rows) {   // rows in [len, rows) carry k == 0 and V == 0 in LDS, so both products are exact zeros
+  if (r < rows) {   // rows in [len, rows) carry k == 0 and V == 0 in LDS: dV == 0 and dK = k * (..) == 0 there
     float* kp = dK + ((int64_t)b * rows + r) * ldd + h * HD + wj * (HD / 2) + 4 * lh;
     float* vp = dV + ((int64_t)b * rows + r) * ldd + h * HD + wj * (HD / 2) + 4 * lh;
 #pragma unroll
     for (int tj = 0; tj < TB; ++tj) {
-      store16(kp + 32 * tj, dk[tj]);
       store16(vp + 32 * tj, dv[tj]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 k4 = *reinterpret_cast<const float4*>(sK + rl * LDP + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh);
+        *reinterpret_cast<float4*>(kp + 32 * tj + 8 * q) =
+            make_float4(k4.x * (dk[tj][4 * q] - scol[tj][q][0]), k4.y * (dk[tj][4 * q + 1] - scol[tj][q][1]),
+                        k4.z * (dk[tj][4 * q + 2] - scol[tj][q][2]), k4.w * (dk[tj][4 * q + 3] - scol[tj][q][3]));
+      }
     }
-  }
-  __syncthreads();   // every wave is done reading sV
-#pragma unroll
-  for (int tj = 0; tj < TB; ++tj)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {   // k * dk into sV ([r][c]) for the column sums of this chunk
-      const int cc = wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh;
-      const float4 k4 = *reinterpret_cast<const float4*>(sK + rl * LDP + cc);
-      *reinterpret_cast<float4*>(sV + rl * LDP + cc) =
-          make_float4(k4.x * dk[tj][4 * q], k4.y * dk[tj][4 * q + 1], k4.z * dk[tj][4 * q + 2], k4.w * dk[tj][4 * q + 3]);
-    }
-  __syncthreads();   // k * dk complete in sV, nobody reads sK any more
-  {
-    const int cc = tid % HD, rg = tid / HD;
-    float t = 0.f;
-#pragma unroll 4
-    for (int rr = rg; rr < CH; rr += RG) t += sV[rr * LDP + cc];
-    swsum[rg * HD + cc] = t;
-  }
-  __syncthreads();
-  if (tid < HD) {
-    float t = 0.f;
-#pragma unroll
-    for (int g = 0; g < RG; ++g) t += swsum[g * HD + tid];
-    colpart[((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * HD + tid] = t;
   }
 }
 
@@ -1165,25 +1166,28 @@ extern "C" int hig_linattn_apply_bwd(const float* dY, int64_t lddy, const float*
   return HIG_OK;
 }
 
-extern "C" int hig_linattn_ctx_bwd(const float* dA, const float* K, const float* V, int64_t ld,
+extern "C" int hig_linattn_ctx_bwd(const float* dA, const float* A, const float* K, const float* V, int64_t ld,
                                    const float* kstat, const int64_t* length, float* dK, float* dV,
                                    int64_t ldd, int32_t B, int32_t rows, int32_t H, int32_t hd,
                                    float* scratch, hig_stream_t stream) {
-  HIG_REQUIRE(dA && K && V && kstat && dK && dV && scratch && B > 0 && rows > 0 && H > 0,
+  HIG_REQUIRE(dA && A && K && V && kstat && dK && dV && scratch && B > 0 && rows > 0 && H > 0,
               "hig_linattn_ctx_bwd: bad arguments");
   HIG_REQUIRE(hd_ok(hd), "hig_linattn: head dim %d not in {8,16,32,64,128}", hd);
   HIG_REQUIRE(ldd % 4 == 0 && (reinterpret_cast<uintptr_t>(dK) & 15) == 0 && (reinterpret_cast<uintptr_t>(dV) & 15) == 0,
               "hig_linattn_ctx_bwd: dK/dV must be 16-byte aligned");
   const int nchunk = (rows + CH - 1) / CH;
-  if (hd == 64)
-    hipLaunchKernelGGL(ctx_bwd_mfma_kernel<64>, dim3(B * H, nchunk), dim3(256), attn_bwd_lds_bytes<64>(),
-                       hig_stream(stream), dA, K, V, ld, kstat, length, dK, dV, ldd, rows, H, scratch);
-  else if (hd == 128 && allow_big_lds() == 0)
-    hipLaunchKernelGGL(ctx_bwd_mfma_kernel<128>, dim3(B * H, nchunk), dim3(256), attn_bwd_lds_bytes<128>(),
-                       hig_stream(stream), dA, K, V, ld, kstat, length, dK, dV, ldd, rows, H, scratch);
-  else
-    HD_SWITCH(hd, hipLaunchKernelGGL((ctx_bwd_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream), dA,
-                                     K, V, ld, kstat, length, dK, dV, ldd, rows, H, scratch));
+  if (hd == 64 || (hd == 128 && allow_big_lds() == 0)) {   // single pass (the column term comes from A and dA)
+    if (hd == 64)
+      hipLaunchKernelGGL(ctx_bwd_mfma_kernel<64>, dim3(B * H, nchunk), dim3(256), attn_bwd_lds_bytes<64>(),
+                         hig_stream(stream), dA, A, K, V, ld, kstat, length, dK, dV, ldd, rows, H);
+    else
+      hipLaunchKernelGGL(ctx_bwd_mfma_kernel<128>, dim3(B * H, nchunk), dim3(256), attn_bwd_lds_bytes<128>(),
+                         hig_stream(stream), dA, A, K, V, ld, kstat, length, dK, dV, ldd, rows, H);
+    HIG_CHECK_LAUNCH();
+    return HIG_OK;
+  }
+  HD_SWITCH(hd, hipLaunchKernelGGL((ctx_bwd_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream), dA,
+                                   K, V, ld, kstat, length, dK, dV, ldd, rows, H, scratch));
   HIG_CHECK_LAUNCH();
   HD_SWITCH(hd, hipLaunchKernelGGL((ctx_bwd_finish_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0,
                                    hig_stream(stream), K, ld, kstat, length, dK, ldd, rows, H, scratch));

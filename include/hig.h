@@ -311,7 +311,7 @@ int64_t hig_linattn_bwd_scratch_floats(int32_t B, int32_t rows, int32_t H, int32
 int hig_linattn_apply_bwd(const float* dY, int64_t lddy, const float* Q, int64_t ldq,
                           const float* A, float* dQ, int64_t lddq, float* dA, int32_t B,
                           int32_t rows, int32_t H, int32_t hd, float* scratch, hig_stream_t stream);
-int hig_linattn_ctx_bwd(const float* dA, const float* K, const float* V, int64_t ld,
+int hig_linattn_ctx_bwd(const float* dA, const float* A, const float* K, const float* V, int64_t ld,
                         const float* kstat, const int64_t* length, float* dK, float* dV,
                         int64_t ldd, int32_t B, int32_t rows, int32_t H, int32_t hd,
                         float* scratch, hig_stream_t stream);

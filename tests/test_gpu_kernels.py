@@ -311,7 +311,7 @@ def test_linear_attention_forward_backward(B, T, H, hd, lens):
     dA = torch.zeros(B, H, hd, hd, device=DEV)
     scr = torch.zeros(L.hig_linattn_bwd_scratch_floats(B, T, H, hd), device=DEV)
     _lib.check(L.hig_linattn_apply_bwd(P(dy.to(DEV)), d, P(g), 3 * d, P(A), P(dqkv), 3 * d, P(dA), B, T, H, hd, P(scr), s))
-    _lib.check(L.hig_linattn_ctx_bwd(P(dA), g.data_ptr() + 4 * d, g.data_ptr() + 8 * d, 3 * d, P(kst), P(lg),
+    _lib.check(L.hig_linattn_ctx_bwd(P(dA), P(A), g.data_ptr() + 4 * d, g.data_ptr() + 8 * d, 3 * d, P(kst), P(lg),
                                      dqkv.data_ptr() + 4 * d, dqkv.data_ptr() + 8 * d, 3 * d, B, T, H, hd, P(scr), s))
     torch.cuda.synchronize()
     ref = qd.grad.view(B * T, 3 * d)

@@ -21,6 +21,6 @@ for (B, T, H, hd) in ((64, 196, 8, 64), (32, 300, 8, 128), (64, 91, 8, 64)):
     ctx()
     app = lambda: _lib.check(L.hig_linattn_apply(P(qkv), 3 * d, P(A), P(y), d, B, T, H, hd, s))
     abw = lambda: _lib.check(L.hig_linattn_apply_bwd(P(dy), d, P(qkv), 3 * d, P(A), P(dqkv), 3 * d, P(dA), B, T, H, hd, P(bscr), s))
-    cbw = lambda: _lib.check(L.hig_linattn_ctx_bwd(P(dA), P(qkv) + 4 * d, P(qkv) + 8 * d, 3 * d, P(kst), P(lg), P(dqkv) + 4 * d, P(dqkv) + 8 * d, 3 * d, B, T, H, hd, P(bscr), s))
+    cbw = lambda: _lib.check(L.hig_linattn_ctx_bwd(P(dA), P(A), P(qkv) + 4 * d, P(qkv) + 8 * d, 3 * d, P(kst), P(lg), P(dqkv) + 4 * d, P(dqkv) + 8 * d, 3 * d, B, T, H, hd, P(bscr), s))
     mb = B * T * d * 4 / 1e6
     print("B=%d T=%d hd=%d (stream %.1f MB): ctx %.1f us  apply %.1f us  apply_bwd %.1f us  ctx_bwd %.1f us" % (B, T, hd, mb, t(ctx), t(app), t(abw), t(cbw)))
