@@ -820,7 +820,7 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const float* __rest
                                                              const float* __restrict__ A,
                                                              float* __restrict__ dQ, int64_t lddq,
                                                              float* __restrict__ dApart, int rows, int H) {
-  constexpr int LDP = HD + 4, TB = HD / 64;
+  constexpr int LDP = HD + 4, TB = HD / 64, Q4 = HD / 4, NPRE = CH * Q4 / 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                    // [c][l]            HD * LDP
   float* sQ = sA + HD * LDP;           // softmax(Q) [r][c] CH * LDP
@@ -828,96 +828,121 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const float* __rest
   float* srow = sD + CH * LDP;         // [2][CH]
   const int tid = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const int r0 = blockIdx.y * CH;
+  const int nchunk = (rows + CH - 1) / CH;
+  const float* Qb = Q + (int64_t)b * rows * ldq + h * HD;
+  const float* Db = dY + (int64_t)b * rows * lddy + h * HD;
+  // The workgroup walks row chunks blockIdx.y, blockIdx.y + gridDim.y, ...: A[b,h] is staged once, the dA
+  // accumulators live across chunks (one partial per workgroup instead of one per chunk), and the next Q / dY
+  // tiles are requested into registers before the products of the current ones.
+  float4 preq[NPRE], pred[NPRE];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = tid + 256 * i, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
+      const bool ok = r < rows;
+      preq[i] = ok ? *reinterpret_cast<const float4*>(Qb + (int64_t)r * ldq + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pred[i] = ok ? *reinterpret_cast<const float4*>(Db + (int64_t)r * lddy + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  fetch(blockIdx.y * CH);
   const float* Ab = A + (int64_t)blockIdx.x * HD * HD;
   for (int idx = tid; idx < HD * HD / 4; idx += 256) {
     const int c = idx / (HD / 4), l4 = idx % (HD / 4);
     *reinterpret_cast<float4*>(sA + c * LDP + 4 * l4) = reinterpret_cast<const float4*>(Ab)[idx];
   }
-  load_tile<HD>(Q + (int64_t)b * rows * ldq + h * HD, ldq, r0, rows, sQ);
-  load_tile<HD>(dY + (int64_t)b * rows * lddy + h * HD, lddy, r0, rows, sD);
-  __syncthreads();
-  row_softmax_tile<HD>(sQ);
-  __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
   const int rl = wi * 32 + lr;
-  // dq_pre[r][c] = sum_l dY[r][l] A[c][l]   (64 x HD, reduce over HD)
-  f32x16 dq[TB];
+  f32x16 da[TB][TB];
 #pragma unroll
-  for (int tj = 0; tj < TB; ++tj) zero16(dq[tj]);
-  {
-    const float* xrow = sD + rl * LDP + 4 * lh;
-    const float* yrow = sA + (wj * (HD / 2) + lr) * LDP + 4 * lh;
+  for (int ti = 0; ti < TB; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TB; ++tj) zero16(da[ti][tj]);
+  for (int chunk = blockIdx.y; chunk < nchunk; chunk += gridDim.y) {
+    const int r0 = chunk * CH;
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = tid + 256 * i;
+      *reinterpret_cast<float4*>(sQ + (idx / Q4) * LDP + 4 * (idx % Q4)) = preq[i];
+      *reinterpret_cast<float4*>(sD + (idx / Q4) * LDP + 4 * (idx % Q4)) = pred[i];
+    }
+    __syncthreads();
+    if (chunk + (int)gridDim.y < nchunk) fetch((chunk + gridDim.y) * CH);
+    row_softmax_tile<HD>(sQ);
+    __syncthreads();
+    // dq_pre[r][c] = sum_l dY[r][l] A[c][l]   (64 x HD, reduce over HD)
+    f32x16 dq[TB];
+#pragma unroll
+    for (int tj = 0; tj < TB; ++tj) zero16(dq[tj]);
+    {
+      const float* xrow = sD + rl * LDP + 4 * lh;
+      const float* yrow = sA + (wj * (HD / 2) + lr) * LDP + 4 * lh;
 #pragma unroll 4
-    for (int ks = 0; ks < HD / 8; ++ks) {
-      const float4 x4 = *reinterpret_cast<const float4*>(xrow + 8 * ks);
+      for (int ks = 0; ks < HD / 8; ++ks) {
+        const float4 x4 = *reinterpret_cast<const float4*>(xrow + 8 * ks);
 #pragma unroll
-      for (int tj = 0; tj < TB; ++tj) {
-        const float4 y4 = *reinterpret_cast<const float4*>(yrow + 32 * tj * LDP + 8 * ks);
-        dq[tj] = mfma4(dq[tj], y4.x, y4.y, y4.z, y4.w, x4);
-      }
-    }
-  }
-  // dA[c][l] = sum_r q[r][c] dY[r][l]   (HD x HD, reduce over the 64 rows)
-  {
-    f32x16 da[TB][TB];
-#pragma unroll
-    for (int ti = 0; ti < TB; ++ti)
-#pragma unroll
-      for (int tj = 0; tj < TB; ++tj) zero16(da[ti][tj]);
-    const float* xcol = sQ + (4 * lh) * LDP + wi * (HD / 2) + lr;
-    const float* ycol = sD + (4 * lh) * LDP + wj * (HD / 2) + lr;
-#pragma unroll 2
-    for (int ks = 0; ks < CH / 8; ++ks) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float xv[TB], yv[TB];
-#pragma unroll
-        for (int t = 0; t < TB; ++t) {
-          xv[t] = xcol[(8 * ks + j) * LDP + 32 * t];
-          yv[t] = ycol[(8 * ks + j) * LDP + 32 * t];
+        for (int tj = 0; tj < TB; ++tj) {
+          const float4 y4 = *reinterpret_cast<const float4*>(yrow + 32 * tj * LDP + 8 * ks);
+          dq[tj] = mfma4(dq[tj], y4.x, y4.y, y4.z, y4.w, x4);
         }
-#pragma unroll
-        for (int ti = 0; ti < TB; ++ti)
-#pragma unroll
-          for (int tj = 0; tj < TB; ++tj)
-            da[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv[tj], xv[ti], da[ti][tj], 0, 0, 0);
       }
     }
-    float* dAb = dApart + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * HD * HD;
+    // dA[c][l] += sum_r q[r][c] dY[r][l]   (HD x HD, reduce over the 64 rows; rows past `rows` are zero in sD)
+    {
+      const float* xcol = sQ + (4 * lh) * LDP + wi * (HD / 2) + lr;
+      const float* ycol = sD + (4 * lh) * LDP + wj * (HD / 2) + lr;
+#pragma unroll 2
+      for (int ks = 0; ks < CH / 8; ++ks) {
 #pragma unroll
-    for (int ti = 0; ti < TB; ++ti)
+        for (int j = 0; j < 4; ++j) {
+          float xv[TB], yv[TB];
 #pragma unroll
-      for (int tj = 0; tj < TB; ++tj)
-        store16(dAb + (wi * (HD / 2) + 32 * ti + lr) * HD + wj * (HD / 2) + 32 * tj + 4 * lh, da[ti][tj]);
-  }
-  // softmax Jacobian over the HD channels of a row: the row lives in 2 lanes (lh) x 2 waves (wj)
-  float part = 0.f;
+          for (int t = 0; t < TB; ++t) {
+            xv[t] = xcol[(8 * ks + j) * LDP + 32 * t];
+            yv[t] = ycol[(8 * ks + j) * LDP + 32 * t];
+          }
 #pragma unroll
-  for (int tj = 0; tj < TB; ++tj)
+          for (int ti = 0; ti < TB; ++ti)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 qv = *reinterpret_cast<const float4*>(sQ + rl * LDP + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh);
-      part += qv.x * dq[tj][4 * q] + qv.y * dq[tj][4 * q + 1] + qv.z * dq[tj][4 * q + 2] + qv.w * dq[tj][4 * q + 3];
+            for (int tj = 0; tj < TB; ++tj)
+              da[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv[tj], xv[ti], da[ti][tj], 0, 0, 0);
+        }
+      }
     }
-  part += __shfl_xor(part, 32, 64);
-  if (lh == 0) srow[wj * CH + rl] = part;
-  __syncthreads();
-  const float sdot = srow[rl] + srow[CH + rl];
-  const int r = r0 + rl;
-  if (r < rows) {
-    float* op = dQ + ((int64_t)b * rows + r) * lddq + h * HD + wj * (HD / 2) + 4 * lh;
+    // softmax Jacobian over the HD channels of a row: the row lives in 2 lanes (lh) x 2 waves (wj)
+    float part = 0.f;
 #pragma unroll
     for (int tj = 0; tj < TB; ++tj)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 qv = *reinterpret_cast<const float4*>(sQ + rl * LDP + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh);
-        *reinterpret_cast<float4*>(op + 32 * tj + 8 * q) =
-            make_float4(qv.x * (dq[tj][4 * q] - sdot), qv.y * (dq[tj][4 * q + 1] - sdot),
-                        qv.z * (dq[tj][4 * q + 2] - sdot), qv.w * (dq[tj][4 * q + 3] - sdot));
+        part += qv.x * dq[tj][4 * q] + qv.y * dq[tj][4 * q + 1] + qv.z * dq[tj][4 * q + 2] + qv.w * dq[tj][4 * q + 3];
       }
+    part += __shfl_xor(part, 32, 64);
+    if (lh == 0) srow[wj * CH + rl] = part;
+    __syncthreads();
+    const float sdot = srow[rl] + srow[CH + rl];
+    const int r = r0 + rl;
+    if (r < rows) {
+      float* op = dQ + ((int64_t)b * rows + r) * lddq + h * HD + wj * (HD / 2) + 4 * lh;
+#pragma unroll
+      for (int tj = 0; tj < TB; ++tj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 qv = *reinterpret_cast<const float4*>(sQ + rl * LDP + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh);
+          *reinterpret_cast<float4*>(op + 32 * tj + 8 * q) =
+              make_float4(qv.x * (dq[tj][4 * q] - sdot), qv.y * (dq[tj][4 * q + 1] - sdot),
+                          qv.z * (dq[tj][4 * q + 2] - sdot), qv.w * (dq[tj][4 * q + 3] - sdot));
+        }
+    }
+    __syncthreads();   // sQ / sD / srow are rewritten by the next chunk
   }
+  float* dAb = dApart + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * HD * HD;
+#pragma unroll
+  for (int ti = 0; ti < TB; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TB; ++tj)
+      store16(dAb + (wi * (HD / 2) + 32 * ti + lr) * HD + wj * (HD / 2) + 32 * tj + 4 * lh, da[ti][tj]);
 }
 
 // Single pass: the column term of the column-softmax Jacobian,  S[c] = sum_r k[r][c] dk[r][c],  needs no pass over
@@ -1148,20 +1173,35 @@ extern "C" int hig_linattn_apply_bwd(const float* dY, int64_t lddy, const float*
                   (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(dQ) & 15) == 0,
               "hig_linattn_apply_bwd: Q/dY/dQ must be 16-byte aligned");
   const int nchunk = (rows + CH - 1) / CH;
-  if (hd == 64)
-    hipLaunchKernelGGL(apply_bwd_mfma_kernel<64>, dim3(B * H, nchunk), dim3(256), attn_bwd_lds_bytes<64>(),
-                       hig_stream(stream), dY, lddy, Q, ldq, A, dQ, lddq, scratch, rows, H);
-  else if (hd == 128 && allow_big_lds() == 0)
-    hipLaunchKernelGGL(apply_bwd_mfma_kernel<128>, dim3(B * H, nchunk), dim3(256), attn_bwd_lds_bytes<128>(),
-                       hig_stream(stream), dY, lddy, Q, ldq, A, dQ, lddq, scratch, rows, H);
-  else
+  int nparts = nchunk;   // dA partials per (sample, head) that chunk_sum_kernel adds up
+  if (hd == 64 || (hd == 128 && allow_big_lds() == 0)) {
+    // chunk-walking workgroups (dA accumulated in registers across a workgroup's chunks): ~3 per CU resident
+    static const int tgt = getenv("HIG_APPLY_BWD_WGS") ? atoi(getenv("HIG_APPLY_BWD_WGS")) : 0;   // tuning knob
+    // measured (tools/attn_time.py): one workgroup per (sample, head) walking all its chunks is fastest once
+    // B * H fills the chip (config 2: 49 -> 38 us, config 5: 135 -> 77 us) and needs no partial sums at all
+    const int target = tgt > 0 ? tgt : 256;
+    nparts = (target + B * H - 1) / (B * H);
+    nparts = nparts < 1 ? 1 : (nparts > nchunk ? nchunk : nparts);
+    float* part = nparts == 1 ? dA : scratch;
+    if (hd == 64)
+      hipLaunchKernelGGL(apply_bwd_mfma_kernel<64>, dim3(B * H, nparts), dim3(256), attn_bwd_lds_bytes<64>(),
+                         hig_stream(stream), dY, lddy, Q, ldq, A, dQ, lddq, part, rows, H);
+    else
+      hipLaunchKernelGGL(apply_bwd_mfma_kernel<128>, dim3(B * H, nparts), dim3(256), attn_bwd_lds_bytes<128>(),
+                         hig_stream(stream), dY, lddy, Q, ldq, A, dQ, lddq, part, rows, H);
+    if (nparts == 1) {
+      HIG_CHECK_LAUNCH();
+      return HIG_OK;
+    }
+  } else {
     HD_SWITCH(hd, hipLaunchKernelGGL((apply_bwd_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream),
                                      dY, lddy, Q, ldq, A, dQ, lddq, scratch, rows, H));
+  }
   HIG_CHECK_LAUNCH();
   const int64_t n = (int64_t)hd * hd, groups = (int64_t)B * H;
   const int64_t want = (groups * n / 4 + 255) / 256;
   hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)(want > 2048 ? 2048 : want)), dim3(256), 0, hig_stream(stream),
-                     scratch, nchunk, n, groups, dA);
+                     scratch, nparts, n, groups, dA);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
