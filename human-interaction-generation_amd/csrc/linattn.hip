@@ -987,7 +987,20 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
   }
   const float* Kb = K + (int64_t)b * rows * ld + h * HD;
   const float* Vb = V + (int64_t)b * rows * ld + h * HD;
-  const int r0 = blockIdx.y * CH;
+  const int nchunk = (rows + CH - 1) / CH;
+  constexpr int Q4 = HD / 4, NPRE = CH * Q4 / 256;
+  // chunk-walking like apply_bwd: dA / S staged once per workgroup, next K / V tiles prefetched into registers
+  float4 prek[NPRE], prev[NPRE];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = tid + 256 * i, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
+      const bool ok = r < len;
+      prek[i] = ok ? *reinterpret_cast<const float4*>(Kb + (int64_t)r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      prev[i] = ok ? *reinterpret_cast<const float4*>(Vb + (int64_t)r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  fetch(blockIdx.y * CH);
   __syncthreads();
   float scol[TB][4][4];   // S[c] for the lane's columns (read before sK is overwritten)
   const int lane = tid & 63, wave = tid >> 6;
@@ -1001,60 +1014,64 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
       scol[tj][q][0] = s4.x; scol[tj][q][1] = s4.y; scol[tj][q][2] = s4.z; scol[tj][q][3] = s4.w;
     }
   __syncthreads();
-  for (int idx = tid; idx < CH * (HD / 4); idx += 256) {   // 16 bytes per lane
-    const int rr = idx / (HD / 4), c4 = idx % (HD / 4), r = r0 + rr;
-    float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), v = kk;
-    if (r < len) {
-      const float4 k4 = *reinterpret_cast<const float4*>(Kb + (int64_t)r * ld + 4 * c4);
-      const float4 mx = *reinterpret_cast<const float4*>(smax + 4 * c4);
-      const float4 iv = *reinterpret_cast<const float4*>(sinv + 4 * c4);
-      kk = make_float4(__expf(k4.x - mx.x) * iv.x, __expf(k4.y - mx.y) * iv.y, __expf(k4.z - mx.z) * iv.z,
-                       __expf(k4.w - mx.w) * iv.w);
-      v = *reinterpret_cast<const float4*>(Vb + (int64_t)r * ld + 4 * c4);
-    }
-    *reinterpret_cast<float4*>(sK + rr * LDP + 4 * c4) = kk;
-    *reinterpret_cast<float4*>(sV + rr * LDP + 4 * c4) = v;
-  }
-  __syncthreads();
-  f32x16 dv[TB], dk[TB];
+  for (int chunk = blockIdx.y; chunk < nchunk; chunk += gridDim.y) {
+    const int r0 = chunk * CH;
 #pragma unroll
-  for (int tj = 0; tj < TB; ++tj) {
-    zero16(dv[tj]);
-    zero16(dk[tj]);
-  }
-  {
-    const float* krow = sK + rl * LDP + 4 * lh;                          // X of dV: k[r][c], reduce over c
-    const float* acol = sdA + (4 * lh) * LDP + wj * (HD / 2) + lr;       // Y of dV: dA[c][l] by rows of c
-    const float* vrow = sV + rl * LDP + 4 * lh;                          // X of dk: V[r][l], reduce over l
-    const float* arow = sdA + (wj * (HD / 2) + lr) * LDP + 4 * lh;       // Y of dk: dA[c][l] by rows of c
-#pragma unroll 2
-    for (int ks = 0; ks < HD / 8; ++ks) {
-      const float4 k4 = *reinterpret_cast<const float4*>(krow + 8 * ks);
-      const float4 v4 = *reinterpret_cast<const float4*>(vrow + 8 * ks);
-#pragma unroll
-      for (int tj = 0; tj < TB; ++tj) {
-        const float* ap = acol + (8 * ks) * LDP + 32 * tj;
-        dv[tj] = mfma4(dv[tj], ap[0], ap[LDP], ap[2 * LDP], ap[3 * LDP], k4);
-        const float4 a4 = *reinterpret_cast<const float4*>(arow + 32 * tj * LDP + 8 * ks);
-        dk[tj] = mfma4(dk[tj], a4.x, a4.y, a4.z, a4.w, v4);
+    for (int i = 0; i < NPRE; ++i) {   // k = exp(K - max) / sum on valid rows, 0 (with V = 0) beyond `len`
+      const int idx = tid + 256 * i, rr = idx / Q4, c4 = idx % Q4;
+      float4 kk = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + rr < len) {
+        const float4 mx = *reinterpret_cast<const float4*>(smax + 4 * c4);
+        const float4 iv = *reinterpret_cast<const float4*>(sinv + 4 * c4);
+        kk = make_float4(__expf(prek[i].x - mx.x) * iv.x, __expf(prek[i].y - mx.y) * iv.y,
+                         __expf(prek[i].z - mx.z) * iv.z, __expf(prek[i].w - mx.w) * iv.w);
       }
+      *reinterpret_cast<float4*>(sK + rr * LDP + 4 * c4) = kk;
+      *reinterpret_cast<float4*>(sV + rr * LDP + 4 * c4) = prev[i];
     }
-  }
-  const int r = r0 + rl;
-  if (r < rows) {   // rows in [len, rows) carry k == 0 and V == 0 in LDS: dV == 0 and dK = k * (..) == 0 there
-    float* kp = dK + ((int64_t)b * rows + r) * ldd + h * HD + wj * (HD / 2) + 4 * lh;
-    float* vp = dV + ((int64_t)b * rows + r) * ldd + h * HD + wj * (HD / 2) + 4 * lh;
+    __syncthreads();
+    if (chunk + (int)gridDim.y < nchunk) fetch((chunk + gridDim.y) * CH);
+    f32x16 dv[TB], dk[TB];
 #pragma unroll
     for (int tj = 0; tj < TB; ++tj) {
-      store16(vp + 32 * tj, dv[tj]);
+      zero16(dv[tj]);
+      zero16(dk[tj]);
+    }
+    {
+      const float* krow = sK + rl * LDP + 4 * lh;                          // X of dV: k[r][c], reduce over c
+      const float* acol = sdA + (4 * lh) * LDP + wj * (HD / 2) + lr;       // Y of dV: dA[c][l] by rows of c
+      const float* vrow = sV + rl * LDP + 4 * lh;                          // X of dk: V[r][l], reduce over l
+      const float* arow = sdA + (wj * (HD / 2) + lr) * LDP + 4 * lh;       // Y of dk: dA[c][l] by rows of c
+#pragma unroll 2
+      for (int ks = 0; ks < HD / 8; ++ks) {
+        const float4 k4 = *reinterpret_cast<const float4*>(krow + 8 * ks);
+        const float4 v4 = *reinterpret_cast<const float4*>(vrow + 8 * ks);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 k4 = *reinterpret_cast<const float4*>(sK + rl * LDP + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh);
-        *reinterpret_cast<float4*>(kp + 32 * tj + 8 * q) =
-            make_float4(k4.x * (dk[tj][4 * q] - scol[tj][q][0]), k4.y * (dk[tj][4 * q + 1] - scol[tj][q][1]),
-                        k4.z * (dk[tj][4 * q + 2] - scol[tj][q][2]), k4.w * (dk[tj][4 * q + 3] - scol[tj][q][3]));
+        for (int tj = 0; tj < TB; ++tj) {
+          const float* ap = acol + (8 * ks) * LDP + 32 * tj;
+          dv[tj] = mfma4(dv[tj], ap[0], ap[LDP], ap[2 * LDP], ap[3 * LDP], k4);
+          const float4 a4 = *reinterpret_cast<const float4*>(arow + 32 * tj * LDP + 8 * ks);
+          dk[tj] = mfma4(dk[tj], a4.x, a4.y, a4.z, a4.w, v4);
+        }
       }
     }
+    const int r = r0 + rl;
+    if (r < rows) {   // rows in [len, rows) carry k == 0 and V == 0 in LDS: dV == 0 and dK = k * (..) == 0 there
+      float* kp = dK + ((int64_t)b * rows + r) * ldd + h * HD + wj * (HD / 2) + 4 * lh;
+      float* vp = dV + ((int64_t)b * rows + r) * ldd + h * HD + wj * (HD / 2) + 4 * lh;
+#pragma unroll
+      for (int tj = 0; tj < TB; ++tj) {
+        store16(vp + 32 * tj, dv[tj]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 k4 = *reinterpret_cast<const float4*>(sK + rl * LDP + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh);
+          *reinterpret_cast<float4*>(kp + 32 * tj + 8 * q) =
+              make_float4(k4.x * (dk[tj][4 * q] - scol[tj][q][0]), k4.y * (dk[tj][4 * q + 1] - scol[tj][q][1]),
+                          k4.z * (dk[tj][4 * q + 2] - scol[tj][q][2]), k4.w * (dk[tj][4 * q + 3] - scol[tj][q][3]));
+        }
+      }
+    }
+    __syncthreads();   // sK / sV are rewritten by the next chunk
   }
 }
 
@@ -1217,11 +1234,15 @@ extern "C" int hig_linattn_ctx_bwd(const float* dA, const float* A, const float*
               "hig_linattn_ctx_bwd: dK/dV must be 16-byte aligned");
   const int nchunk = (rows + CH - 1) / CH;
   if (hd == 64 || (hd == 128 && allow_big_lds() == 0)) {   // single pass (the column term comes from A and dA)
+    static const int tgt = getenv("HIG_CTX_BWD_WGS") ? atoi(getenv("HIG_CTX_BWD_WGS")) : 0;   // tuning knob
+    const int target = tgt > 0 ? tgt : 256;
+    int gy = (target + B * H - 1) / (B * H);
+    gy = gy < 1 ? 1 : (gy > nchunk ? nchunk : gy);
     if (hd == 64)
-      hipLaunchKernelGGL(ctx_bwd_mfma_kernel<64>, dim3(B * H, nchunk), dim3(256), attn_bwd_lds_bytes<64>(),
+      hipLaunchKernelGGL(ctx_bwd_mfma_kernel<64>, dim3(B * H, gy), dim3(256), attn_bwd_lds_bytes<64>(),
                          hig_stream(stream), dA, A, K, V, ld, kstat, length, dK, dV, ldd, rows, H);
     else
-      hipLaunchKernelGGL(ctx_bwd_mfma_kernel<128>, dim3(B * H, nchunk), dim3(256), attn_bwd_lds_bytes<128>(),
+      hipLaunchKernelGGL(ctx_bwd_mfma_kernel<128>, dim3(B * H, gy), dim3(256), attn_bwd_lds_bytes<128>(),
                          hig_stream(stream), dA, A, K, V, ld, kstat, length, dK, dV, ldd, rows, H);
     HIG_CHECK_LAUNCH();
     return HIG_OK;
