@@ -61,6 +61,7 @@ class GemmDesc(C.Structure):
         ("ss", C.c_void_p), ("ss_ld", C.c_int64), ("ss_shift_off", C.c_int32),
         ("rows_per_sample", C.c_int32),
         ("pos", C.c_void_p), ("ldpos", C.c_int64), ("T", C.c_int32), ("pos_shift", C.c_int32),
+        ("xcolsum", C.c_void_p),
     ]
 
 

@@ -455,17 +455,24 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
   // exact-fp32 mode: both operands read reduce-slow straight from their row-major buffers.
   // bf16 product modes: both are transposed first (LN fused into the transpose) so the GEMM gets
   // reduce-contiguous operands -- the layout the bf16 MFMA fragments need.
+  // `dbias` (optional) = column sums of dC, the bias gradient of the same Linear: in the exact-fp32 path the wgrad
+  // GEMM produces it while it streams dC (its reduce-slow X operand); otherwise a separate column-sum pass.
   auto wgrad_act = [&](const float* dC, int n_out, const float* act, int k_in, float* out, int64_t rows,
-                       const float* stats, const float* gamma, const float* beta) -> int {
+                       const float* stats, const float* gamma, const float* beta, float* dbias = nullptr) -> int {
     if (D.prec != HIG_PREC_F32 && rows % 32 == 0) {
       float* ta = b + bw.tA;
       float* tb = b + bw.tB;
+      if (dbias) HIG_TRY(hig_colsum(dC, n_out, rows, n_out, dbias, colp, stream));
       HIG_TRY(hig_transpose(dC, n_out, (int)rows, n_out, ta, rows, nullptr, nullptr, nullptr, stream));
       HIG_TRY(hig_transpose(act, k_in, (int)rows, k_in, tb, rows, stats, gamma, beta, stream));
       return wgrad(G(ta, rows, 0, tb, rows, 0, out, k_in, n_out, k_in, rows).prec(D.prec));
     }
     G gd(dC, n_out, 1, act, k_in, 1, out, k_in, n_out, k_in, rows);
     if (stats) gd.ln(1, stats, gamma, beta);
+    if (dbias) {
+      if (n_out % 4 == 0) gd.xsum(dbias);
+      else HIG_TRY(hig_colsum(dC, n_out, rows, n_out, dbias, colp, stream));
+    }
     return wgrad(gd);
   };
   // W (out, in) row-major -> W^T (in, out): the data-gradient GEMM dA = dC . W then reads both
@@ -484,8 +491,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
   auto sty_bwd = [&](int l, int s, const float* dh, const float* y, const float* a_saved, const float* stats,
                      int norm_w, int norm_b, int out_w, int out_b, int64_t wt_off, float* dy_out) -> int {
     const float* ssl = ws + w.ss + (int64_t)s * 2 * d;
-    HIG_TRY(colsum(dh, d, M, d, GL(grads, l, out_b)));
-    HIG_TRY(wgrad_act(dh, d, a_saved, d, GL(grads, l, out_w), M, nullptr, nullptr, nullptr));
+    HIG_TRY(wgrad_act(dh, d, a_saved, d, GL(grads, l, out_w), M, nullptr, nullptr, nullptr, GL(grads, l, out_b)));
     HIG_TRY(hig_gemm_launch(G(dh, d, 0, wT + wt_off, d, 0, b + bw.t1, d, M, d, d).prec(D.prec).g, 1, nullptr, st));
     return hig_ln_bwd(b + bw.t1, d, y, d, stats, PL(params, l, norm_w), PL(params, l, norm_b), ssl, ss_ld, d, 1,
                       nullptr, 0, dy_out, d, M, d, D.T, GL(grads, l, norm_w), GL(grads, l, norm_b),
@@ -546,13 +552,13 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
     HIG_TRY(sty_bwd(l, D.nsty * l + D.nsty - 1, dh, lb + w.y3, lb + w.a3, lb + w.st5, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B,
                     HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B, o_sty3, b + bw.t2));
     const float* dy3 = b + bw.t2;
-    HIG_TRY(colsum(dy3, d, M, d, GL(grads, l, HIG_L_FFN_B2)));
-    HIG_TRY(wgrad_act(dy3, d, lb + w.f1, ff, GL(grads, l, HIG_L_FFN_W2), M, nullptr, nullptr, nullptr));
+    HIG_TRY(wgrad_act(dy3, d, lb + w.f1, ff, GL(grads, l, HIG_L_FFN_W2), M, nullptr, nullptr, nullptr,
+                      GL(grads, l, HIG_L_FFN_B2)));
     HIG_TRY(hig_gemm_launch(G(dy3, d, 0, wT + o_w2t, d, 0, b + bw.tff, ff, M, ff, d).prec(D.prec)
                                 .epi(HIG_EPI_DGELU).aux(const_cast<float*>(lb + w.z1), ff).g, 1, nullptr, st));
     const float* dz1 = b + bw.tff;
-    HIG_TRY(colsum(dz1, ff, M, ff, GL(grads, l, HIG_L_FFN_B1)));
-    HIG_TRY(wgrad_act(dz1, ff, hffn, d, GL(grads, l, HIG_L_FFN_W1), M, nullptr, nullptr, nullptr));
+    HIG_TRY(wgrad_act(dz1, ff, hffn, d, GL(grads, l, HIG_L_FFN_W1), M, nullptr, nullptr, nullptr,
+                      GL(grads, l, HIG_L_FFN_B1)));
     HIG_TRY(hig_gemm_launch(G(dz1, ff, 0, wT + o_w1t, ff, 0, dh_alt, d, M, d, ff).prec(D.prec)
                                 .epi(HIG_EPI_RES).res(dh, d).g, 1, nullptr, st));
     { float* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h2), or d(h2b) in the interaction model
@@ -570,8 +576,8 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                                     dqkv + halfM * 3 * d, 3 * d, b + bw.dA, Bp, D.T, D.H, D.hd, b + bw.attn, stream));
       HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, lb + w.Ai, lb + w.iqkv + d, lb + w.iqkv + 2 * d, 3 * d, lb + w.ksti, len_partner,
                                   dqkv + d, dqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, b + bw.attn, stream));
-      HIG_TRY(colsum(dqkv, 3 * d, M, 3 * d, GL(grads, l, HIG_L_INT_QKV_B)));
-      HIG_TRY(wgrad_act(dqkv, 3 * d, lb + w.xn3, d, GL(grads, l, HIG_L_INT_QKV_W), M, nullptr, nullptr, nullptr));
+      HIG_TRY(wgrad_act(dqkv, 3 * d, lb + w.xn3, d, GL(grads, l, HIG_L_INT_QKV_W), M, nullptr, nullptr, nullptr,
+                        GL(grads, l, HIG_L_INT_QKV_B)));
       HIG_TRY(hig_gemm_launch(G(dqkv, 3 * d, 0, wT + o_iqkv, 3 * d, 0, b + bw.t2, d, M, d, 3 * d).prec(D.prec).g, 1,
                               nullptr, st));
       HIG_TRY(hig_ln_bwd(b + bw.t2, d, lb + w.h2, d, lb + w.st6, PL(params, l, HIG_L_INT_NORM_W),
@@ -593,8 +599,8 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
       HIG_TRY(hig_linattn_apply_bwd(b + bw.t2, d, lb + w.qc, d, Ac, b + bw.t1, d, b + bw.dA, D.B, D.T, D.H, D.hd,
                                     b + bw.attn, stream));
     const float* dqc = b + bw.t1;
-    HIG_TRY(colsum(dqc, d, M, d, GL(grads, l, HIG_L_CA_Q_B)));
-    HIG_TRY(wgrad_act(dqc, d, lb + w.xn2, d, GL(grads, l, HIG_L_CA_Q_W), M, nullptr, nullptr, nullptr));
+    HIG_TRY(wgrad_act(dqc, d, lb + w.xn2, d, GL(grads, l, HIG_L_CA_Q_W), M, nullptr, nullptr, nullptr,
+                      GL(grads, l, HIG_L_CA_Q_B)));
     HIG_TRY(hig_gemm_launch(G(dqc, d, 0, wT + o_caq, d, 0, b + bw.t2, d, M, d, d).prec(D.prec).g, 1, nullptr, st));
     HIG_TRY(hig_ln_bwd(b + bw.t2, d, lb + w.h1, d, lb + w.st3, PL(params, l, HIG_L_CA_NORM_W),
                        PL(params, l, HIG_L_CA_NORM_B), nullptr, 0, 0, 0, dh, d, dh_alt, d, M, d, D.T,
@@ -604,9 +610,8 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
     if (!D.full)
       HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, Ac, kv, kv + d, 2 * d, kstc, nullptr, b + bw.dkv, b + bw.dkv + d, 2 * d, D.B,
                                   D.N, D.H, D.hd, b + bw.attn, stream));
-    HIG_TRY(colsum(b + bw.dkv, 2 * d, Mt, 2 * d, GL(grads, l, HIG_L_CA_KV_B)));
     HIG_TRY(wgrad_act(b + bw.dkv, 2 * d, xf_out, Lt, GL(grads, l, HIG_L_CA_KV_W), Mt, tc + tl.stt,
-                      PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B)));
+                      PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B), GL(grads, l, HIG_L_CA_KV_B)));
     HIG_TRY(hig_gemm_launch(G(b + bw.dkv, 2 * d, 0, wT + o_kv, 2 * d, 0, b + bw.dxfn, Lt, Mt, Lt, 2 * d).prec(D.prec).g,
                             1, nullptr, st));
     HIG_TRY(hig_ln_bwd(b + bw.dxfn, Lt, xf_out, Lt, tc + tl.stt, PL(params, l, HIG_L_CA_TNORM_W),
@@ -627,8 +632,8 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
       HIG_TRY(hig_linattn_ctx_bwd(b + bw.dA, lb + w.A1, lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, lb + w.kst1, length, dqkv + d,
                                   dqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, b + bw.attn, stream));
     }
-    HIG_TRY(colsum(dqkv, 3 * d, M, 3 * d, GL(grads, l, HIG_L_SA_QKV_B)));
-    HIG_TRY(wgrad_act(dqkv, 3 * d, lb + w.xn1, d, GL(grads, l, HIG_L_SA_QKV_W), M, nullptr, nullptr, nullptr));
+    HIG_TRY(wgrad_act(dqkv, 3 * d, lb + w.xn1, d, GL(grads, l, HIG_L_SA_QKV_W), M, nullptr, nullptr, nullptr,
+                      GL(grads, l, HIG_L_SA_QKV_B)));
     HIG_TRY(hig_gemm_launch(G(dqkv, 3 * d, 0, wT + o_qkv, 3 * d, 0, b + bw.t2, d, M, d, 3 * d).prec(D.prec).g, 1,
                             nullptr, st));
     HIG_TRY(hig_ln_bwd(b + bw.t2, d, hin, d, lb + w.st1, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B),

@@ -47,6 +47,7 @@ struct KArgs {
   int r_chunk;     // reduce elements per split (multiple of BK)
   int64_t slab;    // floats between split outputs
   int vecx, vecy, vecc;  // 16-byte access allowed for X / Y / (C,res,aux)
+  float* xsum;           // reduce-slow X only: xsum[split][i] = sum_r X[r][i] over this split (bias gradient), or null
 };
 
 template <int XF>
@@ -424,10 +425,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
   // registers as the fetch of tile kt+2, (3) the MFMA block on the current buffer, (4) barrier.
   // The only global-memory wait is on loads that had a full MFMA block to land, the LDS writes
   // have a full MFMA block before the barrier, and one register set suffices.
+  // Weight gradients read dC as the reduce-slow X operand; the tiles of the first output-column block sum what they
+  // stage over the reduce rows -- that IS the bias gradient of the same layer (one column sum of dC saved per layer op).
+  f32x4 xsum4 = {0.f, 0.f, 0.f, 0.f};
+  bool track_xsum = false;
+  auto add_xsum = [&]() {
+    if constexpr (X_RS && PREC == HIG_PREC_F32) {
+      if (track_xsum) {
+#pragma unroll
+        for (int p = 0; p < XP; ++p) xsum4 += xr[p];
+      }
+    }
+  };
   auto iteration = [&](int kt, int nk, int buf) {
     constexpr int NG = PREC != HIG_PREC_F32 ? BK / 16 : BK / 8;  // k-groups per tile
     if (kt + 1 < nk) {
       mask_tiles(rbeg + (kt + 1) * BK);
+      add_xsum();
       transform(rbeg + (kt + 1) * BK);
       store_tiles(buf ^ 1);
     }
@@ -451,8 +465,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
       for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[tj][ti][e] = 0.f;
+    if constexpr (X_RS && PREC == HIG_PREC_F32) {
+      track_xsum = a.xsum != nullptr && j0 == 0;
+      xsum4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if (nk > 0) {
       mask_tiles(rbeg);
+      add_xsum();
       transform(rbeg);
       store_tiles(0);
       if (nk > 1) load_tiles(rbeg + BK);
@@ -461,6 +480,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
     for (int kt = 0; kt < nk; kt += 2) {
       iteration(kt, nk, 0);
       if (kt + 1 < nk) iteration(kt + 1, nk, 1);
+    }
+    if constexpr (X_RS && PREC == HIG_PREC_F32) {
+      if (track_xsum) {   // fold the NTHREADS / XQ thread rows that share a column quad, through the idle staging LDS
+        float* sB = smem;
+        *reinterpret_cast<f32x4*>(sB + x_r * BI + 4 * x_c4) = xsum4;
+        __syncthreads();
+        if (tid < BI && i0 + tid < g.I) {
+          float t = 0.f;
+#pragma unroll
+          for (int r = 0; r < NTHREADS / XQ; ++r) t += sB[r * BI + tid];
+          a.xsum[(int64_t)split * g.I + i0 + tid] = t;
+        }
+        __syncthreads();
+      }
     }
     // epilogue coordinates of THIS tile, then start fetching the next one (the staging registers
     // and both LDS buffers are free: the main loop ended on a barrier)
@@ -662,6 +695,7 @@ template <int BI, int BJ, bool X_RS, bool Y_RS, int XF, bool XF_ON_Y, int EPI>
 int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipStream_t st) {
   KArgs a;
   a.g = g;
+  a.xsum = nullptr;
   const int nbi = (g.I + BI - 1) / BI;
   a.nbj = (g.J + BJ - 1) / BJ;
   a.ntiles = nbi * a.nbj;
@@ -676,6 +710,9 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
     a.slab = slab;
     a.g.C = slabs;
     a.g.ldc = g.J;  // slabs are dense [I][J]
+  }
+  if (g.xcolsum) {
+    if constexpr (X_RS) a.xsum = splits > 1 ? slabs + (int64_t)splits * slab : g.xcolsum;   // [splits][I] after the slabs
   }
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vecx = (g.ldx % 4 == 0) && al16(g.X);
@@ -729,6 +766,11 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
     const int blocks = (int)(want > 2048 ? 2048 : want);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, splits, slab, n4, g.C);
     HIG_CHECK_LAUNCH();
+    if (a.xsum) {
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((g.I / 4 + 255) / 256), dim3(256), 0, st, a.xsum, splits, (int64_t)g.I,
+                         (int64_t)g.I / 4, g.xcolsum);
+      HIG_CHECK_LAUNCH();
+    }
   }
   return HIG_OK;
 }
@@ -801,6 +843,9 @@ int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_
     if (g.xf == HIG_XF_LN_MOD_SILU) HIG_REQUIRE(g.ss && g.rows_per_sample > 0, "hig_gemm: modulation needs ss");
   }
   const int64_t slab = (int64_t)g.I * g.J;
+  if (g.xcolsum)
+    HIG_REQUIRE(g.x_rs == 1 && g.prec == HIG_PREC_F32 && g.I % 4 == 0 && (g.xf == HIG_XF_NONE || g.xf_on_y),
+                "hig_gemm: xcolsum needs a reduce-slow X operand, fp32 products, I %% 4 == 0");
   if (splits > 1) HIG_REQUIRE(slabs && g.epi == HIG_EPI_NONE && slab % 4 == 0 && g.ldc == g.J,
                               "hig_gemm: split-R needs slabs, EPI_NONE, dense C");
 #define CASE(xrs, yrs, xfv, ony, epiv)                                                   \

@@ -29,6 +29,7 @@ struct G {  // small builder for gemm descriptors
   G& ln(int on_y, const float* stats, const float* gamma, const float* beta) {
     g.xf = HIG_XF_LN; g.xf_on_y = on_y; g.stats = stats; g.gamma = gamma; g.beta = beta; return *this;
   }
+  G& xsum(float* out) { g.xcolsum = out; return *this; }   // wgrad: also the bias gradient (column sums of dC)
   G& mod(const float* ss, int64_t ss_ld, int shift_off, int rows_per_sample) {
     g.xf = HIG_XF_LN_MOD_SILU; g.ss = ss; g.ss_ld = ss_ld; g.ss_shift_off = shift_off;
     g.rows_per_sample = rows_per_sample; return *this;
@@ -45,7 +46,7 @@ inline int wgrad_splits(int64_t I, int64_t J, int64_t R, int64_t slab_floats) {
   int64_t s = target / tiles;
   const int64_t maxs = R / 256 > 1 ? R / 256 : 1;
   if (s > maxs) s = maxs;
-  while (s > 1 && s * I * J > slab_floats) --s;
+  while (s > 1 && s * (I * J + I) > slab_floats) --s;   // slabs + the per-split column sums of X behind them
   if ((I * J) % 4 != 0) s = 1;
   return (int)(s < 1 ? 1 : s);
 }

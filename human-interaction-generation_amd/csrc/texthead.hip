@@ -199,15 +199,21 @@ extern "C" int hig_text_head_bwd(const hig_text_dims* dims, const void* const* p
     return hig_gemm_launch(gd.g, s, slabs, st);
   };
   // dW[n][k] = sum_m dC[m][n] * act[m][k]; bf16 product modes transpose both operands first
-  auto wgrad_act = [&](const float* dC, int n_out, const float* act, int k_in, float* out, int64_t rows) -> int {
+  // dbias = column sums of dC (the bias gradient): from the wgrad GEMM itself in the exact-fp32 path
+  auto wgrad_act = [&](const float* dC, int n_out, const float* act, int k_in, float* out, int64_t rows,
+                       float* dbias) -> int {
     if (D.prec != HIG_PREC_F32 && rows % 32 == 0) {
       float* ta = b + bw.tA;
       float* tb = b + bw.tB;
+      HIG_TRY(hig_colsum(dC, n_out, rows, n_out, dbias, colp, stream));
       HIG_TRY(hig_transpose(dC, n_out, (int)rows, n_out, ta, rows, nullptr, nullptr, nullptr, stream));
       HIG_TRY(hig_transpose(act, k_in, (int)rows, k_in, tb, rows, nullptr, nullptr, nullptr, stream));
       return wgrad(G(ta, rows, 0, tb, rows, 0, out, k_in, n_out, k_in, rows).prec(D.prec));
     }
-    return wgrad(G(dC, n_out, 1, act, k_in, 1, out, k_in, n_out, k_in, rows));
+    G gd(dC, n_out, 1, act, k_in, 1, out, k_in, n_out, k_in, rows);
+    if (n_out % 4 == 0) gd.xsum(dbias);
+    else HIG_TRY(hig_colsum(dC, n_out, rows, n_out, dbias, colp, stream));
+    return wgrad(gd);
   };
   // dX = dC . W with W (out_f, in_f) transposed first, so both operands are reduce-contiguous
   auto dgrad = [&](const float* dC, const float* W, int out_f, int in_f, int64_t rows, float* dX, int epi,
@@ -259,13 +265,11 @@ extern "C" int hig_text_head_bwd(const hig_text_dims* dims, const void* const* p
                        nullptr, 0, lnp, stream));
     const float* dr2 = t1;
     // r2 = x1 + linear2(gelu(z)),  z = linear1(x1)
-    HIG_TRY(colsum(dr2, Lt, M, Lt, TGL(grads, l, HIG_TL_FF2_B)));
-    HIG_TRY(wgrad_act(dr2, Lt, lb + w.f, ff, TGL(grads, l, HIG_TL_FF2_W), M));
+    HIG_TRY(wgrad_act(dr2, Lt, lb + w.f, ff, TGL(grads, l, HIG_TL_FF2_W), M, TGL(grads, l, HIG_TL_FF2_B)));
     HIG_TRY(dgrad(dr2, TPL(params, l, HIG_TL_FF2_W), Lt, ff, M, b + bw.dff, HIG_EPI_DGELU, nullptr,
                   const_cast<float*>(lb + w.z)));
     const float* dz = b + bw.dff;
-    HIG_TRY(colsum(dz, ff, M, ff, TGL(grads, l, HIG_TL_FF1_B)));
-    HIG_TRY(wgrad_act(dz, ff, lb + w.x1, Lt, TGL(grads, l, HIG_TL_FF1_W), M));
+    HIG_TRY(wgrad_act(dz, ff, lb + w.x1, Lt, TGL(grads, l, HIG_TL_FF1_W), M, TGL(grads, l, HIG_TL_FF1_B)));
     HIG_TRY(dgrad(dz, TPL(params, l, HIG_TL_FF1_W), ff, Lt, M, t2, HIG_EPI_RES, dr2, nullptr));  // t2 = d(x1)
     // norm1: x1 = LN(r1)
     HIG_TRY(hig_ln_bwd(t2, Lt, lb + w.r1, Lt, lb + w.st1, TPL(params, l, HIG_TL_N1_W), TPL(params, l, HIG_TL_N1_B), nullptr,
@@ -273,21 +277,18 @@ extern "C" int hig_text_head_bwd(const hig_text_dims* dims, const void* const* p
                        nullptr, 0, lnp, stream));
     const float* dr1 = t1;
     // r1 = xin + out_proj(att)
-    HIG_TRY(colsum(dr1, Lt, M, Lt, TGL(grads, l, HIG_TL_OUT_B)));
-    HIG_TRY(wgrad_act(dr1, Lt, lb + w.att, Lt, TGL(grads, l, HIG_TL_OUT_W), M));
+    HIG_TRY(wgrad_act(dr1, Lt, lb + w.att, Lt, TGL(grads, l, HIG_TL_OUT_W), M, TGL(grads, l, HIG_TL_OUT_B)));
     HIG_TRY(dgrad(dr1, TPL(params, l, HIG_TL_OUT_W), Lt, Lt, M, t2, HIG_EPI_NONE, nullptr, nullptr));  // t2 = d(att)
     float* dqkv = b + bw.dqkv;
     HIG_TRY(hig_fullattn_bwd(t2, Lt, lb + w.att, Lt, lb + w.qkv, 3 * Lt, lb + w.qkv + Lt, lb + w.qkv + 2 * Lt, 3 * Lt, D.B,
                              D.N, D.N, D.H, D.hd, nullptr, lb + w.lse, b + bw.delta, dqkv, 3 * Lt, dqkv + Lt,
                              dqkv + 2 * Lt, 3 * Lt, stream));
-    HIG_TRY(colsum(dqkv, 3 * Lt, M, 3 * Lt, TGL(grads, l, HIG_TL_IN_B)));
-    HIG_TRY(wgrad_act(dqkv, 3 * Lt, xin, Lt, TGL(grads, l, HIG_TL_IN_W), M));
+    HIG_TRY(wgrad_act(dqkv, 3 * Lt, xin, Lt, TGL(grads, l, HIG_TL_IN_W), M, TGL(grads, l, HIG_TL_IN_B)));
     HIG_TRY(dgrad(dqkv, TPL(params, l, HIG_TL_IN_W), 3 * Lt, Lt, M, d, HIG_EPI_RES, dr1, nullptr));   // d = d(xin)
   }
   // ---- text_pre_proj -----------------------------------------------------------------------
   if (D.pre) {
-    HIG_TRY(colsum(d, Lt, M, Lt, TG(grads, HIG_T_PRE_B)));
-    HIG_TRY(wgrad_act(d, Lt, clip_out, D.W, TG(grads, HIG_T_PRE_W), M));
+    HIG_TRY(wgrad_act(d, Lt, clip_out, D.W, TG(grads, HIG_T_PRE_W), M, TG(grads, HIG_T_PRE_B)));
     if (dclip) HIG_TRY(dgrad(d, TP(params, HIG_T_PRE_W), Lt, D.W, M, dclip, HIG_EPI_NONE, nullptr, nullptr));
   } else if (dclip) {
     if (hipMemcpyAsync(dclip, d, (size_t)M * Lt * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)

@@ -268,6 +268,8 @@ typedef struct hig_gemm_desc {
   const float* ss; int64_t ss_ld; int32_t ss_shift_off; int32_t rows_per_sample;
   const float* pos; int64_t ldpos; int32_t T;
   int32_t pos_shift;                 /* EPI_BIAS_POS adds pos[(i % T) - pos_shift]; rows with a negative index get none */
+  float* xcolsum;                    /* optional, x_rs == 1 + fp32 products + I % 4 == 0: xcolsum[i] = sum_r X[r][i] -- the
+                                        bias gradient that goes with a weight gradient dW = dC^T . act (X = dC) */
 } hig_gemm_desc;
 int hig_gemm(const hig_gemm_desc* g, hig_stream_t stream);
 

@@ -456,3 +456,25 @@ def test_transpose_batch_matches_torch():
         assert torch.equal(b, a.t())
     with pytest.raises(RuntimeError, match="matrices"):
         _lib.check(_lib.lib().hig_transpose_batch(13, srcs, dsts, rows, cols, _lib.stream_ptr()))
+
+
+@pytest.mark.parametrize("I,J,R", [(512, 512, 1000), (1536, 512, 196), (64, 32, 77), (132, 256, 640)])
+def test_gemm_wgrad_with_fused_column_sums(I, J, R):
+    """wgrad layout (X = dC reduce-slow, Y = activations reduce-slow) with xcolsum: C = X^T-contracted product
+    and xcolsum[i] = sum_r X[r][i] (the bias gradient) from the same pass."""
+    import ctypes as C
+    X, Y = rnd(R, I, seed=3), rnd(R, J, seed=4)
+    out = torch.full((I, J), float("nan"), device=DEV)
+    xs = torch.full((I,), float("nan"), device=DEV)
+    d = _lib.GemmDesc()
+    Xd, Yd = X.to(DEV), Y.to(DEV)
+    d.X, d.ldx, d.x_rs, d.Y, d.ldy, d.y_rs = Xd.data_ptr(), I, 1, Yd.data_ptr(), J, 1
+    d.C, d.ldc, d.I, d.J, d.R = out.data_ptr(), J, I, J, R
+    d.xf, d.epi, d.prec = _lib.XF_NONE, _lib.EPI_NONE, _lib.PREC_F32
+    d.xcolsum = xs.data_ptr()
+    _lib.check(_lib.lib().hig_gemm(C.byref(d), _lib.stream_ptr()))
+    assert rel(out, X.double().t() @ Y.double()) < 2e-6
+    assert rel(xs, X.double().sum(0)) < 2e-6
+    d.x_rs, d.ldx = 0, R                     # a reduce-contiguous X cannot provide the sums: loud error
+    with pytest.raises(RuntimeError, match="xcolsum"):
+        _lib.check(_lib.lib().hig_gemm(C.byref(d), _lib.stream_ptr()))
