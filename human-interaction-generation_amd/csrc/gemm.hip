@@ -47,7 +47,8 @@ struct KArgs {
   int r_chunk;     // reduce elements per split (multiple of BK)
   int64_t slab;    // floats between split outputs
   int vecx, vecy, vecc;  // 16-byte access allowed for X / Y / (C,res,aux)
-  float* xsum;           // reduce-slow X only: xsum[split][i] = sum_r X[r][i] over this split (bias gradient), or null
+  float* xsum;           // reduce-slow X only: xsum[split * xsum_stride + i] = sum_r X[r][i] over this split, or null
+  int64_t xsum_stride;   // (the per-split sums sit right behind each split's slab, so one reduction pass folds both)
 };
 
 template <int XF>
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
           float t = 0.f;
 #pragma unroll
           for (int r = 0; r < NTHREADS / XQ; ++r) t += sB[r * BI + tid];
-          a.xsum[(int64_t)split * g.I + i0 + tid] = t;
+          a.xsum[(int64_t)split * a.xsum_stride + i0 + tid] = t;
         }
         __syncthreads();
       }
@@ -677,17 +678,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
   }  // persistent tile loop
 }
 
-// out[e] = sum_s slabs[s][e]
+// out[e] = sum_s slabs[s][e] for the first n4 float4 of a slab; the float4 behind them (n4 <= e < n4_all: the
+// per-split column sums of X) go to out2
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit, int64_t slab,
-                                    int64_t n4, float* __restrict__ out) {
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n4;
+                                    int64_t n4, float* __restrict__ out, int64_t n4_all = 0,
+                                    float* __restrict__ out2 = nullptr) {
+  const int64_t total = n4_all > n4 ? n4_all : n4;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
     float4 s = reinterpret_cast<const float4*>(slabs)[e];
     for (int k = 1; k < nsplit; ++k) {
       const float4 t = reinterpret_cast<const float4*>(slabs + k * slab)[e];
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    reinterpret_cast<float4*>(out)[e] = s;
+    if (e < n4) reinterpret_cast<float4*>(out)[e] = s;
+    else reinterpret_cast<float4*>(out2)[e - n4] = s;
   }
 }
 
@@ -696,6 +701,7 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
   KArgs a;
   a.g = g;
   a.xsum = nullptr;
+  a.xsum_stride = 0;
   const int nbi = (g.I + BI - 1) / BI;
   a.nbj = (g.J + BJ - 1) / BJ;
   a.ntiles = nbi * a.nbj;
@@ -712,7 +718,15 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
     a.g.ldc = g.J;  // slabs are dense [I][J]
   }
   if (g.xcolsum) {
-    if constexpr (X_RS) a.xsum = splits > 1 ? slabs + (int64_t)splits * slab : g.xcolsum;   // [splits][I] after the slabs
+    if constexpr (X_RS) {
+      if (splits > 1) {   // each split's slab is followed by its I column sums
+        a.slab = slab + g.I;
+        a.xsum = slabs + slab;
+        a.xsum_stride = a.slab;
+      } else {
+        a.xsum = g.xcolsum;
+      }
+    }
   }
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vecx = (g.ldx % 4 == 0) && al16(g.X);
@@ -764,13 +778,9 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
     const int64_t n4 = (int64_t)g.I * g.J / 4;
     const int64_t want = (n4 + 255) / 256;
     const int blocks = (int)(want > 2048 ? 2048 : want);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, splits, slab, n4, g.C);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, splits, a.slab, n4, g.C,
+                       a.xsum ? n4 + g.I / 4 : (int64_t)0, a.xsum ? g.xcolsum : (float*)nullptr);
     HIG_CHECK_LAUNCH();
-    if (a.xsum) {
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((g.I / 4 + 255) / 256), dim3(256), 0, st, a.xsum, splits, (int64_t)g.I,
-                         (int64_t)g.I / 4, g.xcolsum);
-      HIG_CHECK_LAUNCH();
-    }
   }
   return HIG_OK;
 }
