@@ -307,61 +307,94 @@ __global__ __launch_bounds__(256) void apply_mfma_kernel(const float* __restrict
   }
 }
 
-// A[b,h][c][l] = sum_r softmax_r(K)[r,c] V[r,l]  (+ kstat), one workgroup per (sample, head)
+// A[b,h][c][l] = sum_r softmax_r(K)[r,c] V[r,l]  (+ kstat): one workgroup per (sample, head) walks the row chunks
+// ONCE with a running column max (online softmax): when a chunk raises the max of channel c, the accumulator row c
+// and the running sum are rescaled by exp(m_old - m_new).  The next K / V tiles are prefetched into registers.
 template <int HD>
 __global__ __launch_bounds__(256) void ctx_mfma_kernel(const float* __restrict__ K, const float* __restrict__ V,
                                                        int64_t ld, int rows, int H,
                                                        const int64_t* __restrict__ length, float* __restrict__ A,
                                                        float* __restrict__ kstat) {
-  constexpr int LDP = HD + 4, RG = 256 / HD, TB = HD / 64;   // TB x TB accumulator blocks per wave
-  __shared__ __attribute__((aligned(16))) float sP[CH * LDP];   // [r][c] = exp(K - colmax)
+  constexpr int LDP = HD + 4, TB = HD / 64, Q4 = HD / 4, NRG = 256 / Q4, PER = CH / NRG;
+  __shared__ __attribute__((aligned(16))) float sP[CH * LDP];   // [r][c] = exp(K - running max)
   __shared__ __attribute__((aligned(16))) float sV[CH * LDP];   // [r][l]
-  __shared__ float sred[256];
-  __shared__ float smax[HD];
-  __shared__ float ssum[HD];
+  __shared__ __attribute__((aligned(16))) float sred[NRG * HD]; // per row-group column maxima, at the end column sums
+  __shared__ __attribute__((aligned(16))) float smax[HD];       // running column max
+  __shared__ __attribute__((aligned(16))) float sscale[HD];     // exp(m_old - m_new) of the current chunk
   const int tid = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   int len = rows;
   if (length) len = (int)min<int64_t>(max<int64_t>(length[b], 0), rows);
   const float* Kb = K + (int64_t)b * rows * ld + h * HD;
   const float* Vb = V + (int64_t)b * rows * ld + h * HD;
-  const int c = tid % HD, rg = tid / HD;
-  {  // pass 1: column max over the valid rows
-    float m = -INFINITY;
-    for (int r = rg; r < len; r += RG) m = fmaxf(m, Kb[(int64_t)r * ld + c]);
-    sred[tid] = m;
-    __syncthreads();
-    if (tid < HD) {
-      for (int g2 = 1; g2 < RG; ++g2) m = fmaxf(m, sred[g2 * HD + tid]);
-      smax[tid] = m;
-    }
-    __syncthreads();
-  }
+  const int c4 = tid % Q4, rgrp = tid / Q4;
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
+  float4 kreg[PER], vreg[PER];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int r = r0 + rgrp + NRG * i;
+      if (r < len) {
+        kreg[i] = *reinterpret_cast<const float4*>(Kb + (int64_t)r * ld + 4 * c4);
+        vreg[i] = *reinterpret_cast<const float4*>(Vb + (int64_t)r * ld + 4 * c4);
+      } else {
+        kreg[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        vreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  fetch(0);
+  if (tid < HD) smax[tid] = -INFINITY;
   f32x16 acc[TB][TB];
 #pragma unroll
   for (int ti = 0; ti < TB; ++ti)
 #pragma unroll
     for (int tj = 0; tj < TB; ++tj) zero16(acc[ti][tj]);
-  float ks = 0.f;                     // this thread's share of sum_r exp(K[r][c] - max[c])
-  const float cm = smax[c];
+  float4 ks4 = make_float4(0.f, 0.f, 0.f, 0.f);   // this thread's share of sum_r exp(K[r][c] - m[c]) for its 4 channels
   const float* pcol = sP + (4 * lh) * LDP + wi * (HD / 2) + lr;
   const float* vcol = sV + (4 * lh) * LDP + wj * (HD / 2) + lr;
   for (int r0 = 0; r0 < len; r0 += CH) {
-#pragma unroll 4
-    for (int rr = rg; rr < CH; rr += RG) {   // thread owns column c of rows rg, rg + RG, ...
-      const int r = r0 + rr;
-      float p = 0.f, v = 0.f;
-      if (r < len) {
-        p = __expf(Kb[(int64_t)r * ld + c] - cm);
-        v = Vb[(int64_t)r * ld + c];
-      }
-      ks += p;
-      sP[rr * LDP + c] = p;
-      sV[rr * LDP + c] = v;
+    float4 m4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      m4.x = fmaxf(m4.x, kreg[i].x); m4.y = fmaxf(m4.y, kreg[i].y);
+      m4.z = fmaxf(m4.z, kreg[i].z); m4.w = fmaxf(m4.w, kreg[i].w);
+    }
+    *reinterpret_cast<float4*>(sred + rgrp * HD + 4 * c4) = m4;
+    __syncthreads();
+    if (tid < HD) {
+      float m = smax[tid];
+      const float mo = m;
+      for (int g2 = 0; g2 < NRG; ++g2) m = fmaxf(m, sred[g2 * HD + tid]);
+      sscale[tid] = mo == -INFINITY ? 0.f : __expf(mo - m);   // (nothing accumulated yet while mo == -inf)
+      smax[tid] = m;
     }
     __syncthreads();
+    const float4 cm = *reinterpret_cast<const float4*>(smax + 4 * c4);
+    const float4 sc = *reinterpret_cast<const float4*>(sscale + 4 * c4);
+    ks4.x *= sc.x; ks4.y *= sc.y; ks4.z *= sc.z; ks4.w *= sc.w;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int rr = rgrp + NRG * i;
+      float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + rr < len)
+        pe = make_float4(__expf(kreg[i].x - cm.x), __expf(kreg[i].y - cm.y), __expf(kreg[i].z - cm.z), __expf(kreg[i].w - cm.w));
+      ks4.x += pe.x; ks4.y += pe.y; ks4.z += pe.z; ks4.w += pe.w;
+      *reinterpret_cast<float4*>(sP + rr * LDP + 4 * c4) = pe;
+      *reinterpret_cast<float4*>(sV + rr * LDP + 4 * c4) = vreg[i];
+    }
+    // rescale the accumulator rows (channel c = row of A) before this chunk is added
+#pragma unroll
+    for (int ti = 0; ti < TB; ++ti) {
+      const float f = sscale[wi * (HD / 2) + 32 * ti + lr];
+#pragma unroll
+      for (int tj = 0; tj < TB; ++tj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ti][tj][e] *= f;
+    }
+    __syncthreads();
+    if (r0 + CH < len) fetch(r0 + CH);
     const int nk = (min(CH, len - r0) + 7) / 8;   // 8-row groups holding valid rows (the rest are zeros)
     for (int g = 0; g < nk; ++g) {
 #pragma unroll
@@ -379,14 +412,14 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const float* __restrict__
             acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[tj], pv[ti], acc[ti][tj], 0, 0, 0);
       }
     }
-    __syncthreads();
+    __syncthreads();   // sP / sV / sred / sscale are rewritten by the next chunk
   }
-  sred[tid] = ks;
+  *reinterpret_cast<float4*>(sred + rgrp * HD + 4 * c4) = ks4;
   __syncthreads();
   if (tid < HD) {
     float t = 0.f;
-    for (int g2 = 0; g2 < RG; ++g2) t += sred[g2 * HD + tid];
-    ssum[tid] = t;
+    for (int g2 = 0; g2 < NRG; ++g2) t += sred[g2 * HD + tid];
+    sscale[tid] = t > 0.f ? 1.0f / t : 0.f;
     float* st = kstat + ((int64_t)blockIdx.x * HD + tid) * 2;
     st[0] = len > 0 ? smax[tid] : 0.f;
     st[1] = len > 0 ? t : 1.f;
@@ -395,8 +428,7 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const float* __restrict__
 #pragma unroll
   for (int ti = 0; ti < TB; ++ti) {
     const int cc = wi * (HD / 2) + 32 * ti + lr;      // lane's context row (channel c)
-    const float sum = ssum[cc];
-    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    const float inv = sscale[cc];
     float* ap = A + (int64_t)blockIdx.x * HD * HD + cc * HD + wj * (HD / 2) + 4 * lh;
 #pragma unroll
     for (int tj = 0; tj < TB; ++tj) store16(ap + 32 * tj, acc[ti][tj], inv);
@@ -1117,7 +1149,9 @@ extern "C" int hig_linattn_ctx(const float* K, const float* V, int64_t ld, int32
   HIG_REQUIRE(K && V && A && kstat && B > 0 && rows > 0 && H > 0, "hig_linattn_ctx: bad arguments");
   HIG_REQUIRE(hd_ok(hd), "hig_linattn: head dim %d not in {8,16,32,64,128}", hd);
   const int nchunk = (rows + CH - 1) / CH;
-  if (scratch && nchunk > 1 && (hd == 64 || hd == 128)) {
+  static const int ctx_walk = getenv("HIG_CTX_WALK") ? atoi(getenv("HIG_CTX_WALK")) : 1;   // tuning knob
+  const bool walk = ctx_walk && B * H >= 256;   // enough (sample, head) pairs to fill the chip with walking workgroups
+  if (!walk && scratch && nchunk > 1 && (hd == 64 || hd == 128)) {
     // row chunks in parallel + a merge: 4-5x the workgroups of the one-per-(sample, head) kernel
     if (hd == 64) {
       hipLaunchKernelGGL(ctx_part_mfma_kernel<64>, dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream), K, V, ld,

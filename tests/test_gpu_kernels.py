@@ -279,7 +279,10 @@ def _linattn_ref(Q, K, V, lengths, H):
 
 @pytest.mark.parametrize("B,T,H,hd,lens", [(2, 16, 8, 8, (16, 9)), (2, 60, 8, 16, (60, 41)),
                                            (3, 196, 8, 64, (196, 77, 1)), (2, 300, 2, 128, (300, 123)),
-                                           (2, 70, 4, 32, (70, 64))])
+                                           (2, 70, 4, 32, (70, 64)),
+                                           # B * H >= 256: the chunk-walking / online-softmax kernels, ragged incl. empty
+                                           (32, 130, 8, 64, tuple((17 * i) % 131 for i in range(32))),
+                                           (32, 70, 8, 128, tuple((29 * i) % 71 for i in range(32)))])
 def test_linear_attention_forward_backward(B, T, H, hd, lens):
     d = H * hd
     qkv = rnd(B * T, 3 * d, scale=1.5)
