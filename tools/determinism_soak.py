@@ -1,0 +1,43 @@
+"""Race / determinism soak (tuning + QA aid): repeats the same forward + backward (+ text head) many times and checks
+that every output and the whole flat gradient buffer are BITWISE identical each time (no float atomics anywhere, so any
+difference would be a missing barrier or an uninitialised read)."""
+import os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench, hig_amd
+dev = torch.device("cuda", 0)
+n = int(os.environ.get("ITERS", 40))
+
+def soak(name, m, i, two=False):
+    m.train()
+    caps = ["a person walks towards another person number %d" % k for k in range(i["x"].shape[0])]
+    tok, feat = m._clip_features(caps, dev)
+    ref = None
+    for it in range(n):
+        m.zero_grad(set_to_none=True)
+        xp, xo = m._text_head(tok, feat)
+        out, saved = m._launch_forward(i["x"], i["t"], i["length"], xp.detach(), xo.detach(), training=True)
+        dx, dxp, dxo = m._launch_backward(i["x"], i["t"], i["length"], xo.detach(), saved, i["x0"], want_dx=True)
+        (xp * dxp).sum().backward(retain_graph=True)
+        tg = torch.cat([p.grad.reshape(-1) for p in m._text_params()])
+        cur = (out.clone(), dx.clone(), dxp.clone(), dxo.clone(), m.flat_params().grad[:m.flat_params().core_numel].clone(), tg.clone())
+        if ref is None:
+            ref = cur
+            assert all(torch.isfinite(t).all() for t in cur)
+        else:
+            for k, (a, b) in enumerate(zip(ref, cur)):
+                assert torch.equal(a, b), (name, it, k, (a - b).abs().max().item())
+    print("%s: %d identical iterations" % (name, n))
+
+c = dict(bench.CFG)
+soak("single-person config 2", bench.build_model(c, dev), bench.make_inputs(c, dev, 0))
+c2 = dict(c, B=64, T=91, F=263)
+torch.manual_seed(0)
+m2 = hig_amd.MotionInteractionTransformer(input_feats=c2["F"], num_frames=196, latent_dim=c2["d"], ff_size=c2["ff"],
+                                          num_layers=c2["L"], num_heads=c2["H"], text_latent_dim=c2["Lt"])
+with torch.no_grad():
+    for name, p in m2.named_parameters():
+        if name.startswith("out") or ".ffn.linear2." in name or ".out_layers.2." in name:
+            p.copy_(torch.randn(p.shape) * 0.02)
+i2 = bench.make_inputs(c2, dev, 0)
+i2["length"] = (torch.arange(64, device=dev) * 7 % 92).long()       # ragged, incl. an empty sample
+soak("two-person, ragged lengths", m2.to(dev), i2)
