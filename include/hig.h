@@ -254,6 +254,8 @@ int hig_recover_joints(const float* motion, const float* stats, int32_t rows, in
 #define HIG_EPI_BIAS_POS 4  /* out = acc + bias + pos[i % T] (joint_embed + sequence_embedding) */
 #define HIG_EPI_RES 5       /* out = res + acc */
 #define HIG_EPI_DGELU 6     /* out = acc * gelu'(aux) */
+/* Zero-initialise the descriptor (memset) and set what the chosen xf / epi need: optional pointers are tested
+ * against NULL. */
 typedef struct hig_gemm_desc {
   const float* X; int64_t ldx; int32_t x_rs;
   const float* Y; int64_t ldy; int32_t y_rs;
