@@ -27,6 +27,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef HIG_GEMM_NT
 #define HIG_GEMM_NT 0
 #endif
+// Wave priority raised over the global fetch + MFMA block of each k-tile (0 = off): with 2-4
+// workgroups per CU in different phases, the arbiter then favours the wave that can feed the
+// matrix pipe over the ones doing the transform / LDS writes of their next tile (fwd -2.3%,
+// fwd+bwd -1.3%, same-box A/B in profiles/r01_notes.md; raising it before the LDS writes too, or
+// only around the MFMAs, is worse).
+#ifndef HIG_GEMM_SETPRIO
+#define HIG_GEMM_SETPRIO 1
+#endif
 #ifndef HIG_GEMM_LDS_EPI
 #define HIG_GEMM_LDS_EPI 1
 #endif
@@ -446,8 +454,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
       transform(rbeg + (kt + 1) * BK);
       store_tiles(buf ^ 1);
     }
+#if HIG_GEMM_SETPRIO
+    __builtin_amdgcn_s_setprio(HIG_GEMM_SETPRIO);
+#endif
     if (kt + 2 < nk) load_tiles(rbeg + (kt + 2) * BK);
     mfma_part(buf, 0, NG);
+#if HIG_GEMM_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();
   };
 
