@@ -438,6 +438,55 @@ def main():
                                   "what": "text_pre_proj + 4-layer encoder (77 tokens, d=256, ff=2048) + text_ln + "
                                           "text_proj, fwd+bwd at B=64, fp32: hig_text_head_* vs nn.TransformerEncoder "
                                           "on PyTorch-ROCm"}
+            # ---- evaluator feature extraction: both classifiers on a batch of generated pairs ----
+            Be, Te, Fe = 256, 91, 259
+            enc = hig_amd.MotionEncoder(Fe, num_frames=196).to(device).eval()
+            con = hig_amd.MotionConsistencyEvalModel(Fe, num_frames=196).to(device).eval()
+            with torch.no_grad():
+                for mod in (enc.out1, enc.out2):        # zero-initialised heads would make the comparison 0 == 0
+                    mod.weight.normal_(0, 0.02)
+            g_e = torch.Generator(device="cpu").manual_seed(5)
+            ex1 = torch.randn(Be, Te, Fe, generator=g_e).to(device)
+            ex2 = torch.randn(Be, Te, Fe, generator=g_e).to(device)
+            elen = torch.randint(20, Te + 1, (Be,), generator=g_e).to(device)
+
+            def eval_hip():
+                with torch.no_grad():
+                    return enc(ex1, ex2, length=elen) + (con(ex1, ex2, length=elen),)
+
+            def eval_stock():   # the same parameters through stock PyTorch-ROCm ops (nn.TransformerEncoder)
+                with torch.no_grad():
+                    m = (torch.arange(Te, device=device)[None] < elen[:, None])
+                    outs = []
+                    for net in (enc, con):
+                        hs = []
+                        for x in (ex1, ex2):
+                            mv = net.joint_embed1(x[:, 1:]) + net.sequence_embedding[None, :Te - 1]
+                            hs.append(torch.cat([net.joint_embed2(x[:, 0, :4])[:, None], mv], 1))
+                        if net is con:
+                            h = torch.cat([net.cls_input.expand(Be, 1, -1)] + hs, 1)
+                            pad = ~torch.cat([m[:, :1] | True, m, m], 1)
+                            outs.append(net.cls_output(net.motionTransEncoder(h, src_key_padding_mask=pad)[:, 0]))
+                        else:
+                            mk = torch.cat([m, m], 1)
+                            h = net.motionTransEncoder(torch.cat(hs, 1), src_key_padding_mask=~mk)
+                            o = net.out1(h)
+                            o[:, 0], o[:, Te] = net.out2(h[:, 0]), net.out2(h[:, Te])
+                            w = mk[..., None].float()
+                            ft = (o * w).sum(1) / w.sum(1)
+                            outs += [net.fin_proj(ft), ft]
+                    return outs
+
+            e_h = timed(eval_hip, k2, 2, 1) / k2 * 1e3
+            e_s = timed(eval_stock, k2, 2, 1) / k2 * 1e3
+            oh, os_ = eval_hip(), eval_stock()
+            extra["evaluator"] = {
+                "pairs_per_s_hip": round(Be / e_h * 1e3, 1), "ms_hip": round(e_h, 3), "ms_stock_torch": round(e_s, 3),
+                "rel_l2_feature_vs_stock": float("%.2e" % ((oh[1] - os_[1]).norm() / os_[1].norm()).item()),
+                "what": "MotionEncoder + MotionConsistencyEvalModel forward (get_motion_embeddings) on 256 generated pairs "
+                        "x 91 tokens x 259 features, d=512 L=8 H=8, fp32: hig_eval_encoder_fwd vs the same parameters "
+                        "through nn.TransformerEncoder on PyTorch-ROCm"}
+            del enc, con, ex1, ex2
     if rank == 0:
         if not a.no_extra and world == 1:
             extra["hbm_bound_kernels"] = hbm_kernel_rooflines(c, device)

@@ -8,7 +8,9 @@ Putting this directory itself on sys.path gives the reference's own import layou
 (`from models.transformer import MotionTransformer`, `from trainers.ddpm_trainer import DDPMTrainer`).
 """
 from . import _lib  # noqa: F401
-from .models import GaussianDiffusion, MotionInteractionTransformer, MotionTransformer  # noqa: F401
+from .models import (GaussianDiffusion, MotionConsistencyEvalModel, MotionEncoder,  # noqa: F401
+                     MotionInteractionTransformer, MotionTransformer)
 from .trainers import DDPMMulTrainer, DDPMTrainer  # noqa: F401
 
-__all__ = ["MotionTransformer", "MotionInteractionTransformer", "GaussianDiffusion", "DDPMTrainer", "DDPMMulTrainer"]
+__all__ = ["MotionTransformer", "MotionInteractionTransformer", "MotionEncoder", "MotionConsistencyEvalModel",
+           "GaussianDiffusion", "DDPMTrainer", "DDPMMulTrainer"]

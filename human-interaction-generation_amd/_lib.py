@@ -31,6 +31,7 @@ SYMBOLS = (
     "hig_masked_mse", "hig_sumsq_partial", "hig_clip_adam",
     "hig_text_head_workspace_bytes", "hig_text_head_bwd_workspace_bytes", "hig_text_head_fwd", "hig_text_head_bwd",
     "hig_layernorm", "hig_gather_rows", "hig_scatter_add_rows", "hig_gather_frames", "hig_recover_joints", "hig_transpose_batch", "hig_linattn_ctx_scratch_floats", "hig_pair_mse",
+    "hig_fullattn_fwd_kpad", "hig_eval_encoder_workspace_bytes", "hig_eval_encoder_fwd",
 )
 
 
@@ -44,6 +45,13 @@ class TextDims(C.Structure):
 
 
 T_NGLOBAL, T_NLAYER = 6, 12
+
+
+class EvalDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "T", "F", "d", "H", "ff", "L", "C", "cls", "prec")]
+
+
+EV_NGLOBAL = 12
 
 
 class GemmDesc(C.Structure):
@@ -123,6 +131,10 @@ def lib():
         L.hig_text_head_bwd_workspace_bytes.argtypes = [C.POINTER(TextDims)]
         L.hig_text_head_fwd.argtypes = [C.POINTER(TextDims), vp, vp, vp, vp, vp, vp, C.c_int, vp]
         L.hig_text_head_bwd.argtypes = [C.POINTER(TextDims)] + [vp] * 11
+        L.hig_fullattn_fwd_kpad.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp, vp]
+        L.hig_eval_encoder_workspace_bytes.restype = i64
+        L.hig_eval_encoder_workspace_bytes.argtypes = [C.POINTER(EvalDims)]
+        L.hig_eval_encoder_fwd.argtypes = [C.POINTER(EvalDims)] + [vp] * 8
         L.hig_layernorm.argtypes = [vp, i64, i64, i32, vp, vp, vp, i64, vp, vp]
         L.hig_gather_rows.argtypes = [vp, i64, i32, i32, vp, i32, vp, i64, vp]
         L.hig_scatter_add_rows.argtypes = [vp, i64, i32, i32, vp, i32, vp, i64, vp]

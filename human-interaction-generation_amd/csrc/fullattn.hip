@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void full_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ K,
                                                        const float* __restrict__ V, int64_t ldk, int Tq,
                                                        int Tk, int H, const int64_t* __restrict__ qlen,
+                                                       const uint8_t* __restrict__ kpad,
                                                        float* __restrict__ Y, int64_t ldy,
                                                        float* __restrict__ lse) {
   constexpr int LDP = HD + 4, PER = HD / 4;
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(256) void full_fwd_kernel(const float* __restrict__
   const float addc = nvalid ? query_const(qlen, b, n) : 0.f;
   const float* Kb = K + (int64_t)b * Tk * ldk + h * HD;
   const float* Vb = V + (int64_t)b * Tk * ldk + h * HD;
+  const uint8_t* pad = kpad ? kpad + (int64_t)b * Tk : nullptr;  // torch's src_key_padding_mask: 1 = not a key
   float m_run = -INFINITY, l_run = 0.f, acc[PER];
 #pragma unroll
   for (int e = 0; e < PER; ++e) acc[e] = 0.f;
@@ -110,16 +112,17 @@ __global__ __launch_bounds__(256) void full_fwd_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int ml = 4 * j + part;
-      s[j] = (kc + ml < Tk) ? (dot_row<HD>(q, sK + ml * LDP) / sq + addc) : -INFINITY;
+      s[j] = (kc + ml < Tk && !(pad && pad[kc + ml])) ? (dot_row<HD>(q, sK + ml * LDP) / sq + addc) : -INFINITY;
       cmax = fmaxf(cmax, s[j]);
     }
     cmax = quad_max(cmax);
     const float m_new = fmaxf(m_run, cmax);
-    const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first chunk
+    // exp(-inf) = 0 on the first chunk; a chunk of padded keys only (m_new still -inf) changes nothing
+    const float alpha = m_new == -INFINITY ? 1.f : __expf(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const float p = __expf(s[j] - m_new);  // -inf -> 0
+      const float p = s[j] == -INFINITY ? 0.f : __expf(s[j] - m_new);
       psum += p;
       sP[rl * (CH + 1) + 4 * j + part] = p;
     }
@@ -300,13 +303,20 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 extern "C" int hig_fullattn_fwd(const float* Q, int64_t ldq, const float* K, const float* V, int64_t ldk,
                                 int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t hd,
                                 const int64_t* qlen, float* Y, int64_t ldy, float* lse, hig_stream_t stream) {
+  return hig_fullattn_fwd_kpad(Q, ldq, K, V, ldk, B, Tq, Tk, H, hd, qlen, nullptr, Y, ldy, lse, stream);
+}
+
+extern "C" int hig_fullattn_fwd_kpad(const float* Q, int64_t ldq, const float* K, const float* V, int64_t ldk,
+                                     int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t hd,
+                                     const int64_t* qlen, const uint8_t* kpad, float* Y, int64_t ldy, float* lse,
+                                     hig_stream_t stream) {
   HIG_REQUIRE(Q && K && V && Y && lse && B > 0 && Tq > 0 && Tk > 0 && H > 0, "hig_fullattn_fwd: bad arguments");
   if (!full_hd_ok(hd))
     return hig_set_error(HIG_EUNSUPPORTED, "hig_fullattn: head dim %d not in {8,16,32,64}", hd);
   HIG_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldy % 4 == 0 && al16(Q) && al16(K) && al16(V) && al16(Y),
               "hig_fullattn_fwd: operands must be 16-byte aligned");
   FHD_SWITCH(hd, hipLaunchKernelGGL((full_fwd_kernel<HDV>), dim3(B * H, (Tq + CH - 1) / CH), dim3(256), 0,
-                                    hig_stream(stream), Q, ldq, K, V, ldk, Tq, Tk, H, qlen, Y, ldy, lse));
+                                    hig_stream(stream), Q, ldq, K, V, ldk, Tq, Tk, H, qlen, kpad, Y, ldy, lse));
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

@@ -210,6 +210,46 @@ int hig_text_head_bwd(const hig_text_dims* dims, const void* const* params, cons
                       hig_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Evaluator feature extraction: the two classifiers that score generated pairs,
+ * `MotionEncoder` (interaction_transformer.py:641-741: class logits + the pooled feature FID /
+ * diversity are computed on) and `MotionConsistencyEvalModel` (:743-829: real/fake logits from a
+ * learned [cls] token).  Inference only (the reference calls them under no_grad,
+ * datasets/evaluator.py:479-493).  Both embed each person like the two-person denoiser (token 0 =
+ * joint_embed2 of the init-pose row's first 4 features, token t >= 1 = joint_embed1 +
+ * sequence_embedding[t-1]), put the two persons one after the other on the token axis
+ * ([cls,] person 1's T tokens, person 2's T tokens), run a post-norm nn.TransformerEncoder with
+ * tokens t >= length[b] of either person excluded as keys, then
+ *   MotionEncoder:  o = out2(token 0) / out1(other tokens);  feature = mean of o over the valid
+ *                   tokens of both persons;  logits = fin_proj(feature)
+ *   Consistency  :  logits = cls_output(encoder output of the [cls] token).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct hig_eval_dims {
+  int32_t B, T, F;         /* pairs, tokens per person (frames + 1), input_feats (dim_pose - 4) */
+  int32_t d, H, ff, L;     /* latent_dim, num_heads (head dim in {8,16,32,64}), ff_size, num_layers */
+  int32_t C;               /* class_num: logits per pair */
+  int32_t cls;             /* 0 = MotionEncoder, 1 = MotionConsistencyEvalModel ([cls] token first) */
+  int32_t prec;            /* HIG_PREC_* of the GEMM products */
+} hig_eval_dims;
+enum {
+  HIG_EV_SEQ_EMB = 0,                /* sequence_embedding (num_frames, d) */
+  HIG_EV_JOINT1_W, HIG_EV_JOINT1_B,  /* joint_embed1 (d, F) */
+  HIG_EV_JOINT2_W, HIG_EV_JOINT2_B,  /* joint_embed2 (d, 4) */
+  HIG_EV_OUT1_W, HIG_EV_OUT1_B,      /* out1 (d, d)            -- MotionEncoder only, else NULL */
+  HIG_EV_OUT2_W, HIG_EV_OUT2_B,      /* out2 (d, d)            -- MotionEncoder only, else NULL */
+  HIG_EV_HEAD_W, HIG_EV_HEAD_B,      /* fin_proj.0 / cls_output.0 (C, d) */
+  HIG_EV_CLS_IN,                     /* cls_input (d)          -- consistency model only, else NULL */
+  HIG_EV_NGLOBAL
+};
+/* Table = HIG_EV_NGLOBAL globals, then per layer the HIG_TL_* block of the text head (same
+ * nn.TransformerEncoderLayer parameters). */
+int64_t hig_eval_encoder_workspace_bytes(const hig_eval_dims* dims);
+/* x1, x2 (B, T, F): the two persons; length (B): valid tokens per person.  Writes logits (B, C)
+ * and, for the MotionEncoder (cls == 0), feature (B, d) (may be NULL). */
+int hig_eval_encoder_fwd(const hig_eval_dims* dims, const void* const* params, const float* x1,
+                         const float* x2, const int64_t* length, float* logits, float* feature,
+                         void* workspace, hig_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Input pipeline: batch assembly from a device-resident bank of motions.
  * Reference arithmetic: Text2MotionMulDataset.__getitem__, datasets/mul_dataset.py:203-209.
  * out[r][t][:] = normalise(bank[seq_off[r] + frame_ix[r][t] * F ...]):  token 0 (the init-pose row)
@@ -328,6 +368,12 @@ int hig_linattn_ctx_bwd(const float* dA, const float* A, const float* K, const f
 int hig_fullattn_fwd(const float* Q, int64_t ldq, const float* K, const float* V, int64_t ldk,
                      int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t hd, const int64_t* qlen,
                      float* Y, int64_t ldy, float* lse, hig_stream_t stream);
+/* Same forward with torch's `src_key_padding_mask` (nn.MultiheadAttention): kpad (B, Tk) bytes,
+ * non-zero = that key takes no part in the softmax (NULL = none).  Used by the evaluator encoders
+ * (interaction_transformer.py:733,827). */
+int hig_fullattn_fwd_kpad(const float* Q, int64_t ldq, const float* K, const float* V, int64_t ldk,
+                          int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t hd, const int64_t* qlen,
+                          const uint8_t* kpad, float* Y, int64_t ldy, float* lse, hig_stream_t stream);
 int hig_fullattn_bwd(const float* dY, int64_t lddy, const float* Y, int64_t ldy, const float* Q,
                      int64_t ldq, const float* K, const float* V, int64_t ldk, int32_t B, int32_t Tq,
                      int32_t Tk, int32_t H, int32_t hd, const int64_t* qlen, const float* lse,

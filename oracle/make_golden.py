@@ -447,6 +447,60 @@ def g12_recover():
     np.savez_compressed(os.path.join(GOLD, "g12_recover.npz"), **out)
 
 
+def g13_eval_models():
+    """The reference's MotionEncoder / MotionConsistencyEvalModel, called like EvaluatorModelWrapper does
+    (eval mode, no_grad; datasets/evaluator.py:468-493)."""
+    from models.interaction_transformer import MotionConsistencyEvalModel, MotionEncoder
+    from oracle.eval_models_ref import EVAL_CASES, eval_inputs
+    out = {}
+    for cname, c in EVAL_CASES.items():
+        kw = dict(input_feats=c["F"], num_frames=c["num_frames"], latent_dim=c["d"], ff_size=c["ff"],
+                  num_layers=c["L"], num_heads=c["H"])
+        x1, x2, length = eval_inputs(cname, c)
+        enc = MotionEncoder(**kw)
+        enc.load_state_dict(fill.fill_state_dict(enc.state_dict()), strict=True)
+        enc.eval()
+        con = MotionConsistencyEvalModel(**kw)
+        con.load_state_dict(fill.fill_state_dict(con.state_dict()), strict=True)
+        con.eval()
+        with torch.no_grad():
+            logits, feat = enc(x1, x2, length=length)
+            clogits = con(x1, x2, length=length)
+        out[cname + ".enc.logits"] = logits.numpy()
+        out[cname + ".enc.feature"] = feat.numpy()
+        out[cname + ".con.logits"] = clogits.numpy()
+        if cname == "tiny":
+            for k, v in enc.state_dict().items():
+                out["keys.enc." + k] = np.array(v.shape, dtype=np.int64)
+            for k, v in con.state_dict().items():
+                out["keys.con." + k] = np.array(v.shape, dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "g13_eval_models.npz"), **out)
+
+
+def g14_metrics():
+    """utils/metrics.py of the reference on seeded activations (FID, diversity, multimodality, R-precision...)."""
+    from utils import metrics as M
+    rs = np.random.RandomState(1234)
+    a = rs.standard_normal((300, 24)).astype(np.float32)
+    b = (rs.standard_normal((280, 24)) * 1.3 + 0.2).astype(np.float32)
+    mm = rs.standard_normal((6, 12, 24)).astype(np.float32)
+    out = {"a": a, "b": b, "mm": mm}
+    mu_a, cov_a = M.calculate_activation_statistics(a)
+    mu_b, cov_b = M.calculate_activation_statistics(b)
+    out["mu_a"], out["cov_a"] = mu_a, cov_a
+    out["fid_ab"] = np.float64(M.calculate_frechet_distance(mu_a, cov_a, mu_b, cov_b))
+    out["fid_aa"] = np.float64(M.calculate_frechet_distance(mu_a, cov_a, mu_a, cov_a))
+    np.random.seed(7)
+    out["diversity"] = np.float64(M.calculate_diversity(a, 100))
+    np.random.seed(8)
+    out["multimodality"] = np.float64(M.calculate_multimodality(mm, 5))
+    out["dist"] = M.euclidean_distance_matrix(a[:40], b[:40])
+    out["rprec"] = M.calculate_R_precision(a[:40], a[:40] + 2.0 * b[:40], 3, sum_all=True)
+    out["rprec_mat"] = M.calculate_R_precision(a[:40], a[:40] + 2.0 * b[:40], 3)
+    out["match"] = np.float64(M.calculate_matching_score(a[:40], b[:40], sum_all=True))
+    np.savez_compressed(os.path.join(GOLD, "g14_metrics.npz"), **out)
+
+
 def g7_state_dict_keys():
     """Key/shape contract of the reference module (tiny config) for the round-trip test."""
     c = fill.CASES["tiny"]
@@ -461,7 +515,8 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for fn in (g1, g2_g3, g4, g5, g6, g7_state_dict_keys, g8_interaction, g9_mul_trainer, g10_text_head, g11_dataset, g12_recover):
+    for fn in (g1, g2_g3, g4, g5, g6, g7_state_dict_keys, g8_interaction, g9_mul_trainer, g10_text_head, g11_dataset, g12_recover,
+               g13_eval_models, g14_metrics):
         if only and fn.__name__ not in only:
             continue
         fn()
