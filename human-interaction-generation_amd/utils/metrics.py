@@ -45,40 +45,46 @@ def calculate_activation_statistics(activations):
     return np.mean(activations, axis=0), np.cov(activations, rowvar=False)
 
 
+def _two_draws(population, times):
+    # the reference draws twice from numpy's global generator, first set then second set
+    return [np.random.choice(population, times, replace=False) for _ in range(2)]
+
+
 def calculate_diversity(activation, diversity_times):
     """Mean distance between `diversity_times` random pairs of embeddings (metrics.py:73-81)."""
     assert activation.ndim == 2 and activation.shape[0] > diversity_times
-    n = activation.shape[0]
-    first = np.random.choice(n, diversity_times, replace=False)
-    second = np.random.choice(n, diversity_times, replace=False)
-    return linalg.norm(activation[first] - activation[second], axis=1).mean()
+    i, j = _two_draws(activation.shape[0], diversity_times)
+    return linalg.norm(activation[i] - activation[j], axis=1).mean()
 
 
 def calculate_multimodality(activation, multimodality_times):
     """activation (captions, repeats, dim): mean distance between random pairs of repeats (metrics.py:84-93)."""
     assert activation.ndim == 3 and activation.shape[1] > multimodality_times
-    n = activation.shape[1]
-    first = np.random.choice(n, multimodality_times, replace=False)
-    second = np.random.choice(n, multimodality_times, replace=False)
-    return linalg.norm(activation[:, first] - activation[:, second], axis=2).mean()
+    i, j = _two_draws(activation.shape[1], multimodality_times)
+    return linalg.norm(activation[:, i] - activation[:, j], axis=2).mean()
+
+
+def _sqrt_of_product(c1, c2, eps):
+    root = linalg.sqrtm(c1 @ c2)
+    if not np.all(np.isfinite(root)):
+        print("fid calculation produces singular product; adding %s to diagonal of cov estimates" % eps)
+        ridge = eps * np.eye(len(c1))
+        root = linalg.sqrtm((c1 + ridge) @ (c2 + ridge))
+    if np.iscomplexobj(root):
+        worst = np.abs(np.diagonal(root).imag)
+        if not np.allclose(worst, 0, atol=1e-3):
+            raise ValueError("Imaginary component {}".format(np.abs(root.imag).max()))
+        root = root.real
+    return root
 
 
 def calculate_frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
     """Frechet distance between N(mu1, sigma1) and N(mu2, sigma2):
     |mu1 - mu2|^2 + Tr(sigma1 + sigma2 - 2 (sigma1 sigma2)^(1/2))   (metrics.py:96-148, incl. its
     eps-regularised retry on a singular product and its tolerance for an imaginary residue)."""
-    mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)
-    sigma1, sigma2 = np.atleast_2d(sigma1), np.atleast_2d(sigma2)
-    assert mu1.shape == mu2.shape, "mean vectors have different lengths"
-    assert sigma1.shape == sigma2.shape, "covariances have different dimensions"
-    root = linalg.sqrtm(sigma1.dot(sigma2))
-    if not np.isfinite(root).all():
-        print("fid calculation produces singular product; adding %s to diagonal of cov estimates" % eps)
-        jitter = eps * np.eye(sigma1.shape[0])
-        root = linalg.sqrtm((sigma1 + jitter).dot(sigma2 + jitter))
-    if np.iscomplexobj(root):
-        if not np.allclose(np.diagonal(root).imag, 0, atol=1e-3):
-            raise ValueError("Imaginary component {}".format(np.max(np.abs(root.imag))))
-        root = root.real
-    delta = mu1 - mu2
-    return delta.dot(delta) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(root)
+    m1, m2 = (np.atleast_1d(m) for m in (mu1, mu2))
+    c1, c2 = (np.atleast_2d(c) for c in (sigma1, sigma2))
+    if m1.shape != m2.shape or c1.shape != c2.shape:
+        raise AssertionError("mean vectors / covariances of the two sets differ in size")
+    gap = m1 - m2
+    return gap @ gap + np.trace(c1) + np.trace(c2) - 2 * np.trace(_sqrt_of_product(c1, c2, eps))
