@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--ddpm-steps", type=int, default=100, help="sampling steps actually replayed (scaled to 1000)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling (SURVEY 8d config 4): global batch 512 split over the ranks instead of 64 per rank")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -251,6 +253,9 @@ def main():
     import hig_amd
     from hig_amd.parallel import broadcast_parameters
     c = dict(CFG)
+    if a.strong:
+        assert 512 % world == 0, "--strong splits a global batch of 512"
+        c["B"] = 512 // world
     model = build_model(c, device).eval()
     broadcast_parameters(model)
     inp = make_inputs(c, device, rank)
@@ -264,11 +269,13 @@ def main():
     frames = B * T * a.steps * world
     value = frames / el
     res = {
-        "metric": "denoiser-fwd frames/s @ B=64·T=196", "value": round(value, 1), "unit": "frames/s",
+        "metric": "denoiser-fwd frames/s @ global B=512·T=196" if a.strong else "denoiser-fwd frames/s @ B=64·T=196",
+        "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "MotionTransformer forward, BASELINE config 2: B=64/GPU T=196 F=150 d=512 L=8 H=8 ff=1024 "
-                               "N=77 Lt=256, linear attention, text embeddings supplied (CLIP stubbed)",
+        "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "MotionTransformer forward, BASELINE config 2: B=%d/GPU T=196 F=150 d=512 L=8 H=8 ff=1024 "
+                               "N=77 Lt=256, linear attention, text embeddings supplied (CLIP stubbed)" % B,
                    "parallelism": "dp%d (independent batches per rank)" % world},
     }
     gflop = flops_per_frame_fwd(c) * B * T / 1e9
@@ -438,6 +445,35 @@ def main():
                                   "what": "text_pre_proj + 4-layer encoder (77 tokens, d=256, ff=2048) + text_ln + "
                                           "text_proj, fwd+bwd at B=64, fp32: hig_text_head_* vs nn.TransformerEncoder "
                                           "on PyTorch-ROCm"}
+            # ---- SURVEY 8d variants of the headline forward: ragged lengths, F = 263, ff = 4 d ----
+            var = {}
+            g_v = torch.Generator().manual_seed(77)
+            ragged = torch.randint(40, T + 1, (B,), generator=g_v).to(device)
+
+            def fwd_ragged():
+                with torch.no_grad():
+                    return model(inp["x"], inp["t"], length=ragged, xf_proj=inp["xf_proj"], xf_out=inp["xf_out"])
+
+            e_v = timed(fwd_ragged, k2, 2, 1) / k2 * 1e3
+            var["lengths_U40_T"] = {"fwd_ms": round(e_v, 3), "frames_per_s": round(B * T / e_v * 1e3, 1),
+                                    "what": "benchmark B: length ~ U{40..196}; padded frames are still computed "
+                                            "(as in the reference), frames/s counts all B*T"}
+            for tag, cv in (("F263", dict(c, F=263)), ("ff2048", dict(c, ff=2048))):
+                mv = build_model(cv, device).eval()
+                iv = make_inputs(cv, device, rank)
+
+                def fwd_v():
+                    with torch.no_grad():
+                        return mv(iv["x"], iv["t"], length=iv["length"], xf_proj=iv["xf_proj"], xf_out=iv["xf_out"])
+
+                e_v = timed(fwd_v, k2, 2, 1) / k2 * 1e3
+                var[tag] = {"fwd_ms": round(e_v, 3), "frames_per_s": round(B * T / e_v * 1e3, 1),
+                            "fwd_tflops": round(flops_per_frame_fwd(cv) * B * T / e_v / 1e9, 1)}
+                del mv, iv
+            var["F263"]["what"] = "the reference's real feature width (dim_pose 263), otherwise config 2"
+            var["ff2048"]["what"] = "north-star FFN shape ff = 4 d, otherwise config 2"
+            extra["config2_variants"] = var
+            torch.cuda.empty_cache()
             # ---- evaluator feature extraction: both classifiers on a batch of generated pairs ----
             Be, Te, Fe = 256, 91, 259
             enc = hig_amd.MotionEncoder(Fe, num_frames=196).to(device).eval()
