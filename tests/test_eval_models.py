@@ -157,6 +157,27 @@ def test_hip_classifiers_full_width_vs_oracle(prec, tol):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,T,length", [(1, 2, [5]), (1, 2, [1]), (70, 3, None), (2, 65, [64, 65])])
+def test_hip_classifiers_edge_shapes(B, T, length):
+    """One pair, the shortest sequence (init-pose row + one frame), lengths beyond T (the reference's mask loop is then
+    empty: everything valid), more pairs than one attention chunk holds rows, a 64-key chunk boundary."""
+    c = dict(B=B, T=T, F=15, d=64, H=8, ff=128, L=2, num_frames=80, length=length or [1 + (i % T) for i in range(B)])
+    x1, x2, ln = eval_inputs("edge%d_%d" % (B, T), c)
+    enc, con = build("enc", c).to(DEV), build("con", c).to(DEV)
+    ref_logits, ref_feat = R.motion_encoder_forward(oracle_params("enc", c), x1, x2, ln, c["H"])
+    ref_c = R.consistency_forward(oracle_params("con", c), x1, x2, ln, c["H"])
+    with torch.no_grad():
+        logits, feat = enc(x1.to(DEV), x2.to(DEV), length=ln)
+        clogits = con(x1.to(DEV), x2.to(DEV), length=ln)
+    assert rel(logits, ref_logits) < 1e-5 and rel(feat, ref_feat) < 1e-5 and rel(clogits, ref_c) < 1e-5
+    with pytest.raises(AssertionError):
+        enc(x1.to(DEV), x2[:, :, :-1].to(DEV), length=ln)               # shape mismatch is refused before any launch
+    with pytest.raises(NotImplementedError):
+        with torch.enable_grad():
+            enc.train()(x1.to(DEV), x2.to(DEV), length=ln)              # inference only
+
+
+@pytest.mark.gpu
 def test_key_padding_attention_kernel():
     import ctypes as C
     from hig_amd import _lib
