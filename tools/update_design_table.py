@@ -57,6 +57,24 @@ sub(r"\| text head fwd\+bwd[^\n]*",
 sub(r"\| CPU oracle on the GPU box[^\n]*",
     "| CPU oracle on the GPU box's host (16 threads = best of a doubling probe) | %.1f k frames/s → GPU/CPU = %.0f× (fp32 headline) |"
     % (d["cpu_baseline"]["value"] / 1e3, e["speedup_vs_cpu"]))
+if "config2_variants" in e:
+    v = e["config2_variants"]
+    rowv = ("| config-2 variants (SURVEY 8d), fp32 forward | ragged lengths U{40..196}: %.2f ms; F = 263: %.2f ms (%.0f TFLOP/s); "
+            "ff = 4·d = 2048: %.2f ms (%.0f TFLOP/s) |\n"
+            % (v["lengths_U40_T"]["fwd_ms"], v["F263"]["fwd_ms"], v["F263"]["fwd_tflops"], v["ff2048"]["fwd_ms"],
+               v["ff2048"]["fwd_tflops"]))
+    if "| config-2 variants" in old:
+        old = re.sub(r"\| config-2 variants[^\n]*\n", lambda m: rowv, old)
+    else:
+        old = old.replace("| text head fwd+bwd", rowv + "| text head fwd+bwd", 1)
+if "evaluator" in e:
+    v = e["evaluator"]
+    rowe = ("| evaluator feature extraction, 256 pairs through both classifiers (91 tokens, 259 features, d=512, L=8), HIP vs stock "
+            "PyTorch-ROCm ops | %.1f ms (%.0f pairs/s) vs %.1f ms |\n" % (v["ms_hip"], v["pairs_per_s_hip"], v["ms_stock_torch"]))
+    if "| evaluator feature extraction" in old:
+        old = re.sub(r"\| evaluator feature extraction[^\n]*\n", lambda m: rowe, old)
+    else:
+        old = old.replace("| CPU oracle on the GPU box", rowe + "| CPU oracle on the GPU box", 1)
 hb = e["hbm_bound_kernels"]
 row = ("| HBM-bound kernels at config 2 (`extra.hbm_bound_kernels`: algorithmic bytes / launch time, of 8 TB/s) | "
        + "; ".join("%s %.0f µs = %.0f %%" % (k.split(" (")[0], v["us"], 100 * v["frac_of_8TB_s"]) for k, v in hb.items()) + " |\n")
