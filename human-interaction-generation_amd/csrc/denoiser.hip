@@ -185,7 +185,7 @@ TextLayout text_layout(const Dims& D, int training) {
 
 struct BwdLayout {
   int64_t dhA, dhB, t1, t2, tff, dqkv, dA, delta, dkv, dxfn, dss, demb, dtmp, dte_h, slabs, slab_floats,
-      colpart, lnpart, wT, tA, tB, attn, tok0, doutm, postmp, total;
+      colpart, colpart_w, lnpart, wT, tA, tB, attn, tok0, doutm, postmp, total;
 };
 BwdLayout bwd_layout(const Dims& D) {
   BwdLayout w;
@@ -222,6 +222,7 @@ BwdLayout bwd_layout(const Dims& D) {
     colp = v > colp ? v : colp;
   }
   w.colpart = take(colp);
+  w.colpart_w = take(colp);   // the weight-gradient stream's own partials (it runs next to the caller's stream)
   int64_t lp = hig_ln_bwd_partial_floats(D.M, D.d, D.T);
   const int64_t lpt = hig_ln_bwd_partial_floats(D.Mt, D.Lt, D.N);
   w.lnpart = take(lp > lpt ? lp : lpt);
@@ -421,6 +422,77 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
   return HIG_OK;
 }
 
+namespace {
+
+// Weight gradients next to the data-gradient chain.  dW = dC^T . act and d(input) = dC . W only share dC, so the
+// backward forks every weight-gradient GEMM onto a second (library-owned, per host thread and device) stream and joins
+// it before returning: the chip is ~13 % idle on one in-order stream (kernel tails, ramp-up / drain between dependent
+// launches, HBM idle under GEMMs; tools/concurrency_probe.py) and this is the one independent half of the work.
+// Protocol (all through events, so it is captured into a hipGraph like any fork / join):
+//   side waits for `ready` (recorded on the caller's stream where the weight gradient is requested: dC exists);
+//   weight gradient k runs on the side stream (in order: they share the split-R slabs) and records done[k % 4];
+//   the caller's stream waits for done[k-2] before it goes past request k -- every buffer a weight gradient reads
+//   (dh ping/pong, t1, t2, tff, dqkv, dkv) is next overwritten at least two requests later (walk of the layer loop
+//   in DESIGN.md section 4), and the saved forward activations are never written during backward;
+//   join = the caller's stream waits for the last done event.
+// HIG_BWD_OVERLAP=0 keeps everything on the caller's stream.
+struct SideStream {
+  hipStream_t s2 = nullptr;
+  hipEvent_t ready = nullptr;
+  hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ok = false;
+};
+
+SideStream* side_stream_for_current_device() {
+  static const int enabled = getenv("HIG_BWD_OVERLAP") ? atoi(getenv("HIG_BWD_OVERLAP")) : 1;
+  if (!enabled) return nullptr;
+  constexpr int kMaxDev = 16;
+  static thread_local SideStream tab[kMaxDev];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+  SideStream& s = tab[dev];
+  if (!s.ok) {
+    // first use on this thread / device (an eager step; the captured trainer path warms up eagerly first)
+    if (hipStreamCreateWithFlags(&s.s2, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    bool good = hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 4 && good; ++i) good = hipEventCreateWithFlags(&s.done[i], hipEventDisableTiming) == hipSuccess;
+    if (!good) return nullptr;
+    s.ok = true;
+  }
+  return &s;
+}
+
+struct WgradFork {
+  SideStream* side;
+  hipStream_t main;
+  int k = 0;
+  WgradFork(SideStream* s, hipStream_t m) : side(s), main(m) {}
+  hipStream_t stream() const { return side ? side->s2 : main; }
+  int begin() {
+    if (!side) return HIG_OK;
+    if (k >= 2 && hipStreamWaitEvent(main, side->done[(k - 2) & 3], 0) != hipSuccess)
+      return hig_set_error(HIG_EHIP, "hipStreamWaitEvent failed");
+    if (hipEventRecord(side->ready, main) != hipSuccess || hipStreamWaitEvent(side->s2, side->ready, 0) != hipSuccess)
+      return hig_set_error(HIG_EHIP, "weight-gradient fork failed");
+    return HIG_OK;
+  }
+  int end() {
+    if (!side) return HIG_OK;
+    if (hipEventRecord(side->done[k & 3], side->s2) != hipSuccess) return hig_set_error(HIG_EHIP, "hipEventRecord failed");
+    ++k;
+    return HIG_OK;
+  }
+  int join() {
+    if (!side || k == 0) return HIG_OK;
+    if (hipStreamWaitEvent(main, side->done[(k - 1) & 3], 0) != hipSuccess)
+      return hig_set_error(HIG_EHIP, "weight-gradient join failed");
+    k = 0;
+    return HIG_OK;
+  }
+};
+
+}  // namespace
+
 extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params, const float* x,
                                 const int64_t* t, const int64_t* length, const float* xf_out,
                                 const void* textctx, const void* workspace, const float* dout,
@@ -447,9 +519,16 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
   float* lnp = b + bw.lnpart;
   float* dss = b + bw.dss;
 
-  auto wgrad = [&](G gd) -> int {  // X, Y both reduce-slow; split over the reduce rows
+  WgradFork fork(side_stream_for_current_device(), st);
+  hig_stream_t wstream = reinterpret_cast<hig_stream_t>(fork.stream());
+  auto wgrad_on = [&](G gd) -> int {  // X, Y both reduce-slow; split over the reduce rows
     const int s = wgrad_splits(gd.g.I, gd.g.J, gd.g.R, bw.slab_floats);
-    return hig_gemm_launch(gd.g, s, slabs, st);
+    return hig_gemm_launch(gd.g, s, slabs, fork.stream());
+  };
+  auto wgrad = [&](G gd) -> int {
+    HIG_TRY(fork.begin());
+    HIG_TRY(wgrad_on(gd));
+    return fork.end();
   };
   // dW[n][k] = sum_m dC[m][n] * act[m][k]  (act optionally LayerNorm'ed on the fly).
   // exact-fp32 mode: both operands read reduce-slow straight from their row-major buffers.
@@ -459,21 +538,24 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
   // GEMM produces it while it streams dC (its reduce-slow X operand); otherwise a separate column-sum pass.
   auto wgrad_act = [&](const float* dC, int n_out, const float* act, int k_in, float* out, int64_t rows,
                        const float* stats, const float* gamma, const float* beta, float* dbias = nullptr) -> int {
+    HIG_TRY(fork.begin());   // everything below (transposes, column sums, the GEMM) goes on the weight-gradient stream
     if (D.prec != HIG_PREC_F32 && rows % 32 == 0) {
       float* ta = b + bw.tA;
       float* tb = b + bw.tB;
-      if (dbias) HIG_TRY(hig_colsum(dC, n_out, rows, n_out, dbias, colp, stream));
-      HIG_TRY(hig_transpose(dC, n_out, (int)rows, n_out, ta, rows, nullptr, nullptr, nullptr, stream));
-      HIG_TRY(hig_transpose(act, k_in, (int)rows, k_in, tb, rows, stats, gamma, beta, stream));
-      return wgrad(G(ta, rows, 0, tb, rows, 0, out, k_in, n_out, k_in, rows).prec(D.prec));
+      if (dbias) HIG_TRY(hig_colsum(dC, n_out, rows, n_out, dbias, b + bw.colpart_w, wstream));
+      HIG_TRY(hig_transpose(dC, n_out, (int)rows, n_out, ta, rows, nullptr, nullptr, nullptr, wstream));
+      HIG_TRY(hig_transpose(act, k_in, (int)rows, k_in, tb, rows, stats, gamma, beta, wstream));
+      HIG_TRY(wgrad_on(G(ta, rows, 0, tb, rows, 0, out, k_in, n_out, k_in, rows).prec(D.prec)));
+      return fork.end();
     }
     G gd(dC, n_out, 1, act, k_in, 1, out, k_in, n_out, k_in, rows);
     if (stats) gd.ln(1, stats, gamma, beta);
     if (dbias) {
       if (n_out % 4 == 0) gd.xsum(dbias);
-      else HIG_TRY(hig_colsum(dC, n_out, rows, n_out, dbias, colp, stream));
+      else HIG_TRY(hig_colsum(dC, n_out, rows, n_out, dbias, b + bw.colpart_w, wstream));
     }
-    return wgrad(gd);
+    HIG_TRY(wgrad_on(gd));
+    return fork.end();
   };
   // W (out, in) row-major -> W^T (in, out): the data-gradient GEMM dA = dC . W then reads both
   // operands reduce-contiguous (fast tile fetch, b128 LDS fragments, bf16 modes available)
@@ -675,6 +757,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
   }
 
   // ---- time / text embedding path ---------------------------------------------------------
+  HIG_TRY(fork.join());   // every weight gradient is done (and the slabs are free) from here on
   const float* emb = ws + w.emb;
   HIG_TRY(colsum(dss, ss_ld, D.B, (int)ss_ld, GP(grads, HIG_P_STY_EMB_B)));
   HIG_TRY(hig_gemm_launch(G(dss, ss_ld, 1, emb, E, 1, GP(grads, HIG_P_STY_EMB_W), E, ss_ld, E, D.B).silu(1).g, 1, nullptr, st));

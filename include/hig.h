@@ -11,9 +11,10 @@
  *   - The caller owns every buffer.  The library allocates no device memory, frees nothing,
  *     keeps no reference past return.  All device pointers must be valid on the current HIP
  *     device (hipSetDevice is the caller's job).
- *   - Every launch goes on the `stream` argument (a hipStream_t passed as void*).  No
- *     synchronisation, allocation, blocking copy or host read-back happens inside, so any
- *     call sequence can be captured into a hipGraph.
+ *   - Every launch is ordered through the `stream` argument (a hipStream_t passed as void*): on it,
+ *     or -- hig_denoiser_bwd's weight gradients only -- on a library-owned stream forked from and
+ *     joined back into it with events.  No host synchronisation, device allocation, blocking copy or
+ *     host read-back happens inside, so any call sequence can be captured into a hipGraph.
  *   - Matrices are row-major fp32 unless stated; nn.Linear weights are (out, in).
  */
 #ifndef HIG_H
@@ -159,7 +160,11 @@ int hig_denoiser_fwd(const hig_dims* dims, const void* const* params, const floa
 
 /* Backward of hig_denoiser_fwd(training=1) for d(out) = dout.  Writes (does not accumulate)
  * every entry of `grads` (same table layout as params; NULL entries are skipped is NOT
- * supported -- all must be valid), dx (B,T,F) or NULL, dxf_proj (B,4d), dxf_out (B,N,Lt). */
+ * supported -- all must be valid), dx (B,T,F) or NULL, dxf_proj (B,4d), dxf_out (B,N,Lt).
+ * Streams: the weight-gradient GEMMs are forked onto a second stream that the library owns (one per
+ * host thread and device, created on first use -- so call it once eagerly before capturing it into a
+ * hipGraph) and joined back into `stream` before the function returns: callers still order everything
+ * through `stream` alone.  Environment HIG_BWD_OVERLAP=0 keeps every launch on `stream`. */
 int hig_denoiser_bwd(const hig_dims* dims, const void* const* params, const float* x,
                      const int64_t* t, const int64_t* length, const float* xf_out,
                      const void* textctx, const void* workspace, const float* dout,
