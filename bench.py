@@ -325,11 +325,18 @@ def main():
         def full_step():
             trainer.train_step_captured(inp["x0"], inp["t"], inp["length"], noise=noise, clip_out=clip_out, eot=eot)
 
+        def full_step_eager():
+            trainer.train_step_fused(inp["x0"], inp["t"], inp["length"], noise=noise, clip_out=clip_out, eot=eot)
+
         el_f = timed(full_step, ksteps, 2, world)
+        el_e = timed(full_step_eager, ksteps, 2, world)
+        best = min(el_f, el_e)
         extra["train_step_full_f32"] = {
-            "frames_per_s": round(B * T * ksteps * world / el_f, 1), "ms_per_step": round(el_f / ksteps * 1e3, 3),
+            "frames_per_s": round(B * T * ksteps * world / best, 1), "ms_per_step": round(best / ksteps * 1e3, 3),
+            "ms_per_step_hipgraph": round(el_f / ksteps * 1e3, 3), "ms_per_step_eager": round(el_e / ksteps * 1e3, 3),
             "what": "as train_step_f32 plus the text head forward/backward inside the step and its %.1f M parameters in "
-                    "the same all-reduce / clip / Adam; hipGraph replay" % (
+                    "the same all-reduce / clip / Adam; the better of hipGraph replay and eager launches (the backward's "
+                    "second stream overlaps better when launched eagerly)" % (
                         (model.flat_params().numel - model.flat_params().core_numel) / 1e6)}
         model.eval()
         if world == 1:
