@@ -28,6 +28,10 @@ sub(r"\| denoiser forward, fp32 \(headline\) \|[^\n]*",
 sub(r"\| FFN linear1 GEMM \(dominant kernel class\), fp32 \| [0-9.]+ ms, \*\*[0-9.]+ TFLOP/s = [0-9]+ % of 157.3\*\*",
     "| FFN linear1 GEMM (dominant kernel class), fp32 | %.3f ms, **%.1f TFLOP/s = %.0f %% of 157.3**"
     % (d["roofline"]["avg_launch_ms"], d["roofline"]["achieved"], 100 * d["roofline"]["frac"]))
+if d["roofline"].get("traffic"):
+    tr = d["roofline"]["traffic"] / 1e6
+    sub(r"HBM traffic \*\*[0-9.]+ MB/launch vs 79.2 MB algorithmic\*\*", "HBM traffic **%.1f MB/launch vs 79.2 MB algorithmic**" % tr)
+    sub(r"which is the remaining [0-9.]+ MB", "which is the remaining %.1f MB" % (tr - 79.2))
 sub(r"\| same forward, split-bf16 products[^\n]*",
     '| same forward, split-bf16 products (`precision="bf16x3"`, opt-in) | %.2f ms → %.2f M frames/s, rel-L2 %.1e vs the fp32 path |'
     % (e["fwd_bf16x3"]["ms_per_step"], e["fwd_bf16x3"]["frames_per_s"] / 1e6, e["fwd_bf16x3"]["rel_l2_vs_f32_path"]))
