@@ -187,8 +187,10 @@ class DDPMTrainer(object):
             self.train_mode()
             for i, batch_data in enumerate(train_loader):
                 if getattr(self.opt, "fused_step", False):
-                    # MI355X path: the same update as forward() + update(), as one captured hipGraph
-                    log_dict = OrderedDict({'loss_mot_rec': self.train_fused_batch(batch_data).item()})
+                    # MI355X path: the same update as forward() + update() as one fused step (`opt.fused_graph`:
+                    # replayed as a hipGraph -- no host work per step, but the backward's second stream overlaps less)
+                    log_dict = OrderedDict({'loss_mot_rec': self.train_fused_batch(
+                        batch_data, captured=getattr(self.opt, "fused_graph", False)).item()})
                 else:
                     self.forward(batch_data)
                     log_dict = self.update()
@@ -304,9 +306,11 @@ class DDPMTrainer(object):
         self._fused_clip_adam(world, lr, with_text)
         return st["loss"]
 
-    def train_fused_batch(self, batch_data, captured=True, noise=None):
+    def train_fused_batch(self, batch_data, captured=False, noise=None):
         """forward(batch) + update() of the reference (ddpm_trainer.py:97-119,180-187) as ONE fused step over every
-        trainable parameter: batch -> device, t ~ sampler, CLIP features -> train_step_captured / _fused."""
+        trainable parameter: batch -> device, t ~ sampler, CLIP features -> train_step_fused (eager launches: measured
+        faster than the replayed graph at every batch size since the backward runs on two streams), or
+        train_step_captured with captured=True (two graph launches per step, no other host work)."""
         caption, motions, m_lens = batch_data
         x_start = motions.detach().to(self.device).float().contiguous()
         B, T = x_start.shape[:2]

@@ -121,7 +121,7 @@ class DDPMMulTrainer(DDPMTrainer):
         if tstate is not None:
             self._text_backward(tstate, dxp, dxo)
 
-    def train_fused_batch(self, batch_data, captured=True, noise=None):
+    def train_fused_batch(self, batch_data, captured=False, noise=None):
         """forward(batch) + update() of the reference (mul_ddpm_trainer.py:90-161, 251-258) as one fused step."""
         if not self.multi:
             return super().train_fused_batch(batch_data, captured, noise)

@@ -153,7 +153,7 @@ def test_end_to_end_two_person_pipeline(tmp_path):
     losses = []
     for it in range(60):
         items = [(4 * it + k) % len(ds) for k in range(4)]
-        losses.append(tr.train_fused_batch(bank.make_batch(items)).item())
+        losses.append(tr.train_fused_batch(bank.make_batch(items), captured=True).item())
     assert all(np.isfinite(losses))
     assert abs(losses[0] - 1.0) < 0.1            # zero-initialised output head: the first loss is E[noise^2]
     assert np.mean(losses[-10:]) < 0.95 * np.mean(losses[:3])  # and it trains (per-step losses are noisy: t is random)

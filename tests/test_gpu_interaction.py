@@ -308,7 +308,8 @@ def test_pit_fused_batch_with_text_head_matches_reference_golden(gold):
     t_fixed = torch.tensor(c["t"])
     trainer.sampler.sample = lambda bs, dev: (t_fixed.to(dev), torch.ones(bs))
     noise = (fill.tensor_for("g9.noise.0", (2 * B, T, Fd)) * 10).to(DEV)
-    loss = trainer.train_fused_batch((CAP1, CAP2, motion1, motion2, torch.tensor(c["lengths"]), None), noise=noise)
+    loss = trainer.train_fused_batch((CAP1, CAP2, motion1, motion2, torch.tensor(c["lengths"]), None), captured=True,
+                                     noise=noise)
     st = trainer.fused_state()
     assert abs(loss.item() - float(g["loss_mot_rec"])) < 1e-4 * float(g["loss_mot_rec"])
     assert abs(st["gnorm"].item() - float(g["gnorm"])) < 2e-4 * float(g["gnorm"])
