@@ -440,10 +440,10 @@ struct SideStream {
   hipStream_t s2 = nullptr;
   hipEvent_t ready = nullptr;
   hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool ok = false;
+  bool ok = false, failed = false;
 };
 
-SideStream* side_stream_for_current_device() {
+SideStream* side_stream_for_current_device(hipStream_t caller) {
   static const int enabled = getenv("HIG_BWD_OVERLAP") ? atoi(getenv("HIG_BWD_OVERLAP")) : 1;
   if (!enabled) return nullptr;
   constexpr int kMaxDev = 16;
@@ -451,12 +451,19 @@ SideStream* side_stream_for_current_device() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
   SideStream& s = tab[dev];
+  if (s.failed) return nullptr;
   if (!s.ok) {
-    // first use on this thread / device (an eager step; the captured trainer path warms up eagerly first)
-    if (hipStreamCreateWithFlags(&s.s2, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    bool good = hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) == hipSuccess;
+    // first use on this thread / device.  Creating a stream is not something to do under capture: a caller that
+    // captures its very first backward (no eager warm-up) simply gets the single-stream order for that graph.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(caller, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    bool good = hipStreamCreateWithFlags(&s.s2, hipStreamNonBlocking) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 4 && good; ++i) good = hipEventCreateWithFlags(&s.done[i], hipEventDisableTiming) == hipSuccess;
-    if (!good) return nullptr;
+    if (!good) {   // do not retry (and leak) on every call: stay on the caller's stream for good
+      s.failed = true;
+      return nullptr;
+    }
     s.ok = true;
   }
   return &s;
@@ -519,7 +526,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
   float* lnp = b + bw.lnpart;
   float* dss = b + bw.dss;
 
-  WgradFork fork(side_stream_for_current_device(), st);
+  WgradFork fork(side_stream_for_current_device(st), st);
   hig_stream_t wstream = reinterpret_cast<hig_stream_t>(fork.stream());
   auto wgrad_on = [&](G gd) -> int {  // X, Y both reduce-slow; split over the reduce rows
     const int s = wgrad_splits(gd.g.I, gd.g.J, gd.g.R, bw.slab_floats);
