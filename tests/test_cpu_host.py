@@ -47,6 +47,18 @@ def test_abi_struct_sizes_and_dim_validation():
     assert lib.hig_workspace_bytes(C.byref(bad), 0) < 0          # d % H != 0
     # NULL arguments are rejected with an error code, never a crash
     assert lib.hig_rowstats(None, 4, 1, 4, None, None) == -1
+    # evaluator encoders: size query and validation, no compute
+    e = _lib.EvalDims(B=4, T=91, F=259, d=512, H=8, ff=1024, L=8, C=26, cls=0, prec=0)
+    n0 = lib.hig_eval_encoder_workspace_bytes(C.byref(e))
+    e.cls = 1
+    assert 0 < n0 < lib.hig_eval_encoder_workspace_bytes(C.byref(e))        # the [cls] token adds a row per pair
+    bad = _lib.EvalDims(B=4, T=91, F=259, d=512, H=4, ff=1024, L=8, C=26, cls=0, prec=0)
+    assert lib.hig_eval_encoder_workspace_bytes(C.byref(bad)) < 0 and "head dim" in _lib.last_error()
+    bad = _lib.EvalDims(B=4, T=1, F=259, d=512, H=8, ff=1024, L=8, C=26, cls=0, prec=0)
+    assert lib.hig_eval_encoder_workspace_bytes(C.byref(bad)) < 0           # a pair needs the init-pose row + a frame
+    assert lib.hig_eval_encoder_fwd(C.byref(e), None, None, None, None, None, None, None, None) < 0
+    t = _lib.TextDims(B=2, N=77, W=512, Lt=256, H=4, ff=2048, L=4, E=2048, prec=0)
+    assert lib.hig_text_head_workspace_bytes(C.byref(t), 1) > lib.hig_text_head_workspace_bytes(C.byref(t), 0) > 0
 
 
 def test_no_cpu_fallback_in_product_path():
