@@ -315,12 +315,18 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
 
   // K0: emb = time_embed(timestep_embedding(t)) + xf_proj; all 3L scale/shift pairs in ONE GEMM
   HIG_TRY(hig_timestep_embedding(t, D.B, d, ws + w.te, stream));
-  HIG_TRY(hig_gemm_launch(G(ws + w.te, d, 0, P(params, HIG_P_TE0_W), d, 0, ws + w.te_h, E, D.B, E, d)
-                              .epi(HIG_EPI_BIAS, P(params, HIG_P_TE0_B)).prec(D.prec).g, 1, nullptr, st));
-  HIG_TRY(hig_gemm_launch(G(ws + w.te_h, E, 0, P(params, HIG_P_TE2_W), E, 0, ws + w.emb, E, D.B, E, E)
-                              .silu(0).epi(HIG_EPI_BIAS_RES, P(params, HIG_P_TE2_B)).res(xf_proj, E).prec(D.prec).g, 1, nullptr, st));
-  HIG_TRY(hig_gemm_launch(G(ws + w.emb, E, 0, P(params, HIG_P_STY_EMB_W), E, 0, ws + w.ss, ss_ld, D.B, ss_ld, E)
-                              .silu(0).epi(HIG_EPI_BIAS, P(params, HIG_P_STY_EMB_B)).prec(D.prec).g, 1, nullptr, st));
+  // per-sample (B-row) GEMMs: weight-bandwidth bound; split over the reduce range with the still unused layer
+  // buffers as scratch (hig_gemm_few_rows)
+  float* few_scratch = ws + w.layer0;
+  const int64_t few_floats = w.total - w.layer0;
+  HIG_TRY(hig_gemm_few_rows(G(ws + w.te, d, 0, P(params, HIG_P_TE0_W), d, 0, ws + w.te_h, E, D.B, E, d)
+                                .epi(HIG_EPI_BIAS, P(params, HIG_P_TE0_B)).prec(D.prec).g, few_scratch, few_floats, st));
+  HIG_TRY(hig_gemm_few_rows(G(ws + w.te_h, E, 0, P(params, HIG_P_TE2_W), E, 0, ws + w.emb, E, D.B, E, E)
+                                .silu(0).epi(HIG_EPI_BIAS_RES, P(params, HIG_P_TE2_B)).res(xf_proj, E).prec(D.prec).g,
+                            few_scratch, few_floats, st));
+  HIG_TRY(hig_gemm_few_rows(G(ws + w.emb, E, 0, P(params, HIG_P_STY_EMB_W), E, 0, ws + w.ss, ss_ld, D.B, ss_ld, E)
+                                .silu(0).epi(HIG_EPI_BIAS, P(params, HIG_P_STY_EMB_B)).prec(D.prec).g, few_scratch, few_floats,
+                            st));
   // K1: h0 = joint_embed(x) + sequence_embedding[:T]
   {
     G ge(x, D.F, 0, P(params, HIG_P_JOINT_W), D.F, 0, ws + w.h0, d, M, d, D.F);

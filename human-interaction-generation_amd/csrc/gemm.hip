@@ -694,9 +694,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
 
 // out[e] = sum_s slabs[s][e] for the first n4 float4 of a slab; the float4 behind them (n4 <= e < n4_all: the
 // per-split column sums of X) go to out2
+// (few-row forward GEMMs: + bias[column] and + res[row][column], the epilogue the split launch could not apply)
+struct SplitEpilogue {
+  const float* bias;   // [J] or null
+  const float* res;    // rows of ldr floats, or null
+  int64_t ldr;
+  int J4;              // J / 4
+};
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit, int64_t slab,
-                                    int64_t n4, float* __restrict__ out, int64_t n4_all = 0,
-                                    float* __restrict__ out2 = nullptr) {
+                                    int64_t n4, float* __restrict__ out, int64_t n4_all, float* __restrict__ out2,
+                                    SplitEpilogue se) {
   const int64_t total = n4_all > n4 ? n4_all : n4;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
@@ -705,13 +712,25 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit,
       const float4 t = reinterpret_cast<const float4*>(slabs + k * slab)[e];
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    if (e < n4) reinterpret_cast<float4*>(out)[e] = s;
-    else reinterpret_cast<float4*>(out2)[e - n4] = s;
+    if (e < n4) {
+      if (se.bias) {
+        const int64_t i = e / se.J4, j4 = e - i * se.J4;
+        const float4 b = reinterpret_cast<const float4*>(se.bias)[j4];
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        if (se.res) {
+          const float4 r = *reinterpret_cast<const float4*>(se.res + i * se.ldr + 4 * j4);
+          s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w;
+        }
+      }
+      reinterpret_cast<float4*>(out)[e] = s;
+    } else {
+      reinterpret_cast<float4*>(out2)[e - n4] = s;
+    }
   }
 }
 
 template <int BI, int BJ, bool X_RS, bool Y_RS, int XF, bool XF_ON_Y, int EPI>
-int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipStream_t st) {
+int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipStream_t st, const SplitEpilogue& se) {
   KArgs a;
   a.g = g;
   a.xsum = nullptr;
@@ -793,7 +812,7 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
     const int64_t want = (n4 + 255) / 256;
     const int blocks = (int)(want > 2048 ? 2048 : want);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, splits, a.slab, n4, g.C,
-                       a.xsum ? n4 + g.I / 4 : (int64_t)0, a.xsum ? g.xcolsum : (float*)nullptr);
+                       a.xsum ? n4 + g.I / 4 : (int64_t)0, a.xsum ? g.xcolsum : (float*)nullptr, se);
     HIG_CHECK_LAUNCH();
   }
   return HIG_OK;
@@ -805,10 +824,10 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
 // but 12.25 64x64 tiles (13 rounds, 94 %).  Pick the shape with the smallest
 // rounds x tile-area x overhead; smaller tiles pay a little more prologue/epilogue/LDS traffic.
 template <bool X_RS, bool Y_RS, int XF, bool XF_ON_Y, int EPI>
-int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipStream_t st) {
+int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipStream_t st, const SplitEpilogue& se) {
   if (splits > 1 || X_RS) {  // weight gradients: split-R already supplies the parallelism
-    if (g.I > 64 && g.J > 64) return launch<128, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
-    return launch<64, 64, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
+    if (g.I > 64 && g.J > 64) return launch<128, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st, se);
+    return launch<64, 64, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st, se);
   }
   struct Cand { int bi, bj; double ovh; };
   // measured (tools/gemm_bench.py): with 64-cycle fp32 MFMAs small tiles cost almost nothing;
@@ -844,10 +863,10 @@ int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab,
   }
   if (forced >= 0) best = forced;
   switch (best) {
-    case 0: return launch<128, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
-    case 1: return launch<64, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
-    case 2: return launch<128, 64, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
-    default: return launch<64, 64, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st);
+    case 0: return launch<128, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st, se);
+    case 1: return launch<64, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st, se);
+    case 2: return launch<128, 64, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st, se);
+    default: return launch<64, 64, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st, se);
   }
 }
 
@@ -855,7 +874,14 @@ int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab,
 
 // Internal entry (used by denoiser.hip): splits > 1 routes partial sums over the reduce range
 // through `slabs` (splits x I x J floats) and a deterministic slab reduction.
+namespace {
+int gemm_dispatch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_t st, const SplitEpilogue& se);
+}
 int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_t st) {
+  return gemm_dispatch(g, splits, slabs, st, SplitEpilogue{nullptr, nullptr, 0, 1});
+}
+namespace {
+int gemm_dispatch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_t st, const SplitEpilogue& se) {
   HIG_REQUIRE(g.X && g.Y && g.C, "hig_gemm: null operand");
   HIG_REQUIRE(g.I >= 0 && g.J >= 0 && g.R >= 0, "hig_gemm: negative extent");
   if (g.I == 0 || g.J == 0) return HIG_OK;
@@ -875,7 +901,7 @@ int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_
 #define CASE(xrs, yrs, xfv, ony, epiv)                                                   \
   if (g.x_rs == xrs && g.y_rs == yrs && g.xf == xfv && (g.xf == HIG_XF_NONE || g.xf_on_y == ony) && \
       g.epi == epiv)                                                                     \
-    return launch_sized<xrs, yrs, xfv, ony, epiv>(g, splits, slabs, slab, st);
+    return launch_sized<xrs, yrs, xfv, ony, epiv>(g, splits, slabs, slab, st, se);
 #ifdef HIG_GEMM_PROBE  // compile-time aid: build a single combination
   CASE(0, 0, HIG_XF_NONE, 0, HIG_EPI_BIAS_GELU)
   return HIG_EUNSUPPORTED;
@@ -892,6 +918,7 @@ int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_
   CASE(0, 0, HIG_XF_LN_MOD_SILU, 0, HIG_EPI_BIAS_RES)
   CASE(0, 0, HIG_XF_SILU, 0, HIG_EPI_BIAS)
   CASE(0, 0, HIG_XF_SILU, 0, HIG_EPI_BIAS_RES)
+  CASE(0, 0, HIG_XF_SILU, 0, HIG_EPI_NONE)   // split-R partials of the few-row GEMMs
   // dgrad (dC x weight)
   CASE(0, 1, HIG_XF_NONE, 0, HIG_EPI_NONE)
   CASE(0, 1, HIG_XF_NONE, 0, HIG_EPI_RES)
@@ -904,6 +931,39 @@ int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_
 #undef CASE
   return hig_set_error(HIG_EUNSUPPORTED, "hig_gemm: combination x_rs=%d y_rs=%d xf=%d on_y=%d epi=%d not built",
                        g.x_rs, g.y_rs, g.xf, g.xf_on_y, g.epi);
+}
+}  // namespace
+
+// Few-row GEMMs (I <= 64: the per-sample time / text embedding MLP and the stacked stylization `emb_layers`):
+// one row tile, so the launch has only J / 64 workgroups and each streams its whole K range of the weight alone --
+// weight-bandwidth bound at a fraction of the HBM rate (B x 24576 x 2048: 200 MB in 102 us; B x 2048 x 2048 on 32
+// workgroups: 60 us).  Split the reduce range so ~1024 workgroups stream the weight together, sum the partial outputs
+// from `scratch` (deterministic slab reduction), which also applies bias / residual.
+// EPI_BIAS / EPI_BIAS_RES, reduce-contiguous operands, dense C; falls back to the plain launch when that does not apply.
+int hig_gemm_few_rows(const hig_gemm_desc& g, float* scratch, int64_t scratch_floats, hipStream_t st) {
+  static const int enabled = getenv("HIG_FEW_ROWS_SPLIT") ? atoi(getenv("HIG_FEW_ROWS_SPLIT")) : 1;   // tuning knob
+  const int64_t out = (int64_t)g.I * g.J;
+  const bool ok = enabled && scratch && g.I > 0 && g.I <= 64 && g.x_rs == 0 && g.y_rs == 0 && g.ldc == g.J && g.J % 4 == 0 &&
+                  (g.epi == HIG_EPI_BIAS || g.epi == HIG_EPI_BIAS_RES) && g.bias &&
+                  (g.xf == HIG_XF_NONE || g.xf == HIG_XF_SILU) && g.R % 32 == 0 &&
+                  (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
+                  (g.epi != HIG_EPI_BIAS_RES || (g.res && (reinterpret_cast<uintptr_t>(g.res) & 15) == 0 && g.ldr % 4 == 0));
+  int splits = 1;
+  if (ok) {
+    const int64_t tiles = (g.J + 63) / 64;
+    int64_t s = 1024 / tiles;
+    if (s > g.R / 64) s = g.R / 64;
+    if (s > 16) s = 16;
+    if (s * out > scratch_floats) s = scratch_floats / out;
+    splits = (int)(s < 1 ? 1 : s);
+  }
+  if (splits <= 1) return hig_gemm_launch(g, 1, nullptr, st);
+  hig_gemm_desc p = g;
+  p.epi = HIG_EPI_NONE;
+  p.bias = nullptr;
+  p.res = nullptr;
+  return gemm_dispatch(p, splits, scratch, st,
+                       SplitEpilogue{g.bias, g.epi == HIG_EPI_BIAS_RES ? g.res : nullptr, g.ldr, g.J / 4});
 }
 
 extern "C" int hig_gemm(const hig_gemm_desc* g, hig_stream_t stream) {

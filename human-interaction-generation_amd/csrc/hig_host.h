@@ -6,6 +6,8 @@
 #include "hig_common.h"
 
 int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_t st);
+// I <= 64 rows with EPI_BIAS / EPI_BIAS_RES: split-R over `scratch` so the weight streams through ~1024 workgroups
+int hig_gemm_few_rows(const hig_gemm_desc& g, float* scratch, int64_t scratch_floats, hipStream_t st);
 
 namespace {
 
