@@ -535,7 +535,7 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
   WgradFork fork(side_stream_for_current_device(st), st);
   hig_stream_t wstream = reinterpret_cast<hig_stream_t>(fork.stream());
   auto wgrad_on = [&](G gd) -> int {  // X, Y both reduce-slow; split over the reduce rows
-    const int s = wgrad_splits(gd.g.I, gd.g.J, gd.g.R, bw.slab_floats);
+    const int s = wgrad_splits(gd.g.I, gd.g.J, gd.g.R, bw.slab_floats, gd.g.prec);
     return hig_gemm_launch(gd.g, s, slabs, fork.stream());
   };
   auto wgrad = [&](G gd) -> int {

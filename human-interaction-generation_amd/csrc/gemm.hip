@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "hig_common.h"
+#include "hig_host.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -825,8 +826,8 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
 // rounds x tile-area x overhead; smaller tiles pay a little more prologue/epilogue/LDS traffic.
 template <bool X_RS, bool Y_RS, int XF, bool XF_ON_Y, int EPI>
 int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipStream_t st, const SplitEpilogue& se) {
-  if (splits > 1 || X_RS) {  // weight gradients: split-R already supplies the parallelism
-    if (g.I > 64 && g.J > 64) return launch<128, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st, se);
+  if (splits > 1 || X_RS) {  // weight gradients: split-R already supplies the parallelism; tile rule in hig_host.h
+    if (wgrad_tile(g.I, g.J, g.prec) == 128) return launch<128, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st, se);
     return launch<64, 64, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st, se);
   }
   struct Cand { int bi, bj; double ovh; };

@@ -38,13 +38,25 @@ struct G {  // small builder for gemm descriptors
   }
 };
 
-// Split the reduce range of a weight-gradient GEMM so that tiles x splits fills, but does not exceed, the
-// 512 workgroups that are resident at once (2 per CU: 64 KB of LDS each) -- one more would start a second,
-// nearly empty round (768 in flight cost the training step 0.6 ms; profiles/r01_notes.md).
-inline int wgrad_splits(int64_t I, int64_t J, int64_t R, int64_t slab_floats) {
-  const int bi = (I > 64 && J > 64) ? 128 : 64;
+// Weight-gradient GEMMs (dW = dC^T . act over the M rows).  Tile: exact-fp32 products run 64x64 tiles (four resident
+// workgroups per CU, 4x fewer split-R slabs to write and sum than with 128x128: forward+backward 20.6 -> 20.2 ms),
+// the bf16 product modes 128x128 (14.9 vs 15.2 ms bf16x3, 12.9 vs 13.5 ms bf16) -- same-box sweeps in
+// profiles/r01_notes.md.  HIG_WGRAD_TILE = 64 / 128 forces one.
+inline int wgrad_tile(int64_t I, int64_t J, int prec) {
+  static const int forced = getenv("HIG_WGRAD_TILE") ? atoi(getenv("HIG_WGRAD_TILE")) : 0;   // tuning knob
+  if (!(I > 64 && J > 64)) return 64;
+  if (forced == 64 || forced == 128) return forced;
+  return prec == HIG_PREC_F32 ? 64 : 128;
+}
+
+// Split the reduce range so that tiles x splits fills, but does not exceed, the workgroups that are resident at once
+// (128x128: 2 per CU = 512, 64 KB of LDS each; 64x64: 4 per CU = 1024) -- one more would start a second, nearly empty
+// round (768 in flight cost the training step 0.6 ms; profiles/r01_notes.md).
+inline int wgrad_splits(int64_t I, int64_t J, int64_t R, int64_t slab_floats, int prec) {
+  const int bi = wgrad_tile(I, J, prec);
   const int64_t tiles = ((I + bi - 1) / bi) * ((J + bi - 1) / bi);
-  static const int target = getenv("HIG_WGRAD_TARGET") ? atoi(getenv("HIG_WGRAD_TARGET")) : 512;  // tuning knob
+  static const int forced_target = getenv("HIG_WGRAD_TARGET") ? atoi(getenv("HIG_WGRAD_TARGET")) : 0;  // tuning knob
+  const int target = forced_target > 0 ? forced_target : (bi == 128 ? 512 : 1024);
   int64_t s = target / tiles;
   const int64_t maxs = R / 256 > 1 ? R / 256 : 1;
   if (s > maxs) s = maxs;

@@ -195,7 +195,7 @@ extern "C" int hig_text_head_bwd(const hig_text_dims* dims, const void* const* p
   float* wT = b + bw.wT;
 
   auto wgrad = [&](G gd) -> int {
-    const int s = wgrad_splits(gd.g.I, gd.g.J, gd.g.R, bw.slab_floats);
+    const int s = wgrad_splits(gd.g.I, gd.g.J, gd.g.R, bw.slab_floats, gd.g.prec);
     return hig_gemm_launch(gd.g, s, slabs, st);
   };
   // dW[n][k] = sum_m dC[m][n] * act[m][k]; bf16 product modes transpose both operands first
