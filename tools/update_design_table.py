@@ -43,7 +43,7 @@ sub(r"\| train step, denoiser core[^\n]*",
     % (e["train_step_f32"]["ms_per_step"], e["train_step_bf16x3"]["ms_per_step"], e["train_step_f32"]["frames_per_s"] / 1e3,
        e["train_step_bf16x3"]["frames_per_s"] / 1e3))
 sub(r"\| train step, every trainable parameter[^\n]*",
-    "| train step, every trainable parameter (text head inside, hipGraph), fp32 | %.1f ms → %.0f k frames/s |"
+    "| train step, every trainable parameter (text head inside; better of eager launches and hipGraph replay), fp32 | %.1f ms → %.0f k frames/s |"
     % (e["train_step_full_f32"]["ms_per_step"], e["train_step_full_f32"]["frames_per_s"] / 1e3))
 sub(r"\| DDPM sampling B=32[^\n]*",
     "| DDPM sampling B=32, hipGraph replay, fp32 / bf16 | %.2f / %.2f ms per step → %.1f / %.1f samples/s per 1000 steps |"
