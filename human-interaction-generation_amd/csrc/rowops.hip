@@ -288,6 +288,51 @@ __global__ void dss_reduce_kernel(const float* __restrict__ partial, int nsplit,
   dss[(int64_t)b * dss_ld + shift_off + c] = s3;
 }
 
+// Both reductions of a stylization LayerNorm backward in one launch: blocks [0, nb_col) are colreduce_kernel blocks over
+// the [dgamma | dbeta] columns of the partial table, the blocks behind them do dss_reduce_kernel's (sample, column) sums.
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int samples, int nsplit,
+                                                             int n, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int shift_off, float* __restrict__ dss, int64_t dss_ld,
+                                                             int nb_col) {
+  if ((int)blockIdx.x < nb_col) {
+    __shared__ float red[16][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx, nr = samples * nsplit;
+    const int64_t rstride = (int64_t)4 * n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < 2 * n) {
+      int r = ry;
+      for (; r + 48 < nr; r += 64) {
+        s0 += partial[(int64_t)r * rstride + c];
+        s1 += partial[(int64_t)(r + 16) * rstride + c];
+        s2 += partial[(int64_t)(r + 32) * rstride + c];
+        s3 += partial[(int64_t)(r + 48) * rstride + c];
+      }
+      for (; r < nr; r += 16) s0 += partial[(int64_t)r * rstride + c];
+    }
+    red[ry][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ry == 0 && c < 2 * n) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[k][cx];
+      if (c < n) dgamma[c] = t; else dbeta[c - n] = t;
+    }
+    return;
+  }
+  const int64_t idx = (int64_t)(blockIdx.x - nb_col) * 1024 + threadIdx.x;
+  const int b = (int)(idx / n), c = (int)(idx % n);
+  if (b >= samples) return;
+  float s2 = 0.f, s3 = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* p = partial + ((int64_t)b * nsplit + s) * 4 * n;
+    s2 += p[2 * (int64_t)n + c];
+    s3 += p[3 * (int64_t)n + c];
+  }
+  dss[(int64_t)b * dss_ld + c] = s2;
+  dss[(int64_t)b * dss_ld + shift_off + c] = s3;
+}
+
 // partial[chunk][c] = sum over this chunk's rows of x[row][c]
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx,
                                                      int64_t rows, int n, float* __restrict__ partial) {
@@ -523,6 +568,14 @@ extern "C" int hig_ln_bwd(const float* da, int64_t ldda, const float* x, int64_t
 #undef LNB
   HIG_CHECK_LAUNCH();
   const int tb = 128;
+  if (dgamma && dbeta && mod_silu) {   // the usual stylization case: all four sums in one launch
+    const int nb_col = (2 * n + 63) / 64;
+    const int nb_dss = (int)(((int64_t)samples * n + 1023) / 1024);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(nb_col + nb_dss), dim3(1024), 0, st, partial, samples, nsplit, n, dgamma,
+                       dbeta, ss_shift_off, dss, dss_ld, nb_col);
+    HIG_CHECK_LAUNCH();
+    return HIG_OK;
+  }
   if (dgamma && dbeta) {   // partial rows are [dgamma n | dbeta n | ...]: both in one launch
     hipLaunchKernelGGL(colreduce_kernel, dim3((2 * n + 63) / 64), dim3(1024), 0, st, partial,
                        samples * nsplit, (int64_t)4 * n, 2 * n, dgamma, n, dbeta);
