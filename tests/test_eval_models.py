@@ -94,6 +94,30 @@ def test_metrics_match_reference_golden(gold):
         M.calculate_diversity(a[:50], 50)
 
 
+def test_metric_properties():
+    """Size-independent properties: FID ignores sample order and any rotation applied to both sets, R-precision of a
+    set against a slightly perturbed copy is perfect and cumulative in k, the distance matrix equals the direct norm."""
+    rs = np.random.RandomState(3)
+    a, b = rs.standard_normal((400, 12)), rs.standard_normal((350, 12)) * 0.7 + 0.3
+    fid = M.calculate_frechet_distance(*M.calculate_activation_statistics(a), *M.calculate_activation_statistics(b))
+    q, _ = np.linalg.qr(rs.standard_normal((12, 12)))
+    fid_rot = M.calculate_frechet_distance(*M.calculate_activation_statistics(a @ q),
+                                           *M.calculate_activation_statistics(b @ q))
+    fid_perm = M.calculate_frechet_distance(*M.calculate_activation_statistics(a[rs.permutation(400)]),
+                                            *M.calculate_activation_statistics(b[rs.permutation(350)]))
+    assert abs(fid_rot - fid) < 1e-8 * max(1.0, fid) and abs(fid_perm - fid) < 1e-9 * max(1.0, fid)
+    top = M.calculate_R_precision(a[:50], a[:50] + 1e-3, 3)         # (an exact copy gives sqrt(-0) = NaN self-distances,
+    assert top.all() and top.shape == (50, 3)                       #  which the reference's expansion formula has too)
+    far = M.calculate_R_precision(a[:50], b[:50], 3)
+    assert (far[:, 1:] >= far[:, :-1]).all()                        # top-k hits are cumulative in k
+    d = M.euclidean_distance_matrix(a[:30], b[:30])
+    assert np.allclose(d, M.euclidean_distance_matrix(b[:30], a[:30]).T, atol=1e-9)
+    assert np.allclose(d, np.linalg.norm(a[:30, None] - b[None, :30], axis=2), atol=1e-9)
+    np.random.seed(0)
+    same = np.repeat(a[:1], 20, axis=0)
+    assert M.calculate_diversity(same, 5) == 0.0 and M.calculate_multimodality(same[None], 5) == 0.0
+
+
 def test_evaluate_fid_host_logic():
     rs = np.random.RandomState(0)
     acts = {"ground truth": rs.standard_normal((200, 8)), "model": rs.standard_normal((200, 8)) + 0.5}
