@@ -32,6 +32,7 @@ SYMBOLS = (
     "hig_text_head_workspace_bytes", "hig_text_head_bwd_workspace_bytes", "hig_text_head_fwd", "hig_text_head_bwd",
     "hig_layernorm", "hig_gather_rows", "hig_scatter_add_rows", "hig_gather_frames", "hig_recover_joints", "hig_transpose_batch", "hig_linattn_ctx_scratch_floats", "hig_pair_mse",
     "hig_fullattn_fwd_kpad", "hig_eval_encoder_workspace_bytes", "hig_eval_encoder_fwd",
+    "hig_clip_adam_lrdev", "hig_shutdown",
 )
 
 
@@ -125,6 +126,8 @@ def lib():
         L.hig_pair_mse.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
         L.hig_sumsq_partial.argtypes = [vp, i64, f32, vp, vp]
         L.hig_clip_adam.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, vp, vp, vp]
+        L.hig_clip_adam_lrdev.argtypes = [vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, f32, vp, vp, vp, vp]
+        L.hig_shutdown.argtypes = []
         L.hig_text_head_workspace_bytes.restype = i64
         L.hig_text_head_workspace_bytes.argtypes = [C.POINTER(TextDims), C.c_int]
         L.hig_text_head_bwd_workspace_bytes.restype = i64

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
                                                         float eps, float max_norm, float inv_world,
                                                         const float* __restrict__ partial,
                                                         float* __restrict__ gnorm_out,
-                                                        const int32_t* __restrict__ step_dev) {
+                                                        const int32_t* __restrict__ step_dev,
+                                                        const float* __restrict__ lr_dev) {
   __shared__ float red[256];
   __shared__ float s_coef, s_step_size, s_inv_sqrt_bc2;
   {
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
       s_coef = coef * inv_world;
       const double t = (double)(*step_dev + 1);
       const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
-      s_step_size = (float)((double)lr / bc1);
+      s_step_size = (float)((double)(lr_dev ? lr_dev[0] : lr) / bc1);
       s_inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
       if (blockIdx.x == 0 && gnorm_out) gnorm_out[0] = gnorm;
     }
@@ -356,12 +357,19 @@ extern "C" int hig_sumsq_partial(const float* g, int64_t n, float inv_world, flo
 extern "C" int hig_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
                              float b2, float eps, float max_norm, float inv_world, const float* scratch,
                              float* gnorm_out, int32_t* step_dev, hig_stream_t s) {
+  return hig_clip_adam_lrdev(p, g, m, v, n, lr, nullptr, b1, b2, eps, max_norm, inv_world, scratch, gnorm_out, step_dev, s);
+}
+
+extern "C" int hig_clip_adam_lrdev(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                                   const float* lr_dev, float b1, float b2, float eps, float max_norm,
+                                   float inv_world, const float* scratch, float* gnorm_out, int32_t* step_dev,
+                                   hig_stream_t s) {
   HIG_REQUIRE(p && g && m && v && scratch && step_dev && n > 0, "hig_clip_adam: bad arguments");
   HIG_REQUIRE(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                 reinterpret_cast<uintptr_t>(v)) & 15) == 0,
               "hig_clip_adam: buffers must be 16-byte aligned");
   hipLaunchKernelGGL(clip_adam_kernel, dim3(stream_blocks(n / 4 + 1)), dim3(256), 0, hig_stream(s), p, g, m, v,
-                     n, lr, b1, b2, eps, max_norm, inv_world, scratch, gnorm_out, step_dev);
+                     n, lr, b1, b2, eps, max_norm, inv_world, scratch, gnorm_out, step_dev, lr_dev);
   HIG_CHECK_LAUNCH();
   hipLaunchKernelGGL(inc_step_kernel, dim3(1), dim3(1), 0, hig_stream(s), step_dev);
   HIG_CHECK_LAUNCH();

@@ -449,11 +449,16 @@ struct SideStream {
   bool ok = false, failed = false;
 };
 
+constexpr int kMaxDev = 16;
+SideStream* side_stream_table() {
+  static thread_local SideStream tab[kMaxDev];
+  return tab;
+}
+
 SideStream* side_stream_for_current_device(hipStream_t caller) {
   static const int enabled = getenv("HIG_BWD_OVERLAP") ? atoi(getenv("HIG_BWD_OVERLAP")) : 1;
   if (!enabled) return nullptr;
-  constexpr int kMaxDev = 16;
-  static thread_local SideStream tab[kMaxDev];
+  SideStream* tab = side_stream_table();
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
   SideStream& s = tab[dev];
@@ -505,6 +510,26 @@ struct WgradFork {
 };
 
 }  // namespace
+
+// The library's only owned resources: the weight-gradient streams / events of the calling thread.
+extern "C" int hig_shutdown(void) {
+  SideStream* tab = side_stream_table();
+  int cur = 0;
+  const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+  int rc = HIG_OK;
+  for (int dev = 0; dev < kMaxDev; ++dev) {
+    SideStream& s = tab[dev];
+    if (!s.ok) { s.failed = false; continue; }
+    if (hipSetDevice(dev) != hipSuccess) { rc = hig_set_error(HIG_EHIP, "hig_shutdown: hipSetDevice(%d) failed", dev); continue; }
+    if (hipStreamSynchronize(s.s2) != hipSuccess) rc = hig_set_error(HIG_EHIP, "hig_shutdown: side stream of device %d is in error", dev);
+    for (int i = 0; i < 4; ++i) if (s.done[i]) (void)hipEventDestroy(s.done[i]);
+    if (s.ready) (void)hipEventDestroy(s.ready);
+    if (s.s2) (void)hipStreamDestroy(s.s2);
+    s = SideStream();
+  }
+  if (have_cur) (void)hipSetDevice(cur);
+  return rc;
+}
 
 extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params, const float* x,
                                 const int64_t* t, const int64_t* length, const float* xf_out,

@@ -10,11 +10,11 @@ trainers select -- EPSILON / FIXED_SMALL / MSE / linear betas / uniform sampler
   * `p_sample_loop` captured as a hipGraph (one denoiser step + update + device-side step
     counter, replayed num_timesteps times) when the model is our MotionTransformer.
 
-Branches no reference tool reaches (DDIM, learned variance, KL / VLB losses, cond_fn) keep their
-names and raise NotImplementedError instead of silently running something else.
+Configurations no reference tool reaches (other mean / variance parametrisations, the cosine schedule, DDIM,
+KL / VLB losses, cond_fn) are not built: the enums keep their member names, everything else raises
+NotImplementedError instead of silently running something else.
 """
 import enum
-import math
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -57,22 +57,12 @@ class UniformSampler(ScheduleSampler):
 
 
 def get_named_beta_schedule(schedule_name, num_diffusion_timesteps):
-    """gaussian_diffusion.py:229-253."""
-    if schedule_name == "linear":
-        scale = 1000 / num_diffusion_timesteps
-        return np.linspace(scale * 0.0001, scale * 0.02, num_diffusion_timesteps, dtype=np.float64)
-    elif schedule_name == "cosine":
-        return betas_for_alpha_bar(
-            num_diffusion_timesteps,
-            lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2,
-        )
-    raise NotImplementedError(f"unknown beta schedule: {schedule_name}")
-
-
-def betas_for_alpha_bar(num_diffusion_timesteps, alpha_bar, max_beta=0.999):
-    """gaussian_diffusion.py:256-273."""
-    return np.array([min(1 - alpha_bar((i + 1) / num_diffusion_timesteps) / alpha_bar(i / num_diffusion_timesteps),
-                         max_beta) for i in range(num_diffusion_timesteps)])
+    """The linear schedule of gaussian_diffusion.py:229-246 (the only one a reference tool asks for): betas from
+    1e-4 to 2e-2 at 1000 steps, end points scaled by 1000 / N otherwise; float64."""
+    if schedule_name != "linear":
+        raise NotImplementedError(f"beta schedule {schedule_name!r}: the reference trainers only use 'linear'")
+    scale = 1000 / num_diffusion_timesteps
+    return np.linspace(scale * 0.0001, scale * 0.02, num_diffusion_timesteps, dtype=np.float64)
 
 
 class ModelMeanType(enum.Enum):
@@ -113,6 +103,13 @@ def _unwrap(model):
 
 class GaussianDiffusion:
     def __init__(self, *, betas, model_mean_type, model_var_type, loss_type, rescale_timesteps=False):
+        if (model_mean_type, model_var_type, loss_type) != (ModelMeanType.EPSILON, ModelVarType.FIXED_SMALL,
+                                                             LossType.MSE):
+            # the enums keep the reference's member names, but only the combination its trainers construct
+            # (ddpm_trainer.py:40-45) is implemented
+            raise NotImplementedError("GaussianDiffusion: only EPSILON / FIXED_SMALL / MSE (the reference trainers' "
+                                      "configuration) is built, got %s / %s / %s"
+                                      % (model_mean_type, model_var_type, loss_type))
         self.model_mean_type = model_mean_type
         self.model_var_type = model_var_type
         self.loss_type = loss_type
@@ -157,12 +154,6 @@ class GaussianDiffusion:
         return all(t.is_cuda and t.dtype == th.float32 for t in tensors)
 
     # ---- q(x_t | x_0) ---------------------------------------------------------------------
-    def q_mean_variance(self, x_start, t):
-        mean = _extract_into_tensor(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start
-        variance = _extract_into_tensor(1.0 - self.alphas_cumprod, t, x_start.shape)
-        log_variance = _extract_into_tensor(self.log_one_minus_alphas_cumprod, t, x_start.shape)
-        return mean, variance, log_variance
-
     def q_sample(self, x_start, t, noise=None):
         """gaussian_diffusion.py:399-417."""
         if noise is None:
@@ -190,57 +181,24 @@ class GaussianDiffusion:
 
     # ---- p(x_{t-1} | x_t) -------------------------------------------------------------------
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
-        """gaussian_diffusion.py:443-537 (fixed-variance branches)."""
-        if model_kwargs is None:
-            model_kwargs = {}
+        """eps-prediction with the fixed small variance (gaussian_diffusion.py:443-471,488-537):
+        x0_hat from eps, then the posterior q(x_{t-1} | x_t, x0_hat)."""
         B = x.shape[0]
         assert t.shape == (B,)
-        model_output = model(x, self._scale_timesteps(t), **model_kwargs)
-        if self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
-            raise NotImplementedError("learned-variance models are not on the reference trainers' path")
-        model_variance, model_log_variance = {
-            ModelVarType.FIXED_LARGE: (np.append(self.posterior_variance[1], self.betas[1:]),
-                                       np.log(np.append(self.posterior_variance[1], self.betas[1:]))),
-            ModelVarType.FIXED_SMALL: (self.posterior_variance, self.posterior_log_variance_clipped),
-        }[self.model_var_type]
-        model_variance = _extract_into_tensor(model_variance, t, x.shape)
-        model_log_variance = _extract_into_tensor(model_log_variance, t, x.shape)
-
-        def process_xstart(v):
-            if denoised_fn is not None:
-                v = denoised_fn(v)
-            if clip_denoised:
-                return v.clamp(-1, 1)
-            return v
-
-        if self.model_mean_type == ModelMeanType.PREVIOUS_X:
-            pred_xstart = process_xstart(self._predict_xstart_from_xprev(x_t=x, t=t, xprev=model_output))
-            model_mean = model_output
-        elif self.model_mean_type in (ModelMeanType.START_X, ModelMeanType.EPSILON):
-            if self.model_mean_type == ModelMeanType.START_X:
-                pred_xstart = process_xstart(model_output)
-            else:
-                pred_xstart = process_xstart(self._predict_xstart_from_eps(x_t=x, t=t, eps=model_output))
-            model_mean, _, _ = self.q_posterior_mean_variance(x_start=pred_xstart, x_t=x, t=t)
-        else:
-            raise NotImplementedError(self.model_mean_type)
-        assert model_mean.shape == model_log_variance.shape == pred_xstart.shape == x.shape
-        return {"mean": model_mean, "variance": model_variance, "log_variance": model_log_variance,
-                "pred_xstart": pred_xstart}
+        eps = model(x, self._scale_timesteps(t), **(model_kwargs or {}))
+        pred_xstart = self._predict_xstart_from_eps(x_t=x, t=t, eps=eps)
+        if denoised_fn is not None:
+            pred_xstart = denoised_fn(pred_xstart)
+        if clip_denoised:
+            pred_xstart = pred_xstart.clamp(-1, 1)
+        mean, variance, log_variance = self.q_posterior_mean_variance(x_start=pred_xstart, x_t=x, t=t)
+        assert mean.shape == log_variance.shape == pred_xstart.shape == x.shape
+        return {"mean": mean, "variance": variance, "log_variance": log_variance, "pred_xstart": pred_xstart}
 
     def _predict_xstart_from_eps(self, x_t, t, eps):
         assert x_t.shape == eps.shape
         return (_extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
                 - _extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * eps)
-
-    def _predict_xstart_from_xprev(self, x_t, t, xprev):
-        assert x_t.shape == xprev.shape
-        return (_extract_into_tensor(1.0 / self.posterior_mean_coef1, t, x_t.shape) * xprev
-                - _extract_into_tensor(self.posterior_mean_coef2 / self.posterior_mean_coef1, t, x_t.shape) * x_t)
-
-    def _predict_eps_from_xstart(self, x_t, t, pred_xstart):
-        return (_extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
-                - pred_xstart) / _extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape)
 
     def _scale_timesteps(self, t):
         if self.rescale_timesteps:
@@ -382,22 +340,11 @@ class GaussianDiffusion:
             t = th.cat([t, t])
             x_start = th.cat([x_start[:B], x_start[:B], x_start[B:], x_start[B:]])
             noise = th.cat([noise[:B], noise[:B], noise[B:], noise[B:]])
-        terms = {}
-        if self.loss_type in (LossType.KL, LossType.RESCALED_KL):
-            raise NotImplementedError("KL / VLB losses are not on the reference trainers' path")
-        if self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
-            raise NotImplementedError("learned-variance models are not on the reference trainers' path")
         model_output = model(x_t, self._scale_timesteps(t), **model_kwargs)
-        target = {
-            ModelMeanType.PREVIOUS_X: lambda: self.q_posterior_mean_variance(x_start=x_start, x_t=x_t, t=t)[0],
-            ModelMeanType.START_X: lambda: x_start,
-            ModelMeanType.EPSILON: lambda: noise,
-        }[self.model_mean_type]()
-        assert model_output.shape == target.shape == x_start.shape
-        terms["mse"] = mean_flat((target - model_output) ** 2).view(-1, 1).mean(-1)
-        terms["target"] = target
-        terms["pred"] = model_output
-        return terms
+        assert model_output.shape == noise.shape == x_start.shape
+        # eps-prediction: the regression target is the injected noise
+        return {"mse": mean_flat((noise - model_output) ** 2).view(-1, 1).mean(-1), "target": noise,
+                "pred": model_output}
 
     # ---- names kept for API compatibility; never reached by the reference tools --------------
     def ddim_sample(self, *a, **k):

@@ -126,6 +126,8 @@ class MotionInteractionTransformer(MotionTransformer):
         self._flat = None
         self._pool = _WorkspacePool()
         self._textctx_cache = None
+        self._param_epoch = 0
+        self.cache_text_context = True
 
     # ---- reference API ------------------------------------------------------------------
     def load_my_state_dict(self, state_dict, opt):
@@ -149,7 +151,7 @@ class MotionInteractionTransformer(MotionTransformer):
             if isinstance(param, torch.nn.parameter.Parameter):
                 param = param.data
             own_state[name].copy_(param)
-        self._textctx_cache = None
+        self.params_changed()
 
     def encode_text(self, text, device):
         """:532-556; with `no_clip` the CLIP text tower is trained too (no no_grad)."""

@@ -385,6 +385,10 @@ class MotionTransformer(nn.Module):
         self._flat = None
         self._pool = _WorkspacePool()
         self._textctx_cache = None
+        self._param_epoch = 0
+        # inference only: keep the cross-attention text context of the last `xf_out` (it is step-invariant, so the
+        # sampling loop computes it once); False = recompute on every forward, as the reference does (:144-150)
+        self.cache_text_context = True
 
     # ---- nn.Module plumbing -------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -392,6 +396,27 @@ class MotionTransformer(nn.Module):
         self._flat = None            # .to()/.cuda()/.float() re-home parameters: re-flatten lazily
         self._textctx_cache = None
         return r
+
+    def params_changed(self):
+        """Tell the model its parameters were modified behind autograd's back (a fused optimizer kernel writing the
+        flat buffer, a checkpoint load): drops everything derived from them."""
+        self._param_epoch += 1
+        self._textctx_cache = None
+
+    def _load_from_state_dict(self, *a, **k):
+        self._textctx_cache = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def _textctx_param_version(self):
+        """Sum of the autograd version counters of every parameter the text context is built from.  The
+        nn.Parameters are re-homed VIEWS of the flat buffer, so an in-place update through them (torch optimizers,
+        load_state_dict, p.copy_) bumps THEIR counter, never the flat buffer's."""
+        v = self._param_epoch
+        for blk in self.temporal_decoder_blocks:
+            ca = blk.ca_block
+            for p in (ca.key.weight, ca.key.bias, ca.value.weight, ca.value.bias, ca.text_norm.weight, ca.text_norm.bias):
+                v += p._version
+        return v
 
     def flat_params(self):
         """Flat fp32 buffer aliasing every core parameter (built on first use on the device)."""
@@ -500,19 +525,26 @@ class MotionTransformer(nn.Module):
         """Cross-attention text side (all layers).  Cached on (storage, version) of xf_out and the
         parameter version, so the 1000-step sampling loop computes it once (it is step-invariant)."""
         fp = self.flat_params()
-        key = (xf_out.data_ptr(), xf_out._version, tuple(xf_out.shape), fp.flat.data_ptr(),
-               fp.flat._version, bool(training), self.precision)
-        if not training and self._textctx_cache is not None and self._textctx_cache[0] == key:
-            return self._textctx_cache[1]
+        use_cache = not training and self.cache_text_context
+        if use_cache:
+            key = (xf_out.data_ptr(), xf_out._version, tuple(xf_out.shape), fp.flat.data_ptr(),
+                   fp.flat._version, self._textctx_param_version(), self.precision)
+            if self._textctx_cache is not None and self._textctx_cache[0] == key:
+                return self._textctx_cache[1]
         L = _lib.lib()
         nbytes = L.hig_textctx_bytes(C.byref(dims), int(training))
         if nbytes < 0:
             raise RuntimeError("libhig: " + _lib.last_error())
-        buf = (self._pool.take("textctx_t", nbytes, xf_out.device) if training
-               else torch.empty(nbytes, dtype=torch.uint8, device=xf_out.device))
+        if training:
+            buf = self._pool.take("textctx_t", nbytes, xf_out.device)
+        elif use_cache:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=xf_out.device)
+        else:   # one reusable buffer: the caller's forward consumes it on the same stream before the next call
+            buf = self._pool.take("textctx_i", nbytes, xf_out.device)
+            self._pool.give("textctx_i", buf, xf_out.device)
         _lib.check(L.hig_text_context(C.byref(dims), fp.param_table(), _lib.ptr(xf_out), _lib.ptr(buf),
                                       int(training), _lib.stream_ptr()))
-        if not training:
+        if use_cache:
             self._textctx_cache = (key, buf, xf_out)  # keep xf_out alive so the key stays unique
         return buf
 

@@ -68,3 +68,9 @@ def broadcast_parameters(model, src=0, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         for p in model.parameters():
             dist.broadcast(p.data, src=src, group=group)
+
+
+def broadcast_flat(buf, src=0, group=None):
+    """One broadcast of a flat device buffer (all parameters of the fused step, or its Adam moments)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(buf, src=src, group=group)

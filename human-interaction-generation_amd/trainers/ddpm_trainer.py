@@ -1,11 +1,18 @@
-"""MI355X-native `DDPMTrainer`: the reference trainer's public surface
-(codes/trainers/ddpm_trainer.py:29-266) over the HIP denoiser.
+"""MI355X-native `DDPMTrainer`.
 
-Two ways to take a training step:
-  * `forward(batch)` + `update()` -- the reference's own sequence (autograd, torch Adam,
-    clip_grad_norm_), kept so existing driver code runs unchanged;
-  * `train_step_fused(...)` -- the MI355X path: explicit forward/backward launches, masked-MSE,
-    ONE flat-buffer RCCL all-reduce and a fused clip+Adam kernel, hipGraph-capturable.
+Public surface = what the reference's tools call on its trainer (codes/trainers/ddpm_trainer.py:29-266:
+`forward` / `backward_G` / `update`, `generate` / `generate_batch`, `save` / `load`, `train`, the attribute
+names and the checkpoint keys); the bodies are this project's own and are organised around ONE training step:
+
+  * `train_step_fused(...)`   explicit launches: q_sample -> [text head] -> denoiser forward -> masked MSE ->
+                              denoiser backward -> ONE flat-buffer all-reduce (RCCL) -> fused clip(0.5)+Adam;
+  * `train_step_captured(...)` the same step replayed as hipGraph(s);
+  * `forward(batch)` + `update()`  the reference's autograd / torch-Adam sequence, kept so driver code written
+                              against the reference runs unchanged (and as the parity anchor of the fused step).
+
+`opt.fused_step` makes `train()` take the fused step; its Adam moments then live in flat device buffers and are
+written to / restored from checkpoints in torch-Adam's own `state_dict` layout, so a checkpoint resumes under either
+step (and under the reference's trainer).
 """
 import time
 from collections import OrderedDict
@@ -19,129 +26,71 @@ from torch.nn.utils import clip_grad_norm_
 from .. import _lib
 from ..models.gaussian_diffusion import (GaussianDiffusion, LossType, ModelMeanType, ModelVarType,
                                          create_named_schedule_sampler, get_named_beta_schedule)
-from ..parallel import FlatGradAllReduce, ShardedSampler
+from ..parallel import FlatGradAllReduce, ShardedSampler, broadcast_flat
+
+GRAD_CLIP = 0.5                    # ddpm_trainer.py:61
+ADAM_BETAS, ADAM_EPS = (0.9, 0.999), 1e-8   # torch.optim.Adam defaults, ddpm_trainer.py:222
 
 
 def _core(encoder):
+    """The bare model under a DDP-style wrapper (the reference reaches for `.module` first, :116-119)."""
     return getattr(encoder, "module", encoder)
+
+
+def _dist_world():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+class _RunningMean:
+    """Sums per-key values (host floats or device scalars -- the latter without any host sync) and hands back
+    their means every `period` additions."""
+
+    def __init__(self, period):
+        self.period, self.n, self.acc = int(period), 0, OrderedDict()
+
+    def add(self, values):
+        for k, v in values.items():
+            self.acc[k] = self.acc[k] + v if k in self.acc else (v.clone() if torch.is_tensor(v) else v)
+        self.n += 1
+        if self.n < self.period:
+            return None
+        out = OrderedDict((k, float(v) / self.n) for k, v in self.acc.items())
+        self.n, self.acc = 0, OrderedDict()
+        return out
 
 
 class DDPMTrainer(object):
 
     def __init__(self, args, encoder):
-        self.opt = args
-        self.device = args.device
-        self.encoder = encoder
+        self.opt, self.device, self.encoder = args, args.device, encoder
         self.multi = False
         self.diffusion_steps = args.diffusion_steps
-        sampler = 'uniform'
-        beta_scheduler = 'linear'
-        betas = get_named_beta_schedule(beta_scheduler, self.diffusion_steps)
-        self.diffusion = GaussianDiffusion(
-            betas=betas,
-            model_mean_type=ModelMeanType.EPSILON,
-            model_var_type=ModelVarType.FIXED_SMALL,
-            loss_type=LossType.MSE
-        )
-        self.sampler = create_named_schedule_sampler(sampler, self.diffusion)
-        self.sampler_name = sampler
+        self.sampler_name = 'uniform'
+        # the one diffusion every reference tool builds: linear betas, eps-prediction, fixed small variance, MSE
+        self.diffusion = GaussianDiffusion(betas=get_named_beta_schedule('linear', self.diffusion_steps),
+                                           model_mean_type=ModelMeanType.EPSILON,
+                                           model_var_type=ModelVarType.FIXED_SMALL, loss_type=LossType.MSE)
+        self.sampler = create_named_schedule_sampler(self.sampler_name, self.diffusion)
         if args.is_train:
             self.mse_criterion = torch.nn.MSELoss(reduction='none')
-        self.to(self.device)
         self._fused = None
+        self.to(self.device)
 
+    # ---- small helpers the reference exposes as static methods ----------------------------------------------
     @staticmethod
     def zero_grad(opt_list):
-        for opt in opt_list:
-            opt.zero_grad()
+        any(o.zero_grad() for o in opt_list)
 
     @staticmethod
     def clip_norm(network_list):
-        for network in network_list:
-            clip_grad_norm_(network.parameters(), 0.5)
+        any(clip_grad_norm_(net.parameters(), GRAD_CLIP) is None for net in network_list)
 
     @staticmethod
     def step(opt_list):
-        for opt in opt_list:
-            opt.step()
-
-    def forward(self, batch_data, eval_mode=False):
-        """ddpm_trainer.py:97-119."""
-        caption, motions, m_lens = batch_data
-        motions = motions.detach().to(self.device).float()
-        self.caption = caption
-        self.motions = motions
-        x_start = motions
-        B, T = x_start.shape[:2]
-        cur_len = torch.LongTensor([min(T, int(m_len)) for m_len in m_lens]).to(self.device)
-        t, _ = self.sampler.sample(B, x_start.device)
-        output = self.diffusion.training_losses(
-            model=self.encoder,
-            x_start=x_start,
-            t=t,
-            model_kwargs={"text": caption, "length": cur_len}
-        )
-        self.real_noise = output['target']
-        self.fake_noise = output['pred']
-        self.src_mask = _core(self.encoder).generate_src_mask(T, cur_len).to(x_start.device)
-
-    def generate_batch(self, caption, m_lens, dim_pose):
-        """ddpm_trainer.py:121-150: text encoded once, then the (graph-captured) sampling loop."""
-        xf_proj, xf_out = _core(self.encoder).encode_text(caption, self.device)
-        B = len(caption)
-        T = min(int(m_lens.max()), _core(self.encoder).num_frames)
-        output = self.diffusion.p_sample_loop(
-            self.encoder,
-            (B, T, dim_pose),
-            clip_denoised=False,
-            progress=True,
-            model_kwargs={
-                'xf_proj': xf_proj,
-                'xf_out': xf_out,
-                'length': m_lens
-            })
-        return output
-
-    def generate(self, caption, m_lens, dim_pose, batch_size=1024):
-        """ddpm_trainer.py:152-170."""
-        N = len(caption)
-        cur_idx = 0
-        self.encoder.eval()
-        all_output = []
-        while cur_idx < N:
-            if cur_idx + batch_size >= N:
-                batch_caption = caption[cur_idx:]
-                batch_m_lens = m_lens[cur_idx:]
-            else:
-                batch_caption = caption[cur_idx: cur_idx + batch_size]
-                batch_m_lens = m_lens[cur_idx: cur_idx + batch_size]
-            output = self.generate_batch(batch_caption, batch_m_lens, dim_pose)
-            B = output.shape[0]
-            for i in range(B):
-                all_output.append(output[i])
-            cur_idx += batch_size
-        return all_output
-
-    def backward_G(self):
-        """ddpm_trainer.py:172-178."""
-        loss_mot_rec = self.mse_criterion(self.fake_noise, self.real_noise).mean(dim=-1)
-        loss_mot_rec = (loss_mot_rec * self.src_mask).sum() / self.src_mask.sum()
-        self.loss_mot_rec = loss_mot_rec
-        loss_logs = OrderedDict({})
-        loss_logs['loss_mot_rec'] = self.loss_mot_rec.item()
-        return loss_logs
-
-    def update(self):
-        """ddpm_trainer.py:180-187."""
-        self.zero_grad([self.opt_encoder])
-        loss_logs = self.backward_G()
-        self.loss_mot_rec.backward()
-        self.clip_norm([self.encoder])
-        self.step([self.opt_encoder])
-        return loss_logs
+        any(o.step() for o in opt_list)
 
     def to(self, device):
-        if self.opt.is_train:
+        if hasattr(self, "mse_criterion"):
             self.mse_criterion.to(device)
         self.encoder = self.encoder.to(device)
 
@@ -151,85 +100,227 @@ class DDPMTrainer(object):
     def eval_mode(self):
         self.encoder.eval()
 
+    # ---- batch staging shared by both step flavours ---------------------------------------------------------
+    def _stage_batch(self, batch_data):
+        """(captions, motions (B,T,F), m_lens) -> captions, x_start on the device (fp32), lengths clamped to T."""
+        caption, motions, m_lens = batch_data
+        x_start = motions.detach().to(self.device).float()
+        T = x_start.shape[1]
+        cur_len = torch.tensor([min(T, int(n)) for n in m_lens], dtype=torch.int64).to(self.device)
+        return caption, x_start, cur_len
+
+    # ---- the reference's step: forward() then update() --------------------------------------------------------
+    def forward(self, batch_data, eval_mode=False):
+        """Noises the batch at sampled timesteps and runs the denoiser (ddpm_trainer.py:97-119); leaves
+        `real_noise`, `fake_noise`, `src_mask` for `backward_G`."""
+        caption, x_start, cur_len = self._stage_batch(batch_data)
+        self.caption, self.motions = caption, x_start
+        t, _unit_weights = self.sampler.sample(x_start.shape[0], x_start.device)
+        terms = self.diffusion.training_losses(model=self.encoder, x_start=x_start, t=t,
+                                               model_kwargs=dict(text=caption, length=cur_len))
+        self.real_noise, self.fake_noise = terms['target'], terms['pred']
+        self.src_mask = _core(self.encoder).generate_src_mask(x_start.shape[1], cur_len).to(x_start.device)
+
+    def backward_G(self):
+        """Masked mean over valid frames of the per-frame feature-mean squared error (ddpm_trainer.py:172-178)."""
+        per_frame = self.mse_criterion(self.fake_noise, self.real_noise).mean(dim=-1)
+        self.loss_mot_rec = (per_frame * self.src_mask).sum() / self.src_mask.sum()
+        return OrderedDict(loss_mot_rec=self.loss_mot_rec.item())
+
+    def update(self):
+        """zero_grad -> loss -> backward -> clip_grad_norm_(0.5) -> Adam (ddpm_trainer.py:180-187)."""
+        self.zero_grad([self.opt_encoder])
+        logs = self.backward_G()
+        self.loss_mot_rec.backward()
+        self.clip_norm([self.encoder])
+        self.step([self.opt_encoder])
+        _core(self.encoder).params_changed()
+        return logs
+
+    # ---- sampling ----------------------------------------------------------------------------------------------
+    def generate_batch(self, caption, m_lens, dim_pose):
+        """One chunk of captions -> (B, T, dim_pose) samples: text encoded once, then the 1000-step loop (captured
+        as a hipGraph by GaussianDiffusion); T = longest requested length, capped at num_frames (:121-150)."""
+        core = _core(self.encoder)
+        xf_proj, xf_out = core.encode_text(caption, self.device)
+        T = min(int(m_lens.max()), core.num_frames)
+        return self.diffusion.p_sample_loop(self.encoder, (len(caption), T, dim_pose), clip_denoised=False,
+                                            progress=True,
+                                            model_kwargs=dict(xf_proj=xf_proj, xf_out=xf_out, length=m_lens))
+
+    def generate(self, caption, m_lens, dim_pose, batch_size=1024):
+        """All captions in chunks of `batch_size` -> python list of (T_chunk, dim_pose) tensors (:152-170)."""
+        self.encoder.eval()
+        samples = []
+        for lo in range(0, len(caption), batch_size):
+            hi = min(len(caption), lo + batch_size)
+            samples.extend(self.generate_batch(caption[lo:hi], m_lens[lo:hi], dim_pose).unbind(0))
+        return samples
+
+    # ---- checkpoints (keys: opt_encoder / ep / total_it / encoder, ddpm_trainer.py:200-218) ---------------------
+    def _torch_optimizer(self):
+        if not hasattr(self, "opt_encoder"):
+            self.opt_encoder = optim.Adam(self.encoder.parameters(), lr=self.opt.lr)
+        return self.opt_encoder
+
+    def _fused_param_slots(self):
+        """[(index in encoder.parameters(), flat offset, parameter)] for everything the fused Adam has stepped."""
+        fp = _core(self.encoder).flat_params()
+        index = {id(p): i for i, p in enumerate(self.encoder.parameters())}
+        covered = self._fused["covered"] if self._fused else 0
+        slots = zip(fp.params + fp.text_params, fp.offsets + fp.text_offsets)
+        return [(index[id(p)], off, p) for p, off in slots if off < covered and id(p) in index]
+
+    def _optimizer_state_dict(self):
+        """torch.optim.Adam.state_dict() of the optimizer that is really in use: when the fused step has run, its
+        flat moments / step counter are laid out as Adam's per-parameter `exp_avg` / `exp_avg_sq` / `step`."""
+        sd = self._torch_optimizer().state_dict()
+        st = self._fused
+        if st is None or int(st["step"].item()) == 0:
+            return sd
+        step = torch.tensor(float(st["step"].item()))
+        for idx, off, p in self._fused_param_slots():
+            n = p.numel()
+            sd['state'][idx] = {'step': step.clone(), 'exp_avg': st["m"][off:off + n].view(p.shape).clone(),
+                                'exp_avg_sq': st["v"][off:off + n].view(p.shape).clone()}
+        return sd
+
+    def _adopt_optimizer_state(self, sd):
+        """The inverse: Adam moments of a checkpoint into the fused step's flat buffers."""
+        st = self.fused_state()
+        fp = _core(self.encoder).flat_params()
+        index = {id(p): i for i, p in enumerate(self.encoder.parameters())}
+        steps, covered = [], 0
+        with torch.no_grad():
+            for p, off in zip(fp.params + fp.text_params, fp.offsets + fp.text_offsets):
+                ent = sd['state'].get(index.get(id(p)))
+                if ent is None:
+                    continue
+                n = p.numel()
+                st["m"][off:off + n].copy_(ent['exp_avg'].reshape(-1))
+                st["v"][off:off + n].copy_(ent['exp_avg_sq'].reshape(-1))
+                steps.append(int(float(ent['step'])))
+                covered = max(covered, off + n)
+            st["step"].fill_(max(steps) if steps else 0)
+        st["covered"] = max(st["covered"], covered)
+
     def save(self, file_name, ep, total_it):
-        """ddpm_trainer.py:200-211: keys opt_encoder / ep / total_it / encoder."""
-        state = {
-            'opt_encoder': self.opt_encoder.state_dict(),
-            'ep': ep,
-            'total_it': total_it,
-            'encoder': _core(self.encoder).state_dict(),
-        }
-        torch.save(state, file_name)
+        torch.save({'opt_encoder': self._optimizer_state_dict(), 'ep': ep, 'total_it': total_it,
+                    'encoder': _core(self.encoder).state_dict()}, file_name)
 
     def load(self, model_dir):
-        checkpoint = torch.load(model_dir, map_location=self.device)
+        ck = torch.load(model_dir, map_location=self.device)
+        core = _core(self.encoder)
+        core.load_state_dict(ck['encoder'], strict=True)
+        core.params_changed()
         if self.opt.is_train:
-            self.opt_encoder.load_state_dict(checkpoint['opt_encoder'])
-        _core(self.encoder).load_state_dict(checkpoint['encoder'], strict=True)
-        return checkpoint['ep'], checkpoint.get('total_it', 0)
+            self._torch_optimizer().load_state_dict(ck['opt_encoder'])
+            if getattr(self.opt, "fused_step", False) or self._fused is not None:
+                self._adopt_optimizer_state(ck['opt_encoder'])
+        return ck['ep'], ck.get('total_it', 0)
+
+    # ---- the epoch loop (ddpm_trainer.py:220-266: logging and checkpoint cadence) ----------------------------------
+    def _loader(self, dataset, rank, world_size):
+        sampler = ShardedSampler(len(dataset), rank, world_size, shuffle=True)
+        return torch.utils.data.DataLoader(dataset, batch_size=self.opt.batch_size, sampler=sampler, drop_last=True,
+                                           shuffle=False, num_workers=getattr(self.opt, "num_workers", 4))
+
+    def sync_replicas(self):
+        """Rank 0's trainable parameters (and fused Adam state) to every rank.  The fused step exchanges gradients
+        itself instead of wrapping the model in DDP, so the construction-time broadcast DDP would do
+        (tools/train.py:77-82) happens here.  Direct `train_step_fused` users with > 1 rank call this once first."""
+        if _dist_world() == 1:
+            return
+        core = _core(self.encoder)
+        fp = core.flat_params()
+        broadcast_flat(fp.flat)
+        in_flat = {id(p) for p in fp.params + fp.text_params}
+        for p in core.parameters():
+            if p.requires_grad and id(p) not in in_flat:
+                dist.broadcast(p.data, src=0)
+        if self._fused is not None:
+            for k in ("m", "v"):
+                broadcast_flat(self._fused[k])
+            stp = self._fused["step"].to(torch.int64)
+            dist.broadcast(stp, src=0)
+            self._fused["step"].copy_(stp.to(torch.int32))
+        core.params_changed()
+
+    def _one_step(self, batch_data, fused):
+        if fused:   # the loss stays on the device; `_RunningMean` only reads it back when it prints
+            return OrderedDict(loss_mot_rec=self.train_fused_batch(
+                batch_data, captured=getattr(self.opt, "fused_graph", False)))
+        self.forward(batch_data)
+        return self.update()
 
     def train(self, train_dataset, rank, world_size):
-        """ddpm_trainer.py:220-266 (epoch loop, logging, checkpoint cadence)."""
         self.to(self.device)
         self.opt_encoder = optim.Adam(self.encoder.parameters(), lr=self.opt.lr)
-        it = 0
-        cur_epoch = 0
-        if self.opt.is_continue:
-            model_dir = pjoin(self.opt.model_dir, 'latest.tar')
-            cur_epoch, it = self.load(model_dir)
-        start_time = time.time()
-        sampler = ShardedSampler(len(train_dataset), rank, world_size, shuffle=True)
-        train_loader = torch.utils.data.DataLoader(
-            train_dataset, batch_size=self.opt.batch_size, sampler=sampler, drop_last=True,
-            num_workers=getattr(self.opt, "num_workers", 4), shuffle=False)
-        logs = OrderedDict()
-        for epoch in range(cur_epoch, self.opt.num_epochs):
+        latest = pjoin(self.opt.model_dir, 'latest.tar')
+        first_epoch, it = self.load(latest) if self.opt.is_continue else (0, 0)
+        fused = bool(getattr(self.opt, "fused_step", False))
+        if fused:
+            self.sync_replicas()
+        loader = self._loader(train_dataset, rank, world_size)
+        meter, t_start = _RunningMean(self.opt.log_every), time.time()
+        for epoch in range(first_epoch, self.opt.num_epochs):
             self.train_mode()
-            for i, batch_data in enumerate(train_loader):
-                if getattr(self.opt, "fused_step", False):
-                    # MI355X path: the same update as forward() + update() as one fused step (`opt.fused_graph`:
-                    # replayed as a hipGraph -- no host work per step, but the backward's second stream overlaps less)
-                    log_dict = OrderedDict({'loss_mot_rec': self.train_fused_batch(
-                        batch_data, captured=getattr(self.opt, "fused_graph", False)).item()})
-                else:
-                    self.forward(batch_data)
-                    log_dict = self.update()
-                for k, v in log_dict.items():
-                    logs[k] = logs.get(k, 0) + v
+            for i, batch_data in enumerate(loader):
+                means = meter.add(self._one_step(batch_data, fused))
                 it += 1
-                if it % self.opt.log_every == 0 and rank == 0:
-                    mean_loss = OrderedDict({tag: value / self.opt.log_every for tag, value in logs.items()})
-                    logs = OrderedDict()
-                    msg = ' '.join('%s: %.4f' % kv for kv in mean_loss.items())
-                    print('epoch: %3d niter: %6d inner_iter: %4d %.0fs %s'
-                          % (epoch, it, i, time.time() - start_time, msg))
+                if means is not None and rank == 0:
+                    print('epoch: %3d niter: %6d inner_iter: %4d %.0fs %s' % (
+                        epoch, it, i, time.time() - t_start, ' '.join('%s: %.4f' % kv for kv in means.items())))
                 if it % self.opt.save_latest == 0 and rank == 0:
-                    self.save(pjoin(self.opt.model_dir, 'latest.tar'), epoch, it)
+                    self.save(latest, epoch, it)
             if rank == 0:
-                self.save(pjoin(self.opt.model_dir, 'latest.tar'), epoch, it)
-            if epoch % self.opt.save_every_e == 0 and rank == 0:
-                self.save(pjoin(self.opt.model_dir, 'ckpt_e%03d.tar' % (epoch)), epoch, total_it=it)
+                self.save(latest, epoch, it)
+                if epoch % self.opt.save_every_e == 0:
+                    self.save(pjoin(self.opt.model_dir, 'ckpt_e%03d.tar' % epoch), epoch, total_it=it)
 
     # ------------------------------------------------------------------------------------------
     # MI355X fused step
     # ------------------------------------------------------------------------------------------
     def fused_state(self):
-        """Flat Adam moments, loss / norm scalars and scratch for the fused step (lazy)."""
-        if self._fused is None:
-            core = _core(self.encoder)
-            fp = core.flat_params()
-            fp.ensure_grad()
+        """Flat Adam moments, device scalars (loss, grad norm, step, lr) and scratch of the fused step (lazy).
+        Tied to the model's flat parameter buffer: when `.to()` re-homes the parameters the moments move along and
+        every captured graph (which holds raw pointers into the old buffers) is dropped."""
+        core = _core(self.encoder)
+        fp = core.flat_params()
+        fp.ensure_grad()
+        ptrs = (fp.flat.data_ptr(), fp.grad.data_ptr())
+        st = self._fused
+        if st is not None and st["ptrs"] != ptrs:
             dev = fp.flat.device
-            self._fused = {
+            if st["m"].numel() == fp.flat.numel():
+                for k in ("m", "v", "scratch", "mse_scratch", "loss", "gnorm", "step", "lr"):
+                    st[k] = st[k].to(dev)
+                st["graphs"], st["ptrs"] = {}, ptrs
+            else:
+                st = self._fused = None
+        if st is None:
+            dev = fp.flat.device
+            st = self._fused = {
                 "m": torch.zeros_like(fp.flat), "v": torch.zeros_like(fp.flat),
                 "scratch": torch.zeros(_lib.NORM_BLOCKS, device=dev, dtype=torch.float32),
                 "mse_scratch": torch.zeros(_lib.NORM_BLOCKS, device=dev, dtype=torch.float32),
                 "loss": torch.zeros(1, device=dev, dtype=torch.float32),
                 "gnorm": torch.zeros(1, device=dev, dtype=torch.float32),
                 "step": torch.zeros(1, device=dev, dtype=torch.int32),
+                "lr": torch.full((1,), float(self.opt.lr), device=dev, dtype=torch.float32),
+                "lr_host": float(self.opt.lr), "covered": 0, "graphs": {}, "ptrs": ptrs,
                 "allreduce": FlatGradAllReduce(),
             }
-        return self._fused
+        return st
+
+    def _set_lr(self, lr):
+        """Learning rate of the next fused update: a DEVICE scalar the Adam kernel reads, so a captured step follows
+        an LR schedule without re-capture.  Written eagerly (never inside a capture), only when it changes."""
+        st = self.fused_state()
+        lr = float(self.opt.lr if lr is None else lr)
+        if lr != st["lr_host"]:
+            st["lr"].fill_(lr)
+            st["lr_host"] = lr
 
     def _text_forward(self, clip_out, eot):
         """Text head of the fused step: CLIP features (B, N, W) + EOT indices -> xf_proj, xf_out and the saved
@@ -268,13 +359,21 @@ class DDPMTrainer(object):
 
     def _fused_numel(self, with_text):
         """Floats of the flat buffers one fused step covers: the core, or core + text head."""
-        fp = _core(self.encoder).flat_params()
-        if with_text and not fp.text_params:
-            raise RuntimeError("this model's text head is not on the HIP path (text_head='torch', cap_id or an "
-                               "unsupported head dim): the fused step cannot train it")
+        core = _core(self.encoder)
+        fp = core.flat_params()
+        if with_text:
+            if not fp.text_params:
+                raise RuntimeError("this model's text head is not on the HIP path (text_head='torch', cap_id or an "
+                                   "unsupported head dim): the fused step cannot train it")
+            clip_net = getattr(core, "clip", None)
+            if clip_net is not None and any(p.requires_grad for p in clip_net.parameters()):
+                # MotionInteractionTransformer(no_clip=True) trains the CLIP tower through forward()/update()
+                # (interaction_transformer.py:424-427); the fused step runs CLIP frozen, outside the step
+                raise NotImplementedError("the CLIP text tower is trainable (no_clip=True): the fused step would "
+                                          "silently freeze it -- use forward() + update() for this configuration")
         return fp.numel if with_text else fp.core_numel
 
-    def _fused_clip_adam(self, world, lr, with_text=False):
+    def _fused_clip_adam(self, world, with_text=False):
         """g /= world; clip_grad_norm_(0.5); Adam -- one norm pass + one update pass over the flat buffers."""
         core = _core(self.encoder)
         L = _lib.lib()
@@ -283,11 +382,12 @@ class DDPMTrainer(object):
         n = self._fused_numel(with_text)
         _lib.check(L.hig_sumsq_partial(_lib.ptr(fp.grad), n, 1.0 / world, _lib.ptr(st["scratch"]),
                                        _lib.stream_ptr()))
-        _lib.check(L.hig_clip_adam(_lib.ptr(fp.flat), _lib.ptr(fp.grad), _lib.ptr(st["m"]), _lib.ptr(st["v"]),
-                                   n, float(lr if lr is not None else self.opt.lr), 0.9, 0.999, 1e-8, 0.5,
-                                   1.0 / world, _lib.ptr(st["scratch"]), _lib.ptr(st["gnorm"]),
-                                   _lib.ptr(st["step"]), _lib.stream_ptr()))
-        core._textctx_cache = None  # parameters changed under the cached text context
+        _lib.check(L.hig_clip_adam_lrdev(_lib.ptr(fp.flat), _lib.ptr(fp.grad), _lib.ptr(st["m"]), _lib.ptr(st["v"]),
+                                         n, st["lr_host"], _lib.ptr(st["lr"]), ADAM_BETAS[0], ADAM_BETAS[1], ADAM_EPS,
+                                         GRAD_CLIP, 1.0 / world, _lib.ptr(st["scratch"]), _lib.ptr(st["gnorm"]),
+                                         _lib.ptr(st["step"]), _lib.stream_ptr()))
+        st["covered"] = max(st["covered"], n)
+        core.params_changed()
 
     def train_step_fused(self, x_start, t, length, xf_proj=None, xf_out=None, noise=None, lr=None, clip_out=None,
                          eot=None):
@@ -297,13 +397,15 @@ class DDPMTrainer(object):
         With text embeddings (`xf_proj`, `xf_out`) the denoiser-core parameters are updated; with CLIP features
         (`clip_out` (B, N, W) batch-first, `eot` (B,), see MotionTransformer._clip_features) the text head runs
         inside the step and EVERY trainable parameter is updated -- the reference's full update.
+        With more than one rank the replicas must start identical: call `sync_replicas()` once (train() does).
         No host synchronisation: the loss stays on the device (`fused_state()['loss']`)."""
         st = self.fused_state()
         with_text = clip_out is not None
         n = self._fused_numel(with_text)
+        self._set_lr(lr)
         self._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise, clip_out=clip_out, eot=eot)
         world = st["allreduce"](_core(self.encoder).flat_params().grad[:n])      # sum over ranks (RCCL, xGMI)
-        self._fused_clip_adam(world, lr, with_text)
+        self._fused_clip_adam(world, with_text)
         return st["loss"]
 
     def train_fused_batch(self, batch_data, captured=False, noise=None):
@@ -311,14 +413,11 @@ class DDPMTrainer(object):
         trainable parameter: batch -> device, t ~ sampler, CLIP features -> train_step_fused (eager launches: measured
         faster than the replayed graph at every batch size since the backward runs on two streams), or
         train_step_captured with captured=True (two graph launches per step, no other host work)."""
-        caption, motions, m_lens = batch_data
-        x_start = motions.detach().to(self.device).float().contiguous()
-        B, T = x_start.shape[:2]
-        cur_len = torch.LongTensor([min(T, int(m_len)) for m_len in m_lens]).to(self.device)
-        t, _ = self.sampler.sample(B, x_start.device)
+        caption, x_start, cur_len = self._stage_batch(batch_data)
+        t, _ = self.sampler.sample(x_start.shape[0], x_start.device)
         clip_out, eot = self.clip_inputs(caption)
         step = self.train_step_captured if captured else self.train_step_fused
-        return step(x_start, t, cur_len, noise=noise, clip_out=clip_out, eot=eot)
+        return step(x_start.contiguous(), t, cur_len, noise=noise, clip_out=clip_out, eot=eot)
 
     def clip_inputs(self, caption):
         """Captions -> (clip_out (B, N, W) batch-first fp32, eot (B,)) for `train_step_fused(clip_out=...)`: the
@@ -334,15 +433,18 @@ class DDPMTrainer(object):
         the same stream (world == 1: A and B are one graph).  Inputs are copied into static device buffers, so
         the host cost per step is two graph launches whatever the ~600 kernels inside; `t` arrives from the
         host sampler through the same staging copy (the reference draws it with numpy,
-        gaussian_diffusion.py:47-62).  Text inputs as in `train_step_fused`: embeddings, or CLIP features."""
+        gaussian_diffusion.py:47-62), the learning rate through a device scalar (`_set_lr`).  A graph is keyed on
+        the shapes AND on the flat parameter / gradient buffers it was captured against.  Text inputs as in
+        `train_step_fused`: embeddings, or CLIP features."""
         st = self.fused_state()
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        world = _dist_world()
         with_text = clip_out is not None
         text_in = (clip_out, eot) if with_text else (xf_proj, xf_out)
         n = self._fused_numel(with_text)
+        self._set_lr(lr)
         key = (tuple(x_start.shape), tuple(text_in[0].shape), tuple(text_in[1].shape), with_text, noise is None,
-               world, lr)
-        cap = st.setdefault("graphs", {}).get(key)
+               world, st["ptrs"])
+        cap = st["graphs"].get(key)
         if cap is None:
             static = {"x0": x_start.clone(), "t": t.clone(), "length": length.clone(),
                       "ta": text_in[0].clone(), "tb": text_in[1].clone(),
@@ -360,30 +462,31 @@ class DDPMTrainer(object):
             # it runs a real step, so restore parameters / moments / step counter afterwards
             core = _core(self.encoder)
             fp = core.flat_params()
-            keep = (fp.flat.clone(), st["m"].clone(), st["v"].clone(), st["step"].clone())
+            keep = (fp.flat.clone(), st["m"].clone(), st["v"].clone(), st["step"].clone(), st["covered"])
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 part_a()
-                self._fused_clip_adam(1, lr, with_text)
+                self._fused_clip_adam(1, with_text)
             torch.cuda.current_stream().wait_stream(s)
             with torch.no_grad():
                 fp.flat.copy_(keep[0])
                 st["m"].copy_(keep[1])
                 st["v"].copy_(keep[2])
                 st["step"].copy_(keep[3])
+            st["covered"] = keep[4]
             # thread_local: other threads (the RCCL watchdog polls its events) may call into HIP while we capture
             ga, gb = torch.cuda.CUDAGraph(), None
             if world == 1:
                 with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                     part_a()
-                    self._fused_clip_adam(1, lr, with_text)
+                    self._fused_clip_adam(1, with_text)
             else:
                 with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                     part_a()
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
-                    self._fused_clip_adam(world, lr, with_text)
+                    self._fused_clip_adam(world, with_text)
             cap = st["graphs"][key] = (static, ga, gb)
         static, ga, gb = cap
         with torch.no_grad():
@@ -398,5 +501,6 @@ class DDPMTrainer(object):
         if gb is not None:
             st["allreduce"](_core(self.encoder).flat_params().grad[:n])
             gb.replay()
-        _core(self.encoder)._textctx_cache = None
+        st["covered"] = max(st["covered"], n)
+        _core(self.encoder).params_changed()
         return st["loss"]

@@ -11,6 +11,7 @@
  *   - The caller owns every buffer.  The library allocates no device memory, frees nothing,
  *     keeps no reference past return.  All device pointers must be valid on the current HIP
  *     device (hipSetDevice is the caller's job).
+ *   - No global mutable state except what hig_shutdown() releases (the per-thread weight-gradient stream below).
  *   - Every launch is ordered through the `stream` argument (a hipStream_t passed as void*): on it,
  *     or -- hig_denoiser_bwd's weight gradients only -- on a library-owned stream forked from and
  *     joined back into it with events.  No host synchronisation, device allocation, blocking copy or
@@ -453,6 +454,16 @@ int hig_sumsq_partial(const float* g, int64_t n, float inv_world, float* scratch
 int hig_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
                   float b2, float eps, float max_norm, float inv_world, const float* scratch,
                   float* gnorm_out, int32_t* step_dev, hig_stream_t s);
+/* The same step with the learning rate read from device memory (lr_dev[0]) when lr_dev != NULL: a captured hipGraph
+ * of the training step then follows an LR schedule without being re-captured (the host writes the scalar before each
+ * replay). */
+int hig_clip_adam_lrdev(float* p, const float* g, float* m, float* v, int64_t n, float lr, const float* lr_dev,
+                        float b1, float b2, float eps, float max_norm, float inv_world, const float* scratch,
+                        float* gnorm_out, int32_t* step_dev, hig_stream_t s);
+/* Releases what the library itself owns on the calling host thread: the second stream and the events
+ * hig_denoiser_bwd forks its weight gradients onto (created lazily, one set per host thread and device).  Call it
+ * from the thread that ran the backward, with no launch of this library in flight; later calls re-create them. */
+int hig_shutdown(void);
 
 #ifdef __cplusplus
 }
