@@ -32,7 +32,7 @@ SYMBOLS = (
     "hig_text_head_workspace_bytes", "hig_text_head_bwd_workspace_bytes", "hig_text_head_fwd", "hig_text_head_bwd",
     "hig_layernorm", "hig_gather_rows", "hig_scatter_add_rows", "hig_gather_frames", "hig_recover_joints", "hig_transpose_batch", "hig_linattn_ctx_scratch_floats", "hig_pair_mse",
     "hig_fullattn_fwd_kpad", "hig_eval_encoder_workspace_bytes", "hig_eval_encoder_fwd",
-    "hig_clip_adam_lrdev", "hig_shutdown",
+    "hig_clip_adam_lrdev", "hig_shutdown", "hig_gemm_split", "hig_gemm_split_scratch_floats",
 )
 
 
@@ -128,6 +128,9 @@ def lib():
         L.hig_clip_adam.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, vp, vp, vp]
         L.hig_clip_adam_lrdev.argtypes = [vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, f32, vp, vp, vp, vp]
         L.hig_shutdown.argtypes = []
+        L.hig_gemm_split.argtypes = [C.POINTER(GemmDesc), i32, vp, i64, vp]
+        L.hig_gemm_split_scratch_floats.restype = i64
+        L.hig_gemm_split_scratch_floats.argtypes = [C.POINTER(GemmDesc), i32]
         L.hig_text_head_workspace_bytes.restype = i64
         L.hig_text_head_workspace_bytes.argtypes = [C.POINTER(TextDims), C.c_int]
         L.hig_text_head_bwd_workspace_bytes.restype = i64

@@ -973,3 +973,23 @@ extern "C" int hig_gemm(const hig_gemm_desc* g, hig_stream_t stream) {
               "hig_gemm: unknown prec %d", g->prec);
   return hig_gemm_launch(*g, 1, nullptr, hig_stream(stream));
 }
+
+// Weight-gradient form of hig_gemm as the backward launches it: the reduce range split over `splits` partial outputs in
+// `slabs` (+ the per-split column sums of X behind each slab when g->xcolsum is set) and the deterministic slab
+// reduction.  splits == 0 asks for the library's own rule (wgrad_splits: tiles x splits fills the chip).
+extern "C" int64_t hig_gemm_split_scratch_floats(const hig_gemm_desc* g, int32_t splits) {
+  if (!g || g->I <= 0 || g->J <= 0) return -1;
+  const int64_t per = (int64_t)g->I * g->J + g->I;
+  const int64_t cap = splits > 0 ? splits : (g->R / 256 > 1 ? g->R / 256 : 1);
+  return per * cap;
+}
+extern "C" int hig_gemm_split(const hig_gemm_desc* g, int32_t splits, float* slabs, int64_t slab_floats,
+                              hig_stream_t stream) {
+  HIG_REQUIRE(g && slabs && splits >= 0, "hig_gemm_split: bad arguments");
+  HIG_REQUIRE(g->prec == HIG_PREC_F32 || g->prec == HIG_PREC_BF16X3 || g->prec == HIG_PREC_BF16,
+              "hig_gemm_split: unknown prec %d", g->prec);
+  int s = splits > 0 ? splits : wgrad_splits(g->I, g->J, g->R, slab_floats, g->prec);
+  HIG_REQUIRE((int64_t)s * ((int64_t)g->I * g->J + g->I) <= slab_floats, "hig_gemm_split: %d splits need %lld scratch floats, got %lld",
+              s, (long long)((int64_t)s * ((int64_t)g->I * g->J + g->I)), (long long)slab_floats);
+  return hig_gemm_launch(*g, s, slabs, hig_stream(stream));
+}

@@ -320,6 +320,12 @@ typedef struct hig_gemm_desc {
                                         bias gradient that goes with a weight gradient dW = dC^T . act (X = dC) */
 } hig_gemm_desc;
 int hig_gemm(const hig_gemm_desc* g, hig_stream_t stream);
+/* The same contraction with the reduce range split over `splits` partial outputs in `slabs` and a deterministic
+ * (fixed-order, no float atomics) slab reduction: how hig_denoiser_bwd runs its weight gradients dW = dC^T . act over
+ * the M = B*T rows (autograd of nn.Linear).  EPI_NONE, dense C (ldc == J), I*J % 4 == 0.  splits == 0: the
+ * library's own rule (tiles x splits fills the chip).  slabs: >= hig_gemm_split_scratch_floats(g, splits) floats. */
+int64_t hig_gemm_split_scratch_floats(const hig_gemm_desc* g, int32_t splits);
+int hig_gemm_split(const hig_gemm_desc* g, int32_t splits, float* slabs, int64_t slab_floats, hig_stream_t stream);
 
 /* Row statistics for LayerNorm: stats[m] = (mean, rstd) of x[m, :n], eps = 1e-5, biased var. */
 int hig_rowstats(const float* x, int64_t ldx, int64_t rows, int32_t n, float* stats,

@@ -1,0 +1,162 @@
+"""Parity at BASELINE.json's FULL sizes on the MI355X (configs 2 and 3): the backward at B=64, T=196, d=512, L=8
+against the CPU oracle's autograd, the weight-gradient GEMM at the product's own split-R geometry, and the
+hipGraph-captured 1000-step sampling loop at B=32 against the eager loop.  Tolerances are written where they apply;
+the gate is north_star's 1e-3 relative fp32."""
+import ctypes as C
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import hig_amd  # noqa: E402
+from hig_amd import _lib  # noqa: E402
+from hig_amd.models import gaussian_diffusion as gdm  # noqa: E402
+from oracle import denoiser_ref as R  # noqa: E402
+from oracle import diffusion_ref as D  # noqa: E402
+from oracle import fill  # noqa: E402
+
+DEV = "cuda"
+CONFIG2 = dict(fill.CASES["width"], B=64, lengths=tuple([196] * 40 + list(range(60, 180, 5))),
+               t=tuple(int(v) for v in np.linspace(0, 999, 64)))
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def build(c, **kw):
+    m = hig_amd.MotionTransformer(input_feats=c["F"], num_frames=c["num_frames"], latent_dim=c["d"],
+                                  ff_size=c["ff"], num_layers=c["L"], num_heads=c["H"],
+                                  text_latent_dim=c["Lt"], **kw)
+    m.load_state_dict(fill.fill_state_dict(m.state_dict()), strict=True)
+    return m.to(DEV)
+
+
+def test_config2_size_backward_against_oracle_autograd():
+    """B=64, T=196, d=512, L=8, ragged lengths: loss = masked MSE against a fixed target (the training loss,
+    ddpm_trainer.py:172-178); every gradient the product computes at this size comes from 16-32 split-R slabs on two
+    streams.  Checked against torch autograd of the fp32 CPU oracle: global gradient norm, input gradients and named
+    parameter gradients from every kind of kernel (row-kernel LayerNorm grads, few-row emb GEMMs, split-R wgrads)."""
+    c = CONFIG2
+    m = build(c).train()
+    inp = fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"])
+    gi = {k: v.to(DEV) for k, v in inp.items()}
+    target = fill.tensor_for("full.target", inp["x"].shape) * 10.0
+    x, xp, xo = (gi[k].clone().requires_grad_(True) for k in ("x", "xf_proj", "xf_out"))
+    out = m(x, gi["t"], length=gi["length"], xf_proj=xp, xf_out=xo)
+    mask = m.generate_src_mask(c["T"], gi["length"]).to(DEV)
+    loss = (((out - target.to(DEV)) ** 2).mean(-1) * mask).sum() / mask.sum()
+    loss.backward()
+
+    names = fill.core_param_shapes(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"])
+    p = {k: v.clone().requires_grad_(True) for k, v in
+         fill.core_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"]).items()}
+    xr, xpr, xor_ = (inp[k].clone().requires_grad_(True) for k in ("x", "xf_proj", "xf_out"))
+    ref = R.denoiser_forward(p, xr, inp["t"], inp["length"], xpr, xor_, c["H"], c["L"])
+    ref_loss = D.masked_mse(ref, target, R.src_mask(c["T"], inp["length"]))
+    ref_loss.backward()
+
+    assert rel(out, ref) < 5e-5
+    assert abs(loss.item() - ref_loss.item()) < 1e-5 * abs(ref_loss.item())
+    assert rel(x.grad, xr.grad) < 1e-3 and rel(xp.grad, xpr.grad) < 1e-3 and rel(xo.grad, xor_.grad) < 1e-3
+    named = dict(m.named_parameters())
+    gn = torch.sqrt(sum((named[k].grad.double() ** 2).sum() for k in names)).item()
+    gn_ref = torch.sqrt(sum((p[k].grad.double() ** 2).sum() for k in names)).item()
+    assert abs(gn - gn_ref) < 2e-4 * gn_ref, (gn, gn_ref)
+    checked = ("temporal_decoder_blocks.0.sa_block.proj_out.emb_layers.1.weight",    # few-row GEMM, 200 of 347 MB
+               "temporal_decoder_blocks.7.ffn.proj_out.emb_layers.1.bias",
+               "temporal_decoder_blocks.3.sa_block.key.weight",                       # split-R wgrad, fused q/k/v
+               "temporal_decoder_blocks.5.ca_block.value.weight",                     # text-side wgrad (M = B*77)
+               "temporal_decoder_blocks.2.ffn.linear1.weight", "temporal_decoder_blocks.6.ffn.linear2.weight",
+               "temporal_decoder_blocks.4.ca_block.proj_out.out_layers.2.weight",
+               "temporal_decoder_blocks.1.sa_block.norm.weight", "temporal_decoder_blocks.7.ca_block.text_norm.bias",
+               "temporal_decoder_blocks.0.ffn.linear1.bias", "time_embed.2.weight", "joint_embed.weight",
+               "sequence_embedding", "out.weight", "out.bias")
+    worst = max((rel(named[k].grad, p[k].grad), k) for k in checked)
+    assert worst[0] < 1e-3, worst                     # the north-star gate
+    assert worst[0] < 3e-4, worst                     # what fp32 accumulation over 12 544 rows delivers
+    # every parameter gradient, loosely (catches a tensor that was never written)
+    all_worst = max((rel(named[k].grad, p[k].grad), k) for k in names)
+    assert all_worst[0] < 2e-3, all_worst
+
+
+@pytest.mark.parametrize("I,J,R,splits", [(1024, 512, 12544, 0), (1536, 512, 12544, 0), (512, 512, 12544, 7),
+                                          (512, 256, 4928, 0)])
+def test_wgrad_split_geometry_of_the_product(I, J, R, splits):
+    """The weight-gradient GEMM exactly as hig_denoiser_bwd launches it at config 2: dW (I x J) = dC^T . act over
+    R = 12 544 rows (R = 4 928 for the text side), reduce range split into slabs by the library's own rule (or a forced
+    odd count), slab reduction, bias gradient (column sums of dC) from the same pass.  fp64 reference."""
+    g = torch.Generator().manual_seed(I + J + R)
+    X = torch.randn(R, I, generator=g)
+    Y = torch.randn(R, J, generator=g)
+    Xd, Yd = X.to(DEV), Y.to(DEV)
+    out = torch.full((I, J), float("nan"), device=DEV)
+    xs = torch.full((I,), float("nan"), device=DEV)
+    d = _lib.GemmDesc()
+    d.X, d.ldx, d.x_rs, d.Y, d.ldy, d.y_rs = Xd.data_ptr(), I, 1, Yd.data_ptr(), J, 1
+    d.C, d.ldc, d.I, d.J, d.R = out.data_ptr(), J, I, J, R
+    d.xf, d.epi, d.prec = _lib.XF_NONE, _lib.EPI_NONE, _lib.PREC_F32
+    d.xcolsum = xs.data_ptr()
+    L = _lib.lib()
+    n = L.hig_gemm_split_scratch_floats(C.byref(d), splits)
+    assert n > 0
+    slabs = torch.full((n,), float("nan"), device=DEV)
+    _lib.check(L.hig_gemm_split(C.byref(d), splits, _lib.ptr(slabs), n, _lib.stream_ptr()))
+    ref = X.double().t() @ Y.double()
+    assert rel(out, ref) < 3e-6
+    assert ((out.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 2e-5
+    assert rel(xs, X.double().sum(0)) < 3e-6
+    first = out.clone()
+    _lib.check(L.hig_gemm_split(C.byref(d), splits, _lib.ptr(slabs), n, _lib.stream_ptr()))
+    assert torch.equal(first, out)                     # fixed-order slab reduction: bitwise reproducible
+    with pytest.raises(RuntimeError, match="scratch"):
+        _lib.check(L.hig_gemm_split(C.byref(d), 4, _lib.ptr(slabs), 16, _lib.stream_ptr()))
+
+
+def _diffusion(n):
+    return hig_amd.GaussianDiffusion(betas=gdm.get_named_beta_schedule("linear", n),
+                                     model_mean_type=gdm.ModelMeanType.EPSILON,
+                                     model_var_type=gdm.ModelVarType.FIXED_SMALL, loss_type=gdm.LossType.MSE)
+
+
+def _zero_noise_loop(m, gd, use_graph, x0, kw):
+    gd.use_hip_graph, gd._debug_zero_noise = use_graph, True
+    old = gdm.th
+    if not use_graph:
+        proxy = types.SimpleNamespace(**{k: getattr(torch, k) for k in dir(torch) if not k.startswith("__")})
+        proxy.randn_like = lambda x, **_: torch.zeros_like(x)
+        gdm.th = proxy
+    try:
+        return gd.p_sample_loop(m, x0.shape, noise=x0.clone(), clip_denoised=False, model_kwargs=kw)
+    finally:
+        gdm.th = old
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_config3_captured_1000_step_loop_equals_eager_loop(mode):
+    """BASELINE config 3: the 1000-step p_sample_loop at B=32, T=196 on the config-2 model, captured as ONE hipGraph
+    replayed 1000 times, against the eager loop (one launch sequence per step, fresh `t` tensor from the host like
+    gaussian_diffusion.py:718-769) with the noise draws zeroed on both sides: same kernels, same order, so the two
+    must agree to rounding, and stay finite over the whole chain."""
+    c = dict(fill.CASES["width"], B=32)
+    m = build(c, precision=mode).eval()
+    with torch.no_grad():       # a random eps-network fed back 1000 times: keep its gain small so the chain stays in range
+        m.out.weight.mul_(0.05)
+        m.out.bias.mul_(0.05)
+    g = torch.Generator().manual_seed(11)
+    kw = {"xf_proj": torch.randn(32, 4 * c["d"], generator=g).to(DEV),
+          "xf_out": torch.randn(32, c["N"], c["Lt"], generator=g).to(DEV),
+          "length": torch.tensor([196] * 20 + list(range(100, 196, 8)), device=DEV)}
+    x0 = torch.randn(32, 196, c["F"], generator=g).to(DEV)
+    eager = _zero_noise_loop(m, _diffusion(1000), False, x0, kw)
+    graph = _zero_noise_loop(m, _diffusion(1000), True, x0, kw)
+    assert torch.isfinite(graph).all() and torch.isfinite(eager).all()
+    assert rel(graph, eager) < 1e-5
+    # with real noise every replay draws fresh noise (Philox offsets advance under replay)
+    gd = _diffusion(1000)
+    a = gd.p_sample_loop(m, x0.shape, noise=x0.clone(), clip_denoised=False, model_kwargs=kw)
+    assert torch.isfinite(a).all() and rel(a, graph) > 1e-3
