@@ -462,7 +462,7 @@ def main():
                                                  model_var_type=gdm.ModelVarType.FIXED_SMALL,
                                                  loss_type=gdm.LossType.MSE)
 
-            gd, gd_warm = diffusion(nst), diffusion(8)
+            gd, gd_warm = diffusion(nst), diffusion(50)
             Bs = 32
             kw = {"xf_proj": inp["xf_proj"][:Bs].contiguous(), "xf_out": inp["xf_out"][:Bs].contiguous(),
                   "length": inp["length"][:Bs].contiguous()}

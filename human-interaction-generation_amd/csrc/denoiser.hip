@@ -55,7 +55,7 @@ __global__ void tok0_kernel(float* __restrict__ buf, int64_t sample_stride, int 
 
 
 struct Dims {
-  int B, T, F, d, H, ff, L, N, Lt, nf, hd, E, prec, full, two, nsty;
+  int B, T, F, d, H, ff, L, N, Lt, nf, hd, E, prec, full, two, nsty, bf16;
   int64_t M, Mt;
 };
 
@@ -92,6 +92,16 @@ int check_dims(const hig_dims* p, Dims& D) {
   }
   D.M = (int64_t)D.B * D.T;
   D.Mt = (int64_t)D.B * D.N;
+  HIG_REQUIRE(p->storage == HIG_STORE_F32 || p->storage == HIG_STORE_BF16, "hig_dims: unknown storage=%d", p->storage);
+  D.bf16 = p->storage == HIG_STORE_BF16;
+  if (D.bf16) {
+    if (D.full || D.two)
+      return hig_set_error(HIG_EUNSUPPORTED, "hig: bf16 storage is built for the single-person linear-attention model");
+    if (D.hd != 64 && D.hd != 128)
+      return hig_set_error(HIG_EUNSUPPORTED, "hig: bf16 storage needs head dim 64 or 128 (got %d)", D.hd);
+    if (D.d % 32 || D.ff % 32 || D.Lt % 32)
+      return hig_set_error(HIG_EUNSUPPORTED, "hig: bf16 storage needs d, ff, Lt multiples of 32 (got %d, %d, %d)", D.d, D.ff, D.Lt);
+  }
   return HIG_OK;
 }
 
@@ -254,19 +264,32 @@ inline float* GL(void* const* t, int l, int idx) {
 
 }  // namespace
 
+namespace {
+int64_t fwd16_total(const Dims& D);
+int64_t text16_total(const Dims& D);
+int bf16_inference_only(const Dims& D, int training) {
+  if (D.bf16 && training) {
+    hig_set_error(HIG_EUNSUPPORTED, "hig: bf16 storage is inference-only (train with fp32 storage)");
+    return 1;
+  }
+  return 0;
+}
+}  // namespace
 extern "C" int64_t hig_workspace_bytes(const hig_dims* dims, int training) {
   Dims D;
-  if (check_dims(dims, D) != HIG_OK) return -1;
+  if (check_dims(dims, D) != HIG_OK || bf16_inference_only(D, training)) return -1;
+  if (D.bf16) return fwd16_total(D);
   return fwd_layout(D, training).total * 4;
 }
 extern "C" int64_t hig_textctx_bytes(const hig_dims* dims, int training) {
   Dims D;
-  if (check_dims(dims, D) != HIG_OK) return -1;
+  if (check_dims(dims, D) != HIG_OK || bf16_inference_only(D, training)) return -1;
+  if (D.bf16) return text16_total(D);
   return text_layout(D, training).total * 4;
 }
 extern "C" int64_t hig_bwd_workspace_bytes(const hig_dims* dims) {
   Dims D;
-  if (check_dims(dims, D) != HIG_OK) return -1;
+  if (check_dims(dims, D) != HIG_OK || bf16_inference_only(D, 1)) return -1;
   return bwd_layout(D).total * 4;
 }
 
@@ -275,6 +298,7 @@ extern "C" int hig_text_context(const hig_dims* dims, const void* const* params,
   Dims D;
   HIG_TRY(check_dims(dims, D));
   HIG_REQUIRE(params && xf_out && textctx, "hig_text_context: null argument");
+  HIG_REQUIRE(!D.bf16, "hig_text_context: bf16 storage goes through hig_text_context_bf16");
   const TextLayout tl = text_layout(D, training);
   float* base = static_cast<float*>(textctx);
   hipStream_t st = hig_stream(stream);
@@ -303,6 +327,7 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
   Dims D;
   HIG_TRY(check_dims(dims, D));
   HIG_REQUIRE(params && x && t && xf_proj && textctx && out && workspace, "hig_denoiser_fwd: null argument");
+  HIG_REQUIRE(!D.bf16, "hig_denoiser_fwd: bf16 storage goes through hig_denoiser_fwd_bf16");
   const FwdLayout w = fwd_layout(D, training);
   const TextLayout tl = text_layout(D, training);
   float* ws = static_cast<float*>(workspace);
@@ -426,6 +451,188 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
     HIG_TRY(hig_gemm_launch(G(hin, (int64_t)D.T * d, 0, P(params, HIG_P_OUT2_W), d, 0, out, (int64_t)D.T * D.F, D.B, D.F, d)
                                 .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT2_B)).g, 1, nullptr, st));
   return HIG_OK;
+}
+
+// ==========================================================================================================
+// bf16-storage forward (hig_dims.storage == HIG_STORE_BF16): the same launch sequence over bf16 activations.
+// Byte layouts (256-byte granules).  Inference only: one layer's buffers serve every layer, the residual stream `h`
+// is updated in place by the stylization-out GEMMs (each thread reads and writes its own 8 columns).
+// ==========================================================================================================
+namespace {
+
+inline int64_t alb(int64_t bytes) { return (bytes + 255) & ~(int64_t)255; }
+
+struct Fwd16Layout {
+  int64_t te32, te16, teh16, semb16, ss, h32, h, xn, qkv, A1, kst1, cscr, y, a, qc, f1, total;
+};
+Fwd16Layout fwd16_layout(const Dims& D) {
+  Fwd16Layout w;
+  int64_t o = 0;
+  auto take = [&](int64_t n) { int64_t r = o; o += alb(n); return r; };
+  w.te32 = take((int64_t)D.B * D.d * 4);
+  w.te16 = take((int64_t)D.B * D.d * 2);
+  w.teh16 = take((int64_t)D.B * D.E * 2);
+  w.semb16 = take((int64_t)D.B * D.E * 2);
+  w.ss = take((int64_t)D.B * D.nsty * D.L * 2 * D.d * 4);
+  w.h32 = take(D.M * D.d * 4);          // joint_embed output (fp32 GEMM over the F-wide, unaligned pose rows)
+  w.h = take(D.M * D.d * 2);
+  w.xn = take(D.M * D.d * 2);
+  w.qkv = take(D.M * 3 * D.d * 2);
+  w.A1 = take((int64_t)D.B * D.H * D.hd * D.hd * 4);
+  w.kst1 = take((int64_t)D.B * D.d * 2 * 4);
+  w.cscr = take(hig_linattn_ctx_scratch_floats(D.B, D.T, D.H, D.hd) * 4);
+  w.y = take(D.M * D.d * 2);
+  w.a = take(D.M * D.d * 2);
+  w.qc = take(D.M * D.d * 2);
+  w.f1 = take(D.M * D.ff * 2);
+  w.total = o;
+  return w;
+}
+
+struct Text16Layout {
+  int64_t xfn, kv, cscr, layer0, lstride, Ac, kstc, total;
+};
+Text16Layout text16_layout(const Dims& D) {
+  Text16Layout t;
+  int64_t o = 0;
+  auto take = [&](int64_t n) { int64_t r = o; o += alb(n); return r; };
+  t.xfn = take(D.Mt * D.Lt * 2);
+  t.kv = take(D.Mt * 2 * D.d * 2);
+  t.cscr = take(hig_linattn_ctx_scratch_floats(D.B, D.N, D.H, D.hd) * 4);
+  t.layer0 = o;
+  o = 0;
+  t.Ac = take((int64_t)D.B * D.H * D.hd * D.hd * 4);
+  t.kstc = take((int64_t)D.B * D.d * 2 * 4);
+  t.lstride = o;
+  t.total = t.layer0 + t.lstride * D.L;
+  return t;
+}
+
+struct G16 {  // small builder for bf16 gemm descriptors
+  hig_gemm16_desc g;
+  G16(const void* X, int64_t ldx, const void* Y, int64_t ldy, void* C, int64_t ldc, int64_t I, int64_t J, int64_t R) {
+    memset(&g, 0, sizeof(g));
+    g.X = X; g.ldx = ldx; g.Y = Y; g.ldy = ldy; g.C = C; g.ldc = ldc;
+    g.I = (int)I; g.J = (int)J; g.R = (int)R; g.epi = HIG_EPI_NONE;
+  }
+  G16& epi(int e, const float* bias) { g.epi = e; g.bias = bias; return *this; }
+  G16& res16(const void* r, int64_t ldr) { g.res = r; g.ldr = ldr; g.res_f32 = 0; return *this; }
+  G16& res32(const float* r, int64_t ldr) { g.res = r; g.ldr = ldr; g.res_f32 = 1; return *this; }
+  G16& out32() { g.c_f32 = 1; return *this; }
+};
+
+int64_t fwd16_total(const Dims& D) { return fwd16_layout(D).total; }
+int64_t text16_total(const Dims& D) { return text16_layout(D).total; }
+
+inline const void* P16(const void* const* t, int idx) { return t[idx]; }
+inline const void* PL16(const void* const* t, int l, int idx) { return t[HIG_NGLOBAL + l * HIG_NLAYER + idx]; }
+
+}  // namespace
+
+extern "C" int hig_text_context_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
+                                     const float* xf_out, void* textctx, hig_stream_t stream) {
+  Dims D;
+  HIG_TRY(check_dims(dims, D));
+  HIG_REQUIRE(D.bf16, "hig_text_context_bf16: dims->storage must be HIG_STORE_BF16");
+  HIG_REQUIRE(params && params16 && xf_out && textctx, "hig_text_context_bf16: null argument");
+  const Text16Layout tl = text16_layout(D);
+  char* base = static_cast<char*>(textctx);
+  hipStream_t st = hig_stream(stream);
+  void* xfn = base + tl.xfn;
+  char* kv = base + tl.kv;
+  for (int l = 0; l < D.L; ++l) {
+    float* Ac = reinterpret_cast<float*>(base + tl.layer0 + tl.lstride * l + tl.Ac);
+    float* kstc = reinterpret_cast<float*>(base + tl.layer0 + tl.lstride * l + tl.kstc);
+    // text_norm (per layer), [key; value] projection, softmax over the N tokens, A_c = k^T v   (transformer.py:146-152)
+    HIG_TRY(hig_ln_bf16(xf_out, 1, D.Lt, D.Mt, D.Lt, PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B),
+                        nullptr, 0, 0, 0, xfn, D.Lt, stream));
+    HIG_TRY(hig_gemm16_launch(G16(xfn, D.Lt, PL16(params16, l, HIG_L_CA_KV_W), D.Lt, kv, 2 * D.d, D.Mt, 2 * D.d, D.Lt)
+                                  .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_KV_B)).g, st));
+    HIG_TRY(hig_linattn_ctx_bf16(kv, kv + (int64_t)D.d * 2, 2 * D.d, D.B, D.N, D.H, D.hd, nullptr, Ac, kstc,
+                                 reinterpret_cast<float*>(base + tl.cscr), stream));
+  }
+  return HIG_OK;
+}
+
+extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
+                                     const float* x, const int64_t* t, const int64_t* length, const float* xf_proj,
+                                     const void* textctx, float* out, void* workspace, hig_stream_t stream) {
+  Dims D;
+  HIG_TRY(check_dims(dims, D));
+  HIG_REQUIRE(D.bf16, "hig_denoiser_fwd_bf16: dims->storage must be HIG_STORE_BF16");
+  HIG_REQUIRE(params && params16 && x && t && xf_proj && textctx && out && workspace, "hig_denoiser_fwd_bf16: null argument");
+  const Fwd16Layout w = fwd16_layout(D);
+  const Text16Layout tl = text16_layout(D);
+  char* ws = static_cast<char*>(workspace);
+  const char* tc = static_cast<const char*>(textctx);
+  hipStream_t st = hig_stream(stream);
+  const int d = D.d, E = D.E;
+  const int64_t M = D.M;
+  const int64_t ss_ld = (int64_t)D.nsty * D.L * 2 * d;
+  float* ss = reinterpret_cast<float*>(ws + w.ss);
+
+  // K0: emb = time_embed(timestep_embedding(t)) + xf_proj; only silu(emb) is consumed (by every stylization block):
+  //     te -> silu(Lin0) -> silu(Lin2 + xf_proj) -> ONE GEMM for all 3L (scale, shift) pairs      (transformer.py:345-349,415,81-83)
+  HIG_TRY(hig_timestep_embedding(t, D.B, d, reinterpret_cast<float*>(ws + w.te32), stream));
+  HIG_TRY(hig_cast_bf16(reinterpret_cast<float*>(ws + w.te32), ws + w.te16, (int64_t)D.B * d, stream));
+  HIG_TRY(hig_gemm16_launch(G16(ws + w.te16, d, P16(params16, HIG_P_TE0_W), d, ws + w.teh16, E, D.B, E, d)
+                                .epi(HIG_EPI_BIAS_SILU, P(params, HIG_P_TE0_B)).g, st));
+  HIG_TRY(hig_gemm16_launch(G16(ws + w.teh16, E, P16(params16, HIG_P_TE2_W), E, ws + w.semb16, E, D.B, E, E)
+                                .epi(HIG_EPI_BIAS_RES_SILU, P(params, HIG_P_TE2_B)).res32(xf_proj, E).g, st));
+  HIG_TRY(hig_gemm16_launch(G16(ws + w.semb16, E, P16(params16, HIG_P_STY_EMB_W), E, ss, ss_ld, D.B, ss_ld, E)
+                                .epi(HIG_EPI_BIAS, P(params, HIG_P_STY_EMB_B)).out32().g, st));
+  // K1: h0 = joint_embed(x) + sequence_embedding[:T]: fp32 operands (x is the fp32 DDPM state, F = 150 rows are not
+  //     16-byte aligned), result rounded once into the bf16 residual stream
+  {
+    float* h32 = reinterpret_cast<float*>(ws + w.h32);
+    G ge(x, D.F, 0, P(params, HIG_P_JOINT_W), D.F, 0, h32, d, M, d, D.F);
+    ge.epi(HIG_EPI_BIAS_POS, P(params, HIG_P_JOINT_B)).pos(P(params, HIG_P_SEQ_EMB), d, D.T);
+    HIG_TRY(hig_gemm_launch(ge.g, 1, nullptr, st));
+    HIG_TRY(hig_cast_bf16(h32, ws + w.h, M * d, stream));
+  }
+  void* h = ws + w.h;
+  void* xn = ws + w.xn;
+  char* qkv = ws + w.qkv;
+  void* y = ws + w.y;
+  void* a = ws + w.a;
+  void* qc = ws + w.qc;
+  void* f1 = ws + w.f1;
+  float* A1 = reinterpret_cast<float*>(ws + w.A1);
+  float* kst1 = reinterpret_cast<float*>(ws + w.kst1);
+  float* cscr = reinterpret_cast<float*>(ws + w.cscr);
+  // one stylization block: h += Lin_out( silu( LN(y) (1 + scale) + shift ) )      (transformer.py:81-85)
+  auto stylize = [&](int l, int slot, int norm_w, int norm_b, int out_w, int out_b) -> int {
+    const float* ssl = ss + (int64_t)(D.nsty * l + slot) * 2 * d;
+    HIG_TRY(hig_ln_bf16(y, 0, d, M, d, PL(params, l, norm_w), PL(params, l, norm_b), ssl, ss_ld, d, D.T, a, d, stream));
+    return hig_gemm16_launch(G16(a, d, PL16(params16, l, out_w), d, h, d, M, d, d)
+                                 .epi(HIG_EPI_BIAS_RES, PL(params, l, out_b)).res16(h, d).g, st);
+  };
+  for (int l = 0; l < D.L; ++l) {
+    // ---- self attention (transformer.py:101-119) ----
+    HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B), nullptr, 0, 0, 0, xn, d, stream));
+    HIG_TRY(hig_gemm16_launch(G16(xn, d, PL16(params16, l, HIG_L_SA_QKV_W), d, qkv, 3 * d, M, 3 * d, d)
+                                  .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_SA_QKV_B)).g, st));
+    HIG_TRY(hig_linattn_ctx_bf16(qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, D.H, D.hd, length, A1, kst1,
+                                 cscr, stream));
+    HIG_TRY(hig_linattn_apply_bf16(qkv, 3 * d, A1, y, d, D.B, D.T, D.H, D.hd, stream));
+    HIG_TRY(stylize(l, 0, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B));
+    // ---- cross attention to the text context (transformer.py:135-155) ----
+    HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B), nullptr, 0, 0, 0, xn, d, stream));
+    HIG_TRY(hig_gemm16_launch(G16(xn, d, PL16(params16, l, HIG_L_CA_Q_W), d, qc, d, M, d, d)
+                                  .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).g, st));
+    HIG_TRY(hig_linattn_apply_bf16(qc, d, reinterpret_cast<const float*>(tc + tl.layer0 + tl.lstride * l + tl.Ac), y, d,
+                                   D.B, D.T, D.H, D.hd, stream));
+    HIG_TRY(stylize(l, 1, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B));
+    // ---- FFN (transformer.py:167-170) ----
+    HIG_TRY(hig_gemm16_launch(G16(h, d, PL16(params16, l, HIG_L_FFN_W1), d, f1, D.ff, M, D.ff, d)
+                                  .epi(HIG_EPI_BIAS_GELU, PL(params, l, HIG_L_FFN_B1)).g, st));
+    HIG_TRY(hig_gemm16_launch(G16(f1, D.ff, PL16(params16, l, HIG_L_FFN_W2), D.ff, y, d, M, d, D.ff)
+                                  .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B2)).g, st));
+    HIG_TRY(stylize(l, 2, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B, HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B));
+  }
+  // K6: out = Linear(d, F)(h_L), fp32 (the DDPM update consumes it)
+  return hig_gemm16_launch(G16(h, d, P16(params16, HIG_P_OUT_W), d, out, D.F, M, D.F, d)
+                               .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT_B)).out32().g, st);
 }
 
 namespace {

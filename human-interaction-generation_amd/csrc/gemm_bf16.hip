@@ -1,0 +1,317 @@
+// bf16-STORAGE GEMM for gfx950 (MI355X):  C[i][j] = epi( sum_r X[i][r] * Y[j][r] )
+//   X (I, ldx) activations and Y (J, ldy) nn.Linear weight (out, in), both bf16, both reduce-contiguous;
+//   fp32 accumulate on v_mfma_f32_32x32x16_bf16; C (and the residual) bf16 or fp32.
+// Serves every nn.Linear of the denoiser forward when hig_dims.storage == HIG_STORE_BF16 (reference:
+// codes/models/transformer.py:81-85,108-114,144-150,168,345-349,425 -- the reference runs them in fp32; BASELINE
+// configs 3 and 5 ask for bf16 storage with fp32 accumulation).
+//
+// CDNA4 mapping.  256 threads = 4 waves; a wave owns 64 rows x (32 TJ) columns as 32x32 accumulators.  Operand tiles
+// go global -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR hop, no conversion): the
+// LDS image of a tile is [rows][BK] bf16 (BK = 64: 128-byte rows) written LINEARLY by the DMA, so the bank-conflict
+// swizzle sits on the per-lane SOURCE address and on the read address (guide rule 21): 16-byte chunk c of row r is
+// stored at chunk position c ^ ((r / RB) & (CHUNKS-1)), RB = rows per 256-byte bank row -- the 16-lane ds_read_b128
+// groups {0-3,12-15,20-27}... then touch 16 distinct 16-byte slots (conflict-free).  One MFMA operand = one
+// ds_read_b128 (8 consecutive k of one row).  The MFMA row operand is Y (output column), so a lane holds 4 consecutive
+// output columns per accumulator quad; the finished tile is staged through LDS (fp32) and leaves as whole rows:
+// 16 bytes of bf16 (8 columns) or 32 bytes of fp32 per lane, bias / GELU / SiLU / residual applied in fp32 on the way.
+// Two LDS stages: the DMA of k-tile kt+1 is issued right after the barrier that publishes k-tile kt and lands
+// during its MFMA block; with 2 workgroups per CU (64 KiB of LDS each) the other workgroup's MFMAs cover the rest.
+#include <stdlib.h>
+
+#include "hig_common.h"
+#include "hig_host.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NT = 256;
+
+struct K16Args {
+  hig_gemm16_desc g;
+  int nbj, ntiles;
+  int vec;          // C / res rows allow 16-byte (bf16) / 32-byte (fp32) row pieces
+};
+
+__device__ __forceinline__ void glds16(const __bf16* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int EPI>
+__device__ __forceinline__ float epi_act(float v) {
+  if (EPI == HIG_EPI_BIAS_GELU) return hig_gelu(v);
+  if (EPI == HIG_EPI_BIAS_SILU || EPI == HIG_EPI_BIAS_RES_SILU) return hig_silu(v);
+  return v;
+}
+
+// WM x WN waves, each 64 x (32 TJ):  BM = 64 WM, BN = 32 TJ WN.
+template <int WM, int TJ, int BK, int EPI>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
+  constexpr int WN = 4 / WM, TI = 2;
+  constexpr int BM = 64 * WM, BN = 32 * TJ * WN;
+  constexpr int ROWB = BK * 2, CHUNKS = BK / 8, RB = 256 / ROWB, RPI = 1024 / ROWB;   // RPI: rows per DMA instruction
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  constexpr int NA = BM / RPI, NB = BN / RPI, NQ = (NA + NB) / 4;   // DMA instructions: per tile, per wave
+  static_assert((NA + NB) % 4 == 0, "DMA instructions must split evenly over the 4 waves");
+  constexpr int CLD = BN + 4;
+  constexpr int EPI_BYTES = 64 * CLD * 4;
+  constexpr int SMEM = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+  const hig_gemm16_desc& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave / WN, wj = wave % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  const __bf16* __restrict__ X = static_cast<const __bf16*>(g.X);
+  const __bf16* __restrict__ Y = static_cast<const __bf16*>(g.Y);
+  const int nk = g.R / BK;
+
+  // read-side byte offsets inside a stage (k-step ks adds the XOR-ed chunk)
+  int xoff[TI], xsw[TI], yoff[TJ], ysw[TJ];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) {
+    const int r = wi * 64 + 32 * ti + lr;
+    xoff[ti] = r * ROWB;
+    xsw[ti] = (r / RB) & (CHUNKS - 1);
+  }
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) {
+    const int r = wj * (32 * TJ) + 32 * tj + lr;
+    yoff[tj] = A_BYTES + r * ROWB;
+    ysw[tj] = (r / RB) & (CHUNKS - 1);
+  }
+
+  for (int lin = blockIdx.x; lin < a.ntiles; lin += gridDim.x) {
+    // XCD-aware order: blocks b, b + 8, ... share an XCD (private L2): give each XCD a contiguous run of tiles, column
+    // tiles of one row panel next to each other, so the X panel is fetched from HBM once per XCD
+    const int q8 = a.ntiles >> 3, r8 = a.ntiles & 7, xcd = lin & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+    const int i0 = (tile / a.nbj) * BM, j0 = (tile % a.nbj) * BN;
+
+    // per-lane DMA sources: instruction q of this wave covers RPI rows of the A (X) or B (Y) tile
+    const __bf16* src[NQ];
+    int dst[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int n = wave + 4 * q;                      // instruction index in [A tile | B tile] order
+      const bool isA = n < NA;
+      const int r = (isA ? n : n - NA) * RPI + lane / CHUNKS;
+      const int c = (lane % CHUNKS) ^ ((r / RB) & (CHUNKS - 1));
+      src[q] = isA ? X + (int64_t)min(i0 + r, g.I - 1) * g.ldx + 8 * c
+                   : Y + (int64_t)min(j0 + r, g.J - 1) * g.ldy + 8 * c;
+      dst[q] = (isA ? 0 : A_BYTES) + (isA ? n : n - NA) * 1024;
+    }
+    auto stage = [&](int buf) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        glds16(src[q], smem + buf * STAGE + dst[q]);
+        src[q] += BK;
+      }
+    };
+
+    f32x16 acc[TJ][TI];
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[tj][ti][e] = 0.f;
+
+    if (nk > 0) stage(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of k-tile kt has landed in LDS
+      __syncthreads();                                    // ... everyone's has; and buffer (kt+1)&1 is no longer read
+      if (kt + 1 < nk) stage((kt + 1) & 1);
+      const char* sb = smem + (kt & 1) * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 xf[TI], yf[TJ];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+          xf[ti] = *reinterpret_cast<const bf16x8*>(sb + xoff[ti] + 16 * ((2 * ks + lh) ^ xsw[ti]));
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+          yf[tj] = *reinterpret_cast<const bf16x8*>(sb + yoff[tj] + 16 * ((2 * ks + lh) ^ ysw[tj]));
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+            acc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[tj], xf[ti], acc[tj][ti], 0, 0, 0);
+      }
+    }
+    __syncthreads();   // all MFMA reads of the staging buffers are done: reuse them for the output tile
+
+    // ---- epilogue: one 64-row pass per wave row, through LDS (fp32), out as whole rows -------------------
+    float* sC = reinterpret_cast<float*>(smem);
+    constexpr int Q8 = BN / 8, RPP = NT / Q8;          // 8-column pieces per row, rows per sweep
+    const int c8 = tid % Q8, rr0 = tid / Q8;
+    const int j = j0 + 8 * c8;
+    float b8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b8[e] = (EPI != HIG_EPI_NONE && j + e < g.J) ? g.bias[j + e] : 0.f;
+#pragma unroll
+    for (int ps = 0; ps < WM; ++ps) {
+      if (wi == ps) {
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *reinterpret_cast<f32x4*>(sC + (32 * ti + lr) * CLD + wj * (32 * TJ) + 32 * tj + 8 * q + 4 * lh) =
+                  f32x4{acc[tj][ti][4 * q], acc[tj][ti][4 * q + 1], acc[tj][ti][4 * q + 2], acc[tj][ti][4 * q + 3]};
+      }
+      __syncthreads();
+      for (int rr = rr0; rr < 64; rr += RPP) {
+        const int i = i0 + 64 * ps + rr;
+        if (i >= g.I || j >= g.J) break;
+        float v[8];
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sC + rr * CLD + 8 * c8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(sC + rr * CLD + 8 * c8 + 4);
+        v[0] = v0.x + b8[0]; v[1] = v0.y + b8[1]; v[2] = v0.z + b8[2]; v[3] = v0.w + b8[3];
+        v[4] = v1.x + b8[4]; v[5] = v1.y + b8[5]; v[6] = v1.z + b8[6]; v[7] = v1.w + b8[7];
+        const bool full = a.vec && j + 8 <= g.J;
+        if (EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU) {
+          if (g.res_f32) {
+            const float* rp = static_cast<const float*>(g.res) + (int64_t)i * g.ldr + j;
+            if (full) {
+              const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+              v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) if (j + e < g.J) v[e] += rp[e];
+            }
+          } else {
+            const __bf16* rp = static_cast<const __bf16*>(g.res) + (int64_t)i * g.ldr + j;
+            if (full) {
+              const bf16x8 r = *reinterpret_cast<const bf16x8*>(rp);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) if (j + e < g.J) v[e] += (float)rp[e];
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = epi_act<EPI>(v[e]);
+        if (g.c_f32) {
+          float* cp = static_cast<float*>(g.C) + (int64_t)i * g.ldc + j;
+          if (full) {
+            *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (j + e < g.J) cp[e] = v[e];
+          }
+        } else {
+          __bf16* cp = static_cast<__bf16*>(g.C) + (int64_t)i * g.ldc + j;
+          if (full) {
+            *reinterpret_cast<bf16x8*>(cp) = bf16x8{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3],
+                                                    (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]};
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (j + e < g.J) cp[e] = (__bf16)v[e];
+          }
+        }
+      }
+      __syncthreads();   // sC is rewritten by the next pass / the next tile's DMA
+    }
+  }
+}
+
+template <int WM, int TJ, int BK, int EPI>
+int launch16(const hig_gemm16_desc& g, hipStream_t st) {
+  constexpr int WN = 4 / WM, BM = 64 * WM, BN = 32 * TJ * WN;
+  K16Args a;
+  a.g = g;
+  const int nbi = (g.I + BM - 1) / BM;
+  a.nbj = (g.J + BN - 1) / BN;
+  a.ntiles = nbi * a.nbj;
+  auto al = [](const void* p, int n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
+  a.vec = (g.c_f32 ? (g.ldc % 4 == 0 && al(g.C, 16)) : (g.ldc % 8 == 0 && al(g.C, 16)));
+  if (g.res) a.vec = a.vec && (g.res_f32 ? (g.ldr % 4 == 0 && al(g.res, 16)) : (g.ldr % 8 == 0 && al(g.res, 16)));
+  constexpr int lds = 2 * (BM + BN) * BK * 2;
+  int per_cu = 160 * 1024 / (lds > 64 * (BN + 4) * 4 ? lds : 64 * (BN + 4) * 4);
+  if (per_cu > 4) per_cu = 4;
+  static const int forced_per_cu = getenv("HIG_BF16_PERCU") ? atoi(getenv("HIG_BF16_PERCU")) : 0;   // tuning knob
+  if (forced_per_cu > 0) per_cu = forced_per_cu;
+  int grid = 256 * per_cu;
+  if (grid > a.ntiles) grid = a.ntiles;
+  hipLaunchKernelGGL((gemm_bf16_kernel<WM, TJ, BK, EPI>), dim3(grid), dim3(NT), 0, st, a);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+template <int EPI>
+int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
+  // 128 x 128 tiles once they fill the chip twice over (2 resident workgroups per CU), else 64 x 128: more, shorter
+  // workgroups (3 per CU) for the M = B*T <= 6272-row launches and the few-row (B-row) GEMMs
+  static const int forced = getenv("HIG_BF16_TILE") ? atoi(getenv("HIG_BF16_TILE")) : 0;   // tuning knob: 64 / 128
+  static const int thr = getenv("HIG_BF16_THR") ? atoi(getenv("HIG_BF16_THR")) : 512;      // tuning knob
+  const int64_t t128 = (int64_t)((g.I + 127) / 128) * ((g.J + 127) / 128);
+  const bool big = forced ? forced == 128 : t128 >= thr;
+  if (g.R % 64 == 0) {
+    if (big) return launch16<2, 2, 64, EPI>(g, st);
+    return launch16<1, 1, 64, EPI>(g, st);
+  }
+  if (big) return launch16<2, 2, 32, EPI>(g, st);
+  return launch16<1, 1, 32, EPI>(g, st);
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int64_t n) {
+  const int64_t n8 = n / 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i], b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+    reinterpret_cast<bf16x8*>(dst)[i] = bf16x8{(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w,
+                                               (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[n8 * 8 + threadIdx.x] = (__bf16)src[n8 * 8 + threadIdx.x];
+}
+
+}  // namespace
+
+int hig_gemm16_launch(const hig_gemm16_desc& g, hipStream_t st) {
+  HIG_REQUIRE(g.X && g.Y && g.C, "hig_gemm_bf16: null operand");
+  HIG_REQUIRE(g.I >= 0 && g.J >= 0 && g.R > 0, "hig_gemm_bf16: bad extent");
+  if (g.I == 0 || g.J == 0) return HIG_OK;
+  if (g.R % 32 != 0)
+    return hig_set_error(HIG_EUNSUPPORTED, "hig_gemm_bf16: the reduce extent must be a multiple of 32 (got %d)", g.R);
+  HIG_REQUIRE(g.ldx % 8 == 0 && g.ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(g.X) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(g.Y) & 15) == 0,
+              "hig_gemm_bf16: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
+  if (g.epi != HIG_EPI_NONE) HIG_REQUIRE(g.bias, "hig_gemm_bf16: epilogue %d needs a bias", g.epi);
+  if (g.epi == HIG_EPI_BIAS_RES || g.epi == HIG_EPI_BIAS_RES_SILU) HIG_REQUIRE(g.res, "hig_gemm_bf16: missing residual");
+  switch (g.epi) {
+    case HIG_EPI_NONE: return launch16_sized<HIG_EPI_NONE>(g, st);
+    case HIG_EPI_BIAS: return launch16_sized<HIG_EPI_BIAS>(g, st);
+    case HIG_EPI_BIAS_GELU: return launch16_sized<HIG_EPI_BIAS_GELU>(g, st);
+    case HIG_EPI_BIAS_RES: return launch16_sized<HIG_EPI_BIAS_RES>(g, st);
+    case HIG_EPI_BIAS_SILU: return launch16_sized<HIG_EPI_BIAS_SILU>(g, st);
+    case HIG_EPI_BIAS_RES_SILU: return launch16_sized<HIG_EPI_BIAS_RES_SILU>(g, st);
+    default: return hig_set_error(HIG_EUNSUPPORTED, "hig_gemm_bf16: epilogue %d not built", g.epi);
+  }
+}
+
+extern "C" int hig_gemm_bf16(const hig_gemm16_desc* g, hig_stream_t stream) {
+  HIG_REQUIRE(g, "hig_gemm_bf16: null descriptor");
+  return hig_gemm16_launch(*g, hig_stream(stream));
+}
+
+extern "C" int hig_cast_bf16(const float* src, void* dst, int64_t n, hig_stream_t stream) {
+  HIG_REQUIRE(src && dst && n >= 0, "hig_cast_bf16: bad arguments");
+  if (n == 0) return HIG_OK;
+  HIG_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
+              "hig_cast_bf16: buffers must be 16-byte aligned");
+  int64_t blocks = (n / 8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)blocks), dim3(256), 0, hig_stream(stream), src,
+                     static_cast<__bf16*>(dst), n);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}

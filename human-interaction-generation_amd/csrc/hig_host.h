@@ -9,6 +9,8 @@ int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_
 // I <= 64 rows with EPI_BIAS / EPI_BIAS_RES: split-R over `scratch` so the weight streams through ~1024 workgroups
 int hig_gemm_few_rows(const hig_gemm_desc& g, float* scratch, int64_t scratch_floats, hipStream_t st);
 
+int hig_gemm16_launch(const hig_gemm16_desc& g, hipStream_t st);
+
 namespace {
 
 inline int64_t al(int64_t floats) { return (floats + 63) & ~(int64_t)63; }  // 256-byte granules

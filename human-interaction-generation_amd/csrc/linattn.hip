@@ -225,6 +225,19 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ Q,
 // accumulator quad (16-byte stores): row = base_i + (lane & 31), columns = base_j + 8q + 4*(lane>>5) + e.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
+// Activation I/O of the forward MFMA kernels: fp32, or bf16 storage (hig_dims.storage == HIG_STORE_BF16) converted on
+// load / store -- the softmax, the context matrices and every accumulation stay fp32.
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const __bf16* p) {
+  const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(__bf16* p, float4 v) {
+  *reinterpret_cast<bf16x4_t*>(p) = bf16x4_t{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+}
 
 __device__ __forceinline__ void zero16(f32x16& a) {
 #pragma unroll
@@ -237,25 +250,25 @@ __device__ __forceinline__ f32x16 mfma4(f32x16 acc, float y0, float y1, float y2
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y3, x.w, acc, 0, 0, 0);
   return acc;
 }
-__device__ __forceinline__ void store16(float* p, const f32x16& a, float scale = 1.0f) {
+template <typename T>
+__device__ __forceinline__ void store16(T* p, const f32x16& a, float scale = 1.0f) {
 #pragma unroll
   for (int q = 0; q < 4; ++q)
-    *reinterpret_cast<float4*>(p + 8 * q) =
-        make_float4(a[4 * q] * scale, a[4 * q + 1] * scale, a[4 * q + 2] * scale, a[4 * q + 3] * scale);
+    st4(p + 8 * q, make_float4(a[4 * q] * scale, a[4 * q + 1] * scale, a[4 * q + 2] * scale, a[4 * q + 3] * scale));
 }
 
 // Y tile (64 rows) = softmax_c(Q tile) . A[b,h]
-template <int HD>
-__global__ __launch_bounds__(256) void apply_mfma_kernel(const float* __restrict__ Q, int64_t ldq,
+template <int HD, typename TIO>
+__global__ __launch_bounds__(256) void apply_mfma_kernel(const TIO* __restrict__ Q, int64_t ldq,
                                                          const float* __restrict__ A,
-                                                         float* __restrict__ Y, int64_t ldy, int rows, int H) {
+                                                         TIO* __restrict__ Y, int64_t ldy, int rows, int H) {
   constexpr int LDP = HD + 4, TJ = HD / 64, Q4 = HD / 4, NPRE = CH * Q4 / 256;
   __shared__ __attribute__((aligned(16))) float sA[HD * HD];    // [c][l]: reduce index major
   __shared__ __attribute__((aligned(16))) float sQ[CH * LDP];   // [row][c]
   const int tid = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int nchunk = (rows + CH - 1) / CH;
-  const float* Qb = Q + (int64_t)b * rows * ldq + h * HD;
+  const TIO* Qb = Q + (int64_t)b * rows * ldq + h * HD;
   // A workgroup walks chunks blockIdx.y, blockIdx.y + gridDim.y, ...: A[b,h] is staged once, and the next Q tile
   // is requested into registers before the softmax / MFMA of the current one (no exposed load per chunk).
   float4 pre[NPRE];
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(256) void apply_mfma_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
       const int idx = tid + 256 * i, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
-      pre[i] = r < rows ? *reinterpret_cast<const float4*>(Qb + (int64_t)r * ldq + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pre[i] = r < rows ? ld4(Qb + (int64_t)r * ldq + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   fetch(blockIdx.y * CH);
@@ -299,7 +312,7 @@ __global__ __launch_bounds__(256) void apply_mfma_kernel(const float* __restrict
     }
     const int r = r0 + wi * 32 + lr;
     if (r < rows) {
-      float* yp = Y + ((int64_t)b * rows + r) * ldy + h * HD + wj * (HD / 2) + 4 * lh;
+      TIO* yp = Y + ((int64_t)b * rows + r) * ldy + h * HD + wj * (HD / 2) + 4 * lh;
 #pragma unroll
       for (int tj = 0; tj < TJ; ++tj) store16(yp + 32 * tj, acc[tj]);
     }
@@ -310,8 +323,8 @@ __global__ __launch_bounds__(256) void apply_mfma_kernel(const float* __restrict
 // A[b,h][c][l] = sum_r softmax_r(K)[r,c] V[r,l]  (+ kstat): one workgroup per (sample, head) walks the row chunks
 // ONCE with a running column max (online softmax): when a chunk raises the max of channel c, the accumulator row c
 // and the running sum are rescaled by exp(m_old - m_new).  The next K / V tiles are prefetched into registers.
-template <int HD>
-__global__ __launch_bounds__(256) void ctx_mfma_kernel(const float* __restrict__ K, const float* __restrict__ V,
+template <int HD, typename TIO>
+__global__ __launch_bounds__(256) void ctx_mfma_kernel(const TIO* __restrict__ K, const TIO* __restrict__ V,
                                                        int64_t ld, int rows, int H,
                                                        const int64_t* __restrict__ length, float* __restrict__ A,
                                                        float* __restrict__ kstat) {
@@ -325,8 +338,8 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const float* __restrict__
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   int len = rows;
   if (length) len = (int)min<int64_t>(max<int64_t>(length[b], 0), rows);
-  const float* Kb = K + (int64_t)b * rows * ld + h * HD;
-  const float* Vb = V + (int64_t)b * rows * ld + h * HD;
+  const TIO* Kb = K + (int64_t)b * rows * ld + h * HD;
+  const TIO* Vb = V + (int64_t)b * rows * ld + h * HD;
   const int c4 = tid % Q4, rgrp = tid / Q4;
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
@@ -336,8 +349,8 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const float* __restrict__
     for (int i = 0; i < PER; ++i) {
       const int r = r0 + rgrp + NRG * i;
       if (r < len) {
-        kreg[i] = *reinterpret_cast<const float4*>(Kb + (int64_t)r * ld + 4 * c4);
-        vreg[i] = *reinterpret_cast<const float4*>(Vb + (int64_t)r * ld + 4 * c4);
+        kreg[i] = ld4(Kb + (int64_t)r * ld + 4 * c4);
+        vreg[i] = ld4(Vb + (int64_t)r * ld + 4 * c4);
       } else {
         kreg[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         vreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -439,8 +452,8 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const float* __restrict__
 // 64 rows and writes the unnormalised partial  A_j[c][l] = sum_r exp(K[r][c] - m_j[c]) V[r][l],  m_j and
 // s_j[c] = sum_r exp(K[r][c] - m_j[c]);  ctx_combine_kernel merges them:  m = max_j m_j,
 // A = sum_j exp(m_j - m) A_j / sum_j exp(m_j - m) s_j.   part layout per (bh, chunk): [HD*HD | m HD | s HD].
-template <int HD>
-__global__ __launch_bounds__(256) void ctx_part_mfma_kernel(const float* __restrict__ K, const float* __restrict__ V,
+template <int HD, typename TIO>
+__global__ __launch_bounds__(256) void ctx_part_mfma_kernel(const TIO* __restrict__ K, const TIO* __restrict__ V,
                                                             int64_t ld, int rows, int H,
                                                             const int64_t* __restrict__ length,
                                                             float* __restrict__ part) {
@@ -455,8 +468,8 @@ __global__ __launch_bounds__(256) void ctx_part_mfma_kernel(const float* __restr
   if (length) len = (int)min<int64_t>(max<int64_t>(length[b], 0), rows);
   const int r0 = blockIdx.y * CH;
   const int nvalid = max(0, min(CH, len - r0));
-  const float* Kb = K + ((int64_t)b * rows + r0) * ld + h * HD;
-  const float* Vb = V + ((int64_t)b * rows + r0) * ld + h * HD;
+  const TIO* Kb = K + ((int64_t)b * rows + r0) * ld + h * HD;
+  const TIO* Vb = V + ((int64_t)b * rows + r0) * ld + h * HD;
   // one pass over HBM, 16 bytes per lane: thread = 4 channels (c4) of rows rgrp, rgrp + NRG, ...
   const int c4 = tid % Q4, rgrp = tid / Q4;
   float4 kreg[PER], vreg[PER];
@@ -465,8 +478,8 @@ __global__ __launch_bounds__(256) void ctx_part_mfma_kernel(const float* __restr
   for (int i = 0; i < PER; ++i) {
     const int rr = rgrp + NRG * i;
     if (rr < nvalid) {
-      kreg[i] = *reinterpret_cast<const float4*>(Kb + (int64_t)rr * ld + 4 * c4);
-      vreg[i] = *reinterpret_cast<const float4*>(Vb + (int64_t)rr * ld + 4 * c4);
+      kreg[i] = ld4(Kb + (int64_t)rr * ld + 4 * c4);
+      vreg[i] = ld4(Vb + (int64_t)rr * ld + 4 * c4);
     } else {
       kreg[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
       vreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1143,39 +1156,63 @@ extern "C" int64_t hig_linattn_ctx_scratch_floats(int32_t B, int32_t rows, int32
   return (int64_t)B * H * nchunk * ((int64_t)hd * hd + 2 * hd);
 }
 
-extern "C" int hig_linattn_ctx(const float* K, const float* V, int64_t ld, int32_t B, int32_t rows,
-                               int32_t H, int32_t hd, const int64_t* length, float* A, float* kstat,
-                               float* scratch, hig_stream_t stream) {
-  HIG_REQUIRE(K && V && A && kstat && B > 0 && rows > 0 && H > 0, "hig_linattn_ctx: bad arguments");
-  HIG_REQUIRE(hd_ok(hd), "hig_linattn: head dim %d not in {8,16,32,64,128}", hd);
+namespace {
+template <typename TIO>
+int linattn_ctx_t(const TIO* K, const TIO* V, int64_t ld, int32_t B, int32_t rows, int32_t H, int32_t hd,
+                  const int64_t* length, float* A, float* kstat, float* scratch, hipStream_t st) {
   const int nchunk = (rows + CH - 1) / CH;
   static const int ctx_walk = getenv("HIG_CTX_WALK") ? atoi(getenv("HIG_CTX_WALK")) : 1;   // tuning knob
   const bool walk = ctx_walk && B * H >= 256;   // enough (sample, head) pairs to fill the chip with walking workgroups
-  if (!walk && scratch && nchunk > 1 && (hd == 64 || hd == 128)) {
+  if (!walk && scratch && nchunk > 1) {
     // row chunks in parallel + a merge: 4-5x the workgroups of the one-per-(sample, head) kernel
     if (hd == 64) {
-      hipLaunchKernelGGL(ctx_part_mfma_kernel<64>, dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream), K, V, ld,
-                         rows, H, length, scratch);
-      hipLaunchKernelGGL(ctx_combine_kernel<64>, dim3(B * H), dim3(256), 0, hig_stream(stream), scratch, nchunk, A,
-                         kstat);
+      hipLaunchKernelGGL((ctx_part_mfma_kernel<64, TIO>), dim3(B * H, nchunk), dim3(256), 0, st, K, V, ld, rows, H, length,
+                         scratch);
+      hipLaunchKernelGGL(ctx_combine_kernel<64>, dim3(B * H), dim3(256), 0, st, scratch, nchunk, A, kstat);
     } else {
-      hipLaunchKernelGGL(ctx_part_mfma_kernel<128>, dim3(B * H, nchunk), dim3(256), 0, hig_stream(stream), K, V, ld,
-                         rows, H, length, scratch);
-      hipLaunchKernelGGL(ctx_combine_kernel<128>, dim3(B * H), dim3(256), 0, hig_stream(stream), scratch, nchunk, A,
-                         kstat);
+      hipLaunchKernelGGL((ctx_part_mfma_kernel<128, TIO>), dim3(B * H, nchunk), dim3(256), 0, st, K, V, ld, rows, H, length,
+                         scratch);
+      hipLaunchKernelGGL(ctx_combine_kernel<128>, dim3(B * H), dim3(256), 0, st, scratch, nchunk, A, kstat);
     }
     HIG_CHECK_LAUNCH();
     return HIG_OK;
   }
   if (hd == 64)
-    hipLaunchKernelGGL(ctx_mfma_kernel<64>, dim3(B * H), dim3(256), 0, hig_stream(stream), K, V, ld, rows, H, length, A,
-                       kstat);
-  else if (hd == 128)
-    hipLaunchKernelGGL(ctx_mfma_kernel<128>, dim3(B * H), dim3(256), 0, hig_stream(stream), K, V, ld, rows, H, length, A,
-                       kstat);
+    hipLaunchKernelGGL((ctx_mfma_kernel<64, TIO>), dim3(B * H), dim3(256), 0, st, K, V, ld, rows, H, length, A, kstat);
   else
-    HD_SWITCH(hd, hipLaunchKernelGGL((ctx_kernel<HDV>), dim3(B * H), dim3(256), 0, hig_stream(stream), K, V,
-                                     ld, rows, H, length, A, kstat));
+    hipLaunchKernelGGL((ctx_mfma_kernel<128, TIO>), dim3(B * H), dim3(256), 0, st, K, V, ld, rows, H, length, A, kstat);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+template <typename TIO>
+int linattn_apply_t(const TIO* Q, int64_t ldq, const float* A, TIO* Y, int64_t ldy, int32_t B, int32_t rows, int32_t H,
+                    int32_t hd, hipStream_t st) {
+  // chunk-walking workgroups: enough of them to fill the chip (~4 per CU), each staging A[b,h] once
+  const int nchunk_a = (rows + CH - 1) / CH;
+  // (hd = 128 keeps 97 KB of LDS per workgroup = one per CU: fewer, longer-lived workgroups; measured with
+  // tools/attn_time.py: 61 -> 47 us at config 5, neutral at hd = 64)
+  static const int apply_target = getenv("HIG_APPLY_WGS") ? atoi(getenv("HIG_APPLY_WGS")) : 0;   // tuning knob
+  const int target = apply_target > 0 ? apply_target : (hd == 128 ? 512 : 1024);
+  int gy = (target + B * H - 1) / (B * H);
+  gy = gy < 1 ? 1 : (gy > nchunk_a ? nchunk_a : gy);
+  if (hd == 64)
+    hipLaunchKernelGGL((apply_mfma_kernel<64, TIO>), dim3(B * H, gy), dim3(256), 0, st, Q, ldq, A, Y, ldy, rows, H);
+  else
+    hipLaunchKernelGGL((apply_mfma_kernel<128, TIO>), dim3(B * H, gy), dim3(256), 0, st, Q, ldq, A, Y, ldy, rows, H);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+}  // namespace
+
+extern "C" int hig_linattn_ctx(const float* K, const float* V, int64_t ld, int32_t B, int32_t rows,
+                               int32_t H, int32_t hd, const int64_t* length, float* A, float* kstat,
+                               float* scratch, hig_stream_t stream) {
+  HIG_REQUIRE(K && V && A && kstat && B > 0 && rows > 0 && H > 0, "hig_linattn_ctx: bad arguments");
+  HIG_REQUIRE(hd_ok(hd), "hig_linattn: head dim %d not in {8,16,32,64,128}", hd);
+  if (hd == 64 || hd == 128) return linattn_ctx_t<float>(K, V, ld, B, rows, H, hd, length, A, kstat, scratch, hig_stream(stream));
+  HD_SWITCH(hd, hipLaunchKernelGGL((ctx_kernel<HDV>), dim3(B * H), dim3(256), 0, hig_stream(stream), K, V,
+                                   ld, rows, H, length, A, kstat));
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
@@ -1187,25 +1224,36 @@ extern "C" int hig_linattn_apply(const float* Q, int64_t ldq, const float* A, fl
   HIG_REQUIRE(ldq % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0 &&
                   (reinterpret_cast<uintptr_t>(Y) & 15) == 0,
               "hig_linattn_apply: Q/Y must be 16-byte aligned");
-  // chunk-walking workgroups: enough of them to fill the chip (~4 per CU), each staging A[b,h] once
-  const int nchunk_a = (rows + CH - 1) / CH;
-  // (hd = 128 keeps 97 KB of LDS per workgroup = one per CU: fewer, longer-lived workgroups; measured with
-  // tools/attn_time.py: 61 -> 47 us at config 5, neutral at hd = 64)
-  static const int apply_target = getenv("HIG_APPLY_WGS") ? atoi(getenv("HIG_APPLY_WGS")) : 0;   // tuning knob
-  const int target = apply_target > 0 ? apply_target : (hd == 128 ? 512 : 1024);
-  int gy = (target + B * H - 1) / (B * H);
-  gy = gy < 1 ? 1 : (gy > nchunk_a ? nchunk_a : gy);
-  if (hd == 64)
-    hipLaunchKernelGGL(apply_mfma_kernel<64>, dim3(B * H, gy), dim3(256), 0, hig_stream(stream), Q, ldq, A, Y, ldy, rows,
-                       H);
-  else if (hd == 128)
-    hipLaunchKernelGGL(apply_mfma_kernel<128>, dim3(B * H, gy), dim3(256), 0, hig_stream(stream), Q, ldq, A, Y, ldy,
-                       rows, H);
-  else
-    HD_SWITCH(hd, hipLaunchKernelGGL((apply_kernel<HDV>), dim3(B * H, (rows + CH - 1) / CH), dim3(256), 0,
-                                     hig_stream(stream), Q, ldq, A, Y, ldy, rows, H));
+  if (hd == 64 || hd == 128) return linattn_apply_t<float>(Q, ldq, A, Y, ldy, B, rows, H, hd, hig_stream(stream));
+  HD_SWITCH(hd, hipLaunchKernelGGL((apply_kernel<HDV>), dim3(B * H, (rows + CH - 1) / CH), dim3(256), 0,
+                                   hig_stream(stream), Q, ldq, A, Y, ldy, rows, H));
   HIG_CHECK_LAUNCH();
   return HIG_OK;
+}
+
+// bf16-storage forms (hig_dims.storage == HIG_STORE_BF16): K / V / Q / Y are bf16, the context matrices and the
+// softmax statistics stay fp32.  Head dim 64 or 128 (the MFMA kernels).
+extern "C" int hig_linattn_ctx_bf16(const void* K, const void* V, int64_t ld, int32_t B, int32_t rows, int32_t H,
+                                    int32_t hd, const int64_t* length, float* A, float* kstat, float* scratch,
+                                    hig_stream_t stream) {
+  HIG_REQUIRE(K && V && A && kstat && B > 0 && rows > 0 && H > 0, "hig_linattn_ctx_bf16: bad arguments");
+  if (hd != 64 && hd != 128)
+    return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn: bf16 storage is built for head dim 64 / 128 (got %d)", hd);
+  HIG_REQUIRE(ld % 4 == 0 && (reinterpret_cast<uintptr_t>(K) & 7) == 0 && (reinterpret_cast<uintptr_t>(V) & 7) == 0,
+              "hig_linattn_ctx_bf16: K/V must be 8-byte aligned");
+  return linattn_ctx_t<__bf16>(static_cast<const __bf16*>(K), static_cast<const __bf16*>(V), ld, B, rows, H, hd, length, A,
+                               kstat, scratch, hig_stream(stream));
+}
+extern "C" int hig_linattn_apply_bf16(const void* Q, int64_t ldq, const float* A, void* Y, int64_t ldy, int32_t B,
+                                      int32_t rows, int32_t H, int32_t hd, hig_stream_t stream) {
+  HIG_REQUIRE(Q && A && Y && B > 0 && rows > 0 && H > 0, "hig_linattn_apply_bf16: bad arguments");
+  if (hd != 64 && hd != 128)
+    return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn: bf16 storage is built for head dim 64 / 128 (got %d)", hd);
+  HIG_REQUIRE(ldq % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 7) == 0 &&
+                  (reinterpret_cast<uintptr_t>(Y) & 7) == 0,
+              "hig_linattn_apply_bf16: Q/Y must be 8-byte aligned");
+  return linattn_apply_t<__bf16>(static_cast<const __bf16*>(Q), ldq, A, static_cast<__bf16*>(Y), ldy, B, rows, H, hd,
+                                 hig_stream(stream));
 }
 
 extern "C" int64_t hig_linattn_bwd_scratch_floats(int32_t B, int32_t rows, int32_t H, int32_t hd) {

@@ -1,0 +1,120 @@
+// Row kernels of the bf16-storage forward (hig_dims.storage == HIG_STORE_BF16): LayerNorm and the stylization front
+//   out[m] = LN(x[m]) * gamma + beta                                           (transformer.py:108,144,146)
+//   out[m] = silu( (LN(x[m]) * gamma + beta) * (1 + scale[b]) + shift[b] )     (transformer.py:81-85)
+// with x bf16 (or fp32: the text embeddings arrive in fp32) and out bf16; statistics and arithmetic in fp32.
+// One 64-lane wave per row, 8 elements (16 bytes of bf16) per lane per sweep, the row stays in registers between the
+// statistics and the transform: x is read once, out written once -- HBM-bound at 2 x rows x n x 2 bytes.
+#include "hig_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int WAVES = 4;
+
+__device__ __forceinline__ void ld8(const __bf16* p, float (&v)[8]) {
+  const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+}
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+template <int NIT, bool MOD, typename TIN>
+__global__ __launch_bounds__(256) void ln16_kernel(const TIN* __restrict__ x, int64_t ldx, int64_t rows, int n,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const float* __restrict__ ss, int64_t ss_ld, int shift_off,
+                                                   int rows_per_sample, __bf16* __restrict__ out, int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const TIN* xr = x + row * ldx;
+  float v[NIT][8];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = 8 * lane + 512 * it;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[it][e] = 0.f;
+    if (c < n) ld8(xr + c, v[it]);
+    s += ((v[it][0] + v[it][1]) + (v[it][2] + v[it][3])) + ((v[it][4] + v[it][5]) + (v[it][6] + v[it][7]));
+  }
+  const float mean = wave_sum(s) / (float)n;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    if (8 * lane + 512 * it < n) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[it][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)n + 1e-5f);
+  const float* ssrow = MOD ? ss + (row / rows_per_sample) * ss_ld : nullptr;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = 8 * lane + 512 * it;
+    if (c < n) {
+      float g[8], b[8], o[8];
+      ld8(gamma + c, g);
+      ld8(beta + c, b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[it][e] - mean) * rstd * g[e] + b[e];
+      if (MOD) {
+        float sc[8], sh[8];
+        ld8(ssrow + c, sc);
+        ld8(ssrow + shift_off + c, sh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = hig_silu(o[e] * (1.0f + sc[e]) + sh[e]);
+      }
+      *reinterpret_cast<bf16x8*>(out + row * ldo + c) =
+          bf16x8{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3], (__bf16)o[4], (__bf16)o[5], (__bf16)o[6], (__bf16)o[7]};
+    }
+  }
+}
+
+template <bool MOD, typename TIN>
+int launch_ln16(const TIN* x, int64_t ldx, int64_t rows, int n, const float* gamma, const float* beta, const float* ss,
+                int64_t ss_ld, int shift_off, int rows_per_sample, __bf16* out, int64_t ldo, hipStream_t st) {
+  const dim3 grid((unsigned)((rows + WAVES - 1) / WAVES));
+  if (n <= 512)
+    hipLaunchKernelGGL((ln16_kernel<1, MOD, TIN>), grid, dim3(256), 0, st, x, ldx, rows, n, gamma, beta, ss, ss_ld, shift_off,
+                       rows_per_sample, out, ldo);
+  else
+    hipLaunchKernelGGL((ln16_kernel<2, MOD, TIN>), grid, dim3(256), 0, st, x, ldx, rows, n, gamma, beta, ss, ss_ld, shift_off,
+                       rows_per_sample, out, ldo);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+}  // namespace
+
+extern "C" int hig_ln_bf16(const void* x, int32_t x_f32, int64_t ldx, int64_t rows, int32_t n, const float* gamma,
+                           const float* beta, const float* ss, int64_t ss_ld, int32_t ss_shift_off,
+                           int32_t rows_per_sample, void* out, int64_t ldo, hig_stream_t stream) {
+  HIG_REQUIRE(x && gamma && beta && out && rows >= 0 && n > 0, "hig_ln_bf16: bad arguments");
+  if (rows == 0) return HIG_OK;
+  HIG_REQUIRE(n % 8 == 0 && n <= 1024 && ldx % 8 == 0 && ldo % 8 == 0,
+              "hig_ln_bf16: n, ldx, ldo must be multiples of 8, n <= 1024");
+  HIG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(gamma) |
+                reinterpret_cast<uintptr_t>(beta)) & 15) == 0,
+              "hig_ln_bf16: buffers must be 16-byte aligned");
+  if (ss)
+    HIG_REQUIRE(rows_per_sample > 0 && ss_ld % 4 == 0 && ss_shift_off % 4 == 0 && (reinterpret_cast<uintptr_t>(ss) & 15) == 0,
+                "hig_ln_bf16: bad modulation arguments");
+  hipStream_t st = hig_stream(stream);
+  __bf16* o = static_cast<__bf16*>(out);
+  if (x_f32) {
+    const float* xf = static_cast<const float*>(x);
+    return ss ? launch_ln16<true, float>(xf, ldx, rows, n, gamma, beta, ss, ss_ld, ss_shift_off, rows_per_sample, o, ldo, st)
+              : launch_ln16<false, float>(xf, ldx, rows, n, gamma, beta, ss, ss_ld, ss_shift_off, rows_per_sample, o, ldo, st);
+  }
+  const __bf16* xb = static_cast<const __bf16*>(x);
+  return ss ? launch_ln16<true, __bf16>(xb, ldx, rows, n, gamma, beta, ss, ss_ld, ss_shift_off, rows_per_sample, o, ldo, st)
+            : launch_ln16<false, __bf16>(xb, ldx, rows, n, gamma, beta, ss, ss_ld, ss_shift_off, rows_per_sample, o, ldo, st);
+}

@@ -69,7 +69,14 @@ typedef struct hig_dims {
                          init-pose row (joint_embed2 on its first 4 features, out2), and each layer has the
                          person<->person linear cross-attention `int_ca_block` (:167-207).
                          2: the same with no_cross_attn=True (no int_ca_block). */
+  int32_t storage;    /* HIG_STORE_F32 (0): fp32 activations and weights.  HIG_STORE_BF16 (1): bf16 activations and a
+                         bf16 shadow of the weight matrices, fp32 accumulation / LayerNorm statistics / softmax /
+                         context matrices / modulation vectors -- BASELINE configs 3 and 5.  Inference only
+                         (hig_denoiser_fwd_bf16); linear attention, single-person model, head dim 64 or 128,
+                         d, ff, Lt multiples of 32. */
 } hig_dims;
+#define HIG_STORE_F32 0
+#define HIG_STORE_BF16 1
 
 /* Parameter table: an array of device pointers, HIG_NGLOBAL global entries followed by
  * HIG_NLAYER entries per decoder layer, in the order below.  The same table layout is used
@@ -158,6 +165,17 @@ int hig_denoiser_fwd(const hig_dims* dims, const void* const* params, const floa
                      const int64_t* t, const int64_t* length, const float* xf_proj,
                      const void* textctx, float* out, void* workspace, int training,
                      hig_stream_t stream);
+
+/* bf16-storage forward (dims->storage == HIG_STORE_BF16, inference).  `params` is the fp32 table above (biases,
+ * LayerNorm vectors and the F-wide input projection are read from it), `params16` the same table laid over the bf16
+ * shadow of the flat parameter buffer (hig_cast_bf16): entry k = shadow base + 2 x (offset of entry k in floats).
+ * x, xf_proj, xf_out and out stay fp32 (the DDPM state is carried in fp32); every activation in between is bf16.
+ * Workspace / text-context sizes: hig_workspace_bytes / hig_textctx_bytes with the same dims (training = 0). */
+int hig_text_context_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
+                          const float* xf_out, void* textctx, hig_stream_t stream);
+int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* params, const void* const* params16, const float* x,
+                          const int64_t* t, const int64_t* length, const float* xf_proj, const void* textctx,
+                          float* out, void* workspace, hig_stream_t stream);
 
 /* Backward of hig_denoiser_fwd(training=1) for d(out) = dout.  Writes (does not accumulate)
  * every entry of `grads` (same table layout as params; NULL entries are skipped is NOT
@@ -300,6 +318,8 @@ int hig_recover_joints(const float* motion, const float* stats, int32_t rows, in
 #define HIG_EPI_BIAS_POS 4  /* out = acc + bias + pos[i % T] (joint_embed + sequence_embedding) */
 #define HIG_EPI_RES 5       /* out = res + acc */
 #define HIG_EPI_DGELU 6     /* out = acc * gelu'(aux) */
+#define HIG_EPI_BIAS_SILU 7      /* out = silu(acc + bias)          (hig_gemm_bf16 only) */
+#define HIG_EPI_BIAS_RES_SILU 8  /* out = silu(res + acc + bias)    (hig_gemm_bf16 only) */
 /* Zero-initialise the descriptor (memset) and set what the chosen xf / epi need: optional pointers are tested
  * against NULL. */
 typedef struct hig_gemm_desc {
@@ -326,6 +346,37 @@ int hig_gemm(const hig_gemm_desc* g, hig_stream_t stream);
  * library's own rule (tiles x splits fills the chip).  slabs: >= hig_gemm_split_scratch_floats(g, splits) floats. */
 int64_t hig_gemm_split_scratch_floats(const hig_gemm_desc* g, int32_t splits);
 int hig_gemm_split(const hig_gemm_desc* g, int32_t splits, float* slabs, int64_t slab_floats, hig_stream_t stream);
+
+/* bf16-STORAGE GEMM (hig_dims.storage == HIG_STORE_BF16):  C[i][j] = epi( sum_r X[i][r] * Y[j][r] ) with X (I, ldx)
+ * and Y (J, ldy) bf16, both reduce-contiguous (activations x nn.Linear weight (out, in)), fp32 accumulation on
+ * v_mfma_f32_32x32x16_bf16, operand tiles DMA-ed global -> LDS (no register hop, no conversion).  R % 32 == 0,
+ * operands 16-byte aligned, ldx / ldy multiples of 8.  bias fp32 [J]; res / C bf16 or fp32 ([I][J], any ld; rows that
+ * are not 16-byte aligned fall back to element stores).  epi: HIG_EPI_NONE, _BIAS, _BIAS_GELU, _BIAS_RES, _BIAS_SILU,
+ * _BIAS_RES_SILU. */
+typedef struct hig_gemm16_desc {
+  const void* X; int64_t ldx;
+  const void* Y; int64_t ldy;
+  void* C; int64_t ldc; int32_t c_f32;          /* C stored as fp32 (1) or bf16 (0) */
+  int32_t I, J, R;
+  int32_t epi;
+  const float* bias;
+  const void* res; int64_t ldr; int32_t res_f32;
+} hig_gemm16_desc;
+int hig_gemm_bf16(const hig_gemm16_desc* g, hig_stream_t stream);
+/* dst[i] = bf16(src[i]) (round to nearest even): builds the bf16 shadow of the flat fp32 parameter buffer. */
+int hig_cast_bf16(const float* src, void* dst, int64_t n, hig_stream_t stream);
+
+/* bf16-storage row kernel: out (bf16) = LN(x) * gamma + beta, and with ss != NULL the stylization front
+ * silu(LN(x) * (1 + scale) + shift) (scale = ss[b][0..n), shift = ss[b][ss_shift_off ..), b = row / rows_per_sample).
+ * x bf16 (x_f32 == 0) or fp32 (x_f32 == 1); n % 8 == 0, n <= 1024. */
+int hig_ln_bf16(const void* x, int32_t x_f32, int64_t ldx, int64_t rows, int32_t n, const float* gamma,
+                const float* beta, const float* ss, int64_t ss_ld, int32_t ss_shift_off, int32_t rows_per_sample,
+                void* out, int64_t ldo, hig_stream_t stream);
+/* bf16-storage forms of hig_linattn_ctx / hig_linattn_apply (below): K, V, Q, Y bf16; A, kstat fp32; head dim 64 / 128. */
+int hig_linattn_ctx_bf16(const void* K, const void* V, int64_t ld, int32_t B, int32_t rows, int32_t H, int32_t hd,
+                         const int64_t* length, float* A, float* kstat, float* scratch, hig_stream_t stream);
+int hig_linattn_apply_bf16(const void* Q, int64_t ldq, const float* A, void* Y, int64_t ldy, int32_t B, int32_t rows,
+                           int32_t H, int32_t hd, hig_stream_t stream);
 
 /* Row statistics for LayerNorm: stats[m] = (mean, rstd) of x[m, :n], eps = 1e-5, biased var. */
 int hig_rowstats(const float* x, int64_t ldx, int64_t rows, int32_t n, float* stats,

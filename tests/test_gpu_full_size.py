@@ -79,8 +79,13 @@ def test_config2_size_backward_against_oracle_autograd():
     worst = max((rel(named[k].grad, p[k].grad), k) for k in checked)
     assert worst[0] < 1e-3, worst                     # the north-star gate
     assert worst[0] < 3e-4, worst                     # what fp32 accumulation over 12 544 rows delivers
-    # every parameter gradient, loosely (catches a tensor that was never written)
-    all_worst = max((rel(named[k].grad, p[k].grad), k) for k in names)
+    # every parameter gradient, loosely (catches a tensor that was never written).  The key biases have an exactly
+    # zero gradient (a per-channel constant drops out of the softmax over tokens, transformer.py:112,148): both sides
+    # hold rounding noise there, so they are held to "tiny" instead of to each other
+    zero_grad = [k for k in names if k.endswith(".key.bias")]
+    for k in zero_grad:
+        assert named[k].grad.norm().item() < 1e-5 * gn_ref and p[k].grad.norm().item() < 1e-5 * gn_ref, k
+    all_worst = max((rel(named[k].grad, p[k].grad), k) for k in names if k not in zero_grad)
     assert all_worst[0] < 2e-3, all_worst
 
 
