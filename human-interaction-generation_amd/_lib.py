@@ -16,7 +16,8 @@ NLAYER = 36
 ATTN_LINEAR, ATTN_FULL = 0, 1
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 XF_NONE, XF_LN, XF_LN_MOD_SILU, XF_SILU = 0, 1, 2, 3
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_BIAS_POS, EPI_RES, EPI_DGELU = range(7)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_BIAS_POS, EPI_RES, EPI_DGELU, EPI_BIAS_SILU, EPI_BIAS_RES_SILU = range(9)
+STORE_F32, STORE_BF16 = 0, 1
 TAB_ROWS = 7
 NORM_BLOCKS = 1024
 COLSUM_CHUNKS = 512
@@ -33,12 +34,15 @@ SYMBOLS = (
     "hig_layernorm", "hig_gather_rows", "hig_scatter_add_rows", "hig_gather_frames", "hig_recover_joints", "hig_transpose_batch", "hig_linattn_ctx_scratch_floats", "hig_pair_mse",
     "hig_fullattn_fwd_kpad", "hig_eval_encoder_workspace_bytes", "hig_eval_encoder_fwd",
     "hig_clip_adam_lrdev", "hig_shutdown", "hig_gemm_split", "hig_gemm_split_scratch_floats",
+    "hig_gemm_bf16", "hig_cast_bf16", "hig_ln_bf16", "hig_linattn_ctx_bf16", "hig_linattn_apply_bf16",
+    "hig_text_context_bf16", "hig_denoiser_fwd_bf16", "hig_linattn_apply_sty_bf16", "hig_denoiser_bwd_hooked",
 )
 
 
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("B", "T", "F", "d", "H", "ff", "L", "N", "Lt", "num_frames", "attn_kind", "prec", "two_person")]
+                ("B", "T", "F", "d", "H", "ff", "L", "N", "Lt", "num_frames", "attn_kind", "prec", "two_person",
+                 "storage")]
 
 
 class TextDims(C.Structure):
@@ -74,6 +78,20 @@ class GemmDesc(C.Structure):
     ]
 
 
+class Gemm16Desc(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("ldx", C.c_int64),
+        ("Y", C.c_void_p), ("ldy", C.c_int64),
+        ("C", C.c_void_p), ("ldc", C.c_int64), ("c_f32", C.c_int32),
+        ("I", C.c_int32), ("J", C.c_int32), ("R", C.c_int32),
+        ("epi", C.c_int32),
+        ("bias", C.c_void_p),
+        ("res", C.c_void_p), ("ldr", C.c_int64), ("res_f32", C.c_int32),
+    ]
+
+
+LAYER_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)
+
 _lib = None
 
 
@@ -97,6 +115,7 @@ def lib():
         L.hig_text_context.argtypes = [C.POINTER(Dims), vp, vp, vp, C.c_int, vp]
         L.hig_denoiser_fwd.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]
         L.hig_denoiser_bwd.argtypes = [C.POINTER(Dims)] + [vp] * 14
+        L.hig_denoiser_bwd_hooked.argtypes = [C.POINTER(Dims)] + [vp] * 14 + [LAYER_HOOK, vp, vp]
         L.hig_gemm.argtypes = [C.POINTER(GemmDesc), vp]
         L.hig_rowstats.argtypes = [vp, i64, i64, i32, vp, vp]
         L.hig_ln_mod_silu.argtypes = [vp, i64, i64, i32, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp]
@@ -128,6 +147,14 @@ def lib():
         L.hig_clip_adam.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, vp, vp, vp]
         L.hig_clip_adam_lrdev.argtypes = [vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, f32, vp, vp, vp, vp]
         L.hig_shutdown.argtypes = []
+        L.hig_gemm_bf16.argtypes = [C.POINTER(Gemm16Desc), vp]
+        L.hig_cast_bf16.argtypes = [vp, vp, i64, vp]
+        L.hig_ln_bf16.argtypes = [vp, i32, i64, i64, i32, vp, vp, vp, i64, i32, i32, vp, i64, vp]
+        L.hig_linattn_ctx_bf16.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+        L.hig_linattn_apply_bf16.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]
+        L.hig_linattn_apply_sty_bf16.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, vp, i64, i32, i32, i32, i32, vp]
+        L.hig_text_context_bf16.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, vp]
+        L.hig_denoiser_fwd_bf16.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.hig_gemm_split.argtypes = [C.POINTER(GemmDesc), i32, vp, i64, vp]
         L.hig_gemm_split_scratch_floats.restype = i64
         L.hig_gemm_split_scratch_floats.argtypes = [C.POINTER(GemmDesc), i32]

@@ -601,11 +601,31 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   float* kst1 = reinterpret_cast<float*>(ws + w.kst1);
   float* cscr = reinterpret_cast<float*>(ws + w.cscr);
   // one stylization block: h += Lin_out( silu( LN(y) (1 + scale) + shift ) )      (transformer.py:81-85)
+  auto sty_out = [&](int l, int out_w, int out_b) -> int {
+    return hig_gemm16_launch(G16(a, d, PL16(params16, l, out_w), d, h, d, M, d, d)
+                                 .epi(HIG_EPI_BIAS_RES, PL(params, l, out_b)).res16(h, d).g, st);
+  };
   auto stylize = [&](int l, int slot, int norm_w, int norm_b, int out_w, int out_b) -> int {
     const float* ssl = ss + (int64_t)(D.nsty * l + slot) * 2 * d;
     HIG_TRY(hig_ln_bf16(y, 0, d, M, d, PL(params, l, norm_w), PL(params, l, norm_b), ssl, ss_ld, d, D.T, a, d, stream));
-    return hig_gemm16_launch(G16(a, d, PL16(params16, l, out_w), d, h, d, M, d, d)
-                                 .epi(HIG_EPI_BIAS_RES, PL(params, l, out_b)).res16(h, d).g, st);
+    return sty_out(l, out_w, out_b);
+  };
+  // attention output -> stylization block.  With 4 or 8 heads the `y = q A` product, the LayerNorm, the modulation and
+  // the SiLU are ONE kernel (y never leaves the chip); otherwise apply + row kernel.
+  // (opt-in: measured equal at B = 64 and 4 % slower at B = 32 -- its fp32 MFMAs serialise 128 per wave behind poorly
+  // coalesced query loads; profiles/r02_notes.md)
+  static const int fuse_env = getenv("HIG_FUSE_APPLY") ? atoi(getenv("HIG_FUSE_APPLY")) : 0;   // tuning knob
+  const bool fuse_apply = fuse_env && (D.H == 4 || D.H == 8);
+  auto attend = [&](int l, int slot, const void* q, int64_t ldq, const float* ctx, int norm_w, int norm_b, int out_w,
+                    int out_b) -> int {
+    if (fuse_apply) {
+      const float* ssl = ss + (int64_t)(D.nsty * l + slot) * 2 * d;
+      HIG_TRY(hig_linattn_apply_sty_bf16(q, ldq, ctx, PL(params, l, norm_w), PL(params, l, norm_b), ssl, ss_ld, d, a, d,
+                                         D.B, D.T, D.H, D.hd, stream));
+      return sty_out(l, out_w, out_b);
+    }
+    HIG_TRY(hig_linattn_apply_bf16(q, ldq, ctx, y, d, D.B, D.T, D.H, D.hd, stream));
+    return stylize(l, slot, norm_w, norm_b, out_w, out_b);
   };
   for (int l = 0; l < D.L; ++l) {
     // ---- self attention (transformer.py:101-119) ----
@@ -614,15 +634,13 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_SA_QKV_B)).g, st));
     HIG_TRY(hig_linattn_ctx_bf16(qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, D.H, D.hd, length, A1, kst1,
                                  cscr, stream));
-    HIG_TRY(hig_linattn_apply_bf16(qkv, 3 * d, A1, y, d, D.B, D.T, D.H, D.hd, stream));
-    HIG_TRY(stylize(l, 0, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B));
+    HIG_TRY(attend(l, 0, qkv, 3 * d, A1, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B));
     // ---- cross attention to the text context (transformer.py:135-155) ----
     HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B), nullptr, 0, 0, 0, xn, d, stream));
     HIG_TRY(hig_gemm16_launch(G16(xn, d, PL16(params16, l, HIG_L_CA_Q_W), d, qc, d, M, d, d)
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).g, st));
-    HIG_TRY(hig_linattn_apply_bf16(qc, d, reinterpret_cast<const float*>(tc + tl.layer0 + tl.lstride * l + tl.Ac), y, d,
-                                   D.B, D.T, D.H, D.hd, stream));
-    HIG_TRY(stylize(l, 1, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B));
+    HIG_TRY(attend(l, 1, qc, d, reinterpret_cast<const float*>(tc + tl.layer0 + tl.lstride * l + tl.Ac),
+                   HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B));
     // ---- FFN (transformer.py:167-170) ----
     HIG_TRY(hig_gemm16_launch(G16(h, d, PL16(params16, l, HIG_L_FFN_W1), d, f1, D.ff, M, D.ff, d)
                                   .epi(HIG_EPI_BIAS_GELU, PL(params, l, HIG_L_FFN_B1)).g, st));
@@ -660,6 +678,11 @@ constexpr int kMaxDev = 16;
 SideStream* side_stream_table() {
   static thread_local SideStream tab[kMaxDev];
   return tab;
+}
+
+hipEvent_t& layer_event() {   // hig_denoiser_bwd_hooked: "layer l is enqueued" marker on the caller's stream
+  static thread_local hipEvent_t ev = nullptr;
+  return ev;
 }
 
 SideStream* side_stream_for_current_device(hipStream_t caller) {
@@ -734,6 +757,10 @@ extern "C" int hig_shutdown(void) {
     if (s.s2) (void)hipStreamDestroy(s.s2);
     s = SideStream();
   }
+  if (layer_event()) {
+    (void)hipEventDestroy(layer_event());
+    layer_event() = nullptr;
+  }
   if (have_cur) (void)hipSetDevice(cur);
   return rc;
 }
@@ -743,6 +770,16 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                                 const void* textctx, const void* workspace, const float* dout,
                                 void* const* grads, float* dx, float* dxf_proj, float* dxf_out,
                                 void* bwd_workspace, hig_stream_t stream) {
+  return hig_denoiser_bwd_hooked(dims, params, x, t, length, xf_out, textctx, workspace, dout, grads, dx, dxf_proj, dxf_out,
+                                 bwd_workspace, stream, nullptr, nullptr, nullptr);
+}
+
+extern "C" int hig_denoiser_bwd_hooked(const hig_dims* dims, const void* const* params, const float* x,
+                                       const int64_t* t, const int64_t* length, const float* xf_out,
+                                       const void* textctx, const void* workspace, const float* dout,
+                                       void* const* grads, float* dx, float* dxf_proj, float* dxf_out,
+                                       void* bwd_workspace, hig_stream_t stream, hig_layer_hook hook, void* hook_user,
+                                       hig_stream_t comm_stream) {
   (void)t;
   Dims D;
   HIG_TRY(check_dims(dims, D));
@@ -967,6 +1004,26 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
                        nullptr, 0, 0, 0, dh, d, dh_alt, d, M, d, D.T, GL(grads, l, HIG_L_SA_NORM_W),
                        GL(grads, l, HIG_L_SA_NORM_B), nullptr, 0, lnp, stream));
     { float* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h_in of this layer)
+    if (hook) {
+      // Every parameter gradient of layer l exists once this layer's stylization `emb_layers.1.weight` rows are
+      // done too (they only need this layer's columns of dss): d(W_emb)[l] = dss[:, l]^T . silu(emb), one more request on
+      // the weight-gradient stream.  Then `comm_stream` is made to wait for both streams and the caller is told: it
+      // can start exchanging layer l's gradients while layers l-1 ... 0 are still in backward.
+      const int64_t rows_l = (int64_t)D.nsty * 2 * d;
+      HIG_TRY(wgrad(G(dss + (int64_t)l * rows_l, ss_ld, 1, ws + w.emb, E, 1, GP(grads, HIG_P_STY_EMB_W) + (int64_t)l * rows_l * E, E,
+                      rows_l, E, D.B).silu(1)));
+      if (comm_stream) {
+        hipStream_t cs = hig_stream(comm_stream);
+        hipEvent_t& ev_layer = layer_event();
+        if (!ev_layer && hipEventCreateWithFlags(&ev_layer, hipEventDisableTiming) != hipSuccess)
+          return hig_set_error(HIG_EHIP, "hipEventCreate failed");
+        if (hipEventRecord(ev_layer, st) != hipSuccess || hipStreamWaitEvent(cs, ev_layer, 0) != hipSuccess)
+          return hig_set_error(HIG_EHIP, "layer hook: event on the caller's stream failed");
+        if (fork.side && fork.k > 0 && hipStreamWaitEvent(cs, fork.side->done[(fork.k - 1) & 3], 0) != hipSuccess)
+          return hig_set_error(HIG_EHIP, "layer hook: event on the weight-gradient stream failed");
+      }
+      hook(hook_user, l);
+    }
   }
 
   // ---- joint_embed + sequence_embedding ------------------------------------------------
@@ -1005,7 +1062,8 @@ extern "C" int hig_denoiser_bwd(const hig_dims* dims, const void* const* params,
   HIG_TRY(fork.join());   // every weight gradient is done (and the slabs are free) from here on
   const float* emb = ws + w.emb;
   HIG_TRY(colsum(dss, ss_ld, D.B, (int)ss_ld, GP(grads, HIG_P_STY_EMB_B)));
-  HIG_TRY(hig_gemm_launch(G(dss, ss_ld, 1, emb, E, 1, GP(grads, HIG_P_STY_EMB_W), E, ss_ld, E, D.B).silu(1).g, 1, nullptr, st));
+  if (!hook)   // (with a layer hook the rows of each layer were produced inside that layer's backward)
+    HIG_TRY(hig_gemm_launch(G(dss, ss_ld, 1, emb, E, 1, GP(grads, HIG_P_STY_EMB_W), E, ss_ld, E, D.B).silu(1).g, 1, nullptr, st));
   {
     G gd(dss, ss_ld, 0, P(params, HIG_P_STY_EMB_W), E, 1, b + bw.dtmp, E, D.B, E, ss_ld);
     int s = (int)(ss_ld / 1024);

@@ -34,6 +34,8 @@ struct K16Args {
   hig_gemm16_desc g;
   int nbj, ntiles;
   int vec;          // C / res rows allow 16-byte (bf16) / 32-byte (fp32) row pieces
+  int dbg;          // timing ablations (HIG_BF16_DBG; results are wrong): 1 = no DMA after the first k-tile,
+                    // 2 = no epilogue, 4 = no MFMA, 8 = epilogue without global stores / residual loads
 };
 
 __device__ __forceinline__ void glds16(const __bf16* src, char* lds_wave_base) {
@@ -41,15 +43,32 @@ __device__ __forceinline__ void glds16(const __bf16* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Exact-erf GELU (nn.GELU(), transformer.py:160) for a result that is rounded to bf16 (2^-9) right away: erf by
+// Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7: one exp, one rcp, five FMAs) instead of the 30-instruction libm erff --
+// the epilogue's VALU work was 10 of the 43 us of the FFN linear1 launch (profiles/r02_notes.md).
+__device__ __forceinline__ float gelu_bf16(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
 template <int EPI>
 __device__ __forceinline__ float epi_act(float v) {
-  if (EPI == HIG_EPI_BIAS_GELU) return hig_gelu(v);
+  if (EPI == HIG_EPI_BIAS_GELU) return gelu_bf16(v);
   if (EPI == HIG_EPI_BIAS_SILU || EPI == HIG_EPI_BIAS_RES_SILU) return hig_silu(v);
   return v;
 }
 
-// WM x WN waves, each 64 x (32 TJ):  BM = 64 WM, BN = 32 TJ WN.
-template <int WM, int TJ, int BK, int EPI>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// WM x WN waves, each 64 x (32 TJ):  BM = 64 WM, BN = 32 TJ WN.  NS LDS stages of one BK-deep k-tile each: the DMA runs
+// NS-1 k-tiles ahead of the MFMAs (ring of buffers, ONE raw s_barrier per k-tile, counted vmcnt so that the younger
+// k-tiles stay in flight across the barrier -- a __syncthreads() here would drain them, guide "Pipelining across
+// barriers").
+template <int WM, int TJ, int BK, int NS, int EPI>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
   constexpr int WN = 4 / WM, TI = 2;
   constexpr int BM = 64 * WM, BN = 32 * TJ * WN;
@@ -59,7 +78,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
   static_assert((NA + NB) % 4 == 0, "DMA instructions must split evenly over the 4 waves");
   constexpr int CLD = BN + 4;
   constexpr int EPI_BYTES = 64 * CLD * 4;
-  constexpr int SMEM = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+  constexpr int SMEM = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   const hig_gemm16_desc& g = a.g;
@@ -113,6 +132,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
       }
     };
 
+    // The epilogue's per-thread bias columns are fetched NOW: every VGPR-returning load of a tile is then retired by
+    // the compiler-visible wait of the barrier that ends the main loop.  (A VGPR load still "pending" in hipcc's
+    // scoreboard when the next tile starts makes it guard the first reuse of that register with s_waitcnt vmcnt(0) --
+    // inside the main loop, where it drains the DMA ring every k-tile.)
+    constexpr int Q8 = BN / 8, RPP = NT / Q8;          // epilogue: 8-column pieces per row, rows per sweep
+    const int c8 = tid % Q8, rr0 = tid / Q8;
+    const int j = j0 + 8 * c8;
+    float b8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b8[e] = (EPI != HIG_EPI_NONE) ? g.bias[min(j + e, g.J - 1)] : 0.f;
+
     f32x16 acc[TJ][TI];
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj)
@@ -121,12 +151,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[tj][ti][e] = 0.f;
 
-    if (nk > 0) stage(0);
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+      if (p < nk) stage(p);
+    int cur = 0, nxt = NS - 1;                            // ring positions of k-tile kt and of k-tile kt + NS - 1
     for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of k-tile kt has landed in LDS
-      __syncthreads();                                    // ... everyone's has; and buffer (kt+1)&1 is no longer read
-      if (kt + 1 < nk) stage((kt + 1) & 1);
-      const char* sb = smem + (kt & 1) * STAGE;
+      // this wave's share of k-tile kt has landed once at most the NS-2 younger k-tiles' DMAs are outstanding
+      if (kt + NS - 2 < nk) wait_vmcnt<(NS - 2) * NQ>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();                       // everyone's share has; and k-tile kt-1's buffer is free
+      asm volatile("" ::: "memory");
+      if (kt + NS - 1 < nk && !(a.dbg & 1)) stage(nxt);
+      const char* sb = smem + cur * STAGE;
+      cur = cur + 1 == NS ? 0 : cur + 1;
+      nxt = nxt + 1 == NS ? 0 : nxt + 1;
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
         bf16x8 xf[TI], yf[TJ];
@@ -136,6 +173,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
 #pragma unroll
         for (int tj = 0; tj < TJ; ++tj)
           yf[tj] = *reinterpret_cast<const bf16x8*>(sb + yoff[tj] + 16 * ((2 * ks + lh) ^ ysw[tj]));
+        if (a.dbg & 4) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[0][0][e] += (float)xf[0][e] + (float)yf[0][e] + (float)xf[1][e] + (float)yf[TJ - 1][e];
+          continue;
+        }
 #pragma unroll
         for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
@@ -143,18 +185,35 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
             acc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[tj], xf[ti], acc[tj][ti], 0, 0, 0);
       }
     }
-    __syncthreads();   // all MFMA reads of the staging buffers are done: reuse them for the output tile
+    __syncthreads();   // all MFMA reads of the staging buffers are done (no DMA in flight): reuse them for the output tile
 
     // ---- epilogue: one 64-row pass per wave row, through LDS (fp32), out as whole rows -------------------
+    if (a.dbg & 2) {
+      if (acc[0][0][0] + acc[TJ - 1][1][3] == 123.456f) static_cast<float*>(g.C)[0] = b8[0];
+      continue;
+    }
     float* sC = reinterpret_cast<float*>(smem);
-    constexpr int Q8 = BN / 8, RPP = NT / Q8;          // 8-column pieces per row, rows per sweep
-    const int c8 = tid % Q8, rr0 = tid / Q8;
-    const int j = j0 + 8 * c8;
-    float b8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) b8[e] = (EPI != HIG_EPI_NONE && j + e < g.J) ? g.bias[j + e] : 0.f;
+    constexpr int NSW = 64 / RPP;                      // row sweeps per pass
+    constexpr bool HAS_RES = EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU;
+    const bool full = a.vec && j + 8 <= g.J;
+    // LDS-only barrier: the output stores of one pass stay in flight across it (a __syncthreads() would wait vmcnt(0)
+    // for them twice per tile: 16 of 43 us at the FFN shape, profiles/r02_notes.md)
+    auto lds_barrier = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
 #pragma unroll
     for (int ps = 0; ps < WM; ++ps) {
+      // the bf16 residual rows of this pass are requested first: their latency hides under the LDS staging + barrier
+      bf16x8 r16[NSW];
+      if (HAS_RES && full && !g.res_f32) {
+#pragma unroll
+        for (int sw = 0; sw < NSW; ++sw) {
+          const int i = min(i0 + 64 * ps + rr0 + RPP * sw, g.I - 1);
+          r16[sw] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(g.res) + (int64_t)i * g.ldr + j);
+        }
+      }
       if (wi == ps) {
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti)
@@ -165,17 +224,22 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
               *reinterpret_cast<f32x4*>(sC + (32 * ti + lr) * CLD + wj * (32 * TJ) + 32 * tj + 8 * q + 4 * lh) =
                   f32x4{acc[tj][ti][4 * q], acc[tj][ti][4 * q + 1], acc[tj][ti][4 * q + 2], acc[tj][ti][4 * q + 3]};
       }
-      __syncthreads();
-      for (int rr = rr0; rr < 64; rr += RPP) {
+      lds_barrier();
+#pragma unroll
+      for (int sw = 0; sw < NSW; ++sw) {
+        const int rr = rr0 + RPP * sw;
         const int i = i0 + 64 * ps + rr;
-        if (i >= g.I || j >= g.J) break;
+        if (i >= g.I || j >= g.J) continue;
         float v[8];
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(sC + rr * CLD + 8 * c8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(sC + rr * CLD + 8 * c8 + 4);
         v[0] = v0.x + b8[0]; v[1] = v0.y + b8[1]; v[2] = v0.z + b8[2]; v[3] = v0.w + b8[3];
         v[4] = v1.x + b8[4]; v[5] = v1.y + b8[5]; v[6] = v1.z + b8[6]; v[7] = v1.w + b8[7];
-        const bool full = a.vec && j + 8 <= g.J;
-        if (EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU) {
+        if (a.dbg & 8) {
+          if (v[0] + v[7] == 123.456f) static_cast<float*>(g.C)[0] = v[3];
+          continue;
+        }
+        if (HAS_RES) {
           if (g.res_f32) {
             const float* rp = static_cast<const float*>(g.res) + (int64_t)i * g.ldr + j;
             if (full) {
@@ -185,16 +249,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) if (j + e < g.J) v[e] += rp[e];
             }
+          } else if (full) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)r16[sw][e];
           } else {
             const __bf16* rp = static_cast<const __bf16*>(g.res) + (int64_t)i * g.ldr + j;
-            if (full) {
-              const bf16x8 r = *reinterpret_cast<const bf16x8*>(rp);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
-            } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) if (j + e < g.J) v[e] += (float)rp[e];
-            }
+            for (int e = 0; e < 8; ++e) if (j + e < g.J) v[e] += (float)rp[e];
           }
         }
 #pragma unroll
@@ -219,12 +280,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
           }
         }
       }
-      __syncthreads();   // sC is rewritten by the next pass / the next tile's DMA
+      lds_barrier();   // sC is rewritten by the next pass / the next tile's DMA
     }
   }
 }
 
-template <int WM, int TJ, int BK, int EPI>
+template <int WM, int TJ, int BK, int NS, int EPI>
 int launch16(const hig_gemm16_desc& g, hipStream_t st) {
   constexpr int WN = 4 / WM, BM = 64 * WM, BN = 32 * TJ * WN;
   K16Args a;
@@ -235,32 +296,53 @@ int launch16(const hig_gemm16_desc& g, hipStream_t st) {
   auto al = [](const void* p, int n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
   a.vec = (g.c_f32 ? (g.ldc % 4 == 0 && al(g.C, 16)) : (g.ldc % 8 == 0 && al(g.C, 16)));
   if (g.res) a.vec = a.vec && (g.res_f32 ? (g.ldr % 4 == 0 && al(g.res, 16)) : (g.ldr % 8 == 0 && al(g.res, 16)));
-  constexpr int lds = 2 * (BM + BN) * BK * 2;
+  constexpr int lds = NS * (BM + BN) * BK * 2;
   int per_cu = 160 * 1024 / (lds > 64 * (BN + 4) * 4 ? lds : 64 * (BN + 4) * 4);
   if (per_cu > 4) per_cu = 4;
   static const int forced_per_cu = getenv("HIG_BF16_PERCU") ? atoi(getenv("HIG_BF16_PERCU")) : 0;   // tuning knob
   if (forced_per_cu > 0) per_cu = forced_per_cu;
+  static const int dbg = getenv("HIG_BF16_DBG") ? atoi(getenv("HIG_BF16_DBG")) : 0;
+  a.dbg = dbg;
   int grid = 256 * per_cu;
   if (grid > a.ntiles) grid = a.ntiles;
-  hipLaunchKernelGGL((gemm_bf16_kernel<WM, TJ, BK, EPI>), dim3(grid), dim3(NT), 0, st, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<WM, TJ, BK, NS, EPI>), dim3(grid), dim3(NT), 0, st, a);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
 
+// Tile choice.  Every launch of this model is a short-K problem (K = 256 ... 2048): per-tile fixed costs (first DMA,
+// epilogue) and the number of ROUNDS the tiles take on the chip decide, not the MFMA rate.  Candidates: 128 x 128 and
+// 128 x 192 (2 resident workgroups per CU = 512 slots), 64 x 128 (3 per CU = 768 slots).  Rule: fewest rounds; among
+// equals the larger tile when it still gives every CU a workgroup, else the smaller one (more CUs busy).
 template <int EPI>
 int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
-  // 128 x 128 tiles once they fill the chip twice over (2 resident workgroups per CU), else 64 x 128: more, shorter
-  // workgroups (3 per CU) for the M = B*T <= 6272-row launches and the few-row (B-row) GEMMs
-  static const int forced = getenv("HIG_BF16_TILE") ? atoi(getenv("HIG_BF16_TILE")) : 0;   // tuning knob: 64 / 128
-  static const int thr = getenv("HIG_BF16_THR") ? atoi(getenv("HIG_BF16_THR")) : 512;      // tuning knob
-  const int64_t t128 = (int64_t)((g.I + 127) / 128) * ((g.J + 127) / 128);
-  const bool big = forced ? forced == 128 : t128 >= thr;
-  if (g.R % 64 == 0) {
-    if (big) return launch16<2, 2, 64, EPI>(g, st);
-    return launch16<1, 1, 64, EPI>(g, st);
+  static const int forced = getenv("HIG_BF16_TILE") ? atoi(getenv("HIG_BF16_TILE")) : 0;   // tuning knob: 64 / 128 / 192
+  auto tiles = [&](int bm, int bn) { return (int64_t)((g.I + bm - 1) / bm) * ((g.J + bn - 1) / bn); };
+  auto rounds = [](int64_t t, int slots) { return (t + slots - 1) / slots; };
+  const int64_t t128 = tiles(128, 128), t192 = tiles(128, 192), t64 = tiles(64, 128);
+  const bool fits192 = g.J % 192 == 0 || g.J >= 1536;
+  int pick = 64;
+  if (forced) {
+    pick = forced;
+  } else {
+    // estimated time = rounds x relative cost of one tile (area ratio, with the smaller tiles' worse fixed-cost share)
+    // (fitted to tools/gemm16_bench.py at M = 6272 and 12544, profiles/r02_notes.md: a 64 x 128 tile costs 0.75 of a
+    // 128 x 128 one, not the 0.5 of its area -- it re-reads the same weight panel for half the rows)
+    const double c128 = (double)rounds(t128, 512) * 1.0, c192 = (double)rounds(t192, 512) * 1.45,
+                 c64 = (double)rounds(t64, 768) * 0.75;
+    pick = 128;
+    double best = c128;
+    if (t128 < 256 && c64 <= best * 1.25) { pick = 64; best = c64; }        // too few big tiles to occupy the chip
+    else if (c64 < best) { pick = 64; best = c64; }
+    if (fits192 && c192 < best) { pick = 192; best = c192; }
   }
-  if (big) return launch16<2, 2, 32, EPI>(g, st);
-  return launch16<1, 1, 32, EPI>(g, st);
+  if (g.R % 64 == 0) {
+    if (pick == 192) return launch16<2, 3, 64, 2, EPI>(g, st);
+    if (pick == 128) return launch16<2, 2, 64, 2, EPI>(g, st);
+    return launch16<1, 1, 64, 2, EPI>(g, st);
+  }
+  if (pick != 64) return launch16<2, 2, 32, 3, EPI>(g, st);
+  return launch16<1, 1, 32, 3, EPI>(g, st);
 }
 
 __global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int64_t n) {

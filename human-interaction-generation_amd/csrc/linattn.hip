@@ -1231,6 +1231,142 @@ extern "C" int hig_linattn_apply(const float* Q, int64_t ldq, const float* A, fl
   return HIG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// apply + stylization front in ONE kernel (bf16 storage):
+//     a[m, :] = silu( LN_d( y[m, :] ) * (1 + scale[b]) + shift[b] ),   y[m, h*HD + l] = sum_c softmax_c(Q[m, h*HD + :])[c] A[b,h][c][l]
+// (transformer.py:111,116-118 followed by :81-85).  A workgroup owns 32 rows of one sample for ALL heads: wave w keeps
+// the heads w*H/4 ... of y in its accumulators (fp32 MFMA 32x32x2, the context slab of the current head staged in a
+// wave-private LDS buffer), the LayerNorm statistics are folded across lanes / waves, and only `a` reaches HBM -- the
+// (rows x d) round trip of y and one launch per attention are gone.
+// ---------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void apply_sty16_kernel(const __bf16* __restrict__ Q, int64_t ldq,
+                                                          const float* __restrict__ A, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ ss,
+                                                          int64_t ss_ld, int shift_off, __bf16* __restrict__ Out,
+                                                          int64_t ldo, int rows, int H, int nblk) {
+  constexpr int TB = HD / 32;            // 32-column blocks per head
+  constexpr int KC = 4096 / HD;          // context channels per 16 KiB slab
+  constexpr int MAXHPW = 2;              // heads per wave (H <= 8)
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  float* sA = reinterpret_cast<float*>(smem_dyn);          // [4 waves][KC][HD]
+  __shared__ float red[2][4][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, kk = lane >> 5;
+  const int b = blockIdx.x / nblk, r0 = (blockIdx.x % nblk) * 32;
+  const int HPW = H / 4;
+  const int d = H * HD;
+  const int row = min(r0 + lr, rows - 1);
+  const __bf16* qrow = Q + ((int64_t)b * rows + row) * ldq;
+  float* sAw = sA + wave * (KC * HD);
+
+  f32x16 acc[MAXHPW][TB];
+#pragma unroll
+  for (int hh = 0; hh < MAXHPW; ++hh)
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) zero16(acc[hh][tb]);
+
+#pragma unroll
+  for (int hh = 0; hh < MAXHPW; ++hh) {
+    if (hh >= HPW) break;
+    const int h = wave * HPW + hh;
+    // this lane's share of the query row: channels 8ks + 4kk + j (the MFMA k order), softmax over all HD channels
+    float4 q[HD / 8];
+    float m = -INFINITY;
+#pragma unroll
+    for (int ks = 0; ks < HD / 8; ++ks) {
+      q[ks] = ld4(qrow + h * HD + 8 * ks + 4 * kk);
+      m = fmaxf(m, fmaxf(fmaxf(q[ks].x, q[ks].y), fmaxf(q[ks].z, q[ks].w)));
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < HD / 8; ++ks) {
+      q[ks].x = __expf(q[ks].x - m); q[ks].y = __expf(q[ks].y - m); q[ks].z = __expf(q[ks].z - m); q[ks].w = __expf(q[ks].w - m);
+      sum += (q[ks].x + q[ks].y) + (q[ks].z + q[ks].w);
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    const float* Ah = A + ((int64_t)b * H + h) * HD * HD;
+#pragma unroll
+    for (int c0 = 0; c0 < HD; c0 += KC) {
+      // stage context rows c0 .. c0+KC of this head: KC x HD floats = 16 KiB = 16 float4 per lane (wave-private buffer:
+      // LDS operations of one wave complete in order, no barrier needed)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        reinterpret_cast<float4*>(sAw)[lane + 64 * i] = reinterpret_cast<const float4*>(Ah + c0 * HD)[lane + 64 * i];
+#pragma unroll
+      for (int ks = c0 / 8; ks < (c0 + KC) / 8; ++ks) {
+        const float4 qv = q[ks];
+        const float* ap = sAw + (8 * ks + 4 * kk - c0) * HD + lr;
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+          acc[hh][tb] = mfma4(acc[hh][tb], ap[32 * tb], ap[HD + 32 * tb], ap[2 * HD + 32 * tb], ap[3 * HD + 32 * tb],
+                              make_float4(qv.x * inv, qv.y * inv, qv.z * inv, qv.w * inv));
+      }
+    }
+  }
+  // ---- LayerNorm statistics of row lr over all d columns: lane -> lane pair -> the 4 waves ----
+  float s = 0.f;
+#pragma unroll
+  for (int hh = 0; hh < MAXHPW; ++hh)
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s += acc[hh][tb][e];      // (zero for hh >= HPW)
+  s += __shfl_xor(s, 32, 64);
+  if (kk == 0) red[0][wave][lr] = s;
+  __syncthreads();
+  const float mean = ((red[0][0][lr] + red[0][1][lr]) + (red[0][2][lr] + red[0][3][lr])) / (float)d;
+  float qd = 0.f;
+#pragma unroll
+  for (int hh = 0; hh < MAXHPW; ++hh) {
+    if (hh >= HPW) break;
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float dv = acc[hh][tb][e] - mean;
+        qd += dv * dv;
+      }
+  }
+  qd += __shfl_xor(qd, 32, 64);
+  if (kk == 0) red[1][wave][lr] = qd;
+  __syncthreads();     // (also: every wave is done with its context slabs -- the LDS is reused for the output tile)
+  const float rstd = rsqrtf(((red[1][0][lr] + red[1][1][lr]) + (red[1][2][lr] + red[1][3][lr])) / (float)d + 1e-5f);
+  // ---- modulate + SiLU, staged as a bf16 [32][d] tile (row stride d + 8 elements), out as whole rows ----
+  __bf16* sO = reinterpret_cast<__bf16*>(smem_dyn);
+  const int ldso = d + 8;
+  const float* ssrow = ss + (int64_t)b * ss_ld;
+#pragma unroll
+  for (int hh = 0; hh < MAXHPW; ++hh) {
+    if (hh >= HPW) break;
+    const int h = wave * HPW + hh;
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int col = h * HD + 32 * tb + 8 * qq + 4 * kk;
+        const float4 g4 = *reinterpret_cast<const float4*>(gamma + col), b4 = *reinterpret_cast<const float4*>(beta + col);
+        const float4 sc = *reinterpret_cast<const float4*>(ssrow + col), sh = *reinterpret_cast<const float4*>(ssrow + shift_off + col);
+        float4 o;
+        o.x = hig_silu(((acc[hh][tb][4 * qq] - mean) * rstd * g4.x + b4.x) * (1.0f + sc.x) + sh.x);
+        o.y = hig_silu(((acc[hh][tb][4 * qq + 1] - mean) * rstd * g4.y + b4.y) * (1.0f + sc.y) + sh.y);
+        o.z = hig_silu(((acc[hh][tb][4 * qq + 2] - mean) * rstd * g4.z + b4.z) * (1.0f + sc.z) + sh.z);
+        o.w = hig_silu(((acc[hh][tb][4 * qq + 3] - mean) * rstd * g4.w + b4.w) * (1.0f + sc.w) + sh.w);
+        st4(sO + lr * ldso + col, o);
+      }
+  }
+  __syncthreads();
+  const int c16 = d / 8;                       // 16-byte chunks per row
+  for (int idx = tid; idx < 32 * c16; idx += 256) {
+    const int rr = idx / c16, ch = idx % c16;
+    if (r0 + rr < rows)
+      *reinterpret_cast<uint4*>(Out + ((int64_t)b * rows + r0 + rr) * ldo + 8 * ch) =
+          *reinterpret_cast<const uint4*>(sO + rr * ldso + 8 * ch);
+  }
+}
+
 // bf16-storage forms (hig_dims.storage == HIG_STORE_BF16): K / V / Q / Y are bf16, the context matrices and the
 // softmax statistics stay fp32.  Head dim 64 or 128 (the MFMA kernels).
 extern "C" int hig_linattn_ctx_bf16(const void* K, const void* V, int64_t ld, int32_t B, int32_t rows, int32_t H,
@@ -1334,6 +1470,48 @@ extern "C" int hig_linattn_ctx_bwd(const float* dA, const float* A, const float*
   HIG_CHECK_LAUNCH();
   HD_SWITCH(hd, hipLaunchKernelGGL((ctx_bwd_finish_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0,
                                    hig_stream(stream), K, ld, kstat, length, dK, ldd, rows, H, scratch));
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+// Fused apply + stylization front (bf16 storage): Out = silu( LN(softmax_hd(Q) . A) * (1 + scale) + shift ), see
+// apply_sty16_kernel.  H must be 4 or 8, head dim 64 or 128; gamma / beta / ss fp32, 16-byte aligned.
+extern "C" int hig_linattn_apply_sty_bf16(const void* Q, int64_t ldq, const float* A, const float* gamma,
+                                          const float* beta, const float* ss, int64_t ss_ld, int32_t ss_shift_off,
+                                          void* Out, int64_t ldo, int32_t B, int32_t rows, int32_t H, int32_t hd,
+                                          hig_stream_t stream) {
+  HIG_REQUIRE(Q && A && gamma && beta && ss && Out && B > 0 && rows > 0, "hig_linattn_apply_sty_bf16: bad arguments");
+  if ((hd != 64 && hd != 128) || (H != 4 && H != 8))
+    return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn_apply_sty_bf16: built for head dim 64 / 128 and 4 or 8 heads (got %d, %d)", hd, H);
+  HIG_REQUIRE(ldq % 4 == 0 && ldo % 8 == 0 && ss_ld % 4 == 0 && ss_shift_off % 4 == 0 &&
+                  ((reinterpret_cast<uintptr_t>(Q) & 7) | (reinterpret_cast<uintptr_t>(Out) & 15) |
+                   (reinterpret_cast<uintptr_t>(gamma) & 15) | (reinterpret_cast<uintptr_t>(beta) & 15) |
+                   (reinterpret_cast<uintptr_t>(ss) & 15)) == 0,
+              "hig_linattn_apply_sty_bf16: alignment");
+  const int nblk = (rows + 31) / 32;
+  const int d = H * hd;
+  size_t lds = 4 * 4096 * sizeof(float);
+  const size_t lds_out = (size_t)32 * (d + 8) * 2;
+  if (lds_out > lds) lds = lds_out;
+  hipStream_t st = hig_stream(stream);
+  const __bf16* q = static_cast<const __bf16*>(Q);
+  __bf16* o = static_cast<__bf16*>(Out);
+  static const int big_lds_rc = [] {   // 64 KiB of context slabs (+ the statistics) exceed the default dynamic-LDS cap
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&apply_sty16_kernel<64>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&apply_sty16_kernel<128>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : 1;
+  }();
+  if (big_lds_rc != 0 || lds > 80 * 1024)
+    return hig_set_error(HIG_EHIP, "hig_linattn_apply_sty_bf16: cannot reserve %zu bytes of LDS", lds);
+  if (hd == 64) {
+    hipLaunchKernelGGL(apply_sty16_kernel<64>, dim3(B * nblk), dim3(256), lds, st, q, ldq, A, gamma, beta, ss, ss_ld, ss_shift_off, o,
+                       ldo, rows, H, nblk);
+  } else {
+    hipLaunchKernelGGL(apply_sty16_kernel<128>, dim3(B * nblk), dim3(256), lds, st, q, ldq, A, gamma, beta, ss, ss_ld, ss_shift_off, o,
+                       ldo, rows, H, nblk);
+  }
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

@@ -247,6 +247,40 @@ class _FlatParams:
             arr[i] = self.grad.data_ptr() + 4 * next(it) if present else None
         return arr
 
+    def layer_buckets(self, num_layers, nsty, d, E):
+        """Element ranges [(start, stop), ...] of the flat gradient that are FINAL when decoder layer l's backward is
+        done (`per_layer[l]`: the layer's own parameters + its rows of the stacked stylization emb_layers.1.weight), and
+        the ranges that are only final at the end of the backward (`tail`: the global parameters)."""
+        ng, nl = _lib.NGLOBAL, _lib.NLAYER
+        offs = self.group_offsets
+
+        def first_of_layer(l):
+            return next(o for o in offs[ng + l * nl: ng + (l + 1) * nl] if o is not None)
+
+        starts = [first_of_layer(l) for l in range(num_layers)] + [self.core_numel]
+        o_w = offs[7]                                    # HIG_P_STY_EMB_W
+        rows = nsty * 2 * d * E
+        per_layer = [[(starts[l], starts[l + 1]), (o_w + l * rows, o_w + (l + 1) * rows)] for l in range(num_layers)]
+        tail = [(0, o_w), (o_w + num_layers * rows, starts[0])]
+        return per_layer, tail
+
+    def shadow16(self, version):
+        """bf16 shadow of the flat buffer (same offsets, 2 bytes per element) and its pointer table, rebuilt by one
+        cast kernel whenever `version` (the caller's view of "the parameters changed") moves."""
+        if getattr(self, "_shadow", None) is None or self._shadow.data_ptr() != getattr(self, "_shadow_ptr", None):
+            self._shadow = torch.empty(self.core_numel, device=self.flat.device, dtype=torch.bfloat16)
+            self._shadow_ptr = self._shadow.data_ptr()
+            n = len(self.group_offsets)
+            self._stable = (C.c_void_p * n)()
+            for i, off in enumerate(self.group_offsets):
+                self._stable[i] = None if off is None else self._shadow_ptr + 2 * off
+            self._shadow_version = None
+        if self._shadow_version != (version, self.flat.data_ptr()):
+            _lib.check(_lib.lib().hig_cast_bf16(_lib.ptr(self.flat), _lib.ptr(self._shadow), self.core_numel,
+                                                _lib.stream_ptr()))
+            self._shadow_version = (version, self.flat.data_ptr())
+        return self._stable
+
     def valid(self):
         base, end = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.numel
         return all(p.is_cuda and base <= p.data_ptr() < end for p in self.params[:3] + self.params[-3:]) \
@@ -382,6 +416,9 @@ class MotionTransformer(nn.Module):
         self.precision = kargs.get("precision", os.environ.get("HIG_PREC", "f32"))
         # "hip": the text head runs through hig_text_head_fwd/_bwd; "torch": stock PyTorch-ROCm ops
         self.text_head = kargs.get("text_head", os.environ.get("HIG_TEXT_HEAD", "hip"))
+        # "f32": fp32 activations / weights (default).  "bf16": bf16 activations + a bf16 shadow of the weight
+        # matrices, fp32 accumulation and statistics (BASELINE configs 3 / 5) -- inference only
+        self.storage = kargs.get("storage", os.environ.get("HIG_STORAGE", "f32"))
         self._flat = None
         self._pool = _WorkspacePool()
         self._textctx_cache = None
@@ -417,6 +454,15 @@ class MotionTransformer(nn.Module):
             for p in (ca.key.weight, ca.key.bias, ca.value.weight, ca.value.bias, ca.text_norm.weight, ca.text_norm.bias):
                 v += p._version
         return v
+
+    def _param_version(self):
+        """Moves whenever any core parameter may have changed (see `_textctx_param_version`)."""
+        return self._param_epoch + sum(p._version for p in self.flat_params().params)
+
+    def _bf16(self):
+        if self.storage not in ("f32", "bf16"):
+            raise ValueError("storage must be 'f32' or 'bf16' (got %r)" % (self.storage,))
+        return self.storage == "bf16"
 
     def flat_params(self):
         """Flat fp32 buffer aliasing every core parameter (built on first use on the device)."""
@@ -485,7 +531,8 @@ class MotionTransformer(nn.Module):
                          ff=self.ff_size, L=self.num_layers, N=N, Lt=self.text_latent_dim,
                          num_frames=self.num_frames,
                          attn_kind=_lib.ATTN_FULL if self.no_eff else _lib.ATTN_LINEAR,
-                         prec={"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16": _lib.PREC_BF16}[self.precision])
+                         prec={"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16": _lib.PREC_BF16}[self.precision],
+                         storage=_lib.STORE_BF16 if getattr(self, "storage", "f32") == "bf16" else _lib.STORE_F32)
 
     def forward(self, x, timesteps, length=None, text=None, xf_proj=None, xf_out=None):
         """x: (B, T, F) -> (B, T, F)   (transformer.py:407-426)."""
@@ -516,6 +563,9 @@ class MotionTransformer(nn.Module):
             x.requires_grad or xf_proj.requires_grad or xf_out.requires_grad
             or any(p.requires_grad for p in fp.params))
         if needs_grad:
+            if self._bf16():
+                raise NotImplementedError("storage='bf16' is inference-only: run it under torch.no_grad() (training keeps "
+                                          "fp32 storage; precision='bf16x3' / 'bf16' select reduced-precision products)")
             return _DenoiserFn.apply(self, x, t, length, xf_proj, xf_out, *fp.params)
         out, _ = self._launch_forward(x, t, length, xf_proj, xf_out, training=False)
         return out
@@ -528,7 +578,7 @@ class MotionTransformer(nn.Module):
         use_cache = not training and self.cache_text_context
         if use_cache:
             key = (xf_out.data_ptr(), xf_out._version, tuple(xf_out.shape), fp.flat.data_ptr(),
-                   fp.flat._version, self._textctx_param_version(), self.precision)
+                   fp.flat._version, self._textctx_param_version(), self.precision, self.storage)
             if self._textctx_cache is not None and self._textctx_cache[0] == key:
                 return self._textctx_cache[1]
         L = _lib.lib()
@@ -542,8 +592,12 @@ class MotionTransformer(nn.Module):
         else:   # one reusable buffer: the caller's forward consumes it on the same stream before the next call
             buf = self._pool.take("textctx_i", nbytes, xf_out.device)
             self._pool.give("textctx_i", buf, xf_out.device)
-        _lib.check(L.hig_text_context(C.byref(dims), fp.param_table(), _lib.ptr(xf_out), _lib.ptr(buf),
-                                      int(training), _lib.stream_ptr()))
+        if self._bf16():
+            _lib.check(L.hig_text_context_bf16(C.byref(dims), fp.param_table(), fp.shadow16(self._param_version()),
+                                               _lib.ptr(xf_out), _lib.ptr(buf), _lib.stream_ptr()))
+        else:
+            _lib.check(L.hig_text_context(C.byref(dims), fp.param_table(), _lib.ptr(xf_out), _lib.ptr(buf),
+                                          int(training), _lib.stream_ptr()))
         if use_cache:
             self._textctx_cache = (key, buf, xf_out)  # keep xf_out alive so the key stays unique
         return buf
@@ -554,12 +608,20 @@ class MotionTransformer(nn.Module):
         L = _lib.lib()
         fp = self.flat_params()
         dims = self.dims(B, T, N)
+        if training and self._bf16():
+            raise NotImplementedError("storage='bf16' is inference-only (the training step keeps fp32 storage)")
         nbytes = L.hig_workspace_bytes(C.byref(dims), int(training))
         if nbytes < 0:
             raise RuntimeError("libhig: " + _lib.last_error())
         textctx = self._text_context(dims, xf_out, training)
         ws = self._pool.take("fwd_t" if training else "fwd_i", nbytes, x.device)
         out = torch.empty(B, T, self.input_feats, device=x.device, dtype=torch.float32)
+        if self._bf16():
+            _lib.check(L.hig_denoiser_fwd_bf16(C.byref(dims), fp.param_table(), fp.shadow16(self._param_version()),
+                                               _lib.ptr(x), _lib.ptr(t), _lib.ptr(length), _lib.ptr(xf_proj),
+                                               _lib.ptr(textctx), _lib.ptr(out), _lib.ptr(ws), _lib.stream_ptr()))
+            self._pool.give("fwd_i", ws, x.device)
+            return out, None
         _lib.check(L.hig_denoiser_fwd(C.byref(dims), fp.param_table(), _lib.ptr(x), _lib.ptr(t),
                                       _lib.ptr(length), _lib.ptr(xf_proj), _lib.ptr(textctx), _lib.ptr(out),
                                       _lib.ptr(ws), int(training), _lib.stream_ptr()))
@@ -568,7 +630,10 @@ class MotionTransformer(nn.Module):
             return out, None
         return out, (dims, ws, textctx)
 
-    def _launch_backward(self, x, t, length, xf_out, saved, dout, want_dx=False):
+    def _launch_backward(self, x, t, length, xf_out, saved, dout, want_dx=False, layer_hook=None, comm_stream=None):
+        """layer_hook(l): called on the host once decoder layer l's backward is enqueued and `comm_stream` (a
+        torch.cuda.Stream) has been made to wait for it -- the data-parallel exchange of layer l's gradients can start
+        there while the earlier layers are still in backward (hig_denoiser_bwd_hooked)."""
         dims, ws, textctx = saved
         L = _lib.lib()
         fp = self.flat_params()
@@ -580,10 +645,28 @@ class MotionTransformer(nn.Module):
         dx = torch.empty_like(x) if want_dx else None
         dxp = torch.empty(B, self.time_embed_dim, device=dev, dtype=torch.float32)
         dxo = torch.empty(B, N, self.text_latent_dim, device=dev, dtype=torch.float32)
-        _lib.check(L.hig_denoiser_bwd(C.byref(dims), fp.param_table(), _lib.ptr(x), _lib.ptr(t),
-                                      _lib.ptr(length), _lib.ptr(xf_out), _lib.ptr(textctx), _lib.ptr(ws),
-                                      _lib.ptr(dout), gtable, _lib.ptr(dx), _lib.ptr(dxp), _lib.ptr(dxo),
-                                      _lib.ptr(bws), _lib.stream_ptr()))
+        if layer_hook is None:
+            _lib.check(L.hig_denoiser_bwd(C.byref(dims), fp.param_table(), _lib.ptr(x), _lib.ptr(t),
+                                          _lib.ptr(length), _lib.ptr(xf_out), _lib.ptr(textctx), _lib.ptr(ws),
+                                          _lib.ptr(dout), gtable, _lib.ptr(dx), _lib.ptr(dxp), _lib.ptr(dxo),
+                                          _lib.ptr(bws), _lib.stream_ptr()))
+        else:
+            errors = []
+
+            def _hook(_user, layer):          # an exception must not unwind through the C frames
+                try:
+                    layer_hook(int(layer))
+                except BaseException as e:  # noqa: BLE001
+                    errors.append(e)
+
+            cb = _lib.LAYER_HOOK(_hook)
+            _lib.check(L.hig_denoiser_bwd_hooked(
+                C.byref(dims), fp.param_table(), _lib.ptr(x), _lib.ptr(t), _lib.ptr(length), _lib.ptr(xf_out),
+                _lib.ptr(textctx), _lib.ptr(ws), _lib.ptr(dout), gtable, _lib.ptr(dx), _lib.ptr(dxp), _lib.ptr(dxo),
+                _lib.ptr(bws), _lib.stream_ptr(), cb, None,
+                None if comm_stream is None else C.c_void_p(comm_stream.cuda_stream)))
+            if errors:
+                raise errors[0]
         self._pool.give("bwd", bws, dev)
         self._pool.give("fwd_t", ws, dev)
         self._pool.give("textctx_t", textctx, dev)

@@ -31,6 +31,53 @@ class FlatGradAllReduce:
         return world
 
 
+class OverlappedGradAllReduce:
+    """The same exchange, started per decoder layer WHILE the backward is still running (what the reference's DDP
+    reducer does with its buckets, tools/train.py:77-82): hig_denoiser_bwd_hooked reports each layer as soon as its
+    gradients are final, the layer's two flat ranges (its own parameters ~15 MB, its rows of the stacked stylization
+    matrix ~25 MB at config 2) are all-reduced from a side stream, and only the global parameters (+ text head) are
+    left for the end.  xGMI is point-to-point, so ~20-40 MB messages still run at link bandwidth; the exposed part of
+    the exchange shrinks from the whole 324 MB to the last layer's bucket + the tail.
+
+        ex = OverlappedGradAllReduce(); ex.begin(flat_grad, per_layer, tail)
+        backward(layer_hook=ex.layer_done, comm_stream=ex.stream)
+        world = ex.finish(extra_ranges)     # current stream now waits for every bucket
+    """
+
+    def __init__(self, group=None):
+        self.group = group
+        self.stream = None
+        self.works = []
+
+    @staticmethod
+    def active(group=None):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def begin(self, flat_grad, per_layer, tail):
+        if self.stream is None or self.stream.device != flat_grad.device:
+            self.stream = torch.cuda.Stream(device=flat_grad.device)
+        self.grad, self.per_layer, self.tail, self.works = flat_grad, per_layer, tail, []
+
+    def _reduce(self, ranges):
+        for a, b in ranges:
+            if b > a:
+                self.works.append(dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def layer_done(self, layer):
+        with torch.cuda.stream(self.stream):       # (the library already made this stream wait for the layer)
+            self._reduce(self.per_layer[layer])
+
+    def finish(self, extra=()):
+        self.stream.wait_stream(torch.cuda.current_stream())     # the tail is final when the backward is
+        with torch.cuda.stream(self.stream):
+            self._reduce(list(self.tail) + list(extra))
+        for w in self.works:
+            w.wait()                                             # current stream waits for the exchange
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.works = []
+        return dist.get_world_size(self.group)
+
+
 class ShardedSampler(torch.utils.data.Sampler):
     """Index sharding of the reference's DistributedSampler (datasets/dataloader.py:16-53):
     permutation seeded by `epoch` (the reference never calls set_epoch, so epoch stays 0),

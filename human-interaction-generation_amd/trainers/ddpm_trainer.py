@@ -26,7 +26,7 @@ from torch.nn.utils import clip_grad_norm_
 from .. import _lib
 from ..models.gaussian_diffusion import (GaussianDiffusion, LossType, ModelMeanType, ModelVarType,
                                          create_named_schedule_sampler, get_named_beta_schedule)
-from ..parallel import FlatGradAllReduce, ShardedSampler, broadcast_flat
+from ..parallel import FlatGradAllReduce, OverlappedGradAllReduce, ShardedSampler, broadcast_flat
 
 GRAD_CLIP = 0.5                    # ddpm_trainer.py:61
 ADAM_BETAS, ADAM_EPS = (0.9, 0.999), 1e-8   # torch.optim.Adam defaults, ddpm_trainer.py:222
@@ -309,7 +309,7 @@ class DDPMTrainer(object):
                 "step": torch.zeros(1, device=dev, dtype=torch.int32),
                 "lr": torch.full((1,), float(self.opt.lr), device=dev, dtype=torch.float32),
                 "lr_host": float(self.opt.lr), "covered": 0, "graphs": {}, "ptrs": ptrs,
-                "allreduce": FlatGradAllReduce(),
+                "allreduce": FlatGradAllReduce(), "overlap": OverlappedGradAllReduce(),
             }
         return st
 
@@ -334,10 +334,12 @@ class DDPMTrainer(object):
         _core(self.encoder)._launch_text_head_backward(clip_out, eot, xf_out, tsaved, dxf_out, dxf_proj,
                                                        want_dclip=False, into_flat=True)
 
-    def _fused_fwd_bwd(self, x_start, t, length, xf_proj, xf_out, noise, clip_out=None, eot=None):
+    def _fused_fwd_bwd(self, x_start, t, length, xf_proj, xf_out, noise, clip_out=None, eot=None, exchange=None):
         """q_sample -> [text head] -> denoiser forward -> masked MSE -> denoiser backward [-> text head backward]
         into the flat gradient.  With `clip_out` / `eot` the text embeddings are computed here and the text
-        head is trained too (the reference's full update); otherwise xf_proj / xf_out are inputs."""
+        head is trained too (the reference's full update); otherwise xf_proj / xf_out are inputs.
+        `exchange` (an OverlappedGradAllReduce that has been begun): the gradient all-reduce of each decoder layer is
+        started from inside the backward."""
         core = _core(self.encoder)
         L = _lib.lib()
         st = self.fused_state()
@@ -353,7 +355,11 @@ class DDPMTrainer(object):
         _lib.check(L.hig_masked_mse(_lib.ptr(pred), _lib.ptr(noise), _lib.ptr(length), B, T, F,
                                     _lib.ptr(st["loss"]), _lib.ptr(dpred), _lib.ptr(st["mse_scratch"]),
                                     _lib.stream_ptr()))
-        _, dxp, dxo = core._launch_backward(x_t, t, length, xf_out, saved, dpred, want_dx=False)
+        if exchange is None:
+            _, dxp, dxo = core._launch_backward(x_t, t, length, xf_out, saved, dpred, want_dx=False)
+        else:
+            _, dxp, dxo = core._launch_backward(x_t, t, length, xf_out, saved, dpred, want_dx=False,
+                                                layer_hook=exchange.layer_done, comm_stream=exchange.stream)
         if tstate is not None:
             self._text_backward(tstate, dxp, dxo)
 
@@ -403,8 +409,19 @@ class DDPMTrainer(object):
         with_text = clip_out is not None
         n = self._fused_numel(with_text)
         self._set_lr(lr)
-        self._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise, clip_out=clip_out, eot=eot)
-        world = st["allreduce"](_core(self.encoder).flat_params().grad[:n])      # sum over ranks (RCCL, xGMI)
+        core = _core(self.encoder)
+        fp = core.flat_params()
+        if (OverlappedGradAllReduce.active() and getattr(self.opt, "overlap_allreduce", True)
+                and type(self)._fused_fwd_bwd is DDPMTrainer._fused_fwd_bwd):
+            # gradient exchange of layer l while layers l-1 ... 0 are still in backward (RCCL on a side stream)
+            ex = st["overlap"]
+            per_layer, tail = fp.layer_buckets(core.num_layers, 3, core.latent_dim, core.time_embed_dim)
+            ex.begin(fp.grad, per_layer, tail)
+            self._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise, clip_out=clip_out, eot=eot, exchange=ex)
+            world = ex.finish([(fp.core_numel, n)] if n > fp.core_numel else ())
+        else:
+            self._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise, clip_out=clip_out, eot=eot)
+            world = st["allreduce"](fp.grad[:n])                                  # one all-reduce after the backward
         self._fused_clip_adam(world, with_text)
         return st["loss"]
 

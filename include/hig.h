@@ -190,6 +190,20 @@ int hig_denoiser_bwd(const hig_dims* dims, const void* const* params, const floa
                      void* const* grads, float* dx, float* dxf_proj, float* dxf_out,
                      void* bwd_workspace, hig_stream_t stream);
 int64_t hig_bwd_workspace_bytes(const hig_dims* dims);
+/* The same backward with a per-layer completion hook, for overlapping the data-parallel gradient exchange with the
+ * backward (the reference's DDP reducer does this with buckets, tools/train.py:77-82).  After the launches of decoder
+ * layer l (l = L-1 ... 0) are enqueued -- including that layer's rows of the stacked stylization `emb_layers.1.weight`
+ * gradient, which this variant computes per layer instead of once at the end -- `comm_stream` (optional) is made to
+ * wait for them and `hook(user, l)` is called on the host: every entry of `grads` that belongs to layer l, and rows
+ * [l * nsty * 2d, (l+1) * nsty * 2d) of HIG_P_STY_EMB_W, are final once `comm_stream` gets there.  The remaining
+ * (global) gradients are final when the call's launches on `stream` have completed.  Not for hipGraph capture. */
+typedef void (*hig_layer_hook)(void* user, int32_t layer);
+int hig_denoiser_bwd_hooked(const hig_dims* dims, const void* const* params, const float* x,
+                            const int64_t* t, const int64_t* length, const float* xf_out,
+                            const void* textctx, const void* workspace, const float* dout,
+                            void* const* grads, float* dx, float* dxf_proj, float* dxf_out,
+                            void* bwd_workspace, hig_stream_t stream, hig_layer_hook hook, void* hook_user,
+                            hig_stream_t comm_stream);
 
 /* ------------------------------------------------------------------------------------------
  * Text head: the trainable part of MotionTransformer.encode_text after CLIP
@@ -377,6 +391,12 @@ int hig_linattn_ctx_bf16(const void* K, const void* V, int64_t ld, int32_t B, in
                          const int64_t* length, float* A, float* kstat, float* scratch, hig_stream_t stream);
 int hig_linattn_apply_bf16(const void* Q, int64_t ldq, const float* A, void* Y, int64_t ldy, int32_t B, int32_t rows,
                            int32_t H, int32_t hd, hig_stream_t stream);
+/* hig_linattn_apply_bf16 followed by the stylization front hig_ln_bf16(ss != NULL) over all H heads, as one kernel:
+ * Out = silu( LN_d( softmax_hd(Q) . A ) * (1 + scale) + shift ) (transformer.py:111,116-118 then :81-85); the
+ * (rows x d) intermediate never reaches memory.  H in {4, 8}, head dim 64 / 128; rows_per_sample == rows. */
+int hig_linattn_apply_sty_bf16(const void* Q, int64_t ldq, const float* A, const float* gamma, const float* beta,
+                               const float* ss, int64_t ss_ld, int32_t ss_shift_off, void* Out, int64_t ldo,
+                               int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
 
 /* Row statistics for LayerNorm: stats[m] = (mean, rstd) of x[m, :n], eps = 1e-5, biased var. */
 int hig_rowstats(const float* x, int64_t ldx, int64_t rows, int32_t n, float* stats,

@@ -202,3 +202,48 @@ def test_shutdown_releases_and_recreates_the_side_stream():
     torch.cuda.synchronize()
     assert not torch.equal(before, m.out.weight) and torch.isfinite(m.out.weight).all()
     assert _lib.lib().hig_shutdown() == 0
+
+
+def test_backward_with_layer_hook_equals_plain_backward():
+    """hig_denoiser_bwd_hooked: the hook fires once per decoder layer, last layer first, with that layer's gradients
+    final on the comm stream; the whole gradient buffer equals the plain backward's (the stylization emb_layers
+    gradient is computed per layer instead of once at the end: same products, same order)."""
+    c = fill.CASES["width"]
+    m = build(c).train()
+    gi = {k: v.to(DEV) for k, v in fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"]).items()}
+    dout = (fill.tensor_for("hook.dout", gi["x"].shape) * 10).to(DEV)
+    fp = m.flat_params()
+
+    def run(hook=None, comm=None):
+        out, saved = m._launch_forward(gi["x"], gi["t"], gi["length"], gi["xf_proj"], gi["xf_out"], training=True)
+        fp.ensure_grad()
+        fp.grad.fill_(float("nan"))
+        m._launch_backward(gi["x"], gi["t"], gi["length"], gi["xf_out"], saved, dout, want_dx=False, layer_hook=hook,
+                           comm_stream=comm)
+        torch.cuda.synchronize()
+        return fp.grad[:fp.core_numel].clone()
+
+    plain = run()
+    assert torch.isfinite(plain).all()
+    per_layer, tail = fp.layer_buckets(c["L"], 3, c["d"], 4 * c["d"])
+    covered = torch.zeros(fp.core_numel, dtype=torch.bool)
+    for a, b in [r for lay in per_layer for r in lay] + list(tail):
+        assert not covered[a:b].any()                   # the buckets partition the flat buffer
+        covered[a:b] = True
+    assert covered.all()
+    comm = torch.cuda.Stream()
+    seen, snaps = [], {}
+
+    def hook(l):
+        seen.append(l)
+        with torch.cuda.stream(comm):                  # what the exchange would read: layer l's ranges, on the comm stream
+            snaps[l] = [fp.grad[a:b].clone() for a, b in per_layer[l]]
+
+    hooked = run(hook, comm)
+    assert seen == list(range(c["L"] - 1, -1, -1))
+    assert torch.equal(hooked, plain)
+    for l, parts in snaps.items():
+        for (a, b), snap in zip(per_layer[l], parts):
+            assert torch.equal(snap, plain[a:b]), (l, a, b)          # already final when the hook's stream got there
+    with pytest.raises(RuntimeError, match="boom"):                  # a failing hook surfaces as a Python exception
+        run(lambda l: (_ for _ in ()).throw(RuntimeError("boom")), comm)
