@@ -136,12 +136,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
     // the compiler-visible wait of the barrier that ends the main loop.  (A VGPR load still "pending" in hipcc's
     // scoreboard when the next tile starts makes it guard the first reuse of that register with s_waitcnt vmcnt(0) --
     // inside the main loop, where it drains the DMA ring every k-tile.)
-    constexpr int Q8 = BN / 8, RPP = NT / Q8;          // epilogue: 8-column pieces per row, rows per sweep
-    const int c8 = tid % Q8, rr0 = tid / Q8;
-    const int j = j0 + 8 * c8;
-    float b8[8];
+    // Epilogue work split: a 64-row pass is 64 x Q8 eight-column pieces, piece idx = tid + NT * sweep.  With Q8 = 16
+    // (BN = 128) a thread keeps one column piece for all sweeps; with Q8 = 24 (BN = 192) it cycles through 3.
+    constexpr int Q8 = BN / 8, NSW = 64 * Q8 / NT, NBS = NT % Q8 == 0 ? 1 : 3;
+    static_assert((64 * Q8) % NT == 0 && (NT % Q8 == 0 || (3 * NT) % Q8 == 0), "epilogue split");
+    float b8[NBS][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) b8[e] = (EPI != HIG_EPI_NONE) ? g.bias[min(j + e, g.J - 1)] : 0.f;
+    for (int u = 0; u < NBS; ++u) {
+      const int ju = j0 + 8 * ((tid + NT * u) % Q8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b8[u][e] = (EPI != HIG_EPI_NONE) ? g.bias[min(ju + e, g.J - 1)] : 0.f;
+    }
 
     f32x16 acc[TJ][TI];
 #pragma unroll
@@ -189,13 +194,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
 
     // ---- epilogue: one 64-row pass per wave row, through LDS (fp32), out as whole rows -------------------
     if (a.dbg & 2) {
-      if (acc[0][0][0] + acc[TJ - 1][1][3] == 123.456f) static_cast<float*>(g.C)[0] = b8[0];
+      if (acc[0][0][0] + acc[TJ - 1][1][3] == 123.456f) static_cast<float*>(g.C)[0] = b8[0][0];
       continue;
     }
     float* sC = reinterpret_cast<float*>(smem);
-    constexpr int NSW = 64 / RPP;                      // row sweeps per pass
     constexpr bool HAS_RES = EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU;
-    const bool full = a.vec && j + 8 <= g.J;
     // LDS-only barrier: the output stores of one pass stay in flight across it (a __syncthreads() would wait vmcnt(0)
     // for them twice per tile: 16 of 43 us at the FFN shape, profiles/r02_notes.md)
     auto lds_barrier = [&]() {
@@ -207,10 +210,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
     for (int ps = 0; ps < WM; ++ps) {
       // the bf16 residual rows of this pass are requested first: their latency hides under the LDS staging + barrier
       bf16x8 r16[NSW];
-      if (HAS_RES && full && !g.res_f32) {
+      if (HAS_RES && a.vec && !g.res_f32) {
 #pragma unroll
         for (int sw = 0; sw < NSW; ++sw) {
-          const int i = min(i0 + 64 * ps + rr0 + RPP * sw, g.I - 1);
+          const int idx = tid + NT * sw;
+          const int i = min(i0 + 64 * ps + idx / Q8, g.I - 1), j = min(j0 + 8 * (idx % Q8), g.J - 8);
           r16[sw] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(g.res) + (int64_t)i * g.ldr + j);
         }
       }
@@ -227,14 +231,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
       lds_barrier();
 #pragma unroll
       for (int sw = 0; sw < NSW; ++sw) {
-        const int rr = rr0 + RPP * sw;
-        const int i = i0 + 64 * ps + rr;
+        const int idx = tid + NT * sw;
+        const int rr = idx / Q8, c8 = idx % Q8;
+        const int i = i0 + 64 * ps + rr, j = j0 + 8 * c8;
         if (i >= g.I || j >= g.J) continue;
+        const bool full = a.vec && j + 8 <= g.J;
+        const float (&bb)[8] = b8[sw % NBS];
         float v[8];
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(sC + rr * CLD + 8 * c8);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(sC + rr * CLD + 8 * c8 + 4);
-        v[0] = v0.x + b8[0]; v[1] = v0.y + b8[1]; v[2] = v0.z + b8[2]; v[3] = v0.w + b8[3];
-        v[4] = v1.x + b8[4]; v[5] = v1.y + b8[5]; v[6] = v1.z + b8[6]; v[7] = v1.w + b8[7];
+        v[0] = v0.x + bb[0]; v[1] = v0.y + bb[1]; v[2] = v0.z + bb[2]; v[3] = v0.w + bb[3];
+        v[4] = v1.x + bb[4]; v[5] = v1.y + bb[5]; v[6] = v1.z + bb[6]; v[7] = v1.w + bb[7];
         if (a.dbg & 8) {
           if (v[0] + v[7] == 123.456f) static_cast<float*>(g.C)[0] = v[3];
           continue;
@@ -334,7 +341,9 @@ int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
     double best = c128;
     if (t128 < 256 && c64 <= best * 1.25) { pick = 64; best = c64; }        // too few big tiles to occupy the chip
     else if (c64 < best) { pick = 64; best = c64; }
-    if (fits192 && c192 < best) { pick = 192; best = c192; }
+    // (128 x 192 -- one round for the q/k/v projection at M = 6272 -- measured 28 us against 25 us for 128 x 128 in two
+    // rounds: kept as a forced option only)
+    (void)c192; (void)fits192;
   }
   if (g.R % 64 == 0) {
     if (pick == 192) return launch16<2, 3, 64, 2, EPI>(g, st);

@@ -221,10 +221,10 @@ def test_backward_with_layer_hook_equals_plain_backward():
         m._launch_backward(gi["x"], gi["t"], gi["length"], gi["xf_out"], saved, dout, want_dx=False, layer_hook=hook,
                            comm_stream=comm)
         torch.cuda.synchronize()
-        return fp.grad[:fp.core_numel].clone()
+        assert all(bool(torch.isfinite(g).all()) for g in fp.grad_views)       # every parameter gradient was written
+        return torch.nan_to_num(fp.grad[:fp.core_numel], nan=0.0)               # (alignment gaps between groups are not)
 
     plain = run()
-    assert torch.isfinite(plain).all()
     per_layer, tail = fp.layer_buckets(c["L"], 3, c["d"], 4 * c["d"])
     covered = torch.zeros(fp.core_numel, dtype=torch.bool)
     for a, b in [r for lay in per_layer for r in lay] + list(tail):
@@ -237,7 +237,7 @@ def test_backward_with_layer_hook_equals_plain_backward():
     def hook(l):
         seen.append(l)
         with torch.cuda.stream(comm):                  # what the exchange would read: layer l's ranges, on the comm stream
-            snaps[l] = [fp.grad[a:b].clone() for a, b in per_layer[l]]
+            snaps[l] = [torch.nan_to_num(fp.grad[a:b], nan=0.0) for a, b in per_layer[l]]
 
     hooked = run(hook, comm)
     assert seen == list(range(c["L"] - 1, -1, -1))
