@@ -48,7 +48,7 @@ __device__ __forceinline__ void glds16(const __bf16* src, char* lds_wave_base) {
 // the epilogue's VALU work was 10 of the 43 us of the FFN linear1 launch (profiles/r02_notes.md).
 __device__ __forceinline__ float gelu_bf16(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float erf_abs = 1.0f - poly * __expf(-z * z);
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
@@ -57,7 +57,7 @@ __device__ __forceinline__ float gelu_bf16(float x) {
 template <int EPI>
 __device__ __forceinline__ float epi_act(float v) {
   if (EPI == HIG_EPI_BIAS_GELU) return gelu_bf16(v);
-  if (EPI == HIG_EPI_BIAS_SILU || EPI == HIG_EPI_BIAS_RES_SILU) return hig_silu(v);
+  if (EPI == HIG_EPI_BIAS_SILU || EPI == HIG_EPI_BIAS_RES_SILU) return hig_silu_fast(v);
   return v;
 }
 

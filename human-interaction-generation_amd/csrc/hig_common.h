@@ -33,6 +33,9 @@ __device__ __forceinline__ float hig_dsilu(float x) {
   float s = 1.0f / (1.0f + __expf(-x));
   return s * (1.0f + x * (1.0f - s));
 }
+// bf16-storage kernels: the result is rounded to 8 significant bits right away, so the 1-ulp hardware reciprocal
+// (v_rcp_f32) replaces the correctly rounded division (v_div_scale / v_div_fmas / v_div_fixup: ~10 instructions).
+__device__ __forceinline__ float hig_silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float hig_gelu(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

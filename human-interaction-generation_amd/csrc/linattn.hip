@@ -1350,10 +1350,10 @@ __global__ __launch_bounds__(256) void apply_sty16_kernel(const __bf16* __restri
         const float4 g4 = *reinterpret_cast<const float4*>(gamma + col), b4 = *reinterpret_cast<const float4*>(beta + col);
         const float4 sc = *reinterpret_cast<const float4*>(ssrow + col), sh = *reinterpret_cast<const float4*>(ssrow + shift_off + col);
         float4 o;
-        o.x = hig_silu(((acc[hh][tb][4 * qq] - mean) * rstd * g4.x + b4.x) * (1.0f + sc.x) + sh.x);
-        o.y = hig_silu(((acc[hh][tb][4 * qq + 1] - mean) * rstd * g4.y + b4.y) * (1.0f + sc.y) + sh.y);
-        o.z = hig_silu(((acc[hh][tb][4 * qq + 2] - mean) * rstd * g4.z + b4.z) * (1.0f + sc.z) + sh.z);
-        o.w = hig_silu(((acc[hh][tb][4 * qq + 3] - mean) * rstd * g4.w + b4.w) * (1.0f + sc.w) + sh.w);
+        o.x = hig_silu_fast(((acc[hh][tb][4 * qq] - mean) * rstd * g4.x + b4.x) * (1.0f + sc.x) + sh.x);
+        o.y = hig_silu_fast(((acc[hh][tb][4 * qq + 1] - mean) * rstd * g4.y + b4.y) * (1.0f + sc.y) + sh.y);
+        o.z = hig_silu_fast(((acc[hh][tb][4 * qq + 2] - mean) * rstd * g4.z + b4.z) * (1.0f + sc.z) + sh.z);
+        o.w = hig_silu_fast(((acc[hh][tb][4 * qq + 3] - mean) * rstd * g4.w + b4.w) * (1.0f + sc.w) + sh.w);
         st4(sO + lr * ldso + col, o);
       }
   }

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void ln16_kernel(const TIN* __restrict__ x, in
         ld8(ssrow + c, sc);
         ld8(ssrow + shift_off + c, sh);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = hig_silu(o[e] * (1.0f + sc[e]) + sh[e]);
+        for (int e = 0; e < 8; ++e) o[e] = hig_silu_fast(o[e] * (1.0f + sc[e]) + sh[e]);
       }
       *reinterpret_cast<bf16x8*>(out + row * ldo + c) =
           bf16x8{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3], (__bf16)o[4], (__bf16)o[5], (__bf16)o[6], (__bf16)o[7]};

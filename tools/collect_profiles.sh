@@ -2,7 +2,7 @@
 # Runs on the GPU box (through gpurun): bench line + rocprofv3 kernel trace of the same command +
 # separate PMC passes for the dominant kernel (FFN linear1 GEMM).  Writes under gpurun_out/$1/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -13,3 +13,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch --
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/tools/ffn_gemm_pmc.py > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- python3 $R/tools/ffn_gemm_pmc.py > $O/pmc_sq.log 2>&1
 cat $O/bench.json
+# round 2: bf16-storage sampling step and the fp32 training step (kernel stats), bf16 FFN GEMM counters, HBM-bound kernels
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_bf16 -- python3 $R/tools/fwd16_time.py 32 bf16 > $O/fwd16_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_train -- python3 $R/tools/train_step_time.py > $O/train_under_rocprof.log 2>&1
+bash $R/tools/pmc_gemm16.sh $TAG/pmc16_ffn1 ffn1 64 > $O/pmc16.log 2>&1
+bash $R/tools/pmc_hbm.sh $TAG/pmc_hbm > $O/pmc_hbm.log 2>&1
