@@ -137,6 +137,43 @@ def ffn_gemm_roofline(c, device, reps=32):
             "how": "%d launches rotating over %d operand sets (HBM-resident activations), HIP events on the launch stream" % (reps, NB)}
 
 
+def ffn_gemm_bf16_roofline(c, device, reps=32):
+    """The same FFN linear1 shape on the bf16-storage GEMM (hig_gemm_bf16: bf16 operands DMA-ed into LDS,
+    v_mfma_f32_32x32x16_bf16, bias + GELU + bf16 store), against the dense bf16 MFMA peak (2.5 PFLOP/s)."""
+    from hig_amd import _lib
+    M, K, Nn = c["B"] * c["T"], c["d"], c["ff"]
+    NB = 12
+    Xs = [torch.randn(M, K, device=device).to(torch.bfloat16) for _ in range(NB)]
+    outs = [torch.empty(M, Nn, device=device, dtype=torch.bfloat16) for _ in range(NB)]
+    W = (torch.randn(Nn, K, device=device) * 0.05).to(torch.bfloat16)
+    b = torch.randn(Nn, device=device)
+    descs = []
+    for X, out in zip(Xs, outs):
+        d = _lib.Gemm16Desc()
+        d.X, d.ldx, d.Y, d.ldy, d.C, d.ldc, d.c_f32 = X.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), Nn, 0
+        d.I, d.J, d.R, d.epi, d.bias = M, Nn, K, _lib.EPI_BIAS_GELU, b.data_ptr()
+        descs.append(d)
+    L = _lib.lib()
+    for i in range(NB):
+        _lib.check(L.hig_gemm_bf16(C.byref(descs[i]), _lib.stream_ptr()))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(reps):
+        _lib.check(L.hig_gemm_bf16(C.byref(descs[i % NB]), _lib.stream_ptr()))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * M * K * Nn
+    ach = flops / (ms * 1e-3) / 1e12
+    by = (M * K + Nn * K + M * Nn) * 2
+    return {"bound": "mfma (nominal; measured: per-tile fixed costs and the L2->LDS operand path, profiles/r02_notes.md)",
+            "kernel": "gemm_bf16_kernel (FFN linear1, bf16 storage: M=%d K=%d N=%d, bias+GELU)" % (M, K, Nn),
+            "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+            "avg_launch_ms": round(ms, 4), "algorithmic_GB_per_s": round(by / ms / 1e6, 0),
+            "how": "%d launches rotating over %d operand sets (%.0f MB > Infinity Cache), HIP events" % (reps, NB, NB * by / 1e6)}
+
+
 def hbm_kernel_rooflines(c, device, reps=30):
     """HBM-bound kernels of the path through the C ABI: achieved GB/s = algorithmic bytes (each operand read or
     written once) / launch time measured with HIP events on the launch stream; peak 8 TB/s."""
@@ -661,6 +698,9 @@ def main():
     if rank == 0:
         if not a.no_extra and world == 1:
             extra["hbm_bound_kernels"] = hbm_kernel_rooflines(c, device)
+            extra["hbm_bound_kernels"]["counter_based"] = ("FETCH_SIZE / WRITE_SIZE passes of the same kernels: "
+                                                           "profiles/r02_hbm_kernels_pmc.json (not collected in this run)")
+            extra["roofline_bf16_ffn_gemm"] = ffn_gemm_bf16_roofline(c, device)
         res["roofline"] = ffn_gemm_roofline(c, device)
         if not a.no_cpu_baseline and world == 1:
             gpu_out = fwd()

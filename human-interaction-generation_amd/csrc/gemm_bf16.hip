@@ -28,14 +28,14 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int NT = 256;
-
 struct K16Args {
   hig_gemm16_desc g;
   int nbj, ntiles;
   int vec;          // C / res rows allow 16-byte (bf16) / 32-byte (fp32) row pieces
-  int dbg;          // timing ablations (HIG_BF16_DBG; results are wrong): 1 = no DMA after the first k-tile,
-                    // 2 = no epilogue, 4 = no MFMA, 8 = epilogue without global stores / residual loads
+  unsigned long long* stamps;   // HIG_BF16_DBG & 16: per-workgroup s_memtime stamps of the first tile's phases (diagnostic build of the run)
+  int dbg;          // timing ablations (HIG_BF16_DBG; results are wrong): 2 = no epilogue, 8 = epilogue without global
+                    // stores / residual loads, 16 = s_memtime stamps (the in-loop ablations 1 = no DMA after the first
+                    // k-tile and 4 = no MFMA were removed after use: profiles/r02_notes.md)
 };
 
 __device__ __forceinline__ void glds16(const __bf16* src, char* lds_wave_base) {
@@ -61,6 +61,8 @@ __device__ __forceinline__ float epi_act(float v) {
   return v;
 }
 
+unsigned long long* g_stamps = nullptr;   // diagnostic only (hig_gemm_bf16_debug_stamps)
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -68,14 +70,15 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // NS-1 k-tiles ahead of the MFMAs (ring of buffers, ONE raw s_barrier per k-tile, counted vmcnt so that the younger
 // k-tiles stay in flight across the barrier -- a __syncthreads() here would drain them, guide "Pipelining across
 // barriers").
-template <int WM, int TJ, int BK, int NS, int EPI>
-__global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
-  constexpr int WN = 4 / WM, TI = 2;
-  constexpr int BM = 64 * WM, BN = 32 * TJ * WN;
+template <int WM, int WN, int TI, int TJ, int BK, int NS, int EPI>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Args a) {
+  constexpr int NT = 64 * WM * WN, NW = WM * WN;
+  constexpr int BM = 32 * TI * WM, BN = 32 * TJ * WN;
+  static_assert(TI % 2 == 0, "a wave row is a whole number of 64-row epilogue passes");
   constexpr int ROWB = BK * 2, CHUNKS = BK / 8, RB = 256 / ROWB, RPI = 1024 / ROWB;   // RPI: rows per DMA instruction
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-  constexpr int NA = BM / RPI, NB = BN / RPI, NQ = (NA + NB) / 4;   // DMA instructions: per tile, per wave
-  static_assert((NA + NB) % 4 == 0, "DMA instructions must split evenly over the 4 waves");
+  constexpr int NA = BM / RPI, NB = BN / RPI, NQ = (NA + NB) / NW;   // DMA instructions: per tile, per wave
+  static_assert((NA + NB) % NW == 0, "DMA instructions must split evenly over the waves");
   constexpr int CLD = BN + 4;
   constexpr int EPI_BYTES = 64 * CLD * 4;
   constexpr int SMEM = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
   int xoff[TI], xsw[TI], yoff[TJ], ysw[TJ];
 #pragma unroll
   for (int ti = 0; ti < TI; ++ti) {
-    const int r = wi * 64 + 32 * ti + lr;
+    const int r = wi * (32 * TI) + 32 * ti + lr;
     xoff[ti] = r * ROWB;
     xsw[ti] = (r / RB) & (CHUNKS - 1);
   }
@@ -104,7 +107,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
     ysw[tj] = (r / RB) & (CHUNKS - 1);
   }
 
+  auto stamp = [&](int k) {
+    if ((a.dbg & 16) && tid == 0 && blockIdx.x < 4096) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      a.stamps[(size_t)blockIdx.x * 8 + k] = t;
+    }
+  };
+  bool first_tile = true;
   for (int lin = blockIdx.x; lin < a.ntiles; lin += gridDim.x) {
+    if (first_tile) stamp(0);
     // XCD-aware order: blocks b, b + 8, ... share an XCD (private L2): give each XCD a contiguous run of tiles, column
     // tiles of one row panel next to each other, so the X panel is fetched from HBM once per XCD
     const int q8 = a.ntiles >> 3, r8 = a.ntiles & 7, xcd = lin & 7;
@@ -116,7 +128,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
     int dst[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int n = wave + 4 * q;                      // instruction index in [A tile | B tile] order
+      const int n = wave + NW * q;                     // instruction index in [A tile | B tile] order
       const bool isA = n < NA;
       const int r = (isA ? n : n - NA) * RPI + lane / CHUNKS;
       const int c = (lane % CHUNKS) ^ ((r / RB) & (CHUNKS - 1));
@@ -130,6 +142,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
         glds16(src[q], smem + buf * STAGE + dst[q]);
         src[q] += BK;
       }
+    };
+    // the same, spread over the KS k-steps of the MFMA block: a wave needs ~150-200 cycles to issue ONE 1-KiB DMA
+    // (s_memtime stamps, profiles/r02_notes.md), so issuing a k-tile's 6-8 back to back held the wave (and, with both
+    // waves of a SIMD leaving the barrier together, the matrix pipe) for longer than the whole MFMA block; slice
+    // `ks` of the DMAs now goes out behind the MFMAs of k-step ks, which execute while the next slice is issued.
+    constexpr int KS = BK / 16;
+    auto stage_slice = [&](int buf, int ks) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (q * KS / NQ == ks) {
+          glds16(src[q], smem + buf * STAGE + dst[q]);
+          src[q] += BK;
+        }
     };
 
     // The epilogue's per-thread bias columns are fetched NOW: every VGPR-returning load of a tile is then retired by
@@ -156,16 +181,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[tj][ti][e] = 0.f;
 
+    if (first_tile) stamp(1);
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
       if (p < nk) stage(p);
+    if (first_tile) stamp(2);
     int cur = 0, nxt = NS - 1;                            // ring positions of k-tile kt and of k-tile kt + NS - 1
     for (int kt = 0; kt < nk; ++kt) {
       // this wave's share of k-tile kt has landed once at most the NS-2 younger k-tiles' DMAs are outstanding
       if (kt + NS - 2 < nk) wait_vmcnt<(NS - 2) * NQ>(); else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();                       // everyone's share has; and k-tile kt-1's buffer is free
       asm volatile("" ::: "memory");
-      if (kt + NS - 1 < nk && !(a.dbg & 1)) stage(nxt);
+      const bool refill = kt + NS - 1 < nk;
+      const int fill = nxt;
       const char* sb = smem + cur * STAGE;
       cur = cur + 1 == NS ? 0 : cur + 1;
       nxt = nxt + 1 == NS ? 0 : nxt + 1;
@@ -178,19 +206,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
 #pragma unroll
         for (int tj = 0; tj < TJ; ++tj)
           yf[tj] = *reinterpret_cast<const bf16x8*>(sb + yoff[tj] + 16 * ((2 * ks + lh) ^ ysw[tj]));
-        if (a.dbg & 4) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[0][0][e] += (float)xf[0][e] + (float)yf[0][e] + (float)xf[1][e] + (float)yf[TJ - 1][e];
-          continue;
-        }
 #pragma unroll
         for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
           for (int ti = 0; ti < TI; ++ti)
             acc[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[tj], xf[ti], acc[tj][ti], 0, 0, 0);
+        if (refill) stage_slice(fill, ks);
       }
     }
     __syncthreads();   // all MFMA reads of the staging buffers are done (no DMA in flight): reuse them for the output tile
+    if (first_tile) stamp(5);
 
     // ---- epilogue: one 64-row pass per wave row, through LDS (fp32), out as whole rows -------------------
     if (a.dbg & 2) {
@@ -207,7 +232,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
       asm volatile("" ::: "memory");
     };
 #pragma unroll
-    for (int ps = 0; ps < WM; ++ps) {
+    for (int ps = 0; ps < BM / 64; ++ps) {
       // the bf16 residual rows of this pass are requested first: their latency hides under the LDS staging + barrier
       bf16x8 r16[NSW];
       if (HAS_RES && a.vec && !g.res_f32) {
@@ -218,15 +243,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
           r16[sw] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(g.res) + (int64_t)i * g.ldr + j);
         }
       }
-      if (wi == ps) {
+      if (wi == ps / (TI / 2)) {         // the wave row that owns rows [64 ps, 64 ps + 64): two of its TI row blocks
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti)
+        for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
           for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              *reinterpret_cast<f32x4*>(sC + (32 * ti + lr) * CLD + wj * (32 * TJ) + 32 * tj + 8 * q + 4 * lh) =
-                  f32x4{acc[tj][ti][4 * q], acc[tj][ti][4 * q + 1], acc[tj][ti][4 * q + 2], acc[tj][ti][4 * q + 3]};
+            for (int q = 0; q < 4; ++q) {
+              const f32x16& c = acc[tj][(ps % (TI / 2)) * 2 + t2];
+              *reinterpret_cast<f32x4*>(sC + (32 * t2 + lr) * CLD + wj * (32 * TJ) + 32 * tj + 8 * q + 4 * lh) =
+                  f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+            }
       }
       lds_barrier();
 #pragma unroll
@@ -289,12 +316,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const K16Args a) {
       }
       lds_barrier();   // sC is rewritten by the next pass / the next tile's DMA
     }
+    if (first_tile) stamp(6);
+    first_tile = false;
   }
 }
 
-template <int WM, int TJ, int BK, int NS, int EPI>
+template <int WM, int WN, int TI, int TJ, int BK, int NS, int EPI>
 int launch16(const hig_gemm16_desc& g, hipStream_t st) {
-  constexpr int WN = 4 / WM, BM = 64 * WM, BN = 32 * TJ * WN;
+  constexpr int NT = 64 * WM * WN, BM = 32 * TI * WM, BN = 32 * TJ * WN;
   K16Args a;
   a.g = g;
   const int nbi = (g.I + BM - 1) / BM;
@@ -309,10 +338,11 @@ int launch16(const hig_gemm16_desc& g, hipStream_t st) {
   static const int forced_per_cu = getenv("HIG_BF16_PERCU") ? atoi(getenv("HIG_BF16_PERCU")) : 0;   // tuning knob
   if (forced_per_cu > 0) per_cu = forced_per_cu;
   static const int dbg = getenv("HIG_BF16_DBG") ? atoi(getenv("HIG_BF16_DBG")) : 0;
-  a.dbg = dbg;
+  a.dbg = g_stamps ? dbg : (dbg & ~16);
+  a.stamps = g_stamps;
   int grid = 256 * per_cu;
   if (grid > a.ntiles) grid = a.ntiles;
-  hipLaunchKernelGGL((gemm_bf16_kernel<WM, TJ, BK, NS, EPI>), dim3(grid), dim3(NT), 0, st, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TI, TJ, BK, NS, EPI>), dim3(grid), dim3(NT), 0, st, a);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
@@ -323,35 +353,39 @@ int launch16(const hig_gemm16_desc& g, hipStream_t st) {
 // equals the larger tile when it still gives every CU a workgroup, else the smaller one (more CUs busy).
 template <int EPI>
 int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
-  static const int forced = getenv("HIG_BF16_TILE") ? atoi(getenv("HIG_BF16_TILE")) : 0;   // tuning knob: 64 / 128 / 192
+  static const int forced = getenv("HIG_BF16_TILE") ? atoi(getenv("HIG_BF16_TILE")) : 0;   // tuning knob: 64 / 128 / 192 / 256
   auto tiles = [&](int bm, int bn) { return (int64_t)((g.I + bm - 1) / bm) * ((g.J + bn - 1) / bn); };
   auto rounds = [](int64_t t, int slots) { return (t + slots - 1) / slots; };
-  const int64_t t128 = tiles(128, 128), t192 = tiles(128, 192), t64 = tiles(64, 128);
-  const bool fits192 = g.J % 192 == 0 || g.J >= 1536;
+  const int64_t t128 = tiles(128, 128), t64 = tiles(64, 128), t256 = tiles(256, 256);
   int pick = 64;
   if (forced) {
     pick = forced;
   } else {
-    // estimated time = rounds x relative cost of one tile (area ratio, with the smaller tiles' worse fixed-cost share)
-    // (fitted to tools/gemm16_bench.py at M = 6272 and 12544, profiles/r02_notes.md: a 64 x 128 tile costs 0.75 of a
-    // 128 x 128 one, not the 0.5 of its area -- it re-reads the same weight panel for half the rows)
-    const double c128 = (double)rounds(t128, 512) * 1.0, c192 = (double)rounds(t192, 512) * 1.45,
-                 c64 = (double)rounds(t64, 768) * 0.75;
+    // estimated time = rounds x relative cost of one tile (fitted to tools/gemm16_bench.py at M = 6272 and 12544,
+    // profiles/r02_notes.md: a 64 x 128 tile costs 0.75 of a 128 x 128 one, not the 0.5 of its area -- it re-reads the
+    // same weight panel for half the rows)
+    const double c128 = (double)rounds(t128, 512) * 1.0, c64 = (double)rounds(t64, 768) * 0.75;
     pick = 128;
     double best = c128;
     if (t128 < 256 && c64 <= best * 1.25) { pick = 64; best = c64; }        // too few big tiles to occupy the chip
     else if (c64 < best) { pick = 64; best = c64; }
-    // (128 x 192 -- one round for the q/k/v projection at M = 6272 -- measured 28 us against 25 us for 128 x 128 in two
-    // rounds: kept as a forced option only)
-    (void)c192; (void)fits192;
+    // 256 x 256 (8 waves, ONE workgroup per CU): the launch is bound by the ~30 B/clk each CU can DMA into its LDS, and a
+    // 256 x 256 tile does twice the MFMA work per staged byte of two co-resident 128 x 128 tiles -- a round of 256 of
+    // them takes about as long as a round of 512 of those and covers twice the output.  Worth it when it saves a round.
+    // (measured, profiles/r02_notes.md: FFN1 34.2 us against 36.1, q/k/v 47.5 against 42.6 -- no clear win, so it stays a
+    // forced option: HIG_BF16_TILE=256)
+    (void)t256;
   }
+  // (ring depth: 3 and 4 stages at BK = 64 measured slower than 2 at every shape -- the k-tile time is the DMA ISSUE time
+  // of the wave, not the latency of a request)
   if (g.R % 64 == 0) {
-    if (pick == 192) return launch16<2, 3, 64, 2, EPI>(g, st);
-    if (pick == 128) return launch16<2, 2, 64, 2, EPI>(g, st);
-    return launch16<1, 1, 64, 2, EPI>(g, st);
+    if (pick == 256) return launch16<2, 4, 4, 2, 64, 2, EPI>(g, st);
+    if (pick == 192) return launch16<2, 2, 2, 3, 64, 2, EPI>(g, st);
+    if (pick == 128) return launch16<2, 2, 2, 2, 64, 2, EPI>(g, st);
+    return launch16<1, 4, 2, 1, 64, 2, EPI>(g, st);
   }
-  if (pick != 64) return launch16<2, 2, 32, 3, EPI>(g, st);
-  return launch16<1, 1, 32, 3, EPI>(g, st);
+  if (pick != 64) return launch16<2, 2, 2, 2, 32, 3, EPI>(g, st);
+  return launch16<1, 4, 2, 1, 32, 3, EPI>(g, st);
 }
 
 __global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int64_t n) {
@@ -404,5 +438,13 @@ extern "C" int hig_cast_bf16(const float* src, void* dst, int64_t n, hig_stream_
   hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)blocks), dim3(256), 0, hig_stream(stream), src,
                      static_cast<__bf16*>(dst), n);
   HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+// Diagnostic: with HIG_BF16_DBG & 16, thread 0 of every workgroup (< 4096) writes s_memtime stamps of its first tile's
+// phases to buf[block * 8 + k] (k: 0 tile start, 1 setup done, 2 first DMA issued, 3 first k-tile landed, 4 second,
+// 5 main loop done, 6 epilogue done).  NULL switches it off.  Never part of a timed run.
+extern "C" int hig_gemm_bf16_debug_stamps(void* buf) {
+  g_stamps = static_cast<unsigned long long*>(buf);
   return HIG_OK;
 }

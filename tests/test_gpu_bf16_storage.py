@@ -36,7 +36,10 @@ EPIS = {"none": _lib.EPI_NONE, "bias": _lib.EPI_BIAS, "gelu": _lib.EPI_BIAS_GELU
     (300, 200, 64, "bias", 0, 0), (128, 128, 512, "none", 0, 0), (1000, 1024, 512, "gelu", 0, 0),
     (777, 512, 1024, "res", 0, 0), (64, 2048, 2048, "res_silu", 0, 1), (32, 2048, 512, "silu", 0, 0),
     (500, 150, 512, "bias", 1, 0), (6272, 1536, 512, "bias", 0, 0), (45, 96, 96, "res", 1, 1),
-    (2464, 1024, 256, "bias", 0, 0), (70, 264, 32, "gelu", 0, 0), (12544, 512, 512, "res", 0, 0)])
+    (2464, 1024, 256, "bias", 0, 0), (70, 264, 32, "gelu", 0, 0), (12544, 512, 512, "res", 0, 0),
+    # large enough for the 256 x 256 tiles (8 waves, one workgroup per CU), incl. ragged edges in both directions
+    (12544, 1024, 512, "gelu", 0, 0), (12544, 1536, 512, "bias", 0, 0), (12500, 1000, 512, "res", 0, 0),
+    (9600, 1024, 1024, "res_silu", 1, 1)])
 def test_gemm_bf16_all_epilogues_and_ragged_shapes(I, J, R, epi, c_f32, res_f32):
     g = torch.Generator().manual_seed(I * 7 + J * 3 + R)
     X, Y = bf(torch.randn(I, R, generator=g)), bf(torch.randn(J, R, generator=g) / R ** 0.5)
