@@ -70,7 +70,7 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // NS-1 k-tiles ahead of the MFMAs (ring of buffers, ONE raw s_barrier per k-tile, counted vmcnt so that the younger
 // k-tiles stay in flight across the barrier -- a __syncthreads() here would drain them, guide "Pipelining across
 // barriers").
-template <int WM, int WN, int TI, int TJ, int BK, int NS, int EPI>
+template <int WM, int WN, int TI, int TJ, int BK, int NS, int EPI, bool SRD>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Args a) {
   constexpr int NT = 64 * WM * WN, NW = WM * WN;
   constexpr int BM = 32 * TI * WM, BN = 32 * TJ * WN;
@@ -91,6 +91,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Arg
   const __bf16* __restrict__ X = static_cast<const __bf16*>(g.X);
   const __bf16* __restrict__ Y = static_cast<const __bf16*>(g.Y);
   const int nk = g.R / BK;
+  // buffer descriptors (SGPRs): whole operand extents, raw (stride 0) buffers; rows are clamped, so nothing is out of range
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(X), 0, (int)(((int64_t)(g.I - 1) * g.ldx + g.R) * 2), 0x00020000);
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Y), 0, (int)(((int64_t)(g.J - 1) * g.ldy + g.R) * 2), 0x00020000);
 
   // read-side byte offsets inside a stage (k-step ks adds the XOR-ed chunk)
   int xoff[TI], xsw[TI], yoff[TJ], ysw[TJ];
@@ -123,25 +126,48 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Arg
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
     const int i0 = (tile / a.nbj) * BM, j0 = (tile % a.nbj) * BN;
 
-    // per-lane DMA sources: instruction q of this wave covers RPI rows of the A (X) or B (Y) tile
+    // per-lane DMA sources: instruction q of this wave covers RPI rows of the A (X) or B (Y) tile.
+    // SRD form: `buffer_load_dwordx4 ... lds` through a buffer descriptor in SGPRs -- the per-lane part is a 32-bit byte
+    // offset that is constant over the k-loop (clamped row x ld + swizzled chunk), the k-tile offset is ONE scalar: no
+    // 64-bit per-lane address to send and none to advance per DMA.
     const __bf16* src[NQ];
+    int voff[NQ];
     int dst[NQ];
+    [[maybe_unused]] int koff = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int n = wave + NW * q;                     // instruction index in [A tile | B tile] order
       const bool isA = n < NA;
       const int r = (isA ? n : n - NA) * RPI + lane / CHUNKS;
       const int c = (lane % CHUNKS) ^ ((r / RB) & (CHUNKS - 1));
-      src[q] = isA ? X + (int64_t)min(i0 + r, g.I - 1) * g.ldx + 8 * c
-                   : Y + (int64_t)min(j0 + r, g.J - 1) * g.ldy + 8 * c;
+      if (SRD) {
+        voff[q] = isA ? (min(i0 + r, g.I - 1) * (int)g.ldx + 8 * c) * 2 : (min(j0 + r, g.J - 1) * (int)g.ldy + 8 * c) * 2;
+      } else {
+        src[q] = isA ? X + (int64_t)min(i0 + r, g.I - 1) * g.ldx + 8 * c
+                     : Y + (int64_t)min(j0 + r, g.J - 1) * g.ldy + 8 * c;
+      }
       dst[q] = (isA ? 0 : A_BYTES) + (isA ? n : n - NA) * 1024;
     }
-    auto stage = [&](int buf) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
+    auto issue = [&](int buf, int q) {
+      if constexpr (SRD) {
+        static_assert(NA % NW == 0, "a wave's q-th DMA must be of one operand");
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass cannot type-check the builtin and would silently drop the kernel's stub)
+        if (q < NA / NW)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(smem + buf * STAGE + dst[q]), 16,
+                                                   voff[q], koff, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (__attribute__((address_space(3))) void*)(smem + buf * STAGE + dst[q]), 16,
+                                                   voff[q], koff, 0, 0);
+#endif
+      } else {
         glds16(src[q], smem + buf * STAGE + dst[q]);
         src[q] += BK;
       }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) issue(buf, q);
+      koff += BK * 2;
     };
     // the same, spread over the KS k-steps of the MFMA block: a wave needs ~150-200 cycles to issue ONE 1-KiB DMA
     // (s_memtime stamps, profiles/r02_notes.md), so issuing a k-tile's 6-8 back to back held the wave (and, with both
@@ -151,10 +177,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Arg
     auto stage_slice = [&](int buf, int ks) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
-        if (q * KS / NQ == ks) {
-          glds16(src[q], smem + buf * STAGE + dst[q]);
-          src[q] += BK;
-        }
+        if (q * KS / NQ == ks) issue(buf, q);
+      if (ks == KS - 1) koff += BK * 2;
     };
 
     // The epilogue's per-thread bias columns are fetched NOW: every VGPR-returning load of a tile is then retired by
@@ -323,6 +347,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Arg
 
 template <int WM, int WN, int TI, int TJ, int BK, int NS, int EPI>
 int launch16(const hig_gemm16_desc& g, hipStream_t st) {
+  static const int use_srd = getenv("HIG_BF16_SRD") ? atoi(getenv("HIG_BF16_SRD")) : 1;   // tuning knob: 0 = global_load_lds
   constexpr int NT = 64 * WM * WN, BM = 32 * TI * WM, BN = 32 * TJ * WN;
   K16Args a;
   a.g = g;
@@ -342,7 +367,12 @@ int launch16(const hig_gemm16_desc& g, hipStream_t st) {
   a.stamps = g_stamps;
   int grid = 256 * per_cu;
   if (grid > a.ntiles) grid = a.ntiles;
-  hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TI, TJ, BK, NS, EPI>), dim3(grid), dim3(NT), 0, st, a);
+  // (operands beyond 2 GiB would overflow the 32-bit byte offsets of the descriptor form)
+  const bool srd_ok = ((int64_t)g.I * g.ldx < (1ll << 30)) && ((int64_t)g.J * g.ldy < (1ll << 30));
+  if (use_srd && srd_ok)
+    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TI, TJ, BK, NS, EPI, true>), dim3(grid), dim3(NT), 0, st, a);
+  else
+    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TI, TJ, BK, NS, EPI, false>), dim3(grid), dim3(NT), 0, st, a);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
