@@ -75,8 +75,6 @@ int check_dims(const hig_dims* p, Dims& D) {
   HIG_REQUIRE(p->attn_kind == HIG_ATTN_LINEAR || p->attn_kind == HIG_ATTN_FULL, "hig_dims: unknown attn_kind=%d",
               p->attn_kind);
   D.full = p->attn_kind == HIG_ATTN_FULL;
-  if (D.full && D.hd > 64)
-    return hig_set_error(HIG_EUNSUPPORTED, "hig: full (no_eff) attention supports head dim <= 64 (got %d)", D.hd);
   if (p->prec != HIG_PREC_F32 && p->prec != HIG_PREC_BF16X3 && p->prec != HIG_PREC_BF16)
     return hig_set_error(HIG_EINVAL, "hig: unknown prec=%d", p->prec);
   D.prec = p->prec;

@@ -29,8 +29,8 @@ int check_edims(const hig_eval_dims* p, EDims& D) {
               "hig_eval_dims: every extent must be positive (T >= 2, F >= 4)");
   HIG_REQUIRE(D.d % D.H == 0, "hig_eval_dims: d=%d not divisible by H=%d", D.d, D.H);
   D.hd = D.d / D.H;
-  if (!(D.hd == 8 || D.hd == 16 || D.hd == 32 || D.hd == 64))
-    return hig_set_error(HIG_EUNSUPPORTED, "hig eval encoder: head dim %d not in {8,16,32,64}", D.hd);
+  if (!(D.hd == 8 || D.hd == 16 || D.hd == 32 || D.hd == 64 || D.hd == 128))
+    return hig_set_error(HIG_EUNSUPPORTED, "hig eval encoder: head dim %d not in {8,16,32,64,128}", D.hd);
   HIG_REQUIRE(D.d % 4 == 0 && D.ff % 4 == 0 && D.d <= 1024, "hig_eval_dims: d, ff must be multiples of 4 and d <= 1024");
   if (p->prec != HIG_PREC_F32 && p->prec != HIG_PREC_BF16X3 && p->prec != HIG_PREC_BF16)
     return hig_set_error(HIG_EINVAL, "hig: unknown prec=%d", p->prec);

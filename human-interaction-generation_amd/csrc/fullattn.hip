@@ -287,7 +287,293 @@ __global__ __launch_bounds__(256) void full_bwd_kv_kernel(const float* __restric
   }
 }
 
-bool full_hd_ok(int hd) { return hd == 8 || hd == 16 || hd == 32 || hd == 64; }
+// ---------------------------------------------------------------------------------------------
+// Matrix-core variant for head dim 64 / 128 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate).
+// One wave owns 32 queries (forward, query-side backward) or 32 keys (key-side backward); a workgroup is 4 such
+// waves sharing LDS-staged 32-row chunks of the other side.  Everything is computed TRANSPOSED so that per-query
+// (per-key) scalars are per-LANE scalars and no probability tile ever crosses lanes:
+//     S^T[key][query] = K_chunk . Q^T     A = LDS rows (keys), B = the lane's own query row in registers
+//       -> lane (lr, g) holds the 16 logits of query lr for keys 8*(i/4) + 4g + (i%4): the online softmax is 16
+//          in-lane values + one xor-32 shuffle;
+//     O^T[col][query] += V^T . P^T        A = V[key_i(g)][32cb + lr] (one LDS word), B = the lane's own p[i]
+//       -> the k index an MFMA step consumes is key 8*(i/4)+(i%4) in lanes 0-31 and +4 in lanes 32-63, which is
+//          exactly where the S^T accumulator left p[i]: no LDS round trip, no permute.
+// The reduce order over the head dim is permuted identically on both operands (k = 8j + 4g + e).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MC = 32;            // rows of the staged side per chunk
+constexpr int MROWS = 128;        // rows of the register side per workgroup (4 waves x 32)
+
+template <int HD, int LD>
+__device__ __forceinline__ void stage32(const float* __restrict__ src, int64_t ld, int r0, int rows,
+                                        float* __restrict__ dst) {
+  constexpr int Q4 = HD / 4;
+#pragma unroll
+  for (int it = 0; it < MC * Q4 / 256; ++it) {
+    const int idx = threadIdx.x + 256 * it, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) v = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + 4 * c4);
+    *reinterpret_cast<float4*>(dst + rr * LD + 4 * c4) = v;
+  }
+}
+// the lane's half of its own row in the permuted reduce order: r[j][e] = row[8j + 4g + e]
+template <int HD>
+__device__ __forceinline__ void load_half_row(const float* __restrict__ p, float (&r)[HD / 8][4], bool valid, int g) {
+#pragma unroll
+  for (int j = 0; j < HD / 8; ++j) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) v = *reinterpret_cast<const float4*>(p + 8 * j + 4 * g);
+    r[j][0] = v.x; r[j][1] = v.y; r[j][2] = v.z; r[j][3] = v.w;
+  }
+}
+// C[staged row 8*(i/4)+4g+(i%4)][owner lr] = sum_k rows[.][k] * own[k]
+template <int HD, int LD>
+__device__ __forceinline__ f32x16 rows_dot(const float* __restrict__ rows, const float (&own)[HD / 8][4], int lr, int g) {
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < HD / 8; ++j) {
+    const float4 a = *reinterpret_cast<const float4*>(rows + lr * LD + 8 * j + 4 * g);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, own[j][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, own[j][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, own[j][2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, own[j][3], acc, 0, 0, 0);
+  }
+  return acc;
+}
+// acc[cb][.] (column 32cb + 8*(i/4)+4g+(i%4), owner lr) += sum over the 32 staged rows of rows[r][col] * w[r]
+template <int HD, int LD>
+__device__ __forceinline__ void cols_acc(const float* __restrict__ rows, const f32x16& w, f32x16 (&acc)[HD / 32], int lr,
+                                         int g) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float* rp = rows + (8 * (i / 4) + 4 * g + (i % 4)) * LD + lr;
+#pragma unroll
+    for (int cb = 0; cb < HD / 32; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(rp[32 * cb], w[i], acc[cb], 0, 0, 0);
+  }
+}
+template <int HD>
+__device__ __forceinline__ void store_cols(float* __restrict__ rowp, const f32x16 (&acc)[HD / 32], float scale, int g) {
+#pragma unroll
+  for (int cb = 0; cb < HD / 32; ++cb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(rowp + 32 * cb + 8 * q + 4 * g) =
+          make_float4(acc[cb][4 * q] * scale, acc[cb][4 * q + 1] * scale, acc[cb][4 * q + 2] * scale, acc[cb][4 * q + 3] * scale);
+}
+__device__ __forceinline__ float half_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+// forward.  grid = (B*H, ceil(Tq / 128))
+template <int HD>
+__global__ __launch_bounds__(256) void full_fwd_mfma_kernel(const float* __restrict__ Q, int64_t ldq,
+                                                            const float* __restrict__ K, const float* __restrict__ V,
+                                                            int64_t ldk, int Tq, int Tk, int H,
+                                                            const int64_t* __restrict__ qlen,
+                                                            const uint8_t* __restrict__ kpad, float* __restrict__ Y,
+                                                            int64_t ldy, float* __restrict__ lse) {
+  constexpr int LDK = HD + 4, LDV = HD + 8, NCB = HD / 32;
+  __shared__ __attribute__((aligned(16))) float sK[MC * LDK];
+  __shared__ __attribute__((aligned(16))) float sV[MC * LDV];
+  __shared__ __attribute__((aligned(16))) float s_mask[MC];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, g = lane >> 5;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int q0 = blockIdx.y * MROWS + wave * 32, n = q0 + lr;
+  const bool wactive = q0 < Tq, nvalid = n < Tq;
+  const float isq = HD == 64 ? 0.125f : 0.08838834764831845f;   // 1 / sqrt(HD)
+  float qf[HD / 8][4];
+  load_half_row<HD>(Q + ((int64_t)b * Tq + (nvalid ? n : 0)) * ldq + h * HD, qf, nvalid, g);
+  const float addc = nvalid ? query_const(qlen, b, n) : 0.f;
+  const float* Kb = K + (int64_t)b * Tk * ldk + h * HD;
+  const float* Vb = V + (int64_t)b * Tk * ldk + h * HD;
+  const uint8_t* pad = kpad ? kpad + (int64_t)b * Tk : nullptr;
+  f32x16 o[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[cb][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int kc = 0; kc < Tk; kc += MC) {
+    __syncthreads();
+    stage32<HD, LDK>(Kb, ldk, kc, Tk, sK);
+    stage32<HD, LDV>(Vb, ldk, kc, Tk, sV);
+    if (tid < MC) s_mask[tid] = (kc + tid < Tk && !(pad && pad[kc + tid])) ? 0.f : -INFINITY;
+    __syncthreads();
+    if (!wactive) continue;
+    const f32x16 st = rows_dot<HD, LDK>(sK, qf, lr, g);
+    f32x16 p;
+    float cmax = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 mk = *reinterpret_cast<const float4*>(s_mask + 8 * q + 4 * g);
+      p[4 * q] = st[4 * q] * isq + addc + mk.x;
+      p[4 * q + 1] = st[4 * q + 1] * isq + addc + mk.y;
+      p[4 * q + 2] = st[4 * q + 2] * isq + addc + mk.z;
+      p[4 * q + 3] = st[4 * q + 3] * isq + addc + mk.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cmax = fmaxf(cmax, p[i]);
+    cmax = half_max(cmax);
+    const float m_new = fmaxf(m_run, cmax);
+    // exp(-inf) = 0 on the first chunk; a chunk of padded keys only (m_new still -inf) changes nothing
+    const float alpha = m_new == -INFINITY ? 1.f : __expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      p[i] = p[i] == -INFINITY ? 0.f : __expf(p[i] - m_new);
+      psum += p[i];
+    }
+    l_run = l_run * alpha + half_sum(psum);
+    m_run = m_new;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[cb][e] *= alpha;
+    cols_acc<HD, LDV>(sV, p, o, lr, g);
+  }
+  if (nvalid) {
+    store_cols<HD>(Y + ((int64_t)b * Tq + n) * ldy + h * HD, o, 1.0f / l_run, g);
+    if (g == 0) lse[(int64_t)blockIdx.x * Tq + n] = m_run + __logf(l_run);
+  }
+}
+
+// backward, query side (also writes delta).  grid = (B*H, ceil(Tq / 128))
+template <int HD>
+__global__ __launch_bounds__(256) void full_bwd_q_mfma_kernel(const float* __restrict__ dY, int64_t lddy,
+                                                              const float* __restrict__ Y, int64_t ldy,
+                                                              const float* __restrict__ Q, int64_t ldq,
+                                                              const float* __restrict__ K, const float* __restrict__ V,
+                                                              int64_t ldk, int Tq, int Tk, int H,
+                                                              const int64_t* __restrict__ qlen,
+                                                              const float* __restrict__ lse, float* __restrict__ delta,
+                                                              float* __restrict__ dQ, int64_t lddq) {
+  constexpr int LDK = HD + 8, LDV = HD + 4, NCB = HD / 32;
+  __shared__ __attribute__((aligned(16))) float sK[MC * LDK];
+  __shared__ __attribute__((aligned(16))) float sV[MC * LDV];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, g = lane >> 5;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int q0 = blockIdx.y * MROWS + wave * 32, n = q0 + lr;
+  const bool wactive = q0 < Tq, nvalid = n < Tq;
+  const float isq = HD == 64 ? 0.125f : 0.08838834764831845f;   // 1 / sqrt(HD)
+  const int64_t rowq = (int64_t)b * Tq + (nvalid ? n : 0);
+  float qf[HD / 8][4], dyf[HD / 8][4];
+  load_half_row<HD>(Q + rowq * ldq + h * HD, qf, nvalid, g);
+  load_half_row<HD>(dY + rowq * lddy + h * HD, dyf, nvalid, g);
+  float dl = 0.f;
+  if (nvalid) {
+    const float* yp = Y + rowq * ldy + h * HD + 4 * g;
+#pragma unroll
+    for (int j = 0; j < HD / 8; ++j) {
+      const float4 yv = *reinterpret_cast<const float4*>(yp + 8 * j);
+      dl += dyf[j][0] * yv.x + dyf[j][1] * yv.y + dyf[j][2] * yv.z + dyf[j][3] * yv.w;
+    }
+  }
+  dl = half_sum(dl);
+  const float addc = nvalid ? query_const(qlen, b, n) : 0.f;
+  const float my_lse = nvalid ? lse[(int64_t)blockIdx.x * Tq + n] : INFINITY;   // +inf: p = 0 on rows past Tq
+  if (nvalid && g == 0) delta[(int64_t)blockIdx.x * Tq + n] = dl;
+  const float* Kb = K + (int64_t)b * Tk * ldk + h * HD;
+  const float* Vb = V + (int64_t)b * Tk * ldk + h * HD;
+  f32x16 dq[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[cb][e] = 0.f;
+  for (int kc = 0; kc < Tk; kc += MC) {
+    __syncthreads();
+    stage32<HD, LDK>(Kb, ldk, kc, Tk, sK);
+    stage32<HD, LDV>(Vb, ldk, kc, Tk, sV);
+    __syncthreads();
+    if (!wactive) continue;
+    const f32x16 st = rows_dot<HD, LDK>(sK, qf, lr, g);
+    const f32x16 dp = rows_dot<HD, LDV>(sV, dyf, lr, g);
+    f32x16 ds;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = kc + 8 * (i / 4) + 4 * g + (i % 4);
+      const float pr = key < Tk ? __expf(st[i] * isq + addc - my_lse) : 0.f;
+      ds[i] = pr * (dp[i] - dl) * isq;
+    }
+    cols_acc<HD, LDK>(sK, ds, dq, lr, g);
+  }
+  if (nvalid) store_cols<HD>(dQ + ((int64_t)b * Tq + n) * lddq + h * HD, dq, 1.0f, g);
+}
+
+// backward, key side.  grid = (B*H, ceil(Tk / 128)); the wave's 32 keys stay in registers, queries are staged.
+template <int HD>
+__global__ __launch_bounds__(256) void full_bwd_kv_mfma_kernel(const float* __restrict__ dY, int64_t lddy,
+                                                               const float* __restrict__ Q, int64_t ldq,
+                                                               const float* __restrict__ K, const float* __restrict__ V,
+                                                               int64_t ldk, int Tq, int Tk, int H,
+                                                               const int64_t* __restrict__ qlen,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta, float* __restrict__ dK,
+                                                               float* __restrict__ dV, int64_t lddk) {
+  constexpr int LD = HD + 8, NCB = HD / 32;
+  __shared__ __attribute__((aligned(16))) float sQ[MC * LD];
+  __shared__ __attribute__((aligned(16))) float sD[MC * LD];
+  __shared__ __attribute__((aligned(16))) float s_lse[MC], s_delta[MC], s_addc[MC];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, g = lane >> 5;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int m0 = blockIdx.y * MROWS + wave * 32, m = m0 + lr;
+  const bool wactive = m0 < Tk, mvalid = m < Tk;
+  const float isq = HD == 64 ? 0.125f : 0.08838834764831845f;   // 1 / sqrt(HD)
+  const int64_t rowk = (int64_t)b * Tk + (mvalid ? m : 0);
+  float kf[HD / 8][4], vf[HD / 8][4];
+  load_half_row<HD>(K + rowk * ldk + h * HD, kf, mvalid, g);
+  load_half_row<HD>(V + rowk * ldk + h * HD, vf, mvalid, g);
+  const float* Qb = Q + (int64_t)b * Tq * ldq + h * HD;
+  const float* Db = dY + (int64_t)b * Tq * lddy + h * HD;
+  f32x16 dk[NCB], dv[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dk[cb][e] = dv[cb][e] = 0.f;
+  for (int qc = 0; qc < Tq; qc += MC) {
+    __syncthreads();
+    stage32<HD, LD>(Qb, ldq, qc, Tq, sQ);
+    stage32<HD, LD>(Db, lddy, qc, Tq, sD);
+    if (tid < MC) {
+      const int n = qc + tid;
+      s_lse[tid] = n < Tq ? lse[(int64_t)blockIdx.x * Tq + n] : INFINITY;   // +inf: p = 0 on rows past Tq
+      s_delta[tid] = n < Tq ? delta[(int64_t)blockIdx.x * Tq + n] : 0.f;
+      s_addc[tid] = n < Tq ? query_const(qlen, b, n) : 0.f;
+    }
+    __syncthreads();
+    if (!wactive) continue;
+    const f32x16 st = rows_dot<HD, LD>(sQ, kf, lr, g);    // S[query 8*(i/4)+4g+(i%4)][key lr]
+    const f32x16 dp = rows_dot<HD, LD>(sD, vf, lr, g);
+    f32x16 p, ds;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 l4 = *reinterpret_cast<const float4*>(s_lse + 8 * q + 4 * g);
+      const float4 d4 = *reinterpret_cast<const float4*>(s_delta + 8 * q + 4 * g);
+      const float4 a4 = *reinterpret_cast<const float4*>(s_addc + 8 * q + 4 * g);
+      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w}, av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * q + e;
+        p[i] = __expf(st[i] * isq + av[e] - lv[e]);
+        ds[i] = p[i] * (dp[i] - dv4[e]) * isq;
+      }
+    }
+    cols_acc<HD, LD>(sD, p, dv, lr, g);
+    cols_acc<HD, LD>(sQ, ds, dk, lr, g);
+  }
+  if (mvalid) {
+    store_cols<HD>(dK + ((int64_t)b * Tk + m) * lddk + h * HD, dk, 1.0f, g);
+    store_cols<HD>(dV + ((int64_t)b * Tk + m) * lddk + h * HD, dv, 1.0f, g);
+  }
+}
+
+// HIG_FULLATTN_VALU=1 keeps head dim 64 on the VALU kernels (A/B measurements); head dim 128 is matrix-core only
+bool use_mfma(int hd) {
+  static const bool valu = [] { const char* e = getenv("HIG_FULLATTN_VALU"); return e && atoi(e) != 0; }();
+  return hd == 128 || (hd == 64 && !valu);
+}
+
+bool full_hd_ok(int hd) { return hd == 8 || hd == 16 || hd == 32 || hd == 64 || hd == 128; }
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 #define FHD_SWITCH(hd, STMT)                            \
@@ -312,9 +598,20 @@ extern "C" int hig_fullattn_fwd_kpad(const float* Q, int64_t ldq, const float* K
                                      hig_stream_t stream) {
   HIG_REQUIRE(Q && K && V && Y && lse && B > 0 && Tq > 0 && Tk > 0 && H > 0, "hig_fullattn_fwd: bad arguments");
   if (!full_hd_ok(hd))
-    return hig_set_error(HIG_EUNSUPPORTED, "hig_fullattn: head dim %d not in {8,16,32,64}", hd);
+    return hig_set_error(HIG_EUNSUPPORTED, "hig_fullattn: head dim %d not in {8,16,32,64,128}", hd);
   HIG_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldy % 4 == 0 && al16(Q) && al16(K) && al16(V) && al16(Y),
               "hig_fullattn_fwd: operands must be 16-byte aligned");
+  if (use_mfma(hd)) {
+    const dim3 grid(B * H, (Tq + MROWS - 1) / MROWS);
+    if (hd == 128)
+      hipLaunchKernelGGL((full_fwd_mfma_kernel<128>), grid, dim3(256), 0, hig_stream(stream), Q, ldq, K, V, ldk, Tq, Tk, H,
+                         qlen, kpad, Y, ldy, lse);
+    else
+      hipLaunchKernelGGL((full_fwd_mfma_kernel<64>), grid, dim3(256), 0, hig_stream(stream), Q, ldq, K, V, ldk, Tq, Tk, H,
+                         qlen, kpad, Y, ldy, lse);
+    HIG_CHECK_LAUNCH();
+    return HIG_OK;
+  }
   FHD_SWITCH(hd, hipLaunchKernelGGL((full_fwd_kernel<HDV>), dim3(B * H, (Tq + CH - 1) / CH), dim3(256), 0,
                                     hig_stream(stream), Q, ldq, K, V, ldk, Tq, Tk, H, qlen, kpad, Y, ldy, lse));
   HIG_CHECK_LAUNCH();
@@ -329,10 +626,27 @@ extern "C" int hig_fullattn_bwd(const float* dY, int64_t lddy, const float* Y, i
   HIG_REQUIRE(dY && Y && Q && K && V && lse && delta && dQ && dK && dV && B > 0 && Tq > 0 && Tk > 0 && H > 0,
               "hig_fullattn_bwd: bad arguments");
   if (!full_hd_ok(hd))
-    return hig_set_error(HIG_EUNSUPPORTED, "hig_fullattn: head dim %d not in {8,16,32,64}", hd);
+    return hig_set_error(HIG_EUNSUPPORTED, "hig_fullattn: head dim %d not in {8,16,32,64,128}", hd);
   HIG_REQUIRE(lddy % 4 == 0 && ldy % 4 == 0 && ldq % 4 == 0 && ldk % 4 == 0 && lddq % 4 == 0 && lddk % 4 == 0 &&
                   al16(dY) && al16(Y) && al16(Q) && al16(K) && al16(V) && al16(dQ) && al16(dK) && al16(dV),
               "hig_fullattn_bwd: operands must be 16-byte aligned");
+  if (use_mfma(hd)) {
+    const dim3 gq(B * H, (Tq + MROWS - 1) / MROWS), gk(B * H, (Tk + MROWS - 1) / MROWS);
+    hipStream_t st = hig_stream(stream);
+    if (hd == 128) {
+      hipLaunchKernelGGL((full_bwd_q_mfma_kernel<128>), gq, dim3(256), 0, st, dY, lddy, Y, ldy, Q, ldq, K, V, ldk, Tq, Tk, H,
+                         qlen, lse, delta, dQ, lddq);
+      hipLaunchKernelGGL((full_bwd_kv_mfma_kernel<128>), gk, dim3(256), 0, st, dY, lddy, Q, ldq, K, V, ldk, Tq, Tk, H, qlen,
+                         lse, delta, dK, dV, lddk);
+    } else {
+      hipLaunchKernelGGL((full_bwd_q_mfma_kernel<64>), gq, dim3(256), 0, st, dY, lddy, Y, ldy, Q, ldq, K, V, ldk, Tq, Tk, H,
+                         qlen, lse, delta, dQ, lddq);
+      hipLaunchKernelGGL((full_bwd_kv_mfma_kernel<64>), gk, dim3(256), 0, st, dY, lddy, Q, ldq, K, V, ldk, Tq, Tk, H, qlen,
+                         lse, delta, dK, dV, lddk);
+    }
+    HIG_CHECK_LAUNCH();
+    return HIG_OK;
+  }
   FHD_SWITCH(hd, hipLaunchKernelGGL((full_bwd_q_kernel<HDV>), dim3(B * H, (Tq + CH - 1) / CH), dim3(256), 0,
                                     hig_stream(stream), dY, lddy, Y, ldy, Q, ldq, K, V, ldk, Tq, Tk, H, qlen, lse,
                                     delta, dQ, lddq));

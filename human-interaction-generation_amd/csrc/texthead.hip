@@ -21,8 +21,8 @@ int check_tdims(const hig_text_dims* p, const void* const* params, TDims& D) {
               "hig_text_dims: every extent must be positive");
   HIG_REQUIRE(D.Lt % D.H == 0, "hig_text_dims: Lt=%d not divisible by H=%d", D.Lt, D.H);
   D.hd = D.Lt / D.H;
-  if (!(D.hd == 8 || D.hd == 16 || D.hd == 32 || D.hd == 64))
-    return hig_set_error(HIG_EUNSUPPORTED, "hig text head: head dim %d not in {8,16,32,64}", D.hd);
+  if (!(D.hd == 8 || D.hd == 16 || D.hd == 32 || D.hd == 64 || D.hd == 128))
+    return hig_set_error(HIG_EUNSUPPORTED, "hig text head: head dim %d not in {8,16,32,64,128}", D.hd);
   HIG_REQUIRE(D.Lt % 4 == 0 && D.W % 4 == 0 && D.ff % 4 == 0 && D.E % 4 == 0 && D.Lt <= 1024,
               "hig_text_dims: W, Lt, ff, E must be multiples of 4 and Lt <= 1024");
   if (p->prec != HIG_PREC_F32 && p->prec != HIG_PREC_BF16X3 && p->prec != HIG_PREC_BF16)

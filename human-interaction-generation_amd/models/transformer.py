@@ -675,11 +675,11 @@ class MotionTransformer(nn.Module):
 
     # ---- text head (hig_text_head_*) -------------------------------------------------------
     def _has_hip_text_head(self):
-        """True when this model owns a text head the HIP kernels cover (not cap_id, head dim in 8..64)."""
+        """True when this model owns a text head the HIP kernels cover (not cap_id, head dim in 8..128)."""
         if getattr(self, "text_head", "hip") != "hip" or not hasattr(self, "textTransEncoder"):
             return False
         l0 = self.textTransEncoder.layers[0]
-        return self.text_latent_dim // l0.self_attn.num_heads in (8, 16, 32, 64)
+        return self.text_latent_dim // l0.self_attn.num_heads in (8, 16, 32, 64, 128)
 
     def _text_params(self):
         """Text-head parameters in hig.h table order (HIG_T_*, then HIG_TL_* per layer)."""

@@ -263,7 +263,7 @@ int hig_text_head_bwd(const hig_text_dims* dims, const void* const* params, cons
  * ---------------------------------------------------------------------------------------- */
 typedef struct hig_eval_dims {
   int32_t B, T, F;         /* pairs, tokens per person (frames + 1), input_feats (dim_pose - 4) */
-  int32_t d, H, ff, L;     /* latent_dim, num_heads (head dim in {8,16,32,64}), ff_size, num_layers */
+  int32_t d, H, ff, L;     /* latent_dim, num_heads (head dim in {8,16,32,64,128}), ff_size, num_layers */
   int32_t C;               /* class_num: logits per pair */
   int32_t cls;             /* 0 = MotionEncoder, 1 = MotionConsistencyEvalModel ([cls] token first) */
   int32_t prec;            /* HIG_PREC_* of the GEMM products */
@@ -447,7 +447,8 @@ int hig_linattn_ctx_bwd(const float* dA, const float* A, const float* K, const f
  * matrix in memory).  S = q.k/sqrt(hd) (+ -100000 on query rows n >= qlen[b]: the reference puts
  * its mask on the QUERY axis; qlen == NULL for cross attention), W = softmax over the Tk keys,
  * Y = W V; lse[b,h,n] = log sum_m exp(S[n,m]) is kept for the backward, `delta` is scratch
- * (B*H*Tq floats).  Head dim in {8,16,32,64}. */
+ * (B*H*Tq floats).  Head dim in {8,16,32,64,128}; 64 and 128 run on the matrix cores
+ * (v_mfma_f32_32x32x2_f32, exact fp32 products), the smaller ones on the VALU. */
 int hig_fullattn_fwd(const float* Q, int64_t ldq, const float* K, const float* V, int64_t ldk,
                      int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t hd, const int64_t* qlen,
                      float* Y, int64_t ldy, float* lse, hig_stream_t stream);

@@ -132,6 +132,38 @@ def test_no_eff_backward_matches_reference_golden(gold, case):
         assert rel(named[k].grad, p[k].grad) < 1e-4, k
 
 
+def test_no_eff_head_dim_128_long_sequence_against_oracle():
+    """no_eff attention on the matrix cores: head dim 128, T = 300 (transformer.py:196-285 has no head-dim
+    limit).  Forward on the valid rows of a ragged batch, forward + backward tight on a full-length batch."""
+    c = dict(B=2, T=300, F=20, d=256, H=2, L=2, ff=256, N=77, Lt=64, num_frames=300)
+    m = build(c, no_eff=True).train()
+    p = {k: v.clone().requires_grad_(True) for k, v in
+         fill.core_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"]).items()}
+    for lens, tight in (((300, 123), False), ((300, 300), True)):
+        inp = fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], lens, (17, 803))
+        gi = {k: v.to(DEV) for k, v in inp.items()}
+        m.zero_grad()
+        x = gi["x"].clone().requires_grad_(True)
+        out = m(x, gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+        xr = inp["x"].clone().requires_grad_(True)
+        ref = R.denoiser_forward(p, xr, inp["t"], inp["length"], inp["xf_proj"], inp["xf_out"], c["H"], c["L"], no_eff=True)
+        for b, n in enumerate(lens):
+            assert rel(out[b, :n], ref[b, :n]) < (2e-5 if tight else 1e-3), (lens, b)
+        if not tight:
+            continue
+        r = (fill.tensor_for("hd128.r", out.shape) * 10.0)
+        for v in p.values():
+            v.grad = None
+        (out * r.to(DEV)).sum().backward()
+        (ref * r).sum().backward()
+        assert rel(x.grad, xr.grad) < 1e-4
+        named = dict(m.named_parameters())
+        for k in ("out.weight", "temporal_decoder_blocks.0.sa_block.query.weight", "temporal_decoder_blocks.1.sa_block.key.weight",
+                  "temporal_decoder_blocks.0.sa_block.value.weight", "temporal_decoder_blocks.1.ca_block.query.weight",
+                  "temporal_decoder_blocks.0.ca_block.value.weight", "temporal_decoder_blocks.0.ca_block.key.weight"):
+            assert rel(named[k].grad, p[k].grad) < 1e-4, k
+
+
 def test_forward_intermediates_layer0(gold):
     """Layer-0 block outputs through the per-kernel ABI against the reference's hooks (tiny)."""
     g = gold("g2_denoiser_fwd.npz")

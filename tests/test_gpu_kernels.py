@@ -327,7 +327,8 @@ def test_linear_attention_forward_backward(B, T, H, hd, lens):
 
 @pytest.mark.parametrize("B,Tq,Tk,H,hd,lens", [(2, 16, 16, 8, 8, (16, 9)), (2, 60, 60, 8, 16, (60, 41)),
                                                 (2, 196, 196, 4, 64, (196, 77)), (2, 70, 77, 4, 32, None),
-                                                (1, 130, 77, 2, 64, None)])
+                                                (1, 130, 77, 2, 64, None), (1, 300, 300, 2, 128, (211,)),
+                                                (2, 130, 77, 2, 128, None), (3, 257, 129, 8, 64, (257, 1, 100))])
 def test_full_attention_forward_backward(B, Tq, Tk, H, hd, lens):
     """no_eff attention (transformer.py:208-227,242-262) incl. the query-axis -1e5 mask, vs fp64."""
     d = H * hd

@@ -100,15 +100,15 @@ def test_hip_text_head_equals_stock_torch_head_in_training_step():
 
 
 def test_identity_pre_proj_and_split_bf16():
-    """text_latent_dim=512 makes text_pre_proj an nn.Identity (transformer.py:325-328); head dim 128 is not
-    built -> loud error, and text_head='torch' is the documented way out.  Lt=256 + bf16x3 stays in parity."""
+    """text_latent_dim=512 makes text_pre_proj an nn.Identity (transformer.py:325-328) and the head dim 128 (matrix-core
+    attention kernels): HIP head == torch head (text_head='torch').  Lt=256 + bf16x3 stays in parity."""
     c = dict(fill.CASES["tiny"], Lt=512)
     m = build(c)
-    with pytest.raises(RuntimeError, match="head dim 128"):
-        m.encode_text(TEXT_CAPTIONS[:2], DEV)
+    got = m.encode_text(TEXT_CAPTIONS[:2], DEV)
     m.text_head = "torch"
     a, b = m.encode_text(TEXT_CAPTIONS[:2], DEV)
     assert a.shape == (2, 4 * c["d"]) and b.shape == (2, 77, 512)
+    assert rel(got[0], a) < 2e-5 and rel(got[1], b) < 2e-5
     c = fill.CASES["config1"]
     m = build(c)
     ref = m.encode_text(TEXT_CAPTIONS, DEV)
