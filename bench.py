@@ -47,11 +47,11 @@ def flops_per_frame_fwd(c):
     return per_tok + per_sample / T
 
 
-def build_model(c, device):
+def build_model(c, device, no_eff=False):
     import hig_amd
     torch.manual_seed(0)
     m = hig_amd.MotionTransformer(input_feats=c["F"], num_frames=c["T"], latent_dim=c["d"], ff_size=c["ff"],
-                                  num_layers=c["L"], num_heads=c["H"], text_latent_dim=c["Lt"])
+                                  num_layers=c["L"], num_heads=c["H"], text_latent_dim=c["Lt"], no_eff=no_eff)
     g = torch.Generator().manual_seed(0)
     with torch.no_grad():
         for name, p in m.named_parameters():
@@ -116,13 +116,15 @@ def ffn_gemm_roofline(c, device, reps=32):
         d.xf, d.epi, d.prec, d.bias = _lib.XF_NONE, _lib.EPI_BIAS_GELU, _lib.PREC_F32, b.data_ptr()
         descs.append(d)
     L = _lib.lib()
+    # the split-tail scratch hig_denoiser_fwd hands its GEMMs (hig_gemm_ws): same kernel, same tile schedule as in the forward
+    tail = torch.zeros(L.hig_gemm_tail_ws_bytes(), dtype=torch.uint8, device=device)
     for i in range(NB):
-        _lib.check(L.hig_gemm(C.byref(descs[i]), _lib.stream_ptr()))
+        _lib.check(L.hig_gemm_ws(C.byref(descs[i]), tail.data_ptr(), tail.numel(), _lib.stream_ptr()))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for i in range(reps):
-        _lib.check(L.hig_gemm(C.byref(descs[i % NB]), _lib.stream_ptr()))
+        _lib.check(L.hig_gemm_ws(C.byref(descs[i % NB]), tail.data_ptr(), tail.numel(), _lib.stream_ptr()))
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
@@ -130,7 +132,8 @@ def ffn_gemm_roofline(c, device, reps=32):
     ach = flops / (ms * 1e-3) / 1e12
     traffic, src = pmc_traffic_bytes()
     return {"bound": "mfma",
-            "kernel": "gemm_f32_kernel<64,64,X_RS=0,Y_RS=0,XF_NONE,EPI_BIAS_GELU,FAST> (FFN linear1: M=%d K=%d N=%d)" % (M, K, Nn),
+            "kernel": "gemm_f32_kernel<64,64,X_RS=0,Y_RS=0,XF_NONE,EPI_BIAS_GELU,FAST> (FFN linear1: M=%d K=%d N=%d; 12 whole "
+                      "rounds of 64x64 tiles + the last 64 tiles split 4-way along K, as in the forward)" % (M, K, Nn),
             "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
             "flops_per_launch": flops, "avg_launch_ms": round(ms, 4),
@@ -642,6 +645,26 @@ def main():
                 var[tag] = {"fwd_ms": round(e_v, 3), "frames_per_s": round(B * T / e_v * 1e3, 1),
                             "fwd_tflops": round(flops_per_frame_fwd(cv) * B * T / e_v / 1e9, 1)}
                 del mv, iv
+            # no_eff=True (full softmax attention, transformer.py:196-285): config 2 and the config-5 shape (head dim 128)
+            for tag, cv in (("no_eff", c), ("no_eff_config5_shape", dict(c, B=32, T=300, d=1024, L=12, H=8, ff=1024))):
+                mv = build_model(cv, device, no_eff=True).eval()
+                iv = make_inputs(cv, device, rank)
+                mv.cache_text_context = False
+                e_v = timed(fwd_v, k2, 2, 1) / k2 * 1e3
+                var[tag] = {"fwd_ms": round(e_v, 3), "frames_per_s": round(cv["B"] * cv["T"] / e_v * 1e3, 1)}
+                if tag == "no_eff":
+                    mv.train()
+                    xg = iv["x"].clone().requires_grad_(True)
+
+                    def fwdbwd_v():
+                        out = mv(xg, iv["t"], length=iv["length"], xf_proj=iv["xf_proj"], xf_out=iv["xf_out"])
+                        out.backward(iv["x0"])
+
+                    var[tag]["fwd_bwd_ms"] = round(timed(fwdbwd_v, k2, 2, 1) / k2 * 1e3, 3)
+                del mv, iv
+            var["no_eff"]["what"] = ("config 2 with no_eff=True: flash attention on v_mfma_f32_32x32x2_f32 (fullattn.hip), "
+                                     "T x T scores never written")
+            var["no_eff_config5_shape"]["what"] = "B=32 T=300 d=1024 L=12 H=8 (head dim 128), no_eff=True, fp32"
             var["F263"]["what"] = "the reference's real feature width (dim_pose 263), otherwise config 2"
             var["ff2048"]["what"] = "north-star FFN shape ff = 4 d, otherwise config 2"
             extra["config2_variants"] = var

@@ -105,7 +105,7 @@ int check_dims(const hig_dims* p, Dims& D) {
 
 // Forward workspace (floats).  Per-layer block repeated L times when training, once otherwise.
 struct FwdLayout {
-  int64_t te, te_h, emb, ss, h0, lenp, cscr;
+  int64_t te, te_h, emb, ss, h0, lenp, cscr, gtail;
   int64_t layer0, lstride;
   int64_t st1, qkv, A1, kst1, lse1, y1, st2, a1, h1, st3, qc, lse2, y2, st4, a2, h2, z1, f1, y3, st5, a3, h3;
   int64_t st6, iqkv, Ai, ksti, y4, st7, a4, h2b;  // two-person interaction attention block
@@ -123,6 +123,7 @@ FwdLayout fwd_layout(const Dims& D, int training) {
   w.h0 = take(D.M * D.d);
   w.lenp = take((int64_t)D.B * 2);  // int64 lengths with the two halves swapped (partner's mask)
   w.cscr = take(hig_linattn_ctx_scratch_floats(D.B, D.T, D.H, D.hd));   // chunk partials of the context build
+  w.gtail = take(HIG_GEMM_TAIL_BYTES / 4);   // split tail of the fp32 GEMMs (hig_gemm_set_tail_scratch)
   w.layer0 = o;
   o = 0;
   w.st1 = take(D.M * 2);
@@ -193,7 +194,7 @@ TextLayout text_layout(const Dims& D, int training) {
 
 struct BwdLayout {
   int64_t dhA, dhB, t1, t2, tff, dqkv, dA, delta, dkv, dxfn, dss, demb, dtmp, dte_h, slabs, slab_floats,
-      colpart, colpart_w, lnpart, wT, tA, tB, attn, tok0, doutm, postmp, total;
+      colpart, colpart_w, lnpart, wT, tA, tB, attn, tok0, doutm, postmp, gtail, total;
 };
 BwdLayout bwd_layout(const Dims& D) {
   BwdLayout w;
@@ -247,9 +248,18 @@ BwdLayout bwd_layout(const Dims& D) {
   w.tok0 = take((int64_t)D.B * D.d);       // two-person: init-pose rows of d(h0)
   w.doutm = take(D.two ? D.M * D.F : 0);   // two-person: d(out) with the init-pose rows zeroed
   w.postmp = take(D.two ? (int64_t)D.T * D.d : 0);
+  w.gtail = take(HIG_GEMM_TAIL_BYTES / 4);   // split tail of the data-gradient GEMMs (caller's stream only)
   w.total = o;
   return w;
 }
+
+// Hands the fp32 GEMMs launched in this scope (same thread, ONE stream) a split-tail scratch (hig_host.h).
+struct TailScratchScope {
+  explicit TailScratchScope(void* p) { hig_gemm_set_tail_scratch(p, HIG_GEMM_TAIL_BYTES); }
+  ~TailScratchScope() { hig_gemm_set_tail_scratch(nullptr, 0); }
+  TailScratchScope(const TailScratchScope&) = delete;
+  TailScratchScope& operator=(const TailScratchScope&) = delete;
+};
 
 inline const float* P(const void* const* t, int idx) { return static_cast<const float*>(t[idx]); }
 inline const float* PL(const void* const* t, int l, int idx) {
@@ -335,6 +345,11 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
   const int64_t M = D.M;
   const int64_t ss_ld = (int64_t)D.nsty * D.L * 2 * d;
   const int Bp = D.B / 2;  // pairs (two-person)
+
+  // the forward's GEMMs all run on `st`: they share one split-tail scratch (tickets zeroed here, left zero by each launch)
+  if (hipMemsetAsync(ws + w.gtail, 0, HIG_GEMM_TAIL_CNT_BYTES, st) != hipSuccess)
+    return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+  const TailScratchScope tail_scope(ws + w.gtail);
 
   // K0: emb = time_embed(timestep_embedding(t)) + xf_proj; all 3L scale/shift pairs in ONE GEMM
   HIG_TRY(hig_timestep_embedding(t, D.B, d, ws + w.te, stream));
@@ -798,6 +813,12 @@ extern "C" int hig_denoiser_bwd_hooked(const hig_dims* dims, const void* const* 
   float* colp = b + bw.colpart;
   float* lnp = b + bw.lnpart;
   float* dss = b + bw.dss;
+
+  // data-gradient GEMMs (caller's stream) may split their tail; the weight gradients on the side stream never do
+  // (reduce-slow X operand or split-R: excluded by the rule in gemm.hip), so one scratch serves the whole backward
+  if (hipMemsetAsync(b + bw.gtail, 0, HIG_GEMM_TAIL_CNT_BYTES, st) != hipSuccess)
+    return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+  const TailScratchScope tail_scope(b + bw.gtail);
 
   WgradFork fork(side_stream_for_current_device(st), st);
   hig_stream_t wstream = reinterpret_cast<hig_stream_t>(fork.stream());

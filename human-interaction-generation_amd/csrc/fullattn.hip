@@ -304,16 +304,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MC = 32;            // rows of the staged side per chunk
 constexpr int MROWS = 128;        // rows of the register side per workgroup (4 waves x 32)
 
-template <int HD, int LD>
-__device__ __forceinline__ void stage32(const float* __restrict__ src, int64_t ld, int r0, int rows,
-                                        float* __restrict__ dst) {
+// a 32-row chunk of the staged side: fetched into registers one chunk ahead (fetch32), written to LDS at the top of the
+// iteration that consumes it (put32) -- the global latency hides behind the previous chunk's MFMAs
+template <int HD>
+struct Chunk32 { float4 v[MC * (HD / 4) / 256]; };
+template <int HD>
+__device__ __forceinline__ void fetch32(const float* __restrict__ src, int64_t ld, int r0, int rows, Chunk32<HD>& c) {
   constexpr int Q4 = HD / 4;
 #pragma unroll
   for (int it = 0; it < MC * Q4 / 256; ++it) {
     const int idx = threadIdx.x + 256 * it, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < rows) v = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + 4 * c4);
-    *reinterpret_cast<float4*>(dst + rr * LD + 4 * c4) = v;
+    c.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) c.v[it] = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + 4 * c4);
+  }
+}
+template <int HD, int LD>
+__device__ __forceinline__ void put32(const Chunk32<HD>& c, float* __restrict__ dst) {
+  constexpr int Q4 = HD / 4;
+#pragma unroll
+  for (int it = 0; it < MC * Q4 / 256; ++it) {
+    const int idx = threadIdx.x + 256 * it, rr = idx / Q4, c4 = idx % Q4;
+    *reinterpret_cast<float4*>(dst + rr * LD + 4 * c4) = c.v[it];
   }
 }
 // the lane's half of its own row in the permuted reduce order: r[j][e] = row[8j + 4g + e]
@@ -394,12 +405,19 @@ __global__ __launch_bounds__(256) void full_fwd_mfma_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[cb][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  Chunk32<HD> ck, cv;
+  fetch32<HD>(Kb, ldk, 0, Tk, ck);
+  fetch32<HD>(Vb, ldk, 0, Tk, cv);
   for (int kc = 0; kc < Tk; kc += MC) {
     __syncthreads();
-    stage32<HD, LDK>(Kb, ldk, kc, Tk, sK);
-    stage32<HD, LDV>(Vb, ldk, kc, Tk, sV);
+    put32<HD, LDK>(ck, sK);
+    put32<HD, LDV>(cv, sV);
     if (tid < MC) s_mask[tid] = (kc + tid < Tk && !(pad && pad[kc + tid])) ? 0.f : -INFINITY;
     __syncthreads();
+    if (kc + MC < Tk) {
+      fetch32<HD>(Kb, ldk, kc + MC, Tk, ck);
+      fetch32<HD>(Vb, ldk, kc + MC, Tk, cv);
+    }
     if (!wactive) continue;
     const f32x16 st = rows_dot<HD, LDK>(sK, qf, lr, g);
     f32x16 p;
@@ -480,11 +498,18 @@ __global__ __launch_bounds__(256) void full_bwd_q_mfma_kernel(const float* __res
   for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq[cb][e] = 0.f;
+  Chunk32<HD> ck, cv;
+  fetch32<HD>(Kb, ldk, 0, Tk, ck);
+  fetch32<HD>(Vb, ldk, 0, Tk, cv);
   for (int kc = 0; kc < Tk; kc += MC) {
     __syncthreads();
-    stage32<HD, LDK>(Kb, ldk, kc, Tk, sK);
-    stage32<HD, LDV>(Vb, ldk, kc, Tk, sV);
+    put32<HD, LDK>(ck, sK);
+    put32<HD, LDV>(cv, sV);
     __syncthreads();
+    if (kc + MC < Tk) {
+      fetch32<HD>(Kb, ldk, kc + MC, Tk, ck);
+      fetch32<HD>(Vb, ldk, kc + MC, Tk, cv);
+    }
     if (!wactive) continue;
     const f32x16 st = rows_dot<HD, LDK>(sK, qf, lr, g);
     const f32x16 dp = rows_dot<HD, LDV>(sV, dyf, lr, g);
@@ -530,10 +555,13 @@ __global__ __launch_bounds__(256) void full_bwd_kv_mfma_kernel(const float* __re
   for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dk[cb][e] = dv[cb][e] = 0.f;
+  Chunk32<HD> cq, cd;
+  fetch32<HD>(Qb, ldq, 0, Tq, cq);
+  fetch32<HD>(Db, lddy, 0, Tq, cd);
   for (int qc = 0; qc < Tq; qc += MC) {
     __syncthreads();
-    stage32<HD, LD>(Qb, ldq, qc, Tq, sQ);
-    stage32<HD, LD>(Db, lddy, qc, Tq, sD);
+    put32<HD, LD>(cq, sQ);
+    put32<HD, LD>(cd, sD);
     if (tid < MC) {
       const int n = qc + tid;
       s_lse[tid] = n < Tq ? lse[(int64_t)blockIdx.x * Tq + n] : INFINITY;   // +inf: p = 0 on rows past Tq
@@ -541,6 +569,10 @@ __global__ __launch_bounds__(256) void full_bwd_kv_mfma_kernel(const float* __re
       s_addc[tid] = n < Tq ? query_const(qlen, b, n) : 0.f;
     }
     __syncthreads();
+    if (qc + MC < Tq) {
+      fetch32<HD>(Qb, ldq, qc + MC, Tq, cq);
+      fetch32<HD>(Db, lddy, qc + MC, Tq, cd);
+    }
     if (!wactive) continue;
     const f32x16 st = rows_dot<HD, LD>(sQ, kf, lr, g);    // S[query 8*(i/4)+4g+(i%4)][key lr]
     const f32x16 dp = rows_dot<HD, LD>(sD, vf, lr, g);

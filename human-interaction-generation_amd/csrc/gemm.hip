@@ -59,6 +59,15 @@ struct KArgs {
   float* xsum;           // reduce-slow X only: xsum[split * xsum_stride + i] = sum_r X[r][i] over this split, or null
   int64_t xsum_stride;   // (the per-split sums sit right behind each split's slab, so one reduction pass folds both)
   int epi_flags;         // bit 0: LDS-only barriers in the LDS-staged epilogue; bit 1: polynomial erf in the GELU epilogue
+  // Split tail (tail_s > 1): the first `nmain` tiles (a multiple of 256: whole rounds of the chip) are computed as
+  // usual; each of the `tail_rem` tiles behind them is cut into tail_s slices of the reduce range (tail_chunk
+  // elements each), so that the last, partly filled round costs 1/tail_s of a tile instead of a whole one.  `ntiles`
+  // then counts UNITS: nmain + tail_rem * tail_s.  A slice parks its accumulators in tail_ws, takes a ticket from
+  // tail_cnt[tile]; the workgroup that draws the last ticket adds the slices in slice order (deterministic) and runs
+  // the epilogue.  No workgroup ever waits for another one.
+  int tail_s, nmain, tail_rem, tail_chunk;
+  float* tail_ws;          // [tail_rem * tail_s][accumulator floats per thread][NTHREADS]
+  unsigned* tail_cnt;      // [tail_rem], zero before the launch, left zero by it
 };
 
 // LDS-only workgroup barrier: orders the LDS traffic of the epilogue without the vmcnt(0) a __syncthreads() carries,
@@ -183,16 +192,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
   // is a multiple of 8, so a block keeps its XCD), and fetches the first k-tile of its next tile
   // before the epilogue of the current one -- no per-tile launch gap, no exposed prologue latency.
   int i0 = 0, j0 = 0;
+  const int split = blockIdx.y;
+  int rbeg = split * a.r_chunk;
+  int rend = min(g.R, rbeg + a.r_chunk);
+  int nk = (rend - rbeg + BK - 1) / BK;
+  constexpr bool TAIL = PREC == HIG_PREC_F32 && !X_RS && FAST && BI == 64 && BJ == 64;   // kernels the host rule picks
+  int u_slice = -1, u_tile = 0;     // split tail: slice of the reduce range / tail tile this unit belongs to
   auto tile_coords = [&](int lin) {
-    const int q = a.ntiles >> 3, r = a.ntiles & 7, xcd = lin & 7;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    int tile;
+    if (TAIL && a.tail_s > 1 && lin >= a.nmain) {
+      const int lp = lin - a.nmain;
+      if ((a.tail_rem & 7) == 0) {   // the slices of one tile stay on one XCD (lin & 7): its L2 holds the partial sums
+        u_tile = (lp & 7) + 8 * ((lp >> 3) / a.tail_s);
+        u_slice = (lp >> 3) % a.tail_s;
+      } else {
+        u_tile = lp / a.tail_s;
+        u_slice = lp % a.tail_s;
+      }
+      tile = a.nmain + u_tile;
+      rbeg = u_slice * a.tail_chunk;
+      rend = rbeg + a.tail_chunk;
+    } else {
+      const int nt = (TAIL && a.tail_s > 1) ? a.nmain : a.ntiles;
+      const int q = nt >> 3, r = nt & 7, xcd = lin & 7;
+      tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+      u_slice = -1;
+    }
+    nk = (rend - rbeg + BK - 1) / BK;
     i0 = (tile / a.nbj) * BI;
     j0 = (tile % a.nbj) * BJ;
   };
-  const int split = blockIdx.y;
-  const int rbeg = split * a.r_chunk;
-  const int rend = min(g.R, rbeg + a.r_chunk);
   float* __restrict__ C = g.C + (int64_t)split * a.slab;
+  __shared__ unsigned s_ticket;
 
   // ---- per-thread staging coordinates ------------------------------------------------
   // RC tile [ROWS][32]: c4 = tid&7, row = (tid>>3) + 32p.   RS tile [32][ROWS]: ROWS/4 float4
@@ -484,7 +515,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
     __syncthreads();
   };
 
-  const int nk = (rend - rbeg + BK - 1) / BK;
   bool prefetched = false;
   for (int lin = blockIdx.x; lin < a.ntiles; lin += gridDim.x) {
     if (!prefetched) {  // first tile of this block: nothing in flight yet
@@ -515,6 +545,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
       iteration(kt, nk, 0);
       if (kt + 1 < nk) iteration(kt + 1, nk, 1);
     }
+    const int cur_slice = u_slice, cur_tile = u_tile;
     if constexpr (X_RS && PREC == HIG_PREC_F32) {
       if (track_xsum) {   // fold the NTHREADS / XQ thread rows that share a column quad, through the idle staging LDS
         float* sB = smem;
@@ -537,6 +568,44 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
       tile_coords(lin + gridDim.x);
       setup_pointers();
       if (nk > 0) load_tiles(rbeg);
+    }
+    if (TAIL && cur_slice >= 0) {   // split tail: park the partial sums, draw a ticket; the last slice to arrive finishes the tile
+      // Every access to the parked sums and the tickets is a device-scope atomic (sc1: performed at the memory side,
+      // past the per-XCD L2s), ordered by the vmcnt(0) of the barrier between them.  No device-scope FENCE: its
+      // acquire half invalidates the whole L2 of the XCD under the workgroups still streaming operands (measured:
+      // +32 us per GEMM).
+      constexpr int AF = TI * TJ * 16;
+      float* mine = a.tail_ws + ((int64_t)(cur_tile * a.tail_s + cur_slice) * AF) * NTHREADS + tid;
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            __hip_atomic_store(mine + ((tj * TI + ti) * 16 + e) * NTHREADS, acc[tj][ti][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();     // s_waitcnt vmcnt(0): every thread's partial sums have reached memory
+      if (tid == 0) s_ticket = __hip_atomic_fetch_add(a.tail_cnt + cur_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const bool last = s_ticket == (unsigned)(a.tail_s - 1);
+      __syncthreads();     // (s_ticket is rewritten by this workgroup's next unit)
+      if (!last) continue;
+      if (tid == 0) __hip_atomic_store(a.tail_cnt + cur_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[tj][ti][e] = 0.f;
+      for (int sl = 0; sl < a.tail_s; ++sl) {   // slice order: the sum does not depend on who arrived when
+        const float* part = a.tail_ws + ((int64_t)(cur_tile * a.tail_s + sl) * AF) * NTHREADS + tid;
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              acc[tj][ti][e] += __hip_atomic_load(part + ((tj * TI + ti) * 16 + e) * NTHREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
 
 #if HIG_GEMM_LDS_EPI
@@ -749,10 +818,16 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit,
   }
 }
 
+// Scratch of the split tail, owned by the caller of the launches that follow on this thread (hig_gemm_set_tail_scratch):
+// HIG_GEMM_TAIL_CNT_BYTES of tickets (zero on first use) followed by the parked partial sums.
+struct TailScratch { unsigned* cnt; float* ws; int64_t ws_bytes; };
+thread_local TailScratch g_tail = {nullptr, nullptr, 0};
+
 template <int BI, int BJ, bool X_RS, bool Y_RS, int XF, bool XF_ON_Y, int EPI>
 int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipStream_t st, const SplitEpilogue& se) {
   KArgs a;
   a.g = g;
+  a.tail_s = 1; a.nmain = 0; a.tail_rem = 0; a.tail_chunk = 0; a.tail_ws = nullptr; a.tail_cnt = nullptr;
   a.xsum = nullptr;
   a.xsum_stride = 0;
   static const int epi_flags = getenv("HIG_GEMM_EPI") ? atoi(getenv("HIG_GEMM_EPI")) : 0;   // tuning knob
@@ -800,10 +875,32 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
   if (per_cu > max_vgpr_blocks) per_cu = max_vgpr_blocks;
   static const int forced_per_cu = getenv("HIG_GEMM_PERCU") ? atoi(getenv("HIG_GEMM_PERCU")) : -1;  // tuning knob
   if (forced_per_cu > 0) per_cu = forced_per_cu;
-  int gridx = 256 * per_cu;
-  if (gridx > a.ntiles || forced_per_cu == 0) gridx = a.ntiles;   // 0: one workgroup per tile
   const bool fast = a.vecx && a.vecy && (g.R % BK == 0) && g.R > 0 &&
                     (!X_RS || (g.I % 4 == 0 && g.I >= 4)) && (!Y_RS || (g.J % 4 == 0 && g.J >= 4));
+  // Split tail.  M = 12 544 leaves every GEMM of the model a last round that fills 12-37 % of the chip (N = 512:
+  // 1568 64x64 tiles = 6 x 256 + 32): cut those remainder tiles along the reduce range so that the last round costs
+  // 1/s of a tile (see KArgs).  Exact-fp32 products, whole rounds in front, reduce slices of >= 2 k-tiles.
+  static const int tail_on = getenv("HIG_GEMM_TAIL") ? atoi(getenv("HIG_GEMM_TAIL")) : 1;   // tuning knob
+  if constexpr (!X_RS) {
+    if (tail_on && BI == 64 && BJ == 64 && splits == 1 && fast && g.prec == HIG_PREC_F32 && g_tail.ws && a.ntiles > 256 &&
+        a.ntiles % 256 != 0) {
+      const int rem = a.ntiles % 256, nkt = g.R / BK;
+      int s = 1;
+      while (2 * s * rem <= 256 && nkt % (2 * s) == 0 && nkt / (2 * s) >= 2) s *= 2;
+      constexpr int64_t unit_bytes = (int64_t)NTHREADS * (BI / 64) * (BJ / 64) * 16 * 4;
+      if (s > 1 && rem <= HIG_GEMM_TAIL_CNT_BYTES / 4 && rem * s * unit_bytes <= g_tail.ws_bytes) {
+        a.tail_s = s;
+        a.tail_rem = rem;
+        a.nmain = a.ntiles - rem;
+        a.tail_chunk = g.R / s;
+        a.tail_ws = g_tail.ws;
+        a.tail_cnt = g_tail.cnt;
+        a.ntiles = a.nmain + rem * s;
+      }
+    }
+  }
+  int gridx = 256 * per_cu;
+  if (gridx > a.ntiles || forced_per_cu == 0) gridx = a.ntiles;   // 0: one workgroup per tile
   if (a.ntiles > 0 && g.R >= 0) {
     // the bf16 product modes exist for aligned reduce-contiguous operands; anything else
     // (F = 150 projections, reduce-slow dgrad / wgrad layouts) runs the exact fp32 kernel
@@ -902,6 +999,15 @@ int gemm_dispatch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_t 
 int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_t st) {
   return gemm_dispatch(g, splits, slabs, st, SplitEpilogue{nullptr, nullptr, 0, 1});
 }
+void hig_gemm_set_tail_scratch(void* ws, int64_t bytes) {
+  if (!ws || bytes <= HIG_GEMM_TAIL_CNT_BYTES || (reinterpret_cast<uintptr_t>(ws) & 15)) {
+    g_tail = TailScratch{nullptr, nullptr, 0};
+    return;
+  }
+  g_tail.cnt = static_cast<unsigned*>(ws);
+  g_tail.ws = reinterpret_cast<float*>(static_cast<char*>(ws) + HIG_GEMM_TAIL_CNT_BYTES);
+  g_tail.ws_bytes = bytes - HIG_GEMM_TAIL_CNT_BYTES;
+}
 namespace {
 int gemm_dispatch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_t st, const SplitEpilogue& se) {
   HIG_REQUIRE(g.X && g.Y && g.C, "hig_gemm: null operand");
@@ -993,6 +1099,20 @@ extern "C" int hig_gemm(const hig_gemm_desc* g, hig_stream_t stream) {
   HIG_REQUIRE(g->prec == HIG_PREC_F32 || g->prec == HIG_PREC_BF16X3 || g->prec == HIG_PREC_BF16,
               "hig_gemm: unknown prec %d", g->prec);
   return hig_gemm_launch(*g, 1, nullptr, hig_stream(stream));
+}
+
+extern "C" int64_t hig_gemm_tail_ws_bytes(void) { return HIG_GEMM_TAIL_BYTES; }
+
+extern "C" int hig_gemm_ws(const hig_gemm_desc* g, void* ws, int64_t ws_bytes, hig_stream_t stream) {
+  HIG_REQUIRE(g, "hig_gemm_ws: null descriptor");
+  HIG_REQUIRE(g->prec == HIG_PREC_F32 || g->prec == HIG_PREC_BF16X3 || g->prec == HIG_PREC_BF16,
+              "hig_gemm_ws: unknown prec %d", g->prec);
+  HIG_REQUIRE(!ws || (ws_bytes >= HIG_GEMM_TAIL_BYTES && (reinterpret_cast<uintptr_t>(ws) & 15) == 0),
+              "hig_gemm_ws: scratch must be 16-byte aligned and hig_gemm_tail_ws_bytes() long");
+  hig_gemm_set_tail_scratch(ws, ws_bytes);
+  const int rc = hig_gemm_launch(*g, 1, nullptr, hig_stream(stream));
+  hig_gemm_set_tail_scratch(nullptr, 0);
+  return rc;
 }
 
 // Weight-gradient form of hig_gemm as the backward launches it: the reduce range split over `splits` partial outputs in

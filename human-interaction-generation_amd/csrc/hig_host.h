@@ -9,6 +9,14 @@ int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_
 // I <= 64 rows with EPI_BIAS / EPI_BIAS_RES: split-R over `scratch` so the weight streams through ~1024 workgroups
 int hig_gemm_few_rows(const hig_gemm_desc& g, float* scratch, int64_t scratch_floats, hipStream_t st);
 
+// Scratch for the split tail of the exact-fp32 GEMM (gemm.hip, KArgs): the launches that follow on this thread may
+// park partial sums in it.  HIG_GEMM_TAIL_BYTES long, 16-byte aligned; its first HIG_GEMM_TAIL_CNT_BYTES (tickets)
+// must be zero before the first launch and are left zero by every launch.  One scratch serves one stream at a time.
+// nullptr switches the tail off.
+constexpr int64_t HIG_GEMM_TAIL_CNT_BYTES = 1024;
+constexpr int64_t HIG_GEMM_TAIL_BYTES = HIG_GEMM_TAIL_CNT_BYTES + 256 * 16384;   // 256 slices of a 64x64 tile
+void hig_gemm_set_tail_scratch(void* ws, int64_t bytes);
+
 int hig_gemm16_launch(const hig_gemm16_desc& g, hipStream_t st);
 
 namespace {

@@ -354,6 +354,14 @@ typedef struct hig_gemm_desc {
                                         bias gradient that goes with a weight gradient dW = dC^T . act (X = dC) */
 } hig_gemm_desc;
 int hig_gemm(const hig_gemm_desc* g, hig_stream_t stream);
+/* hig_gemm with a scratch for the SPLIT TAIL of the exact-fp32 kernel, as hig_denoiser_fwd runs its GEMMs: when the
+ * 64x64 tiles do not fill whole rounds of the 256 CUs (M = 12 544 never does), the tiles of the last, partly filled
+ * round are cut into 2-8 slices of the reduce range; a slice parks its accumulators in `ws`, draws a ticket, and the
+ * workgroup drawing a tile's last ticket sums the slices in slice order and applies the epilogue (deterministic; no
+ * workgroup waits for another).  ws: hig_gemm_tail_ws_bytes() bytes, 16-byte aligned, its first 1024 bytes zero
+ * before the first launch (every launch leaves them zero); one scratch per stream in flight.  ws == NULL: hig_gemm. */
+int64_t hig_gemm_tail_ws_bytes(void);
+int hig_gemm_ws(const hig_gemm_desc* g, void* ws, int64_t ws_bytes, hig_stream_t stream);
 /* The same contraction with the reduce range split over `splits` partial outputs in `slabs` and a deterministic
  * (fixed-order, no float atomics) slab reduction: how hig_denoiser_bwd runs its weight gradients dW = dC^T . act over
  * the M = B*T rows (autograd of nn.Linear).  EPI_NONE, dense C (ldc == J), I*J % 4 == 0.  splits == 0: the

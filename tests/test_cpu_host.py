@@ -52,7 +52,9 @@ def test_abi_struct_sizes_and_dim_validation():
     n0 = lib.hig_eval_encoder_workspace_bytes(C.byref(e))
     e.cls = 1
     assert 0 < n0 < lib.hig_eval_encoder_workspace_bytes(C.byref(e))        # the [cls] token adds a row per pair
-    bad = _lib.EvalDims(B=4, T=91, F=259, d=512, H=4, ff=1024, L=8, C=26, cls=0, prec=0)
+    ok128 = _lib.EvalDims(B=4, T=91, F=259, d=512, H=4, ff=1024, L=8, C=26, cls=0, prec=0)
+    assert lib.hig_eval_encoder_workspace_bytes(C.byref(ok128)) > 0               # head dim 128: matrix-core attention
+    bad = _lib.EvalDims(B=4, T=91, F=259, d=512, H=2, ff=1024, L=8, C=26, cls=0, prec=0)
     assert lib.hig_eval_encoder_workspace_bytes(C.byref(bad)) < 0 and "head dim" in _lib.last_error()
     bad = _lib.EvalDims(B=4, T=1, F=259, d=512, H=8, ff=1024, L=8, C=26, cls=0, prec=0)
     assert lib.hig_eval_encoder_workspace_bytes(C.byref(bad)) < 0           # a pair needs the init-pose row + a frame

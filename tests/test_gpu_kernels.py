@@ -41,7 +41,7 @@ def P(t):
 
 def gemm(X, Y, I, J, R, x_rs=0, y_rs=0, xf=0, xf_on_y=0, epi=0, bias=None, res=None, aux=None,
          stats=None, gamma=None, beta=None, ss=None, ss_shift_off=0, rows_per_sample=0, pos=None, T=0,
-         prec=0):
+         prec=0, tail_ws=None):
     out = torch.full((I, J), float("nan"), device=DEV)
     d = _lib.GemmDesc()
     d.X, d.ldx, d.x_rs = P(X), X.stride(0), x_rs
@@ -59,7 +59,10 @@ def gemm(X, Y, I, J, R, x_rs=0, y_rs=0, xf=0, xf_on_y=0, epi=0, bias=None, res=N
         d.ss, d.ss_ld, d.ss_shift_off, d.rows_per_sample = P(ss), ss.stride(0), ss_shift_off, rows_per_sample
     if pos is not None:
         d.pos, d.ldpos, d.T = P(pos), pos.stride(0), T
-    _lib.check(_lib.lib().hig_gemm(C.byref(d), _lib.stream_ptr()))
+    if tail_ws is not None:
+        _lib.check(_lib.lib().hig_gemm_ws(C.byref(d), P(tail_ws), tail_ws.numel(), _lib.stream_ptr()))
+    else:
+        _lib.check(_lib.lib().hig_gemm(C.byref(d), _lib.stream_ptr()))
     torch.cuda.synchronize()
     return out
 
@@ -100,6 +103,43 @@ def test_gemm_split_bf16_modes(I, J, R):
                stats=stats_of(X).to(DEV), gamma=gm.to(DEV), beta=be.to(DEV), prec=_lib.PREC_BF16X3)
     refln = F.linear(F.layer_norm(X.double(), (R,), gm.double(), be.double()), Y.double(), b.double())
     assert rel(out, refln) < 2e-5
+
+
+@pytest.mark.parametrize("I,J,R,epi", [(12544, 512, 512, "res"), (12544, 1024, 512, "gelu"), (12544, 1536, 512, "bias"),
+                                       (12544, 512, 1024, "bias"), (8000, 320, 256, "res"), (6272, 512, 512, "bias"),
+                                       (12544, 512, 96, "bias"), (300, 512, 512, "bias")])
+def test_gemm_split_tail(I, J, R, epi):
+    """hig_gemm_ws: the tiles of the last, partly filled round are cut along the reduce range and finished by the
+    workgroup that draws the last ticket.  Same numbers as the fp64 product, run-to-run identical, integer operands
+    exact, tickets left zero, rows outside the tail tiles bit-identical to hig_gemm."""
+    L = _lib.lib()
+    ws = torch.full((L.hig_gemm_tail_ws_bytes(),), 0x5A, dtype=torch.uint8, device=DEV)
+    ws[:1024] = 0
+    X, Y, b, r = rnd(I, R), rnd(J, R, seed=1), rnd(J, seed=2), rnd(I, J, seed=3)
+    kw = dict(bias=b.to(DEV))
+    ref = X.double() @ Y.double().T + b.double()
+    if epi == "res":
+        kw.update(epi=_lib.EPI_BIAS_RES, res=r.to(DEV))
+        ref = ref + r.double()
+    elif epi == "gelu":
+        kw.update(epi=_lib.EPI_BIAS_GELU)
+        ref = F.gelu(ref)
+    else:
+        kw.update(epi=_lib.EPI_BIAS)
+    Xg, Yg = X.to(DEV), Y.to(DEV)
+    plain = gemm(Xg, Yg, I, J, R, **kw)
+    a = gemm(Xg, Yg, I, J, R, tail_ws=ws, **kw)
+    assert rel(a, ref) < 2e-6
+    assert int(ws[:1024].max()) == 0                      # every ticket counter is back to zero
+    for _ in range(3):
+        assert torch.equal(gemm(Xg, Yg, I, J, R, tail_ws=ws, **kw), a)
+    tiles = ((I + 63) // 64) * ((J + 63) // 64)
+    main_rows = (tiles - tiles % 256) // ((J + 63) // 64) * 64 if tiles > 256 else I
+    assert torch.equal(a[:main_rows], plain[:main_rows])   # whole rounds: untouched by the split
+    g = torch.Generator().manual_seed(5)
+    Xi = torch.randint(-4, 5, (I, R), generator=g).float()
+    Yi = torch.randint(-4, 5, (J, R), generator=g).float()
+    assert torch.equal(gemm(Xi.to(DEV), Yi.to(DEV), I, J, R, tail_ws=ws).cpu(), Xi @ Yi.T)
 
 
 def test_gemm_exact_small_integers():
