@@ -280,6 +280,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Arg
             }
       }
       lds_barrier();
+      if (first_tile) stamp(ps == 0 ? 3 : 7);
 #pragma unroll
       for (int sw = 0; sw < NSW; ++sw) {
         const int idx = tid + NT * sw;
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Arg
         }
       }
       lds_barrier();   // sC is rewritten by the next pass / the next tile's DMA
+      if (first_tile && ps == 0) stamp(4);
     }
     if (first_tile) stamp(6);
     first_tile = false;
@@ -406,8 +408,11 @@ int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
     // forced option: HIG_BF16_TILE=256)
     (void)t256;
   }
-  // (ring depth: 3 and 4 stages at BK = 64 measured slower than 2 at every shape -- the k-tile time is the DMA ISSUE time
-  // of the wave, not the latency of a request)
+  // (ring shape, re-measured with per-phase stamps at the FFN linear1 shape, profiles/r02_notes.md section 7: the main
+  // loops of two co-resident workgroups move 2 x 256 KB in ~19.3K cycles = 27 B/clk per CU, which IS the CU's L2 -> LDS
+  // rate (guide: 66-73 GB/s per CU for L2-resident rows, DMA and register staging alike).  4 x BK 32 stages: 18.5K;
+  // 3 x BK 64 stages (one workgroup per CU): 10.9K for its single tile but no second workgroup to cover the epilogue,
+  // 44.9 against 36.5 us; start-time offsets between the co-resident workgroups: no effect.)
   if (g.R % 64 == 0) {
     if (pick == 256) return launch16<2, 4, 4, 2, 64, 2, EPI>(g, st);
     if (pick == 192) return launch16<2, 2, 2, 3, 64, 2, EPI>(g, st);

@@ -25,12 +25,14 @@ for it in range(3):
     _lib.check(lib.hig_gemm_bf16(C.byref(d), _lib.stream_ptr())); torch.cuda.synchronize()
     s = stamps.view(4096, 8).cpu()
     s = s[s[:, 0] > 0]
-    t0 = s[:, 0].min()
-    rel = (s - t0).double() / 1e2            # hundreds of shader cycles (s_memtime ticks = shader cycles; per-XCD counters
-                                             # are not synchronised: read the DELTAS)
-    names = ["start", "setup", "dma0 issued", "-", "-", "mainloop done", "epilogue done"]
-    print("%s B=%d run %d: %d workgroups" % (name, B, it, len(s)))
-    for k in range(7):
-        col = rel[:, k]
-        print("   %-14s median %7.2f x100cyc p10 %7.2f   p90 %7.2f   (delta to previous median %6.2f)" %
-              (names[k], col.median(), col.quantile(0.1), col.quantile(0.9), (col.median() - rel[:, k - 1].median()) if k else 0.0))
+    # per-workgroup DELTAS between consecutive stamps (s_memtime ticks = shader cycles; the per-XCD counters are not
+    # synchronised, so absolute offsets across workgroups mean nothing)
+    cols = [0, 1, 2, 5, 3, 4, 7, 6]
+    names = ["setup (coords, bias, acc = 0)", "first stage(s) of DMA issued", "main loop", "epi: pass 0 staged in LDS",
+             "epi: pass 0 read, stored", "epi: pass 1 staged", "epi: pass 1 read, stored"]
+    print("%s B=%d run %d: %d workgroups (first tile of each)" % (name, B, it, len(s)))
+    for k in range(len(names)):
+        dlt = (s[:, cols[k + 1]] - s[:, cols[k]]).double()
+        print("   %-30s median %7.0f cycles   p10 %7.0f   p90 %7.0f" % (names[k], dlt.median(), dlt.quantile(0.1), dlt.quantile(0.9)))
+    tot = (s[:, 6] - s[:, 0]).double()
+    print("   %-30s median %7.0f cycles" % ("tile", tot.median()))
