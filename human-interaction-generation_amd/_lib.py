@@ -26,7 +26,7 @@ COLSUM_CHUNKS = 512
 SYMBOLS = (
     "hig_version", "hig_last_error", "hig_workspace_bytes", "hig_textctx_bytes",
     "hig_bwd_workspace_bytes", "hig_text_context", "hig_denoiser_fwd", "hig_denoiser_bwd",
-    "hig_gemm", "hig_gemm_ws", "hig_gemm_tail_ws_bytes", "hig_rowstats", "hig_ln_mod_silu", "hig_linattn_ctx", "hig_linattn_apply", "hig_linattn_apply_bwd",
+    "hig_gemm", "hig_gemm_ws", "hig_gemm_tail_ws_bytes", "hig_gemm_debug_stamps", "hig_rowstats", "hig_ln_mod_silu", "hig_linattn_ctx", "hig_linattn_apply", "hig_linattn_apply_bwd",
     "hig_linattn_ctx_bwd", "hig_linattn_bwd_scratch_floats", "hig_fullattn_fwd", "hig_fullattn_bwd", "hig_ln_bwd", "hig_ln_bwd_partial_floats", "hig_transpose", "hig_colsum", "hig_colsum_chunks",
     "hig_timestep_embedding", "hig_q_sample", "hig_p_sample_step", "hig_dec_timesteps",
     "hig_masked_mse", "hig_sumsq_partial", "hig_clip_adam",
@@ -120,6 +120,7 @@ def lib():
         L.hig_gemm_ws.argtypes = [C.POINTER(GemmDesc), vp, i64, vp]
         L.hig_gemm_tail_ws_bytes.argtypes = []
         L.hig_gemm_tail_ws_bytes.restype = i64
+        L.hig_gemm_debug_stamps.argtypes = [vp]
         L.hig_rowstats.argtypes = [vp, i64, i64, i32, vp, vp]
         L.hig_ln_mod_silu.argtypes = [vp, i64, i64, i32, vp, vp, vp, i64, i32, i32, vp, i64, vp, vp]
         L.hig_linattn_ctx.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp]

@@ -68,6 +68,7 @@ struct KArgs {
   int tail_s, nmain, tail_rem, tail_chunk;
   float* tail_ws;          // [tail_rem * tail_s][accumulator floats per thread][NTHREADS]
   unsigned* tail_cnt;      // [tail_rem], zero before the launch, left zero by it
+  unsigned long long* stamps;   // diagnostic (hig_gemm_debug_stamps): s_memtime of the phases of each workgroup's first 2 tiles
 };
 
 // LDS-only workgroup barrier: orders the LDS traffic of the epilogue without the vmcnt(0) a __syncthreads() carries,
@@ -224,6 +225,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
   };
   float* __restrict__ C = g.C + (int64_t)split * a.slab;
   __shared__ unsigned s_ticket;
+  int nth = 0;    // tiles this workgroup has started
+  auto stamp = [&](int k) {
+    if (a.stamps && nth == 2 && threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {   // the SECOND tile: steady state
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      a.stamps[(size_t)blockIdx.x * 8 + k] = t;
+    }
+  };
 
   // ---- per-thread staging coordinates ------------------------------------------------
   // RC tile [ROWS][32]: c4 = tid&7, row = (tid>>3) + 32p.   RS tile [32][ROWS]: ROWS/4 float4
@@ -517,6 +526,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
 
   bool prefetched = false;
   for (int lin = blockIdx.x; lin < a.ntiles; lin += gridDim.x) {
+    ++nth;
+    stamp(0);
     if (!prefetched) {  // first tile of this block: nothing in flight yet
       tile_coords(lin);
       setup_pointers();
@@ -541,10 +552,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
       if (nk > 1) load_tiles(rbeg + BK);
     }
     __syncthreads();
+    stamp(1);
     for (int kt = 0; kt < nk; kt += 2) {
       iteration(kt, nk, 0);
       if (kt + 1 < nk) iteration(kt + 1, nk, 1);
     }
+    stamp(2);
     const int cur_slice = u_slice, cur_tile = u_tile;
     if constexpr (X_RS && PREC == HIG_PREC_F32) {
       if (track_xsum) {   // fold the NTHREADS / XQ thread rows that share a column quad, through the idle staging LDS
@@ -569,6 +582,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
       setup_pointers();
       if (nk > 0) load_tiles(rbeg);
     }
+    stamp(3);
     if (TAIL && cur_slice >= 0) {   // split tail: park the partial sums, draw a ticket; the last slice to arrive finishes the tile
       // Every access to the parked sums and the tickets is a device-scope atomic (sc1: performed at the memory side,
       // past the per-XCD L2s), ordered by the vmcnt(0) of the barrier between them.  No device-scope FENCE: its
@@ -626,6 +640,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
           *reinterpret_cast<f32x4*>(sC + (wi * (32 * TI) + 32 * ti + lr) * CLD + wj * (32 * TJ) + 32 * tj + 8 * q + 4 * lh) =
               f32x4{acc[tj][ti][4 * q], acc[tj][ti][4 * q + 1], acc[tj][ti][4 * q + 2], acc[tj][ti][4 * q + 3]};
     if (a.epi_flags & 1) lds_barrier(); else __syncthreads();
+    stamp(4);
     constexpr int Q4 = BJ / 4, RPP = NTHREADS / Q4;     // float4 per row, rows per pass
     const int c4 = tid % Q4, rr0 = tid / Q4;
     const int j = ej0 + 4 * c4;
@@ -653,7 +668,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
       }
       *reinterpret_cast<f32x4*>(C + (int64_t)i * g.ldc + j) = v;
     }
+    stamp(5);
     if (a.epi_flags & 1) lds_barrier(); else __syncthreads();   // the next tile's store_tiles() reuses this LDS
+    stamp(6);
     continue;
   }
   // tiles too large for one pass (128-row tiles of the bf16 modes, whose staging buffers are small): the two
@@ -820,6 +837,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit,
 
 // Scratch of the split tail, owned by the caller of the launches that follow on this thread (hig_gemm_set_tail_scratch):
 // HIG_GEMM_TAIL_CNT_BYTES of tickets (zero on first use) followed by the parked partial sums.
+unsigned long long* g_gemm_stamps = nullptr;   // diagnostic only (hig_gemm_debug_stamps)
 struct TailScratch { unsigned* cnt; float* ws; int64_t ws_bytes; };
 thread_local TailScratch g_tail = {nullptr, nullptr, 0};
 
@@ -828,6 +846,7 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
   KArgs a;
   a.g = g;
   a.tail_s = 1; a.nmain = 0; a.tail_rem = 0; a.tail_chunk = 0; a.tail_ws = nullptr; a.tail_cnt = nullptr;
+  a.stamps = g_gemm_stamps;
   a.xsum = nullptr;
   a.xsum_stride = 0;
   static const int epi_flags = getenv("HIG_GEMM_EPI") ? atoi(getenv("HIG_GEMM_EPI")) : 0;   // tuning knob
@@ -1099,6 +1118,15 @@ extern "C" int hig_gemm(const hig_gemm_desc* g, hig_stream_t stream) {
   HIG_REQUIRE(g->prec == HIG_PREC_F32 || g->prec == HIG_PREC_BF16X3 || g->prec == HIG_PREC_BF16,
               "hig_gemm: unknown prec %d", g->prec);
   return hig_gemm_launch(*g, 1, nullptr, hig_stream(stream));
+}
+
+// Diagnostic: thread 0 of every workgroup (< 4096) writes s_memtime stamps of its SECOND tile to buf[block * 8 + k]
+// (k: 0 tile start, 1 first k-tile staged, 2 main loop done, 3 next tile's first fetch issued, 4 tile staged in LDS,
+// 5 rows read / epilogue applied / stores issued, 6 closing barrier passed).
+// NULL switches it off.  Never part of a timed run.
+extern "C" int hig_gemm_debug_stamps(void* buf) {
+  g_gemm_stamps = static_cast<unsigned long long*>(buf);
+  return HIG_OK;
 }
 
 extern "C" int64_t hig_gemm_tail_ws_bytes(void) { return HIG_GEMM_TAIL_BYTES; }

@@ -362,6 +362,9 @@ int hig_gemm(const hig_gemm_desc* g, hig_stream_t stream);
  * before the first launch (every launch leaves them zero); one scratch per stream in flight.  ws == NULL: hig_gemm. */
 int64_t hig_gemm_tail_ws_bytes(void);
 int hig_gemm_ws(const hig_gemm_desc* g, void* ws, int64_t ws_bytes, hig_stream_t stream);
+/* Diagnostic (tools/gemm_stamps.py): while buf != NULL, thread 0 of every workgroup (< 4096) of the exact-fp32 kernel
+ * writes s_memtime stamps of its second tile's phases to buf[block * 8 + k].  Never set during a timed run. */
+int hig_gemm_debug_stamps(void* buf);
 /* The same contraction with the reduce range split over `splits` partial outputs in `slabs` and a deterministic
  * (fixed-order, no float atomics) slab reduction: how hig_denoiser_bwd runs its weight gradients dW = dC^T . act over
  * the M = B*T rows (autograd of nn.Linear).  EPI_NONE, dense C (ldc == J), I*J % 4 == 0.  splits == 0: the
