@@ -382,6 +382,14 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
     HIG_CHECK_LAUNCH();
     len_partner = lp;
   }
+  // inference + linear attention: `apply` and the stylization front that follows it can run as ONE kernel (the (M, d)
+  // attention output never reaches HBM); training keeps the pair -- the backward reads y and the LayerNorm statistics.
+  // Opt-in (HIG_FUSE_APPLY_F32=1): measured 34.0 against 36.0 us per attention at B = 64 (head dim 64), equal at B = 32,
+  // 83.8 against 71.1 us at head dim 128, forward 6.24 against 6.26 ms -- the fused kernel's fp32 MFMAs and its
+  // LayerNorm / SiLU arithmetic share the SIMD lanes and a workgroup's chain (load, 2 heads, statistics, epilogue,
+  // store) is 26K cycles long with two workgroups per CU to hide it (profiles/r02_notes.md section 9)
+  static const int fuse_env = getenv("HIG_FUSE_APPLY_F32") ? atoi(getenv("HIG_FUSE_APPLY_F32")) : 0;   // tuning knob
+  const bool fuse_apply = fuse_env && !training && !D.full && (D.H == 4 || D.H == 8) && (D.hd == 64 || D.hd == 128);
   const float* hin = ws + w.h0;
   for (int l = 0; l < D.L; ++l) {
     float* lb = ws + w.layer0 + w.lstride * l;
@@ -400,10 +408,15 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
     } else {
       HIG_TRY(hig_linattn_ctx(lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, length,
                               lb + w.A1, lb + w.kst1, ws + w.cscr, stream));
-      HIG_TRY(hig_linattn_apply(lb + w.qkv, 3 * d, lb + w.A1, lb + w.y1, d, D.B, D.T, D.H, D.hd, stream));
+      if (fuse_apply)   // inference: apply + LayerNorm + modulation + SiLU in one kernel, y1 is never written
+        HIG_TRY(hig_linattn_apply_sty(lb + w.qkv, 3 * d, lb + w.A1, PL(params, l, HIG_L_SA_STY_NORM_W),
+                                      PL(params, l, HIG_L_SA_STY_NORM_B), ssl, ss_ld, d, lb + w.a1, d, D.B, D.T, D.H, D.hd, stream));
+      else
+        HIG_TRY(hig_linattn_apply(lb + w.qkv, 3 * d, lb + w.A1, lb + w.y1, d, D.B, D.T, D.H, D.hd, stream));
     }
-    HIG_TRY(hig_ln_mod_silu(lb + w.y1, d, M, d, PL(params, l, HIG_L_SA_STY_NORM_W), PL(params, l, HIG_L_SA_STY_NORM_B),
-                            ssl, ss_ld, d, D.T, lb + w.a1, d, lb + w.st2, stream));
+    if (!fuse_apply)
+      HIG_TRY(hig_ln_mod_silu(lb + w.y1, d, M, d, PL(params, l, HIG_L_SA_STY_NORM_W), PL(params, l, HIG_L_SA_STY_NORM_B),
+                              ssl, ss_ld, d, D.T, lb + w.a1, d, lb + w.st2, stream));
     HIG_TRY(hig_gemm_launch(G(lb + w.a1, d, 0, PL(params, l, HIG_L_SA_STY_OUT_W), d, 0, lb + w.h1, d, M, d, d)
                                 .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_SA_STY_OUT_B)).res(hin, d).prec(D.prec).g, 1, nullptr, st));
     // ---- cross attention ------------------------------------------------------------
@@ -416,11 +429,17 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
       HIG_TRY(hig_fullattn_fwd(lb + w.qc, d, kvl, kvl + d, 2 * d, D.B, D.T, D.N, D.H, D.hd, nullptr, lb + w.y2, d,
                                lb + w.lse2, stream));
     } else {
-      HIG_TRY(hig_linattn_apply(lb + w.qc, d, tc + tl.layer0 + tl.lstride * l + tl.Ac, lb + w.y2, d, D.B, D.T,
-                                D.H, D.hd, stream));
+      if (fuse_apply)
+        HIG_TRY(hig_linattn_apply_sty(lb + w.qc, d, tc + tl.layer0 + tl.lstride * l + tl.Ac, PL(params, l, HIG_L_CA_STY_NORM_W),
+                                      PL(params, l, HIG_L_CA_STY_NORM_B), ssl + 2 * d, ss_ld, d, lb + w.a2, d, D.B, D.T, D.H, D.hd,
+                                      stream));
+      else
+        HIG_TRY(hig_linattn_apply(lb + w.qc, d, tc + tl.layer0 + tl.lstride * l + tl.Ac, lb + w.y2, d, D.B, D.T,
+                                  D.H, D.hd, stream));
     }
-    HIG_TRY(hig_ln_mod_silu(lb + w.y2, d, M, d, PL(params, l, HIG_L_CA_STY_NORM_W), PL(params, l, HIG_L_CA_STY_NORM_B),
-                            ssl + 2 * d, ss_ld, d, D.T, lb + w.a2, d, lb + w.st4, stream));
+    if (!fuse_apply)
+      HIG_TRY(hig_ln_mod_silu(lb + w.y2, d, M, d, PL(params, l, HIG_L_CA_STY_NORM_W), PL(params, l, HIG_L_CA_STY_NORM_B),
+                              ssl + 2 * d, ss_ld, d, D.T, lb + w.a2, d, lb + w.st4, stream));
     HIG_TRY(hig_gemm_launch(G(lb + w.a2, d, 0, PL(params, l, HIG_L_CA_STY_OUT_W), d, 0, lb + w.h2, d, M, d, d)
                                 .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_CA_STY_OUT_B)).res(lb + w.h1, d).prec(D.prec).g, 1, nullptr, st));
     const float* hffn = lb + w.h2;

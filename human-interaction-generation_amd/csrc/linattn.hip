@@ -1231,34 +1231,66 @@ extern "C" int hig_linattn_apply(const float* Q, int64_t ldq, const float* A, fl
   return HIG_OK;
 }
 
+namespace {
+
+// SiLU of the fused stylization front: exact division for an fp32 result (== ln_mod_silu_kernel), v_rcp_f32 when the
+// result is rounded to bf16 anyway
+template <typename TO> __device__ __forceinline__ float apply_sty_act(float x) { return hig_silu_fast(x); }
+template <> __device__ __forceinline__ float apply_sty_act<float>(float x) { return hig_silu(x); }
+
 // ---------------------------------------------------------------------------------------------
-// apply + stylization front in ONE kernel (bf16 storage):
+// apply + stylization front in ONE kernel (inference: y is not kept):
 //     a[m, :] = silu( LN_d( y[m, :] ) * (1 + scale[b]) + shift[b] ),   y[m, h*HD + l] = sum_c softmax_c(Q[m, h*HD + :])[c] A[b,h][c][l]
 // (transformer.py:111,116-118 followed by :81-85).  A workgroup owns 32 rows of one sample for ALL heads: wave w keeps
-// the heads w*H/4 ... of y in its accumulators (fp32 MFMA 32x32x2, the context slab of the current head staged in a
-// wave-private LDS buffer), the LayerNorm statistics are folded across lanes / waves, and only `a` reaches HBM -- the
-// (rows x d) round trip of y and one launch per attention are gone.
+// the heads w*H/4 ... of y in its accumulators (fp32 MFMA 32x32x2), the LayerNorm statistics are folded across lanes /
+// waves, and only `a` reaches HBM -- the (rows x d) round trip of y and one launch per attention are gone.
+// Per wave: the query tile of a head (32 rows x HD) arrives by coalesced 16-byte loads and is turned into the MFMA
+// layout through a wave-private LDS tile; the context slab (16 KiB of A[b,h]) sits in a second wave-private buffer.
+// Both are fetched into registers ONE STEP AHEAD (the next slab while the current one is multiplied, the next head's
+// queries during the current head), so a wave's MFMAs do not wait behind its own loads.  Wave-private LDS needs no
+// barrier: the LDS executes one wave's operations in order.
+// TQ / TO: storage type of the queries / of `a` (float or __bf16).
 // ---------------------------------------------------------------------------------------------
-template <int HD>
-__global__ __launch_bounds__(256) void apply_sty16_kernel(const __bf16* __restrict__ Q, int64_t ldq,
-                                                          const float* __restrict__ A, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, const float* __restrict__ ss,
-                                                          int64_t ss_ld, int shift_off, __bf16* __restrict__ Out,
-                                                          int64_t ldo, int rows, int H, int nblk) {
+template <typename T> struct Vec16 {};
+template <> struct Vec16<float> { static constexpr int N = 4; };
+template <> struct Vec16<__bf16> { static constexpr int N = 8; };
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));   // native vectors: arrays of them stay in registers (SROA)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void put16(float* dst, u32x4_t raw, const float*) {
+  *reinterpret_cast<u32x4_t*>(dst) = raw;
+}
+__device__ __forceinline__ void put16(float* dst, u32x4_t raw, const __bf16*) {   // 8 bf16 -> 8 floats
+  *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u),
+                                             __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xffff0000u)};
+  *reinterpret_cast<f32x4_t*>(dst + 4) = f32x4_t{__uint_as_float(raw.z << 16), __uint_as_float(raw.z & 0xffff0000u),
+                                                 __uint_as_float(raw.w << 16), __uint_as_float(raw.w & 0xffff0000u)};
+}
+
+template <int HD, typename TQ, typename TO>
+__global__ __launch_bounds__(256) void apply_sty_kernel(const TQ* __restrict__ Q, int64_t ldq,
+                                                        const float* __restrict__ A, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ ss,
+                                                        int64_t ss_ld, int shift_off, TO* __restrict__ Out,
+                                                        int64_t ldo, int rows, int H, int nblk) {
   constexpr int TB = HD / 32;            // 32-column blocks per head
   constexpr int KC = 4096 / HD;          // context channels per 16 KiB slab
+  constexpr int NSLAB = HD / KC;         // slabs per head
   constexpr int MAXHPW = 2;              // heads per wave (H <= 8)
+  constexpr int QLD = HD + 4;            // row stride of the wave's query tile (floats)
+  constexpr int EQ = Vec16<TQ>::N;       // query elements per 16-byte load
+  constexpr int CPR = HD / EQ;           // 16-byte pieces per query row of one head
+  constexpr int NQL = 32 * CPR / 64;     // ... per lane
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  float* sA = reinterpret_cast<float*>(smem_dyn);          // [4 waves][KC][HD]
   __shared__ float red[2][4][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, kk = lane >> 5;
   const int b = blockIdx.x / nblk, r0 = (blockIdx.x % nblk) * 32;
   const int HPW = H / 4;
   const int d = H * HD;
-  const int row = min(r0 + lr, rows - 1);
-  const __bf16* qrow = Q + ((int64_t)b * rows + row) * ldq;
-  float* sAw = sA + wave * (KC * HD);
+  constexpr int WBUF = 32 * QLD > KC * HD ? 32 * QLD : KC * HD;   // floats per wave
+  float* sAw = reinterpret_cast<float*>(smem_dyn) + wave * WBUF;   // [KC][HD] context slab of the current step
+  float* sQw = sAw;   // [32][QLD] query tile of a head: lives there only until its rows are back in registers (in MFMA
+                      // order), i.e. before the head's first slab is written -- one wave's LDS operations execute in order
 
   f32x16 acc[MAXHPW][TB];
 #pragma unroll
@@ -1266,16 +1298,40 @@ __global__ __launch_bounds__(256) void apply_sty16_kernel(const __bf16* __restri
 #pragma unroll
     for (int tb = 0; tb < TB; ++tb) zero16(acc[hh][tb]);
 
+  u32x4_t pq[NQL];   // next head's query tile, as loaded
+  f32x4_t pa[16];    // next context slab
+  auto fetch_q = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < NQL; ++i) {
+      const int idx = lane + 64 * i, rr = idx / CPR, c = idx % CPR;
+      const int row = min(r0 + rr, rows - 1);
+      pq[i] = *reinterpret_cast<const u32x4_t*>(Q + ((int64_t)b * rows + row) * ldq + h * HD + EQ * c);
+    }
+  };
+  auto fetch_a = [&](int h, int c0) {
+    const f32x4_t* src = reinterpret_cast<const f32x4_t*>(A + (((int64_t)b * H + h) * HD + c0) * HD);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pa[i] = src[lane + 64 * i];
+  };
+  fetch_q(wave * HPW);
+  fetch_a(wave * HPW, 0);
+
 #pragma unroll
   for (int hh = 0; hh < MAXHPW; ++hh) {
     if (hh >= HPW) break;
     const int h = wave * HPW + hh;
-    // this lane's share of the query row: channels 8ks + 4kk + j (the MFMA k order), softmax over all HD channels
-    float4 q[HD / 8];
+    // query tile -> LDS (fp32), then this lane's share of row lr: channels 8ks + 4kk + j (the MFMA k order)
+#pragma unroll
+    for (int i = 0; i < NQL; ++i) {
+      const int idx = lane + 64 * i, rr = idx / CPR, c = idx % CPR;
+      put16(sQw + rr * QLD + EQ * c, pq[i], static_cast<const TQ*>(nullptr));
+    }
+    if (hh + 1 < HPW) fetch_q(h + 1);
+    f32x4_t q[HD / 8];
     float m = -INFINITY;
 #pragma unroll
     for (int ks = 0; ks < HD / 8; ++ks) {
-      q[ks] = ld4(qrow + h * HD + 8 * ks + 4 * kk);
+      q[ks] = *reinterpret_cast<const f32x4_t*>(sQw + lr * QLD + 8 * ks + 4 * kk);
       m = fmaxf(m, fmaxf(fmaxf(q[ks].x, q[ks].y), fmaxf(q[ks].z, q[ks].w)));
     }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -1287,22 +1343,21 @@ __global__ __launch_bounds__(256) void apply_sty16_kernel(const __bf16* __restri
     }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    const float* Ah = A + ((int64_t)b * H + h) * HD * HD;
 #pragma unroll
-    for (int c0 = 0; c0 < HD; c0 += KC) {
-      // stage context rows c0 .. c0+KC of this head: KC x HD floats = 16 KiB = 16 float4 per lane (wave-private buffer:
-      // LDS operations of one wave complete in order, no barrier needed)
+    for (int ks = 0; ks < HD / 8; ++ks) q[ks] *= inv;
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
-        reinterpret_cast<float4*>(sAw)[lane + 64 * i] = reinterpret_cast<const float4*>(Ah + c0 * HD)[lane + 64 * i];
+    for (int sl = 0; sl < NSLAB; ++sl) {
+      const int c0 = sl * KC;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) reinterpret_cast<f32x4_t*>(sAw)[lane + 64 * i] = pa[i];
+      if (sl + 1 < NSLAB) fetch_a(h, c0 + KC);
+      else if (hh + 1 < HPW) fetch_a(h + 1, 0);
 #pragma unroll
       for (int ks = c0 / 8; ks < (c0 + KC) / 8; ++ks) {
-        const float4 qv = q[ks];
         const float* ap = sAw + (8 * ks + 4 * kk - c0) * HD + lr;
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb)
-          acc[hh][tb] = mfma4(acc[hh][tb], ap[32 * tb], ap[HD + 32 * tb], ap[2 * HD + 32 * tb], ap[3 * HD + 32 * tb],
-                              make_float4(qv.x * inv, qv.y * inv, qv.z * inv, qv.w * inv));
+          acc[hh][tb] = mfma4(acc[hh][tb], ap[32 * tb], ap[HD + 32 * tb], ap[2 * HD + 32 * tb], ap[3 * HD + 32 * tb], make_float4(q[ks].x, q[ks].y, q[ks].z, q[ks].w));
       }
     }
   }
@@ -1332,11 +1387,11 @@ __global__ __launch_bounds__(256) void apply_sty16_kernel(const __bf16* __restri
   }
   qd += __shfl_xor(qd, 32, 64);
   if (kk == 0) red[1][wave][lr] = qd;
-  __syncthreads();     // (also: every wave is done with its context slabs -- the LDS is reused for the output tile)
+  __syncthreads();     // (also: every wave is done with its LDS buffers -- they are reused for the output tile)
   const float rstd = rsqrtf(((red[1][0][lr] + red[1][1][lr]) + (red[1][2][lr] + red[1][3][lr])) / (float)d + 1e-5f);
-  // ---- modulate + SiLU, staged as a bf16 [32][d] tile (row stride d + 8 elements), out as whole rows ----
-  __bf16* sO = reinterpret_cast<__bf16*>(smem_dyn);
-  const int ldso = d + 8;
+  // ---- modulate + SiLU, staged as a [32][d] tile of TO (padded rows), out as whole rows ----
+  TO* sO = reinterpret_cast<TO*>(smem_dyn);
+  const int ldso = d + 16 / (int)sizeof(TO);
   const float* ssrow = ss + (int64_t)b * ss_ld;
 #pragma unroll
   for (int hh = 0; hh < MAXHPW; ++hh) {
@@ -1350,22 +1405,54 @@ __global__ __launch_bounds__(256) void apply_sty16_kernel(const __bf16* __restri
         const float4 g4 = *reinterpret_cast<const float4*>(gamma + col), b4 = *reinterpret_cast<const float4*>(beta + col);
         const float4 sc = *reinterpret_cast<const float4*>(ssrow + col), sh = *reinterpret_cast<const float4*>(ssrow + shift_off + col);
         float4 o;
-        o.x = hig_silu_fast(((acc[hh][tb][4 * qq] - mean) * rstd * g4.x + b4.x) * (1.0f + sc.x) + sh.x);
-        o.y = hig_silu_fast(((acc[hh][tb][4 * qq + 1] - mean) * rstd * g4.y + b4.y) * (1.0f + sc.y) + sh.y);
-        o.z = hig_silu_fast(((acc[hh][tb][4 * qq + 2] - mean) * rstd * g4.z + b4.z) * (1.0f + sc.z) + sh.z);
-        o.w = hig_silu_fast(((acc[hh][tb][4 * qq + 3] - mean) * rstd * g4.w + b4.w) * (1.0f + sc.w) + sh.w);
+        o.x = apply_sty_act<TO>(((acc[hh][tb][4 * qq] - mean) * rstd * g4.x + b4.x) * (1.0f + sc.x) + sh.x);
+        o.y = apply_sty_act<TO>(((acc[hh][tb][4 * qq + 1] - mean) * rstd * g4.y + b4.y) * (1.0f + sc.y) + sh.y);
+        o.z = apply_sty_act<TO>(((acc[hh][tb][4 * qq + 2] - mean) * rstd * g4.z + b4.z) * (1.0f + sc.z) + sh.z);
+        o.w = apply_sty_act<TO>(((acc[hh][tb][4 * qq + 3] - mean) * rstd * g4.w + b4.w) * (1.0f + sc.w) + sh.w);
         st4(sO + lr * ldso + col, o);
       }
   }
   __syncthreads();
-  const int c16 = d / 8;                       // 16-byte chunks per row
+  constexpr int EO = 16 / (int)sizeof(TO);     // output elements per 16-byte chunk
+  const int c16 = d / EO;                      // 16-byte chunks per row
   for (int idx = tid; idx < 32 * c16; idx += 256) {
     const int rr = idx / c16, ch = idx % c16;
     if (r0 + rr < rows)
-      *reinterpret_cast<uint4*>(Out + ((int64_t)b * rows + r0 + rr) * ldo + 8 * ch) =
-          *reinterpret_cast<const uint4*>(sO + rr * ldso + 8 * ch);
+      *reinterpret_cast<uint4*>(Out + ((int64_t)b * rows + r0 + rr) * ldo + EO * ch) =
+          *reinterpret_cast<const uint4*>(sO + rr * ldso + EO * ch);
   }
 }
+
+template <typename TQ, typename TO>
+int launch_apply_sty(const TQ* q, int64_t ldq, const float* A, const float* gamma, const float* beta, const float* ss,
+                     int64_t ss_ld, int32_t shift_off, TO* o, int64_t ldo, int32_t B, int32_t rows, int32_t H, int32_t hd,
+                     hipStream_t st) {
+  const int nblk = (rows + 31) / 32;
+  const int d = H * hd;
+  const size_t wbuf = (size_t)32 * (hd + 4) > 4096 ? (size_t)32 * (hd + 4) : 4096;
+  const size_t lds_main = 4 * wbuf * sizeof(float);
+  const size_t lds_out = (size_t)32 * (d + 16 / sizeof(TO)) * sizeof(TO);
+  const size_t lds = lds_main > lds_out ? lds_main : lds_out;
+  static const int big_lds_rc = [] {   // more than the default dynamic-LDS cap
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&apply_sty_kernel<64, TQ, TO>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&apply_sty_kernel<128, TQ, TO>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : 1;
+  }();
+  if (big_lds_rc != 0 || lds > 156 * 1024)
+    return hig_set_error(HIG_EHIP, "hig_linattn_apply_sty: cannot reserve %zu bytes of LDS", lds);
+  if (hd == 64)
+    hipLaunchKernelGGL((apply_sty_kernel<64, TQ, TO>), dim3(B * nblk), dim3(256), lds, st, q, ldq, A, gamma, beta, ss, ss_ld,
+                       shift_off, o, ldo, rows, H, nblk);
+  else
+    hipLaunchKernelGGL((apply_sty_kernel<128, TQ, TO>), dim3(B * nblk), dim3(256), lds, st, q, ldq, A, gamma, beta, ss, ss_ld,
+                       shift_off, o, ldo, rows, H, nblk);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+}  // namespace
 
 // bf16-storage forms (hig_dims.storage == HIG_STORE_BF16): K / V / Q / Y are bf16, the context matrices and the
 // softmax statistics stay fp32.  Head dim 64 or 128 (the MFMA kernels).
@@ -1483,35 +1570,27 @@ extern "C" int hig_linattn_apply_sty_bf16(const void* Q, int64_t ldq, const floa
   HIG_REQUIRE(Q && A && gamma && beta && ss && Out && B > 0 && rows > 0, "hig_linattn_apply_sty_bf16: bad arguments");
   if ((hd != 64 && hd != 128) || (H != 4 && H != 8))
     return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn_apply_sty_bf16: built for head dim 64 / 128 and 4 or 8 heads (got %d, %d)", hd, H);
-  HIG_REQUIRE(ldq % 4 == 0 && ldo % 8 == 0 && ss_ld % 4 == 0 && ss_shift_off % 4 == 0 &&
-                  ((reinterpret_cast<uintptr_t>(Q) & 7) | (reinterpret_cast<uintptr_t>(Out) & 15) |
+  HIG_REQUIRE(ldq % 8 == 0 && ldo % 8 == 0 && ss_ld % 4 == 0 && ss_shift_off % 4 == 0 &&
+                  ((reinterpret_cast<uintptr_t>(Q) & 15) | (reinterpret_cast<uintptr_t>(Out) & 15) |
                    (reinterpret_cast<uintptr_t>(gamma) & 15) | (reinterpret_cast<uintptr_t>(beta) & 15) |
                    (reinterpret_cast<uintptr_t>(ss) & 15)) == 0,
               "hig_linattn_apply_sty_bf16: alignment");
-  const int nblk = (rows + 31) / 32;
-  const int d = H * hd;
-  size_t lds = 4 * 4096 * sizeof(float);
-  const size_t lds_out = (size_t)32 * (d + 8) * 2;
-  if (lds_out > lds) lds = lds_out;
-  hipStream_t st = hig_stream(stream);
-  const __bf16* q = static_cast<const __bf16*>(Q);
-  __bf16* o = static_cast<__bf16*>(Out);
-  static const int big_lds_rc = [] {   // 64 KiB of context slabs (+ the statistics) exceed the default dynamic-LDS cap
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&apply_sty16_kernel<64>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&apply_sty16_kernel<128>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : 1;
-  }();
-  if (big_lds_rc != 0 || lds > 80 * 1024)
-    return hig_set_error(HIG_EHIP, "hig_linattn_apply_sty_bf16: cannot reserve %zu bytes of LDS", lds);
-  if (hd == 64) {
-    hipLaunchKernelGGL(apply_sty16_kernel<64>, dim3(B * nblk), dim3(256), lds, st, q, ldq, A, gamma, beta, ss, ss_ld, ss_shift_off, o,
-                       ldo, rows, H, nblk);
-  } else {
-    hipLaunchKernelGGL(apply_sty16_kernel<128>, dim3(B * nblk), dim3(256), lds, st, q, ldq, A, gamma, beta, ss, ss_ld, ss_shift_off, o,
-                       ldo, rows, H, nblk);
-  }
-  HIG_CHECK_LAUNCH();
-  return HIG_OK;
+  return launch_apply_sty<__bf16, __bf16>(static_cast<const __bf16*>(Q), ldq, A, gamma, beta, ss, ss_ld, ss_shift_off,
+                                          static_cast<__bf16*>(Out), ldo, B, rows, H, hd, hig_stream(stream));
+}
+
+// fp32 storage form of the same kernel (inference forward of hig_denoiser_fwd): Q and Out fp32.
+extern "C" int hig_linattn_apply_sty(const float* Q, int64_t ldq, const float* A, const float* gamma, const float* beta,
+                                     const float* ss, int64_t ss_ld, int32_t ss_shift_off, float* Out, int64_t ldo,
+                                     int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream) {
+  HIG_REQUIRE(Q && A && gamma && beta && ss && Out && B > 0 && rows > 0, "hig_linattn_apply_sty: bad arguments");
+  if ((hd != 64 && hd != 128) || (H != 4 && H != 8))
+    return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn_apply_sty: built for head dim 64 / 128 and 4 or 8 heads (got %d, %d)", hd, H);
+  HIG_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ss_ld % 4 == 0 && ss_shift_off % 4 == 0 &&
+                  ((reinterpret_cast<uintptr_t>(Q) & 15) | (reinterpret_cast<uintptr_t>(Out) & 15) |
+                   (reinterpret_cast<uintptr_t>(gamma) & 15) | (reinterpret_cast<uintptr_t>(beta) & 15) |
+                   (reinterpret_cast<uintptr_t>(ss) & 15)) == 0,
+              "hig_linattn_apply_sty: alignment");
+  return launch_apply_sty<float, float>(Q, ldq, A, gamma, beta, ss, ss_ld, ss_shift_off, Out, ldo, B, rows, H, hd,
+                                        hig_stream(stream));
 }

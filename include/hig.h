@@ -408,6 +408,11 @@ int hig_linattn_apply_bf16(const void* Q, int64_t ldq, const float* A, void* Y, 
 int hig_linattn_apply_sty_bf16(const void* Q, int64_t ldq, const float* A, const float* gamma, const float* beta,
                                const float* ss, int64_t ss_ld, int32_t ss_shift_off, void* Out, int64_t ldo,
                                int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
+/* The same fused kernel with fp32 storage (hig_denoiser_fwd uses it for inference when HIG_FUSE_APPLY_F32=1; by default
+ * it runs hig_linattn_apply + hig_ln_mod_silu, which measured equal).  Q, Out fp32, 16-byte aligned. */
+int hig_linattn_apply_sty(const float* Q, int64_t ldq, const float* A, const float* gamma, const float* beta,
+                          const float* ss, int64_t ss_ld, int32_t ss_shift_off, float* Out, int64_t ldo,
+                          int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
 
 /* Row statistics for LayerNorm: stats[m] = (mean, rstd) of x[m, :n], eps = 1e-5, biased var. */
 int hig_rowstats(const float* x, int64_t ldx, int64_t rows, int32_t n, float* stats,

@@ -406,6 +406,37 @@ def test_full_attention_forward_backward(B, Tq, Tk, H, hd, lens):
     assert rel(dkv, kvd.grad.reshape(B * Tk, 2 * d)) < 2e-5
 
 
+@pytest.mark.parametrize("hd,H,B,T", [(64, 8, 3, 196), (128, 8, 2, 75), (64, 4, 2, 33), (128, 4, 1, 300)])
+def test_fused_apply_stylization_front_fp32(hd, H, B, T):
+    """hig_linattn_apply_sty (the inference forward's attention epilogue: apply + LayerNorm + (1 + scale) + shift + SiLU in
+    one kernel, transformer.py:111,116-118 then :81-85) == hig_linattn_apply followed by hig_ln_mod_silu, and both == fp64."""
+    d = H * hd
+    g = torch.Generator().manual_seed(hd + H + B + T)
+    q = (torch.randn(B * T, 3 * d, generator=g) * 2).to(DEV)          # queries inside a q/k/v buffer (ld = 3 d)
+    A = (torch.randn(B, H, hd, hd, generator=g) * 0.5).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV), (0.1 * torch.randn(d, generator=g)).to(DEV)
+    ss = (0.3 * torch.randn(B, 6 * d, generator=g)).to(DEV)            # one (scale, shift) pair inside the stacked table
+    L, s = _lib.lib(), _lib.stream_ptr()
+    out = torch.full((B * T, d), float("nan"), device=DEV)
+    _lib.check(L.hig_linattn_apply_sty(P(q), 3 * d, P(A), P(gamma), P(beta), ss.data_ptr() + 8 * d, 6 * d, d, P(out), d,
+                                       B, T, H, hd, s))
+    y = torch.empty(B * T, d, device=DEV)
+    two = torch.empty(B * T, d, device=DEV)
+    st = torch.empty(B * T, 2, device=DEV)
+    _lib.check(L.hig_linattn_apply(P(q), 3 * d, P(A), P(y), d, B, T, H, hd, s))
+    _lib.check(L.hig_ln_mod_silu(P(y), d, B * T, d, P(gamma), P(beta), ss.data_ptr() + 8 * d, 6 * d, d, T, P(two), d, P(st), s))
+    torch.cuda.synchronize()
+    qd = q[:, :d].double().cpu().view(B, T, H, hd)
+    yd = torch.einsum("bthc,bhcl->bthl", torch.softmax(qd, -1), A.double().cpu()).reshape(B * T, d)
+    ref = F.layer_norm(yd, (d,), gamma.double().cpu(), beta.double().cpu(), 1e-5)
+    sc = ss[:, 2 * d:3 * d].double().cpu().repeat_interleave(T, 0)
+    sh = ss[:, 3 * d:4 * d].double().cpu().repeat_interleave(T, 0)
+    ref = F.silu(ref * (1 + sc) + sh)
+    assert torch.isfinite(out).all()
+    assert rel(out, ref) < 2e-6 and rel(two, ref) < 2e-6
+    assert rel(out, two) < 2e-6
+
+
 def test_timestep_embedding_matches_reference_formula():
     from oracle import denoiser_ref as R
     t = torch.tensor([0, 1, 7, 500, 999])
