@@ -1562,7 +1562,7 @@ extern "C" int hig_linattn_ctx_bwd(const float* dA, const float* A, const float*
 }
 
 // Fused apply + stylization front (bf16 storage): Out = silu( LN(softmax_hd(Q) . A) * (1 + scale) + shift ), see
-// apply_sty16_kernel.  H must be 4 or 8, head dim 64 or 128; gamma / beta / ss fp32, 16-byte aligned.
+// apply_sty_kernel.  H must be 4 or 8, head dim 64 or 128; gamma / beta / ss fp32, 16-byte aligned.
 extern "C" int hig_linattn_apply_sty_bf16(const void* Q, int64_t ldq, const float* A, const float* gamma,
                                           const float* beta, const float* ss, int64_t ss_ld, int32_t ss_shift_off,
                                           void* Out, int64_t ldo, int32_t B, int32_t rows, int32_t H, int32_t hd,
