@@ -302,28 +302,28 @@ __global__ __launch_bounds__(256) void full_bwd_kv_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MC = 32;            // rows of the staged side per chunk
-constexpr int MROWS = 128;        // rows of the register side per workgroup (4 waves x 32)
 
 // a 32-row chunk of the staged side: fetched into registers one chunk ahead (fetch32), written to LDS at the top of the
 // iteration that consumes it (put32) -- the global latency hides behind the previous chunk's MFMAs
-template <int HD>
-struct Chunk32 { float4 v[MC * (HD / 4) / 256]; };
-template <int HD>
-__device__ __forceinline__ void fetch32(const float* __restrict__ src, int64_t ld, int r0, int rows, Chunk32<HD>& c) {
-  constexpr int Q4 = HD / 4;
+// NW = waves per workgroup (2 / 4 / 8: 64 / 128 / 256 rows of the register side share one staged chunk)
+template <int HD, int NW>
+struct Chunk32 { float4 v[MC * (HD / 4) / (64 * NW)]; };
+template <int HD, int NW>
+__device__ __forceinline__ void fetch32(const float* __restrict__ src, int64_t ld, int r0, int rows, Chunk32<HD, NW>& c) {
+  constexpr int Q4 = HD / 4, NT = 64 * NW;
 #pragma unroll
-  for (int it = 0; it < MC * Q4 / 256; ++it) {
-    const int idx = threadIdx.x + 256 * it, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
+  for (int it = 0; it < MC * Q4 / NT; ++it) {
+    const int idx = threadIdx.x + NT * it, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
     c.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < rows) c.v[it] = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + 4 * c4);
   }
 }
-template <int HD, int LD>
-__device__ __forceinline__ void put32(const Chunk32<HD>& c, float* __restrict__ dst) {
-  constexpr int Q4 = HD / 4;
+template <int HD, int LD, int NW>
+__device__ __forceinline__ void put32(const Chunk32<HD, NW>& c, float* __restrict__ dst) {
+  constexpr int Q4 = HD / 4, NT = 64 * NW;
 #pragma unroll
-  for (int it = 0; it < MC * Q4 / 256; ++it) {
-    const int idx = threadIdx.x + 256 * it, rr = idx / Q4, c4 = idx % Q4;
+  for (int it = 0; it < MC * Q4 / NT; ++it) {
+    const int idx = threadIdx.x + NT * it, rr = idx / Q4, c4 = idx % Q4;
     *reinterpret_cast<float4*>(dst + rr * LD + 4 * c4) = c.v[it];
   }
 }
@@ -376,9 +376,9 @@ __device__ __forceinline__ void store_cols(float* __restrict__ rowp, const f32x1
 __device__ __forceinline__ float half_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
-// forward.  grid = (B*H, ceil(Tq / 128))
-template <int HD>
-__global__ __launch_bounds__(256) void full_fwd_mfma_kernel(const float* __restrict__ Q, int64_t ldq,
+// forward.  grid = (B*H, ceil(Tq / (32 NW)))
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW) void full_fwd_mfma_kernel(const float* __restrict__ Q, int64_t ldq,
                                                             const float* __restrict__ K, const float* __restrict__ V,
                                                             int64_t ldk, int Tq, int Tk, int H,
                                                             const int64_t* __restrict__ qlen,
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void full_fwd_mfma_kernel(const float* __restr
   __shared__ __attribute__((aligned(16))) float s_mask[MC];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, g = lane >> 5;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const int q0 = blockIdx.y * MROWS + wave * 32, n = q0 + lr;
+  const int q0 = blockIdx.y * (32 * NW) + wave * 32, n = q0 + lr;
   const bool wactive = q0 < Tq, nvalid = n < Tq;
   const float isq = HD == 64 ? 0.125f : 0.08838834764831845f;   // 1 / sqrt(HD)
   float qf[HD / 8][4];
@@ -405,18 +405,18 @@ __global__ __launch_bounds__(256) void full_fwd_mfma_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[cb][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  Chunk32<HD> ck, cv;
-  fetch32<HD>(Kb, ldk, 0, Tk, ck);
-  fetch32<HD>(Vb, ldk, 0, Tk, cv);
+  Chunk32<HD, NW> ck, cv;
+  fetch32<HD, NW>(Kb, ldk, 0, Tk, ck);
+  fetch32<HD, NW>(Vb, ldk, 0, Tk, cv);
   for (int kc = 0; kc < Tk; kc += MC) {
     __syncthreads();
-    put32<HD, LDK>(ck, sK);
-    put32<HD, LDV>(cv, sV);
+    put32<HD, LDK, NW>(ck, sK);
+    put32<HD, LDV, NW>(cv, sV);
     if (tid < MC) s_mask[tid] = (kc + tid < Tk && !(pad && pad[kc + tid])) ? 0.f : -INFINITY;
     __syncthreads();
     if (kc + MC < Tk) {
-      fetch32<HD>(Kb, ldk, kc + MC, Tk, ck);
-      fetch32<HD>(Vb, ldk, kc + MC, Tk, cv);
+      fetch32<HD, NW>(Kb, ldk, kc + MC, Tk, ck);
+      fetch32<HD, NW>(Vb, ldk, kc + MC, Tk, cv);
     }
     if (!wactive) continue;
     const f32x16 st = rows_dot<HD, LDK>(sK, qf, lr, g);
@@ -456,9 +456,9 @@ __global__ __launch_bounds__(256) void full_fwd_mfma_kernel(const float* __restr
   }
 }
 
-// backward, query side (also writes delta).  grid = (B*H, ceil(Tq / 128))
-template <int HD>
-__global__ __launch_bounds__(256) void full_bwd_q_mfma_kernel(const float* __restrict__ dY, int64_t lddy,
+// backward, query side (also writes delta).  grid = (B*H, ceil(Tq / (32 NW)))
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW) void full_bwd_q_mfma_kernel(const float* __restrict__ dY, int64_t lddy,
                                                               const float* __restrict__ Y, int64_t ldy,
                                                               const float* __restrict__ Q, int64_t ldq,
                                                               const float* __restrict__ K, const float* __restrict__ V,
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void full_bwd_q_mfma_kernel(const float* __res
   __shared__ __attribute__((aligned(16))) float sV[MC * LDV];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, g = lane >> 5;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const int q0 = blockIdx.y * MROWS + wave * 32, n = q0 + lr;
+  const int q0 = blockIdx.y * (32 * NW) + wave * 32, n = q0 + lr;
   const bool wactive = q0 < Tq, nvalid = n < Tq;
   const float isq = HD == 64 ? 0.125f : 0.08838834764831845f;   // 1 / sqrt(HD)
   const int64_t rowq = (int64_t)b * Tq + (nvalid ? n : 0);
@@ -498,17 +498,17 @@ __global__ __launch_bounds__(256) void full_bwd_q_mfma_kernel(const float* __res
   for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq[cb][e] = 0.f;
-  Chunk32<HD> ck, cv;
-  fetch32<HD>(Kb, ldk, 0, Tk, ck);
-  fetch32<HD>(Vb, ldk, 0, Tk, cv);
+  Chunk32<HD, NW> ck, cv;
+  fetch32<HD, NW>(Kb, ldk, 0, Tk, ck);
+  fetch32<HD, NW>(Vb, ldk, 0, Tk, cv);
   for (int kc = 0; kc < Tk; kc += MC) {
     __syncthreads();
-    put32<HD, LDK>(ck, sK);
-    put32<HD, LDV>(cv, sV);
+    put32<HD, LDK, NW>(ck, sK);
+    put32<HD, LDV, NW>(cv, sV);
     __syncthreads();
     if (kc + MC < Tk) {
-      fetch32<HD>(Kb, ldk, kc + MC, Tk, ck);
-      fetch32<HD>(Vb, ldk, kc + MC, Tk, cv);
+      fetch32<HD, NW>(Kb, ldk, kc + MC, Tk, ck);
+      fetch32<HD, NW>(Vb, ldk, kc + MC, Tk, cv);
     }
     if (!wactive) continue;
     const f32x16 st = rows_dot<HD, LDK>(sK, qf, lr, g);
@@ -525,9 +525,9 @@ __global__ __launch_bounds__(256) void full_bwd_q_mfma_kernel(const float* __res
   if (nvalid) store_cols<HD>(dQ + ((int64_t)b * Tq + n) * lddq + h * HD, dq, 1.0f, g);
 }
 
-// backward, key side.  grid = (B*H, ceil(Tk / 128)); the wave's 32 keys stay in registers, queries are staged.
-template <int HD>
-__global__ __launch_bounds__(256) void full_bwd_kv_mfma_kernel(const float* __restrict__ dY, int64_t lddy,
+// backward, key side.  grid = (B*H, ceil(Tk / (32 NW))); the wave's 32 keys stay in registers, queries are staged.
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW) void full_bwd_kv_mfma_kernel(const float* __restrict__ dY, int64_t lddy,
                                                                const float* __restrict__ Q, int64_t ldq,
                                                                const float* __restrict__ K, const float* __restrict__ V,
                                                                int64_t ldk, int Tq, int Tk, int H,
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void full_bwd_kv_mfma_kernel(const float* __re
   __shared__ __attribute__((aligned(16))) float s_lse[MC], s_delta[MC], s_addc[MC];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, g = lane >> 5;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const int m0 = blockIdx.y * MROWS + wave * 32, m = m0 + lr;
+  const int m0 = blockIdx.y * (32 * NW) + wave * 32, m = m0 + lr;
   const bool wactive = m0 < Tk, mvalid = m < Tk;
   const float isq = HD == 64 ? 0.125f : 0.08838834764831845f;   // 1 / sqrt(HD)
   const int64_t rowk = (int64_t)b * Tk + (mvalid ? m : 0);
@@ -555,13 +555,13 @@ __global__ __launch_bounds__(256) void full_bwd_kv_mfma_kernel(const float* __re
   for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dk[cb][e] = dv[cb][e] = 0.f;
-  Chunk32<HD> cq, cd;
-  fetch32<HD>(Qb, ldq, 0, Tq, cq);
-  fetch32<HD>(Db, lddy, 0, Tq, cd);
+  Chunk32<HD, NW> cq, cd;
+  fetch32<HD, NW>(Qb, ldq, 0, Tq, cq);
+  fetch32<HD, NW>(Db, lddy, 0, Tq, cd);
   for (int qc = 0; qc < Tq; qc += MC) {
     __syncthreads();
-    put32<HD, LD>(cq, sQ);
-    put32<HD, LD>(cd, sD);
+    put32<HD, LD, NW>(cq, sQ);
+    put32<HD, LD, NW>(cd, sD);
     if (tid < MC) {
       const int n = qc + tid;
       s_lse[tid] = n < Tq ? lse[(int64_t)blockIdx.x * Tq + n] : INFINITY;   // +inf: p = 0 on rows past Tq
@@ -570,8 +570,8 @@ __global__ __launch_bounds__(256) void full_bwd_kv_mfma_kernel(const float* __re
     }
     __syncthreads();
     if (qc + MC < Tq) {
-      fetch32<HD>(Qb, ldq, qc + MC, Tq, cq);
-      fetch32<HD>(Db, lddy, qc + MC, Tq, cd);
+      fetch32<HD, NW>(Qb, ldq, qc + MC, Tq, cq);
+      fetch32<HD, NW>(Db, lddy, qc + MC, Tq, cd);
     }
     if (!wactive) continue;
     const f32x16 st = rows_dot<HD, LD>(sQ, kf, lr, g);    // S[query 8*(i/4)+4g+(i%4)][key lr]
@@ -600,6 +600,21 @@ __global__ __launch_bounds__(256) void full_bwd_kv_mfma_kernel(const float* __re
 }
 
 // HIG_FULLATTN_VALU=1 keeps head dim 64 on the VALU kernels (A/B measurements); head dim 128 is matrix-core only
+// Waves per workgroup of the matrix-core kernels (tuning knob HIG_FULLATTN_WAVES = 2 / 4 / 8).  From the sweep in
+// profiles/r02_attn_sweep.md: 8 waves (256 rows share each staged 32-row chunk; <= 256 registers per lane, two waves
+// per SIMD) win the forward at both head dims and the backward at head dim 64; the head-dim-128 backward needs more
+// than 256 registers per lane (it spills at 8) and is fastest at 4.
+int mfma_waves(bool backward, int hd) {
+  static const int forced = [] { const char* e = getenv("HIG_FULLATTN_WAVES"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 4 || v == 8) ? v : 0; }();
+  if (forced) return forced;
+  return (backward && hd == 128) ? 4 : 8;
+}
+#define FNW_SWITCH(BWD, HDIM, ...)                           \
+  switch (mfma_waves(BWD, HDIM)) {                           \
+    case 2: { constexpr int NWV = 2; __VA_ARGS__; } break;   \
+    case 8: { constexpr int NWV = 8; __VA_ARGS__; } break;   \
+    default: { constexpr int NWV = 4; __VA_ARGS__; } break;  \
+  }
 bool use_mfma(int hd) {
   static const bool valu = [] { const char* e = getenv("HIG_FULLATTN_VALU"); return e && atoi(e) != 0; }();
   return hd == 128 || (hd == 64 && !valu);
@@ -634,13 +649,15 @@ extern "C" int hig_fullattn_fwd_kpad(const float* Q, int64_t ldq, const float* K
   HIG_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldy % 4 == 0 && al16(Q) && al16(K) && al16(V) && al16(Y),
               "hig_fullattn_fwd: operands must be 16-byte aligned");
   if (use_mfma(hd)) {
-    const dim3 grid(B * H, (Tq + MROWS - 1) / MROWS);
-    if (hd == 128)
-      hipLaunchKernelGGL((full_fwd_mfma_kernel<128>), grid, dim3(256), 0, hig_stream(stream), Q, ldq, K, V, ldk, Tq, Tk, H,
-                         qlen, kpad, Y, ldy, lse);
-    else
-      hipLaunchKernelGGL((full_fwd_mfma_kernel<64>), grid, dim3(256), 0, hig_stream(stream), Q, ldq, K, V, ldk, Tq, Tk, H,
-                         qlen, kpad, Y, ldy, lse);
+    FNW_SWITCH(false, hd, {
+      const dim3 grid(B * H, (Tq + 32 * NWV - 1) / (32 * NWV));
+      if (hd == 128)
+        hipLaunchKernelGGL((full_fwd_mfma_kernel<128, NWV>), grid, dim3(64 * NWV), 0, hig_stream(stream), Q, ldq, K, V, ldk, Tq,
+                           Tk, H, qlen, kpad, Y, ldy, lse);
+      else
+        hipLaunchKernelGGL((full_fwd_mfma_kernel<64, NWV>), grid, dim3(64 * NWV), 0, hig_stream(stream), Q, ldq, K, V, ldk, Tq,
+                           Tk, H, qlen, kpad, Y, ldy, lse);
+    });
     HIG_CHECK_LAUNCH();
     return HIG_OK;
   }
@@ -663,19 +680,21 @@ extern "C" int hig_fullattn_bwd(const float* dY, int64_t lddy, const float* Y, i
                   al16(dY) && al16(Y) && al16(Q) && al16(K) && al16(V) && al16(dQ) && al16(dK) && al16(dV),
               "hig_fullattn_bwd: operands must be 16-byte aligned");
   if (use_mfma(hd)) {
-    const dim3 gq(B * H, (Tq + MROWS - 1) / MROWS), gk(B * H, (Tk + MROWS - 1) / MROWS);
     hipStream_t st = hig_stream(stream);
-    if (hd == 128) {
-      hipLaunchKernelGGL((full_bwd_q_mfma_kernel<128>), gq, dim3(256), 0, st, dY, lddy, Y, ldy, Q, ldq, K, V, ldk, Tq, Tk, H,
-                         qlen, lse, delta, dQ, lddq);
-      hipLaunchKernelGGL((full_bwd_kv_mfma_kernel<128>), gk, dim3(256), 0, st, dY, lddy, Q, ldq, K, V, ldk, Tq, Tk, H, qlen,
-                         lse, delta, dK, dV, lddk);
-    } else {
-      hipLaunchKernelGGL((full_bwd_q_mfma_kernel<64>), gq, dim3(256), 0, st, dY, lddy, Y, ldy, Q, ldq, K, V, ldk, Tq, Tk, H,
-                         qlen, lse, delta, dQ, lddq);
-      hipLaunchKernelGGL((full_bwd_kv_mfma_kernel<64>), gk, dim3(256), 0, st, dY, lddy, Q, ldq, K, V, ldk, Tq, Tk, H, qlen,
-                         lse, delta, dK, dV, lddk);
-    }
+    FNW_SWITCH(true, hd, {
+      const dim3 gq(B * H, (Tq + 32 * NWV - 1) / (32 * NWV)), gk(B * H, (Tk + 32 * NWV - 1) / (32 * NWV));
+      if (hd == 128) {
+        hipLaunchKernelGGL((full_bwd_q_mfma_kernel<128, NWV>), gq, dim3(64 * NWV), 0, st, dY, lddy, Y, ldy, Q, ldq, K, V, ldk, Tq,
+                           Tk, H, qlen, lse, delta, dQ, lddq);
+        hipLaunchKernelGGL((full_bwd_kv_mfma_kernel<128, NWV>), gk, dim3(64 * NWV), 0, st, dY, lddy, Q, ldq, K, V, ldk, Tq, Tk, H,
+                           qlen, lse, delta, dK, dV, lddk);
+      } else {
+        hipLaunchKernelGGL((full_bwd_q_mfma_kernel<64, NWV>), gq, dim3(64 * NWV), 0, st, dY, lddy, Y, ldy, Q, ldq, K, V, ldk, Tq,
+                           Tk, H, qlen, lse, delta, dQ, lddq);
+        hipLaunchKernelGGL((full_bwd_kv_mfma_kernel<64, NWV>), gk, dim3(64 * NWV), 0, st, dY, lddy, Q, ldq, K, V, ldk, Tq, Tk, H,
+                           qlen, lse, delta, dK, dV, lddk);
+      }
+    });
     HIG_CHECK_LAUNCH();
     return HIG_OK;
   }

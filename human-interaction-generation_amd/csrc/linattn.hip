@@ -1193,7 +1193,8 @@ int linattn_apply_t(const TIO* Q, int64_t ldq, const float* A, TIO* Y, int64_t l
   // (hd = 128 keeps 97 KB of LDS per workgroup = one per CU: fewer, longer-lived workgroups; measured with
   // tools/attn_time.py: 61 -> 47 us at config 5, neutral at hd = 64)
   static const int apply_target = getenv("HIG_APPLY_WGS") ? atoi(getenv("HIG_APPLY_WGS")) : 0;   // tuning knob
-  const int target = apply_target > 0 ? apply_target : (hd == 128 ? 512 : 1024);
+  // (re-swept in round 2, profiles/r02_attn_sweep.md: hd = 128 at 256 / 512 / 1024 workgroups: 42.4 / 48.7 / 58.9 us)
+  const int target = apply_target > 0 ? apply_target : (hd == 128 ? 256 : 1024);
   int gy = (target + B * H - 1) / (B * H);
   gy = gy < 1 ? 1 : (gy > nchunk_a ? nchunk_a : gy);
   if (hd == 64)

@@ -7,10 +7,11 @@ import hig_amd  # noqa: F401
 from hig_amd import _lib
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+T5 = int(sys.argv[2]) if len(sys.argv) > 2 else 196      # sequence length of the head-dim-128 rows (config 5: 300)
 L, s, P = _lib.lib(), _lib.stream_ptr(), _lib.ptr
 dev = "cuda"
 for (name, Tq, Tk, H, hd, self_) in (("self d=512", 196, 196, 8, 64, True), ("cross d=512", 196, 77, 8, 64, False),
-                                     ("self d=1024", 196, 196, 8, 128, True), ("cross d=1024", 196, 77, 8, 128, False)):
+                                     ("self d=1024", T5, T5, 8, 128, True), ("cross d=1024", T5, 77, 8, 128, False)):
     d = H * hd
     q = torch.randn(B * Tq, d, device=dev)
     kv = torch.randn(B * Tk, 2 * d, device=dev)
@@ -38,4 +39,4 @@ for (name, Tq, Tk, H, hd, self_) in (("self d=512", 196, 196, 8, 64, True), ("cr
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
         fl = mult * B * H * Tq * Tk * hd
-        print(f"{name:14s} {nm}: {us:8.1f} us   {fl / us * 1e-6:7.1f} TFLOP/s executed-products", flush=True)
+        print(f"{name:14s} T={Tq} {nm}: {us:8.1f} us   {fl / us * 1e-6:7.1f} TFLOP/s executed-products", flush=True)
