@@ -9,10 +9,13 @@
 // Flash-style: the T x T score matrix (78.7 MB per layer at B=64, T=196, H=8) is never written;
 // forward keeps one log-sum-exp per (b,h,n), backward recomputes the probabilities from it.
 //
-// fp32 hd-long dot products run at the VALU rate on gfx950 (the f32 MFMA has the same rate), so
-// this stays on the VALU: one workgroup = (sample, head, 64-row chunk); thread (row = tid>>2,
-// part = tid&3) scores its row against keys {part, part+4, ...} of each staged 64-key chunk,
-// the 4 lanes of a row combine by shuffles, probabilities cross lanes through a 64x64 LDS tile.
+// Two sets of kernels:
+//  * head dim 64 / 128 (every model of the reference, the text head at Lt = 256 / 512, the evaluator encoders): the
+//    matrix-core kernels in the second half of this file (v_mfma_f32_32x32x2_f32, exact fp32 products; 1.8-3.4x the
+//    VALU kernels' speed, profiles/r02_notes.md section 5);
+//  * head dim 8 / 16 / 32 (small test models): the VALU kernels that follow -- one workgroup = (sample, head, 64-row
+//    chunk); thread (row = tid>>2, part = tid&3) scores its row against keys {part, part+4, ...} of each staged 64-key
+//    chunk, the 4 lanes of a row combine by shuffles, probabilities cross lanes through a 64x64 LDS tile.
 #include "hig_common.h"
 
 namespace {
