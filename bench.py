@@ -434,6 +434,20 @@ def main():
                                         (world, model.flat_params().core_numel * 4 / 1e6)}
         res["train_tflops"] = round(3 * gflop * train_res["steps"] * world /
                                     (train_res["ms_per_step"] * train_res["steps"] * 1e-3) / 1e3, 2)
+        # scaling reference measured in the SAME job: the identical step with the gradient exchange switched off, i.e.
+        # what one GPU does alone (the N = 1 run of this script headlines the forward, not the training step)
+        fst = trainer.fused_state()
+        keep = (getattr(args, "overlap_allreduce", True), fst["allreduce"])
+        args.overlap_allreduce, fst["allreduce"] = False, (lambda g: world)
+        model.train()
+        el_l = timed(train_step, ksteps, 2, world)
+        args.overlap_allreduce, fst["allreduce"] = keep
+        trainer.sync_replicas()
+        model.eval()
+        res["single_gpu_reference"] = {
+            "ms_per_step": round(el_l / ksteps * 1e3, 4), "frames_per_s_per_gpu": round(B * T * ksteps / el_l, 1),
+            "what": "the same training step with the gradient exchange skipped (max over ranks): value / (n_gpus x this) "
+                    "is the weak-scaling efficiency of the data-parallel step"}
 
     extra = {}
     if world > 1:
