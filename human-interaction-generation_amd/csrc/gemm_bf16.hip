@@ -413,6 +413,13 @@ int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
   // rate (guide: 66-73 GB/s per CU for L2-resident rows, DMA and register staging alike).  4 x BK 32 stages: 18.5K;
   // 3 x BK 64 stages (one workgroup per CU): 10.9K for its single tile but no second workgroup to cover the epilogue,
   // 44.9 against 36.5 us; start-time offsets between the co-resident workgroups: no effect.)
+  // 64-row tiles are what the small-M launches get (M = 6272: one partly filled round of 2-3 workgroups per CU): there a
+  // k-tile is bound by the LATENCY of its DMA, not by the CU's fetch rate, and a third ring stage (72 KB of LDS, still
+  // two workgroups per CU) hides it: stylization-out 14.9 -> 12.8 us, FFN linear2 21.4 -> 18.2 us, config-3 forward
+  // 1.515 -> 1.409 ms (B = 64: 2.30 -> 2.28 ms).  Not for K = 256 (4 k-tiles: 8.8 -> 15.4 us) and not for the 128-row
+  // tile (96 KB = one workgroup per CU: FFN linear1 20.6 -> 24.2 us).  HIG_BF16_RING3=0 switches it off.
+  static const int ring3 = getenv("HIG_BF16_RING3") ? atoi(getenv("HIG_BF16_RING3")) : 1;   // tuning knob
+  if (ring3 && pick == 64 && g.R % 64 == 0 && g.R >= 512) return launch16<1, 4, 2, 1, 64, 3, EPI>(g, st);
   if (g.R % 64 == 0) {
     if (pick == 256) return launch16<2, 4, 4, 2, 64, 2, EPI>(g, st);
     if (pick == 192) return launch16<2, 2, 2, 3, 64, 2, EPI>(g, st);
