@@ -420,6 +420,12 @@ int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
   // tile (96 KB = one workgroup per CU: FFN linear1 20.6 -> 24.2 us).  HIG_BF16_RING3=0 switches it off.
   static const int ring3 = getenv("HIG_BF16_RING3") ? atoi(getenv("HIG_BF16_RING3")) : 1;   // tuning knob
   if (ring3 && pick == 64 && g.R % 64 == 0 && g.R >= 512) return launch16<1, 4, 2, 1, 64, 3, EPI>(g, st);
+  // 128 x 128 tiles over several rounds (M >= 8192: every launch of the B = 64 forward): four stages of BK = 32 (the
+  // same 64 KB) keep one more k-tile in flight than two of BK = 64: B = 64 forward 2.308 -> 2.261 ms (q/k/v 44.2 ->
+  // 41.8 us); at M = 6272, where these launches are single partly filled rounds, it is neutral to slightly slower
+  // (1.425 -> 1.435 ms), so the rule is on the row count.  HIG_BF16_RING4_ROWS moves the threshold (0 = never).
+  static const int ring4_rows = getenv("HIG_BF16_RING4_ROWS") ? atoi(getenv("HIG_BF16_RING4_ROWS")) : 8192;   // tuning knob
+  if (ring4_rows > 0 && pick == 128 && g.I >= ring4_rows && g.R >= 512) return launch16<2, 2, 2, 2, 32, 4, EPI>(g, st);
   if (g.R % 64 == 0) {
     if (pick == 256) return launch16<2, 4, 4, 2, 64, 2, EPI>(g, st);
     if (pick == 192) return launch16<2, 2, 2, 3, 64, 2, EPI>(g, st);
