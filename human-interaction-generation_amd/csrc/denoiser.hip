@@ -506,7 +506,8 @@ Fwd16Layout fwd16_layout(const Dims& D) {
   w.teh16 = take((int64_t)D.B * D.E * 2);
   w.semb16 = take((int64_t)D.B * D.E * 2);
   w.ss = take((int64_t)D.B * D.nsty * D.L * 2 * D.d * 4);
-  w.h32 = take(D.M * D.d * 4);          // joint_embed output (fp32 GEMM over the F-wide, unaligned pose rows)
+  w.h32 = take(D.M * D.d * 4 > (int64_t)D.d * 544 * 2 ? D.M * D.d * 4 : (int64_t)D.d * 544 * 2);   // joint_embed: padded bf16
+                                        // weight of hig_joint_embed_bf16 (d x Fp), or the fp32 output of the fallback GEMM
   w.h = take(D.M * D.d * 2);
   w.xn = take(D.M * D.d * 2);
   w.qkv = take(D.M * 3 * D.d * 2);
@@ -615,7 +616,12 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
                                 .epi(HIG_EPI_BIAS, P(params, HIG_P_STY_EMB_B)).out32().g, st));
   // K1: h0 = joint_embed(x) + sequence_embedding[:T]: fp32 operands (x is the fp32 DDPM state, F = 150 rows are not
   //     16-byte aligned), result rounded once into the bf16 residual stream
-  {
+  static const int joint16 = getenv("HIG_JOINT16") ? atoi(getenv("HIG_JOINT16")) : 1;   // tuning knob
+  if (joint16 && d % 128 == 0 && D.F <= 512) {
+    // own kernel pair (weight padded / rounded to bf16, x rounded in LDS, bf16 MFMA): 31 -> ~8 us at B = 32
+    HIG_TRY(hig_joint_embed_bf16(x, M, D.F, P(params, HIG_P_JOINT_W), P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d,
+                                 D.T, 0, ws + w.h, d, d, ws + w.h32, stream));
+  } else {
     float* h32 = reinterpret_cast<float*>(ws + w.h32);
     G ge(x, D.F, 0, P(params, HIG_P_JOINT_W), D.F, 0, h32, d, M, d, D.F);
     ge.epi(HIG_EPI_BIAS_POS, P(params, HIG_P_JOINT_B)).pos(P(params, HIG_P_SEQ_EMB), d, D.T);

@@ -446,6 +446,97 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restri
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[n8 * 8 + threadIdx.x] = (__bf16)src[n8 * 8 + threadIdx.x];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// joint_embed of the bf16-storage forward:  h0[m][n] = sum_f x[m][f] Wj[n][f] + bj[n] + pos[(m % T) - shift][n]
+// (transformer.py:418-419).  x is the fp32 DDPM state with F = 150 / 263 / ... features per row (rows are not 16-byte
+// aligned, F is not a multiple of the MFMA k), the output is the bf16 residual stream.  The general kernel above cannot
+// take such operands and the exact-fp32 GEMM it went through before (+ a cast) cost 31 us of a 1.5 ms step for 1 GFLOP.
+// Here: (1) the weight is padded to Fp = 32-multiple columns and rounded to bf16 once per call (pad_cast_rows_kernel,
+// 150 KB); (2) a workgroup takes 64 rows of x, converts them to bf16 in LDS (zero beyond F), and walks the d columns
+// of ONE block of 128 (grid.y): weight block -> LDS, v_mfma_f32_32x32x16_bf16 with the weight as the row operand (a lane then
+// holds 4 consecutive output columns), bias + positional row added in fp32, 8-byte bf16 stores.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void pad_cast_rows_kernel(const float* __restrict__ W, int rows, int F, int Fp, __bf16* __restrict__ out) {
+  const int64_t n = (int64_t)rows * Fp;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / Fp), c = (int)(i % Fp);
+    out[i] = c < F ? (__bf16)W[(int64_t)r * F + c] : (__bf16)0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void joint_embed16_kernel(const float* __restrict__ x, int F, int Fp,
+                                                            const __bf16* __restrict__ Wp, const float* __restrict__ bias,
+                                                            const float* __restrict__ pos, int64_t ldpos, int T,
+                                                            int pos_shift, __bf16* __restrict__ out, int64_t ldo,
+                                                            int64_t M, int d) {
+  extern __shared__ __attribute__((aligned(16))) char smem_je[];
+  const int LDX = Fp + 8;                                  // bf16 elements per LDS row (16-byte aligned, skewed banks)
+  __bf16* sX = reinterpret_cast<__bf16*>(smem_je);         // [64][LDX]
+  __bf16* sW = sX + 64 * LDX;                              // [128][LDX]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  // x tile: a wave takes 16 rows, its lanes walk a row in element pairs (coalesced along the row; 8-byte loads when the
+  // rows are 8-byte aligned, i.e. F even), rounded to bf16, zero beyond F and beyond M
+  const bool pairs = (F & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
+  for (int rr = wave; rr < 64; rr += 4) {
+    const bool rv = m0 + rr < M;
+    const float* xr = x + (m0 + rr) * F;
+    for (int c = 2 * lane; c < Fp; c += 128) {
+      float v0 = 0.f, v1 = 0.f;
+      if (rv && c + 1 < F && pairs) {
+        const float2 t = *reinterpret_cast<const float2*>(xr + c);
+        v0 = t.x; v1 = t.y;
+      } else if (rv) {
+        if (c < F) v0 = xr[c];
+        if (c + 1 < F) v1 = xr[c + 1];
+      }
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<bf16x2*>(sX + rr * LDX + c) = bf16x2{(__bf16)v0, (__bf16)v1};
+    }
+  }
+  const int c16 = Fp / 8;                                  // 16-byte chunks per padded weight row
+  // one 128-column block per workgroup (blockIdx.y): the x tile is fetched d / 128 times (from L2), in exchange every
+  // block of every row tile runs at once instead of as a serial chain of load -> MFMA -> store steps per workgroup
+  {
+    const int cb = blockIdx.y * 128;
+    for (int idx = tid; idx < 128 * c16; idx += 256) {
+      const int rr = idx / c16, ch = idx % c16;
+      *reinterpret_cast<uint4*>(sW + rr * LDX + 8 * ch) = *reinterpret_cast<const uint4*>(Wp + (int64_t)(cb + rr) * Fp + 8 * ch);
+    }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
+    const __bf16* wrow = sW + (32 * wave + lr) * LDX + 8 * lh;
+    for (int ks = 0; ks < Fp / 16; ++ks) {
+      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + 16 * ks);
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sX + (32 * rb + lr) * LDX + 16 * ks + 8 * lh);
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[rb], 0, 0, 0);
+      }
+    }
+    // acc[rb][4q + e]: output column cb + 32 wave + 8q + 4lh + e of row m0 + 32 rb + lr
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int64_t m = m0 + 32 * rb + lr;
+      if (m >= M) continue;
+      const int tp = (int)(m % T) - pos_shift;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = cb + 32 * wave + 8 * q + 4 * lh;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + col);
+        f32x4 v = f32x4{acc[rb][4 * q], acc[rb][4 * q + 1], acc[rb][4 * q + 2], acc[rb][4 * q + 3]} + b4;
+        if (tp >= 0) v += *reinterpret_cast<const f32x4*>(pos + (int64_t)tp * ldpos + col);
+        *reinterpret_cast<bf16x4*>(out + m * ldo + col) = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int hig_gemm16_launch(const hig_gemm16_desc& g, hipStream_t st) {
@@ -473,6 +564,41 @@ int hig_gemm16_launch(const hig_gemm16_desc& g, hipStream_t st) {
 extern "C" int hig_gemm_bf16(const hig_gemm16_desc* g, hig_stream_t stream) {
   HIG_REQUIRE(g, "hig_gemm_bf16: null descriptor");
   return hig_gemm16_launch(*g, hig_stream(stream));
+}
+
+// joint_embed + sequence_embedding of the bf16-storage forward (see joint_embed16_kernel).  w_scratch: d x Fp bf16
+// (Fp = F rounded up to a multiple of 32), rewritten by every call.  d % 128 == 0, F <= 512, 16-byte aligned bias / pos / out.
+extern "C" int64_t hig_joint_embed_bf16_scratch_bytes(int32_t F, int32_t d) {
+  if (F <= 0 || d <= 0) return -1;
+  return (int64_t)d * ((F + 31) / 32 * 32) * 2;
+}
+extern "C" int hig_joint_embed_bf16(const float* x, int64_t M, int32_t F, const float* W, const float* bias, const float* pos,
+                                    int64_t ldpos, int32_t T, int32_t pos_shift, void* out, int64_t ldo, int32_t d,
+                                    void* w_scratch, hig_stream_t stream) {
+  HIG_REQUIRE(x && W && bias && pos && out && w_scratch && M >= 0 && F > 0 && d > 0 && T > 0, "hig_joint_embed_bf16: bad arguments");
+  if (M == 0) return HIG_OK;
+  if (d % 128 != 0 || F > 512)
+    return hig_set_error(HIG_EUNSUPPORTED, "hig_joint_embed_bf16: needs d %% 128 == 0 and F <= 512 (got %d, %d)", d, F);
+  HIG_REQUIRE(ldo % 4 == 0 && ldpos % 4 == 0 &&
+                  ((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(w_scratch)) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(out) & 7) == 0,
+              "hig_joint_embed_bf16: alignment");
+  const int Fp = (F + 31) / 32 * 32;
+  hipStream_t st = hig_stream(stream);
+  __bf16* wp = static_cast<__bf16*>(w_scratch);
+  const int64_t nw = (int64_t)d * Fp;
+  hipLaunchKernelGGL(pad_cast_rows_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, d, F, Fp, wp);
+  HIG_CHECK_LAUNCH();
+  const size_t lds = (size_t)(64 + 128) * (Fp + 8) * 2;
+  static const int big_lds_rc = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_embed16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               156 * 1024) == hipSuccess ? 0 : 1;
+  }();
+  if (big_lds_rc != 0 || lds > 156 * 1024) return hig_set_error(HIG_EHIP, "hig_joint_embed_bf16: cannot reserve %zu bytes of LDS", lds);
+  hipLaunchKernelGGL(joint_embed16_kernel, dim3((unsigned)((M + 63) / 64), d / 128), dim3(256), lds, st, x, F, Fp, wp, bias, pos, ldpos, T,
+                     pos_shift, static_cast<__bf16*>(out), ldo, M, d);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
 }
 
 extern "C" int hig_cast_bf16(const float* src, void* dst, int64_t n, hig_stream_t stream) {

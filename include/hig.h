@@ -389,6 +389,14 @@ typedef struct hig_gemm16_desc {
 } hig_gemm16_desc;
 int hig_gemm_bf16(const hig_gemm16_desc* g, hig_stream_t stream);
 /* dst[i] = bf16(src[i]) (round to nearest even): builds the bf16 shadow of the flat fp32 parameter buffer. */
+/* joint_embed + sequence_embedding of the bf16-storage forward (transformer.py:418-419) as its own kernel pair:
+ * out[m][:] = bf16( x[m][:F] . W^T + bias + pos[(m % T) - pos_shift] ), x fp32 with F (e.g. 150, 263) features per
+ * row, W fp32 (d, F) padded / rounded to bf16 into `w_scratch` (hig_joint_embed_bf16_scratch_bytes) by the call,
+ * rows with a negative positional index get no positional term.  d % 128 == 0, F <= 512. */
+int64_t hig_joint_embed_bf16_scratch_bytes(int32_t F, int32_t d);
+int hig_joint_embed_bf16(const float* x, int64_t M, int32_t F, const float* W, const float* bias, const float* pos,
+                         int64_t ldpos, int32_t T, int32_t pos_shift, void* out, int64_t ldo, int32_t d,
+                         void* w_scratch, hig_stream_t stream);
 int hig_cast_bf16(const float* src, void* dst, int64_t n, hig_stream_t stream);
 
 /* bf16-storage row kernel: out (bf16) = LN(x) * gamma + beta, and with ss != NULL the stylization front

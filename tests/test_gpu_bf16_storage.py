@@ -154,6 +154,33 @@ def test_fused_apply_stylization_front_matches_the_two_kernel_sequence(hd, H, B,
     assert (out.float().cpu() != bf(ref.float()).float()).float().mean().item() < 0.03   # correctly rounded almost everywhere
 
 
+@pytest.mark.parametrize("M,T,F,d,shift", [(6272, 196, 150, 512, 0), (333, 37, 263, 256, 0), (70, 7, 12, 128, 1),
+                                           (9600, 300, 150, 1024, 0)])
+def test_joint_embed_bf16_kernel(M, T, F, d, shift):
+    """hig_joint_embed_bf16 (joint_embed + sequence_embedding of the bf16-storage forward, transformer.py:418-419):
+    x and the weight are rounded to bf16, products accumulate in fp32, bias and the positional row are added in fp32,
+    the result is rounded to bf16 once -- compared with exactly that arithmetic in fp64 (correctly rounded almost
+    everywhere) and with the fp32 reference at the bf16 level."""
+    g = torch.Generator().manual_seed(M + F)
+    x = torch.randn(M, F, generator=g) * 2
+    W, b = torch.randn(d, F, generator=g) * 0.1, torch.randn(d, generator=g) * 0.1
+    pos = torch.randn(T + 3, d, generator=g) * 0.5
+    L = _lib.lib()
+    out = torch.full((M, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    scratch = torch.empty(L.hig_joint_embed_bf16_scratch_bytes(F, d), dtype=torch.uint8, device=DEV)
+    xg, Wg, bg, pg = x.to(DEV), W.to(DEV), b.to(DEV), pos.to(DEV)
+    _lib.check(L.hig_joint_embed_bf16(_lib.ptr(xg), M, F, _lib.ptr(Wg), _lib.ptr(bg), _lib.ptr(pg), d, T, shift,
+                                      _lib.ptr(out), d, d, _lib.ptr(scratch), _lib.stream_ptr()))
+    tp = torch.arange(M) % T - shift
+    padd = torch.where((tp >= 0)[:, None], pos[tp.clamp_min(0)].double(), torch.zeros(1, d, dtype=torch.float64))
+    ref16 = bf(x).double() @ bf(W).double().T + b.double() + padd          # the kernel's arithmetic
+    ref32 = x.double() @ W.double().T + b.double() + padd                  # the reference's
+    o = out.float().cpu()
+    assert torch.isfinite(o).all()
+    assert (o != bf(ref16.float()).float()).float().mean().item() < 0.02
+    assert rel(o, ref32) < 6e-3
+
+
 def build(c, **kw):
     m = hig_amd.MotionTransformer(input_feats=c["F"], num_frames=c["num_frames"], latent_dim=c["d"], ff_size=c["ff"],
                                   num_layers=c["L"], num_heads=c["H"], text_latent_dim=c["Lt"], **kw)
