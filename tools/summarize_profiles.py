@@ -23,6 +23,14 @@ shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.jso
 shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
 ks = one("trace/**/*kernel_stats.csv")
 shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
+# round 2: kernel stats of the bf16-storage sampling step and of the fp32 training step, counter summaries of the bf16 FFN
+# GEMM and of the HBM-bound kernels (written by tools/collect_profiles.sh next to the headline's trace)
+for pattern, name in (("trace_bf16/**/*kernel_stats.csv", "_kernel_stats_bf16_sampling_step.csv"),
+                      ("trace_train/**/*kernel_stats.csv", "_kernel_stats_train_step.csv"),
+                      ("pmc_hbm/summary.json", "_hbm_kernels_pmc.json"), ("pmc16_ffn1/summary.json", "_pmc16_ffn1.json")):
+    f = one(pattern)
+    if f:
+        shutil.copy(f, os.path.join(dst, tag + name))
 lines = ["# %s: rocprofv3 summaries (MI355X, one GPU)" % tag, "",
          "Command profiled: `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra`", "",
          "## Kernel time (rocprofv3 --kernel-trace --stats), top 12", "",
