@@ -674,6 +674,9 @@ def main():
                 mv.cache_text_context = False
                 e_v = timed(fwd_v, k2, 2, 1) / k2 * 1e3
                 var[tag] = {"fwd_ms": round(e_v, 3), "frames_per_s": round(cv["B"] * cv["T"] / e_v * 1e3, 1)}
+                set_mode(mv, "bf16s")            # bf16 storage: bf16 Q / K / V / Y through the same matrix-core kernels
+                var[tag]["fwd_ms_bf16_storage"] = round(timed(fwd_v, k2, 2, 1) / k2 * 1e3, 3)
+                set_mode(mv, "f32")
                 if tag == "no_eff":
                     mv.train()
                     xg = iv["x"].clone().requires_grad_(True)

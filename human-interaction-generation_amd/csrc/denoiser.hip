@@ -93,8 +93,8 @@ int check_dims(const hig_dims* p, Dims& D) {
   HIG_REQUIRE(p->storage == HIG_STORE_F32 || p->storage == HIG_STORE_BF16, "hig_dims: unknown storage=%d", p->storage);
   D.bf16 = p->storage == HIG_STORE_BF16;
   if (D.bf16) {
-    if (D.full || D.two)
-      return hig_set_error(HIG_EUNSUPPORTED, "hig: bf16 storage is built for the single-person linear-attention model");
+    if (D.two)
+      return hig_set_error(HIG_EUNSUPPORTED, "hig: bf16 storage is built for the single-person model");
     if (D.hd != 64 && D.hd != 128)
       return hig_set_error(HIG_EUNSUPPORTED, "hig: bf16 storage needs head dim 64 or 128 (got %d)", D.hd);
     if (D.d % 32 || D.ff % 32 || D.Lt % 32)
@@ -523,14 +523,16 @@ Fwd16Layout fwd16_layout(const Dims& D) {
 }
 
 struct Text16Layout {
-  int64_t xfn, kv, cscr, layer0, lstride, Ac, kstc, total;
+  int64_t xfn, kv, kv_stride, cscr, layer0, lstride, Ac, kstc, total;
 };
 Text16Layout text16_layout(const Dims& D) {
   Text16Layout t;
   int64_t o = 0;
   auto take = [&](int64_t n) { int64_t r = o; o += alb(n); return r; };
   t.xfn = take(D.Mt * D.Lt * 2);
-  t.kv = take(D.Mt * 2 * D.d * 2);
+  // linear attention consumes key / value right away (into A_c); full attention reads them at every step: kept per layer
+  t.kv_stride = D.full ? alb(D.Mt * 2 * D.d * 2) : 0;
+  t.kv = take(D.full ? t.kv_stride * D.L : D.Mt * 2 * D.d * 2);
   t.cscr = take(hig_linattn_ctx_scratch_floats(D.B, D.N, D.H, D.hd) * 4);
   t.layer0 = o;
   o = 0;
@@ -572,8 +574,8 @@ extern "C" int hig_text_context_bf16(const hig_dims* dims, const void* const* pa
   char* base = static_cast<char*>(textctx);
   hipStream_t st = hig_stream(stream);
   void* xfn = base + tl.xfn;
-  char* kv = base + tl.kv;
   for (int l = 0; l < D.L; ++l) {
+    char* kv = base + tl.kv + tl.kv_stride * l;
     float* Ac = reinterpret_cast<float*>(base + tl.layer0 + tl.lstride * l + tl.Ac);
     float* kstc = reinterpret_cast<float*>(base + tl.layer0 + tl.lstride * l + tl.kstc);
     // text_norm (per layer), [key; value] projection, softmax over the N tokens, A_c = k^T v   (transformer.py:146-152)
@@ -581,8 +583,9 @@ extern "C" int hig_text_context_bf16(const hig_dims* dims, const void* const* pa
                         nullptr, 0, 0, 0, xfn, D.Lt, stream));
     HIG_TRY(hig_gemm16_launch(G16(xfn, D.Lt, PL16(params16, l, HIG_L_CA_KV_W), D.Lt, kv, 2 * D.d, D.Mt, 2 * D.d, D.Lt)
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_KV_B)).g, st));
-    HIG_TRY(hig_linattn_ctx_bf16(kv, kv + (int64_t)D.d * 2, 2 * D.d, D.B, D.N, D.H, D.hd, nullptr, Ac, kstc,
-                                 reinterpret_cast<float*>(base + tl.cscr), stream));
+    if (!D.full)
+      HIG_TRY(hig_linattn_ctx_bf16(kv, kv + (int64_t)D.d * 2, 2 * D.d, D.B, D.N, D.H, D.hd, nullptr, Ac, kstc,
+                                   reinterpret_cast<float*>(base + tl.cscr), stream));
   }
   return HIG_OK;
 }
@@ -670,15 +673,27 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
     HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B), nullptr, 0, 0, 0, xn, d, stream));
     HIG_TRY(hig_gemm16_launch(G16(xn, d, PL16(params16, l, HIG_L_SA_QKV_W), d, qkv, 3 * d, M, 3 * d, d)
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_SA_QKV_B)).g, st));
-    HIG_TRY(hig_linattn_ctx_bf16(qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, D.H, D.hd, length, A1, kst1,
-                                 cscr, stream));
-    HIG_TRY(attend(l, 0, qkv, 3 * d, A1, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B));
+    if (D.full) {   // no_eff=True: softmax over the T keys, query-axis mask constant (transformer.py:208-227)
+      HIG_TRY(hig_fullattn_fwd_bf16(qkv, 3 * d, qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, D.T, D.H, D.hd,
+                                    length, y, d, stream));
+      HIG_TRY(stylize(l, 0, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B));
+    } else {
+      HIG_TRY(hig_linattn_ctx_bf16(qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, D.H, D.hd, length, A1, kst1,
+                                   cscr, stream));
+      HIG_TRY(attend(l, 0, qkv, 3 * d, A1, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B));
+    }
     // ---- cross attention to the text context (transformer.py:135-155) ----
     HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B), nullptr, 0, 0, 0, xn, d, stream));
     HIG_TRY(hig_gemm16_launch(G16(xn, d, PL16(params16, l, HIG_L_CA_Q_W), d, qc, d, M, d, d)
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).g, st));
-    HIG_TRY(attend(l, 1, qc, d, reinterpret_cast<const float*>(tc + tl.layer0 + tl.lstride * l + tl.Ac),
-                   HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B));
+    if (D.full) {   // softmax over the N text tokens, no mask (transformer.py:242-262)
+      const char* kvl = tc + tl.kv + tl.kv_stride * l;
+      HIG_TRY(hig_fullattn_fwd_bf16(qc, d, kvl, kvl + (int64_t)d * 2, 2 * d, D.B, D.T, D.N, D.H, D.hd, nullptr, y, d, stream));
+      HIG_TRY(stylize(l, 1, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B));
+    } else {
+      HIG_TRY(attend(l, 1, qc, d, reinterpret_cast<const float*>(tc + tl.layer0 + tl.lstride * l + tl.Ac),
+                     HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B));
+    }
     // ---- FFN (transformer.py:167-170) ----
     HIG_TRY(hig_gemm16_launch(G16(h, d, PL16(params16, l, HIG_L_FFN_W1), d, f1, D.ff, M, D.ff, d)
                                   .epi(HIG_EPI_BIAS_GELU, PL(params, l, HIG_L_FFN_B1)).g, st));

@@ -308,17 +308,28 @@ constexpr int MC = 32;            // rows of the staged side per chunk
 
 // a 32-row chunk of the staged side: fetched into registers one chunk ahead (fetch32), written to LDS at the top of the
 // iteration that consumes it (put32) -- the global latency hides behind the previous chunk's MFMAs
+// 4 consecutive elements of an fp32 or bf16 row as floats (bf16 storage: hig_fullattn_fwd_bf16)
+typedef __bf16 bf16x4_fa __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4f(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4f(const __bf16* p) {
+  const bf16x4_fa v = *reinterpret_cast<const bf16x4_fa*>(p);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void st4f(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4f(__bf16* p, float4 v) {
+  *reinterpret_cast<bf16x4_fa*>(p) = bf16x4_fa{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+}
 // NW = waves per workgroup (2 / 4 / 8: 64 / 128 / 256 rows of the register side share one staged chunk)
 template <int HD, int NW>
 struct Chunk32 { float4 v[MC * (HD / 4) / (64 * NW)]; };
-template <int HD, int NW>
-__device__ __forceinline__ void fetch32(const float* __restrict__ src, int64_t ld, int r0, int rows, Chunk32<HD, NW>& c) {
+template <int HD, int NW, typename T>
+__device__ __forceinline__ void fetch32(const T* __restrict__ src, int64_t ld, int r0, int rows, Chunk32<HD, NW>& c) {
   constexpr int Q4 = HD / 4, NT = 64 * NW;
 #pragma unroll
   for (int it = 0; it < MC * Q4 / NT; ++it) {
     const int idx = threadIdx.x + NT * it, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
     c.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < rows) c.v[it] = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + 4 * c4);
+    if (r < rows) c.v[it] = ld4f(src + (int64_t)r * ld + 4 * c4);
   }
 }
 template <int HD, int LD, int NW>
@@ -331,12 +342,12 @@ __device__ __forceinline__ void put32(const Chunk32<HD, NW>& c, float* __restric
   }
 }
 // the lane's half of its own row in the permuted reduce order: r[j][e] = row[8j + 4g + e]
-template <int HD>
-__device__ __forceinline__ void load_half_row(const float* __restrict__ p, float (&r)[HD / 8][4], bool valid, int g) {
+template <int HD, typename T>
+__device__ __forceinline__ void load_half_row(const T* __restrict__ p, float (&r)[HD / 8][4], bool valid, int g) {
 #pragma unroll
   for (int j = 0; j < HD / 8; ++j) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) v = *reinterpret_cast<const float4*>(p + 8 * j + 4 * g);
+    if (valid) v = ld4f(p + 8 * j + 4 * g);
     r[j][0] = v.x; r[j][1] = v.y; r[j][2] = v.z; r[j][3] = v.w;
   }
 }
@@ -367,26 +378,26 @@ __device__ __forceinline__ void cols_acc(const float* __restrict__ rows, const f
     for (int cb = 0; cb < HD / 32; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(rp[32 * cb], w[i], acc[cb], 0, 0, 0);
   }
 }
-template <int HD>
-__device__ __forceinline__ void store_cols(float* __restrict__ rowp, const f32x16 (&acc)[HD / 32], float scale, int g) {
+template <int HD, typename T>
+__device__ __forceinline__ void store_cols(T* __restrict__ rowp, const f32x16 (&acc)[HD / 32], float scale, int g) {
 #pragma unroll
   for (int cb = 0; cb < HD / 32; ++cb)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<float4*>(rowp + 32 * cb + 8 * q + 4 * g) =
-          make_float4(acc[cb][4 * q] * scale, acc[cb][4 * q + 1] * scale, acc[cb][4 * q + 2] * scale, acc[cb][4 * q + 3] * scale);
+      st4f(rowp + 32 * cb + 8 * q + 4 * g,
+           make_float4(acc[cb][4 * q] * scale, acc[cb][4 * q + 1] * scale, acc[cb][4 * q + 2] * scale, acc[cb][4 * q + 3] * scale));
 }
 __device__ __forceinline__ float half_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
 // forward.  grid = (B*H, ceil(Tq / (32 NW)))
-template <int HD, int NW>
-__global__ __launch_bounds__(64 * NW) void full_fwd_mfma_kernel(const float* __restrict__ Q, int64_t ldq,
-                                                            const float* __restrict__ K, const float* __restrict__ V,
-                                                            int64_t ldk, int Tq, int Tk, int H,
-                                                            const int64_t* __restrict__ qlen,
-                                                            const uint8_t* __restrict__ kpad, float* __restrict__ Y,
-                                                            int64_t ldy, float* __restrict__ lse) {
+template <int HD, int NW, typename TIO>
+__global__ __launch_bounds__(64 * NW) void full_fwd_mfma_kernel(const TIO* __restrict__ Q, int64_t ldq,
+                                                               const TIO* __restrict__ K, const TIO* __restrict__ V,
+                                                               int64_t ldk, int Tq, int Tk, int H,
+                                                               const int64_t* __restrict__ qlen,
+                                                               const uint8_t* __restrict__ kpad, TIO* __restrict__ Y,
+                                                               int64_t ldy, float* __restrict__ lse) {
   constexpr int LDK = HD + 4, LDV = HD + 8, NCB = HD / 32;
   __shared__ __attribute__((aligned(16))) float sK[MC * LDK];
   __shared__ __attribute__((aligned(16))) float sV[MC * LDV];
@@ -399,8 +410,8 @@ __global__ __launch_bounds__(64 * NW) void full_fwd_mfma_kernel(const float* __r
   float qf[HD / 8][4];
   load_half_row<HD>(Q + ((int64_t)b * Tq + (nvalid ? n : 0)) * ldq + h * HD, qf, nvalid, g);
   const float addc = nvalid ? query_const(qlen, b, n) : 0.f;
-  const float* Kb = K + (int64_t)b * Tk * ldk + h * HD;
-  const float* Vb = V + (int64_t)b * Tk * ldk + h * HD;
+  const TIO* Kb = K + (int64_t)b * Tk * ldk + h * HD;
+  const TIO* Vb = V + (int64_t)b * Tk * ldk + h * HD;
   const uint8_t* pad = kpad ? kpad + (int64_t)b * Tk : nullptr;
   f32x16 o[NCB];
 #pragma unroll
@@ -455,7 +466,7 @@ __global__ __launch_bounds__(64 * NW) void full_fwd_mfma_kernel(const float* __r
   }
   if (nvalid) {
     store_cols<HD>(Y + ((int64_t)b * Tq + n) * ldy + h * HD, o, 1.0f / l_run, g);
-    if (g == 0) lse[(int64_t)blockIdx.x * Tq + n] = m_run + __logf(l_run);
+    if (g == 0 && lse) lse[(int64_t)blockIdx.x * Tq + n] = m_run + __logf(l_run);
   }
 }
 
@@ -655,10 +666,10 @@ extern "C" int hig_fullattn_fwd_kpad(const float* Q, int64_t ldq, const float* K
     FNW_SWITCH(false, hd, {
       const dim3 grid(B * H, (Tq + 32 * NWV - 1) / (32 * NWV));
       if (hd == 128)
-        hipLaunchKernelGGL((full_fwd_mfma_kernel<128, NWV>), grid, dim3(64 * NWV), 0, hig_stream(stream), Q, ldq, K, V, ldk, Tq,
+        hipLaunchKernelGGL((full_fwd_mfma_kernel<128, NWV, float>), grid, dim3(64 * NWV), 0, hig_stream(stream), Q, ldq, K, V, ldk, Tq,
                            Tk, H, qlen, kpad, Y, ldy, lse);
       else
-        hipLaunchKernelGGL((full_fwd_mfma_kernel<64, NWV>), grid, dim3(64 * NWV), 0, hig_stream(stream), Q, ldq, K, V, ldk, Tq,
+        hipLaunchKernelGGL((full_fwd_mfma_kernel<64, NWV, float>), grid, dim3(64 * NWV), 0, hig_stream(stream), Q, ldq, K, V, ldk, Tq,
                            Tk, H, qlen, kpad, Y, ldy, lse);
     });
     HIG_CHECK_LAUNCH();
@@ -666,6 +677,31 @@ extern "C" int hig_fullattn_fwd_kpad(const float* Q, int64_t ldq, const float* K
   }
   FHD_SWITCH(hd, hipLaunchKernelGGL((full_fwd_kernel<HDV>), dim3(B * H, (Tq + CH - 1) / CH), dim3(256), 0,
                                     hig_stream(stream), Q, ldq, K, V, ldk, Tq, Tk, H, qlen, kpad, Y, ldy, lse));
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+// bf16-storage form of the forward (hig_dims.storage == HIG_STORE_BF16, inference): Q / K / V / Y bf16, no log-sum-exp.
+// Head dim 64 or 128 (the matrix-core kernel; logits, softmax and accumulation in fp32).
+extern "C" int hig_fullattn_fwd_bf16(const void* Q, int64_t ldq, const void* K, const void* V, int64_t ldk, int32_t B,
+                                     int32_t Tq, int32_t Tk, int32_t H, int32_t hd, const int64_t* qlen, void* Y, int64_t ldy,
+                                     hig_stream_t stream) {
+  HIG_REQUIRE(Q && K && V && Y && B > 0 && Tq > 0 && Tk > 0 && H > 0, "hig_fullattn_fwd_bf16: bad arguments");
+  if (hd != 64 && hd != 128) return hig_set_error(HIG_EUNSUPPORTED, "hig_fullattn_fwd_bf16: head dim %d not in {64,128}", hd);
+  auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+  HIG_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldy % 4 == 0 && al8(Q) && al8(K) && al8(V) && al8(Y),
+              "hig_fullattn_fwd_bf16: operands must be 8-byte aligned");
+  const __bf16 *q = static_cast<const __bf16*>(Q), *k = static_cast<const __bf16*>(K), *v = static_cast<const __bf16*>(V);
+  __bf16* y = static_cast<__bf16*>(Y);
+  FNW_SWITCH(false, hd, {
+    const dim3 grid(B * H, (Tq + 32 * NWV - 1) / (32 * NWV));
+    if (hd == 128)
+      hipLaunchKernelGGL((full_fwd_mfma_kernel<128, NWV, __bf16>), grid, dim3(64 * NWV), 0, hig_stream(stream), q, ldq, k, v, ldk,
+                         Tq, Tk, H, qlen, (const uint8_t*)nullptr, y, ldy, (float*)nullptr);
+    else
+      hipLaunchKernelGGL((full_fwd_mfma_kernel<64, NWV, __bf16>), grid, dim3(64 * NWV), 0, hig_stream(stream), q, ldq, k, v, ldk,
+                         Tq, Tk, H, qlen, (const uint8_t*)nullptr, y, ldy, (float*)nullptr);
+  });
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

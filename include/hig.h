@@ -72,7 +72,7 @@ typedef struct hig_dims {
   int32_t storage;    /* HIG_STORE_F32 (0): fp32 activations and weights.  HIG_STORE_BF16 (1): bf16 activations and a
                          bf16 shadow of the weight matrices, fp32 accumulation / LayerNorm statistics / softmax /
                          context matrices / modulation vectors -- BASELINE configs 3 and 5.  Inference only
-                         (hig_denoiser_fwd_bf16); linear attention, single-person model, head dim 64 or 128,
+                         (hig_denoiser_fwd_bf16); single-person model (linear or full attention), head dim 64 or 128,
                          d, ff, Lt multiples of 32. */
 } hig_dims;
 #define HIG_STORE_F32 0
@@ -482,6 +482,10 @@ int hig_fullattn_fwd(const float* Q, int64_t ldq, const float* K, const float* V
 int hig_fullattn_fwd_kpad(const float* Q, int64_t ldq, const float* K, const float* V, int64_t ldk,
                           int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t hd, const int64_t* qlen,
                           const uint8_t* kpad, float* Y, int64_t ldy, float* lse, hig_stream_t stream);
+/* bf16-storage form of hig_fullattn_fwd (inference, hig_dims.storage == HIG_STORE_BF16 with attn_kind FULL): Q, K, V, Y
+ * bf16, logits / softmax / accumulation fp32, no log-sum-exp kept.  Head dim 64 or 128. */
+int hig_fullattn_fwd_bf16(const void* Q, int64_t ldq, const void* K, const void* V, int64_t ldk, int32_t B, int32_t Tq,
+                          int32_t Tk, int32_t H, int32_t hd, const int64_t* qlen, void* Y, int64_t ldy, hig_stream_t stream);
 int hig_fullattn_bwd(const float* dY, int64_t lddy, const float* Y, int64_t ldy, const float* Q,
                      int64_t ldq, const float* K, const float* V, int64_t ldk, int32_t B, int32_t Tq,
                      int32_t Tk, int32_t H, int32_t hd, const int64_t* qlen, const float* lse,

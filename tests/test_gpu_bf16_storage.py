@@ -219,6 +219,51 @@ def test_bf16_storage_forward_against_fp32_oracle(case):
     assert mx < 6e-2, mx
 
 
+@pytest.mark.parametrize("B,Tq,Tk,H,hd,lens", [(2, 196, 196, 8, 64, (196, 77)), (2, 130, 77, 4, 64, None),
+                                                (1, 300, 300, 2, 128, (211,)), (3, 70, 77, 8, 128, None)])
+def test_full_attention_bf16_io_equals_the_fp32_kernel_on_the_same_values(B, Tq, Tk, H, hd, lens):
+    """hig_fullattn_fwd_bf16 (no_eff attention of the bf16-storage forward) == hig_fullattn_fwd on the bf16-rounded inputs,
+    output rounded to bf16 once: the bf16 kernel is the fp32 matrix-core kernel with bf16 loads / stores."""
+    d = H * hd
+    g = torch.Generator().manual_seed(B + Tq + hd)
+    q16 = bf(torch.randn(B * Tq, d, generator=g) * 1.5).to(DEV)
+    kv16 = bf(torch.randn(B * Tk, 2 * d, generator=g) * 1.5).to(DEV)
+    lg = None if lens is None else torch.tensor(lens).to(DEV)
+    L, s = _lib.lib(), _lib.stream_ptr()
+    y16 = torch.full((B * Tq, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _lib.check(L.hig_fullattn_fwd_bf16(_lib.ptr(q16), d, _lib.ptr(kv16), kv16.data_ptr() + 2 * d, 2 * d, B, Tq, Tk, H, hd,
+                                       _lib.ptr(lg), _lib.ptr(y16), d, s))
+    q32, kv32 = q16.float(), kv16.float()
+    y32 = torch.empty(B * Tq, d, device=DEV)
+    lse = torch.empty(B * H * Tq, device=DEV)
+    _lib.check(L.hig_fullattn_fwd(_lib.ptr(q32), d, _lib.ptr(kv32), kv32.data_ptr() + 4 * d, 2 * d, B, Tq, Tk, H, hd,
+                                  _lib.ptr(lg), _lib.ptr(y32), d, _lib.ptr(lse), s))
+    torch.cuda.synchronize()
+    assert torch.equal(y16, bf(y32))
+
+
+@pytest.mark.parametrize("case", ["width", "hd128"])
+def test_bf16_storage_no_eff_forward_against_fp32_oracle(case):
+    """storage='bf16' with no_eff=True (full softmax attention on the matrix cores, bf16 Q / K / V / Y): valid rows of a
+    ragged batch against the fp32 CPU oracle (padded query rows carry the reference's -1e5-quantised logits, App. B-3)."""
+    c = CASES16[case]
+    m = build(c, storage="bf16", no_eff=True).eval()
+    inp = fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"])
+    gi = {k: v.to(DEV) for k, v in inp.items()}
+    with torch.no_grad():
+        out = m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+        p = fill.core_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"])
+        ref = R.denoiser_forward(p, inp["x"], inp["t"], inp["length"], inp["xf_proj"], inp["xf_out"], c["H"], c["L"], no_eff=True)
+    assert torch.isfinite(out).all()
+    errs = []
+    for b, n in enumerate(c["lengths"]):
+        n = min(n, c["T"])
+        if n:
+            errs.append(rel(out[b, :n], ref[b, :n]))
+    print("bf16 storage, no_eff, %s: rel-L2 of the valid rows vs fp32 oracle %s" % (case, ["%.2e" % e for e in errs]))
+    assert all(1e-4 < e < 3e-2 for e in errs), errs
+
+
 def test_bf16_storage_sees_parameter_updates_and_refuses_training():
     c = CASES16["small"]
     m = build(c, storage="bf16").eval()
