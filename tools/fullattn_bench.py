@@ -27,7 +27,12 @@ for (name, Tq, Tk, H, hd, self_) in (("self d=512", 196, 196, 8, 64, True), ("cr
         _lib.check(L.hig_fullattn_bwd(P(dy), d, P(y), d, P(q), d, P(kv), kv.data_ptr() + 4 * d, 2 * d, B, Tq, Tk, H, hd,
                                       P(ln), P(lse), P(delta), P(dq), d, P(dkv), dkv.data_ptr() + 4 * d, 2 * d, s))
 
-    for fn, nm, mult in ((fwd, "fwd", 4), (bwd, "bwd", 14)):   # bwd: 7 products (S and dP twice, dQ, dK, dV)
+    q16, kv16, y16 = q.to(torch.bfloat16), kv.to(torch.bfloat16), torch.empty(B * Tq, d, device=dev, dtype=torch.bfloat16)
+
+    def fwd16():   # bf16 storage (hig_denoiser_fwd_bf16 with no_eff): same kernel template, bf16 loads / stores
+        _lib.check(L.hig_fullattn_fwd_bf16(P(q16), d, P(kv16), kv16.data_ptr() + 2 * d, 2 * d, B, Tq, Tk, H, hd, P(ln), P(y16), d, s))
+
+    for fn, nm, mult in ((fwd, "fwd", 4), (fwd16, "fwd bf16 I/O", 4), (bwd, "bwd", 14)):   # bwd: 7 products (S and dP twice, dQ, dK, dV)
         for _ in range(3):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
