@@ -93,8 +93,7 @@ int check_dims(const hig_dims* p, Dims& D) {
   HIG_REQUIRE(p->storage == HIG_STORE_F32 || p->storage == HIG_STORE_BF16, "hig_dims: unknown storage=%d", p->storage);
   D.bf16 = p->storage == HIG_STORE_BF16;
   if (D.bf16) {
-    if (D.two)
-      return hig_set_error(HIG_EUNSUPPORTED, "hig: bf16 storage is built for the single-person model");
+
     if (D.hd != 64 && D.hd != 128)
       return hig_set_error(HIG_EUNSUPPORTED, "hig: bf16 storage needs head dim 64 or 128 (got %d)", D.hd);
     if (D.d % 32 || D.ff % 32 || D.Lt % 32)
@@ -495,7 +494,7 @@ namespace {
 inline int64_t alb(int64_t bytes) { return (bytes + 255) & ~(int64_t)255; }
 
 struct Fwd16Layout {
-  int64_t te32, te16, teh16, semb16, ss, h32, h, xn, qkv, A1, kst1, cscr, y, a, qc, f1, total;
+  int64_t te32, te16, teh16, semb16, ss, h32, h, xn, qkv, A1, kst1, cscr, y, a, qc, f1, lenp, tok0, total;
 };
 Fwd16Layout fwd16_layout(const Dims& D) {
   Fwd16Layout w;
@@ -518,8 +517,20 @@ Fwd16Layout fwd16_layout(const Dims& D) {
   w.a = take(D.M * D.d * 2);
   w.qc = take(D.M * D.d * 2);
   w.f1 = take(D.M * D.ff * 2);
+  w.lenp = take((int64_t)D.B * 8);           // two-person: lengths with the two halves swapped (the partner's mask)
+  w.tok0 = take((int64_t)D.B * D.d * 4);     // two-person: joint_embed2 of the init-pose rows (fp32) before they enter h
   w.total = o;
   return w;
+}
+
+// dst[r][0..n) = bf16(src[r][0..n)) for `rows` rows with their own leading dimensions (the init-pose rows of h)
+__global__ void cast_rows_bf16_kernel(const float* __restrict__ src, int64_t lds, __bf16* __restrict__ dst, int64_t ldd,
+                                      int rows, int n) {
+  const int64_t total = (int64_t)rows * n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / n, c = i % n;
+    dst[r * ldd + c] = (__bf16)src[r * lds + c];
+  }
 }
 
 struct Text16Layout {
@@ -623,13 +634,30 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   if (joint16 && d % 128 == 0 && D.F <= 512) {
     // own kernel pair (weight padded / rounded to bf16, x rounded in LDS, bf16 MFMA): 31 -> ~8 us at B = 32
     HIG_TRY(hig_joint_embed_bf16(x, M, D.F, P(params, HIG_P_JOINT_W), P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d,
-                                 D.T, 0, ws + w.h, d, d, ws + w.h32, stream));
+                                 D.T, D.two ? 1 : 0, ws + w.h, d, d, ws + w.h32, stream));
   } else {
     float* h32 = reinterpret_cast<float*>(ws + w.h32);
     G ge(x, D.F, 0, P(params, HIG_P_JOINT_W), D.F, 0, h32, d, M, d, D.F);
     ge.epi(HIG_EPI_BIAS_POS, P(params, HIG_P_JOINT_B)).pos(P(params, HIG_P_SEQ_EMB), d, D.T);
+    ge.g.pos_shift = D.two ? 1 : 0;
     HIG_TRY(hig_gemm_launch(ge.g, 1, nullptr, st));
     HIG_TRY(hig_cast_bf16(h32, ws + w.h, M * d, stream));
+  }
+  const int64_t* len_partner = nullptr;
+  const int Bp = D.B / 2;
+  if (D.two) {
+    // token 0 is the init-pose row: joint_embed2 on its first 4 features, no positional term
+    // (interaction_transformer.py:596); fp32 GEMM over the B rows, then into the bf16 residual stream
+    float* tok0 = reinterpret_cast<float*>(ws + w.tok0);
+    HIG_TRY(hig_gemm_launch(G(x, (int64_t)D.T * D.F, 0, P(params, HIG_P_JOINT2_W), 4, 0, tok0, d, D.B, d, 4)
+                                .epi(HIG_EPI_BIAS, P(params, HIG_P_JOINT2_B)).g, 1, nullptr, st));
+    hipLaunchKernelGGL(cast_rows_bf16_kernel, dim3((unsigned)(((int64_t)D.B * d + 255) / 256)), dim3(256), 0, st, tok0, (int64_t)d,
+                       reinterpret_cast<__bf16*>(ws + w.h), (int64_t)D.T * d, D.B, d);
+    HIG_CHECK_LAUNCH();
+    int64_t* lp = reinterpret_cast<int64_t*>(ws + w.lenp);
+    hipLaunchKernelGGL(swap_halves_i64_kernel, dim3((D.B + 255) / 256), dim3(256), 0, st, length, D.B, (int64_t)D.T, lp);
+    HIG_CHECK_LAUNCH();
+    len_partner = lp;
   }
   void* h = ws + w.h;
   void* xn = ws + w.xn;
@@ -694,16 +722,34 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
       HIG_TRY(attend(l, 1, qc, d, reinterpret_cast<const float*>(tc + tl.layer0 + tl.lstride * l + tl.Ac),
                      HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B));
     }
+    if (D.two == 1) {
+      // ---- person <-> person linear cross attention (interaction_transformer.py:181-205): queries from the own
+      // stream, key / value from the partner's (same LayerNorm on both), key softmax masked with the consumer's length
+      HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B), nullptr, 0, 0, 0, xn, d, stream));
+      HIG_TRY(hig_gemm16_launch(G16(xn, d, PL16(params16, l, HIG_L_INT_QKV_W), d, qkv, 3 * d, M, 3 * d, d)
+                                    .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_INT_QKV_B)).g, st));
+      HIG_TRY(hig_linattn_ctx_bf16(qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, D.H, D.hd, len_partner, A1, kst1,
+                                   cscr, stream));
+      const int64_t halfA = (int64_t)Bp * D.H * D.hd * D.hd, halfM = (int64_t)Bp * D.T;
+      HIG_TRY(hig_linattn_apply_bf16(qkv, 3 * d, A1 + halfA, y, d, Bp, D.T, D.H, D.hd, stream));
+      HIG_TRY(hig_linattn_apply_bf16(qkv + halfM * 3 * d * 2, 3 * d, A1, static_cast<char*>(y) + halfM * d * 2, d, Bp, D.T, D.H, D.hd,
+                                     stream));
+      HIG_TRY(stylize(l, 2, HIG_L_INT_STY_NORM_W, HIG_L_INT_STY_NORM_B, HIG_L_INT_STY_OUT_W, HIG_L_INT_STY_OUT_B));
+    }
     // ---- FFN (transformer.py:167-170) ----
     HIG_TRY(hig_gemm16_launch(G16(h, d, PL16(params16, l, HIG_L_FFN_W1), d, f1, D.ff, M, D.ff, d)
                                   .epi(HIG_EPI_BIAS_GELU, PL(params, l, HIG_L_FFN_B1)).g, st));
     HIG_TRY(hig_gemm16_launch(G16(f1, D.ff, PL16(params16, l, HIG_L_FFN_W2), D.ff, y, d, M, d, D.ff)
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B2)).g, st));
-    HIG_TRY(stylize(l, 2, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B, HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B));
+    HIG_TRY(stylize(l, D.nsty - 1, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B, HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B));
   }
   // K6: out = Linear(d, F)(h_L), fp32 (the DDPM update consumes it)
-  return hig_gemm16_launch(G16(h, d, P16(params16, HIG_P_OUT_W), d, out, D.F, M, D.F, d)
-                               .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT_B)).out32().g, st);
+  HIG_TRY(hig_gemm16_launch(G16(h, d, P16(params16, HIG_P_OUT_W), d, out, D.F, M, D.F, d)
+                                .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT_B)).out32().g, st));
+  if (D.two)  // init-pose rows go through out2 instead (interaction_transformer.py:613-614)
+    HIG_TRY(hig_gemm16_launch(G16(h, (int64_t)D.T * d, P16(params16, HIG_P_OUT2_W), d, out, (int64_t)D.T * D.F, D.B, D.F, d)
+                                  .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT2_B)).out32().g, st));
+  return HIG_OK;
 }
 
 namespace {

@@ -123,7 +123,7 @@ class MotionInteractionTransformer(MotionTransformer):
 
         self.precision = kargs.get("precision", os.environ.get("HIG_PREC", "f32"))
         self.text_head = kargs.get("text_head", os.environ.get("HIG_TEXT_HEAD", "hip"))
-        self.storage = "f32"     # bf16 storage is built for the single-person model
+        self.storage = kargs.get("storage", os.environ.get("HIG_STORAGE", "f32"))   # "bf16": inference with bf16 activations
         self._flat = None
         self._pool = _WorkspacePool()
         self._textctx_cache = None

@@ -105,6 +105,30 @@ def test_all_gradients_against_oracle_autograd():
         assert (gr - v.grad).norm().item() <= 2e-4 * scale + 1e-5, (k, (gr - v.grad).norm().item(), scale)
 
 
+@pytest.mark.parametrize("nocross", [False, True])
+@pytest.mark.parametrize("case", ["hd64", "hd128"])
+def test_bf16_storage_two_person_forward_against_oracle(case, nocross):
+    """storage='bf16' on the two-person model (interaction attention with the partner's keys / values and the consumer's
+    length, joint_embed2 / out2 on the init-pose rows, 4 stylization blocks per layer): bf16 activations and weights vs
+    the fp32 CPU oracle -- bounded at the bf16 level and clearly above fp32 noise."""
+    c = {"hd64": dict(B=2, T=33, F=20, d=256, H=4, L=2, ff=256, N=77, Lt=64, num_frames=40, lengths=(33, 12), t=(4, 700)),
+         "hd128": dict(B=1, T=61, F=150, d=256, H=2, L=3, ff=512, N=77, Lt=64, num_frames=60, lengths=(45,), t=(250,))}[case]
+    m = build(c, no_cross_attn=nocross, storage="bf16").eval()
+    inp, gi = case_inputs(c)
+    with torch.no_grad():
+        out = m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+        m.storage = "f32"
+        out32 = m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+    p = fill.interaction_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"])
+    ref = IR.interaction_forward(p, inp["x"], inp["t"], inp["length"], inp["xf_proj"], inp["xf_out"], c["H"], c["L"],
+                                 no_cross_attn=nocross)
+    assert rel(out32, ref) < 2e-5
+    e = rel(out, ref)
+    print("two-person bf16 storage %s nocross=%s: rel-L2 vs fp32 oracle %.3e" % (case, nocross, e))
+    assert torch.isfinite(out).all() and 1e-4 < e < 3e-2, e
+    assert 1e-4 < rel(out[:, 0], ref[:, 0]) < 3e-2          # init-pose rows (joint_embed2 -> ... -> out2)
+
+
 def test_swapping_the_two_persons_swaps_the_outputs():
     """Size-independent property at a production-like size: the model is symmetric in the two
     persons, so model(cat[x2, x1]) == swap(model(cat[x1, x2])) when both share text / t / length."""
