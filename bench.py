@@ -586,10 +586,14 @@ def main():
 
             e_pit = timed(pit_step, k2, 2, 1)
             m2.eval()
+            m2.storage = "bf16"          # bf16 storage of the two-person forward (inference)
+            e_f16 = timed(fwd2, k2, 2, 1)
+            m2.storage = "f32"
             extra["two_person"] = {
                 "pit_train_step_ms": round(e_pit / k2 * 1e3, 3),
                 "pit_train_pairs_per_s": round(16 * k2 / e_pit, 1),
                 "fwd_frames_per_s": round(c2["B"] * c2["T"] * k2 / e_f, 1), "fwd_ms": round(e_f / k2 * 1e3, 3),
+                "fwd_ms_bf16_storage": round(e_f16 / k2 * 1e3, 3),
                 "fwd_bwd_frames_per_s": round(c2["B"] * c2["T"] * k2 / e_fb, 1), "fwd_bwd_ms": round(e_fb / k2 * 1e3, 3),
                 "what": "MotionInteractionTransformer, 32 pairs (model batch 64) x 91 tokens x 263 features, d=512 L=8, "
                         "f32 products; frames = person-tokens.  pit_train_step: 16 pairs run twice (64 rows), q_sample + "

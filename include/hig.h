@@ -72,7 +72,8 @@ typedef struct hig_dims {
   int32_t storage;    /* HIG_STORE_F32 (0): fp32 activations and weights.  HIG_STORE_BF16 (1): bf16 activations and a
                          bf16 shadow of the weight matrices, fp32 accumulation / LayerNorm statistics / softmax /
                          context matrices / modulation vectors -- BASELINE configs 3 and 5.  Inference only
-                         (hig_denoiser_fwd_bf16); single-person model (linear or full attention), head dim 64 or 128,
+                         (hig_denoiser_fwd_bf16); single-person model (linear or full attention) and two-person model
+                         (linear attention), head dim 64 or 128,
                          d, ff, Lt multiples of 32. */
 } hig_dims;
 #define HIG_STORE_F32 0
