@@ -245,6 +245,23 @@ def test_labelled_trainer_loss_and_generate():
     assert all(torch.isfinite(o[0]).all() and torch.isfinite(o[1]).all() for o in outs)
 
 
+def test_two_person_generate_with_bf16_storage():
+    """DDPMMulTrainer.generate (captured p_sample_loop over the two-person model) with storage='bf16': runs, is finite,
+    returns (motion1, motion2) pairs, and repeats itself bitwise under the same noise stream."""
+    c = dict(B=2, T=33, F=20, d=256, H=4, L=2, ff=256, N=77, Lt=64, num_frames=40, lengths=(33, 12), t=(4, 700))
+    m = build(c, storage="bf16").eval()
+    trainer = _trainer(c, m)
+    trainer.diffusion = make_diffusion(30)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(7)
+        outs.append(trainer.generate(CAP1[:2], CAP2[:2], torch.tensor([33, 20]), c["F"]))
+    assert len(outs[0]) == 2 and all(len(o) == 2 and o[0].shape == (33, c["F"]) for o in outs[0])
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_cap_id_mode_class_embeddings_single_text_token():
     """cap_id=True: captions are class ids, the text context is ONE token per sample (N=1,
     interaction_transformer.py:558-563); forward + backward against the oracle."""
