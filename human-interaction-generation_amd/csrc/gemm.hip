@@ -597,7 +597,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
 #pragma unroll
           for (int e = 0; e < 16; ++e)
             __hip_atomic_store(mine + ((tj * TI + ti) * 16 + e) * NTHREADS, acc[tj][ti][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();     // s_waitcnt vmcnt(0): every thread's partial sums have reached memory
+      // Every storing wave drains its own stores BEFORE the barrier: gfx950's s_barrier does not wait on vmcnt and
+      // hipcc emits no wait for a workgroup-scope barrier here, so without this the ticket could be counted while
+      // another wave's partial sums are still in flight (the last arriver would then sum stale scratch).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
       if (tid == 0) s_ticket = __hip_atomic_fetch_add(a.tail_cnt + cur_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
       const bool last = s_ticket == (unsigned)(a.tail_s - 1);

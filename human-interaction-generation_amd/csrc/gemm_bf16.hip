@@ -18,13 +18,8 @@
 // during its MFMA block; with 2 workgroups per CU (64 KiB of LDS each) the other workgroup's MFMAs cover the rest.
 #include <stdlib.h>
 
-#include "hig_common.h"
+#include "gemm16_epi.h"
 #include "hig_host.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -41,24 +36,6 @@ struct K16Args {
 __device__ __forceinline__ void glds16(const __bf16* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// Exact-erf GELU (nn.GELU(), transformer.py:160) for a result that is rounded to bf16 (2^-9) right away: erf by
-// Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7: one exp, one rcp, five FMAs) instead of the 30-instruction libm erff --
-// the epilogue's VALU work was 10 of the 43 us of the FFN linear1 launch (profiles/r02_notes.md).
-__device__ __forceinline__ float gelu_bf16(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float erf_abs = 1.0f - poly * __expf(-z * z);
-  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
-}
-
-template <int EPI>
-__device__ __forceinline__ float epi_act(float v) {
-  if (EPI == HIG_EPI_BIAS_GELU) return gelu_bf16(v);
-  if (EPI == HIG_EPI_BIAS_SILU || EPI == HIG_EPI_BIAS_RES_SILU) return hig_silu_fast(v);
-  return v;
 }
 
 unsigned long long* g_stamps = nullptr;   // diagnostic only (hig_gemm_bf16_debug_stamps)
@@ -550,6 +527,10 @@ int hig_gemm16_launch(const hig_gemm16_desc& g, hipStream_t st) {
               "hig_gemm_bf16: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
   if (g.epi != HIG_EPI_NONE) HIG_REQUIRE(g.bias, "hig_gemm_bf16: epilogue %d needs a bias", g.epi);
   if (g.epi == HIG_EPI_BIAS_RES || g.epi == HIG_EPI_BIAS_RES_SILU) HIG_REQUIRE(g.res, "hig_gemm_bf16: missing residual");
+  {   // many rows, short reduce range: the weight-stationary kernel (gemm_ws16.hip) when it serves the shape
+    const int rc = hig_gemm_ws16_try(g, st);
+    if (rc <= 0) return rc;
+  }
   switch (g.epi) {
     case HIG_EPI_NONE: return launch16_sized<HIG_EPI_NONE>(g, st);
     case HIG_EPI_BIAS: return launch16_sized<HIG_EPI_BIAS>(g, st);

@@ -1,0 +1,467 @@
+// WEIGHT-STATIONARY bf16-storage GEMM for gfx950 (MI355X):  C[i][j] = epi( sum_r X[i][r] * W[j][r] ), bf16 in / out,
+// fp32 accumulate on v_mfma_f32_32x32x16_bf16.  Serves the nn.Linear layers of the bf16-storage denoiser forward
+// (codes/models/transformer.py:81-85,108-114,144-150,168) whose reduce extent is short (K = 256 / 512 / 1024) and
+// whose row count is large (M = B.T = 6 272 ... 12 544): every one of them is a short-K problem in which a tiled
+// kernel (gemm_bf16.hip) re-stages the same 128 x K weight panel for every 128 rows -- 200 MB of L2 -> LDS operand
+// traffic for the 39.5 MB FFN linear1 launch, at the ~30 B/clk a CU can pull from its L2 (profiles/r02_notes.md s.7).
+//
+// CDNA4 mapping.  The register file of a CU (512 KB) is three times its LDS: a workgroup keeps its WEIGHT PANEL in
+// VGPRs for its whole life -- wave w holds the MFMA A-fragments of 32 output columns x KW reduce elements (KW / 4
+// VGPRs: 128 at KW = 512) -- and only the activation rows stream: 32-row X tiles go global -> LDS by DMA
+// (global_load_lds_dwordx4, XOR swizzle on the per-lane SOURCE address and on the read address), double-buffered as
+// WHOLE tiles (32 x K), so the k-loop of a tile is barrier-free: per k-step one ds_read_b128 (the X fragment, shared
+// by all waves) and one MFMA.  One barrier per tile.  The workgroup is persistent over the row tiles of ONE column
+// panel; bias columns live in registers for its whole life.
+// The epilogue of tile t-1 (bias / GELU / SiLU / residual in fp32, bf16 pack, swizzled LDS staging) is interleaved
+// with the MFMAs of tile t inside each wave (the two waves of a SIMD alternate on the matrix pipe, which leaves
+// each ~56 cycles of vector issue per MFMA), and tile t-2 leaves the staging buffer as whole rows (16 bytes per
+// lane) right after the barrier of iteration t.
+// K = 1024: the reduce range is split over wave pairs (wave (j, kh) holds columns 32 j, k in [512 kh, +512)); the
+// partial accumulators are exchanged through LDS: each wave keeps two of its four accumulator quads, parks the other
+// two for its partner, and finishes the kept half -- balanced; one more barrier per tile (the parked halves have one
+// buffer: X double-buffered is 128 of the 160 KB).
+// Work split: block b runs on XCD b % 8 (observed round-robin; speed only).  XCD x owns a contiguous range of row
+// tiles for ALL column panels, so an X tile is fetched from HBM once and by the other panels from that XCD's L2.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "gemm16_epi.h"
+#include "hig_host.h"
+
+namespace {
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct WsArgs {
+  const __bf16* X; int64_t ldx;
+  const __bf16* W; int64_t ldy;
+  __bf16* C; int64_t ldc;
+  const __bf16* res; int64_t ldr;
+  const float* bias;
+  int I, J;
+  int np;        // column panels (J / BN)
+  int g;         // row groups per XCD: slot s of an XCD works on panel s % np, row tiles rg, rg + g, ... (rg = s / np)
+  int ntiles;    // 32-row tiles in all
+  unsigned long long* stamps;   // diagnostic (hig_gemm_ws16_debug_stamps): 16 s_memtime stamps per workgroup, else NULL
+};
+
+unsigned long long* g_ws_stamps = nullptr;
+
+// s_waitcnt vmcnt(N) as a BUILTIN (hipcc's wait-count pass sees it and retires the loads it tracks; an asm wait it does
+// not see) -- gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14, unused counters at their maximum
+template <int N>
+__device__ __forceinline__ void ws_wait_vmcnt_visible() {
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70);
+  asm volatile("" ::: "memory");
+}
+
+// KW: reduce elements per wave; KSPLIT: wave pairs splitting K = KW * KSPLIT; NWJ: 32-column slices per workgroup.
+template <int KW, int KSPLIT, int NWJ, int EPI>
+__global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) void gemm_ws16_kernel(const WsArgs a) {
+  constexpr int NW = NWJ * KSPLIT, NT = 64 * NW;
+  constexpr int K = KW * KSPLIT;
+  constexpr int BM = 32, BN = 32 * NWJ;
+  constexpr int NKS = KW / 16;                 // MFMA k-steps per wave and tile
+  constexpr int ROWB = K * 2;                  // bytes per X row in LDS
+  constexpr int XBUF = BM * ROWB;
+  constexpr int NDMA = XBUF / 1024, NQ = NDMA / NW;
+  static_assert(NDMA % NW == 0, "DMA instructions must split evenly over the waves");
+  constexpr int SROWB = BN * 2;                // bytes per staged output row
+  constexpr int SBUF = BM * SROWB;
+  constexpr int PBUF = KSPLIT > 1 ? NW * 8 * 64 * 4 : 0;   // parked accumulator halves: [wave][8][64] floats (one buffer: 160 KB of LDS are all there is at K = 1024)
+  constexpr int PPR = BN / 8;                  // 16-byte pieces per output row
+  constexpr int NPC = BM * PPR / NT;           // pieces per thread in the store pass
+  static_assert((BM * PPR) % NT == 0, "store pass split");
+  constexpr bool HAS_RES = EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU;
+  // 4-wave workgroups (one wave per SIMD, 512 registers each): X fragments are read XD k-steps ahead into a register ring
+  // and the k-loop's order is pinned; 8-wave workgroups (256 registers per wave: the ring spills) leave the k-loop to hipcc
+  constexpr bool RING = NW < 8;
+  constexpr int XD = 4;
+  // X ring: three tiles where LDS allows (a tile requested in iteration t is waited for at the top of iteration t + 2:
+  // one tile in flight across every barrier); two at K = 1024 (64 KB tiles)
+  constexpr int RBUF = HAS_RES ? SBUF : 0;     // residual tiles come in by DMA too (two buffers, staged-tile sized)
+  static_assert(!(HAS_RES && KSPLIT > 1), "the K-split variant has no LDS left for residual tiles");
+  constexpr int NXB = (3 * XBUF + 2 * SBUF + 2 * RBUF + PBUF <= 160 * 1024) ? 3 : 2;
+  constexpr int NRQ = RBUF / 1024 / NW;        // residual DMA instructions per wave and tile
+  static_assert(RBUF % (1024 * NW) == 0, "residual DMA instructions must split evenly over the waves");
+  // bias: in LDS where there is room (sixteen registers less per lane), else in registers for the workgroup's life
+  constexpr bool BIAS_LDS = NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + BN * 4 <= 160 * 1024;
+  __shared__ __attribute__((aligned(1024))) char smem[NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + (BIAS_LDS ? BN * 4 : 0)];
+  [[maybe_unused]] float* const sB = reinterpret_cast<float*>(smem + NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF);
+  char* const sX = smem;
+  char* const sS = smem + NXB * XBUF;
+  [[maybe_unused]] char* const sR = smem + NXB * XBUF + 2 * SBUF;
+  [[maybe_unused]] char* const sP = smem + NXB * XBUF + 2 * SBUF + 2 * RBUF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: row / buffer arithmetic of the DMA stays scalar
+  const int wj = wave % NWJ, kh = wave / NWJ;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // ---- which tiles ----------------------------------------------------------------------------------------------
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int panel = slot % a.np, rg = slot / a.np;
+  if (rg >= a.g) return;
+  const int tl = (int)((int64_t)xcd * a.ntiles >> 3), th = (int)((int64_t)(xcd + 1) * a.ntiles >> 3);
+  const int t0 = tl + rg;
+  if (t0 >= th) return;
+  const int nt = (th - t0 + a.g - 1) / a.g;
+  const int j0 = panel * BN;
+  auto stamp = [&](int k) {
+    if (a.stamps && tid == 0) {
+      unsigned long long tm;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm)::"memory");
+      a.stamps[(size_t)blockIdx.x * 16 + k] = tm;
+    }
+  };
+  stamp(0);
+
+  // which accumulator quads this wave finishes: all four, or (K split) two of them: kh = 0 -> quads 0, 1; kh = 1 -> 2, 3.
+  // A K-split wave with kh = 1 swaps the halves of its accumulator vector when a tile's k-loop ends, so "slot u" below is
+  // real quad qf0 + u for both kinds (a select between two register INDICES would send the vector to scratch memory).
+  constexpr int NQF = KSPLIT > 1 ? 2 : 4;
+  const int qf0 = KSPLIT > 1 ? 2 * kh : 0;
+  // bias of the columns this lane finishes: slot u, element e is column 32 wj + 8 (qf0 + u) + 4 lh + e.  Requested
+  // FIRST: the (compiler-visible) wait of the first weight round retires these loads, so that hipcc never guards their
+  // use with a vmcnt(0) of its own further down, where it would drain the X ring.
+  float bq[BIAS_LDS ? 1 : 4 * NQF];
+  if constexpr (BIAS_LDS) {
+    if (tid < BN) sB[tid] = (EPI != HIG_EPI_NONE) ? a.bias[j0 + tid] : 0.f;    // (published by the barriers of the weight rounds)
+  } else {
+#pragma unroll
+    for (int u = 0; u < NQF; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bq[4 * u + e] = (EPI != HIG_EPI_NONE) ? a.bias[j0 + 32 * wj + 8 * (qf0 + u) + 4 * lh + e] : 0.f;
+  }
+
+  // raw (stride 0) buffer descriptors over the whole operands; rows are clamped, so nothing is out of range
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.X), 0, (int)(((int64_t)(a.I - 1) * a.ldx + K) * 2), 0x00020000);
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.W), 0, (int)(((int64_t)(a.J - 1) * a.ldy + K) * 2), 0x00020000);
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(HAS_RES ? a.res : a.X), 0, (int)(((int64_t)(a.I - 1) * (HAS_RES ? a.ldr : a.ldx) + (HAS_RES ? a.J : K)) * 2), 0x00020000);
+  // ---- DMA: instruction n of a tile covers bytes [1024 n, 1024 n + 1024) of the [32][K] image; LDS position p of row r
+  // receives the source row's 16-byte chunk p ^ (r & 15) ------------------------------------------------------------
+  // 32 rows [row0, row0 + 32) of a row-major bf16 matrix (rows clamped to rmax) -> X-tile-shaped buffer `buf`
+  // `buffer_load_dwordx4 ... lds` through a buffer descriptor in SGPRs: the per-lane part of the address is one 32-bit
+  // byte offset (the swizzled chunk), the row is a scalar -- no 64-bit per-lane address to build and keep in VGPRs.
+  auto dma_one = [&]([[maybe_unused]] __amdgpu_buffer_rsrc_t rs, int ld, int row0, int rmax, int buf, int q) {
+    const int n = wave + NW * q;                // scalar
+    [[maybe_unused]] int voff, soff;
+    if constexpr (ROWB >= 1024) {               // one row (or a 1-KiB part of one) per instruction: lane = chunk position
+      constexpr int IPR = ROWB / 1024;
+      const int r = n / IPR;
+      voff = 16 * ((n % IPR) * 64 + (lane ^ (r & 15)));
+      soff = min(row0 + r, rmax) * ld * 2;
+    } else {                                    // two 512-byte rows per instruction
+      const int r = 2 * n + (lane >> 5);
+      voff = (min(row0 + r, rmax) * ld + 8 * ((lane & 31) ^ (r & 15))) * 2;
+      soff = 0;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass cannot type-check the builtin)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(sX + buf * XBUF + n * 1024), 16, voff, soff, 0, 0);
+#endif
+  };
+  auto dma_rows = [&](__amdgpu_buffer_rsrc_t rs, int ld, int row0, int rmax, int buf) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) dma_one(rs, ld, row0, rmax, buf, q);
+  };
+  auto dma_tile = [&](int t, int buf) { dma_rows(rsX, (int)a.ldx, (t0 + t * a.g) * BM, a.I - 1, buf); };
+
+  // read-side offsets: k-step ks reads chunk (2 ks + lh) of row lr, stored at chunk ^ (lr & 15)
+  int xo[8];
+  {
+    const int tsw = (lr & 15) ^ lh;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xo[j] = lr * ROWB + kh * (KW * 2) + 16 * ((2 * j) ^ tsw);
+  }
+
+  // ---- the weight panel of this wave: 32 columns x KW, as MFMA A-fragments, for the life of the workgroup ----------
+  // Fetched through LDS like an X tile (round r = the 32 weight rows of column slice r, whole 1-KiB rows by DMA, NXB
+  // rounds in flight), then read as fragments by the wave(s) that own the slice.  Loading the fragments straight from
+  // global memory (32 rows x 32 bytes per instruction) took 8.3K cycles to ISSUE and 11K more to land at M = 12 544
+  // (tools/gemm_ws16_stamps.py): the address path handles such a fragment-shaped load one 128-byte line at a time.
+  bf16x8 wf[NKS];
+  constexpr int NWB = NXB;                                   // X-tile-sized buffers the rounds use
+  constexpr int RLAST0 = ((NWJ - 1) / NWB) * NWB;            // last round that uses buffer 0: the first X tile goes there afterwards
+#pragma unroll
+  for (int r = 0; r < NWB && r < NWJ; ++r) dma_rows(rsW, (int)a.ldy, j0 + 32 * r, a.J - 1, r);
+#pragma unroll
+  for (int r = 0; r < NWJ; ++r) {
+    // round r has landed once only the younger requests are outstanding: the rounds behind it, the first X tile
+    const int younger = (NWB - 1 < NWJ - 1 - r ? NWB - 1 : NWJ - 1 - r) + (r > RLAST0 ? 1 : 0);
+    if (younger == 0) ws_wait_vmcnt_visible<0>();
+    else if (younger == 1) ws_wait_vmcnt_visible<NQ>();
+    else if (younger == 2) ws_wait_vmcnt_visible<2 * NQ>();
+    else ws_wait_vmcnt_visible<3 * NQ>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wj == r) {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+        wf[ks] = *reinterpret_cast<const bf16x8*>(sX + (r % NWB) * XBUF + xo[ks & 7] + 256 * (ks >> 3));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // the buffer may be overwritten
+    asm volatile("" ::: "memory");
+    if (r + NWB < NWJ) dma_rows(rsW, (int)a.ldy, j0 + 32 * (r + NWB), a.J - 1, r % NWB);
+    if (r == RLAST0) dma_tile(0, 0);
+  }
+  stamp(1);
+
+  // a tile's accumulators START at the bias of the columns this wave finishes (K split: the half it parks starts at 0;
+  // a kh = 1 wave finishes elements 8 .. 15, which it swaps to the front when the k-loop ends)
+  f32x16 acc, old;
+  auto acc_start = [&]() {
+    if constexpr (BIAS_LDS) {
+      static_assert(!BIAS_LDS || KSPLIT == 1, "bias in LDS: single-split variants only");
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sB + 32 * wj + 8 * q + 4 * lh);
+        acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+      }
+    } else if constexpr (KSPLIT > 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { acc[j] = kh ? 0.f : bq[j]; acc[8 + j] = kh ? bq[j] : 0.f; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = bq[j];
+    }
+  };
+  acc_start();
+#pragma unroll
+  for (int e = 0; e < 16; ++e) old[e] = 0.f;
+
+  // The epilogue of the tile whose accumulators sit in `old`, one ELEMENT at a time (element j = 4 u + e of this
+  // wave's finished quads): the k-loop calls epi_elem(j) between its MFMAs so that the vector work is spread evenly.
+  float ev[4];
+  u32x2 rq = u32x2{0u, 0u};                    // residual of the quad in work: four bf16, raw bits
+  auto epi_elem = [&](int j, char* stg, [[maybe_unused]] const float* parked, [[maybe_unused]] const char* rbuf) {
+    const int u = j >> 2, e = j & 3;
+    float v = old[j];
+    if constexpr (KSPLIT > 1) v += parked[j * 64];
+    if constexpr (HAS_RES) {
+      if (e == 0) rq = *reinterpret_cast<const u32x2*>(rbuf + lr * SROWB + 16 * ((4 * wj + qf0 + u) ^ (lr & 15)) + 8 * lh);
+      const unsigned w = e < 2 ? rq.x : rq.y;
+      v += __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));
+    }
+    ev[e] = epi_act<EPI>(v);
+    if (e == 3) {
+      const int pos16 = (4 * wj + qf0 + u) ^ (lr & 15);
+      *reinterpret_cast<bf16x4*>(stg + lr * SROWB + 16 * pos16 + 8 * lh) =
+          bf16x4{(__bf16)ev[0], (__bf16)ev[1], (__bf16)ev[2], (__bf16)ev[3]};
+    }
+  };
+  // Residual tile t -> LDS by DMA, in the layout of the staged output tile (row r, 16-byte chunk c at position
+  // c ^ (r & 15)): each lane later reads the 8 bytes it is about to overwrite in the staging buffer's twin.  No VGPR
+  // destination, hence nothing hipcc could guard with a vmcnt(0) of its own, and nothing it could copy before the data
+  // has landed (an inline-asm load into registers was tried: hipcc copied the destination registers BEFORE the wait
+  // statement that named them).  Requested as the OLDEST requests of iteration t, so the counted wait at the top of
+  // iteration t + 1 retires them while the younger X tile and output stores stay in flight.
+  auto dma_res = [&](int t, int buf) {
+    if constexpr (HAS_RES) {
+      const int i0 = (t0 + t * a.g) * BM;
+#pragma unroll
+      for (int q = 0; q < NRQ; ++q) {
+        const int n = wave + NW * q;            // scalar
+        const int o = n * 1024 + lane * 16;
+        const int r = o / SROWB, p = (o % SROWB) / 16;
+        [[maybe_unused]] const int voff = (min(i0 + r, a.I - 1) * (int)a.ldr + j0 + 8 * (p ^ (r & 15))) * 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsR, (__attribute__((address_space(3))) void*)(sR + buf * RBUF + n * 1024), 16, voff, 0, 0, 0);
+#endif
+      }
+    }
+  };
+  // s_waitcnt vmcnt(N): everything but the N youngest requests of this wave is done
+#define WS_WAIT_ALL_BUT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+  // tile t leaves the staging buffer as whole rows
+  auto store_tile = [&](int t, const char* stg) {
+    const int i0 = (t0 + t * a.g) * BM;
+#pragma unroll
+    for (int u = 0; u < NPC; ++u) {
+      const int idx = tid + NT * u;
+      const int r = idx / PPR, p = idx % PPR;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + r * SROWB + 16 * (p ^ (r & 15)));
+      // Rows beyond I go to row I - 1: their X rows (and residual rows) were clamped to it too, so they hold bit-identical
+      // values.  No predicate: every wave must issue exactly NPC stores per tile -- the counted waits assume it (a wave
+      // whose lanes are all masked would skip the instruction and leave an OLDER request, e.g. a DMA, uncounted).
+      const int i = min(i0 + r, a.I - 1);
+      *reinterpret_cast<bf16x8*>(a.C + (int64_t)i * a.ldc + j0 + 8 * p) = v;
+    }
+  };
+
+  // Requests of iteration t, in this order: residual of tile t and stores of tile t - 2 (ahead of the k-loop), then the
+  // DMA of tile t + NXB - 1 (spread over the k-loop).  At the top of iteration t + 1 the wave needs the residual and
+  // X(t + 1); with three buffers X(t + 1) was requested an iteration earlier, so this iteration's DMA (the youngest NQ
+  // requests) may stay in flight.
+  bool dma_pend = false;
+  if (NXB >= 3 && nt > 1) { dma_tile(1, 1); dma_pend = true; }
+  stamp(2);
+  for (int t = 0; t < nt; ++t) {
+    if (NXB >= 3 && dma_pend) WS_WAIT_ALL_BUT(NQ); else WS_WAIT_ALL_BUT(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // everyone's share has landed; k-loop(t-1) is over everywhere: its buffer, staging(t-1), parked(t-1) are complete
+    asm volatile("" ::: "memory");
+    if (t < 9) stamp(3 + t);
+    dma_res(t, t & 1);
+    if (t >= 2) store_tile(t - 2, sS + (t & 1) * SBUF);
+    dma_pend = t + NXB - 1 < nt;                 // its DMA instructions go out between the MFMAs below
+    const int drow0 = (t0 + (t + NXB - 1) * a.g) * BM, dbuf = (t + NXB - 1) % NXB;
+    // (a wave stalls ~150-300 cycles on every 1-KiB DMA it issues -- the CU takes ~25 bytes per clock from its L2 --
+    // and issued in a block ahead of the k-loop that was 600-1200 cycles per tile in which the wave fed no MFMA; the
+    // two waves of a SIMD issue theirs at different k-steps, so one of them keeps the matrix pipe busy)
+    const char* xb = sX + (t % NXB) * XBUF;
+    char* stg = sS + ((t + 1) & 1) * SBUF;       // staging of tile t-1
+    [[maybe_unused]] const char* rbuf = sR + ((t + 1) & 1) * RBUF;   // its residual
+    [[maybe_unused]] const float* parked = reinterpret_cast<const float*>(sP) + (wave ^ NWJ) * 512 + lane;
+    // The MFMAs of this tile with the epilogue of the previous one (garbage in, nothing stored, at t = 0) riding in their
+    // gaps, element by element.  X fragments are read XD k-steps ahead into a register ring: LDS answers a ds_read_b128
+    // in ~130-200 cycles when eight waves read at once, an MFMA issues every 32-64, and hipcc on its own keeps only two
+    // reads in flight (4 900 cycles per tile against 2 048 of MFMA work, tools/gemm_ws16_stamps.py).  The k-loop is
+    // compiled in four copies (this iteration requests an X tile or not; first or second wave of its SIMD) so that it
+    // stays ONE basic block: a runtime test per k-step cut it into blocks of eight MFMAs, each starting with a drained
+    // LDS queue.
+    auto kloop = [&](auto with_dma, auto second_half) {
+      constexpr bool DMA = decltype(with_dma)::value;
+      constexpr int DPH = decltype(second_half)::value ? (NKS / NQ) / 2 : 0;
+      bf16x8 xr[XD];
+      if constexpr (RING) {
+#pragma unroll
+        for (int i = 0; i < XD; ++i) xr[i] = *reinterpret_cast<const bf16x8*>(xb + xo[i & 7] + 256 * (i >> 3));
+      }
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        if constexpr (RING) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xr[ks % XD], acc, 0, 0, 0);
+          if (ks + XD < NKS) xr[ks % XD] = *reinterpret_cast<const bf16x8*>(xb + xo[(ks + XD) & 7] + 256 * ((ks + XD) >> 3));
+        } else {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xb + xo[ks & 7] + 256 * (ks >> 3));
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf, acc, 0, 0, 0);
+        }
+        if constexpr (DMA) {
+          if (ks % (NKS / NQ) == DPH) dma_one(rsX, (int)a.ldx, drow0, a.I - 1, dbuf, ks / (NKS / NQ));
+        }
+        constexpr int STEP = NKS / (4 * NQF);    // k-steps per epilogue element (2 at K = 512; 1 at K = 256 or K-split)
+        static_assert(STEP >= 1 && NKS % (4 * NQF) == 0, "epilogue elements per k-step");
+        if (ks % STEP == STEP - 1) epi_elem(ks / STEP, stg, parked, rbuf);
+        if constexpr (RING) __builtin_amdgcn_sched_barrier(0);   // nothing moves across: the order above IS the schedule
+      }
+    };
+    if (wave < NW / 2 || NW < 8) {
+      if (dma_pend) kloop(std::true_type{}, std::false_type{}); else kloop(std::false_type{}, std::false_type{});
+    } else {
+      if (dma_pend) kloop(std::true_type{}, std::true_type{}); else kloop(std::false_type{}, std::true_type{});
+    }
+    if constexpr (KSPLIT > 1) {
+      if (kh) acc = __builtin_shufflevector(acc, acc, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7);
+      // park the two quads the partner finishes (elements 8 .. 15 after the swap): [wave][8][64] floats, element (4 u + e) of lane l at [(4 u + e)][l];
+      // one buffer, so everyone must be done reading the previous tile's parked halves first
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      float* mine = reinterpret_cast<float*>(sP) + wave * 512 + lane;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mine[(4 * u + e) * 64] = acc[8 + 4 * u + e];
+    }
+    old = acc;
+    acc_start();
+  }
+  // ---- drain: epilogue of the last tile, then the last two stores -------------------------------------------------
+  WS_WAIT_ALL_BUT(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  stamp(12);
+  if (nt >= 2) store_tile(nt - 2, sS + (nt & 1) * SBUF);
+  {
+    char* stg = sS + ((nt + 1) & 1) * SBUF;
+    [[maybe_unused]] const float* parked = reinterpret_cast<const float*>(sP) + (wave ^ NWJ) * 512 + lane;
+    [[maybe_unused]] const char* rbuf = sR + ((nt + 1) & 1) * RBUF;
+#pragma unroll
+    for (int j = 0; j < 4 * NQF; ++j) epi_elem(j, stg, parked, rbuf);
+  }
+  __syncthreads();
+  store_tile(nt - 1, sS + ((nt + 1) & 1) * SBUF);
+  stamp(13);
+  if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + 14] = (unsigned long long)nt;
+}
+
+template <int KW, int KSPLIT, int NWJ, int EPI>
+int launch_ws(const hig_gemm16_desc& g, int slots_per_xcd, hipStream_t st) {
+  constexpr int BN = 32 * NWJ;
+  WsArgs a;
+  a.X = static_cast<const __bf16*>(g.X); a.ldx = g.ldx;
+  a.W = static_cast<const __bf16*>(g.Y); a.ldy = g.ldy;
+  a.C = static_cast<__bf16*>(g.C); a.ldc = g.ldc;
+  a.res = static_cast<const __bf16*>(g.res); a.ldr = g.ldr;
+  a.bias = g.bias;
+  a.I = g.I; a.J = g.J;
+  a.np = g.J / BN;
+  a.g = slots_per_xcd / a.np;
+  a.ntiles = (g.I + 31) / 32;
+  a.stamps = g_ws_stamps;
+  hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, EPI>), dim3(8 * slots_per_xcd), dim3(64 * NWJ * KSPLIT), 0, st, a);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+template <int EPI>
+int launch_ws_sized(const hig_gemm16_desc& g, int nwj, hipStream_t st) {
+  // 4-wave workgroups (128-column panels, 80 KB of LDS): one per CU (32 slots per XCD) or two (64)
+  static const int slots4 = getenv("HIG_BF16_WS_SLOTS") ? atoi(getenv("HIG_BF16_WS_SLOTS")) : 32;   // tuning knob
+  if (g.R == 512) return nwj == 8 ? launch_ws<512, 1, 8, EPI>(g, 32, st) : launch_ws<512, 1, 4, EPI>(g, slots4, st);
+  if (g.R == 256) return nwj == 8 ? launch_ws<256, 1, 8, EPI>(g, 32, st) : launch_ws<256, 1, 4, EPI>(g, slots4, st);
+  if constexpr (EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU) return 1;   // (no LDS left for residual tiles)
+  else return launch_ws<512, 2, 4, EPI>(g, 32, st);   // K = 1024: 8 waves = 4 column slices x 2 halves of the reduce range
+}
+
+}  // namespace
+
+// Returns HIG_OK when the launch was made, 1 when this kernel does not serve the shape (the caller falls back to the
+// tiled kernel), a negative HIG_E* code on error.
+int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
+  static const int ws_on = getenv("HIG_BF16_WS") ? atoi(getenv("HIG_BF16_WS")) : 1;          // tuning knob: 0 = tiled kernel only
+  static const int forced_nwj = getenv("HIG_BF16_WS_NWJ") ? atoi(getenv("HIG_BF16_WS_NWJ")) : 0;   // 4 / 8
+  static const int min_rows = getenv("HIG_BF16_WS_ROWS") ? atoi(getenv("HIG_BF16_WS_ROWS")) : 2048;
+  if (!ws_on) return 1;
+  if (g.c_f32 || (g.res && g.res_f32)) return 1;
+  if (!(g.R == 256 || g.R == 512 || g.R == 1024)) return 1;
+  if (g.I < min_rows) return 1;
+  auto al = [](const void* p, int n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
+  if (!(g.ldc % 8 == 0 && al(g.C, 16))) return 1;
+  if ((int64_t)g.I * g.ldx >= (1ll << 30) || (int64_t)g.J * g.ldy >= (1ll << 30) || (g.res && (int64_t)g.I * g.ldr >= (1ll << 30))) return 1;   // 32-bit byte offsets of the DMA descriptors
+  const bool has_res = g.epi == HIG_EPI_BIAS_RES || g.epi == HIG_EPI_BIAS_RES_SILU;
+  if (has_res && !(g.ldr % 4 == 0 && al(g.res, 8))) return 1;
+  // columns per CU: the weight panel is fetched once per workgroup (cols x K x 2 bytes at the CU's ~30 B/clk), the X
+  // rows once per panel -- the sum is smallest near cols = sqrt(M N / 256)
+  // (measured, tools/gemm16_bench.py: the 8-wave variant wins for the wide bias-only launches -- q/k/v at M = 12 544: 28 us
+  // against 38 -- ; with a GELU or residual epilogue it spills registers at 256 per wave and the 4-wave variant wins)
+  int nwj = 8;
+  if (g.R == 1024) nwj = 4;
+  else if ((int64_t)g.I * g.J < (int64_t)256 * 192 * 192) nwj = 4;
+  else if (!(g.epi == HIG_EPI_NONE || g.epi == HIG_EPI_BIAS)) nwj = 4;
+  if (forced_nwj == 4 || (forced_nwj == 8 && g.R != 1024)) nwj = forced_nwj;
+  if (g.J % (32 * nwj) != 0) {
+    if (g.J % 128 == 0) nwj = 4; else return 1;
+  }
+  if (g.J / (32 * nwj) > 32) return 1;
+  switch (g.epi) {
+    case HIG_EPI_NONE: return launch_ws_sized<HIG_EPI_NONE>(g, nwj, st);
+    case HIG_EPI_BIAS: return launch_ws_sized<HIG_EPI_BIAS>(g, nwj, st);
+    case HIG_EPI_BIAS_GELU: return launch_ws_sized<HIG_EPI_BIAS_GELU>(g, nwj, st);
+    case HIG_EPI_BIAS_RES: return launch_ws_sized<HIG_EPI_BIAS_RES>(g, nwj, st);
+    case HIG_EPI_BIAS_SILU: return launch_ws_sized<HIG_EPI_BIAS_SILU>(g, nwj, st);
+    case HIG_EPI_BIAS_RES_SILU: return launch_ws_sized<HIG_EPI_BIAS_RES_SILU>(g, nwj, st);
+    default: return 1;
+  }
+}
+
+// Diagnostic: thread 0 of every workgroup of the weight-stationary kernel writes s_memtime stamps to buf[block * 16 + k]
+// (k: 0 start, 1 weights / first X tile requested, 2 landed, 3 + t barrier of iteration t (t < 9), 12 drain barrier, 13
+// end, 14 = number of tiles).  buf must hold 16 x 256 x 8 bytes; NULL switches it off.  Never part of a timed run.
+extern "C" int hig_gemm_ws16_debug_stamps(void* buf) {
+  g_ws_stamps = static_cast<unsigned long long*>(buf);
+  return HIG_OK;
+}

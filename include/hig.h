@@ -389,6 +389,12 @@ typedef struct hig_gemm16_desc {
   const void* res; int64_t ldr; int32_t res_f32;
 } hig_gemm16_desc;
 int hig_gemm_bf16(const hig_gemm16_desc* g, hig_stream_t stream);
+/* Diagnostics (tools/gemm16_stamps.py, tools/gemm_ws16_stamps.py): while buf != NULL, thread 0 of every workgroup of the
+ * tiled bf16 kernel (HIG_BF16_DBG & 16; buf[block * 8 + k], block < 4096) / of the weight-stationary kernel
+ * (buf[block * 16 + k], 256 blocks) writes s_memtime stamps of its phases.  This pointer is the library's only mutable
+ * global state besides what hig_shutdown() releases; it is NULL unless a tool sets it, and is never set during a timed run. */
+int hig_gemm_bf16_debug_stamps(void* buf);
+int hig_gemm_ws16_debug_stamps(void* buf);
 /* dst[i] = bf16(src[i]) (round to nearest even): builds the bf16 shadow of the flat fp32 parameter buffer. */
 /* joint_embed + sequence_embedding of the bf16-storage forward (transformer.py:418-419) as its own kernel pair:
  * out[m][:] = bf16( x[m][:F] . W^T + bias + pos[(m % T) - pos_shift] ), x fp32 with F (e.g. 150, 263) features per

@@ -39,7 +39,14 @@ EPIS = {"none": _lib.EPI_NONE, "bias": _lib.EPI_BIAS, "gelu": _lib.EPI_BIAS_GELU
     (2464, 1024, 256, "bias", 0, 0), (70, 264, 32, "gelu", 0, 0), (12544, 512, 512, "res", 0, 0),
     # large enough for the 256 x 256 tiles (8 waves, one workgroup per CU), incl. ragged edges in both directions
     (12544, 1024, 512, "gelu", 0, 0), (12544, 1536, 512, "bias", 0, 0), (12500, 1000, 512, "res", 0, 0),
-    (9600, 1024, 1024, "res_silu", 1, 1)])
+    (9600, 1024, 1024, "res_silu", 1, 1),
+    # the weight-stationary kernel (gemm_ws16.hip: >= 2048 rows, K in {256, 512, 1024}, N % 128 == 0, bf16 out): every
+    # epilogue, both panel widths (N % 256 != 0 forces 128-column panels), the K-split variant, ragged row counts, row
+    # counts that leave some workgroups of an XCD without a tile
+    (6272, 512, 1024, "bias", 0, 0), (9600, 1024, 1024, "res", 0, 0), (4000, 3072, 1024, "gelu", 0, 0),
+    (6250, 512, 512, "res", 0, 0), (2049, 256, 256, "gelu", 0, 0), (3001, 384, 512, "res_silu", 0, 0),
+    (2100, 1536, 512, "silu", 0, 0), (12544, 512, 512, "none", 0, 0), (2464, 1024, 256, "res", 0, 0),
+    (6272, 1024, 512, "gelu", 0, 0), (2177, 640, 1024, "res", 0, 0)])
 def test_gemm_bf16_all_epilogues_and_ragged_shapes(I, J, R, epi, c_f32, res_f32):
     g = torch.Generator().manual_seed(I * 7 + J * 3 + R)
     X, Y = bf(torch.randn(I, R, generator=g)), bf(torch.randn(J, R, generator=g) / R ** 0.5)
@@ -55,6 +62,13 @@ def test_gemm_bf16_all_epilogues_and_ragged_shapes(I, J, R, epi, c_f32, res_f32)
     if "res" in epi:
         d.res, d.ldr, d.res_f32 = rd.data_ptr(), J, res_f32
     _lib.check(_lib.lib().hig_gemm_bf16(C.byref(d), _lib.stream_ptr()))
+    if "res" in epi and not c_f32 and not res_f32:
+        # the residual stream is updated IN PLACE by the stylization-out GEMMs (C aliases res)
+        inplace = rd.clone()
+        d.C, d.res = inplace.data_ptr(), inplace.data_ptr()
+        _lib.check(_lib.lib().hig_gemm_bf16(C.byref(d), _lib.stream_ptr()))
+        assert torch.equal(inplace, out)
+        d.C, d.res = out.data_ptr(), rd.data_ptr()
     ref = X.double() @ Y.double().t()
     if epi != "none":
         ref = ref + bias.double()

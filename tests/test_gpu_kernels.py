@@ -133,6 +133,21 @@ def test_gemm_split_tail(I, J, R, epi):
     assert int(ws[:1024].max()) == 0                      # every ticket counter is back to zero
     for _ in range(3):
         assert torch.equal(gemm(Xg, Yg, I, J, R, tail_ws=ws, **kw), a)
+    # Stale parked sums must never be read: alternate between two DIFFERENT operand sets on the same scratch, with the
+    # parked-sum area poisoned (NaN bytes) before every launch.  A ticket counted before another wave's partial sums
+    # have landed would make the last arriver add poison (or the other operand set's sums) into the tile.
+    X2g, Y2g = rnd(I, R, seed=11).to(DEV), rnd(J, R, seed=12).to(DEV)
+    a2 = None
+    for it in range(12):
+        ws[1024:] = 0xFF
+        if it % 2 == 0:
+            assert torch.equal(gemm(Xg, Yg, I, J, R, tail_ws=ws, **kw), a)
+        else:
+            o2 = gemm(X2g, Y2g, I, J, R, tail_ws=ws, **kw)
+            assert torch.isfinite(o2).all()
+            a2 = o2 if a2 is None else a2
+            assert torch.equal(o2, a2)
+    assert int(ws[:1024].max()) == 0
     tiles = ((I + 63) // 64) * ((J + 63) // 64)
     main_rows = (tiles - tiles % 256) // ((J + 63) // 64) * 64 if tiles > 256 else I
     assert torch.equal(a[:main_rows], plain[:main_rows])   # whole rounds: untouched by the split

@@ -12,12 +12,12 @@ from hig_amd import _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 M = B * 196
 SHAPES = [("qkv", M, 1536, 512, _lib.EPI_BIAS), ("sty_out", M, 512, 512, _lib.EPI_BIAS_RES),
-          ("ffn1", M, 1024, 512, _lib.EPI_BIAS_GELU), ("ffn2", M, 512, 1024, _lib.EPI_BIAS),
+          ("ffn1", M, 1024, 512, _lib.EPI_BIAS_GELU), ("ffn2", M, 512, 1024, _lib.EPI_BIAS), ("ca_q", M, 512, 512, _lib.EPI_BIAS),
           ("text_kv", B * 77, 1024, 256, _lib.EPI_BIAS), ("emb_ss", B, 24576, 2048, _lib.EPI_BIAS),
           ("te2", B, 2048, 2048, _lib.EPI_BIAS_SILU)]
 L = _lib.lib()
 dev = "cuda"
-tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("HIG_BF16_TILE", "HIG_BF16_PERCU", "HIG_BF16_THR") if k in os.environ)
+tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("HIG_BF16_TILE", "HIG_BF16_PERCU", "HIG_BF16_THR", "HIG_BF16_WS", "HIG_BF16_WS_NWJ", "HIG_BF16_WS_SLOTS") if k in os.environ)
 for name, I, J, R, epi in SHAPES:
     per = (I * R + I * J * 2) * 2
     nb = max(2, min(16, int(600e6 // per) + 1))
