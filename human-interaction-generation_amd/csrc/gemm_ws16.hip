@@ -56,12 +56,15 @@ __device__ __forceinline__ void ws_wait_vmcnt_visible() {
   asm volatile("" ::: "memory");
 }
 
-// KW: reduce elements per wave; KSPLIT: wave pairs splitting K = KW * KSPLIT; NWJ: 32-column slices per workgroup.
-template <int KW, int KSPLIT, int NWJ, int EPI>
+// KW: reduce elements per wave; KSPLIT: wave pairs splitting K = KW * KSPLIT; NWJ: column slices per workgroup, each
+// NCB blocks of 32 columns wide (NCB = 2: a wave holds 64 columns x KW = 256 registers of weights -- one wave per SIMD,
+// 512 registers each -- and every X fragment it reads from LDS feeds two MFMAs).
+template <int KW, int KSPLIT, int NWJ, int NCB, int EPI, int DBG = 0>
 __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) void gemm_ws16_kernel(const WsArgs a) {
   constexpr int NW = NWJ * KSPLIT, NT = 64 * NW;
   constexpr int K = KW * KSPLIT;
-  constexpr int BM = 32, BN = 32 * NWJ;
+  constexpr int BM = 32, BN = 32 * NWJ * NCB;
+  static_assert(NCB == 1 || KSPLIT == 1, "wide slices: single-split variants only");
   constexpr int NKS = KW / 16;                 // MFMA k-steps per wave and tile
   constexpr int ROWB = K * 2;                  // bytes per X row in LDS
   constexpr int XBUF = BM * ROWB;
@@ -78,6 +81,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) voi
   // and the k-loop's order is pinned; 8-wave workgroups (256 registers per wave: the ring spills) leave the k-loop to hipcc
   constexpr bool RING = NW < 8;
   constexpr int XD = 4;
+  constexpr int GK = 4;                        // k-steps per scheduling group
   // X ring: three tiles where LDS allows (a tile requested in iteration t is waited for at the top of iteration t + 2:
   // one tile in flight across every barrier); two at K = 1024 (64 KB tiles)
   constexpr int RBUF = HAS_RES ? SBUF : 0;     // residual tiles come in by DMA too (two buffers, staged-tile sized)
@@ -125,14 +129,18 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) voi
   // bias of the columns this lane finishes: slot u, element e is column 32 wj + 8 (qf0 + u) + 4 lh + e.  Requested
   // FIRST: the (compiler-visible) wait of the first weight round retires these loads, so that hipcc never guards their
   // use with a vmcnt(0) of its own further down, where it would drain the X ring.
-  float bq[BIAS_LDS ? 1 : 4 * NQF];
+  float bq[BIAS_LDS ? 1 : NCB * 4 * NQF];
   if constexpr (BIAS_LDS) {
+    static_assert(BN <= NT, "one thread per bias column");
     if (tid < BN) sB[tid] = (EPI != HIG_EPI_NONE) ? a.bias[j0 + tid] : 0.f;    // (published by the barriers of the weight rounds)
   } else {
 #pragma unroll
-    for (int u = 0; u < NQF; ++u)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bq[4 * u + e] = (EPI != HIG_EPI_NONE) ? a.bias[j0 + 32 * wj + 8 * (qf0 + u) + 4 * lh + e] : 0.f;
+      for (int u = 0; u < NQF; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          bq[(cb * NQF + u) * 4 + e] = (EPI != HIG_EPI_NONE) ? a.bias[j0 + 32 * (NCB * wj + cb) + 8 * (qf0 + u) + 4 * lh + e] : 0.f;
   }
 
   // raw (stride 0) buffer descriptors over the whole operands; rows are clamped, so nothing is out of range
@@ -180,73 +188,81 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) voi
   // rounds in flight), then read as fragments by the wave(s) that own the slice.  Loading the fragments straight from
   // global memory (32 rows x 32 bytes per instruction) took 8.3K cycles to ISSUE and 11K more to land at M = 12 544
   // (tools/gemm_ws16_stamps.py): the address path handles such a fragment-shaped load one 128-byte line at a time.
-  bf16x8 wf[NKS];
+  bf16x8 wf[NCB][NKS];
   constexpr int NWB = NXB;                                   // X-tile-sized buffers the rounds use
-  constexpr int RLAST0 = ((NWJ - 1) / NWB) * NWB;            // last round that uses buffer 0: the first X tile goes there afterwards
+  constexpr int NR = NWJ * NCB;                              // rounds: one per block of 32 columns
+  constexpr int RLAST0 = ((NR - 1) / NWB) * NWB;             // last round that uses buffer 0: the first X tile goes there afterwards
 #pragma unroll
-  for (int r = 0; r < NWB && r < NWJ; ++r) dma_rows(rsW, (int)a.ldy, j0 + 32 * r, a.J - 1, r);
+  for (int r = 0; r < NWB && r < NR; ++r) dma_rows(rsW, (int)a.ldy, j0 + 32 * r, a.J - 1, r);
 #pragma unroll
-  for (int r = 0; r < NWJ; ++r) {
+  for (int r = 0; r < NR; ++r) {
     // round r has landed once only the younger requests are outstanding: the rounds behind it, the first X tile
-    const int younger = (NWB - 1 < NWJ - 1 - r ? NWB - 1 : NWJ - 1 - r) + (r > RLAST0 ? 1 : 0);
+    const int younger = (NWB - 1 < NR - 1 - r ? NWB - 1 : NR - 1 - r) + (r > RLAST0 ? 1 : 0);
     if (younger == 0) ws_wait_vmcnt_visible<0>();
     else if (younger == 1) ws_wait_vmcnt_visible<NQ>();
     else if (younger == 2) ws_wait_vmcnt_visible<2 * NQ>();
     else ws_wait_vmcnt_visible<3 * NQ>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (wj == r) {
+    if (wj == r / NCB) {
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks)
-        wf[ks] = *reinterpret_cast<const bf16x8*>(sX + (r % NWB) * XBUF + xo[ks & 7] + 256 * (ks >> 3));
+        wf[r % NCB][ks] = *reinterpret_cast<const bf16x8*>(sX + (r % NWB) * XBUF + xo[ks & 7] + 256 * (ks >> 3));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();               // the buffer may be overwritten
     asm volatile("" ::: "memory");
-    if (r + NWB < NWJ) dma_rows(rsW, (int)a.ldy, j0 + 32 * (r + NWB), a.J - 1, r % NWB);
+    if (r + NWB < NR) dma_rows(rsW, (int)a.ldy, j0 + 32 * (r + NWB), a.J - 1, r % NWB);
     if (r == RLAST0) dma_tile(0, 0);
   }
   stamp(1);
 
   // a tile's accumulators START at the bias of the columns this wave finishes (K split: the half it parks starts at 0;
   // a kh = 1 wave finishes elements 8 .. 15, which it swaps to the front when the k-loop ends)
-  f32x16 acc, old;
+  f32x16 acc[NCB], old[NCB];
   auto acc_start = [&]() {
     if constexpr (BIAS_LDS) {
       static_assert(!BIAS_LDS || KSPLIT == 1, "bias in LDS: single-split variants only");
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sB + 32 * wj + 8 * q + 4 * lh);
-        acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
-      }
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(sB + 32 * (NCB * wj + cb) + 8 * q + 4 * lh);
+          acc[cb][4 * q] = b4.x; acc[cb][4 * q + 1] = b4.y; acc[cb][4 * q + 2] = b4.z; acc[cb][4 * q + 3] = b4.w;
+        }
     } else if constexpr (KSPLIT > 1) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { acc[j] = kh ? 0.f : bq[j]; acc[8 + j] = kh ? bq[j] : 0.f; }
+      for (int j = 0; j < 8; ++j) { acc[0][j] = kh ? 0.f : bq[j]; acc[0][8 + j] = kh ? bq[j] : 0.f; }
     } else {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] = bq[j];
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[cb][j] = bq[cb * 16 + j];
     }
   };
   acc_start();
 #pragma unroll
-  for (int e = 0; e < 16; ++e) old[e] = 0.f;
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) old[cb][e] = 0.f;
 
   // The epilogue of the tile whose accumulators sit in `old`, one ELEMENT at a time (element j = 4 u + e of this
   // wave's finished quads): the k-loop calls epi_elem(j) between its MFMAs so that the vector work is spread evenly.
   float ev[4];
   u32x2 rq = u32x2{0u, 0u};                    // residual of the quad in work: four bf16, raw bits
   auto epi_elem = [&](int j, char* stg, [[maybe_unused]] const float* parked, [[maybe_unused]] const char* rbuf) {
-    const int u = j >> 2, e = j & 3;
-    float v = old[j];
-    if constexpr (KSPLIT > 1) v += parked[j * 64];
+    const int cb = j / (4 * NQF), jj = j % (4 * NQF);
+    const int u = jj >> 2, e = jj & 3;
+    float v = old[cb][jj];
+    if constexpr (KSPLIT > 1) v += parked[jj * 64];
     if constexpr (HAS_RES) {
-      if (e == 0) rq = *reinterpret_cast<const u32x2*>(rbuf + lr * SROWB + 16 * ((4 * wj + qf0 + u) ^ (lr & 15)) + 8 * lh);
+      if (e == 0) rq = *reinterpret_cast<const u32x2*>(rbuf + lr * SROWB + 16 * ((4 * (NCB * wj + cb) + qf0 + u) ^ (lr & 15)) + 8 * lh);
       const unsigned w = e < 2 ? rq.x : rq.y;
       v += __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));
     }
-    ev[e] = epi_act<EPI>(v);
+    ev[e] = (DBG & 2) ? v : epi_act<EPI>(v);
     if (e == 3) {
-      const int pos16 = (4 * wj + qf0 + u) ^ (lr & 15);
+      const int pos16 = (4 * (NCB * wj + cb) + qf0 + u) ^ (lr & 15);
       *reinterpret_cast<bf16x4*>(stg + lr * SROWB + 16 * pos16 + 8 * lh) =
           bf16x4{(__bf16)ev[0], (__bf16)ev[1], (__bf16)ev[2], (__bf16)ev[3]};
     }
@@ -332,19 +348,40 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) voi
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         if constexpr (RING) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xr[ks % XD], acc, 0, 0, 0);
-          if (ks + XD < NKS) xr[ks % XD] = *reinterpret_cast<const bf16x8*>(xb + xo[(ks + XD) & 7] + 256 * ((ks + XD) >> 3));
+          // (DBG: timing ablations of the diagnostic instances -- results are wrong by construction.  1 = no MFMA,
+          // 2 = no epilogue arithmetic, 4 = no LDS reads of X fragments, 8 = no DMA inside the k-loop)
+          if constexpr (!(DBG & 1)) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][ks], xr[ks % XD], acc[cb], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) asm volatile("" : "+v"(acc[cb]) : "v"(wf[cb][ks]), "v"(xr[ks % XD]));
+          }
+          if constexpr (!(DBG & 4)) {
+            if (ks + XD < NKS) xr[ks % XD] = *reinterpret_cast<const bf16x8*>(xb + xo[(ks + XD) & 7] + 256 * ((ks + XD) >> 3));
+          }
         } else {
           const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xb + xo[ks & 7] + 256 * (ks >> 3));
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf, acc, 0, 0, 0);
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][ks], xf, acc[cb], 0, 0, 0);
         }
-        if constexpr (DMA) {
+        if constexpr (DMA && !(DBG & 8)) {
           if (ks % (NKS / NQ) == DPH) dma_one(rsX, (int)a.ldx, drow0, a.I - 1, dbuf, ks / (NKS / NQ));
         }
-        constexpr int STEP = NKS / (4 * NQF);    // k-steps per epilogue element (2 at K = 512; 1 at K = 256 or K-split)
-        static_assert(STEP >= 1 && NKS % (4 * NQF) == 0, "epilogue elements per k-step");
-        if (ks % STEP == STEP - 1) epi_elem(ks / STEP, stg, parked, rbuf);
-        if constexpr (RING) __builtin_amdgcn_sched_barrier(0);   // nothing moves across: the order above IS the schedule
+        constexpr int NEL = 4 * NQF * NCB;       // epilogue elements per tile and lane, spread over the NKS k-steps
+        if constexpr (NEL >= NKS) {
+          static_assert(NEL % NKS == 0 || NEL < NKS, "epilogue elements per k-step");
+#pragma unroll
+          for (int i = 0; i < NEL / NKS; ++i) epi_elem(ks * (NEL / NKS) + i, stg, parked, rbuf);
+        } else {
+          constexpr int STEP = NKS / NEL;
+          static_assert(NKS % NEL == 0, "k-steps per epilogue element");
+          if (ks % STEP == STEP - 1) epi_elem(ks / STEP, stg, parked, rbuf);
+        }
+        // nothing moves across the end of a group of GK k-steps; inside a group hipcc interleaves the MFMAs with the
+        // group's epilogue elements (several independent chains: one element alone is a chain of ~14 dependent vector
+        // instructions at ~8 cycles each, 4 900 cycles per tile when the elements came one by one)
+        if constexpr (RING) { if (ks % GK == GK - 1) __builtin_amdgcn_sched_barrier(0); }
       }
     };
     if (wave < NW / 2 || NW < 8) {
@@ -353,7 +390,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) voi
       if (dma_pend) kloop(std::true_type{}, std::true_type{}); else kloop(std::false_type{}, std::true_type{});
     }
     if constexpr (KSPLIT > 1) {
-      if (kh) acc = __builtin_shufflevector(acc, acc, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7);
+      if (kh) acc[0] = __builtin_shufflevector(acc[0], acc[0], 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7);
       // park the two quads the partner finishes (elements 8 .. 15 after the swap): [wave][8][64] floats, element (4 u + e) of lane l at [(4 u + e)][l];
       // one buffer, so everyone must be done reading the previous tile's parked halves first
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -363,9 +400,10 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) voi
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) mine[(4 * u + e) * 64] = acc[8 + 4 * u + e];
+        for (int e = 0; e < 4; ++e) mine[(4 * u + e) * 64] = acc[0][8 + 4 * u + e];
     }
-    old = acc;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) old[cb] = acc[cb];
     acc_start();
   }
   // ---- drain: epilogue of the last tile, then the last two stores -------------------------------------------------
@@ -380,7 +418,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) voi
     [[maybe_unused]] const float* parked = reinterpret_cast<const float*>(sP) + (wave ^ NWJ) * 512 + lane;
     [[maybe_unused]] const char* rbuf = sR + ((nt + 1) & 1) * RBUF;
 #pragma unroll
-    for (int j = 0; j < 4 * NQF; ++j) epi_elem(j, stg, parked, rbuf);
+    for (int j = 0; j < 4 * NQF * NCB; ++j) epi_elem(j, stg, parked, rbuf);
   }
   __syncthreads();
   store_tile(nt - 1, sS + ((nt + 1) & 1) * SBUF);
@@ -388,9 +426,9 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) voi
   if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + 14] = (unsigned long long)nt;
 }
 
-template <int KW, int KSPLIT, int NWJ, int EPI>
+template <int KW, int KSPLIT, int NWJ, int NCB, int EPI>
 int launch_ws(const hig_gemm16_desc& g, int slots_per_xcd, hipStream_t st) {
-  constexpr int BN = 32 * NWJ;
+  constexpr int BN = 32 * NWJ * NCB;
   WsArgs a;
   a.X = static_cast<const __bf16*>(g.X); a.ldx = g.ldx;
   a.W = static_cast<const __bf16*>(g.Y); a.ldy = g.ldy;
@@ -402,7 +440,21 @@ int launch_ws(const hig_gemm16_desc& g, int slots_per_xcd, hipStream_t st) {
   a.g = slots_per_xcd / a.np;
   a.ntiles = (g.I + 31) / 32;
   a.stamps = g_ws_stamps;
-  hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, EPI>), dim3(8 * slots_per_xcd), dim3(64 * NWJ * KSPLIT), 0, st, a);
+  static const int dbg = getenv("HIG_BF16_WS_DBG") ? atoi(getenv("HIG_BF16_WS_DBG")) : 0;   // timing ablations (diagnostic instances only)
+  if constexpr (KW == 512 && KSPLIT == 1 && NWJ == 4 && NCB == 2 && EPI == HIG_EPI_BIAS_GELU) {
+    const dim3 gr(8 * slots_per_xcd), bl(64 * NWJ * KSPLIT);
+    switch (dbg) {
+      case 1: hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 1>), gr, bl, 0, st, a); HIG_CHECK_LAUNCH(); return HIG_OK;
+      case 2: hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 2>), gr, bl, 0, st, a); HIG_CHECK_LAUNCH(); return HIG_OK;
+      case 4: hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 4>), gr, bl, 0, st, a); HIG_CHECK_LAUNCH(); return HIG_OK;
+      case 8: hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 8>), gr, bl, 0, st, a); HIG_CHECK_LAUNCH(); return HIG_OK;
+      case 3: hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 3>), gr, bl, 0, st, a); HIG_CHECK_LAUNCH(); return HIG_OK;
+      case 14: hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 14>), gr, bl, 0, st, a); HIG_CHECK_LAUNCH(); return HIG_OK;
+      case 15: hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 15>), gr, bl, 0, st, a); HIG_CHECK_LAUNCH(); return HIG_OK;
+      default: break;
+    }
+  }
+  hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI>), dim3(8 * slots_per_xcd), dim3(64 * NWJ * KSPLIT), 0, st, a);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
@@ -411,10 +463,11 @@ template <int EPI>
 int launch_ws_sized(const hig_gemm16_desc& g, int nwj, hipStream_t st) {
   // 4-wave workgroups (128-column panels, 80 KB of LDS): one per CU (32 slots per XCD) or two (64)
   static const int slots4 = getenv("HIG_BF16_WS_SLOTS") ? atoi(getenv("HIG_BF16_WS_SLOTS")) : 32;   // tuning knob
-  if (g.R == 512) return nwj == 8 ? launch_ws<512, 1, 8, EPI>(g, 32, st) : launch_ws<512, 1, 4, EPI>(g, slots4, st);
-  if (g.R == 256) return nwj == 8 ? launch_ws<256, 1, 8, EPI>(g, 32, st) : launch_ws<256, 1, 4, EPI>(g, slots4, st);
+  // nwj: 8 = eight waves x 32 columns, 4 = four waves x 32 columns, 2 = four waves x 64 columns (256-column panels)
+  if (g.R == 512) return nwj == 8 ? launch_ws<512, 1, 8, 1, EPI>(g, 32, st) : nwj == 2 ? launch_ws<512, 1, 4, 2, EPI>(g, 32, st) : launch_ws<512, 1, 4, 1, EPI>(g, slots4, st);
+  if (g.R == 256) return nwj == 8 ? launch_ws<256, 1, 8, 1, EPI>(g, 32, st) : launch_ws<256, 1, 4, 1, EPI>(g, slots4, st);
   if constexpr (EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU) return 1;   // (no LDS left for residual tiles)
-  else return launch_ws<512, 2, 4, EPI>(g, 32, st);   // K = 1024: 8 waves = 4 column slices x 2 halves of the reduce range
+  else return launch_ws<512, 2, 4, 1, EPI>(g, 32, st);   // K = 1024: 8 waves = 4 column slices x 2 halves of the reduce range
 }
 
 }  // namespace
@@ -442,11 +495,12 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
   if (g.R == 1024) nwj = 4;
   else if ((int64_t)g.I * g.J < (int64_t)256 * 192 * 192) nwj = 4;
   else if (!(g.epi == HIG_EPI_NONE || g.epi == HIG_EPI_BIAS)) nwj = 4;
-  if (forced_nwj == 4 || (forced_nwj == 8 && g.R != 1024)) nwj = forced_nwj;
-  if (g.J % (32 * nwj) != 0) {
+  if (forced_nwj == 4 || (forced_nwj == 8 && g.R != 1024) || (forced_nwj == 2 && g.R == 512)) nwj = forced_nwj;
+  const int bn = nwj == 4 ? 128 : 256;
+  if (g.J % bn != 0) {
     if (g.J % 128 == 0) nwj = 4; else return 1;
   }
-  if (g.J / (32 * nwj) > 32) return 1;
+  if (g.J / (nwj == 4 ? 128 : 256) > 32) return 1;
   switch (g.epi) {
     case HIG_EPI_NONE: return launch_ws_sized<HIG_EPI_NONE>(g, nwj, st);
     case HIG_EPI_BIAS: return launch_ws_sized<HIG_EPI_BIAS>(g, nwj, st);

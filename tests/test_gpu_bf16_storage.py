@@ -3,6 +3,8 @@ Kernel-level checks are against fp64 references evaluated on the SAME bf16-round
 order and the final rounding differ); the whole model is held to the fp32 CPU oracle with the error REPORTED and
 bounded at the bf16 level (expect ~1e-2, not gated at 1e-3)."""
 import ctypes as C
+import os
+import sys
 import types
 
 import pytest
@@ -17,6 +19,7 @@ from oracle import denoiser_ref as R  # noqa: E402
 from oracle import fill  # noqa: E402
 
 DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def rel(a, b):
@@ -84,6 +87,44 @@ def test_gemm_bf16_all_epilogues_and_ragged_shapes(I, J, R, epi, c_f32, res_f32)
     if not c_f32:   # the bf16 result must be the correctly rounded fp32 value almost everywhere
         exact = bf(ref.float()).float()
         assert (out.float().cpu() != exact).float().mean().item() < 0.02
+
+
+@pytest.mark.parametrize("nwj", ["2", "4", "8"])
+@pytest.mark.parametrize("I,J,R,epi", [(6272, 512, 512, "res"), (12544, 1024, 512, "gelu"), (3001, 768, 512, "bias"),
+                                       (2049, 256, 256, "silu"), (7000, 1536, 512, "none")])
+def test_gemm_ws16_every_variant(I, J, R, epi, nwj, monkeypatch):
+    """The three shapes of the weight-stationary kernel (HIG_BF16_WS_NWJ: 8 waves x 32 columns, 4 x 32, 4 x 64), each
+    forced on shapes the default rule would give to another one.  The knob is read once per process, so the forced
+    runs happen in a child process."""
+    import subprocess
+    code = (
+        "import sys, torch, ctypes as C; sys.path.insert(0, %r); from hig_amd import _lib\n"
+        "I, J, R, epi = %d, %d, %d, %r\n"
+        "g = torch.Generator().manual_seed(I + J + R)\n"
+        "X = torch.randn(I, R, generator=g).to(torch.bfloat16); Y = (torch.randn(J, R, generator=g) / R ** 0.5).to(torch.bfloat16)\n"
+        "b = torch.randn(J, generator=g); r = torch.randn(I, J, generator=g).to(torch.bfloat16)\n"
+        "Xd, Yd, bd, rd = X.cuda(), Y.cuda(), b.cuda(), r.cuda()\n"
+        "out = torch.full((I, J), float('nan'), device='cuda', dtype=torch.bfloat16)\n"
+        "d = _lib.Gemm16Desc()\n"
+        "d.X, d.ldx, d.Y, d.ldy, d.C, d.ldc, d.c_f32 = Xd.data_ptr(), R, Yd.data_ptr(), R, out.data_ptr(), J, 0\n"
+        "d.I, d.J, d.R = I, J, R\n"
+        "d.epi = {'none': _lib.EPI_NONE, 'bias': _lib.EPI_BIAS, 'gelu': _lib.EPI_BIAS_GELU, 'res': _lib.EPI_BIAS_RES, 'silu': _lib.EPI_BIAS_SILU}[epi]\n"
+        "d.bias = bd.data_ptr() if epi != 'none' else None\n"
+        "if epi == 'res': d.res, d.ldr, d.res_f32 = rd.data_ptr(), J, 0\n"
+        "for _ in range(3): _lib.check(_lib.lib().hig_gemm_bf16(C.byref(d), _lib.stream_ptr()))\n"
+        "ref = X.double() @ Y.double().t()\n"
+        "if epi != 'none': ref = ref + b.double()\n"
+        "if epi == 'res': ref = ref + r.double()\n"
+        "if epi == 'gelu': ref = torch.nn.functional.gelu(ref)\n"
+        "if epi == 'silu': ref = torch.nn.functional.silu(ref)\n"
+        "o = out.float().cpu().double()\n"
+        "assert torch.isfinite(o).all()\n"
+        "e = ((o - ref).norm() / ref.norm()).item(); assert e < 3e-3, e\n"
+        "assert (out.float().cpu() != ref.float().to(torch.bfloat16).float()).float().mean().item() < 0.02\n"
+        "print('ok', e)\n" % (ROOT, I, J, R, epi))
+    env = dict(os.environ, HIG_BF16_WS_NWJ=nwj)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_gemm_bf16_rejects_what_it_cannot_run():
