@@ -11,8 +11,26 @@ exchange is a single all-reduce of ~324 MB per step; the 1/world scale is folded
 clip+Adam kernel.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): one large message lets
 RCCL use every link at once; 25 MB DDP buckets would be latency-bound per link.
 """
+import os
+import socket
+
 import torch
 import torch.distributed as dist
+
+
+def exchange_forced():
+    """HIG_FORCE_EXCHANGE=1: issue the gradient all-reduces even in a group of ONE rank (where they are the identity).
+    Lets a single GPU exercise the real RCCL path -- the collectives on the side stream, their ordering against the
+    backward's two streams, the graph-A / all-reduce / graph-B split of the captured step -- without a second device
+    (tests/test_gpu_rccl.py)."""
+    return os.environ.get("HIG_FORCE_EXCHANGE", "0") == "1"
+
+
+def exchange_active(group=None):
+    """True when the training step has a gradient exchange to run: more than one rank, or one rank with the switch."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or exchange_forced()
 
 
 class FlatGradAllReduce:
@@ -26,7 +44,7 @@ class FlatGradAllReduce:
         if not (dist.is_available() and dist.is_initialized()):
             return 1
         world = dist.get_world_size(self.group)
-        if world > 1:
+        if world > 1 or exchange_forced():
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         return world
 
@@ -51,7 +69,7 @@ class OverlappedGradAllReduce:
 
     @staticmethod
     def active(group=None):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        return exchange_active(group)
 
     def begin(self, flat_grad, per_layer, tail):
         if self.stream is None or self.stream.device != flat_grad.device:
@@ -121,3 +139,60 @@ def broadcast_flat(buf, src=0, group=None):
     """One broadcast of a flat device buffer (all parameters of the fused step, or its Adam moments)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(buf, src=src, group=group)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _launch_entry(local_rank, fn, world_size, backend, args, kwargs, port, set_device):
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the hosts only support dmabuf IPC
+    run_distributed(fn, local_rank, world_size, backend, *args, set_device=set_device, **kwargs)
+
+
+def run_distributed(fn, rank, world_size, backend=None, *args, set_device=True, **kwargs):
+    """One rank of a data-parallel job: `setup` + `ddp_train` of the reference launcher (tools/train.py:53-90) around
+    `fn(rank, world_size, *args, **kwargs)`.  Rendezvous from MASTER_ADDR / MASTER_PORT (torchrun's variables work
+    unchanged); backend "nccl" (= RCCL over xGMI) when a GPU is present, else "gloo" (the reference's choice,
+    tools/train.py:55) -- HIG_DIST_BACKEND overrides.  One process per GPU: rank r uses device r % device_count.
+    Barrier before `fn`, like the reference after creating its output directories; the group is destroyed afterwards,
+    also when `fn` raises."""
+    have_gpu = torch.cuda.device_count() > 0
+    backend = backend or os.environ.get("HIG_DIST_BACKEND") or ("nccl" if have_gpu else "gloo")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    kw = {}
+    if have_gpu and set_device:
+        dev = torch.device("cuda", rank % torch.cuda.device_count())
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            kw["device_id"] = dev
+    dist.init_process_group(backend, rank=rank, world_size=world_size, **kw)
+    try:
+        if world_size > 1:
+            dist.barrier()
+        return fn(rank, world_size, *args, **kwargs)
+    finally:
+        dist.destroy_process_group()
+
+
+def launch(fn, world_size=None, backend=None, args=(), kwargs=None, port=None, set_device=True):
+    """`main` of the reference launcher (tools/train.py:92-102): one process per GPU of this node running
+    `fn(rank, world_size, *args)` inside an initialised process group.  Under torchrun (RANK / WORLD_SIZE in the
+    environment) the processes already exist: this one just joins as its rank.  Otherwise `world_size` processes
+    (default: one per visible GPU, at least one) are spawned, rendezvous on 127.0.0.1 at a free port.  The parent never
+    touches the GPU."""
+    kwargs = kwargs or {}
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        return run_distributed(fn, int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), backend, *args,
+                               set_device=set_device, **kwargs)
+    world_size = world_size or max(1, torch.cuda.device_count())
+    port = port or _free_port()
+    import torch.multiprocessing as mp
+    mp.spawn(_launch_entry, args=(fn, world_size, backend, args, kwargs, port, set_device), nprocs=world_size, join=True)

@@ -26,7 +26,8 @@ from torch.nn.utils import clip_grad_norm_
 from .. import _lib
 from ..models.gaussian_diffusion import (GaussianDiffusion, LossType, ModelMeanType, ModelVarType,
                                          create_named_schedule_sampler, get_named_beta_schedule)
-from ..parallel import FlatGradAllReduce, OverlappedGradAllReduce, ShardedSampler, broadcast_flat
+from ..parallel import (FlatGradAllReduce, OverlappedGradAllReduce, ShardedSampler, broadcast_flat, broadcast_parameters,
+                        exchange_active)
 
 GRAD_CLIP = 0.5                    # ddpm_trainer.py:61
 ADAM_BETAS, ADAM_EPS = (0.9, 0.999), 1e-8   # torch.optim.Adam defaults, ddpm_trainer.py:222
@@ -42,19 +43,23 @@ def _dist_world():
 
 
 class _RunningMean:
-    """Sums per-key values (host floats or device scalars -- the latter without any host sync) and hands back
-    their means every `period` additions."""
+    """Sums per-key values (host floats or device scalars -- the latter without any host sync) and hands back their
+    means when the ITERATION COUNT is a multiple of `period` -- the reference prints at `it % log_every == 0`
+    (ddpm_trainer.py:247-256), which after a resume from a checkpoint is not every `period` additions.  Only a rank
+    that prints (`read=True`) reads the device scalars back; the others just drop the sums."""
 
     def __init__(self, period):
         self.period, self.n, self.acc = int(period), 0, OrderedDict()
 
-    def add(self, values):
+    def add(self, values, it=None, read=True):
         for k, v in values.items():
             self.acc[k] = self.acc[k] + v if k in self.acc else (v.clone() if torch.is_tensor(v) else v)
         self.n += 1
-        if self.n < self.period:
+        due = (it % self.period == 0) if it is not None else (self.n >= self.period)
+        if not due:
             return None
-        out = OrderedDict((k, float(v) / self.n) for k, v in self.acc.items())
+        div = self.period if it is not None else self.n      # (the reference divides by log_every whatever it summed)
+        out = OrderedDict((k, float(v) / div) for k, v in self.acc.items()) if read else None
         self.n, self.acc = 0, OrderedDict()
         return out
 
@@ -132,10 +137,30 @@ class DDPMTrainer(object):
         self.zero_grad([self.opt_encoder])
         logs = self.backward_G()
         self.loss_mot_rec.backward()
+        self._exchange_param_grads()
         self.clip_norm([self.encoder])
         self.step([self.opt_encoder])
         _core(self.encoder).params_changed()
         return logs
+
+    def _exchange_param_grads(self):
+        """The reference ALWAYS trains through a DDP wrapper when world > 1 (tools/train.py:77-82), whose reducer
+        averages the gradients during backward().  When this trainer is handed a bare model in a multi-rank group,
+        the same averaging happens here (one all-reduce of the flat gradient buffer + one per parameter outside it)
+        instead of silently stepping every rank on its own gradient.  A wrapped model (`.module`) already did it."""
+        world = _dist_world()
+        if world == 1 or hasattr(self.encoder, "module"):
+            return
+        # (under autograd the parameter gradients are tensors of their own -- _DenoiserFn.backward hands out copies of
+        # the flat buffer's views -- so they are packed into one message here, like one DDP bucket)
+        grads = [p.grad for p in self.encoder.parameters() if p.grad is not None]
+        if not grads:
+            return
+        flat = torch._utils._flatten_dense_tensors(grads)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / world)
+        for g, r in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+            g.copy_(r)
 
     # ---- sampling ----------------------------------------------------------------------------------------------
     def generate_batch(self, caption, m_lens, dim_pose):
@@ -259,15 +284,21 @@ class DDPMTrainer(object):
         latest = pjoin(self.opt.model_dir, 'latest.tar')
         first_epoch, it = self.load(latest) if self.opt.is_continue else (0, 0)
         fused = bool(getattr(self.opt, "fused_step", False))
+        if world_size > 1 and _dist_world() != world_size:
+            raise RuntimeError("train(world_size=%d) needs an initialised process group of that size (found %d rank(s)): "
+                               "start the ranks through hig_amd.parallel.launch / torchrun" % (world_size, _dist_world()))
         if fused:
             self.sync_replicas()
+        elif world_size > 1 and not hasattr(self.encoder, "module"):
+            broadcast_parameters(self.encoder)      # what DDP's constructor does; the step averages the gradients itself
+            _core(self.encoder).params_changed()
         loader = self._loader(train_dataset, rank, world_size)
         meter, t_start = _RunningMean(self.opt.log_every), time.time()
         for epoch in range(first_epoch, self.opt.num_epochs):
             self.train_mode()
             for i, batch_data in enumerate(loader):
-                means = meter.add(self._one_step(batch_data, fused))
                 it += 1
+                means = meter.add(self._one_step(batch_data, fused), it=it, read=(rank == 0))
                 if means is not None and rank == 0:
                     print('epoch: %3d niter: %6d inner_iter: %4d %.0fs %s' % (
                         epoch, it, i, time.time() - t_start, ' '.join('%s: %.4f' % kv for kv in means.items())))
@@ -415,7 +446,9 @@ class DDPMTrainer(object):
                 and type(self)._fused_fwd_bwd is DDPMTrainer._fused_fwd_bwd):
             # gradient exchange of layer l while layers l-1 ... 0 are still in backward (RCCL on a side stream)
             ex = st["overlap"]
-            per_layer, tail = fp.layer_buckets(core.num_layers, 3, core.latent_dim, core.time_embed_dim)
+            nsty = 4 if int(getattr(core.dims(1, 1, 1), "two_person", 0)) == 1 else 3   # stylization blocks per layer
+            per_layer, tail = fp.layer_buckets(core.num_layers, nsty, core.latent_dim, core.time_embed_dim)
+            assert per_layer[-1][1][1] - per_layer[0][1][0] == core.num_layers * nsty * 2 * core.latent_dim * core.time_embed_dim
             ex.begin(fp.grad, per_layer, tail)
             self._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise, clip_out=clip_out, eot=eot, exchange=ex)
             world = ex.finish([(fp.core_numel, n)] if n > fp.core_numel else ())
@@ -455,12 +488,13 @@ class DDPMTrainer(object):
         `train_step_fused`: embeddings, or CLIP features."""
         st = self.fused_state()
         world = _dist_world()
+        split = exchange_active()         # graph A | all-reduce | graph B (more than one rank, or HIG_FORCE_EXCHANGE)
         with_text = clip_out is not None
         text_in = (clip_out, eot) if with_text else (xf_proj, xf_out)
         n = self._fused_numel(with_text)
         self._set_lr(lr)
         key = (tuple(x_start.shape), tuple(text_in[0].shape), tuple(text_in[1].shape), with_text, noise is None,
-               world, st["ptrs"])
+               world, split, st["ptrs"])
         cap = st["graphs"].get(key)
         if cap is None:
             static = {"x0": x_start.clone(), "t": t.clone(), "length": length.clone(),
@@ -494,7 +528,7 @@ class DDPMTrainer(object):
             st["covered"] = keep[4]
             # thread_local: other threads (the RCCL watchdog polls its events) may call into HIP while we capture
             ga, gb = torch.cuda.CUDAGraph(), None
-            if world == 1:
+            if not split:
                 with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                     part_a()
                     self._fused_clip_adam(1, with_text)

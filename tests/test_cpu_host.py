@@ -213,3 +213,52 @@ def test_data_parallel_exchange_world2_gloo(tmp_path):
 def test_flat_allreduce_is_noop_without_process_group():
     g = torch.ones(4)
     assert hig_amd.parallel.FlatGradAllReduce()(g) == 1 and torch.equal(g, torch.ones(4))
+
+
+def test_launcher_spawns_ranks_runs_them_in_a_group_and_tears_it_down(tmp_path):
+    """hig_amd.parallel.launch == tools/train.py:53-102 (setup -> body -> destroy_process_group, one process per
+    rank): gloo here (no GPU), 2 ranks, 127.0.0.1 rendezvous on a free port."""
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import launch_helper
+    from hig_amd import parallel
+    parallel.launch(launch_helper.allreduce_rank, world_size=2, backend="gloo", args=(str(tmp_path),), kwargs={"scale": 2.0})
+    assert not dist.is_initialized()                    # the parent never joins
+    for r in range(2):
+        assert open(tmp_path / ("rank%d.txt" % r)).read() == "gloo 2 6"
+    # under torchrun's variables the caller IS a rank: joins, runs, destroys the group again
+    env = {"RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(parallel._free_port())}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        parallel.launch(launch_helper.allreduce_rank, backend="gloo", args=(str(tmp_path),))
+        assert open(tmp_path / "rank0.txt").read() == "gloo 1 1" and not dist.is_initialized()
+        with pytest.raises(ValueError, match="boom"):
+            parallel.launch(launch_helper.failing_rank, backend="gloo")
+        assert not dist.is_initialized()                # destroyed also when the body raises
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
+def test_train_refuses_a_world_size_without_a_process_group():
+    import types
+    import hig_amd
+    from hig_amd.trainers import ddpm_trainer as tr
+    t = object.__new__(hig_amd.DDPMTrainer)
+    t.opt = types.SimpleNamespace(lr=1e-4, model_dir="/tmp", is_continue=False, fused_step=False)
+    t.device, t._fused = "cpu", None
+    t.encoder = torch.nn.Linear(2, 2)
+    t.to = lambda dev: None
+    with pytest.raises(RuntimeError, match="initialised process group"):
+        t.train([], 0, 2)
+    assert tr._dist_world() == 1
+
+
+def test_running_mean_prints_on_iteration_multiples_like_the_reference():
+    from hig_amd.trainers.ddpm_trainer import _RunningMean
+    m = _RunningMean(4)
+    outs = [m.add({"l": 1.0}, it=it) for it in range(7, 13)]        # resumed at it = 6: the reference prints at 8 and 12
+    assert [o is not None for o in outs] == [False, True, False, False, False, True]
+    assert outs[1]["l"] == 2.0 / 4 and outs[5]["l"] == 1.0           # (sums divided by log_every, ddpm_trainer.py:250)
+    assert m.add({"l": 1.0}, it=16, read=False) is None and m.n == 0 # non-printing ranks never read the values back

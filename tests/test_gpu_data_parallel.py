@@ -44,3 +44,37 @@ def test_two_rank_fused_training_step_matches_mean_gradient_step(dp_workers):
     ref = fp.flat[:n].cpu()
     # same kernels on the same numbers (a two-term sum commutes): expect bitwise equality; gate at fp32 rounding
     assert (ref - got[0]["flat"]).abs().max().item() <= 1e-7 * ref.abs().max().item()
+
+
+def test_two_rank_epoch_loop_shards_checkpoints_and_resumes(dp_train_workers):
+    """`DDPMMulTrainer.train(dataset, rank, world=2)` (ddpm_trainer.py:220-266 + datasets/dataloader.py:16-53 +
+    tools/train.py:53-90) as a whole: disjoint rank-strided shards of the SAME permutation in every epoch, replicas
+    bit-identical after every phase, checkpoints written by rank 0 only, resume from rank 0's file, and the
+    reference's own forward()/update() step averaging its gradients when handed a bare model in a 2-rank group."""
+    from hig_amd.parallel import ShardedSampler
+    outdir, codes, logs = dp_train_workers
+    assert codes == [0, 0], "\n".join(logs)[-6000:]
+    got = [torch.load(os.path.join(outdir, "train_rank%d.pt" % r)) for r in range(2)]
+    n, bs = got[0]["n"], 2
+    assert n == got[1]["n"] and n >= 5
+    want = [ShardedSampler(n, r, 2).indices() for r in range(2)]
+    per_epoch = (len(want[0]) // bs) * bs                      # drop_last
+    assert sorted(want[0] + want[1])[:n] != [] and set(want[0] + want[1]) == set(range(n))   # together: every clip
+    # (a resume re-enters the epoch index stored in the checkpoint, like the reference: `range(cur_epoch, num_epochs)`,
+    # ddpm_trainer.py:226-241 -- phase 2 resumes at ep = 1 with num_epochs = 3 and so runs epochs 1 and 2)
+    for tag, epochs in (("p1", 2), ("p2", 2), ("p3", 1)):
+        for r in range(2):
+            # the reference never calls set_epoch (dataloader.py:34-37): the same shard, in the same order, every epoch
+            assert got[r][tag + ".seen"] == want[r][:per_epoch] * epochs, (tag, r)
+        assert torch.equal(got[0][tag + ".params"], got[1][tag + ".params"]), tag      # replicas identical
+        assert got[1][tag + ".saves"] == []                                            # only rank 0 writes
+    steps = per_epoch // bs
+    names = [s[0] for s in got[0]["p1.saves"]]
+    assert names.count("latest.tar") >= 2 and "ckpt_e000.tar" in names and "ckpt_e001.tar" in names
+    assert got[0]["p1.saves"][-2][1:] == (1, 2 * steps) or got[0]["p1.saves"][-1][1:] == (1, 2 * steps)
+    ck = torch.load(os.path.join(outdir, "model", "latest.tar"), map_location="cpu")
+    assert ck["ep"] == 2 and ck["total_it"] == 4 * steps                               # 2 epochs + the 2 resumed ones
+    assert sorted(ck) == ["encoder", "ep", "opt_encoder", "total_it"]
+    # the resumed epoch started from the checkpoint, not from the fresh (different) models: it moved on from phase 1
+    assert not torch.equal(got[0]["p1.params"], got[0]["p2.params"])
+    assert (got[0]["p1.params"] - got[0]["p2.params"]).abs().max().item() < 0.05
