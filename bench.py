@@ -331,6 +331,18 @@ def cpu_baseline(c, model, inp, gpu_out):
             "legs": legs}, rel
 
 
+def oracle_slice_error(c, model, inp, gpu_out, n=2):
+    """rel-L2 of the first `n` samples of a GPU forward against the CPU oracle run on just those samples (samples are
+    independent, so the slice of the full-batch output is comparable): pins the bf16 numbers of this file to the
+    reference's arithmetic rather than to the fp32 GPU path."""
+    from oracle import denoiser_ref as R
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.startswith("clip.")}
+    ci = {k: v[:n].cpu() for k, v in inp.items() if k in ("x", "t", "length", "xf_proj", "xf_out")}
+    with torch.no_grad():
+        ref = R.denoiser_forward(p, ci["x"], ci["t"], ci["length"], ci["xf_proj"], ci["xf_out"], c["H"], c["L"])
+    return ((gpu_out[:n].double().cpu() - ref.double()).norm() / ref.double().norm()).item()
+
+
 SAMPLING_MODES = ("f32", "bf16", "bf16s")
 MODE_TEXT = {"f32": "exact fp32 products, fp32 storage", "bf16": "bf16 products, fp32 storage",
              "bf16s": "bf16 STORAGE (bf16 activations + bf16 weight shadow, fp32 accumulate / statistics)"}
@@ -476,10 +488,13 @@ def main():
         for mode in ("bf16x3", "bf16", "bf16s"):
             set_mode(model, mode)
             el_m = timed(fwd, max(5, a.steps // 2), 2, world)
-            err = ((fwd().double() - ref_out.double()).norm() / ref_out.double().norm()).item()
+            out_m = fwd()
+            err = ((out_m.double() - ref_out.double()).norm() / ref_out.double().norm()).item()
             extra["fwd_" + mode] = {"frames_per_s": round(B * T * max(5, a.steps // 2) * world / el_m, 1),
                                     "ms_per_step": round(el_m / max(5, a.steps // 2) * 1e3, 3),
                                     "rel_l2_vs_f32_path": float("%.2e" % err)}
+            if rank == 0 and not a.no_cpu_baseline:
+                extra["fwd_" + mode]["rel_l2_vs_cpu_oracle"] = float("%.2e" % oracle_slice_error(c, model, inp, out_m))
         set_mode(model, "f32")
         extra["fwd_bf16s"]["what"] = MODE_TEXT["bf16s"] + " -- BASELINE configs 3 / 5 arithmetic; incl. the per-call text side"
         extra["fwd_bf16s"]["fwd_tflops"] = round(gflop / extra["fwd_bf16s"]["ms_per_step"], 1)
@@ -548,6 +563,27 @@ def main():
                     "what": "p_sample_loop B=32 T=196, %s: %d replays of the captured step actually run (text encoding "
                             "excluded, graph capture included)%s" % (
                                 MODE_TEXT[mode], nst, "" if nst == 1000 else ", scaled x%.1f to 1000" % (1000.0 / nst))}
+            # ---- the same loop at the batch sizes generation really runs at (ddpm_trainer.py:152 `generate(..., batch_size=1024)`,
+            # the evaluation tools sample hundreds of captions per call): bf16 storage, all 1000 steps ----
+            set_mode(model, "bf16s")
+            by_batch = {}
+            for Bg in (128, 512):
+                cg = dict(c, B=Bg)
+                ig = make_inputs(cg, device, rank)
+                kwg = {"xf_proj": ig["xf_proj"], "xf_out": ig["xf_out"], "length": ig["length"]}
+                gd_warm.p_sample_loop(model, (Bg, T, c["F"]), clip_denoised=False, model_kwargs=kwg)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                smp = gd.p_sample_loop(model, (Bg, T, c["F"]), clip_denoised=False, model_kwargs=kwg)
+                torch.cuda.synchronize()
+                el_s = time.perf_counter() - t0
+                by_batch["B%d" % Bg] = {"samples_per_s": round(Bg / (el_s * (1000.0 / nst)), 3),
+                                        "ms_per_denoise_step": round(el_s / nst * 1e3, 4),
+                                        "finite": bool(torch.isfinite(smp).all())}
+                del ig, kwg, smp
+            by_batch["B32"] = {k: extra["ddpm_sampling_bf16s"][k] for k in ("samples_per_s", "ms_per_denoise_step", "finite")}
+            by_batch["what"] = "p_sample_loop T=196, bf16 storage, captured step replayed %d times, by batch size" % nst
+            extra["ddpm_sampling_bf16s_by_batch"] = by_batch
             set_mode(model, "f32")
             model.cache_text_context = False
             # ---- two-person denoiser: 32 pairs x 91 tokens x 263 features, fwd and fwd+bwd ----
@@ -588,8 +624,25 @@ def main():
             m2.eval()
             m2.storage = "bf16"          # bf16 storage of the two-person forward (inference)
             e_f16 = timed(fwd2, k2, 2, 1)
+            # the 1000-step loop of the two-person model (what mul_ddpm_trainer.py:164-222 `generate_batch` runs): 32 pairs
+            loops2 = {}
+            kw2 = {"xf_proj": i2["xf_proj"], "xf_out": i2["xf_out"], "length": i2["length"]}
+            m2.cache_text_context = True
+            for st2 in ("bf16", "f32"):
+                m2.storage = st2
+                gd_warm.p_sample_loop(m2, (c2["B"], c2["T"], c2["F"]), clip_denoised=False, model_kwargs=kw2)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                smp2 = gd.p_sample_loop(m2, (c2["B"], c2["T"], c2["F"]), clip_denoised=False, model_kwargs=kw2)
+                torch.cuda.synchronize()
+                el2 = time.perf_counter() - t0
+                loops2[st2] = {"pairs_per_s": round(32 / (el2 * (1000.0 / nst)), 3), "ms_per_denoise_step": round(el2 / nst * 1e3, 4),
+                               "finite": bool(torch.isfinite(smp2).all())}
+            m2.cache_text_context = False
             m2.storage = "f32"
             extra["two_person"] = {
+                "ddpm_sampling_1000_steps": dict(loops2, what="p_sample_loop of the two-person model, 32 pairs x 91 tokens, "
+                                                 "captured step replayed %d times; keys = storage" % nst),
                 "pit_train_step_ms": round(e_pit / k2 * 1e3, 3),
                 "pit_train_pairs_per_s": round(16 * k2 / e_pit, 1),
                 "fwd_frames_per_s": round(c2["B"] * c2["T"] * k2 / e_f, 1), "fwd_ms": round(e_f / k2 * 1e3, 3),
@@ -621,6 +674,9 @@ def main():
                 "fwd_tflops_f32": round(g5 / r5["f32"][0], 1), "fwd_tflops_bf16_storage": round(g5 / r5["bf16s"][0], 1),
                 "rel_l2_bf16_products_vs_f32": float("%.2e" % ((r5["bf16"][1] - r5["f32"][1]).norm() / r5["f32"][1].norm()).item()),
                 "rel_l2_bf16_storage_vs_f32": float("%.2e" % ((r5["bf16s"][1] - r5["f32"][1]).norm() / r5["f32"][1].norm()).item()),
+                "rel_l2_vs_cpu_oracle": None if a.no_cpu_baseline else {
+                    k: float("%.2e" % oracle_slice_error(c5, m5, i5, r5[m][1]))
+                    for k, m in (("f32", "f32"), ("bf16_products", "bf16"), ("bf16_storage", "bf16s"))},
                 "what": "MotionTransformer forward B=32 T=300 d=1024 L=12 H=8 (head dim 128) ff=1024, text side included: "
                         "fp32; bf16 products with fp32 storage; bf16 storage (BASELINE config 5)"}
             del m5, i5, r5

@@ -720,20 +720,24 @@ extern "C" int hig_fullattn_bwd(const float* dY, int64_t lddy, const float* Y, i
               "hig_fullattn_bwd: operands must be 16-byte aligned");
   if (use_mfma(hd)) {
     hipStream_t st = hig_stream(stream);
-    FNW_SWITCH(true, hd, {
+    if (hd == 128) {
+      // head dim 128: four waves, always (the key-side kernel needs more than 256 registers per lane: the 8- and 2-wave
+      // instances spilled and were never selected -- profiles/r02_attn_sweep.md -- so they are not built)
+      constexpr int NWV = 4;
       const dim3 gq(B * H, (Tq + 32 * NWV - 1) / (32 * NWV)), gk(B * H, (Tk + 32 * NWV - 1) / (32 * NWV));
-      if (hd == 128) {
-        hipLaunchKernelGGL((full_bwd_q_mfma_kernel<128, NWV>), gq, dim3(64 * NWV), 0, st, dY, lddy, Y, ldy, Q, ldq, K, V, ldk, Tq,
-                           Tk, H, qlen, lse, delta, dQ, lddq);
-        hipLaunchKernelGGL((full_bwd_kv_mfma_kernel<128, NWV>), gk, dim3(64 * NWV), 0, st, dY, lddy, Q, ldq, K, V, ldk, Tq, Tk, H,
-                           qlen, lse, delta, dK, dV, lddk);
-      } else {
+      hipLaunchKernelGGL((full_bwd_q_mfma_kernel<128, NWV>), gq, dim3(64 * NWV), 0, st, dY, lddy, Y, ldy, Q, ldq, K, V, ldk, Tq,
+                         Tk, H, qlen, lse, delta, dQ, lddq);
+      hipLaunchKernelGGL((full_bwd_kv_mfma_kernel<128, NWV>), gk, dim3(64 * NWV), 0, st, dY, lddy, Q, ldq, K, V, ldk, Tq, Tk, H,
+                         qlen, lse, delta, dK, dV, lddk);
+    } else {
+      FNW_SWITCH(true, hd, {
+        const dim3 gq(B * H, (Tq + 32 * NWV - 1) / (32 * NWV)), gk(B * H, (Tk + 32 * NWV - 1) / (32 * NWV));
         hipLaunchKernelGGL((full_bwd_q_mfma_kernel<64, NWV>), gq, dim3(64 * NWV), 0, st, dY, lddy, Y, ldy, Q, ldq, K, V, ldk, Tq,
                            Tk, H, qlen, lse, delta, dQ, lddq);
         hipLaunchKernelGGL((full_bwd_kv_mfma_kernel<64, NWV>), gk, dim3(64 * NWV), 0, st, dY, lddy, Q, ldq, K, V, ldk, Tq, Tk, H,
                            qlen, lse, delta, dK, dV, lddk);
-      }
-    });
+      });
+    }
     HIG_CHECK_LAUNCH();
     return HIG_OK;
   }

@@ -362,7 +362,7 @@ int launch16(const hig_gemm16_desc& g, hipStream_t st) {
 // equals the larger tile when it still gives every CU a workgroup, else the smaller one (more CUs busy).
 template <int EPI>
 int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
-  static const int forced = getenv("HIG_BF16_TILE") ? atoi(getenv("HIG_BF16_TILE")) : 0;   // tuning knob: 64 / 128 / 192 / 256
+  static const int forced = getenv("HIG_BF16_TILE") ? atoi(getenv("HIG_BF16_TILE")) : 0;   // tuning knob: 64 / 128 / 256
   auto tiles = [&](int bm, int bn) { return (int64_t)((g.I + bm - 1) / bm) * ((g.J + bn - 1) / bn); };
   auto rounds = [](int64_t t, int slots) { return (t + slots - 1) / slots; };
   const int64_t t128 = tiles(128, 128), t64 = tiles(64, 128), t256 = tiles(256, 256);
@@ -405,7 +405,6 @@ int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
   if (ring4_rows > 0 && pick == 128 && g.I >= ring4_rows && g.R >= 512) return launch16<2, 2, 2, 2, 32, 4, EPI>(g, st);
   if (g.R % 64 == 0) {
     if (pick == 256) return launch16<2, 4, 4, 2, 64, 2, EPI>(g, st);
-    if (pick == 192) return launch16<2, 2, 2, 3, 64, 2, EPI>(g, st);
     if (pick == 128) return launch16<2, 2, 2, 2, 64, 2, EPI>(g, st);
     return launch16<1, 4, 2, 1, 64, 2, EPI>(g, st);
   }

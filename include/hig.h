@@ -11,7 +11,11 @@
  *   - The caller owns every buffer.  The library allocates no device memory, frees nothing,
  *     keeps no reference past return.  All device pointers must be valid on the current HIP
  *     device (hipSetDevice is the caller's job).
- *   - No global mutable state except what hig_shutdown() releases (the per-thread weight-gradient stream below).
+ *   - No global mutable state except (a) what hig_shutdown() releases (the per-thread weight-gradient stream below),
+ *     (b) the diagnostic stamp pointers of hig_gemm_debug_stamps / hig_gemm_bf16_debug_stamps /
+ *     hig_gemm_ws16_debug_stamps (NULL unless a profiling tool sets them; never set during a timed or captured run),
+ *     and (c) tuning knobs read ONCE from the environment (HIG_*: DESIGN.md section 5 lists them) into function-local
+ *     constants on first use -- after that first call they never change, so calls stay re-entrant.
  *   - Every launch is ordered through the `stream` argument (a hipStream_t passed as void*): on it,
  *     or -- hig_denoiser_bwd's weight gradients only -- on a library-owned stream forked from and
  *     joined back into it with events.  No host synchronisation, device allocation, blocking copy or

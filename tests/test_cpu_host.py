@@ -262,3 +262,17 @@ def test_running_mean_prints_on_iteration_multiples_like_the_reference():
     assert [o is not None for o in outs] == [False, True, False, False, False, True]
     assert outs[1]["l"] == 2.0 / 4 and outs[5]["l"] == 1.0           # (sums divided by log_every, ddpm_trainer.py:250)
     assert m.add({"l": 1.0}, it=16, read=False) is None and m.n == 0 # non-printing ranks never read the values back
+
+
+def test_host_entry_points_under_asan_ubsan():
+    """SURVEY section 5 (sanitizers on the CPU build): the host side of every translation unit compiled with
+    -fsanitize=address,undefined (no device code), driven through the entry points that return before any HIP call --
+    workspace / scratch size queries over a sweep of shapes, and descriptor validation with null / misaligned / negative
+    arguments (tests/host_sanitize/driver.cpp).  A sanitizer report aborts the driver."""
+    csrc = os.path.join(ROOT, "human-interaction-generation_amd", "csrc")
+    b = subprocess.run(["make", "-C", csrc, "-j8", "sanitize"], capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stdout[-3000:] + b.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([os.path.join(ROOT, "build", "host_sanitize", "driver")], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "host entry points clean" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]

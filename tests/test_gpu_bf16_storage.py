@@ -248,6 +248,13 @@ CASES16 = {
     "hd128": dict(B=3, T=75, F=150, d=256, H=2, L=3, ff=512, N=77, Lt=64, num_frames=80, lengths=(75, 40, 1), t=(0, 999, 313)),
     "small": dict(B=2, T=33, F=12, d=128, H=2, L=2, ff=96, N=77, Lt=32, num_frames=40, lengths=(33, 5), t=(7, 650)),
     "wide8": dict(B=2, T=70, F=150, d=1024, H=8, L=2, ff=1024, N=77, Lt=256, num_frames=80, lengths=(70, 33), t=(5, 900)),
+    # BASELINE config 5 as specified (T = 300, d = 1024, head dim 128, bf16 storage), two layers deep; 8 x 300 = 2400 rows,
+    # so every large GEMM runs on the weight-stationary kernel (K = 1024: its K-split variant)
+    "config5": dict(B=8, T=300, F=150, d=1024, H=8, L=2, ff=1024, N=77, Lt=256, num_frames=300,
+                    lengths=(300, 211, 300, 1, 150, 299, 64, 300), t=(5, 900, 0, 999, 313, 650, 77, 500)),
+    # the config-2 model on enough rows (16 x 196 = 3136) for the weight-stationary kernel's K = 512 / 256 variants
+    "width16": dict(fill.CASES["width"], B=16, lengths=(196, 77, 196, 1, 120, 196, 50, 196) * 2,
+                    t=(0, 999, 500, 250, 7, 650, 313, 900) * 2),
 }
 
 
@@ -297,7 +304,7 @@ def test_full_attention_bf16_io_equals_the_fp32_kernel_on_the_same_values(B, Tq,
     assert torch.equal(y16, bf(y32))
 
 
-@pytest.mark.parametrize("case", ["width", "hd128"])
+@pytest.mark.parametrize("case", ["width", "hd128", "config5"])
 def test_bf16_storage_no_eff_forward_against_fp32_oracle(case):
     """storage='bf16' with no_eff=True (full softmax attention on the matrix cores, bf16 Q / K / V / Y): valid rows of a
     ragged batch against the fp32 CPU oracle (padded query rows carry the reference's -1e5-quantised logits, App. B-3)."""
