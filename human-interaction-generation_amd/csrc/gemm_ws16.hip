@@ -59,8 +59,11 @@ __device__ __forceinline__ void ws_wait_vmcnt_visible() {
 // KW: reduce elements per wave; KSPLIT: wave pairs splitting K = KW * KSPLIT; NWJ: column slices per workgroup, each
 // NCB blocks of 32 columns wide (NCB = 2: a wave holds 64 columns x KW = 256 registers of weights -- one wave per SIMD,
 // 512 registers each -- and every X fragment it reads from LDS feeds two MFMAs).
-template <int KW, int KSPLIT, int NWJ, int NCB, int EPI, int DBG = 0>
-__global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) void gemm_ws16_kernel(const WsArgs a) {
+// OCC: workgroups per CU the kernel is laid out for (LDS budget 160 KB / OCC, registers 512 / (OCC waves per SIMD)).
+template <int KW, int KSPLIT, int NWJ, int NCB, int EPI, int DBG = 0, int OCC = 1>
+__global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) void gemm_ws16_kernel(const WsArgs a) {
+  constexpr int LDS_MAX = 160 * 1024 / OCC;
+  static_assert(OCC == 1 || NWJ * KSPLIT == 4, "two workgroups per CU: 4-wave variants only");
   constexpr int NW = NWJ * KSPLIT, NT = 64 * NW;
   constexpr int K = KW * KSPLIT;
   constexpr int BM = 32, BN = 32 * NWJ * NCB;
@@ -79,18 +82,19 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) voi
   constexpr bool HAS_RES = EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU;
   // 4-wave workgroups (one wave per SIMD, 512 registers each): X fragments are read XD k-steps ahead into a register ring
   // and the k-loop's order is pinned; 8-wave workgroups (256 registers per wave: the ring spills) leave the k-loop to hipcc
-  constexpr bool RING = NW < 8;
-  constexpr int XD = 4;
-  constexpr int GK = 4;                        // k-steps per scheduling group
+  constexpr bool RING = NW < 8 && OCC == 1;   // (two workgroups per CU: 256 registers again, and the other workgroup's waves hide the LDS latency)
+  constexpr int XD = OCC > 1 ? 2 : 4;          // (256 registers per wave with two workgroups per CU: a shorter ring)
+  constexpr int GK = OCC > 1 ? 2 : 4;          // k-steps per scheduling group
   // X ring: three tiles where LDS allows (a tile requested in iteration t is waited for at the top of iteration t + 2:
   // one tile in flight across every barrier); two at K = 1024 (64 KB tiles)
   constexpr int RBUF = HAS_RES ? SBUF : 0;     // residual tiles come in by DMA too (two buffers, staged-tile sized)
   static_assert(!(HAS_RES && KSPLIT > 1), "the K-split variant has no LDS left for residual tiles");
-  constexpr int NXB = (3 * XBUF + 2 * SBUF + 2 * RBUF + PBUF <= 160 * 1024) ? 3 : 2;
+  constexpr int NXB = (3 * XBUF + 2 * SBUF + 2 * RBUF + PBUF <= LDS_MAX) ? 3 : 2;
+  static_assert(2 * XBUF + 2 * SBUF + 2 * RBUF + PBUF <= LDS_MAX, "LDS budget");
   constexpr int NRQ = RBUF / 1024 / NW;        // residual DMA instructions per wave and tile
   static_assert(RBUF % (1024 * NW) == 0, "residual DMA instructions must split evenly over the waves");
   // bias: in LDS where there is room (sixteen registers less per lane), else in registers for the workgroup's life
-  constexpr bool BIAS_LDS = NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + BN * 4 <= 160 * 1024;
+  constexpr bool BIAS_LDS = NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + BN * 4 <= LDS_MAX;
   __shared__ __attribute__((aligned(1024))) char smem[NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + (BIAS_LDS ? BN * 4 : 0)];
   [[maybe_unused]] float* const sB = reinterpret_cast<float*>(smem + NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF);
   char* const sX = smem;
@@ -322,6 +326,9 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) voi
     dma_res(t, t & 1);
     if (t >= 2) store_tile(t - 2, sS + (t & 1) * SBUF);
     dma_pend = t + NXB - 1 < nt;                 // its DMA instructions go out between the MFMAs below
+    constexpr bool DMA_IN_LOOP = OCC == 1;       // (two workgroups per CU: issued here in one block -- the other workgroup's
+                                                 // waves feed the matrix pipe meanwhile, and the k-loop needs fewer registers)
+    if (!DMA_IN_LOOP && dma_pend) dma_tile(t + NXB - 1, (t + NXB - 1) % NXB);
     const int drow0 = (t0 + (t + NXB - 1) * a.g) * BM, dbuf = (t + NXB - 1) % NXB;
     // (a wave stalls ~150-300 cycles on every 1-KiB DMA it issues -- the CU takes ~25 bytes per clock from its L2 --
     // and issued in a block ahead of the k-loop that was 600-1200 cycles per tile in which the wave fed no MFMA; the
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) voi
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][ks], xf, acc[cb], 0, 0, 0);
         }
-        if constexpr (DMA && !(DBG & 8)) {
+        if constexpr (DMA && DMA_IN_LOOP && !(DBG & 8)) {
           if (ks % (NKS / NQ) == DPH) dma_one(rsX, (int)a.ldx, drow0, a.I - 1, dbuf, ks / (NKS / NQ));
         }
         constexpr int NEL = 4 * NQF * NCB;       // epilogue elements per tile and lane, spread over the NKS k-steps
@@ -384,7 +391,9 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) voi
         if constexpr (RING) { if (ks % GK == GK - 1) __builtin_amdgcn_sched_barrier(0); }
       }
     };
-    if (wave < NW / 2 || NW < 8) {
+    if (!DMA_IN_LOOP) {
+      kloop(std::false_type{}, std::false_type{});
+    } else if (wave < NW / 2 || NW < 8) {
       if (dma_pend) kloop(std::true_type{}, std::false_type{}); else kloop(std::false_type{}, std::false_type{});
     } else {
       if (dma_pend) kloop(std::true_type{}, std::true_type{}); else kloop(std::false_type{}, std::true_type{});
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : 1)) voi
   if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + 14] = (unsigned long long)nt;
 }
 
-template <int KW, int KSPLIT, int NWJ, int NCB, int EPI>
+template <int KW, int KSPLIT, int NWJ, int NCB, int EPI, int OCC = 1>
 int launch_ws(const hig_gemm16_desc& g, int slots_per_xcd, hipStream_t st) {
   constexpr int BN = 32 * NWJ * NCB;
   WsArgs a;
@@ -454,18 +463,24 @@ int launch_ws(const hig_gemm16_desc& g, int slots_per_xcd, hipStream_t st) {
       default: break;
     }
   }
-  hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI>), dim3(8 * slots_per_xcd), dim3(64 * NWJ * KSPLIT), 0, st, a);
+  hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 0, OCC>), dim3(8 * slots_per_xcd), dim3(64 * NWJ * KSPLIT), 0, st, a);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
 
 template <int EPI>
 int launch_ws_sized(const hig_gemm16_desc& g, int nwj, hipStream_t st) {
-  // 4-wave workgroups (128-column panels, 80 KB of LDS): one per CU (32 slots per XCD) or two (64)
-  static const int slots4 = getenv("HIG_BF16_WS_SLOTS") ? atoi(getenv("HIG_BF16_WS_SLOTS")) : 32;   // tuning knob
-  // nwj: 8 = eight waves x 32 columns, 4 = four waves x 32 columns, 2 = four waves x 64 columns (256-column panels)
-  if (g.R == 512) return nwj == 8 ? launch_ws<512, 1, 8, 1, EPI>(g, 32, st) : nwj == 2 ? launch_ws<512, 1, 4, 2, EPI>(g, 32, st) : launch_ws<512, 1, 4, 1, EPI>(g, slots4, st);
-  if (g.R == 256) return nwj == 8 ? launch_ws<256, 1, 8, 1, EPI>(g, 32, st) : launch_ws<256, 1, 4, 1, EPI>(g, slots4, st);
+  // nwj: 8 = eight waves x 32 columns, 4 = four waves x 32 columns, 2 = four waves x 64 columns (256-column panels),
+  // 44 = four waves x 32 columns laid out for TWO workgroups per CU (80 KB of LDS, 256 registers; epilogues without a
+  // residual tile only)
+  constexpr bool has_res = EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU;
+  if constexpr (!has_res) {
+    if (nwj == 44 && g.R == 512) return launch_ws<512, 1, 4, 1, EPI, 2>(g, 64, st);
+    if (nwj == 44 && g.R == 256) return launch_ws<256, 1, 4, 1, EPI, 2>(g, 64, st);
+  }
+  if (nwj == 44) nwj = 4;
+  if (g.R == 512) return nwj == 8 ? launch_ws<512, 1, 8, 1, EPI>(g, 32, st) : nwj == 2 ? launch_ws<512, 1, 4, 2, EPI>(g, 32, st) : launch_ws<512, 1, 4, 1, EPI>(g, 32, st);
+  if (g.R == 256) return nwj == 8 ? launch_ws<256, 1, 8, 1, EPI>(g, 32, st) : launch_ws<256, 1, 4, 1, EPI>(g, 32, st);
   if constexpr (EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU) return 1;   // (no LDS left for residual tiles)
   else return launch_ws<512, 2, 4, 1, EPI>(g, 32, st);   // K = 1024: 8 waves = 4 column slices x 2 halves of the reduce range
 }
@@ -495,12 +510,16 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
   if (g.R == 1024) nwj = 4;
   else if ((int64_t)g.I * g.J < (int64_t)256 * 192 * 192) nwj = 4;
   else if (!(g.epi == HIG_EPI_NONE || g.epi == HIG_EPI_BIAS)) nwj = 4;
-  if (forced_nwj == 4 || (forced_nwj == 8 && g.R != 1024) || (forced_nwj == 2 && g.R == 512)) nwj = forced_nwj;
-  const int bn = nwj == 4 ? 128 : 256;
+  // GELU: every wave is bound by instruction issue (the erf arithmetic alone is 13 instructions per output, ~4 cycles
+  // each from one wave); two 4-wave workgroups per CU put a second, independent wave on every SIMD: FFN linear1 at
+  // M = 12 544 28.5 -> 25.2 us, at M = 6 272 17.2 -> 15.1 us
+  if (g.epi == HIG_EPI_BIAS_GELU && g.R != 1024) nwj = 44;
+  if (forced_nwj == 4 || (forced_nwj == 8 && g.R != 1024) || (forced_nwj == 2 && g.R == 512) || (forced_nwj == 44 && g.R != 1024)) nwj = forced_nwj;
+  const int bn = (nwj == 4 || nwj == 44) ? 128 : 256;
   if (g.J % bn != 0) {
     if (g.J % 128 == 0) nwj = 4; else return 1;
   }
-  if (g.J / (nwj == 4 ? 128 : 256) > 32) return 1;
+  if (g.J / ((nwj == 4 || nwj == 44) ? 128 : 256) > 32) return 1;
   switch (g.epi) {
     case HIG_EPI_NONE: return launch_ws_sized<HIG_EPI_NONE>(g, nwj, st);
     case HIG_EPI_BIAS: return launch_ws_sized<HIG_EPI_BIAS>(g, nwj, st);

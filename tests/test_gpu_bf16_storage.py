@@ -89,7 +89,7 @@ def test_gemm_bf16_all_epilogues_and_ragged_shapes(I, J, R, epi, c_f32, res_f32)
         assert (out.float().cpu() != exact).float().mean().item() < 0.02
 
 
-@pytest.mark.parametrize("nwj", ["2", "4", "8"])
+@pytest.mark.parametrize("nwj", ["2", "4", "8", "44"])
 @pytest.mark.parametrize("I,J,R,epi", [(6272, 512, 512, "res"), (12544, 1024, 512, "gelu"), (3001, 768, 512, "bias"),
                                        (2049, 256, 256, "silu"), (7000, 1536, 512, "none")])
 def test_gemm_ws16_every_variant(I, J, R, epi, nwj, monkeypatch):
