@@ -109,6 +109,7 @@ struct FwdLayout {
   int64_t st1, qkv, A1, kst1, lse1, y1, st2, a1, h1, st3, qc, lse2, y2, st4, a2, h2, z1, f1, y3, st5, a3, h3;
   int64_t st6, iqkv, Ai, ksti, y4, st7, a4, h2b;  // two-person interaction attention block
   int64_t xn1, xn2, xn3;  // LayerNorm outputs feeding the q/k/v GEMMs (kept: wgrad operands)
+  int64_t cscr2, gtail2;  // second set of per-stream scratch (two-stream forward)
   int64_t total;
 };
 FwdLayout fwd_layout(const Dims& D, int training) {
@@ -123,6 +124,8 @@ FwdLayout fwd_layout(const Dims& D, int training) {
   w.lenp = take((int64_t)D.B * 2);  // int64 lengths with the two halves swapped (partner's mask)
   w.cscr = take(hig_linattn_ctx_scratch_floats(D.B, D.T, D.H, D.hd));   // chunk partials of the context build
   w.gtail = take(HIG_GEMM_TAIL_BYTES / 4);   // split tail of the fp32 GEMMs (hig_gemm_set_tail_scratch)
+  w.cscr2 = take(hig_linattn_ctx_scratch_floats(D.B, D.T, D.H, D.hd));
+  w.gtail2 = take(HIG_GEMM_TAIL_BYTES / 4);
   w.layer0 = o;
   o = 0;
   w.st1 = take(D.M * 2);
@@ -327,6 +330,54 @@ extern "C" int hig_text_context(const hig_dims* dims, const void* const* params,
   return HIG_OK;
 }
 
+namespace {
+
+// (the library-owned second stream of the calling thread: protocol described at WgradFork below)
+struct SideStream {
+  hipStream_t s2 = nullptr;
+  hipEvent_t ready = nullptr;
+  hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ok = false, failed = false;
+};
+
+constexpr int kMaxDev = 16;
+SideStream* side_stream_table() {
+  static thread_local SideStream tab[kMaxDev];
+  return tab;
+}
+
+hipEvent_t& layer_event() {   // hig_denoiser_bwd_hooked: "layer l is enqueued" marker on the caller's stream
+  static thread_local hipEvent_t ev = nullptr;
+  return ev;
+}
+
+SideStream* side_stream_for_current_device(hipStream_t caller) {
+  static const int enabled = getenv("HIG_BWD_OVERLAP") ? atoi(getenv("HIG_BWD_OVERLAP")) : 1;
+  if (!enabled) return nullptr;
+  SideStream* tab = side_stream_table();
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+  SideStream& s = tab[dev];
+  if (s.failed) return nullptr;
+  if (!s.ok) {
+    // first use on this thread / device.  Creating a stream is not something to do under capture: a caller that
+    // captures its very first backward (no eager warm-up) simply gets the single-stream order for that graph.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(caller, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    bool good = hipStreamCreateWithFlags(&s.s2, hipStreamNonBlocking) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 4 && good; ++i) good = hipEventCreateWithFlags(&s.done[i], hipEventDisableTiming) == hipSuccess;
+    if (!good) {   // do not retry (and leak) on every call: stay on the caller's stream for good
+      s.failed = true;
+      return nullptr;
+    }
+    s.ok = true;
+  }
+  return &s;
+}
+
+}  // namespace
+
 extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params, const float* x,
                                 const int64_t* t, const int64_t* length, const float* xf_proj,
                                 const void* textctx, float* out, void* workspace, int training,
@@ -389,95 +440,152 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
   // store) is 26K cycles long with two workgroups per CU to hide it (profiles/r02_notes.md section 9)
   static const int fuse_env = getenv("HIG_FUSE_APPLY_F32") ? atoi(getenv("HIG_FUSE_APPLY_F32")) : 0;   // tuning knob
   const bool fuse_apply = fuse_env && !training && !D.full && (D.H == 4 || D.H == 8) && (D.hd == 64 || D.hd == 128);
-  const float* hin = ws + w.h0;
-  for (int l = 0; l < D.L; ++l) {
+  // One decoder layer for the samples [b0, b0 + nb) on stream `s` (every kernel of a layer is row- or sample-local, so a
+  // batch range is a pointer offset).  `hin` / the returned pointer are the FULL-batch residual stream of the layer.
+  auto layer = [&](int l, const float* hin_full, int b0, int nb, hipStream_t s, float* cscr) -> const float* {
+    hig_stream_t hs = reinterpret_cast<hig_stream_t>(s);
     float* lb = ws + w.layer0 + w.lstride * l;
-    const float* ssl = ws + w.ss + (int64_t)(D.nsty * l) * 2 * d;
+    const int64_t r0 = (int64_t)b0 * D.T, Mh = (int64_t)nb * D.T;          // first row / rows of this range
+    const int64_t aoff = (int64_t)b0 * D.H * D.hd * D.hd;                   // context matrices (B, H, hd, hd)
+    const float* ssl = ws + w.ss + (int64_t)(D.nsty * l) * 2 * d + (int64_t)b0 * ss_ld;
     const float* ss_ffn = ssl + (int64_t)(D.nsty - 1) * 2 * d;
+    const int64_t* len = length ? length + b0 : nullptr;
+    const float* hin = hin_full + r0 * d;
+    auto R = [&](int64_t off, int64_t ld) { return lb + off + r0 * ld; };  // rows of an (M, ld) buffer of the layer
+    auto fail = [&](int rc) -> const float* { (void)rc; return nullptr; };
+#define HIG_L(expr) do { if ((expr) != HIG_OK) return fail(0); } while (0)
     // ---- self attention -------------------------------------------------------------
     // LayerNorm as its own row kernel: the GEMM then stages plain operands (a fused LN prologue cost
     // the q/k/v GEMM 258 -> 207 us at config 2, the row pass 13 us; profiles/r01_notes.md)
-    HIG_TRY(hig_layernorm(hin, d, M, d, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B), lb + w.xn1, d,
-                          lb + w.st1, stream));
-    HIG_TRY(hig_gemm_launch(G(lb + w.xn1, d, 0, PL(params, l, HIG_L_SA_QKV_W), d, 0, lb + w.qkv, 3 * d, M, 3 * d, d)
-                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_SA_QKV_B)).prec(D.prec).g, 1, nullptr, st));
+    HIG_L(hig_layernorm(hin, d, Mh, d, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B), R(w.xn1, d), d,
+                        R(w.st1, 2), hs));
+    HIG_L(hig_gemm_launch(G(R(w.xn1, d), d, 0, PL(params, l, HIG_L_SA_QKV_W), d, 0, R(w.qkv, 3 * d), 3 * d, Mh, 3 * d, d)
+                              .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_SA_QKV_B)).prec(D.prec).g, 1, nullptr, s));
     if (D.full) {
-      HIG_TRY(hig_fullattn_fwd(lb + w.qkv, 3 * d, lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, D.B, D.T, D.T, D.H, D.hd,
-                               length, lb + w.y1, d, lb + w.lse1, stream));
+      HIG_L(hig_fullattn_fwd(R(w.qkv, 3 * d), 3 * d, R(w.qkv, 3 * d) + d, R(w.qkv, 3 * d) + 2 * d, 3 * d, nb, D.T, D.T, D.H, D.hd,
+                             len, R(w.y1, d), d, lb + w.lse1 + (int64_t)b0 * D.H * D.T, hs));
     } else {
-      HIG_TRY(hig_linattn_ctx(lb + w.qkv + d, lb + w.qkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, length,
-                              lb + w.A1, lb + w.kst1, ws + w.cscr, stream));
+      HIG_L(hig_linattn_ctx(R(w.qkv, 3 * d) + d, R(w.qkv, 3 * d) + 2 * d, 3 * d, nb, D.T, D.H, D.hd, len,
+                            lb + w.A1 + aoff, lb + w.kst1 + (int64_t)b0 * d * 2, cscr, hs));
       if (fuse_apply)   // inference: apply + LayerNorm + modulation + SiLU in one kernel, y1 is never written
-        HIG_TRY(hig_linattn_apply_sty(lb + w.qkv, 3 * d, lb + w.A1, PL(params, l, HIG_L_SA_STY_NORM_W),
-                                      PL(params, l, HIG_L_SA_STY_NORM_B), ssl, ss_ld, d, lb + w.a1, d, D.B, D.T, D.H, D.hd, stream));
+        HIG_L(hig_linattn_apply_sty(R(w.qkv, 3 * d), 3 * d, lb + w.A1 + aoff, PL(params, l, HIG_L_SA_STY_NORM_W),
+                                    PL(params, l, HIG_L_SA_STY_NORM_B), ssl, ss_ld, d, R(w.a1, d), d, nb, D.T, D.H, D.hd, hs));
       else
-        HIG_TRY(hig_linattn_apply(lb + w.qkv, 3 * d, lb + w.A1, lb + w.y1, d, D.B, D.T, D.H, D.hd, stream));
+        HIG_L(hig_linattn_apply(R(w.qkv, 3 * d), 3 * d, lb + w.A1 + aoff, R(w.y1, d), d, nb, D.T, D.H, D.hd, hs));
     }
     if (!fuse_apply)
-      HIG_TRY(hig_ln_mod_silu(lb + w.y1, d, M, d, PL(params, l, HIG_L_SA_STY_NORM_W), PL(params, l, HIG_L_SA_STY_NORM_B),
-                              ssl, ss_ld, d, D.T, lb + w.a1, d, lb + w.st2, stream));
-    HIG_TRY(hig_gemm_launch(G(lb + w.a1, d, 0, PL(params, l, HIG_L_SA_STY_OUT_W), d, 0, lb + w.h1, d, M, d, d)
-                                .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_SA_STY_OUT_B)).res(hin, d).prec(D.prec).g, 1, nullptr, st));
+      HIG_L(hig_ln_mod_silu(R(w.y1, d), d, Mh, d, PL(params, l, HIG_L_SA_STY_NORM_W), PL(params, l, HIG_L_SA_STY_NORM_B),
+                            ssl, ss_ld, d, D.T, R(w.a1, d), d, R(w.st2, 2), hs));
+    HIG_L(hig_gemm_launch(G(R(w.a1, d), d, 0, PL(params, l, HIG_L_SA_STY_OUT_W), d, 0, R(w.h1, d), d, Mh, d, d)
+                              .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_SA_STY_OUT_B)).res(hin, d).prec(D.prec).g, 1, nullptr, s));
     // ---- cross attention ------------------------------------------------------------
-    HIG_TRY(hig_layernorm(lb + w.h1, d, M, d, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B),
-                          lb + w.xn2, d, lb + w.st3, stream));
-    HIG_TRY(hig_gemm_launch(G(lb + w.xn2, d, 0, PL(params, l, HIG_L_CA_Q_W), d, 0, lb + w.qc, d, M, d, d)
-                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).prec(D.prec).g, 1, nullptr, st));
+    HIG_L(hig_layernorm(R(w.h1, d), d, Mh, d, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B),
+                        R(w.xn2, d), d, R(w.st3, 2), hs));
+    HIG_L(hig_gemm_launch(G(R(w.xn2, d), d, 0, PL(params, l, HIG_L_CA_Q_W), d, 0, R(w.qc, d), d, Mh, d, d)
+                              .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).prec(D.prec).g, 1, nullptr, s));
+    const float* Acl = tc + tl.layer0 + tl.lstride * l + tl.Ac + aoff;
     if (D.full) {
-      const float* kvl = tc + tl.kv + tl.kv_stride * l;
-      HIG_TRY(hig_fullattn_fwd(lb + w.qc, d, kvl, kvl + d, 2 * d, D.B, D.T, D.N, D.H, D.hd, nullptr, lb + w.y2, d,
-                               lb + w.lse2, stream));
+      const float* kvl = tc + tl.kv + tl.kv_stride * l + (int64_t)b0 * D.N * 2 * d;
+      HIG_L(hig_fullattn_fwd(R(w.qc, d), d, kvl, kvl + d, 2 * d, nb, D.T, D.N, D.H, D.hd, nullptr, R(w.y2, d), d,
+                             lb + w.lse2 + (int64_t)b0 * D.H * D.T, hs));
     } else {
       if (fuse_apply)
-        HIG_TRY(hig_linattn_apply_sty(lb + w.qc, d, tc + tl.layer0 + tl.lstride * l + tl.Ac, PL(params, l, HIG_L_CA_STY_NORM_W),
-                                      PL(params, l, HIG_L_CA_STY_NORM_B), ssl + 2 * d, ss_ld, d, lb + w.a2, d, D.B, D.T, D.H, D.hd,
-                                      stream));
+        HIG_L(hig_linattn_apply_sty(R(w.qc, d), d, Acl, PL(params, l, HIG_L_CA_STY_NORM_W),
+                                    PL(params, l, HIG_L_CA_STY_NORM_B), ssl + 2 * d, ss_ld, d, R(w.a2, d), d, nb, D.T, D.H, D.hd, hs));
       else
-        HIG_TRY(hig_linattn_apply(lb + w.qc, d, tc + tl.layer0 + tl.lstride * l + tl.Ac, lb + w.y2, d, D.B, D.T,
-                                  D.H, D.hd, stream));
+        HIG_L(hig_linattn_apply(R(w.qc, d), d, Acl, R(w.y2, d), d, nb, D.T, D.H, D.hd, hs));
     }
     if (!fuse_apply)
-      HIG_TRY(hig_ln_mod_silu(lb + w.y2, d, M, d, PL(params, l, HIG_L_CA_STY_NORM_W), PL(params, l, HIG_L_CA_STY_NORM_B),
-                              ssl + 2 * d, ss_ld, d, D.T, lb + w.a2, d, lb + w.st4, stream));
-    HIG_TRY(hig_gemm_launch(G(lb + w.a2, d, 0, PL(params, l, HIG_L_CA_STY_OUT_W), d, 0, lb + w.h2, d, M, d, d)
-                                .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_CA_STY_OUT_B)).res(lb + w.h1, d).prec(D.prec).g, 1, nullptr, st));
-    const float* hffn = lb + w.h2;
+      HIG_L(hig_ln_mod_silu(R(w.y2, d), d, Mh, d, PL(params, l, HIG_L_CA_STY_NORM_W), PL(params, l, HIG_L_CA_STY_NORM_B),
+                            ssl + 2 * d, ss_ld, d, D.T, R(w.a2, d), d, R(w.st4, 2), hs));
+    HIG_L(hig_gemm_launch(G(R(w.a2, d), d, 0, PL(params, l, HIG_L_CA_STY_OUT_W), d, 0, R(w.h2, d), d, Mh, d, d)
+                              .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_CA_STY_OUT_B)).res(R(w.h1, d), d).prec(D.prec).g, 1, nullptr, s));
+    const float* hffn = R(w.h2, d);
+    int64_t hffn_off = w.h2;
     if (D.two == 1) {
       // ---- person <-> person linear cross attention (interaction_transformer.py:181-205): queries from
       // the own stream, key/value from the partner's (same LayerNorm on both), key softmax masked with
-      // the consumer's length, value unmasked (masked rows carry k == 0 anyway)
-      HIG_TRY(hig_layernorm(lb + w.h2, d, M, d, PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B),
-                            lb + w.xn3, d, lb + w.st6, stream));
-      HIG_TRY(hig_gemm_launch(G(lb + w.xn3, d, 0, PL(params, l, HIG_L_INT_QKV_W), d, 0, lb + w.iqkv, 3 * d, M, 3 * d, d)
-                                  .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_INT_QKV_B)).prec(D.prec).g, 1, nullptr, st));
-      HIG_TRY(hig_linattn_ctx(lb + w.iqkv + d, lb + w.iqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, len_partner,
-                              lb + w.Ai, lb + w.ksti, ws + w.cscr, stream));
+      // the consumer's length, value unmasked (masked rows carry k == 0 anyway).  Whole batch only (b0 == 0): the two
+      // persons of a pair sit in different halves of the batch.
+      HIG_L(hig_layernorm(lb + w.h2, d, M, d, PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B),
+                          lb + w.xn3, d, lb + w.st6, hs));
+      HIG_L(hig_gemm_launch(G(lb + w.xn3, d, 0, PL(params, l, HIG_L_INT_QKV_W), d, 0, lb + w.iqkv, 3 * d, M, 3 * d, d)
+                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_INT_QKV_B)).prec(D.prec).g, 1, nullptr, s));
+      HIG_L(hig_linattn_ctx(lb + w.iqkv + d, lb + w.iqkv + 2 * d, 3 * d, D.B, D.T, D.H, D.hd, len_partner,
+                            lb + w.Ai, lb + w.ksti, cscr, hs));
       const int64_t halfA = (int64_t)Bp * D.H * D.hd * D.hd, halfM = (int64_t)Bp * D.T;
-      HIG_TRY(hig_linattn_apply(lb + w.iqkv, 3 * d, lb + w.Ai + halfA, lb + w.y4, d, Bp, D.T, D.H, D.hd, stream));
-      HIG_TRY(hig_linattn_apply(lb + w.iqkv + halfM * 3 * d, 3 * d, lb + w.Ai, lb + w.y4 + halfM * d, d, Bp, D.T, D.H,
-                                D.hd, stream));
-      HIG_TRY(hig_ln_mod_silu(lb + w.y4, d, M, d, PL(params, l, HIG_L_INT_STY_NORM_W), PL(params, l, HIG_L_INT_STY_NORM_B),
-                              ssl + 4 * d, ss_ld, d, D.T, lb + w.a4, d, lb + w.st7, stream));
-      HIG_TRY(hig_gemm_launch(G(lb + w.a4, d, 0, PL(params, l, HIG_L_INT_STY_OUT_W), d, 0, lb + w.h2b, d, M, d, d)
-                                  .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_INT_STY_OUT_B)).res(lb + w.h2, d).prec(D.prec).g,
-                              1, nullptr, st));
+      HIG_L(hig_linattn_apply(lb + w.iqkv, 3 * d, lb + w.Ai + halfA, lb + w.y4, d, Bp, D.T, D.H, D.hd, hs));
+      HIG_L(hig_linattn_apply(lb + w.iqkv + halfM * 3 * d, 3 * d, lb + w.Ai, lb + w.y4 + halfM * d, d, Bp, D.T, D.H,
+                              D.hd, hs));
+      HIG_L(hig_ln_mod_silu(lb + w.y4, d, M, d, PL(params, l, HIG_L_INT_STY_NORM_W), PL(params, l, HIG_L_INT_STY_NORM_B),
+                            ssl + 4 * d, ss_ld, d, D.T, lb + w.a4, d, lb + w.st7, hs));
+      HIG_L(hig_gemm_launch(G(lb + w.a4, d, 0, PL(params, l, HIG_L_INT_STY_OUT_W), d, 0, lb + w.h2b, d, M, d, d)
+                                .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_INT_STY_OUT_B)).res(lb + w.h2, d).prec(D.prec).g,
+                            1, nullptr, s));
       hffn = lb + w.h2b;
+      hffn_off = w.h2b;
     }
+    (void)hffn_off;
     // ---- FFN ------------------------------------------------------------------------
-    HIG_TRY(hig_gemm_launch(G(hffn, d, 0, PL(params, l, HIG_L_FFN_W1), d, 0, lb + w.f1, D.ff, M, D.ff, d)
-                                .epi(HIG_EPI_BIAS_GELU, PL(params, l, HIG_L_FFN_B1))
-                                .aux(training ? lb + w.z1 : nullptr, D.ff).prec(D.prec).g, 1, nullptr, st));
-    HIG_TRY(hig_gemm_launch(G(lb + w.f1, D.ff, 0, PL(params, l, HIG_L_FFN_W2), D.ff, 0, lb + w.y3, d, M, d, D.ff)
-                                .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B2)).prec(D.prec).g, 1, nullptr, st));
-    HIG_TRY(hig_ln_mod_silu(lb + w.y3, d, M, d, PL(params, l, HIG_L_FFN_STY_NORM_W), PL(params, l, HIG_L_FFN_STY_NORM_B),
-                            ss_ffn, ss_ld, d, D.T, lb + w.a3, d, lb + w.st5, stream));
-    HIG_TRY(hig_gemm_launch(G(lb + w.a3, d, 0, PL(params, l, HIG_L_FFN_STY_OUT_W), d, 0, lb + w.h3, d, M, d, d)
-                                .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_FFN_STY_OUT_B)).res(hffn, d).prec(D.prec).g, 1, nullptr, st));
-    hin = lb + w.h3;
+    HIG_L(hig_gemm_launch(G(hffn, d, 0, PL(params, l, HIG_L_FFN_W1), d, 0, R(w.f1, D.ff), D.ff, Mh, D.ff, d)
+                              .epi(HIG_EPI_BIAS_GELU, PL(params, l, HIG_L_FFN_B1))
+                              .aux(training ? R(w.z1, D.ff) : nullptr, D.ff).prec(D.prec).g, 1, nullptr, s));
+    HIG_L(hig_gemm_launch(G(R(w.f1, D.ff), D.ff, 0, PL(params, l, HIG_L_FFN_W2), D.ff, 0, R(w.y3, d), d, Mh, d, D.ff)
+                              .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B2)).prec(D.prec).g, 1, nullptr, s));
+    HIG_L(hig_ln_mod_silu(R(w.y3, d), d, Mh, d, PL(params, l, HIG_L_FFN_STY_NORM_W), PL(params, l, HIG_L_FFN_STY_NORM_B),
+                          ss_ffn, ss_ld, d, D.T, R(w.a3, d), d, R(w.st5, 2), hs));
+    HIG_L(hig_gemm_launch(G(R(w.a3, d), d, 0, PL(params, l, HIG_L_FFN_STY_OUT_W), d, 0, R(w.h3, d), d, Mh, d, d)
+                              .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_FFN_STY_OUT_B)).res(hffn, d).prec(D.prec).g, 1, nullptr, s));
+#undef HIG_L
+    return lb + w.h3;
+  };
+  // K6: out = Linear(d, F)(h_L) for the samples [b0, b0 + nb)
+  auto out_proj = [&](const float* hin_full, int b0, int nb, hipStream_t s) -> int {
+    const int64_t r0 = (int64_t)b0 * D.T;
+    return hig_gemm_launch(G(hin_full + r0 * d, d, 0, P(params, HIG_P_OUT_W), d, 0, out + r0 * D.F, D.F, (int64_t)nb * D.T, D.F, d)
+                               .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT_B)).prec(D.prec).g, 1, nullptr, s);
+  };
+
+  // Two halves of the batch on two streams (single-person model, enough rows): the second half runs on the library's
+  // side stream, forked after the per-sample prologue and joined before returning (events only: capturable).  An
+  // in-order stream leaves the chip idle in every kernel's tail and ramp-up; two independent chains of the same
+  // kernels fill those gaps (two whole forwards side by side: 5.85 ms each against 6.6 alone).
+  static const int split_env = getenv("HIG_FWD_SPLIT") ? atoi(getenv("HIG_FWD_SPLIT")) : 1;   // tuning knob
+  SideStream* side = (split_env && !D.two && D.B >= 16 && M >= 4096) ? side_stream_for_current_device(st) : nullptr;
+  if (side) {   // eager launches only: replayed from a hipGraph the two branches cost more than they gain (captured
+                // training step 21.2 -> 22.2 ms, against 20.4 -> 20.2 ms eager; forward 6.23 -> 6.10 ms eager)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) side = nullptr;
   }
-  // K6: out = Linear(d, F)(h_L)
-  HIG_TRY(hig_gemm_launch(G(hin, d, 0, P(params, HIG_P_OUT_W), d, 0, out, D.F, M, D.F, d)
-                              .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT_B)).prec(D.prec).g, 1, nullptr, st));
+  const float* hin = ws + w.h0;
+  if (side) {
+    const int nbA = D.B / 2, nbB = D.B - nbA;
+    if (hipMemsetAsync(ws + w.gtail2, 0, HIG_GEMM_TAIL_CNT_BYTES, st) != hipSuccess)
+      return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+    if (hipEventRecord(side->ready, st) != hipSuccess || hipStreamWaitEvent(side->s2, side->ready, 0) != hipSuccess)
+      return hig_set_error(HIG_EHIP, "forward fork failed");
+    for (int l = 0; l < D.L; ++l) {
+      hig_gemm_set_tail_scratch(ws + w.gtail, HIG_GEMM_TAIL_BYTES);
+      const float* ha = layer(l, hin, 0, nbA, st, ws + w.cscr);
+      hig_gemm_set_tail_scratch(ws + w.gtail2, HIG_GEMM_TAIL_BYTES);
+      const float* hb = layer(l, hin, nbA, nbB, side->s2, ws + w.cscr2);
+      if (!ha || !hb) return HIG_EHIP;
+      hin = ha;
+    }
+    hig_gemm_set_tail_scratch(ws + w.gtail, HIG_GEMM_TAIL_BYTES);
+    HIG_TRY(out_proj(hin, 0, nbA, st));
+    hig_gemm_set_tail_scratch(ws + w.gtail2, HIG_GEMM_TAIL_BYTES);
+    HIG_TRY(out_proj(hin, nbA, nbB, side->s2));
+    hig_gemm_set_tail_scratch(ws + w.gtail, HIG_GEMM_TAIL_BYTES);
+    if (hipEventRecord(side->done[0], side->s2) != hipSuccess || hipStreamWaitEvent(st, side->done[0], 0) != hipSuccess)
+      return hig_set_error(HIG_EHIP, "forward join failed");
+    return HIG_OK;
+  }
+  for (int l = 0; l < D.L; ++l) {
+    hin = layer(l, hin, 0, D.B, st, ws + w.cscr);
+    if (!hin) return HIG_EHIP;
+  }
+  HIG_TRY(out_proj(hin, 0, D.B, st));
   if (D.two)  // init-pose rows go through out2 instead (:613-614)
     HIG_TRY(hig_gemm_launch(G(hin, (int64_t)D.T * d, 0, P(params, HIG_P_OUT2_W), d, 0, out, (int64_t)D.T * D.F, D.B, D.F, d)
                                 .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT2_B)).g, 1, nullptr, st));
@@ -766,49 +874,6 @@ namespace {
 //   in DESIGN.md section 4), and the saved forward activations are never written during backward;
 //   join = the caller's stream waits for the last done event.
 // HIG_BWD_OVERLAP=0 keeps everything on the caller's stream.
-struct SideStream {
-  hipStream_t s2 = nullptr;
-  hipEvent_t ready = nullptr;
-  hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool ok = false, failed = false;
-};
-
-constexpr int kMaxDev = 16;
-SideStream* side_stream_table() {
-  static thread_local SideStream tab[kMaxDev];
-  return tab;
-}
-
-hipEvent_t& layer_event() {   // hig_denoiser_bwd_hooked: "layer l is enqueued" marker on the caller's stream
-  static thread_local hipEvent_t ev = nullptr;
-  return ev;
-}
-
-SideStream* side_stream_for_current_device(hipStream_t caller) {
-  static const int enabled = getenv("HIG_BWD_OVERLAP") ? atoi(getenv("HIG_BWD_OVERLAP")) : 1;
-  if (!enabled) return nullptr;
-  SideStream* tab = side_stream_table();
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
-  SideStream& s = tab[dev];
-  if (s.failed) return nullptr;
-  if (!s.ok) {
-    // first use on this thread / device.  Creating a stream is not something to do under capture: a caller that
-    // captures its very first backward (no eager warm-up) simply gets the single-stream order for that graph.
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(caller, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
-    bool good = hipStreamCreateWithFlags(&s.s2, hipStreamNonBlocking) == hipSuccess;
-    good = good && hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < 4 && good; ++i) good = hipEventCreateWithFlags(&s.done[i], hipEventDisableTiming) == hipSuccess;
-    if (!good) {   // do not retry (and leak) on every call: stay on the caller's stream for good
-      s.failed = true;
-      return nullptr;
-    }
-    s.ok = true;
-  }
-  return &s;
-}
-
 struct WgradFork {
   SideStream* side;
   hipStream_t main;
