@@ -602,7 +602,7 @@ namespace {
 inline int64_t alb(int64_t bytes) { return (bytes + 255) & ~(int64_t)255; }
 
 struct Fwd16Layout {
-  int64_t te32, te16, teh16, semb16, ss, h32, h, xn, qkv, A1, kst1, cscr, y, a, qc, f1, lenp, tok0, total;
+  int64_t te32, te16, teh16, semb16, ss, h32, h, xn, qkv, A1, At1, kst1, cscr, y, a, qc, f1, lenp, tok0, total;
 };
 Fwd16Layout fwd16_layout(const Dims& D) {
   Fwd16Layout w;
@@ -619,6 +619,7 @@ Fwd16Layout fwd16_layout(const Dims& D) {
   w.xn = take(D.M * D.d * 2);
   w.qkv = take(D.M * 3 * D.d * 2);
   w.A1 = take((int64_t)D.B * D.H * D.hd * D.hd * 4);
+  w.At1 = take((int64_t)D.B * D.H * D.hd * D.hd * 2);   // the same, transposed, bf16 (linattn16.hip)
   w.kst1 = take((int64_t)D.B * D.d * 2 * 4);
   w.cscr = take(hig_linattn_ctx_scratch_floats(D.B, D.T, D.H, D.hd) * 4);
   w.y = take(D.M * D.d * 2);
@@ -642,7 +643,7 @@ __global__ void cast_rows_bf16_kernel(const float* __restrict__ src, int64_t lds
 }
 
 struct Text16Layout {
-  int64_t xfn, kv, kv_stride, cscr, layer0, lstride, Ac, kstc, total;
+  int64_t xfn, kv, kv_stride, cscr, layer0, lstride, Ac, Atc, kstc, total;
 };
 Text16Layout text16_layout(const Dims& D) {
   Text16Layout t;
@@ -656,6 +657,7 @@ Text16Layout text16_layout(const Dims& D) {
   t.layer0 = o;
   o = 0;
   t.Ac = take((int64_t)D.B * D.H * D.hd * D.hd * 4);
+  t.Atc = take((int64_t)D.B * D.H * D.hd * D.hd * 2);   // transposed bf16 copy (linattn16.hip)
   t.kstc = take((int64_t)D.B * D.d * 2 * 4);
   t.lstride = o;
   t.total = t.layer0 + t.lstride * D.L;
@@ -704,7 +706,7 @@ extern "C" int hig_text_context_bf16(const hig_dims* dims, const void* const* pa
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_KV_B)).g, st));
     if (!D.full)
       HIG_TRY(hig_linattn_ctx_bf16(kv, kv + (int64_t)D.d * 2, 2 * D.d, D.B, D.N, D.H, D.hd, nullptr, Ac, kstc,
-                                   reinterpret_cast<float*>(base + tl.cscr), stream));
+                                   reinterpret_cast<float*>(base + tl.cscr), base + tl.layer0 + tl.lstride * l + tl.Atc, stream));
   }
   return HIG_OK;
 }
@@ -791,14 +793,21 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   // the SiLU are ONE kernel (y never leaves the chip); otherwise apply + row kernel.
   // (opt-in: measured equal at B = 64 and 4 % slower at B = 32 -- its fp32 MFMAs serialise 128 per wave behind poorly
   // coalesced query loads; profiles/r02_notes.md)
-  static const int fuse_env = getenv("HIG_FUSE_APPLY") ? atoi(getenv("HIG_FUSE_APPLY")) : 0;   // tuning knob
-  const bool fuse_apply = fuse_env && (D.H == 4 || D.H == 8);
-  auto attend = [&](int l, int slot, const void* q, int64_t ldq, const float* ctx, int norm_w, int norm_b, int out_w,
-                    int out_b) -> int {
+  // HIG_FUSE_APPLY: 2 (default) = the bf16-matrix-core kernel of linattn16.hip where it is built (head dim 64), 1 = the
+  // fp32-MFMA fused kernel, 0 = apply + row kernel
+  static const int fuse_env = getenv("HIG_FUSE_APPLY") ? atoi(getenv("HIG_FUSE_APPLY")) : 2;   // tuning knob
+  const bool fuse_mm16 = fuse_env == 2 && D.hd == 64 && (D.H == 4 || D.H == 8);
+  const bool fuse_apply = (fuse_env == 1 || fuse_mm16) && (D.H == 4 || D.H == 8);
+  auto attend = [&](int l, int slot, const void* q, int64_t ldq, const float* ctx, const void* ctx_t16, int norm_w, int norm_b,
+                    int out_w, int out_b) -> int {
     if (fuse_apply) {
       const float* ssl = ss + (int64_t)(D.nsty * l + slot) * 2 * d;
-      HIG_TRY(hig_linattn_apply_sty_bf16(q, ldq, ctx, PL(params, l, norm_w), PL(params, l, norm_b), ssl, ss_ld, d, a, d,
-                                         D.B, D.T, D.H, D.hd, stream));
+      if (fuse_mm16)
+        HIG_TRY(hig_linattn_apply_sty_mm16(q, ldq, ctx_t16, PL(params, l, norm_w), PL(params, l, norm_b), ssl, ss_ld, d, a, d,
+                                           D.B, D.T, D.H, D.hd, stream));
+      else
+        HIG_TRY(hig_linattn_apply_sty_bf16(q, ldq, ctx, PL(params, l, norm_w), PL(params, l, norm_b), ssl, ss_ld, d, a, d,
+                                           D.B, D.T, D.H, D.hd, stream));
       return sty_out(l, out_w, out_b);
     }
     HIG_TRY(hig_linattn_apply_bf16(q, ldq, ctx, y, d, D.B, D.T, D.H, D.hd, stream));
@@ -815,8 +824,8 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
       HIG_TRY(stylize(l, 0, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B));
     } else {
       HIG_TRY(hig_linattn_ctx_bf16(qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, D.H, D.hd, length, A1, kst1,
-                                   cscr, stream));
-      HIG_TRY(attend(l, 0, qkv, 3 * d, A1, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B));
+                                   cscr, ws + w.At1, stream));
+      HIG_TRY(attend(l, 0, qkv, 3 * d, A1, ws + w.At1, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B));
     }
     // ---- cross attention to the text context (transformer.py:135-155) ----
     HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B), nullptr, 0, 0, 0, xn, d, stream));
@@ -828,7 +837,7 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
       HIG_TRY(stylize(l, 1, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B));
     } else {
       HIG_TRY(attend(l, 1, qc, d, reinterpret_cast<const float*>(tc + tl.layer0 + tl.lstride * l + tl.Ac),
-                     HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B));
+                     tc + tl.layer0 + tl.lstride * l + tl.Atc, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B));
     }
     if (D.two == 1) {
       // ---- person <-> person linear cross attention (interaction_transformer.py:181-205): queries from the own
@@ -837,7 +846,7 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
       HIG_TRY(hig_gemm16_launch(G16(xn, d, PL16(params16, l, HIG_L_INT_QKV_W), d, qkv, 3 * d, M, 3 * d, d)
                                     .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_INT_QKV_B)).g, st));
       HIG_TRY(hig_linattn_ctx_bf16(qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, D.H, D.hd, len_partner, A1, kst1,
-                                   cscr, stream));
+                                   cscr, nullptr, stream));
       const int64_t halfA = (int64_t)Bp * D.H * D.hd * D.hd, halfM = (int64_t)Bp * D.T;
       HIG_TRY(hig_linattn_apply_bf16(qkv, 3 * d, A1 + halfA, y, d, Bp, D.T, D.H, D.hd, stream));
       HIG_TRY(hig_linattn_apply_bf16(qkv + halfM * 3 * d * 2, 3 * d, A1, static_cast<char*>(y) + halfM * d * 2, d, Bp, D.T, D.H, D.hd,

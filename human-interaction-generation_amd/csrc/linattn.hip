@@ -327,7 +327,7 @@ template <int HD, typename TIO>
 __global__ __launch_bounds__(256) void ctx_mfma_kernel(const TIO* __restrict__ K, const TIO* __restrict__ V,
                                                        int64_t ld, int rows, int H,
                                                        const int64_t* __restrict__ length, float* __restrict__ A,
-                                                       float* __restrict__ kstat) {
+                                                       float* __restrict__ kstat, __bf16* __restrict__ At16) {
   constexpr int LDP = HD + 4, TB = HD / 64, Q4 = HD / 4, NRG = 256 / Q4, PER = CH / NRG;
   __shared__ __attribute__((aligned(16))) float sP[CH * LDP];   // [r][c] = exp(K - running max)
   __shared__ __attribute__((aligned(16))) float sV[CH * LDP];   // [r][l]
@@ -445,6 +445,15 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const TIO* __restrict__ K
     float* ap = A + (int64_t)blockIdx.x * HD * HD + cc * HD + wj * (HD / 2) + 4 * lh;
 #pragma unroll
     for (int tj = 0; tj < TB; ++tj) store16(ap + 32 * tj, acc[ti][tj], inv);
+    if (At16) {   // the same matrix transposed and rounded, At[l][c] = bf16(A[c][l]): the MFMA row operand of linattn16.hip
+#pragma unroll
+      for (int tj = 0; tj < TB; ++tj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int l = wj * (HD / 2) + 32 * tj + 8 * (e >> 2) + 4 * lh + (e & 3);
+          At16[((int64_t)blockIdx.x * HD + l) * HD + cc] = (__bf16)(acc[ti][tj][e] * inv);
+        }
+    }
   }
 }
 
@@ -551,7 +560,8 @@ __global__ __launch_bounds__(256) void ctx_part_mfma_kernel(const TIO* __restric
 
 template <int HD>
 __global__ __launch_bounds__(256) void ctx_combine_kernel(const float* __restrict__ part, int nchunk,
-                                                          float* __restrict__ A, float* __restrict__ kstat) {
+                                                          float* __restrict__ A, float* __restrict__ kstat,
+                                                          __bf16* __restrict__ At16) {
   constexpr int PS = HD * HD + 2 * HD;
   __shared__ float sw[16][HD];        // weight of chunk j for channel c (nchunk <= 16 per pass)
   __shared__ float sinv[HD];
@@ -591,6 +601,11 @@ __global__ __launch_bounds__(256) void ctx_combine_kernel(const float* __restric
       if (j0 + nj >= nchunk) {
         const float inv = sinv[c];
         a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
+        if (At16) {
+          const int l0 = (idx * 4) % HD;
+          __bf16* at = At16 + ((int64_t)blockIdx.x * HD + l0) * HD + c;
+          at[0] = (__bf16)a.x; at[HD] = (__bf16)a.y; at[2 * HD] = (__bf16)a.z; at[3 * HD] = (__bf16)a.w;
+        }
       }
       reinterpret_cast<float4*>(Ab)[idx] = a;
     }
@@ -1159,7 +1174,7 @@ extern "C" int64_t hig_linattn_ctx_scratch_floats(int32_t B, int32_t rows, int32
 namespace {
 template <typename TIO>
 int linattn_ctx_t(const TIO* K, const TIO* V, int64_t ld, int32_t B, int32_t rows, int32_t H, int32_t hd,
-                  const int64_t* length, float* A, float* kstat, float* scratch, hipStream_t st) {
+                  const int64_t* length, float* A, float* kstat, float* scratch, hipStream_t st, __bf16* At16 = nullptr) {
   const int nchunk = (rows + CH - 1) / CH;
   static const int ctx_walk = getenv("HIG_CTX_WALK") ? atoi(getenv("HIG_CTX_WALK")) : 1;   // tuning knob
   const bool walk = ctx_walk && B * H >= 256;   // enough (sample, head) pairs to fill the chip with walking workgroups
@@ -1168,19 +1183,19 @@ int linattn_ctx_t(const TIO* K, const TIO* V, int64_t ld, int32_t B, int32_t row
     if (hd == 64) {
       hipLaunchKernelGGL((ctx_part_mfma_kernel<64, TIO>), dim3(B * H, nchunk), dim3(256), 0, st, K, V, ld, rows, H, length,
                          scratch);
-      hipLaunchKernelGGL(ctx_combine_kernel<64>, dim3(B * H), dim3(256), 0, st, scratch, nchunk, A, kstat);
+      hipLaunchKernelGGL(ctx_combine_kernel<64>, dim3(B * H), dim3(256), 0, st, scratch, nchunk, A, kstat, At16);
     } else {
       hipLaunchKernelGGL((ctx_part_mfma_kernel<128, TIO>), dim3(B * H, nchunk), dim3(256), 0, st, K, V, ld, rows, H, length,
                          scratch);
-      hipLaunchKernelGGL(ctx_combine_kernel<128>, dim3(B * H), dim3(256), 0, st, scratch, nchunk, A, kstat);
+      hipLaunchKernelGGL(ctx_combine_kernel<128>, dim3(B * H), dim3(256), 0, st, scratch, nchunk, A, kstat, At16);
     }
     HIG_CHECK_LAUNCH();
     return HIG_OK;
   }
   if (hd == 64)
-    hipLaunchKernelGGL((ctx_mfma_kernel<64, TIO>), dim3(B * H), dim3(256), 0, st, K, V, ld, rows, H, length, A, kstat);
+    hipLaunchKernelGGL((ctx_mfma_kernel<64, TIO>), dim3(B * H), dim3(256), 0, st, K, V, ld, rows, H, length, A, kstat, At16);
   else
-    hipLaunchKernelGGL((ctx_mfma_kernel<128, TIO>), dim3(B * H), dim3(256), 0, st, K, V, ld, rows, H, length, A, kstat);
+    hipLaunchKernelGGL((ctx_mfma_kernel<128, TIO>), dim3(B * H), dim3(256), 0, st, K, V, ld, rows, H, length, A, kstat, At16);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
@@ -1459,14 +1474,14 @@ int launch_apply_sty(const TQ* q, int64_t ldq, const float* A, const float* gamm
 // softmax statistics stay fp32.  Head dim 64 or 128 (the MFMA kernels).
 extern "C" int hig_linattn_ctx_bf16(const void* K, const void* V, int64_t ld, int32_t B, int32_t rows, int32_t H,
                                     int32_t hd, const int64_t* length, float* A, float* kstat, float* scratch,
-                                    hig_stream_t stream) {
+                                    void* At16, hig_stream_t stream) {
   HIG_REQUIRE(K && V && A && kstat && B > 0 && rows > 0 && H > 0, "hig_linattn_ctx_bf16: bad arguments");
   if (hd != 64 && hd != 128)
     return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn: bf16 storage is built for head dim 64 / 128 (got %d)", hd);
   HIG_REQUIRE(ld % 4 == 0 && (reinterpret_cast<uintptr_t>(K) & 7) == 0 && (reinterpret_cast<uintptr_t>(V) & 7) == 0,
               "hig_linattn_ctx_bf16: K/V must be 8-byte aligned");
   return linattn_ctx_t<__bf16>(static_cast<const __bf16*>(K), static_cast<const __bf16*>(V), ld, B, rows, H, hd, length, A,
-                               kstat, scratch, hig_stream(stream));
+                               kstat, scratch, hig_stream(stream), static_cast<__bf16*>(At16));
 }
 extern "C" int hig_linattn_apply_bf16(const void* Q, int64_t ldq, const float* A, void* Y, int64_t ldy, int32_t B,
                                       int32_t rows, int32_t H, int32_t hd, hig_stream_t stream) {

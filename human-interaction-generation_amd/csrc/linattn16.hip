@@ -1,0 +1,249 @@
+// bf16-storage linear attention, second half, as ONE kernel on the bf16 matrix cores:
+//     Out = silu( LN_d( softmax_hd(Q) . A ) * (1 + scale) + shift )                       (bf16 in, bf16 out)
+// i.e. `y = q A` of LinearTemporalSelfAttention / LinearTemporalCrossAttention (codes/models/transformer.py:111,116-117 and
+// :147,152-153) followed by the front of the StylizationBlock that consumes it (:81-85: LayerNorm, (1 + scale) / shift
+// from the time/text embedding, SiLU).  The (rows, d) attention output never reaches memory.
+//
+// Why a new kernel.  The bf16 forward ran hig_linattn_apply_bf16 (fp32 MFMA, 64 cycles each: 11.0 us at B = 32) and
+// then hig_ln_bf16 (5.7 us): sixteen such pairs are 270 us of the 1.29 ms sampling step, each launch 3-5x above its
+// bandwidth time (profiles/r03_kernel_stats_bf16_sampling_step.csv).  The fp32-MFMA fused kernel (apply_sty_kernel) was
+// not faster than the pair.  Here the hd x hd products run on v_mfma_f32_32x32x16_bf16 (1/16 of the fp32 MFMA time),
+// a workgroup owns 32 whole rows (all heads), so the LayerNorm statistics are a register / LDS reduction, and every
+// global access is a whole 1-KiB row: the Q tile comes in by LDS-DMA (global_load_lds_dwordx4, XOR swizzle on the
+// source address and on the read address), the result leaves through LDS as whole rows.
+//
+// CDNA4 mapping.  256 threads = 4 waves; wave w owns heads w, w + 4 (H = 8) of the 32 rows.  MFMA: the context matrix is
+// the row ("weight") operand, transposed -- At[l][c] = A[c][l], bf16, staged in LDS once per workgroup for all heads --
+// and softmax(q) the column operand straight from registers: the lane that holds row lr of a q fragment (8 channels)
+// shares the row with lane lr + 32, so the row maximum / sum are one cross-lane exchange.  The accumulator leaves a
+// lane 4 consecutive output columns per quad of ONE row: LayerNorm statistics = lane sums + one exchange + a 4-wave
+// LDS reduction.  softmax(q) and A are rounded to bf16 for the product (fp32 accumulate): the same rounding the bf16
+// storage mode applies to every other matrix operand.
+#include <stdlib.h>
+
+#include "gemm16_epi.h"
+#include "hig_host.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// HD: head dim (64); H: heads (4 or 8); rows of Q / Out are d = H * HD bf16 wide.  grid = (ceil(T / 32), B).
+template <int HD, int H>
+__global__ __launch_bounds__(256) void apply_sty16_kernel(const __bf16* __restrict__ Q, int64_t ldq,
+                                                          const __bf16* __restrict__ At16, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ ss,
+                                                          int64_t ss_ld, int shift_off, __bf16* __restrict__ Out, int64_t ldo,
+                                                          int T) {
+  constexpr int D_ = H * HD;                   // model width
+  constexpr int ROWB = D_ * 2;                 // bytes of a Q / Out row
+  constexpr int BR = 32;                       // rows per workgroup
+  constexpr int HPW = H / 4;                   // heads per wave
+  constexpr int NKS = HD / 16, NLB = HD / 32;  // MFMA k-steps / 32-column blocks per head
+  constexpr int QBYTES = BR * ROWB;
+  constexpr int ATROWB = HD * 2;               // bytes of an At row (one l, all c)
+  constexpr int ATBYTES = H * HD * ATROWB;
+  static_assert(HD == 64, "At swizzle below is written for 128-byte rows");
+  static_assert(ROWB == 1024 || ROWB == 512, "Q rows of 512 or 1024 bytes");
+  __shared__ __attribute__((aligned(1024))) char smem[QBYTES + ATBYTES + 4 * D_ * 4 + 4 * BR * 2 * 4];
+  char* const sQ = smem;                                       // [32][ROWB] bf16, 16-byte chunk c of row r at c ^ (r & 15); later the output tile
+  char* const sAt = smem + QBYTES;                             // [H * HD][128 B] bf16, chunk c of row r at c ^ ((r >> 1) & 7)
+  float* const sPar = reinterpret_cast<float*>(smem + QBYTES + ATBYTES);   // gamma | beta | scale | shift
+  float* const sRed = sPar + 4 * D_;                           // [4 waves][32 rows][2]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y, r0 = blockIdx.x * BR;
+  const __bf16* Qb = Q + (int64_t)b * T * ldq;
+
+  // ---- Q tile by DMA: whole rows, swizzled on the source side ---------------------------------------------------
+  {
+    constexpr int NDMA = QBYTES / 1024, NQ = NDMA / 4;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int n = wave + 4 * q;
+      const __bf16* src;
+      if constexpr (ROWB == 1024) {
+        src = Qb + (int64_t)min(r0 + n, T - 1) * ldq + 8 * (lane ^ (n & 15));
+      } else {
+        const int r = 2 * n + (lane >> 5);
+        src = Qb + (int64_t)min(r0 + r, T - 1) * ldq + 8 * ((lane & 31) ^ (r & 15));
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sQ + n * 1024), 16, 0, 0);
+    }
+  }
+  // ---- gamma | beta | scale | shift (fp32, D_ each) by DMA as well: no VGPR-returning load in this kernel, so hipcc has
+  // nothing to guard with a vmcnt(0) of its own while the DMAs are in flight ------------------------------------------
+  {
+    constexpr int NP = 4 * D_ * 4 / 1024;        // 1-KiB instructions for the four vectors
+    static_assert(NP % 4 == 0 && (D_ * 4) % 1024 == 0, "parameter vectors in whole 1-KiB pieces");
+    const float* ssb = ss + (int64_t)b * ss_ld;
+#pragma unroll
+    for (int q = 0; q < NP / 4; ++q) {
+      const int n = wave + 4 * q;               // piece n: vector n / (D_ / 256), part n % (D_ / 256)
+      const int vec = n / (D_ / 256), part = n % (D_ / 256);
+      const float* base = vec == 0 ? gamma : vec == 1 ? beta : vec == 2 ? ssb : ssb + shift_off;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + part * 256 + lane * 4),
+                                       (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(sPar) + n * 1024), 16, 0, 0);
+    }
+  }
+  // ---- context matrices of this sample, At16[b][h][l][c] (hig_linattn_ctx_bf16 wrote them transposed and rounded): all
+  // H heads by DMA, 8 rows of 128 bytes per instruction, chunk c of row r to position c ^ ((r >> 1) & 7) ----------------
+  {
+    const __bf16* Ab = At16 + (int64_t)b * H * HD * HD;
+    constexpr int NA = ATBYTES / 1024 / 4;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int n = wave + 4 * q;
+      const int row = 8 * n + (lane >> 3), pos = lane & 7;
+      const __bf16* src = Ab + (int64_t)row * HD + 8 * (pos ^ ((row >> 1) & 7));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sAt + n * 1024), 16, 0, 0);
+    }
+  }
+  // (requests so far, oldest first: Q tile, LayerNorm / modulation vectors, context matrices.  The softmax below needs
+  // only the Q tile: it runs while the 64 KB of context matrices are still landing.)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ATBYTES / 1024 / 4) : "memory");
+  __syncthreads();
+
+  // ---- per head: softmax over the head's channels (a row is shared by lanes lr and lr + 32), then y = p . A ----------
+  f32x16 acc[HPW][NLB];
+  float s1 = 0.f, s2 = 0.f;                    // this lane's share of sum(y), sum(y^2) over its row
+  bf16x8 pfs[HPW][NKS];
+#pragma unroll
+  for (int hh = 0; hh < HPW; ++hh) {
+    const int h = wave + 4 * hh;
+    u32x4 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int chunk = (h * HD) / 8 + 2 * ks + lh;
+      qf[ks] = *reinterpret_cast<const u32x4*>(sQ + lr * ROWB + 16 * (chunk ^ (lr & 15)));
+    }
+    float v[NKS][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[ks][2 * e] = bf_lo(qf[ks][e]);
+        v[ks][2 * e + 1] = bf_hi(qf[ks][e]);
+        mx = fmaxf(mx, fmaxf(v[ks][2 * e], v[ks][2 * e + 1]));
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[ks][e] = __expf(v[ks][e] - mx);
+        sum += v[ks][e];
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pfs[hh][ks][e] = (__bf16)(v[ks][e] * inv);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the context matrices have landed
+  __syncthreads();
+#pragma unroll
+  for (int hh = 0; hh < HPW; ++hh) {
+    const int h = wave + 4 * hh;
+#pragma unroll
+    for (int lb = 0; lb < NLB; ++lb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[hh][lb][e] = 0.f;
+      const int row = h * HD + 32 * lb + lr;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(sAt + row * ATROWB + 16 * ((2 * ks + lh) ^ ((row >> 1) & 7)));
+        acc[hh][lb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pfs[hh][ks], acc[hh][lb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        s1 += acc[hh][lb][e];
+        s2 += acc[hh][lb][e] * acc[hh][lb][e];
+      }
+    }
+  }
+  // ---- LayerNorm statistics of the 32 rows: lane pair, then the four waves ------------------------------------------
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  if (lh == 0) {
+    sRed[(wave * BR + lr) * 2] = s1;
+    sRed[(wave * BR + lr) * 2 + 1] = s2;
+  }
+  __syncthreads();                              // (also: every wave is done reading sQ -- it becomes the output tile)
+  float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    t1 += sRed[(w * BR + lr) * 2];
+    t2 += sRed[(w * BR + lr) * 2 + 1];
+  }
+  const float mean = t1 * (1.0f / D_);
+  const float rstd = rsqrtf(fmaxf(t2 * (1.0f / D_) - mean * mean, 0.f) + 1e-5f);
+  // ---- LN, modulation, SiLU; bf16 tile into LDS (same swizzle as the Q tile) -----------------------------------------
+#pragma unroll
+  for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+    for (int lb = 0; lb < NLB; ++lb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = (wave + 4 * hh) * HD + 32 * lb + 8 * q + 4 * lh;
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(sPar + col), b4 = *reinterpret_cast<const f32x4*>(sPar + D_ + col);
+        const f32x4 sc4 = *reinterpret_cast<const f32x4*>(sPar + 2 * D_ + col) + 1.0f, sh4 = *reinterpret_cast<const f32x4*>(sPar + 3 * D_ + col);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float u = (acc[hh][lb][4 * q + e] - mean) * rstd * g4[e] + b4[e];
+          o[e] = hig_silu_fast(u * sc4[e] + sh4[e]);
+        }
+        *reinterpret_cast<bf16x4*>(sQ + lr * ROWB + 16 * ((col >> 3) ^ (lr & 15)) + 2 * (col & 7)) =
+            bf16x4{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+      }
+  __syncthreads();
+  // ---- whole rows out ----------------------------------------------------------------------------------------------
+  constexpr int PPR = ROWB / 16;
+#pragma unroll
+  for (int u = 0; u < BR * PPR / 256; ++u) {
+    const int idx = tid + 256 * u;
+    const int r = idx / PPR, p = idx % PPR;
+    if (r0 + r < T)
+      *reinterpret_cast<bf16x8*>(Out + ((int64_t)b * T + r0 + r) * ldo + 8 * p) =
+          *reinterpret_cast<const bf16x8*>(sQ + r * ROWB + 16 * (p ^ (r & 15)));
+  }
+}
+
+}  // namespace
+
+// Out = silu( LN( softmax_hd(Q) . A ) * (1 + scale) + shift ), bf16 matrix products (see the kernel).  Q, Out bf16 (B * rows,
+// H * hd); At16 bf16 (B, H, hd, hd) [l][c] = the TRANSPOSED context matrices (hig_linattn_ctx_bf16); gamma, beta, ss fp32; scale = ss[b][0 .. d), shift = ss[b][shift_off .. + d).
+// Head dim 64 with 4 or 8 heads (other shapes: hig_linattn_apply_sty_bf16 / the unfused pair).
+extern "C" int hig_linattn_apply_sty_mm16(const void* Q, int64_t ldq, const void* At16, const float* gamma, const float* beta,
+                                          const float* ss, int64_t ss_ld, int32_t ss_shift_off, void* Out, int64_t ldo,
+                                          int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream) {
+  HIG_REQUIRE(Q && At16 && gamma && beta && ss && Out && B > 0 && rows > 0, "hig_linattn_apply_sty_mm16: bad arguments");
+  if (hd != 64 || (H != 4 && H != 8))
+    return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn_apply_sty_mm16: built for head dim 64 and 4 or 8 heads (got %d, %d)", hd, H);
+  HIG_REQUIRE(ldq % 8 == 0 && ldo % 8 == 0 && ss_ld % 4 == 0 && ss_shift_off % 4 == 0 &&
+                  ((reinterpret_cast<uintptr_t>(Q) & 15) | (reinterpret_cast<uintptr_t>(Out) & 15) |
+                   (reinterpret_cast<uintptr_t>(At16) & 15) | (reinterpret_cast<uintptr_t>(gamma) & 15) |
+                   (reinterpret_cast<uintptr_t>(beta) & 15) | (reinterpret_cast<uintptr_t>(ss) & 15)) == 0,
+              "hig_linattn_apply_sty_mm16: alignment");
+  const dim3 grid((rows + 31) / 32, B);
+  hipStream_t st = hig_stream(stream);
+  if (H == 8)
+    hipLaunchKernelGGL((apply_sty16_kernel<64, 8>), grid, dim3(256), 0, st, static_cast<const __bf16*>(Q), ldq, static_cast<const __bf16*>(At16), gamma, beta, ss,
+                       ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo, rows);
+  else
+    hipLaunchKernelGGL((apply_sty16_kernel<64, 4>), grid, dim3(256), 0, st, static_cast<const __bf16*>(Q), ldq, static_cast<const __bf16*>(At16), gamma, beta, ss,
+                       ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo, rows);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}

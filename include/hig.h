@@ -417,14 +417,23 @@ int hig_ln_bf16(const void* x, int32_t x_f32, int64_t ldx, int64_t rows, int32_t
                 const float* beta, const float* ss, int64_t ss_ld, int32_t ss_shift_off, int32_t rows_per_sample,
                 void* out, int64_t ldo, hig_stream_t stream);
 /* bf16-storage forms of hig_linattn_ctx / hig_linattn_apply (below): K, V, Q, Y bf16; A, kstat fp32; head dim 64 / 128. */
+/* At16 (nullable): the context matrices once more, transposed and rounded -- At16[b][h][l][c] = bf16(A[b][h][c][l]) --
+ * the matrix-core operand of hig_linattn_apply_sty_mm16. */
 int hig_linattn_ctx_bf16(const void* K, const void* V, int64_t ld, int32_t B, int32_t rows, int32_t H, int32_t hd,
-                         const int64_t* length, float* A, float* kstat, float* scratch, hig_stream_t stream);
+                         const int64_t* length, float* A, float* kstat, float* scratch, void* At16, hig_stream_t stream);
 int hig_linattn_apply_bf16(const void* Q, int64_t ldq, const float* A, void* Y, int64_t ldy, int32_t B, int32_t rows,
                            int32_t H, int32_t hd, hig_stream_t stream);
 /* hig_linattn_apply_bf16 followed by the stylization front hig_ln_bf16(ss != NULL) over all H heads, as one kernel:
  * Out = silu( LN_d( softmax_hd(Q) . A ) * (1 + scale) + shift ) (transformer.py:111,116-118 then :81-85); the
  * (rows x d) intermediate never reaches memory.  H in {4, 8}, head dim 64 / 128; rows_per_sample == rows. */
 int hig_linattn_apply_sty_bf16(const void* Q, int64_t ldq, const float* A, const float* gamma, const float* beta,
+                               const float* ss, int64_t ss_ld, int32_t ss_shift_off, void* Out, int64_t ldo,
+                               int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
+/* The same operator with the hd x hd products on the bf16 matrix cores (csrc/linattn16.hip): softmax(Q) and A are rounded
+ * to bf16 for the product (fp32 accumulate), a workgroup owns 32 whole rows, Q / Out and the context matrices move as
+ * whole rows through LDS (DMA).  At16: the transposed bf16 context matrices hig_linattn_ctx_bf16 writes.
+ * Head dim 64 with 4 or 8 heads.  Default of the bf16-storage forward (HIG_FUSE_APPLY=2). */
+int hig_linattn_apply_sty_mm16(const void* Q, int64_t ldq, const void* At16, const float* gamma, const float* beta,
                                const float* ss, int64_t ss_ld, int32_t ss_shift_off, void* Out, int64_t ldo,
                                int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
 /* The same fused kernel with fp32 storage (hig_denoiser_fwd uses it for inference when HIG_FUSE_APPLY_F32=1; by default

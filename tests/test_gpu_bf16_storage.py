@@ -171,8 +171,10 @@ def test_linear_attention_bf16_io_matches_fp32_kernels(hd, H, B, T):
     scr = torch.zeros(L.hig_linattn_ctx_scratch_floats(B, T, H, hd), device=DEV)
     A16, A32 = torch.empty(B, H, hd, hd, device=DEV), torch.empty(B, H, hd, hd, device=DEV)
     k16, k32 = torch.empty(B, d, 2, device=DEV), torch.empty(B, d, 2, device=DEV)
+    At = torch.full((B, H, hd, hd), float("nan"), device=DEV, dtype=torch.bfloat16)
     _lib.check(L.hig_linattn_ctx_bf16(qkv16.data_ptr() + 2 * d, qkv16.data_ptr() + 4 * d, 3 * d, B, T, H, hd, _lib.ptr(lens),
-                                      _lib.ptr(A16), _lib.ptr(k16), _lib.ptr(scr), _lib.stream_ptr()))
+                                      _lib.ptr(A16), _lib.ptr(k16), _lib.ptr(scr), _lib.ptr(At), _lib.stream_ptr()))
+    assert torch.equal(At, bf(A16.transpose(2, 3)).contiguous())     # the transposed, rounded copy for linattn16.hip
     _lib.check(L.hig_linattn_ctx(qkv32.data_ptr() + 4 * d, qkv32.data_ptr() + 8 * d, 3 * d, B, T, H, hd, _lib.ptr(lens),
                                  _lib.ptr(A32), _lib.ptr(k32), _lib.ptr(scr), _lib.stream_ptr()))
     assert torch.equal(A16, A32) and torch.equal(k16, k32)          # identical arithmetic on identical values
@@ -207,6 +209,40 @@ def test_fused_apply_stylization_front_matches_the_two_kernel_sequence(hd, H, B,
     assert torch.isfinite(out.float()).all()
     assert rel(out.float(), ref) < 3e-3
     assert (out.float().cpu() != bf(ref.float()).float()).float().mean().item() < 0.03   # correctly rounded almost everywhere
+
+
+@pytest.mark.parametrize("H,B,T", [(8, 5, 196), (8, 32, 196), (4, 3, 33), (8, 2, 1), (4, 7, 91)])
+def test_fused_apply_stylization_front_on_the_bf16_matrix_cores(H, B, T):
+    """hig_linattn_apply_sty_mm16 (csrc/linattn16.hip): softmax(q) and the context matrices are rounded to bf16 for the
+    hd x hd products (fp32 accumulate) -- the rounding the bf16 storage mode applies to every other matrix operand.  Held
+    (a) to exactly that arithmetic in fp64 (bf16-rounded p and A, fp64 products, LayerNorm / modulation / SiLU): only the
+    accumulation order, the fp32 softmax and the final rounding differ; (b) to the unrounded reference at the bf16 level."""
+    hd, d = 64, H * 64
+    g = torch.Generator().manual_seed(H + B + T)
+    q16 = bf(torch.randn(B * T, d, generator=g) * 2).to(DEV)
+    A = (torch.randn(B, H, hd, hd, generator=g) * 0.5).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV), (0.1 * torch.randn(d, generator=g)).to(DEV)
+    ss = (0.3 * torch.randn(B, 2 * d, generator=g)).to(DEV)
+    out = torch.full((B * T, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    At = bf(A.transpose(2, 3)).contiguous()
+    _lib.check(_lib.lib().hig_linattn_apply_sty_mm16(_lib.ptr(q16), d, _lib.ptr(At), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(ss),
+                                                     2 * d, d, _lib.ptr(out), d, B, T, H, hd, _lib.stream_ptr()))
+    q = q16.double().cpu().view(B, T, H, hd)
+    p = torch.softmax(q, dim=-1)
+
+    def front(y):
+        y = torch.nn.functional.layer_norm(y.reshape(B * T, d), (d,), gamma.double().cpu(), beta.double().cpu(), 1e-5)
+        sc = ss[:, :d].double().cpu().repeat_interleave(T, 0)
+        sh = ss[:, d:].double().cpu().repeat_interleave(T, 0)
+        return torch.nn.functional.silu(y * (1 + sc) + sh)
+
+    Ad = A.double().cpu()
+    ref16 = front(torch.einsum("bthc,bhcl->bthl", bf(p.float()).double(), bf(Ad.float()).double()))
+    ref = front(torch.einsum("bthc,bhcl->bthl", p, Ad))
+    assert torch.isfinite(out.float()).all()
+    assert rel(out.float(), ref16) < 3e-3
+    assert (out.float().cpu() != bf(ref16.float()).float()).float().mean().item() < 0.05
+    assert rel(out.float(), ref) < 1e-2
 
 
 @pytest.mark.parametrize("M,T,F,d,shift", [(6272, 196, 150, 512, 0), (333, 37, 263, 256, 0), (70, 7, 12, 128, 1),

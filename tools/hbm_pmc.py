@@ -38,7 +38,7 @@ q16 = qkv.to(torch.bfloat16)
 y16, a16 = torch.empty(M, d, device=dev, dtype=torch.bfloat16), torch.empty(M, d, device=dev, dtype=torch.bfloat16)
 
 cases = [
-    lambda: L.hig_linattn_ctx(P(qkv) + 4 * d, P(qkv) + 8 * d, 3 * d, B, T, H, hd, P(lg), P(A), P(kst), P(scr), s),
+    lambda: L.hig_linattn_ctx(P(qkv) + 4 * d, P(qkv) + 8 * d, 3 * d, B, T, H, hd, P(lg), P(A), P(kst), P(scr), None, s),
     lambda: L.hig_linattn_apply(P(qkv), 3 * d, P(A), P(y), d, B, T, H, hd, s),
     lambda: L.hig_linattn_apply_bwd(P(dy), d, P(qkv), 3 * d, P(A), P(dqkv), 3 * d, P(dA), B, T, H, hd, P(bscr), s),
     lambda: L.hig_linattn_ctx_bwd(P(dA), P(A), P(qkv) + 4 * d, P(qkv) + 8 * d, 3 * d, P(kst), P(lg), P(dqkv) + 4 * d, P(dqkv) + 8 * d, 3 * d, B, T, H, hd, P(bscr), s),
@@ -47,7 +47,7 @@ cases = [
     lambda: L.hig_ln_bwd(P(dy), d, P(y), d, P(st), P(g), P(be), P(ss), 2 * d, d, 1, None, 0, P(a_), d, M, d, T, P(dg), P(db), P(dss), 2 * d, P(lnpart), s),
     lambda: (L.hig_sumsq_partial(P(g_), n_adam, 1.0, P(nscr), s) or
              L.hig_clip_adam(P(p_), P(g_), P(m_), P(v_), n_adam, 2e-4, 0.9, 0.999, 1e-8, 0.5, 1.0, P(nscr), P(gn), P(stp), s)),
-    lambda: L.hig_linattn_ctx_bf16(P(q16) + 2 * d, P(q16) + 4 * d, 3 * d, B, T, H, hd, P(lg), P(A), P(kst), P(scr), s),
+    lambda: L.hig_linattn_ctx_bf16(P(q16) + 2 * d, P(q16) + 4 * d, 3 * d, B, T, H, hd, P(lg), P(A), P(kst), P(scr), None, s),
     lambda: L.hig_linattn_apply_bf16(P(q16), 3 * d, P(A), P(y16), d, B, T, H, hd, s),
     lambda: L.hig_ln_bf16(P(y16), 0, d, M, d, P(g), P(be), P(ss), 2 * d, d, T, P(a16), d, s),
     lambda: L.hig_ln_bf16(P(y16), 0, d, M, d, P(g), P(be), None, 0, 0, 0, P(a16), d, s),

@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for s in 0 1 0 1; do HIG_FWD_SPLIT=$s python tools/fwd_time.py 2>&1 | tail -1 | sed "s/^/split=$s /"; done
-for s in 0 1; do HIG_FWD_SPLIT=$s python tools/train_step_time.py 2>&1 | tail -3 | sed "s/^/split=$s /"; done
-timeout 1500 python -m pytest tests/test_gpu_denoiser.py tests/test_gpu_full_size.py tests/test_gpu_trainer_state.py -x -q 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_gpu_bf16_storage.py -x -q -k "matrix_cores or oracle or io_matches" 2>&1 | tail -5
+for B in 32 64; do
+  for f in 0 2; do HIG_FUSE_APPLY=$f python tools/fwd16_time.py $B 2>&1 | grep -v amdgpu.ids | tail -1 | sed "s/^/B=$B fuse=$f /"; done
+done
