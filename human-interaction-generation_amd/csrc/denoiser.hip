@@ -685,6 +685,15 @@ inline const void* PL16(const void* const* t, int l, int idx) { return t[HIG_NGL
 
 }  // namespace
 
+// Context build of the bf16-storage forward: the bf16-matrix-core kernel of linattn16.hip where it is built (head dim 64),
+// else the fp32-MFMA kernels with bf16 loads (HIG_CTX16=0 forces those).
+static int ctx16(const Dims& D, const void* K, const void* V, int64_t ld, int B, int rows, const int64_t* length, float* A,
+                 float* kstat, float* scratch, void* At16, hig_stream_t stream) {
+  static const int mm16 = getenv("HIG_CTX16") ? atoi(getenv("HIG_CTX16")) : 1;   // tuning knob
+  if (mm16 && D.hd == 64) return hig_linattn_ctx_mm16(K, V, ld, B, rows, D.H, D.hd, length, A, kstat, At16, stream);
+  return hig_linattn_ctx_bf16(K, V, ld, B, rows, D.H, D.hd, length, A, kstat, scratch, At16, stream);
+}
+
 extern "C" int hig_text_context_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
                                      const float* xf_out, void* textctx, hig_stream_t stream) {
   Dims D;
@@ -705,8 +714,8 @@ extern "C" int hig_text_context_bf16(const hig_dims* dims, const void* const* pa
     HIG_TRY(hig_gemm16_launch(G16(xfn, D.Lt, PL16(params16, l, HIG_L_CA_KV_W), D.Lt, kv, 2 * D.d, D.Mt, 2 * D.d, D.Lt)
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_KV_B)).g, st));
     if (!D.full)
-      HIG_TRY(hig_linattn_ctx_bf16(kv, kv + (int64_t)D.d * 2, 2 * D.d, D.B, D.N, D.H, D.hd, nullptr, Ac, kstc,
-                                   reinterpret_cast<float*>(base + tl.cscr), base + tl.layer0 + tl.lstride * l + tl.Atc, stream));
+      HIG_TRY(ctx16(D, kv, kv + (int64_t)D.d * 2, 2 * D.d, D.B, D.N, nullptr, Ac, kstc,
+                    reinterpret_cast<float*>(base + tl.cscr), base + tl.layer0 + tl.lstride * l + tl.Atc, stream));
   }
   return HIG_OK;
 }
@@ -823,8 +832,7 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
                                     length, y, d, stream));
       HIG_TRY(stylize(l, 0, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B));
     } else {
-      HIG_TRY(hig_linattn_ctx_bf16(qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, D.H, D.hd, length, A1, kst1,
-                                   cscr, ws + w.At1, stream));
+      HIG_TRY(ctx16(D, qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, length, A1, kst1, cscr, ws + w.At1, stream));
       HIG_TRY(attend(l, 0, qkv, 3 * d, A1, ws + w.At1, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B));
     }
     // ---- cross attention to the text context (transformer.py:135-155) ----
@@ -845,8 +853,7 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
       HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B), nullptr, 0, 0, 0, xn, d, stream));
       HIG_TRY(hig_gemm16_launch(G16(xn, d, PL16(params16, l, HIG_L_INT_QKV_W), d, qkv, 3 * d, M, 3 * d, d)
                                     .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_INT_QKV_B)).g, st));
-      HIG_TRY(hig_linattn_ctx_bf16(qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, D.H, D.hd, len_partner, A1, kst1,
-                                   cscr, nullptr, stream));
+      HIG_TRY(ctx16(D, qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, len_partner, A1, kst1, cscr, nullptr, stream));
       const int64_t halfA = (int64_t)Bp * D.H * D.hd * D.hd, halfM = (int64_t)Bp * D.T;
       HIG_TRY(hig_linattn_apply_bf16(qkv, 3 * d, A1 + halfA, y, d, Bp, D.T, D.H, D.hd, stream));
       HIG_TRY(hig_linattn_apply_bf16(qkv + halfM * 3 * d * 2, 3 * d, A1, static_cast<char*>(y) + halfM * d * 2, d, Bp, D.T, D.H, D.hd,

@@ -27,6 +27,7 @@
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
@@ -220,6 +221,197 @@ __global__ __launch_bounds__(256) void apply_sty16_kernel(const __bf16* __restri
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Context build of the bf16-storage forward on the bf16 matrix cores:
+//     A[b,h][c][l] = sum_r softmax_r(K)[r][c] V[r][l]          (transformer.py:112-116 / :148-152; rows r >= length masked)
+// One workgroup per (sample, head) walks the rows in chunks of 64 with a running column maximum (online softmax), like
+// ctx_mfma_kernel (linattn.hip) -- whose 32 fp32 MFMAs per wave and chunk (2 048 cycles) are four bf16 MFMAs here.
+// Both operands of v_mfma_f32_32x32x16_bf16 need the ROW index r as their k: V^T and P^T.  Neither is ever transposed in
+// memory: the V chunk lands row-major in LDS by DMA, P = exp(K - max) is written row-major by the threads that hold K,
+// and ds_read_b64_tr_b16 (the transpose read of gfx950) hands each lane four consecutive rows of one column.
+// Per chunk: column maxima (wave shuffles + one LDS exchange), P, two barriers, 4 MFMAs + 16 transpose reads per wave.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <int HD>
+__global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restrict__ K, const __bf16* __restrict__ V, int64_t ld,
+                                                         int rows, int H, const int64_t* __restrict__ length,
+                                                         float* __restrict__ A, float* __restrict__ kstat,
+                                                         __bf16* __restrict__ At16) {
+  static_assert(HD == 64, "layouts below are written for 128-byte rows");
+  constexpr int CHK = 64;                       // rows per chunk
+  constexpr int ROWB = HD * 2;                  // 128 bytes per LDS row
+  constexpr int NB = 4;                         // K / V chunks in LDS: the DMA runs three chunks ahead of the arithmetic
+  __shared__ __attribute__((aligned(1024))) char sV[NB][CHK * ROWB];  // [r][l] bf16, 16-byte chunk c of row r at c ^ f(r)
+  __shared__ __attribute__((aligned(1024))) char sK[NB][CHK * ROWB];  // [r][c] bf16, same layout (K arrives by DMA too: no VGPR load
+                                                                      // for hipcc to guard with a vmcnt(0) while a DMA is in flight)
+  __shared__ __attribute__((aligned(1024))) char sP[2][CHK * ROWB];   // [r][c] bf16 = exp(K - running max), same layout
+  __shared__ float sWmax[4][HD];                // per-wave column maxima of the chunk; at the end per-wave column sums
+  __shared__ float sScale[HD];                  // exp(m_old - m_new) of the chunk; at the end 1 / column sum
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  int len = rows;
+  if (length) len = (int)min<int64_t>(max<int64_t>(length[b], 0), rows);
+  const __bf16* Kb = K + (int64_t)b * rows * ld + h * HD;
+  const __bf16* Vb = V + (int64_t)b * rows * ld + h * HD;
+  auto fsw = [](int r) { return ((r >> 1) & 1) << 2; };   // swizzle: rows r, r + 2 of a transpose read use disjoint bank halves
+  // K: thread (wave, rl = lane / 16, c4 = lane % 16) holds channels 4 c4 .. 4 c4 + 3 of rows 16 wave + 4 i + rl, i = 0 .. 3
+  const int rl = lane >> 4, c4 = lane & 15;
+  float kreg[4][4];
+  auto read_k = [&](int r0, int buf) {          // this thread's K values of the chunk, from LDS (rows beyond len: -inf)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = 16 * wave + 4 * i + rl;
+      const u32x2 w = *reinterpret_cast<const u32x2*>(sK[buf] + rr * ROWB + 16 * ((c4 >> 1) ^ fsw(rr)) + 8 * (c4 & 1));
+      const bool ok = r0 + rr < len;
+      kreg[i][0] = ok ? bf_lo(w.x) : -INFINITY; kreg[i][1] = ok ? bf_hi(w.x) : -INFINITY;
+      kreg[i][2] = ok ? bf_lo(w.y) : -INFINITY; kreg[i][3] = ok ? bf_hi(w.y) : -INFINITY;
+    }
+  };
+  auto dma_chunk = [&](int r0, int buf) {   // K and V rows [r0, r0 + 64) x 128 bytes: 2 x 8 instructions, 4 per wave (rows beyond len:
+                                            // any valid row -- they are masked / multiplied by P = 0)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int n = wave + 4 * q;
+      const int row = 8 * n + (lane >> 3), pos = lane & 7;
+      const int64_t off = (int64_t)min(r0 + row, max(len - 1, 0)) * ld + 8 * (pos ^ fsw(row));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + off),
+                                       (__attribute__((address_space(3))) void*)(sK[buf] + n * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vb + off),
+                                       (__attribute__((address_space(3))) void*)(sV[buf] + n * 1024), 16, 0, 0);
+    }
+  };
+  // MFMA roles: wave (wi, wj) owns the 32 x 32 block A[32 wi ..][32 wj ..]; first operand V^T (rows l), second P^T (rows c):
+  // accumulator element 4 q + e of lane (lr, lh) is A[c = 32 wi + lr][l = 32 wj + 8 q + 4 lh + e]
+  const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
+  const int gi = lane & 15, gg = lane >> 4;     // transpose read: lane gi of 16-lane group gg
+  auto tr_addr = [&](int colbase, int rr) {     // byte offset of (row rr, columns colbase + 16 (gg & 1) + 4 (gi & 3) ..) in a chunk image
+    const int col = colbase + 16 * (gg & 1) + 4 * (gi & 3);
+    return rr * ROWB + 16 * ((col >> 3) ^ fsw(rr)) + 2 * (col & 7);
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  float mrun[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // running maximum of this thread's 4 channels
+  float ksum[4] = {0.f, 0.f, 0.f, 0.f};         // this thread's share of sum_r exp(K - m)
+  const int nchunk = (len + CHK - 1) / CHK;
+  for (int t = 0; t < NB - 1 && t < nchunk; ++t) dma_chunk(t * CHK, t);
+  for (int r0 = 0, it = 0; r0 < len; r0 += CHK, ++it) {
+    const int buf = it & 1, kb = it % NB;
+    // chunk `it` has landed once only the younger chunks' requests (4 per wave and chunk) are outstanding
+    {
+      const int younger = min(NB - 2, nchunk - 1 - it);
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();               // #0: everyone's share of the chunk has landed
+    asm volatile("" ::: "memory");
+    read_k(r0, kb);
+    // ---- column maxima of the chunk ----
+    float m4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float m = fmaxf(fmaxf(kreg[0][c], kreg[1][c]), fmaxf(kreg[2][c], kreg[3][c]));
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      m4[c] = m;
+    }
+    if (rl == 0) *reinterpret_cast<f32x4*>(&sWmax[wave][4 * c4]) = f32x4{m4[0], m4[1], m4[2], m4[3]};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();               // #1
+    asm volatile("" ::: "memory");
+    float sc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float m = mrun[c];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) m = fmaxf(m, sWmax[w][4 * c4 + c]);
+      sc[c] = mrun[c] == -INFINITY ? 0.f : __expf(mrun[c] - m);   // (nothing accumulated yet while the old maximum is -inf)
+      mrun[c] = m;
+      ksum[c] *= sc[c];
+    }
+    if (wave == 0 && rl == 0) *reinterpret_cast<f32x4*>(&sScale[4 * c4]) = f32x4{sc[0], sc[1], sc[2], sc[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = 16 * wave + 4 * i + rl;
+      float pe[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        pe[c] = (r0 + rr < len) ? __expf(kreg[i][c] - mrun[c]) : 0.f;
+        ksum[c] += pe[c];
+      }
+      *reinterpret_cast<bf16x4*>(sP[buf] + rr * ROWB + 16 * ((c4 >> 1) ^ fsw(rr)) + 8 * (c4 & 1)) =
+          bf16x4{(__bf16)pe[0], (__bf16)pe[1], (__bf16)pe[2], (__bf16)pe[3]};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // P is written
+    __builtin_amdgcn_s_barrier();               // #2
+    asm volatile("" ::: "memory");
+    if (it + NB - 1 < nchunk) dma_chunk((it + NB - 1) * CHK, (it + NB - 1) % NB);   // into the buffer of chunk it - 1: everyone is past it
+    // ---- rescale the accumulator row (channel c = 32 wi + lr), then add this chunk: 4 k-steps of 16 rows ----
+    const float f = sScale[32 * wi + lr];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] *= f;
+#pragma unroll
+    for (int ks = 0; ks < CHK / 16; ++ks) {
+      s16x8 vf, pf;
+#pragma unroll
+      for (int part = 0; part < 2; ++part) {
+        const int rr = 16 * ks + 8 * (gg >> 1) + 4 * part + (gi >> 2);
+        const s16x4 v4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sV[kb] + tr_addr(32 * wj, rr)));
+        const s16x4 p4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sP[buf] + tr_addr(32 * wi, rr)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vf[4 * part + e] = v4[e]; pf[4 * part + e] = p4[e]; }
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf), acc, 0, 0, 0);
+    }
+  }
+  // ---- column sums, normalisation, outputs ----
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  float t4[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float t = ksum[c];
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    t4[c] = t;
+  }
+  if (rl == 0) *reinterpret_cast<f32x4*>(&sWmax[wave][4 * c4]) = f32x4{t4[0], t4[1], t4[2], t4[3]};
+  __syncthreads();
+  if (tid < HD) {
+    const float t = sWmax[0][tid] + sWmax[1][tid] + sWmax[2][tid] + sWmax[3][tid];
+    sScale[tid] = t > 0.f ? 1.0f / t : 0.f;
+  }
+  if (wave == 0 && rl == 0) {                   // (this thread's running maxima are the final ones of its 4 channels)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float t = sWmax[0][4 * c4 + c] + sWmax[1][4 * c4 + c] + sWmax[2][4 * c4 + c] + sWmax[3][4 * c4 + c];
+      float* st = kstat + ((int64_t)blockIdx.x * HD + 4 * c4 + c) * 2;
+      st[0] = len > 0 ? mrun[c] : 0.f;
+      st[1] = len > 0 ? t : 1.f;
+    }
+  }
+  __syncthreads();
+  const int cc = 32 * wi + lr;
+  const float inv = sScale[cc];
+  float* ap = A + (int64_t)blockIdx.x * HD * HD + cc * HD + 32 * wj + 4 * lh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<f32x4*>(ap + 8 * q) = f32x4{acc[4 * q] * inv, acc[4 * q + 1] * inv, acc[4 * q + 2] * inv, acc[4 * q + 3] * inv};
+  if (At16) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int l = 32 * wj + 8 * (e >> 2) + 4 * lh + (e & 3);
+      At16[((int64_t)blockIdx.x * HD + l) * HD + cc] = (__bf16)(acc[e] * inv);
+    }
+  }
+}
+
 }  // namespace
 
 // Out = silu( LN( softmax_hd(Q) . A ) * (1 + scale) + shift ), bf16 matrix products (see the kernel).  Q, Out bf16 (B * rows,
@@ -244,6 +436,22 @@ extern "C" int hig_linattn_apply_sty_mm16(const void* Q, int64_t ldq, const void
   else
     hipLaunchKernelGGL((apply_sty16_kernel<64, 4>), grid, dim3(256), 0, st, static_cast<const __bf16*>(Q), ldq, static_cast<const __bf16*>(At16), gamma, beta, ss,
                        ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo, rows);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+// A (fp32, [c][l]) + kstat (column max, column sum) + At16 (nullable: transposed bf16 copy) of the linear-attention context,
+// K / V bf16, on the bf16 matrix cores (ctx16_mfma_kernel): softmax_r(K) and V are rounded to bf16 for the product, fp32
+// accumulate and statistics.  Head dim 64; one workgroup per (sample, head).
+extern "C" int hig_linattn_ctx_mm16(const void* K, const void* V, int64_t ld, int32_t B, int32_t rows, int32_t H, int32_t hd,
+                                    const int64_t* length, float* A, float* kstat, void* At16, hig_stream_t stream) {
+  HIG_REQUIRE(K && V && A && kstat && B > 0 && rows > 0 && H > 0, "hig_linattn_ctx_mm16: bad arguments");
+  if (hd != 64) return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn_ctx_mm16: built for head dim 64 (got %d)", hd);
+  HIG_REQUIRE(ld % 8 == 0 && (reinterpret_cast<uintptr_t>(K) & 15) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(A) & 15) == 0,
+              "hig_linattn_ctx_mm16: K / V / A must be 16-byte aligned with ld %% 8 == 0");
+  hipLaunchKernelGGL(ctx16_mfma_kernel<64>, dim3(B * H), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(K),
+                     static_cast<const __bf16*>(V), ld, rows, H, length, A, kstat, static_cast<__bf16*>(At16));
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

@@ -423,6 +423,11 @@ int hig_linattn_ctx_bf16(const void* K, const void* V, int64_t ld, int32_t B, in
                          const int64_t* length, float* A, float* kstat, float* scratch, void* At16, hig_stream_t stream);
 int hig_linattn_apply_bf16(const void* Q, int64_t ldq, const float* A, void* Y, int64_t ldy, int32_t B, int32_t rows,
                            int32_t H, int32_t hd, hig_stream_t stream);
+/* hig_linattn_ctx_bf16 with the k^T v product on the bf16 matrix cores (csrc/linattn16.hip: softmax_r(K) and V rounded to
+ * bf16 for the product, fp32 accumulate / statistics; K and V chunks by LDS-DMA, ds_read_b64_tr_b16 transpose reads).
+ * Head dim 64, one workgroup per (sample, head).  Default of the bf16-storage forward (HIG_CTX16=1). */
+int hig_linattn_ctx_mm16(const void* K, const void* V, int64_t ld, int32_t B, int32_t rows, int32_t H, int32_t hd,
+                         const int64_t* length, float* A, float* kstat, void* At16, hig_stream_t stream);
 /* hig_linattn_apply_bf16 followed by the stylization front hig_ln_bf16(ss != NULL) over all H heads, as one kernel:
  * Out = silu( LN_d( softmax_hd(Q) . A ) * (1 + scale) + shift ) (transformer.py:111,116-118 then :81-85); the
  * (rows x d) intermediate never reaches memory.  H in {4, 8}, head dim 64 / 128; rows_per_sample == rows. */

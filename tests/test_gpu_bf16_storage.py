@@ -211,6 +211,42 @@ def test_fused_apply_stylization_front_matches_the_two_kernel_sequence(hd, H, B,
     assert (out.float().cpu() != bf(ref.float()).float()).float().mean().item() < 0.03   # correctly rounded almost everywhere
 
 
+@pytest.mark.parametrize("H,B,T", [(8, 4, 196), (8, 32, 196), (2, 40, 77), (8, 3, 300), (4, 5, 1), (8, 2, 64), (8, 2, 65)])
+def test_context_build_on_the_bf16_matrix_cores(H, B, T):
+    """hig_linattn_ctx_mm16 (csrc/linattn16.hip: online column softmax over row chunks, k^T v on v_mfma_f32_32x32x16_bf16 with
+    transpose reads) against the definition in fp64 on the same bf16 K / V -- exp(K - max) and V are rounded to bf16 for the
+    product, so A is held at the bf16 level, the statistics (column max, column sum) at the fp32 level -- with ragged and
+    zero lengths, one and many chunks, and the transposed bf16 copy checked against the kernel's own A."""
+    hd, d = 64, H * 64
+    g = torch.Generator().manual_seed(H + B + T)
+    qkv16 = bf(torch.randn(B * T, 3 * d, generator=g) * 1.5).to(DEV)
+    lens = torch.randint(0, T + 1, (B,), generator=g)
+    lens[0] = T
+    L = _lib.lib()
+    A = torch.full((B, H, hd, hd), float("nan"), device=DEV)
+    kst = torch.full((B, d, 2), float("nan"), device=DEV)
+    At = torch.full((B, H, hd, hd), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _lib.check(L.hig_linattn_ctx_mm16(qkv16.data_ptr() + 2 * d, qkv16.data_ptr() + 4 * d, 3 * d, B, T, H, hd, _lib.ptr(lens.to(DEV)),
+                                      _lib.ptr(A), _lib.ptr(kst), _lib.ptr(At), _lib.stream_ptr()))
+    x = qkv16.double().cpu().view(B, T, 3, H, hd)
+    K, V = x[:, :, 1], x[:, :, 2]
+    mask = (torch.arange(T)[None, :] < lens[:, None])[:, :, None, None]
+    Km = torch.where(mask, K, torch.full_like(K, float("-inf")))
+    mx = Km.max(dim=1).values                                            # (B, H, hd)
+    p = torch.where(mask, torch.exp(K - torch.where(torch.isfinite(mx), mx, torch.zeros_like(mx))[:, None]), torch.zeros_like(K))
+    s = p.sum(dim=1)
+    ref = torch.einsum("bthc,bthl->bhcl", p, V) / torch.where(s > 0, s, torch.ones_like(s))[..., None]
+    Ac = A.double().cpu()
+    assert torch.isfinite(Ac).all()
+    live = lens > 0
+    assert rel(Ac[live], ref[live]) < 4e-3
+    assert Ac[~live].abs().max().item() == 0.0 if (~live).any() else True      # empty samples: zero context
+    ks = kst.double().cpu().view(B, H, hd, 2)
+    assert torch.equal(ks[live][..., 0], mx[live])                            # running maximum == column maximum
+    assert rel(ks[live][..., 1], s[live]) < 1e-5
+    assert torch.equal(At.cpu(), bf(A.transpose(2, 3)).contiguous().cpu())
+
+
 @pytest.mark.parametrize("H,B,T", [(8, 5, 196), (8, 32, 196), (4, 3, 33), (8, 2, 1), (4, 7, 91)])
 def test_fused_apply_stylization_front_on_the_bf16_matrix_cores(H, B, T):
     """hig_linattn_apply_sty_mm16 (csrc/linattn16.hip): softmax(q) and the context matrices are rounded to bf16 for the
