@@ -87,6 +87,7 @@ class Gemm16Desc(C.Structure):
         ("epi", C.c_int32),
         ("bias", C.c_void_p),
         ("res", C.c_void_p), ("ldr", C.c_int64), ("res_f32", C.c_int32),
+        ("row_stats_out", C.c_void_p), ("row_stats_in", C.c_void_p), ("ln_colsum", C.c_void_p),
     ]
 
 
@@ -167,7 +168,7 @@ def lib():
         L.hig_joint_embed_bf16.argtypes = [vp, i64, i32, vp, vp, vp, i64, i32, i32, vp, i64, i32, vp, vp]
         L.hig_linattn_apply_sty.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, vp, i64, i32, i32, i32, i32, vp]
         L.hig_text_context_bf16.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, vp]
-        L.hig_denoiser_fwd_bf16.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.hig_denoiser_fwd_bf16.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.hig_gemm_split.argtypes = [C.POINTER(GemmDesc), i32, vp, i64, vp]
         L.hig_gemm_split_scratch_floats.restype = i64
         L.hig_gemm_split_scratch_floats.argtypes = [C.POINTER(GemmDesc), i32]

@@ -602,7 +602,7 @@ namespace {
 inline int64_t alb(int64_t bytes) { return (bytes + 255) & ~(int64_t)255; }
 
 struct Fwd16Layout {
-  int64_t te32, te16, teh16, semb16, ss, h32, h, xn, qkv, A1, At1, kst1, cscr, y, a, qc, f1, lenp, tok0, total;
+  int64_t te32, te16, teh16, semb16, ss, h32, h, xn, qkv, A1, At1, kst1, cscr, y, a, qc, f1, lenp, tok0, stats, total;
 };
 Fwd16Layout fwd16_layout(const Dims& D) {
   Fwd16Layout w;
@@ -628,6 +628,7 @@ Fwd16Layout fwd16_layout(const Dims& D) {
   w.f1 = take(D.M * D.ff * 2);
   w.lenp = take((int64_t)D.B * 8);           // two-person: lengths with the two halves swapped (the partner's mask)
   w.tok0 = take((int64_t)D.B * D.d * 4);     // two-person: joint_embed2 of the init-pose rows (fp32) before they enter h
+  w.stats = take(D.M * 4 * 2 * 4);           // LayerNorm fold: (sum, sum of squares) per row and 128-column panel of h
   w.total = o;
   return w;
 }
@@ -721,7 +722,8 @@ extern "C" int hig_text_context_bf16(const hig_dims* dims, const void* const* pa
 }
 
 extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
-                                     const float* x, const int64_t* t, const int64_t* length, const float* xf_proj,
+                                     const void* const* lnfold, const float* x, const int64_t* t, const int64_t* length,
+                                     const float* xf_proj,
                                      const void* textctx, float* out, void* workspace, hig_stream_t stream) {
   Dims D;
   HIG_TRY(check_dims(dims, D));
@@ -789,9 +791,29 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   float* kst1 = reinterpret_cast<float*>(ws + w.kst1);
   float* cscr = reinterpret_cast<float*>(ws + w.cscr);
   // one stylization block: h += Lin_out( silu( LN(y) (1 + scale) + shift ) )      (transformer.py:81-85)
+  // LayerNorm fold (see include/hig.h): when the NEXT consumer of the residual stream is a LayerNorm + Linear pair, the
+  // stylization-out GEMM also writes the row statistics of the new h (`want_stats` set by the layer loop below)
+  const bool fold = lnfold && hig_gemm_ws16_lnfold_ok(M, d);
+  float* stats = reinterpret_cast<float*>(ws + w.stats);
+  bool want_stats = false, have_stats = false;
   auto sty_out = [&](int l, int out_w, int out_b) -> int {
-    return hig_gemm16_launch(G16(a, d, PL16(params16, l, out_w), d, h, d, M, d, d)
-                                 .epi(HIG_EPI_BIAS_RES, PL(params, l, out_b)).res16(h, d).g, st);
+    G16 g(a, d, PL16(params16, l, out_w), d, h, d, M, d, d);
+    g.epi(HIG_EPI_BIAS_RES, PL(params, l, out_b)).res16(h, d);
+    if (fold && want_stats) g.g.row_stats_out = stats;
+    have_stats = fold && want_stats;
+    return hig_gemm16_launch(g.g, st);
+  };
+  // xn-free projection of LN(h): out = LN(h) W^T + b through the folded operands (k = 0: q/k/v, k = 1: cross-attention query)
+  auto ln_proj = [&](int l, int k, int norm_w, int norm_b, int lin_w, int lin_b, void* outp, int64_t ncols) -> int {
+    if (have_stats) {
+      G16 g(h, d, lnfold[6 * l + 3 * k], d, outp, ncols, M, ncols, d);
+      g.epi(HIG_EPI_BIAS, static_cast<const float*>(lnfold[6 * l + 3 * k + 2]));
+      g.g.row_stats_in = stats;
+      g.g.ln_colsum = static_cast<const float*>(lnfold[6 * l + 3 * k + 1]);
+      return hig_gemm16_launch(g.g, st);
+    }
+    HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, norm_w), PL(params, l, norm_b), nullptr, 0, 0, 0, xn, d, stream));
+    return hig_gemm16_launch(G16(xn, d, PL16(params16, l, lin_w), d, outp, ncols, M, ncols, d).epi(HIG_EPI_BIAS, PL(params, l, lin_b)).g, st);
   };
   auto stylize = [&](int l, int slot, int norm_w, int norm_b, int out_w, int out_b) -> int {
     const float* ssl = ss + (int64_t)(D.nsty * l + slot) * 2 * d;
@@ -824,9 +846,8 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   };
   for (int l = 0; l < D.L; ++l) {
     // ---- self attention (transformer.py:101-119) ----
-    HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B), nullptr, 0, 0, 0, xn, d, stream));
-    HIG_TRY(hig_gemm16_launch(G16(xn, d, PL16(params16, l, HIG_L_SA_QKV_W), d, qkv, 3 * d, M, 3 * d, d)
-                                  .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_SA_QKV_B)).g, st));
+    HIG_TRY(ln_proj(l, 0, HIG_L_SA_NORM_W, HIG_L_SA_NORM_B, HIG_L_SA_QKV_W, HIG_L_SA_QKV_B, qkv, 3 * d));
+    want_stats = true;                           // the self-attention stylization block feeds the cross-attention LayerNorm
     if (D.full) {   // no_eff=True: softmax over the T keys, query-axis mask constant (transformer.py:208-227)
       HIG_TRY(hig_fullattn_fwd_bf16(qkv, 3 * d, qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, D.T, D.H, D.hd,
                                     length, y, d, stream));
@@ -836,9 +857,8 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
       HIG_TRY(attend(l, 0, qkv, 3 * d, A1, ws + w.At1, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B));
     }
     // ---- cross attention to the text context (transformer.py:135-155) ----
-    HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B), nullptr, 0, 0, 0, xn, d, stream));
-    HIG_TRY(hig_gemm16_launch(G16(xn, d, PL16(params16, l, HIG_L_CA_Q_W), d, qc, d, M, d, d)
-                                  .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).g, st));
+    HIG_TRY(ln_proj(l, 1, HIG_L_CA_NORM_W, HIG_L_CA_NORM_B, HIG_L_CA_Q_W, HIG_L_CA_Q_B, qc, d));
+    want_stats = false;                          // (cross-attention / interaction stylization blocks: no folded consumer behind them)
     if (D.full) {   // softmax over the N text tokens, no mask (transformer.py:242-262)
       const char* kvl = tc + tl.kv + tl.kv_stride * l;
       HIG_TRY(hig_fullattn_fwd_bf16(qc, d, kvl, kvl + (int64_t)d * 2, 2 * d, D.B, D.T, D.N, D.H, D.hd, nullptr, y, d, stream));
@@ -865,6 +885,7 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
                                   .epi(HIG_EPI_BIAS_GELU, PL(params, l, HIG_L_FFN_B1)).g, st));
     HIG_TRY(hig_gemm16_launch(G16(f1, D.ff, PL16(params16, l, HIG_L_FFN_W2), D.ff, y, d, M, d, D.ff)
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B2)).g, st));
+    want_stats = l + 1 < D.L;                    // the FFN stylization block feeds the next layer's self-attention LayerNorm
     HIG_TRY(stylize(l, D.nsty - 1, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B, HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B));
   }
   // K6: out = Linear(d, F)(h_L), fp32 (the DDPM update consumes it)

@@ -43,6 +43,12 @@ struct WsArgs {
   int np;        // column panels (J / BN)
   int g;         // row groups per XCD: slot s of an XCD works on panel s % np, row tiles rg, rg + g, ... (rg = s / np)
   int ntiles;    // 32-row tiles in all
+  // LayerNorm folded into the NEXT GEMM (XT template parameter): a producer (XT = 1) also writes, per output row and column
+  // panel, (sum, sum of squares) of its bf16-rounded outputs to stats_out[row][np][2]; a consumer (XT = 2) reads
+  // stats_in[row][4][2] of its X rows and computes  rstd (x . W'^T) - rstd mean colsum + bias'  with W' = gamma (.) W.
+  float* stats_out;
+  const float* stats_in;
+  const float* colsum;
   unsigned long long* stamps;   // diagnostic (hig_gemm_ws16_debug_stamps): 16 s_memtime stamps per workgroup, else NULL
 };
 
@@ -60,8 +66,9 @@ __device__ __forceinline__ void ws_wait_vmcnt_visible() {
 // NCB blocks of 32 columns wide (NCB = 2: a wave holds 64 columns x KW = 256 registers of weights -- one wave per SIMD,
 // 512 registers each -- and every X fragment it reads from LDS feeds two MFMAs).
 // OCC: workgroups per CU the kernel is laid out for (LDS budget 160 KB / OCC, registers 512 / (OCC waves per SIMD)).
-template <int KW, int KSPLIT, int NWJ, int NCB, int EPI, int DBG = 0, int OCC = 1>
+template <int KW, int KSPLIT, int NWJ, int NCB, int EPI, int DBG = 0, int OCC = 1, int XT = 0>
 __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) void gemm_ws16_kernel(const WsArgs a) {
+  static_assert(XT == 0 || (KSPLIT == 1 && NCB == 1 && OCC == 1 && KW == 512), "LayerNorm fold: K = 512 single-split variants");
   constexpr int LDS_MAX = 160 * 1024 / OCC;
   static_assert(OCC == 1 || NWJ * KSPLIT == 4, "two workgroups per CU: 4-wave variants only");
   constexpr int NW = NWJ * KSPLIT, NT = 64 * NW;
@@ -95,8 +102,14 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   static_assert(RBUF % (1024 * NW) == 0, "residual DMA instructions must split evenly over the waves");
   // bias: in LDS where there is room (sixteen registers less per lane), else in registers for the workgroup's life
   constexpr bool BIAS_LDS = NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + BN * 4 <= LDS_MAX;
-  __shared__ __attribute__((aligned(1024))) char smem[NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + (BIAS_LDS ? BN * 4 : 0)];
+  static_assert(XT != 2 || BIAS_LDS, "the LayerNorm-fold consumer keeps bias' and the column sums in LDS");
+  constexpr int XLDS = XT == 1 ? 2 * NW * BM * 2 * 4 : XT == 2 ? BN * 4 + 2 * 1024 : 0;
+  __shared__ __attribute__((aligned(1024))) char smem[NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + (BIAS_LDS ? BN * 4 : 0) + XLDS];
   [[maybe_unused]] float* const sB = reinterpret_cast<float*>(smem + NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF);
+  [[maybe_unused]] char* const sXT = smem + NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + (BIAS_LDS ? BN * 4 : 0);
+  [[maybe_unused]] float* const sStat = reinterpret_cast<float*>(sXT);          // XT = 1: [2][NW][32 rows][2]
+  [[maybe_unused]] char* const sLn = sXT;                                        // XT = 2: [2][32 rows][4 panels][2] floats
+  [[maybe_unused]] float* const sC = reinterpret_cast<float*>(sXT + 2 * 1024);   // XT = 2: column sums of W' of this panel
   char* const sX = smem;
   char* const sS = smem + NXB * XBUF;
   [[maybe_unused]] char* const sR = smem + NXB * XBUF + 2 * SBUF;
@@ -137,6 +150,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   if constexpr (BIAS_LDS) {
     static_assert(BN <= NT, "one thread per bias column");
     if (tid < BN) sB[tid] = (EPI != HIG_EPI_NONE) ? a.bias[j0 + tid] : 0.f;    // (published by the barriers of the weight rounds)
+    if constexpr (XT == 2) { if (tid < BN) sC[tid] = a.colsum[j0 + tid]; }
   } else {
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
@@ -225,7 +239,10 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   // a kh = 1 wave finishes elements 8 .. 15, which it swaps to the front when the k-loop ends)
   f32x16 acc[NCB], old[NCB];
   auto acc_start = [&]() {
-    if constexpr (BIAS_LDS) {
+    if constexpr (XT == 2) {                     // (bias' enters after the row scaling)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[0][j] = 0.f;
+    } else if constexpr (BIAS_LDS) {
       static_assert(!BIAS_LDS || KSPLIT == 1, "bias in LDS: single-split variants only");
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb)
@@ -254,10 +271,29 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   // wave's finished quads): the k-loop calls epi_elem(j) between its MFMAs so that the vector work is spread evenly.
   float ev[4];
   u32x2 rq = u32x2{0u, 0u};                    // residual of the quad in work: four bf16, raw bits
+  [[maybe_unused]] float st_s1 = 0.f, st_s2 = 0.f;          // XT = 1: this lane's share of its row's (sum, sum of squares)
+  [[maybe_unused]] float* statw = nullptr;                  //         where the wave parks them (set per tile)
+  [[maybe_unused]] float ln_rstd = 0.f, ln_mr = 0.f;        // XT = 2: rstd and -mean * rstd of this lane's row
+  [[maybe_unused]] f32x4 ln_b4 = f32x4{0.f, 0.f, 0.f, 0.f}, ln_c4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] const char* lnbuf = nullptr;             //         the tile's statistics in LDS (set per tile)
   auto epi_elem = [&](int j, char* stg, [[maybe_unused]] const float* parked, [[maybe_unused]] const char* rbuf) {
     const int cb = j / (4 * NQF), jj = j % (4 * NQF);
     const int u = jj >> 2, e = jj & 3;
     float v = old[cb][jj];
+    if constexpr (XT == 2) {
+      if (j == 0) {                              // LayerNorm statistics of this lane's row from the four panel partials
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(lnbuf + lr * 32), p1 = *reinterpret_cast<const f32x4*>(lnbuf + lr * 32 + 16);
+        const float mean = (p0.x + p0.z + p1.x + p1.z) * (1.0f / K);
+        const float var = fmaxf((p0.y + p0.w + p1.y + p1.w) * (1.0f / K) - mean * mean, 0.f);
+        ln_rstd = rsqrtf(var + 1e-5f);
+        ln_mr = -mean * ln_rstd;
+      }
+      if (e == 0) {
+        ln_b4 = *reinterpret_cast<const f32x4*>(sB + 32 * wj + 8 * u + 4 * lh);
+        ln_c4 = *reinterpret_cast<const f32x4*>(sC + 32 * wj + 8 * u + 4 * lh);
+      }
+      v = fmaf(v, ln_rstd, fmaf(ln_mr, ln_c4[e], ln_b4[e]));
+    }
     if constexpr (KSPLIT > 1) v += parked[jj * 64];
     if constexpr (HAS_RES) {
       if (e == 0) rq = *reinterpret_cast<const u32x2*>(rbuf + lr * SROWB + 16 * ((4 * (NCB * wj + cb) + qf0 + u) ^ (lr & 15)) + 8 * lh);
@@ -267,8 +303,22 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
     ev[e] = (DBG & 2) ? v : epi_act<EPI>(v);
     if (e == 3) {
       const int pos16 = (4 * (NCB * wj + cb) + qf0 + u) ^ (lr & 15);
-      *reinterpret_cast<bf16x4*>(stg + lr * SROWB + 16 * pos16 + 8 * lh) =
-          bf16x4{(__bf16)ev[0], (__bf16)ev[1], (__bf16)ev[2], (__bf16)ev[3]};
+      const bf16x4 o4 = bf16x4{(__bf16)ev[0], (__bf16)ev[1], (__bf16)ev[2], (__bf16)ev[3]};
+      *reinterpret_cast<bf16x4*>(stg + lr * SROWB + 16 * pos16 + 8 * lh) = o4;
+      if constexpr (XT == 1) {                   // row sums of the ROUNDED outputs (what the consumer will read)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float vr = (float)o4[k];
+          st_s1 += vr;
+          st_s2 = fmaf(vr, vr, st_s2);
+        }
+        if (j == 4 * NQF * NCB - 1) {
+          st_s1 += __shfl_xor(st_s1, 32, 64);
+          st_s2 += __shfl_xor(st_s2, 32, 64);
+          if (lh == 0) *reinterpret_cast<float2*>(statw + lr * 2) = make_float2(st_s1, st_s2);
+          st_s1 = st_s2 = 0.f;
+        }
+      }
     }
   };
   // Residual tile t -> LDS by DMA, in the layout of the staged output tile (row r, 16-byte chunk c at position
@@ -308,6 +358,17 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
       const int i = min(i0 + r, a.I - 1);
       *reinterpret_cast<bf16x8*>(a.C + (int64_t)i * a.ldc + j0 + 8 * p) = v;
     }
+    if constexpr (XT == 1) {
+      if (wave == 0) {                           // (one more store instruction for wave 0, ahead of the k-loop's DMAs like the others)
+        const int r = lane & 31;
+        const float* sp = sStat + (size_t)(t & 1) * NW * BM * 2 + r * 2;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { s1 += sp[w * BM * 2]; s2 += sp[w * BM * 2 + 1]; }
+        const int i = min(i0 + r, a.I - 1);
+        if (lane < 32) *reinterpret_cast<float2*>(a.stats_out + ((int64_t)i * a.np + panel) * 2) = make_float2(s1, s2);
+      }
+    }
   };
 
   // Requests of iteration t, in this order: residual of tile t and stores of tile t - 2 (ahead of the k-loop), then the
@@ -324,6 +385,15 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
     asm volatile("" ::: "memory");
     if (t < 9) stamp(3 + t);
     dma_res(t, t & 1);
+    if constexpr (XT == 2) {
+      if (wave == 0) {                           // the statistics of tile t's rows: one 1-KiB DMA (32 rows x 4 panels x 2 floats)
+        const int i = min((t0 + t * a.g) * BM + (lane >> 1), a.I - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.stats_in + (int64_t)i * 8 + 4 * (lane & 1)),
+                                         (__attribute__((address_space(3))) void*)(sLn + (t & 1) * 1024), 16, 0, 0);
+      }
+      lnbuf = sLn + ((t + 1) & 1) * 1024;        // statistics of tile t - 1, whose epilogue runs in this iteration
+    }
+    if constexpr (XT == 1) statw = sStat + (size_t)((t + 1) & 1) * NW * BM * 2 + wave * BM * 2;
     if (t >= 2) store_tile(t - 2, sS + (t & 1) * SBUF);
     dma_pend = t + NXB - 1 < nt;                 // its DMA instructions go out between the MFMAs below
     constexpr bool DMA_IN_LOOP = OCC == 1;       // (two workgroups per CU: issued here in one block -- the other workgroup's
@@ -421,6 +491,8 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   stamp(12);
+  if constexpr (XT == 2) lnbuf = sLn + ((nt + 1) & 1) * 1024;
+  if constexpr (XT == 1) statw = sStat + (size_t)((nt + 1) & 1) * NW * BM * 2 + wave * BM * 2;
   if (nt >= 2) store_tile(nt - 2, sS + (nt & 1) * SBUF);
   {
     char* stg = sS + ((nt + 1) & 1) * SBUF;
@@ -435,7 +507,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + 14] = (unsigned long long)nt;
 }
 
-template <int KW, int KSPLIT, int NWJ, int NCB, int EPI, int OCC = 1>
+template <int KW, int KSPLIT, int NWJ, int NCB, int EPI, int OCC = 1, int XT = 0>
 int launch_ws(const hig_gemm16_desc& g, int slots_per_xcd, hipStream_t st) {
   constexpr int BN = 32 * NWJ * NCB;
   WsArgs a;
@@ -448,6 +520,9 @@ int launch_ws(const hig_gemm16_desc& g, int slots_per_xcd, hipStream_t st) {
   a.np = g.J / BN;
   a.g = slots_per_xcd / a.np;
   a.ntiles = (g.I + 31) / 32;
+  a.stats_out = g.row_stats_out;
+  a.stats_in = g.row_stats_in;
+  a.colsum = g.ln_colsum;
   a.stamps = g_ws_stamps;
   static const int dbg = getenv("HIG_BF16_WS_DBG") ? atoi(getenv("HIG_BF16_WS_DBG")) : 0;   // timing ablations (diagnostic instances only)
   if constexpr (KW == 512 && KSPLIT == 1 && NWJ == 4 && NCB == 2 && EPI == HIG_EPI_BIAS_GELU) {
@@ -463,7 +538,7 @@ int launch_ws(const hig_gemm16_desc& g, int slots_per_xcd, hipStream_t st) {
       default: break;
     }
   }
-  hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 0, OCC>), dim3(8 * slots_per_xcd), dim3(64 * NWJ * KSPLIT), 0, st, a);
+  hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 0, OCC, XT>), dim3(8 * slots_per_xcd), dim3(64 * NWJ * KSPLIT), 0, st, a);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
@@ -479,6 +554,13 @@ int launch_ws_sized(const hig_gemm16_desc& g, int nwj, hipStream_t st) {
     if (nwj == 44 && g.R == 256) return launch_ws<256, 1, 4, 1, EPI, 2>(g, 64, st);
   }
   if (nwj == 44) nwj = 4;
+  // LayerNorm folded into the next GEMM (K = 512): the producer writes row statistics, the consumer applies them
+  if constexpr (EPI == HIG_EPI_BIAS_RES) {
+    if (g.row_stats_out) return launch_ws<512, 1, 4, 1, EPI, 1, 1>(g, 32, st);
+  }
+  if constexpr (EPI == HIG_EPI_BIAS) {
+    if (g.row_stats_in) return nwj == 8 ? launch_ws<512, 1, 8, 1, EPI, 1, 2>(g, 32, st) : launch_ws<512, 1, 4, 1, EPI, 1, 2>(g, 32, st);
+  }
   if (g.R == 512) return nwj == 8 ? launch_ws<512, 1, 8, 1, EPI>(g, 32, st) : nwj == 2 ? launch_ws<512, 1, 4, 2, EPI>(g, 32, st) : launch_ws<512, 1, 4, 1, EPI>(g, 32, st);
   if (g.R == 256) return nwj == 8 ? launch_ws<256, 1, 8, 1, EPI>(g, 32, st) : launch_ws<256, 1, 4, 1, EPI>(g, 32, st);
   if constexpr (EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU) return 1;   // (no LDS left for residual tiles)
@@ -493,6 +575,13 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
   static const int ws_on = getenv("HIG_BF16_WS") ? atoi(getenv("HIG_BF16_WS")) : 1;          // tuning knob: 0 = tiled kernel only
   static const int forced_nwj = getenv("HIG_BF16_WS_NWJ") ? atoi(getenv("HIG_BF16_WS_NWJ")) : 0;   // 4 / 8
   static const int min_rows = getenv("HIG_BF16_WS_ROWS") ? atoi(getenv("HIG_BF16_WS_ROWS")) : 2048;
+  const bool fold = g.row_stats_out || g.row_stats_in;
+  if (fold) {   // only this kernel implements the LayerNorm fold: the caller checks hig_gemm_ws16_lnfold_ok() first
+    const bool ok = ws_on && !g.c_f32 && !(g.res && g.res_f32) && g.R == 512 && g.I >= min_rows &&
+                    (g.row_stats_out ? (g.epi == HIG_EPI_BIAS_RES && g.J == 512 && !g.row_stats_in)
+                                     : (g.epi == HIG_EPI_BIAS && g.ln_colsum && g.J % 128 == 0));
+    if (!ok) return hig_set_error(HIG_EUNSUPPORTED, "hig_gemm_bf16: LayerNorm-fold operands on a shape the weight-stationary kernel does not serve");
+  }
   if (!ws_on) return 1;
   if (g.c_f32 || (g.res && g.res_f32)) return 1;
   if (!(g.R == 256 || g.R == 512 || g.R == 1024)) return 1;
@@ -514,7 +603,8 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
   // each from one wave); two 4-wave workgroups per CU put a second, independent wave on every SIMD: FFN linear1 at
   // M = 12 544 28.5 -> 25.2 us, at M = 6 272 17.2 -> 15.1 us
   if (g.epi == HIG_EPI_BIAS_GELU && g.R != 1024) nwj = 44;
-  if (forced_nwj == 4 || (forced_nwj == 8 && g.R != 1024) || (forced_nwj == 2 && g.R == 512) || (forced_nwj == 44 && g.R != 1024)) nwj = forced_nwj;
+  if (g.row_stats_out) nwj = 4;                 // (the statistics are per 128-column panel)
+  else if (forced_nwj == 4 || (forced_nwj == 8 && g.R != 1024) || (forced_nwj == 2 && g.R == 512) || (forced_nwj == 44 && g.R != 1024)) nwj = forced_nwj;
   const int bn = (nwj == 4 || nwj == 44) ? 128 : 256;
   if (g.J % bn != 0) {
     if (g.J % 128 == 0) nwj = 4; else return 1;
@@ -537,4 +627,14 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
 extern "C" int hig_gemm_ws16_debug_stamps(void* buf) {
   g_ws_stamps = static_cast<unsigned long long*>(buf);
   return HIG_OK;
+}
+
+// Can a d-wide LayerNorm in front of a GEMM over `rows` rows be folded into the weight-stationary kernels (the producer of
+// the rows writes their statistics, the consumer applies them)?  HIG_LNFOLD=0 switches it off.
+bool hig_gemm_ws16_lnfold_ok(int64_t rows, int d) {
+  static const int on = getenv("HIG_LNFOLD") ? atoi(getenv("HIG_LNFOLD")) : 1;            // tuning knob
+  static const int ws_on = getenv("HIG_BF16_WS") ? atoi(getenv("HIG_BF16_WS")) : 1;
+  static const int min_rows = getenv("HIG_BF16_WS_ROWS") ? atoi(getenv("HIG_BF16_WS_ROWS")) : 2048;
+  static const int forced_nwj = getenv("HIG_BF16_WS_NWJ") ? atoi(getenv("HIG_BF16_WS_NWJ")) : 0;
+  return on && ws_on && !forced_nwj && d == 512 && rows >= min_rows;
 }

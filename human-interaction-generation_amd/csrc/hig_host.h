@@ -20,6 +20,7 @@ void hig_gemm_set_tail_scratch(void* ws, int64_t bytes);
 int hig_gemm16_launch(const hig_gemm16_desc& g, hipStream_t st);
 // weight-stationary variant (gemm_ws16.hip): HIG_OK = launched, 1 = shape not served (use the tiled kernel), < 0 = error
 int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st);
+bool hig_gemm_ws16_lnfold_ok(int64_t rows, int d);
 
 namespace {
 

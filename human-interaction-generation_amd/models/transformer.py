@@ -602,6 +602,35 @@ class MotionTransformer(nn.Module):
             self._textctx_cache = (key, buf, xf_out)  # keep xf_out alive so the key stays unique
         return buf
 
+    def _lnfold_table(self, fp):
+        """Operands of the LayerNorm-folded q/k/v and cross-attention query GEMMs of the bf16-storage forward (d = 512):
+        per layer [W'_qkv (bf16), colsum_qkv, bias'_qkv, W'_q (bf16), colsum_q, bias'_q] with W' = gamma (.) W,
+        colsum[j] = sum_r float(W'[j][r]), bias' = b + W beta -- LayerNorm(x) W^T + b == rstd (x W'^T) - rstd mean colsum +
+        bias' (transformer.py:108-110,144).  The library applies them wherever the producer of x wrote its row statistics;
+        rebuilt when the parameters change.  None: no fold (the library runs its LayerNorm kernel)."""
+        if self.latent_dim != 512:
+            return None
+        ver = (self._param_version(), fp.flat.data_ptr())
+        if getattr(self, "_lnfold", None) is None or self._lnfold[0] != ver:
+            d, nl, ng, offs = self.latent_dim, _lib.NLAYER, _lib.NGLOBAL, fp.group_offsets
+            arr, bufs = (C.c_void_p * (6 * self.num_layers))(), []
+            with torch.no_grad():
+                for l in range(self.num_layers):
+                    def grp(idx, n):
+                        o = offs[ng + l * nl + idx]
+                        return fp.flat[o:o + n]
+                    # (norm weight, norm bias, Linear weight, Linear bias, output rows): sa_block q/k/v, ca_block query
+                    for k, (nw, nb, wi, bi, rows) in enumerate(((0, 1, 2, 3, 3 * d), (8, 9, 12, 13, d))):
+                        gamma, beta = grp(nw, d), grp(nb, d)
+                        W, b = grp(wi, rows * d).view(rows, d), grp(bi, rows)
+                        Wp = (W * gamma[None, :]).to(torch.bfloat16).contiguous()
+                        cs = Wp.float().sum(dim=1).contiguous()
+                        bp = (b + W @ beta).contiguous()
+                        bufs += [Wp, cs, bp]
+                        arr[6 * l + 3 * k], arr[6 * l + 3 * k + 1], arr[6 * l + 3 * k + 2] = Wp.data_ptr(), cs.data_ptr(), bp.data_ptr()
+            self._lnfold = (ver, arr, bufs)
+        return self._lnfold[1]
+
     def _launch_forward(self, x, t, length, xf_proj, xf_out, training):
         B, T, N = x.shape[0], x.shape[1], xf_out.shape[1]
         assert xf_out.shape == (B, N, self.text_latent_dim) and xf_proj.shape == (B, self.time_embed_dim)
@@ -618,8 +647,9 @@ class MotionTransformer(nn.Module):
         out = torch.empty(B, T, self.input_feats, device=x.device, dtype=torch.float32)
         if self._bf16():
             _lib.check(L.hig_denoiser_fwd_bf16(C.byref(dims), fp.param_table(), fp.shadow16(self._param_version()),
-                                               _lib.ptr(x), _lib.ptr(t), _lib.ptr(length), _lib.ptr(xf_proj),
-                                               _lib.ptr(textctx), _lib.ptr(out), _lib.ptr(ws), _lib.stream_ptr()))
+                                               self._lnfold_table(fp), _lib.ptr(x), _lib.ptr(t), _lib.ptr(length),
+                                               _lib.ptr(xf_proj), _lib.ptr(textctx), _lib.ptr(out), _lib.ptr(ws),
+                                               _lib.stream_ptr()))
             self._pool.give("fwd_i", ws, x.device)
             return out, None
         _lib.check(L.hig_denoiser_fwd(C.byref(dims), fp.param_table(), _lib.ptr(x), _lib.ptr(t),

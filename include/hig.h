@@ -178,7 +178,13 @@ int hig_denoiser_fwd(const hig_dims* dims, const void* const* params, const floa
  * Workspace / text-context sizes: hig_workspace_bytes / hig_textctx_bytes with the same dims (training = 0). */
 int hig_text_context_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
                           const float* xf_out, void* textctx, hig_stream_t stream);
-int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* params, const void* const* params16, const float* x,
+/* lnfold (nullable; d == 512): per layer l six device pointers [6 l + 0 .. 5] = W'_qkv (bf16, 3d x d), colsum_qkv (fp32, 3d),
+ * bias'_qkv (fp32, 3d), W'_q (bf16, d x d), colsum_q, bias'_q of the cross-attention query -- W' = gamma (.) W of the
+ * LayerNorm in front of the Linear, colsum[j] = sum_r float(W'[j][r]), bias' = b + W beta.  With them (and >= 2048 rows)
+ * the LayerNorm kernels in front of the q/k/v and query projections disappear: the stylization-out GEMM that produces the
+ * residual stream also writes its row statistics, and the projection applies them in its epilogue (hig_gemm16_desc). */
+int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
+                          const void* const* lnfold, const float* x,
                           const int64_t* t, const int64_t* length, const float* xf_proj, const void* textctx,
                           float* out, void* workspace, hig_stream_t stream);
 
@@ -391,6 +397,14 @@ typedef struct hig_gemm16_desc {
   int32_t epi;
   const float* bias;
   const void* res; int64_t ldr; int32_t res_f32;
+  /* LayerNorm folded into the NEXT GEMM (weight-stationary kernel only: >= 2048 rows, R == 512; all NULL otherwise):
+   * row_stats_out (EPI_BIAS_RES, J == 512): also write (sum, sum of squares) of the bf16-rounded output rows per 128-column
+   * panel, [I][4][2] fp32.  row_stats_in + ln_colsum (EPI_BIAS): X holds UN-normalised rows whose statistics are in
+   * row_stats_in; Y must be W' = bf16(gamma (.) W), ln_colsum[j] = sum_r float(W'[j][r]), bias[j] = b[j] + sum_r beta[r] W[j][r]:
+   * C = rstd (X W'^T) - rstd mean ln_colsum + bias  ==  LayerNorm(X) W^T + b  (transformer.py:108-110,144). */
+  float* row_stats_out;
+  const float* row_stats_in;
+  const float* ln_colsum;
 } hig_gemm16_desc;
 int hig_gemm_bf16(const hig_gemm16_desc* g, hig_stream_t stream);
 /* Diagnostics (tools/gemm16_stamps.py, tools/gemm_ws16_stamps.py): while buf != NULL, thread 0 of every workgroup of the

@@ -76,7 +76,7 @@ int main() {
     EXPECT(hig_last_error(msg, 4) >= 0 && strlen(msg) <= 3);                               // truncation, no overrun
     // entry points with null arguments / mismatched storage
     EXPECT(hig_denoiser_fwd(&D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr) != HIG_OK);
-    EXPECT(hig_denoiser_fwd_bf16(&D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != HIG_OK);
+    EXPECT(hig_denoiser_fwd_bf16(&D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != HIG_OK);
     EXPECT(hig_text_context(&D, nullptr, nullptr, nullptr, 0, nullptr) != HIG_OK);
   }
   // ---- scratch-size queries ----

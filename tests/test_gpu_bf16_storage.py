@@ -127,6 +127,54 @@ def test_gemm_ws16_every_variant(I, J, R, epi, nwj, monkeypatch):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("I,J", [(6272, 1536), (12544, 512), (2049, 512), (3000, 1536)])
+def test_layernorm_folded_into_the_weight_stationary_gemm(I, J):
+    """LayerNorm(x) W^T + b without a LayerNorm kernel (hig_gemm16_desc.row_stats_*): the GEMM that PRODUCES x also writes
+    (sum, sum of squares) of its bf16 output rows per 128-column panel; the consumer runs on the un-normalised x with
+    W' = gamma (.) W and applies rstd / mean / column sums / bias' in its epilogue.  Checked: the statistics against the
+    producer's own output, the consumer against the fp64 LayerNorm + Linear of the same bf16 x (transformer.py:108-110)."""
+    d = 512
+    g = torch.Generator().manual_seed(I + J)
+    L = _lib.lib()
+    # producer: h = a Wo^T + bo + h_old (a stylization-out GEMM), with statistics
+    a16, Wo = bf(torch.randn(I, d, generator=g)), bf(torch.randn(d, d, generator=g) / d ** 0.5)
+    bo = torch.randn(d, generator=g)
+    hold = bf(torch.randn(I, d, generator=g) * 3 + 1.5)               # (a mean far from zero: the fold must cancel it)
+    ad, Wod, bod = a16.to(DEV), Wo.to(DEV), bo.to(DEV)
+    h = hold.to(DEV).clone()
+    stats = torch.full((I, 4, 2), float("nan"), device=DEV)
+    dsc = _lib.Gemm16Desc()
+    dsc.X, dsc.ldx, dsc.Y, dsc.ldy, dsc.C, dsc.ldc, dsc.c_f32 = ad.data_ptr(), d, Wod.data_ptr(), d, h.data_ptr(), d, 0
+    dsc.I, dsc.J, dsc.R, dsc.epi, dsc.bias = I, d, d, _lib.EPI_BIAS_RES, bod.data_ptr()
+    dsc.res, dsc.ldr, dsc.res_f32 = h.data_ptr(), d, 0
+    dsc.row_stats_out = stats.data_ptr()
+    _lib.check(L.hig_gemm_bf16(C.byref(dsc), _lib.stream_ptr()))
+    ref_h = a16.double() @ Wo.double().t() + bo.double() + hold.double()
+    assert rel(h.float(), ref_h) < 3e-3
+    hp = h.float().double().cpu().view(I, 4, 128)
+    assert rel(stats[:, :, 0], hp.sum(-1)) < 1e-5 and rel(stats[:, :, 1], (hp * hp).sum(-1)) < 1e-5
+    # consumer: LN(h) W^T + b through the folded operands
+    gamma, beta = 1 + 0.2 * torch.randn(d, generator=g), 0.3 * torch.randn(d, generator=g)
+    W, b = torch.randn(J, d, generator=g) / d ** 0.5, torch.randn(J, generator=g)
+    Wp = bf(W * gamma[None, :])
+    cs, bp = Wp.float().sum(1), b + W @ beta
+    out = torch.full((I, J), float("nan"), device=DEV, dtype=torch.bfloat16)
+    Wpd, csd, bpd = Wp.to(DEV), cs.to(DEV), bp.to(DEV)
+    c2 = _lib.Gemm16Desc()
+    c2.X, c2.ldx, c2.Y, c2.ldy, c2.C, c2.ldc, c2.c_f32 = h.data_ptr(), d, Wpd.data_ptr(), d, out.data_ptr(), J, 0
+    c2.I, c2.J, c2.R, c2.epi, c2.bias = I, J, d, _lib.EPI_BIAS, bpd.data_ptr()
+    c2.row_stats_in, c2.ln_colsum = stats.data_ptr(), csd.data_ptr()
+    _lib.check(L.hig_gemm_bf16(C.byref(c2), _lib.stream_ptr()))
+    hd = h.float().double().cpu()
+    ref = torch.nn.functional.layer_norm(hd, (d,), gamma.double(), beta.double(), 1e-5) @ W.double().t() + b.double()
+    assert torch.isfinite(out.float()).all()
+    assert rel(out.float(), ref) < 4e-3
+    # shapes the kernel does not serve must fail loudly, not silently drop the LayerNorm
+    c2.I = 100
+    with pytest.raises(RuntimeError, match="LayerNorm-fold"):
+        _lib.check(L.hig_gemm_bf16(C.byref(c2), _lib.stream_ptr()))
+
+
 def test_gemm_bf16_rejects_what_it_cannot_run():
     X = torch.zeros(64, 48, device=DEV, dtype=torch.bfloat16)
     out = torch.zeros(64, 64, device=DEV, dtype=torch.bfloat16)
