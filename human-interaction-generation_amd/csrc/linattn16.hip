@@ -32,41 +32,68 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 
-// HD: head dim (64); H: heads (4 or 8); rows of Q / Out are d = H * HD bf16 wide.  grid = (ceil(T / 32), B).
-template <int HD, int H>
-__global__ __launch_bounds__(256) void apply_sty16_kernel(const __bf16* __restrict__ Q, int64_t ldq,
-                                                          const __bf16* __restrict__ At16, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, const float* __restrict__ ss,
-                                                          int64_t ss_ld, int shift_off, __bf16* __restrict__ Out, int64_t ldo,
-                                                          int T) {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// HD: head dim (64); H: heads (4 or 8); NW: waves per workgroup (H % NW == 0); rows of Q / Out are d = H * HD bf16 wide.
+// grid = (ceil(T / 32), B).
+// Instruction budget.  One workgroup per CU (105 KB of LDS) means one or two waves per SIMD, and a wave64 VALU instruction
+// takes its SIMD 4 cycles (a transcendental 16): the kernel is bound by the NUMBER of vector instructions, 64 elements per
+// lane (tools/apply16_stamps.py: 14.6 K cycles per workgroup with the straightforward arithmetic, 2.5 K of them waiting
+// for the first tile).  So the element-wise work is written on float pairs (v_pk_fma / v_pk_mul / v_pk_add_f32: two
+// elements per issue): softmax = unpack, v_max3, one packed fma into the exp2 argument, exp2, packed sum, packed scale,
+// packed convert; LayerNorm + modulation = TWO packed fmas, with gamma' = gamma (1 + scale), beta' = beta (1 + scale) +
+// shift combined once per workgroup in LDS; SiLU = packed multiply, exp2, packed add, rcp, packed multiply.
+template <int HD, int H, int NW>
+__global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __restrict__ Q, int64_t ldq,
+                                                              const __bf16* __restrict__ At16, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ ss,
+                                                              int64_t ss_ld, int shift_off, __bf16* __restrict__ Out, int64_t ldo,
+                                                              int T, unsigned long long* __restrict__ stamps) {
   constexpr int D_ = H * HD;                   // model width
   constexpr int ROWB = D_ * 2;                 // bytes of a Q / Out row
   constexpr int BR = 32;                       // rows per workgroup
-  constexpr int HPW = H / 4;                   // heads per wave
+  constexpr int NT = 64 * NW;                  // threads
+  constexpr int HPW = H / NW;                  // heads per wave
   constexpr int NKS = HD / 16, NLB = HD / 32;  // MFMA k-steps / 32-column blocks per head
   constexpr int QBYTES = BR * ROWB;
   constexpr int ATROWB = HD * 2;               // bytes of an At row (one l, all c)
   constexpr int ATBYTES = H * HD * ATROWB;
+  constexpr float LOG2E = 1.4426950408889634f;
   static_assert(HD == 64, "At swizzle below is written for 128-byte rows");
   static_assert(ROWB == 1024 || ROWB == 512, "Q rows of 512 or 1024 bytes");
-  __shared__ __attribute__((aligned(1024))) char smem[QBYTES + ATBYTES + 4 * D_ * 4 + 4 * BR * 2 * 4];
+  static_assert(H % NW == 0, "whole heads per wave");
+  __shared__ __attribute__((aligned(1024))) char smem[QBYTES + ATBYTES + 4 * D_ * 4 + NW * BR * 2 * 4];
   char* const sQ = smem;                                       // [32][ROWB] bf16, 16-byte chunk c of row r at c ^ (r & 15); later the output tile
   char* const sAt = smem + QBYTES;                             // [H * HD][128 B] bf16, chunk c of row r at c ^ ((r >> 1) & 7)
-  float* const sPar = reinterpret_cast<float*>(smem + QBYTES + ATBYTES);   // gamma | beta | scale | shift
-  float* const sRed = sPar + 4 * D_;                           // [4 waves][32 rows][2]
+  float* const sPar = reinterpret_cast<float*>(smem + QBYTES + ATBYTES);   // gamma | beta | scale | shift, then gamma' | beta'
+  float* const sRed = sPar + 4 * D_;                           // [NW waves][32 rows][2]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.y, r0 = blockIdx.x * BR;
   const __bf16* Qb = Q + (int64_t)b * T * ldq;
+  auto stamp = [&](int k) {                    // diagnostic only (hig_linattn16_debug_stamps); stamps == NULL in every real run
+    if (stamps && tid == 0) {
+      unsigned long long tm;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm)::"memory");
+      stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = tm;
+    }
+  };
+  stamp(0);
 
   // ---- Q tile by DMA: whole rows, swizzled on the source side ---------------------------------------------------
   {
-    constexpr int NDMA = QBYTES / 1024, NQ = NDMA / 4;
+    constexpr int NDMA = QBYTES / 1024, NQ = NDMA / NW;
+    static_assert(NDMA % NW == 0, "Q tile in whole rounds of the waves");
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int n = wave + 4 * q;
+      const int n = wave + NW * q;
       const __bf16* src;
       if constexpr (ROWB == 1024) {
         src = Qb + (int64_t)min(r0 + n, T - 1) * ldq + 8 * (lane ^ (n & 15));
@@ -80,13 +107,14 @@ __global__ __launch_bounds__(256) void apply_sty16_kernel(const __bf16* __restri
   }
   // ---- gamma | beta | scale | shift (fp32, D_ each) by DMA as well: no VGPR-returning load in this kernel, so hipcc has
   // nothing to guard with a vmcnt(0) of its own while the DMAs are in flight ------------------------------------------
+  constexpr int NP = 4 * D_ * 4 / 1024;          // 1-KiB instructions for the four vectors
+  constexpr int NPW = (NP + NW - 1) / NW;        // ... per wave (the last round may be partly filled: NP = 4 at d = 256)
   {
-    constexpr int NP = 4 * D_ * 4 / 1024;        // 1-KiB instructions for the four vectors
-    static_assert(NP % 4 == 0 && (D_ * 4) % 1024 == 0, "parameter vectors in whole 1-KiB pieces");
+    static_assert((D_ * 4) % 1024 == 0, "parameter vectors in whole 1-KiB pieces");
     const float* ssb = ss + (int64_t)b * ss_ld;
 #pragma unroll
-    for (int q = 0; q < NP / 4; ++q) {
-      const int n = wave + 4 * q;               // piece n: vector n / (D_ / 256), part n % (D_ / 256)
+    for (int q = 0; q < NPW; ++q) {
+      const int n = min(wave + NW * q, NP - 1);   // piece n: vector n / (D_ / 256), part n % (D_ / 256); a surplus wave repeats the last piece
       const int vec = n / (D_ / 256), part = n % (D_ / 256);
       const float* base = vec == 0 ? gamma : vec == 1 ? beta : vec == 2 ? ssb : ssb + shift_off;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + part * 256 + lane * 4),
@@ -95,12 +123,13 @@ __global__ __launch_bounds__(256) void apply_sty16_kernel(const __bf16* __restri
   }
   // ---- context matrices of this sample, At16[b][h][l][c] (hig_linattn_ctx_bf16 wrote them transposed and rounded): all
   // H heads by DMA, 8 rows of 128 bytes per instruction, chunk c of row r to position c ^ ((r >> 1) & 7) ----------------
+  constexpr int NA = ATBYTES / 1024 / NW;
   {
+    static_assert((ATBYTES / 1024) % NW == 0, "context matrices in whole rounds of the waves");
     const __bf16* Ab = At16 + (int64_t)b * H * HD * HD;
-    constexpr int NA = ATBYTES / 1024 / 4;
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
-      const int n = wave + 4 * q;
+      const int n = wave + NW * q;
       const int row = 8 * n + (lane >> 3), pos = lane & 7;
       const __bf16* src = Ab + (int64_t)row * HD + 8 * (pos ^ ((row >> 1) & 7));
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -109,53 +138,70 @@ __global__ __launch_bounds__(256) void apply_sty16_kernel(const __bf16* __restri
   }
   // (requests so far, oldest first: Q tile, LayerNorm / modulation vectors, context matrices.  The softmax below needs
   // only the Q tile: it runs while the 64 KB of context matrices are still landing.)
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ATBYTES / 1024 / 4) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
   __syncthreads();
+  stamp(1);
+
+  // ---- gamma' = gamma (1 + scale), beta' = beta (1 + scale) + shift, in place over gamma | beta (each thread its own
+  // columns; read after the next barrier) ----------------------------------------------------------------------------
+  for (int c = tid; c < D_; c += NT) {
+    const float g = sPar[c], be = sPar[D_ + c], sc = 1.0f + sPar[2 * D_ + c], sh = sPar[3 * D_ + c];
+    sPar[c] = g * sc;
+    sPar[D_ + c] = fmaf(be, sc, sh);
+  }
 
   // ---- per head: softmax over the head's channels (a row is shared by lanes lr and lr + 32), then y = p . A ----------
-  f32x16 acc[HPW][NLB];
-  float s1 = 0.f, s2 = 0.f;                    // this lane's share of sum(y), sum(y^2) over its row
   bf16x8 pfs[HPW][NKS];
 #pragma unroll
   for (int hh = 0; hh < HPW; ++hh) {
-    const int h = wave + 4 * hh;
+    const int h = wave + NW * hh;
     u32x4 qf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const int chunk = (h * HD) / 8 + 2 * ks + lh;
       qf[ks] = *reinterpret_cast<const u32x4*>(sQ + lr * ROWB + 16 * (chunk ^ (lr & 15)));
     }
-    float v[NKS][8];
+    f32x2 v[NKS][4];
     float mx = -INFINITY;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[ks][2 * e] = bf_lo(qf[ks][e]);
-        v[ks][2 * e + 1] = bf_hi(qf[ks][e]);
-        mx = fmaxf(mx, fmaxf(v[ks][2 * e], v[ks][2 * e + 1]));
+        v[ks][e] = f32x2{bf_lo(qf[ks][e]), bf_hi(qf[ks][e])};
+        mx = max3f(mx, v[ks][e][0], v[ks][e][1]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
+    const float m2 = -mx * LOG2E;
+    f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[ks][e] = __expf(v[ks][e] - mx);
-        sum += v[ks][e];
+      for (int e = 0; e < 4; ++e) {
+        const f32x2 arg = __builtin_elementwise_fma(v[ks][e], f32x2{LOG2E, LOG2E}, f32x2{m2, m2});
+        v[ks][e] = f32x2{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+        sum2 += v[ks][e];
       }
+    float sum = sum2[0] + sum2[1];
     sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+    const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pfs[hh][ks][e] = (__bf16)(v[ks][e] * inv);
+      for (int e = 0; e < 4; ++e) {
+        const f32x2 pp = v[ks][e] * inv;
+        pfs[hh][ks][2 * e] = (__bf16)pp[0];
+        pfs[hh][ks][2 * e + 1] = (__bf16)pp[1];
+      }
   }
+  stamp(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the context matrices have landed
   __syncthreads();
+  stamp(3);
+  f32x16 acc[HPW][NLB];
+  f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};      // this lane's share of sum(y), sum(y^2) over its row
 #pragma unroll
   for (int hh = 0; hh < HPW; ++hh) {
-    const int h = wave + 4 * hh;
+    const int h = wave + NW * hh;
 #pragma unroll
     for (int lb = 0; lb < NLB; ++lb) {
 #pragma unroll
@@ -167,28 +213,26 @@ __global__ __launch_bounds__(256) void apply_sty16_kernel(const __bf16* __restri
         acc[hh][lb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pfs[hh][ks], acc[hh][lb], 0, 0, 0);
       }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        s1 += acc[hh][lb][e];
-        s2 += acc[hh][lb][e] * acc[hh][lb][e];
+      for (int e = 0; e < 16; e += 2) {
+        const f32x2 y = {acc[hh][lb][e], acc[hh][lb][e + 1]};
+        s1 += y;
+        s2 = __builtin_elementwise_fma(y, y, s2);
       }
     }
   }
-  // ---- LayerNorm statistics of the 32 rows: lane pair, then the four waves ------------------------------------------
-  s1 += __shfl_xor(s1, 32, 64);
-  s2 += __shfl_xor(s2, 32, 64);
-  if (lh == 0) {
-    sRed[(wave * BR + lr) * 2] = s1;
-    sRed[(wave * BR + lr) * 2 + 1] = s2;
-  }
+  // ---- LayerNorm statistics of the 32 rows: lane pair, then the waves ------------------------------------------------
+  float r1 = s1[0] + s1[1], r2 = s2[0] + s2[1];
+  r1 += __shfl_xor(r1, 32, 64);
+  r2 += __shfl_xor(r2, 32, 64);
+  if (lh == 0) *reinterpret_cast<f32x2*>(sRed + (wave * BR + lr) * 2) = f32x2{r1, r2};
+  stamp(4);
   __syncthreads();                              // (also: every wave is done reading sQ -- it becomes the output tile)
-  float t1 = 0.f, t2 = 0.f;
+  f32x2 t12 = {0.f, 0.f};
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    t1 += sRed[(w * BR + lr) * 2];
-    t2 += sRed[(w * BR + lr) * 2 + 1];
-  }
-  const float mean = t1 * (1.0f / D_);
-  const float rstd = rsqrtf(fmaxf(t2 * (1.0f / D_) - mean * mean, 0.f) + 1e-5f);
+  for (int w = 0; w < NW; ++w) t12 += *reinterpret_cast<const f32x2*>(sRed + (w * BR + lr) * 2);
+  const float mean = t12[0] * (1.0f / D_);
+  const float rstd = rsqrtf(fmaxf(t12[1] * (1.0f / D_) - mean * mean, 0.f) + 1e-5f);
+  const f32x2 rs2 = {rstd, rstd}, nm2 = {-mean * rstd, -mean * rstd};
   // ---- LN, modulation, SiLU; bf16 tile into LDS (same swizzle as the Q tile) -----------------------------------------
 #pragma unroll
   for (int hh = 0; hh < HPW; ++hh)
@@ -196,29 +240,34 @@ __global__ __launch_bounds__(256) void apply_sty16_kernel(const __bf16* __restri
     for (int lb = 0; lb < NLB; ++lb)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int col = (wave + 4 * hh) * HD + 32 * lb + 8 * q + 4 * lh;
+        const int col = (wave + NW * hh) * HD + 32 * lb + 8 * q + 4 * lh;
         const f32x4 g4 = *reinterpret_cast<const f32x4*>(sPar + col), b4 = *reinterpret_cast<const f32x4*>(sPar + D_ + col);
-        const f32x4 sc4 = *reinterpret_cast<const f32x4*>(sPar + 2 * D_ + col) + 1.0f, sh4 = *reinterpret_cast<const f32x4*>(sPar + 3 * D_ + col);
-        float o[4];
+        f32x2 o[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float u = (acc[hh][lb][4 * q + e] - mean) * rstd * g4[e] + b4[e];
-          o[e] = hig_silu_fast(u * sc4[e] + sh4[e]);
+        for (int e = 0; e < 2; ++e) {
+          const f32x2 y = {acc[hh][lb][4 * q + 2 * e], acc[hh][lb][4 * q + 2 * e + 1]};
+          const f32x2 u = __builtin_elementwise_fma(y, rs2, nm2);
+          const f32x2 x = __builtin_elementwise_fma(u, f32x2{g4[2 * e], g4[2 * e + 1]}, f32x2{b4[2 * e], b4[2 * e + 1]});
+          const f32x2 w = x * -LOG2E;
+          const f32x2 den = f32x2{__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])} + 1.0f;
+          o[e] = x * f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
         }
         *reinterpret_cast<bf16x4*>(sQ + lr * ROWB + 16 * ((col >> 3) ^ (lr & 15)) + 2 * (col & 7)) =
-            bf16x4{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+            bf16x4{(__bf16)o[0][0], (__bf16)o[0][1], (__bf16)o[1][0], (__bf16)o[1][1]};
       }
   __syncthreads();
+  stamp(5);
   // ---- whole rows out ----------------------------------------------------------------------------------------------
   constexpr int PPR = ROWB / 16;
 #pragma unroll
-  for (int u = 0; u < BR * PPR / 256; ++u) {
-    const int idx = tid + 256 * u;
+  for (int u = 0; u < BR * PPR / NT; ++u) {
+    const int idx = tid + NT * u;
     const int r = idx / PPR, p = idx % PPR;
     if (r0 + r < T)
       *reinterpret_cast<bf16x8*>(Out + ((int64_t)b * T + r0 + r) * ldo + 8 * p) =
           *reinterpret_cast<const bf16x8*>(sQ + r * ROWB + 16 * (p ^ (r & 15)));
   }
+  stamp(6);
 }
 
 
@@ -417,6 +466,15 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
 // Out = silu( LN( softmax_hd(Q) . A ) * (1 + scale) + shift ), bf16 matrix products (see the kernel).  Q, Out bf16 (B * rows,
 // H * hd); At16 bf16 (B, H, hd, hd) [l][c] = the TRANSPOSED context matrices (hig_linattn_ctx_bf16); gamma, beta, ss fp32; scale = ss[b][0 .. d), shift = ss[b][shift_off .. + d).
 // Head dim 64 with 4 or 8 heads (other shapes: hig_linattn_apply_sty_bf16 / the unfused pair).
+unsigned long long* g_ap_stamps = nullptr;
+// Diagnostic: thread 0 of every workgroup of apply_sty16_kernel writes s_memtime stamps to buf[workgroup * 8 + k] (k: 0 start,
+// 1 Q tile landed, 2 softmax done, 3 context matrices landed, 4 products + row sums done, 5 output tile in LDS, 6 end).
+// NULL switches it off.  Never part of a timed run (tools/apply16_stamps.py).
+extern "C" int hig_linattn16_debug_stamps(void* buf) {
+  g_ap_stamps = static_cast<unsigned long long*>(buf);
+  return HIG_OK;
+}
+
 extern "C" int hig_linattn_apply_sty_mm16(const void* Q, int64_t ldq, const void* At16, const float* gamma, const float* beta,
                                           const float* ss, int64_t ss_ld, int32_t ss_shift_off, void* Out, int64_t ldo,
                                           int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream) {
@@ -430,12 +488,16 @@ extern "C" int hig_linattn_apply_sty_mm16(const void* Q, int64_t ldq, const void
               "hig_linattn_apply_sty_mm16: alignment");
   const dim3 grid((rows + 31) / 32, B);
   hipStream_t st = hig_stream(stream);
-  if (H == 8)
-    hipLaunchKernelGGL((apply_sty16_kernel<64, 8>), grid, dim3(256), 0, st, static_cast<const __bf16*>(Q), ldq, static_cast<const __bf16*>(At16), gamma, beta, ss,
-                       ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo, rows);
+  static const int nw8 = getenv("HIG_APPLY16_NW") ? atoi(getenv("HIG_APPLY16_NW")) : 8;      // tuning knob: waves per workgroup at 8 heads
+  if (H == 8 && nw8 == 8)
+    hipLaunchKernelGGL((apply_sty16_kernel<64, 8, 8>), grid, dim3(512), 0, st, static_cast<const __bf16*>(Q), ldq, static_cast<const __bf16*>(At16), gamma, beta, ss,
+                       ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo, rows, g_ap_stamps);
+  else if (H == 8)
+    hipLaunchKernelGGL((apply_sty16_kernel<64, 8, 4>), grid, dim3(256), 0, st, static_cast<const __bf16*>(Q), ldq, static_cast<const __bf16*>(At16), gamma, beta, ss,
+                       ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo, rows, g_ap_stamps);
   else
-    hipLaunchKernelGGL((apply_sty16_kernel<64, 4>), grid, dim3(256), 0, st, static_cast<const __bf16*>(Q), ldq, static_cast<const __bf16*>(At16), gamma, beta, ss,
-                       ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo, rows);
+    hipLaunchKernelGGL((apply_sty16_kernel<64, 4, 4>), grid, dim3(256), 0, st, static_cast<const __bf16*>(Q), ldq, static_cast<const __bf16*>(At16), gamma, beta, ss,
+                       ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo, rows, g_ap_stamps);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

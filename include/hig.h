@@ -13,7 +13,7 @@
  *     device (hipSetDevice is the caller's job).
  *   - No global mutable state except (a) what hig_shutdown() releases (the per-thread weight-gradient stream below),
  *     (b) the diagnostic stamp pointers of hig_gemm_debug_stamps / hig_gemm_bf16_debug_stamps /
- *     hig_gemm_ws16_debug_stamps (NULL unless a profiling tool sets them; never set during a timed or captured run),
+ *     hig_gemm_ws16_debug_stamps / hig_linattn16_debug_stamps (NULL unless a profiling tool sets them; never set during a timed or captured run),
  *     and (c) tuning knobs read ONCE from the environment (HIG_*: DESIGN.md section 5 lists them) into function-local
  *     constants on first use -- after that first call they never change, so calls stay re-entrant.
  *   - Every launch is ordered through the `stream` argument (a hipStream_t passed as void*): on it,
@@ -413,6 +413,8 @@ int hig_gemm_bf16(const hig_gemm16_desc* g, hig_stream_t stream);
  * global state besides what hig_shutdown() releases; it is NULL unless a tool sets it, and is never set during a timed run. */
 int hig_gemm_bf16_debug_stamps(void* buf);
 int hig_gemm_ws16_debug_stamps(void* buf);
+/* the same for hig_linattn_apply_sty_mm16: 8 stamps per workgroup (see linattn16.hip) */
+int hig_linattn16_debug_stamps(void* buf);
 /* dst[i] = bf16(src[i]) (round to nearest even): builds the bf16 shadow of the flat fp32 parameter buffer. */
 /* joint_embed + sequence_embedding of the bf16-storage forward (transformer.py:418-419) as its own kernel pair:
  * out[m][:] = bf16( x[m][:F] . W^T + bias + pos[(m % T) - pos_shift] ), x fp32 with F (e.g. 150, 263) features per
