@@ -754,8 +754,12 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   static const int joint16 = getenv("HIG_JOINT16") ? atoi(getenv("HIG_JOINT16")) : 1;   // tuning knob
   if (joint16 && d % 128 == 0 && D.F <= 512) {
     // own kernel pair (weight padded / rounded to bf16, x rounded in LDS, bf16 MFMA): 31 -> ~8 us at B = 32
-    HIG_TRY(hig_joint_embed_bf16(x, M, D.F, P(params, HIG_P_JOINT_W), P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d,
-                                 D.T, D.two ? 1 : 0, ws + w.h, d, d, ws + w.h32, stream));
+    if (lnfold && lnfold[6 * D.L])   // (weight padded / rounded once, next to the caller's bf16 shadow)
+      HIG_TRY(hig_joint_embed_bf16_w(x, M, D.F, lnfold[6 * D.L], P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d, D.T,
+                                     D.two ? 1 : 0, ws + w.h, d, d, stream));
+    else
+      HIG_TRY(hig_joint_embed_bf16(x, M, D.F, P(params, HIG_P_JOINT_W), P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d,
+                                   D.T, D.two ? 1 : 0, ws + w.h, d, d, ws + w.h32, stream));
   } else {
     float* h32 = reinterpret_cast<float*>(ws + w.h32);
     G ge(x, D.F, 0, P(params, HIG_P_JOINT_W), D.F, 0, h32, d, M, d, D.F);
@@ -793,7 +797,7 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   // one stylization block: h += Lin_out( silu( LN(y) (1 + scale) + shift ) )      (transformer.py:81-85)
   // LayerNorm fold (see include/hig.h): when the NEXT consumer of the residual stream is a LayerNorm + Linear pair, the
   // stylization-out GEMM also writes the row statistics of the new h (`want_stats` set by the layer loop below)
-  const bool fold = lnfold && hig_gemm_ws16_lnfold_ok(M, d);
+  const bool fold = lnfold && lnfold[0] && hig_gemm_ws16_lnfold_ok(M, d);
   float* stats = reinterpret_cast<float*>(ws + w.stats);
   bool want_stats = false, have_stats = false;
   auto sty_out = [&](int l, int out_w, int out_b) -> int {

@@ -428,10 +428,11 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restri
 // (transformer.py:418-419).  x is the fp32 DDPM state with F = 150 / 263 / ... features per row (rows are not 16-byte
 // aligned, F is not a multiple of the MFMA k), the output is the bf16 residual stream.  The general kernel above cannot
 // take such operands and the exact-fp32 GEMM it went through before (+ a cast) cost 31 us of a 1.5 ms step for 1 GFLOP.
-// Here: (1) the weight is padded to Fp = 32-multiple columns and rounded to bf16 once per call (pad_cast_rows_kernel,
-// 150 KB); (2) a workgroup takes 64 rows of x, converts them to bf16 in LDS (zero beyond F), and walks the d columns
+// Here: (1) the weight is padded to Fp = 32-multiple columns and rounded to bf16 (by the caller next to its weight shadow,
+// hig_joint_embed_bf16_w, or per call by pad_cast_rows_kernel, 150 KB); (2) a workgroup takes 64 rows of x, converts them to bf16 in LDS (zero beyond F), and walks the d columns
 // of ONE block of 128 (grid.y): weight block -> LDS, v_mfma_f32_32x32x16_bf16 with the weight as the row operand (a lane then
-// holds 4 consecutive output columns), bias + positional row added in fp32, 8-byte bf16 stores.
+// holds 4 consecutive output columns); the fp32 tile goes through LDS so that bias + positional row are added and the bf16
+// result is stored a whole 256-byte row segment at a time.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void pad_cast_rows_kernel(const float* __restrict__ W, int rows, int F, int Fp, __bf16* __restrict__ out) {
   const int64_t n = (int64_t)rows * Fp;
@@ -450,66 +451,89 @@ __global__ __launch_bounds__(256) void joint_embed16_kernel(const float* __restr
   const int LDX = Fp + 8;                                  // bf16 elements per LDS row (16-byte aligned, skewed banks)
   __bf16* sX = reinterpret_cast<__bf16*>(smem_je);         // [64][LDX]
   __bf16* sW = sX + 64 * LDX;                              // [128][LDX]
+  constexpr int LDC = 132;                                 // fp32 elements per row of the output tile (over sX / sW after the products)
+  float* sC = reinterpret_cast<float*>(smem_je);           // [64][LDC]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * 64;
-  // x tile: a wave takes 16 rows, its lanes walk a row in element pairs (coalesced along the row; 8-byte loads when the
-  // rows are 8-byte aligned, i.e. F even), rounded to bf16, zero beyond F and beyond M
-  const bool pairs = (F & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
-  for (int rr = wave; rr < 64; rr += 4) {
-    const bool rv = m0 + rr < M;
-    const float* xr = x + (m0 + rr) * F;
-    for (int c = 2 * lane; c < Fp; c += 128) {
-      float v0 = 0.f, v1 = 0.f;
-      if (rv && c + 1 < F && pairs) {
-        const float2 t = *reinterpret_cast<const float2*>(xr + c);
-        v0 = t.x; v1 = t.y;
-      } else if (rv) {
-        if (c < F) v0 = xr[c];
-        if (c + 1 < F) v1 = xr[c + 1];
+  const int cb = blockIdx.y * 128;
+  // one 128-column block per workgroup (blockIdx.y): the x tile is fetched d / 128 times (from L2), in exchange every
+  // block of every row tile runs at once instead of as a serial chain of load -> MFMA -> store steps per workgroup.
+  // Weight block first (independent 16-byte loads, the loop unrolled so they are all in flight together):
+  const int c16 = Fp / 8;                                  // 16-byte chunks per padded weight row
+#pragma unroll 4
+  for (int idx = tid; idx < 128 * c16; idx += 256) {
+    const int rr = idx / c16, ch = idx % c16;
+    *reinterpret_cast<uint4*>(sW + rr * LDX + 8 * ch) = *reinterpret_cast<const uint4*>(Wp + (int64_t)(cb + rr) * Fp + 8 * ch);
+  }
+  // x tile: the 64 rows are ONE contiguous run of 64 F floats (the pose rows are dense), read as 16-byte vectors whatever
+  // F is, rounded to bf16 and scattered to (row, column) in LDS; columns F .. Fp of every row are zeroed (rows beyond M
+  // only produce outputs that are never stored)
+  {
+    const int padc = Fp - F;
+    for (int idx = tid; idx < 64 * padc; idx += 256) sX[(idx / padc) * LDX + F + idx % padc] = (__bf16)0.f;
+    const float* xt = x + m0 * F;
+    const int64_t rows_here = M - m0 < 64 ? M - m0 : 64;
+    const int n_el = (int)(rows_here * F);
+    const bool vec = (reinterpret_cast<uintptr_t>(xt) & 15) == 0;
+#pragma unroll 4
+    for (int e0 = 4 * tid; e0 < n_el; e0 += 1024) {
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (vec && e0 + 3 < n_el) {
+        const float4 q = *reinterpret_cast<const float4*>(xt + e0);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (e0 + k < n_el) v[k] = xt[e0 + k];
       }
-      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-      *reinterpret_cast<bf16x2*>(sX + rr * LDX + c) = bf16x2{(__bf16)v0, (__bf16)v1};
+      int r = e0 / F, c = e0 - r * F;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (e0 + k < n_el) sX[r * LDX + c] = (__bf16)v[k];
+        if (++c == F) { c = 0; ++r; }
+      }
     }
   }
-  const int c16 = Fp / 8;                                  // 16-byte chunks per padded weight row
-  // one 128-column block per workgroup (blockIdx.y): the x tile is fetched d / 128 times (from L2), in exchange every
-  // block of every row tile runs at once instead of as a serial chain of load -> MFMA -> store steps per workgroup
-  {
-    const int cb = blockIdx.y * 128;
-    for (int idx = tid; idx < 128 * c16; idx += 256) {
-      const int rr = idx / c16, ch = idx % c16;
-      *reinterpret_cast<uint4*>(sW + rr * LDX + 8 * ch) = *reinterpret_cast<const uint4*>(Wp + (int64_t)(cb + rr) * Fp + 8 * ch);
-    }
-    __syncthreads();
-    f32x16 acc[2];
+  __syncthreads();
+  f32x16 acc[2];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+  for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
-    const __bf16* wrow = sW + (32 * wave + lr) * LDX + 8 * lh;
-    for (int ks = 0; ks < Fp / 16; ++ks) {
-      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + 16 * ks);
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sX + (32 * rb + lr) * LDX + 16 * ks + 8 * lh);
-        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[rb], 0, 0, 0);
-      }
-    }
-    // acc[rb][4q + e]: output column cb + 32 wave + 8q + 4lh + e of row m0 + 32 rb + lr
+    for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
+  const __bf16* wrow = sW + (32 * wave + lr) * LDX + 8 * lh;
+  for (int ks = 0; ks < Fp / 16; ++ks) {
+    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + 16 * ks);
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
-      const int64_t m = m0 + 32 * rb + lr;
-      if (m >= M) continue;
-      const int tp = (int)(m % T) - pos_shift;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = cb + 32 * wave + 8 * q + 4 * lh;
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + col);
-        f32x4 v = f32x4{acc[rb][4 * q], acc[rb][4 * q + 1], acc[rb][4 * q + 2], acc[rb][4 * q + 3]} + b4;
-        if (tp >= 0) v += *reinterpret_cast<const f32x4*>(pos + (int64_t)tp * ldpos + col);
-        *reinterpret_cast<bf16x4*>(out + m * ldo + col) = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-      }
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sX + (32 * rb + lr) * LDX + 16 * ks + 8 * lh);
+      acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[rb], 0, 0, 0);
     }
+  }
+  __syncthreads();                                         // the operands are consumed: their LDS becomes the fp32 output tile
+  // acc[rb][4q + e]: output column cb + 32 wave + 8q + 4lh + e of row m0 + 32 rb + lr
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<f32x4*>(sC + (32 * rb + lr) * LDC + 32 * wave + 8 * q + 4 * lh) =
+          f32x4{acc[rb][4 * q], acc[rb][4 * q + 1], acc[rb][4 * q + 2], acc[rb][4 * q + 3]};
+  __syncthreads();
+  // rows out: 16 lanes per row, 8 columns each: bias + positional row added in fp32 (coalesced 32-byte reads), one 16-byte
+  // bf16 store per lane = 256 contiguous bytes per row
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = tid + 256 * u, r = idx >> 4, c8 = 8 * (idx & 15);
+    const int64_t m = m0 + r;
+    if (m >= M) continue;
+    const int tp = (int)(m % T) - pos_shift;
+    f32x4 v0 = *reinterpret_cast<const f32x4*>(sC + r * LDC + c8) + *reinterpret_cast<const f32x4*>(bias + cb + c8);
+    f32x4 v1 = *reinterpret_cast<const f32x4*>(sC + r * LDC + c8 + 4) + *reinterpret_cast<const f32x4*>(bias + cb + c8 + 4);
+    if (tp >= 0) {
+      v0 += *reinterpret_cast<const f32x4*>(pos + (int64_t)tp * ldpos + cb + c8);
+      v1 += *reinterpret_cast<const f32x4*>(pos + (int64_t)tp * ldpos + cb + c8 + 4);
+    }
+    *reinterpret_cast<bf16x8*>(out + m * ldo + cb + c8) = bf16x8{(__bf16)v0.x, (__bf16)v0.y, (__bf16)v0.z, (__bf16)v0.w,
+                                                                 (__bf16)v1.x, (__bf16)v1.y, (__bf16)v1.z, (__bf16)v1.w};
   }
 }
 
@@ -546,39 +570,49 @@ extern "C" int hig_gemm_bf16(const hig_gemm16_desc* g, hig_stream_t stream) {
   return hig_gemm16_launch(*g, hig_stream(stream));
 }
 
-// joint_embed + sequence_embedding of the bf16-storage forward (see joint_embed16_kernel).  w_scratch: d x Fp bf16
-// (Fp = F rounded up to a multiple of 32), rewritten by every call.  d % 128 == 0, F <= 512, 16-byte aligned bias / pos / out.
+// joint_embed + sequence_embedding of the bf16-storage forward (see joint_embed16_kernel).
+// hig_joint_embed_bf16_w: the weight already padded and rounded (d x Fp bf16, Fp = F rounded up to a multiple of 32, zero
+// columns beyond F) -- what a caller keeps next to its bf16 weight shadow; hig_joint_embed_bf16: fp32 (d, F) weight, padded
+// into `w_scratch` (hig_joint_embed_bf16_scratch_bytes) by every call.  d % 128 == 0, F <= 512, 16-byte aligned bias / pos / out.
 extern "C" int64_t hig_joint_embed_bf16_scratch_bytes(int32_t F, int32_t d) {
   if (F <= 0 || d <= 0) return -1;
   return (int64_t)d * ((F + 31) / 32 * 32) * 2;
 }
-extern "C" int hig_joint_embed_bf16(const float* x, int64_t M, int32_t F, const float* W, const float* bias, const float* pos,
-                                    int64_t ldpos, int32_t T, int32_t pos_shift, void* out, int64_t ldo, int32_t d,
-                                    void* w_scratch, hig_stream_t stream) {
-  HIG_REQUIRE(x && W && bias && pos && out && w_scratch && M >= 0 && F > 0 && d > 0 && T > 0, "hig_joint_embed_bf16: bad arguments");
+extern "C" int hig_joint_embed_bf16_w(const float* x, int64_t M, int32_t F, const void* w_padded, const float* bias, const float* pos,
+                                      int64_t ldpos, int32_t T, int32_t pos_shift, void* out, int64_t ldo, int32_t d,
+                                      hig_stream_t stream) {
+  HIG_REQUIRE(x && w_padded && bias && pos && out && M >= 0 && F > 0 && d > 0 && T > 0, "hig_joint_embed_bf16: bad arguments");
   if (M == 0) return HIG_OK;
   if (d % 128 != 0 || F > 512)
     return hig_set_error(HIG_EUNSUPPORTED, "hig_joint_embed_bf16: needs d %% 128 == 0 and F <= 512 (got %d, %d)", d, F);
-  HIG_REQUIRE(ldo % 4 == 0 && ldpos % 4 == 0 &&
-                  ((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(w_scratch)) & 15) == 0 &&
-                  (reinterpret_cast<uintptr_t>(out) & 7) == 0,
+  HIG_REQUIRE(ldo % 8 == 0 && ldpos % 4 == 0 &&
+                  ((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(w_padded) |
+                    reinterpret_cast<uintptr_t>(out)) & 15) == 0,
               "hig_joint_embed_bf16: alignment");
   const int Fp = (F + 31) / 32 * 32;
-  hipStream_t st = hig_stream(stream);
-  __bf16* wp = static_cast<__bf16*>(w_scratch);
-  const int64_t nw = (int64_t)d * Fp;
-  hipLaunchKernelGGL(pad_cast_rows_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, d, F, Fp, wp);
-  HIG_CHECK_LAUNCH();
-  const size_t lds = (size_t)(64 + 128) * (Fp + 8) * 2;
+  size_t lds = (size_t)(64 + 128) * (Fp + 8) * 2;
+  if (lds < 64 * 132 * 4) lds = 64 * 132 * 4;             // (the fp32 output tile reuses the operand space)
   static const int big_lds_rc = [] {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_embed16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                156 * 1024) == hipSuccess ? 0 : 1;
   }();
   if (big_lds_rc != 0 || lds > 156 * 1024) return hig_set_error(HIG_EHIP, "hig_joint_embed_bf16: cannot reserve %zu bytes of LDS", lds);
-  hipLaunchKernelGGL(joint_embed16_kernel, dim3((unsigned)((M + 63) / 64), d / 128), dim3(256), lds, st, x, F, Fp, wp, bias, pos, ldpos, T,
-                     pos_shift, static_cast<__bf16*>(out), ldo, M, d);
+  hipLaunchKernelGGL(joint_embed16_kernel, dim3((unsigned)((M + 63) / 64), d / 128), dim3(256), lds, hig_stream(stream), x, F, Fp,
+                     static_cast<const __bf16*>(w_padded), bias, pos, ldpos, T, pos_shift, static_cast<__bf16*>(out), ldo, M, d);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
+}
+extern "C" int hig_joint_embed_bf16(const float* x, int64_t M, int32_t F, const float* W, const float* bias, const float* pos,
+                                    int64_t ldpos, int32_t T, int32_t pos_shift, void* out, int64_t ldo, int32_t d,
+                                    void* w_scratch, hig_stream_t stream) {
+  HIG_REQUIRE(W && w_scratch && F > 0 && d > 0, "hig_joint_embed_bf16: bad arguments");
+  if (M == 0) return HIG_OK;
+  const int Fp = (F + 31) / 32 * 32;
+  const int64_t nw = (int64_t)d * Fp;
+  hipLaunchKernelGGL(pad_cast_rows_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, hig_stream(stream), W, d, F, Fp,
+                     static_cast<__bf16*>(w_scratch));
+  HIG_CHECK_LAUNCH();
+  return hig_joint_embed_bf16_w(x, M, F, w_scratch, bias, pos, ldpos, T, pos_shift, out, ldo, d, stream);
 }
 
 extern "C" int hig_cast_bf16(const float* src, void* dst, int64_t n, hig_stream_t stream) {

@@ -602,20 +602,20 @@ class MotionTransformer(nn.Module):
             self._textctx_cache = (key, buf, xf_out)  # keep xf_out alive so the key stays unique
         return buf
 
-    def _lnfold_table(self, fp):
-        """Operands of the LayerNorm-folded q/k/v and cross-attention query GEMMs of the bf16-storage forward (d = 512):
-        per layer [W'_qkv (bf16), colsum_qkv, bias'_qkv, W'_q (bf16), colsum_q, bias'_q] with W' = gamma (.) W,
-        colsum[j] = sum_r float(W'[j][r]), bias' = b + W beta -- LayerNorm(x) W^T + b == rstd (x W'^T) - rstd mean colsum +
-        bias' (transformer.py:108-110,144).  The library applies them wherever the producer of x wrote its row statistics;
-        rebuilt when the parameters change.  None: no fold (the library runs its LayerNorm kernel)."""
-        if self.latent_dim != 512:
-            return None
+    def _derived16(self, fp):
+        """Operands of the bf16-storage forward derived from the parameters, kept next to the bf16 shadow and rebuilt
+        when the parameters change (`derived` of hig_denoiser_fwd_bf16): 6 L + 1 device pointers.
+        [6 l + 0 .. 5] (d = 512 only, else NULL: the library runs its LayerNorm kernel): the LayerNorm-folded q/k/v and
+        cross-attention query projections of layer l -- [W'_qkv (bf16), colsum_qkv, bias'_qkv, W'_q (bf16), colsum_q, bias'_q]
+        with W' = gamma (.) W, colsum[j] = sum_r float(W'[j][r]), bias' = b + W beta: LayerNorm(x) W^T + b == rstd (x W'^T) -
+        rstd mean colsum + bias' (transformer.py:108-110,144); applied wherever the producer of x wrote its row statistics.
+        [6 L]: joint_embed weight (transformer.py:418) rounded to bf16 and padded to a multiple of 32 columns."""
         ver = (self._param_version(), fp.flat.data_ptr())
-        if getattr(self, "_lnfold", None) is None or self._lnfold[0] != ver:
+        if getattr(self, "_derived", None) is None or self._derived[0] != ver:
             d, nl, ng, offs = self.latent_dim, _lib.NLAYER, _lib.NGLOBAL, fp.group_offsets
-            arr, bufs = (C.c_void_p * (6 * self.num_layers))(), []
+            arr, bufs = (C.c_void_p * (6 * self.num_layers + 1))(), []
             with torch.no_grad():
-                for l in range(self.num_layers):
+                for l in range(self.num_layers if d == 512 else 0):
                     def grp(idx, n):
                         o = offs[ng + l * nl + idx]
                         return fp.flat[o:o + n]
@@ -628,8 +628,14 @@ class MotionTransformer(nn.Module):
                         bp = (b + W @ beta).contiguous()
                         bufs += [Wp, cs, bp]
                         arr[6 * l + 3 * k], arr[6 * l + 3 * k + 1], arr[6 * l + 3 * k + 2] = Wp.data_ptr(), cs.data_ptr(), bp.data_ptr()
-            self._lnfold = (ver, arr, bufs)
-        return self._lnfold[1]
+                F = self.input_feats
+                Fp = (F + 31) // 32 * 32
+                wj = torch.zeros(d, Fp, device=fp.flat.device, dtype=torch.bfloat16)
+                wj[:, :F] = self.joint_embed.weight.detach().to(torch.bfloat16)
+                bufs.append(wj)
+                arr[6 * self.num_layers] = wj.data_ptr()
+            self._derived = (ver, arr, bufs)
+        return self._derived[1]
 
     def _launch_forward(self, x, t, length, xf_proj, xf_out, training):
         B, T, N = x.shape[0], x.shape[1], xf_out.shape[1]
@@ -647,7 +653,7 @@ class MotionTransformer(nn.Module):
         out = torch.empty(B, T, self.input_feats, device=x.device, dtype=torch.float32)
         if self._bf16():
             _lib.check(L.hig_denoiser_fwd_bf16(C.byref(dims), fp.param_table(), fp.shadow16(self._param_version()),
-                                               self._lnfold_table(fp), _lib.ptr(x), _lib.ptr(t), _lib.ptr(length),
+                                               self._derived16(fp), _lib.ptr(x), _lib.ptr(t), _lib.ptr(length),
                                                _lib.ptr(xf_proj), _lib.ptr(textctx), _lib.ptr(out), _lib.ptr(ws),
                                                _lib.stream_ptr()))
             self._pool.give("fwd_i", ws, x.device)

@@ -178,13 +178,16 @@ int hig_denoiser_fwd(const hig_dims* dims, const void* const* params, const floa
  * Workspace / text-context sizes: hig_workspace_bytes / hig_textctx_bytes with the same dims (training = 0). */
 int hig_text_context_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
                           const float* xf_out, void* textctx, hig_stream_t stream);
-/* lnfold (nullable; d == 512): per layer l six device pointers [6 l + 0 .. 5] = W'_qkv (bf16, 3d x d), colsum_qkv (fp32, 3d),
- * bias'_qkv (fp32, 3d), W'_q (bf16, d x d), colsum_q, bias'_q of the cross-attention query -- W' = gamma (.) W of the
- * LayerNorm in front of the Linear, colsum[j] = sum_r float(W'[j][r]), bias' = b + W beta.  With them (and >= 2048 rows)
- * the LayerNorm kernels in front of the q/k/v and query projections disappear: the stylization-out GEMM that produces the
- * residual stream also writes its row statistics, and the projection applies them in its epilogue (hig_gemm16_desc). */
+/* derived (nullable): 6 L + 1 device pointers the caller derives from the parameters and keeps next to the bf16 shadow
+ * (rebuilt when the parameters change); any entry may be NULL (the library then does that piece per call).
+ * [6 l + 0 .. 5], all six or none, d == 512: W'_qkv (bf16, 3d x d), colsum_qkv (fp32, 3d), bias'_qkv (fp32, 3d), W'_q
+ * (bf16, d x d), colsum_q, bias'_q of the cross-attention query -- W' = gamma (.) W of the LayerNorm in front of the
+ * Linear, colsum[j] = sum_r float(W'[j][r]), bias' = b + W beta.  With them (and >= 2048 rows) the LayerNorm kernels in
+ * front of the q/k/v and query projections disappear: the stylization-out GEMM that produces the residual stream also
+ * writes its row statistics, and the projection applies them in its epilogue (hig_gemm16_desc).
+ * [6 L]: joint_embed weight padded and rounded for hig_joint_embed_bf16_w ((d, Fp) bf16, Fp = F rounded up to 32). */
 int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
-                          const void* const* lnfold, const float* x,
+                          const void* const* derived, const float* x,
                           const int64_t* t, const int64_t* length, const float* xf_proj, const void* textctx,
                           float* out, void* workspace, hig_stream_t stream);
 
@@ -419,8 +422,12 @@ int hig_linattn16_debug_stamps(void* buf);
 /* joint_embed + sequence_embedding of the bf16-storage forward (transformer.py:418-419) as its own kernel pair:
  * out[m][:] = bf16( x[m][:F] . W^T + bias + pos[(m % T) - pos_shift] ), x fp32 with F (e.g. 150, 263) features per
  * row, W fp32 (d, F) padded / rounded to bf16 into `w_scratch` (hig_joint_embed_bf16_scratch_bytes) by the call,
- * rows with a negative positional index get no positional term.  d % 128 == 0, F <= 512. */
+ * rows with a negative positional index get no positional term.  d % 128 == 0, F <= 512, out 16-byte aligned, ldo % 8 == 0.
+ * hig_joint_embed_bf16_w takes the weight already padded and rounded: (d, Fp) bf16, Fp = F rounded up to a multiple of 32,
+ * zeros beyond column F (kept by the caller next to its bf16 weight shadow: no per-call padding launch). */
 int64_t hig_joint_embed_bf16_scratch_bytes(int32_t F, int32_t d);
+int hig_joint_embed_bf16_w(const float* x, int64_t M, int32_t F, const void* w_padded, const float* bias, const float* pos,
+                           int64_t ldpos, int32_t T, int32_t pos_shift, void* out, int64_t ldo, int32_t d, hig_stream_t stream);
 int hig_joint_embed_bf16(const float* x, int64_t M, int32_t F, const float* W, const float* bias, const float* pos,
                          int64_t ldpos, int32_t T, int32_t pos_shift, void* out, int64_t ldo, int32_t d,
                          void* w_scratch, hig_stream_t stream);

@@ -330,7 +330,7 @@ def test_fused_apply_stylization_front_on_the_bf16_matrix_cores(H, B, T):
 
 
 @pytest.mark.parametrize("M,T,F,d,shift", [(6272, 196, 150, 512, 0), (333, 37, 263, 256, 0), (70, 7, 12, 128, 1),
-                                           (9600, 300, 150, 1024, 0)])
+                                           (9600, 300, 150, 1024, 0), (129, 43, 151, 128, 0), (64, 8, 32, 128, 0)])
 def test_joint_embed_bf16_kernel(M, T, F, d, shift):
     """hig_joint_embed_bf16 (joint_embed + sequence_embedding of the bf16-storage forward, transformer.py:418-419):
     x and the weight are rounded to bf16, products accumulate in fp32, bias and the positional row are added in fp32,
@@ -354,6 +354,14 @@ def test_joint_embed_bf16_kernel(M, T, F, d, shift):
     assert torch.isfinite(o).all()
     assert (o != bf(ref16.float()).float()).float().mean().item() < 0.02
     assert rel(o, ref32) < 6e-3
+    # the same with the weight padded / rounded by the caller (what the model keeps next to its bf16 shadow): same bits
+    Fp = (F + 31) // 32 * 32
+    wpad = torch.zeros(d, Fp, device=DEV, dtype=torch.bfloat16)
+    wpad[:, :F] = Wg.to(torch.bfloat16)
+    out2 = torch.full((M, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _lib.check(L.hig_joint_embed_bf16_w(_lib.ptr(xg), M, F, _lib.ptr(wpad), _lib.ptr(bg), _lib.ptr(pg), d, T, shift,
+                                        _lib.ptr(out2), d, d, _lib.stream_ptr()))
+    assert torch.equal(out2, out)
 
 
 def build(c, **kw):
