@@ -412,6 +412,96 @@ int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
   return launch16<1, 4, 2, 1, 32, 3, EPI>(g, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Few rows (I <= 64: the per-sample Linear layers of the time / text embedding chain, transformer.py:345-349,81-83 at the
+// sampling batch sizes): the launch is a WEIGHT read -- J x K x 2 bytes against I x J outputs -- and what bounds it is how
+// many CUs pull on the weight at once (a CU fetches ~25-30 B/clk).  The tiled kernel above gives such a launch J / 128
+// workgroups (time_embed.2 at B = 32: 16 workgroups streaming 512 KB each, 20 us).  Here a workgroup owns 32 output
+// columns and all rows; its 4 waves split the reduce range into quarters (contiguous 32-byte pieces of every weight row
+// per load, successive loads walk the same cache lines), operands go global -> registers in MFMA fragment shape (no LDS
+// staging: nothing is reused), the four partial tiles are summed through LDS and the epilogue runs on whole 32-column row
+// pieces.  J / 32 workgroups: 64 for the 2048-wide embedding layers.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NRB, int EPI>
+__global__ __launch_bounds__(256) void gemm_fewrow16_kernel(const hig_gemm16_desc g) {
+  constexpr int PLD = 33;                                  // fp32 elements per row of a partial tile in LDS
+  __shared__ float sP[4 * NRB * 32 * PLD];
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j0 = blockIdx.x * 32;
+  const __bf16* __restrict__ X = static_cast<const __bf16*>(g.X);
+  const __bf16* __restrict__ Y = static_cast<const __bf16*>(g.Y);
+  const int nks = g.R / 16, per = (nks + 3) / 4;           // k-steps: all, per wave
+  const int ks0 = wave * per, ks1 = min(nks, ks0 + per);
+  const __bf16* yp = Y + (int64_t)(j0 + lr) * g.ldy + 8 * lh;
+  const __bf16* xp[NRB];
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) xp[rb] = X + (int64_t)min(32 * rb + lr, g.I - 1) * g.ldx + 8 * lh;
+  f32x16 acc[NRB];
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
+#pragma unroll 8
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(yp + 16 * ks);
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp[rb] + 16 * ks);
+      acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[rb], 0, 0, 0);
+    }
+  }
+  // acc[rb][4q + e]: output column j0 + 8q + 4lh + e of row 32 rb + lr
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sP[((wave * NRB + rb) * 32 + lr) * PLD + 8 * q + 4 * lh + e] = acc[rb][4 * q + e];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NRB * 4; ++u) {
+    const int idx = tid + 256 * u, r = idx >> 5, c = idx & 31;      // r: row of the (32 NRB)-row tile; 32 lanes = one row piece
+    if (r >= g.I) continue;
+    const int rb = r >> 5, rr = r & 31;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += sP[((w * NRB + rb) * 32 + rr) * PLD + c];
+    const int j = j0 + c;
+    if (EPI != HIG_EPI_NONE) v += g.bias[j];
+    if (EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU)
+      v += g.res_f32 ? static_cast<const float*>(g.res)[(int64_t)r * g.ldr + j] : (float)static_cast<const __bf16*>(g.res)[(int64_t)r * g.ldr + j];
+    v = epi_act<EPI>(v);
+    if (g.c_f32) static_cast<float*>(g.C)[(int64_t)r * g.ldc + j] = v;
+    else static_cast<__bf16*>(g.C)[(int64_t)r * g.ldc + j] = (__bf16)v;
+  }
+}
+
+template <int EPI>
+int launch_fewrow16(const hig_gemm16_desc& g, hipStream_t st) {
+  if (g.I <= 32) hipLaunchKernelGGL((gemm_fewrow16_kernel<1, EPI>), dim3(g.J / 32), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((gemm_fewrow16_kernel<2, EPI>), dim3(g.J / 32), dim3(256), 0, st, g);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+// Serves: I <= 64, J a multiple of 32 with at most 512 column blocks (beyond that the tiled kernel already has every CU
+// busy), reduce range a multiple of 64 of at least 256.  Returns 1 when the shape is not served.  HIG_BF16_FEWROW=0: off.
+int fewrow16_try(const hig_gemm16_desc& g, hipStream_t st) {
+  static const int on = getenv("HIG_BF16_FEWROW") ? atoi(getenv("HIG_BF16_FEWROW")) : 1;   // tuning knob
+  if (!on || g.I > 64 || g.J % 32 != 0 || g.J / 32 > 512 || g.R % 64 != 0 || g.R < 256) return 1;
+  switch (g.epi) {
+    case HIG_EPI_NONE: return launch_fewrow16<HIG_EPI_NONE>(g, st);
+    case HIG_EPI_BIAS: return launch_fewrow16<HIG_EPI_BIAS>(g, st);
+    case HIG_EPI_BIAS_GELU: return launch_fewrow16<HIG_EPI_BIAS_GELU>(g, st);
+    case HIG_EPI_BIAS_RES: return launch_fewrow16<HIG_EPI_BIAS_RES>(g, st);
+    case HIG_EPI_BIAS_SILU: return launch_fewrow16<HIG_EPI_BIAS_SILU>(g, st);
+    case HIG_EPI_BIAS_RES_SILU: return launch_fewrow16<HIG_EPI_BIAS_RES_SILU>(g, st);
+    default: return 1;
+  }
+}
+
+
 __global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int64_t n) {
   const int64_t n8 = n / 8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
@@ -552,6 +642,10 @@ int hig_gemm16_launch(const hig_gemm16_desc& g, hipStream_t st) {
   if (g.epi == HIG_EPI_BIAS_RES || g.epi == HIG_EPI_BIAS_RES_SILU) HIG_REQUIRE(g.res, "hig_gemm_bf16: missing residual");
   {   // many rows, short reduce range: the weight-stationary kernel (gemm_ws16.hip) when it serves the shape
     const int rc = hig_gemm_ws16_try(g, st);
+    if (rc <= 0) return rc;
+  }
+  {   // a handful of rows: one workgroup per 32 output columns (gemm_fewrow16_kernel)
+    const int rc = fewrow16_try(g, st);
     if (rc <= 0) return rc;
   }
   switch (g.epi) {

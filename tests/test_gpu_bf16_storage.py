@@ -43,6 +43,10 @@ EPIS = {"none": _lib.EPI_NONE, "bias": _lib.EPI_BIAS, "gelu": _lib.EPI_BIAS_GELU
     # large enough for the 256 x 256 tiles (8 waves, one workgroup per CU), incl. ragged edges in both directions
     (12544, 1024, 512, "gelu", 0, 0), (12544, 1536, 512, "bias", 0, 0), (12500, 1000, 512, "res", 0, 0),
     (9600, 1024, 1024, "res_silu", 1, 1),
+    # a handful of rows (gemm_fewrow16_kernel: <= 64 rows, N % 32 == 0, K % 64 == 0, K >= 256): one and two row blocks,
+    # every epilogue, bf16 / fp32 outputs and residuals, the in-place residual
+    (1, 512, 256, "bias", 0, 0), (33, 96, 320, "res", 0, 0), (40, 2048, 2048, "none", 1, 0), (7, 64, 2048, "gelu", 0, 0),
+    (64, 1024, 512, "res", 1, 0), (32, 2048, 2048, "res_silu", 0, 1), (17, 160, 1024, "silu", 1, 0),
     # the weight-stationary kernel (gemm_ws16.hip: >= 2048 rows, K in {256, 512, 1024}, N % 128 == 0, bf16 out): every
     # epilogue, both panel widths (N % 256 != 0 forces 128-column panels), the K-split variant, ragged row counts, row
     # counts that leave some workgroups of an XCD without a tile
