@@ -10,11 +10,14 @@ trainers select -- EPSILON / FIXED_SMALL / MSE / linear betas / uniform sampler
   * `p_sample_loop` captured as a hipGraph (one denoiser step + update + device-side step
     counter, replayed num_timesteps times) when the model is our MotionTransformer.
 
-Configurations no reference tool reaches (other mean / variance parametrisations, the cosine schedule, DDIM,
-KL / VLB losses, cond_fn) are not built: the enums keep their member names, everything else raises
-NotImplementedError instead of silently running something else.
+The other fixed-variance parametrisations of the reference class (START_X / PREVIOUS_X mean types, FIXED_LARGE
+variance, the cosine schedule, q_mean_variance, the eps <-> x0 <-> x_{t-1} conversions) run as plain tensor
+arithmetic on whatever device the tensors live on; only the trainers' combination takes the HIP kernels.  Not built
+(no reference tool reaches them): learned variances and the KL / VLB losses that train them, DDIM, cond_fn guidance --
+the enums keep their member names and those paths raise NotImplementedError instead of silently running something else.
 """
 import enum
+import math
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -57,12 +60,23 @@ class UniformSampler(ScheduleSampler):
 
 
 def get_named_beta_schedule(schedule_name, num_diffusion_timesteps):
-    """The linear schedule of gaussian_diffusion.py:229-246 (the only one a reference tool asks for): betas from
-    1e-4 to 2e-2 at 1000 steps, end points scaled by 1000 / N otherwise; float64."""
-    if schedule_name != "linear":
-        raise NotImplementedError(f"beta schedule {schedule_name!r}: the reference trainers only use 'linear'")
-    scale = 1000 / num_diffusion_timesteps
-    return np.linspace(scale * 0.0001, scale * 0.02, num_diffusion_timesteps, dtype=np.float64)
+    """gaussian_diffusion.py:229-254.  "linear" (what the reference trainers ask for): betas from 1e-4 to 2e-2 at 1000
+    steps, end points scaled by 1000 / N otherwise; "cosine": the alpha-bar curve cos^2((t + 0.008) / 1.008 * pi / 2)
+    discretised by betas_for_alpha_bar.  float64."""
+    n = num_diffusion_timesteps
+    if schedule_name == "linear":
+        scale = 1000 / n
+        return np.linspace(scale * 0.0001, scale * 0.02, n, dtype=np.float64)
+    if schedule_name == "cosine":
+        return betas_for_alpha_bar(n, lambda u: math.cos((u + 0.008) / 1.008 * math.pi / 2) ** 2)
+    raise NotImplementedError(f"unknown beta schedule: {schedule_name}")
+
+
+def betas_for_alpha_bar(num_diffusion_timesteps, alpha_bar, max_beta=0.999):
+    """gaussian_diffusion.py:256-274: beta_i = 1 - alpha_bar((i + 1) / N) / alpha_bar(i / N), capped at max_beta
+    (alpha_bar: cumulative product of (1 - beta) as a function of t in [0, 1])."""
+    n = num_diffusion_timesteps
+    return np.array([min(1 - alpha_bar((i + 1) / n) / alpha_bar(i / n), max_beta) for i in range(n)])
 
 
 class ModelMeanType(enum.Enum):
@@ -103,13 +117,11 @@ def _unwrap(model):
 
 class GaussianDiffusion:
     def __init__(self, *, betas, model_mean_type, model_var_type, loss_type, rescale_timesteps=False):
-        if (model_mean_type, model_var_type, loss_type) != (ModelMeanType.EPSILON, ModelVarType.FIXED_SMALL,
-                                                             LossType.MSE):
-            # the enums keep the reference's member names, but only the combination its trainers construct
-            # (ddpm_trainer.py:40-45) is implemented
-            raise NotImplementedError("GaussianDiffusion: only EPSILON / FIXED_SMALL / MSE (the reference trainers' "
-                                      "configuration) is built, got %s / %s / %s"
-                                      % (model_mean_type, model_var_type, loss_type))
+        if model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE) or loss_type.is_vb():
+            # learned variances need a model with 2 C output channels and the VLB terms that train them: no reference
+            # tool builds one (ddpm_trainer.py:40-45 is EPSILON / FIXED_SMALL / MSE)
+            raise NotImplementedError("GaussianDiffusion: learned variances and the KL / VLB losses are not built, got "
+                                      "%s / %s / %s" % (model_mean_type, model_var_type, loss_type))
         self.model_mean_type = model_mean_type
         self.model_var_type = model_var_type
         self.loss_type = loss_type
@@ -154,6 +166,13 @@ class GaussianDiffusion:
         return all(t.is_cuda and t.dtype == th.float32 for t in tensors)
 
     # ---- q(x_t | x_0) ---------------------------------------------------------------------
+    def q_mean_variance(self, x_start, t):
+        """(mean, variance, log variance) of q(x_t | x_0), each of x_start's shape (gaussian_diffusion.py:382-397)."""
+        shape = x_start.shape
+        return (_extract_into_tensor(self.sqrt_alphas_cumprod, t, shape) * x_start,
+                _extract_into_tensor(1.0 - self.alphas_cumprod, t, shape),
+                _extract_into_tensor(self.log_one_minus_alphas_cumprod, t, shape))
+
     def q_sample(self, x_start, t, noise=None):
         """gaussian_diffusion.py:399-417."""
         if noise is None:
@@ -181,17 +200,33 @@ class GaussianDiffusion:
 
     # ---- p(x_{t-1} | x_t) -------------------------------------------------------------------
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
-        """eps-prediction with the fixed small variance (gaussian_diffusion.py:443-471,488-537):
-        x0_hat from eps, then the posterior q(x_{t-1} | x_t, x0_hat)."""
+        """Model output -> {'mean', 'variance', 'log_variance', 'pred_xstart'} of p(x_{t-1} | x_t) for the fixed
+        variances (gaussian_diffusion.py:443-537).  The x0 estimate goes through denoised_fn, then the clamp; for
+        START_X / EPSILON the mean is the posterior q(x_{t-1} | x_t, x0_hat), for PREVIOUS_X it is the output itself."""
         B = x.shape[0]
         assert t.shape == (B,)
-        eps = model(x, self._scale_timesteps(t), **(model_kwargs or {}))
-        pred_xstart = self._predict_xstart_from_eps(x_t=x, t=t, eps=eps)
-        if denoised_fn is not None:
-            pred_xstart = denoised_fn(pred_xstart)
-        if clip_denoised:
-            pred_xstart = pred_xstart.clamp(-1, 1)
-        mean, variance, log_variance = self.q_posterior_mean_variance(x_start=pred_xstart, x_t=x, t=t)
+        out = model(x, self._scale_timesteps(t), **(model_kwargs or {}))
+        if self.model_var_type == ModelVarType.FIXED_LARGE:
+            # beta_t, with the first entry taken from the posterior variance (better decoder likelihood at t = 0)
+            var_tab = np.append(self.posterior_variance[1], self.betas[1:])
+            variance = _extract_into_tensor(var_tab, t, x.shape)
+            log_variance = _extract_into_tensor(np.log(var_tab), t, x.shape)
+        else:
+            variance = _extract_into_tensor(self.posterior_variance, t, x.shape)
+            log_variance = _extract_into_tensor(self.posterior_log_variance_clipped, t, x.shape)
+
+        def finish(x0):
+            if denoised_fn is not None:
+                x0 = denoised_fn(x0)
+            return x0.clamp(-1, 1) if clip_denoised else x0
+
+        if self.model_mean_type == ModelMeanType.PREVIOUS_X:
+            pred_xstart = finish(self._predict_xstart_from_xprev(x_t=x, t=t, xprev=out))
+            mean = out
+        else:
+            pred_xstart = finish(out if self.model_mean_type == ModelMeanType.START_X
+                                 else self._predict_xstart_from_eps(x_t=x, t=t, eps=out))
+            mean = self.q_posterior_mean_variance(x_start=pred_xstart, x_t=x, t=t)[0]
         assert mean.shape == log_variance.shape == pred_xstart.shape == x.shape
         return {"mean": mean, "variance": variance, "log_variance": log_variance, "pred_xstart": pred_xstart}
 
@@ -199,6 +234,17 @@ class GaussianDiffusion:
         assert x_t.shape == eps.shape
         return (_extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
                 - _extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * eps)
+
+    def _predict_xstart_from_xprev(self, x_t, t, xprev):
+        """Posterior mean solved for x0: (x_{t-1} - coef2 x_t) / coef1 (gaussian_diffusion.py:546-554)."""
+        assert x_t.shape == xprev.shape
+        return (_extract_into_tensor(1.0 / self.posterior_mean_coef1, t, x_t.shape) * xprev
+                - _extract_into_tensor(self.posterior_mean_coef2 / self.posterior_mean_coef1, t, x_t.shape) * x_t)
+
+    def _predict_eps_from_xstart(self, x_t, t, pred_xstart):
+        """Inverse of _predict_xstart_from_eps (gaussian_diffusion.py:556-560)."""
+        return ((_extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - pred_xstart)
+                / _extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape))
 
     def _scale_timesteps(self, t):
         if self.rescale_timesteps:
@@ -341,9 +387,16 @@ class GaussianDiffusion:
             x_start = th.cat([x_start[:B], x_start[:B], x_start[B:], x_start[B:]])
             noise = th.cat([noise[:B], noise[:B], noise[B:], noise[B:]])
         model_output = model(x_t, self._scale_timesteps(t), **model_kwargs)
-        assert model_output.shape == noise.shape == x_start.shape
-        # eps-prediction: the regression target is the injected noise
-        return {"mse": mean_flat((noise - model_output) ** 2).view(-1, 1).mean(-1), "target": noise,
+        # regression target by what the model predicts: the injected noise (the trainers' choice), x_0, or the
+        # posterior mean of x_{t-1}                                                 (gaussian_diffusion.py:1041-1047)
+        if self.model_mean_type == ModelMeanType.EPSILON:
+            target = noise
+        elif self.model_mean_type == ModelMeanType.START_X:
+            target = x_start
+        else:
+            target = self.q_posterior_mean_variance(x_start=x_start, x_t=x_t, t=t)[0]
+        assert model_output.shape == target.shape == x_start.shape
+        return {"mse": mean_flat((target - model_output) ** 2).view(-1, 1).mean(-1), "target": target,
                 "pred": model_output}
 
     # ---- names kept for API compatibility; never reached by the reference tools --------------

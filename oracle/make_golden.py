@@ -501,6 +501,36 @@ def g14_metrics():
     np.savez_compressed(os.path.join(GOLD, "g14_metrics.npz"), **out)
 
 
+def g15_diffusion_variants():
+    """The fixed-variance parametrisations no reference tool constructs but the class supports: cosine schedule,
+    FIXED_LARGE variance, START_X / PREVIOUS_X mean types, q_mean_variance, the eps / x0 / x_{t-1} conversions."""
+    from models.gaussian_diffusion import (GaussianDiffusion, LossType, ModelMeanType, ModelVarType,
+                                           get_named_beta_schedule)
+    out = {"cosine_betas_50": get_named_beta_schedule("cosine", 50), "cosine_betas_1000": get_named_beta_schedule("cosine", 1000)}
+    B, T, Fd = 4, 5, 6
+    x = fill.tensor_for("g15.x", (B, T, Fd)) * 2
+    mo = fill.tensor_for("g15.model_out", (B, T, Fd)) * 2
+    noise = fill.tensor_for("g15.noise", (B, T, Fd)) * 10
+    t = torch.tensor([0, 1, 25, 49])
+    out.update(x=x.numpy(), model_out=mo.numpy(), noise=noise.numpy(), t=t.numpy())
+    for mean in ("EPSILON", "START_X", "PREVIOUS_X"):
+        for var in ("FIXED_SMALL", "FIXED_LARGE"):
+            gd = GaussianDiffusion(betas=get_named_beta_schedule("cosine", 50), model_mean_type=ModelMeanType[mean],
+                                   model_var_type=ModelVarType[var], loss_type=LossType.MSE)
+            for clip in (False, True):
+                pmv = gd.p_mean_variance(lambda *_a, **_k: mo, x, t, clip_denoised=clip)
+                for k, v in pmv.items():
+                    out["%s.%s.clip%d.%s" % (mean, var, int(clip), k)] = v.numpy()
+            tl = gd.training_losses(lambda *_a, **_k: mo, x, t, noise=noise)
+            out["%s.%s.tl_mse" % (mean, var)] = tl["mse"].numpy()
+            out["%s.%s.tl_target" % (mean, var)] = tl["target"].numpy()
+    qm = gd.q_mean_variance(x, t)
+    out["q_mean"], out["q_variance"], out["q_log_variance"] = (v.numpy() for v in qm)
+    out["eps_from_xstart"] = gd._predict_eps_from_xstart(x, t, mo).numpy()
+    out["xstart_from_xprev"] = gd._predict_xstart_from_xprev(x, t, mo).numpy()
+    np.savez_compressed(os.path.join(GOLD, "g15_diffusion_variants.npz"), **out)
+
+
 def g7_state_dict_keys():
     """Key/shape contract of the reference module (tiny config) for the round-trip test."""
     c = fill.CASES["tiny"]
@@ -516,7 +546,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
     for fn in (g1, g2_g3, g4, g5, g6, g7_state_dict_keys, g8_interaction, g9_mul_trainer, g10_text_head, g11_dataset, g12_recover,
-               g13_eval_models, g14_metrics):
+               g13_eval_models, g14_metrics, g15_diffusion_variants):
         if only and fn.__name__ not in only:
             continue
         fn()

@@ -142,6 +142,38 @@ def test_schedule_tables_match_reference_golden(gold):
         gd.ddim_sample()
 
 
+def test_diffusion_parametrisations_beyond_the_trainers_choice(gold):
+    """Cosine schedule, FIXED_LARGE variance, START_X / PREVIOUS_X mean types, q_mean_variance and the conversions between
+    eps / x0 / x_{t-1} (gaussian_diffusion.py:247-274,382-397,488-560,1041-1047): plain tensor arithmetic, held to the
+    reference's outputs on the same inputs (golden G15, oracle/make_golden.py)."""
+    g = gold("g15_diffusion_variants.npz")
+    for n in (50, 1000):
+        assert np.array_equal(gdm.get_named_beta_schedule("cosine", n), g["cosine_betas_%d" % n])
+    x, mo, noise, t = (torch.from_numpy(g[k]) for k in ("x", "model_out", "noise", "t"))
+    for mean in ("EPSILON", "START_X", "PREVIOUS_X"):
+        for var in ("FIXED_SMALL", "FIXED_LARGE"):
+            gd = hig_amd.GaussianDiffusion(betas=gdm.get_named_beta_schedule("cosine", 50), model_mean_type=gdm.ModelMeanType[mean],
+                                           model_var_type=gdm.ModelVarType[var], loss_type=gdm.LossType.MSE)
+            for clip in (False, True):
+                pmv = gd.p_mean_variance(lambda *_a, **_k: mo, x, t, clip_denoised=clip)
+                for k, v in pmv.items():
+                    assert np.array_equal(v.numpy(), g["%s.%s.clip%d.%s" % (mean, var, int(clip), k)]), (mean, var, clip, k)
+            tl = gd.training_losses(lambda *_a, **_k: mo, x, t, noise=noise)
+            assert np.array_equal(tl["mse"].numpy(), g["%s.%s.tl_mse" % (mean, var)])
+            assert np.array_equal(tl["target"].numpy(), g["%s.%s.tl_target" % (mean, var)])
+    for v, k in zip(gd.q_mean_variance(x, t), ("q_mean", "q_variance", "q_log_variance")):
+        assert np.array_equal(v.numpy(), g[k])
+    assert np.array_equal(gd._predict_eps_from_xstart(x, t, mo).numpy(), g["eps_from_xstart"])
+    assert np.array_equal(gd._predict_xstart_from_xprev(x, t, mo).numpy(), g["xstart_from_xprev"])
+    # what stays out of scope says so
+    with pytest.raises(NotImplementedError):
+        hig_amd.GaussianDiffusion(betas=gdm.get_named_beta_schedule("linear", 10), model_mean_type=gdm.ModelMeanType.EPSILON,
+                                  model_var_type=gdm.ModelVarType.LEARNED_RANGE, loss_type=gdm.LossType.MSE)
+    with pytest.raises(NotImplementedError):
+        hig_amd.GaussianDiffusion(betas=gdm.get_named_beta_schedule("linear", 10), model_mean_type=gdm.ModelMeanType.EPSILON,
+                                  model_var_type=gdm.ModelVarType.FIXED_SMALL, loss_type=gdm.LossType.KL)
+
+
 def test_generic_diffusion_plumbing_on_host_tensors(gold):
     """q_sample / p_sample / training_losses over a stub model: the tensor-op branch used for
     anything that is not (fp32, ROCm) follows the reference arithmetic (golden G4)."""
