@@ -831,7 +831,7 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   // HIG_FUSE_APPLY: 2 (default) = the bf16-matrix-core kernel of linattn16.hip where it is built (head dim 64), 1 = the
   // fp32-MFMA fused kernel, 0 = apply + row kernel
   static const int fuse_env = getenv("HIG_FUSE_APPLY") ? atoi(getenv("HIG_FUSE_APPLY")) : 2;   // tuning knob
-  const bool fuse_mm16 = fuse_env == 2 && D.hd == 64 && (D.H == 4 || D.H == 8);
+  const bool fuse_mm16 = fuse_env == 2 && (D.hd == 64 || D.hd == 128) && (D.H == 4 || D.H == 8);
   const bool fuse_apply = (fuse_env == 1 || fuse_mm16) && (D.H == 4 || D.H == 8);
   auto attend = [&](int l, int slot, const void* q, int64_t ldq, const float* ctx, const void* ctx_t16, int norm_w, int norm_b,
                     int out_w, int out_b) -> int {

@@ -36,6 +36,13 @@ __device__ __forceinline__ float hig_dsilu(float x) {
 // bf16-storage kernels: the result is rounded to 8 significant bits right away, so the 1-ulp hardware reciprocal
 // (v_rcp_f32) replaces the correctly rounded division (v_div_scale / v_div_fmas / v_div_fixup: ~10 instructions).
 __device__ __forceinline__ float hig_silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// Element order of the transposed bf16 context matrices At16 (At[l][c] = bf16(A[c][l]); written by the context kernels,
+// read by apply_sty16_kernel, linattn16.hip): "fragment-major" -- the 32 (l) x 16 (c) block that ONE lane-wise 16-byte
+// load of a v_mfma_f32_32x32x16_bf16 row operand needs is one contiguous 1-KiB run, lane (l % 32) + 32 ((c % 16) / 8)
+// holding c % 8 = 0 .. 7: the consumer fetches its operands global -> registers in whole coalesced KiB, no LDS staging.
+__host__ __device__ __forceinline__ int hig_at16_offset(int hd, int l, int c) {
+  return ((((l >> 5) * (hd >> 4) + (c >> 4)) * 64 + (l & 31) + 32 * ((c >> 3) & 1)) << 3) + (c & 7);
+}
 __device__ __forceinline__ float hig_gelu(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

@@ -445,13 +445,14 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const TIO* __restrict__ K
     float* ap = A + (int64_t)blockIdx.x * HD * HD + cc * HD + wj * (HD / 2) + 4 * lh;
 #pragma unroll
     for (int tj = 0; tj < TB; ++tj) store16(ap + 32 * tj, acc[ti][tj], inv);
-    if (At16) {   // the same matrix transposed and rounded, At[l][c] = bf16(A[c][l]): the MFMA row operand of linattn16.hip
+    if (At16) {   // the same matrix transposed and rounded, At[l][c] = bf16(A[c][l]), in the fragment-major order of
+                  // hig_at16_offset: the MFMA row operand of linattn16.hip
 #pragma unroll
       for (int tj = 0; tj < TB; ++tj)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int l = wj * (HD / 2) + 32 * tj + 8 * (e >> 2) + 4 * lh + (e & 3);
-          At16[((int64_t)blockIdx.x * HD + l) * HD + cc] = (__bf16)(acc[ti][tj][e] * inv);
+          At16[(int64_t)blockIdx.x * HD * HD + hig_at16_offset(HD, l, cc)] = (__bf16)(acc[ti][tj][e] * inv);
         }
     }
   }
@@ -603,8 +604,9 @@ __global__ __launch_bounds__(256) void ctx_combine_kernel(const float* __restric
         a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
         if (At16) {
           const int l0 = (idx * 4) % HD;
-          __bf16* at = At16 + ((int64_t)blockIdx.x * HD + l0) * HD + c;
-          at[0] = (__bf16)a.x; at[HD] = (__bf16)a.y; at[2 * HD] = (__bf16)a.z; at[3 * HD] = (__bf16)a.w;
+          __bf16* at = At16 + (int64_t)blockIdx.x * HD * HD;
+          at[hig_at16_offset(HD, l0, c)] = (__bf16)a.x; at[hig_at16_offset(HD, l0 + 1, c)] = (__bf16)a.y;
+          at[hig_at16_offset(HD, l0 + 2, c)] = (__bf16)a.z; at[hig_at16_offset(HD, l0 + 3, c)] = (__bf16)a.w;
         }
       }
       reinterpret_cast<float4*>(Ab)[idx] = a;

@@ -39,15 +39,18 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
   return r;
 }
 
-// HD: head dim (64); H: heads (4 or 8); NW: waves per workgroup (H % NW == 0); rows of Q / Out are d = H * HD bf16 wide.
-// grid = (ceil(T / 32), B).
-// Instruction budget.  One workgroup per CU (105 KB of LDS) means one or two waves per SIMD, and a wave64 VALU instruction
-// takes its SIMD 4 cycles (a transcendental 16): the kernel is bound by the NUMBER of vector instructions, 64 elements per
-// lane (tools/apply16_stamps.py: 14.6 K cycles per workgroup with the straightforward arithmetic, 2.5 K of them waiting
-// for the first tile).  So the element-wise work is written on float pairs (v_pk_fma / v_pk_mul / v_pk_add_f32: two
-// elements per issue): softmax = unpack, v_max3, one packed fma into the exp2 argument, exp2, packed sum, packed scale,
-// packed convert; LayerNorm + modulation = TWO packed fmas, with gamma' = gamma (1 + scale), beta' = beta (1 + scale) +
-// shift combined once per workgroup in LDS; SiLU = packed multiply, exp2, packed add, rcp, packed multiply.
+// HD: head dim (64 / 128); H: heads (4 or 8); NW: waves per workgroup (H % NW == 0); rows of Q / Out are d = H * HD bf16
+// wide.  grid = (ceil(T / 32), B).
+// Instruction budget.  One or two workgroups per CU means one or two waves per SIMD, and a wave64 VALU instruction takes
+// its SIMD 4 cycles (a transcendental 16): the kernel is bound by the NUMBER of vector instructions, 64 elements per lane
+// at d = 512 (tools/apply16_stamps.py: 14.6 K cycles per workgroup with the straightforward arithmetic, 2.5 K of them
+// waiting for the first tile).  So the element-wise work is written on float pairs (v_pk_fma / v_pk_mul / v_pk_add_f32:
+// two elements per issue): softmax = unpack, v_max3, one packed fma into the exp2 argument, exp2, packed sum, packed
+// scale, packed convert; LayerNorm + modulation = TWO packed fmas, with gamma' = gamma (1 + scale), beta' = beta (1 +
+// scale) + shift combined once per workgroup in LDS; SiLU = packed multiply, exp2, packed add, rcp, packed multiply.
+// Context matrices.  At16 is stored fragment-major (hig_at16_offset): a wave reads the operands of ITS heads global ->
+// registers, one coalesced KiB per MFMA operand, while the Q tile is still landing -- no LDS staging (at head dim 128 the
+// eight matrices are 256 KB; at 64 it leaves LDS for a second workgroup per CU).
 template <int HD, int H, int NW>
 __global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __restrict__ Q, int64_t ldq,
                                                               const __bf16* __restrict__ At16, const float* __restrict__ gamma,
@@ -60,17 +63,15 @@ __global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __re
   constexpr int NT = 64 * NW;                  // threads
   constexpr int HPW = H / NW;                  // heads per wave
   constexpr int NKS = HD / 16, NLB = HD / 32;  // MFMA k-steps / 32-column blocks per head
+  constexpr int NPRE = NLB < 2 ? NLB : 2;      // column blocks whose context operands are requested before the softmax
   constexpr int QBYTES = BR * ROWB;
-  constexpr int ATROWB = HD * 2;               // bytes of an At row (one l, all c)
-  constexpr int ATBYTES = H * HD * ATROWB;
   constexpr float LOG2E = 1.4426950408889634f;
-  static_assert(HD == 64, "At swizzle below is written for 128-byte rows");
-  static_assert(ROWB == 1024 || ROWB == 512, "Q rows of 512 or 1024 bytes");
+  static_assert(HD == 64 || HD == 128, "head dim 64 or 128");
+  static_assert(ROWB == 512 || ROWB == 1024 || ROWB == 2048, "Q rows of 512, 1024 or 2048 bytes");
   static_assert(H % NW == 0, "whole heads per wave");
-  __shared__ __attribute__((aligned(1024))) char smem[QBYTES + ATBYTES + 4 * D_ * 4 + NW * BR * 2 * 4];
+  __shared__ __attribute__((aligned(1024))) char smem[QBYTES + 4 * D_ * 4 + NW * BR * 2 * 4];
   char* const sQ = smem;                                       // [32][ROWB] bf16, 16-byte chunk c of row r at c ^ (r & 15); later the output tile
-  char* const sAt = smem + QBYTES;                             // [H * HD][128 B] bf16, chunk c of row r at c ^ ((r >> 1) & 7)
-  float* const sPar = reinterpret_cast<float*>(smem + QBYTES + ATBYTES);   // gamma | beta | scale | shift, then gamma' | beta'
+  float* const sPar = reinterpret_cast<float*>(smem + QBYTES); // gamma | beta | scale | shift, then gamma' | beta'
   float* const sRed = sPar + 4 * D_;                           // [NW waves][32 rows][2]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -95,8 +96,10 @@ __global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __re
     for (int q = 0; q < NQ; ++q) {
       const int n = wave + NW * q;
       const __bf16* src;
-      if constexpr (ROWB == 1024) {
-        src = Qb + (int64_t)min(r0 + n, T - 1) * ldq + 8 * (lane ^ (n & 15));
+      if constexpr (ROWB >= 1024) {
+        constexpr int IPR = ROWB / 1024;        // instructions per row
+        const int r = n / IPR, part = n % IPR;
+        src = Qb + (int64_t)min(r0 + r, T - 1) * ldq + 8 * ((64 * part + lane) ^ (r & 15));
       } else {
         const int r = 2 * n + (lane >> 5);
         src = Qb + (int64_t)min(r0 + r, T - 1) * ldq + 8 * ((lane & 31) ^ (r & 15));
@@ -105,8 +108,7 @@ __global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __re
                                        (__attribute__((address_space(3))) void*)(sQ + n * 1024), 16, 0, 0);
     }
   }
-  // ---- gamma | beta | scale | shift (fp32, D_ each) by DMA as well: no VGPR-returning load in this kernel, so hipcc has
-  // nothing to guard with a vmcnt(0) of its own while the DMAs are in flight ------------------------------------------
+  // ---- gamma | beta | scale | shift (fp32, D_ each) by DMA as well ----------------------------------------------------
   constexpr int NP = 4 * D_ * 4 / 1024;          // 1-KiB instructions for the four vectors
   constexpr int NPW = (NP + NW - 1) / NW;        // ... per wave (the last round may be partly filled: NP = 4 at d = 256)
   {
@@ -121,25 +123,25 @@ __global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __re
                                        (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(sPar) + n * 1024), 16, 0, 0);
     }
   }
-  // ---- context matrices of this sample, At16[b][h][l][c] (hig_linattn_ctx_bf16 wrote them transposed and rounded): all
-  // H heads by DMA, 8 rows of 128 bytes per instruction, chunk c of row r to position c ^ ((r >> 1) & 7) ----------------
-  constexpr int NA = ATBYTES / 1024 / NW;
-  {
-    static_assert((ATBYTES / 1024) % NW == 0, "context matrices in whole rounds of the waves");
-    const __bf16* Ab = At16 + (int64_t)b * H * HD * HD;
+  // ---- context matrices of this wave's heads, At16[b][h] in fragment-major order: operand (lb, ks) = bytes
+  // [(lb NKS + ks) KiB, + 1 KiB), 16 per lane.  The first NPRE column blocks are requested now, the rest after the softmax
+  // (their registers are the softmax's until then) ------------------------------------------------------------------
+  bf16x8 af[HPW][NLB][NKS];
+  auto load_at = [&](int hh, int lb) {
+    const __bf16* Ab = At16 + ((int64_t)b * H + wave + NW * hh) * HD * HD;
 #pragma unroll
-    for (int q = 0; q < NA; ++q) {
-      const int n = wave + NW * q;
-      const int row = 8 * n + (lane >> 3), pos = lane & 7;
-      const __bf16* src = Ab + (int64_t)row * HD + 8 * (pos ^ ((row >> 1) & 7));
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sAt + n * 1024), 16, 0, 0);
-    }
-  }
-  // (requests so far, oldest first: Q tile, LayerNorm / modulation vectors, context matrices.  The softmax below needs
-  // only the Q tile: it runs while the 64 KB of context matrices are still landing.)
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
-  __syncthreads();
+    for (int ks = 0; ks < NKS; ++ks) af[hh][lb][ks] = *reinterpret_cast<const bf16x8*>(Ab + ((lb * NKS + ks) * 64 + lane) * 8);
+  };
+#pragma unroll
+  for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+    for (int lb = 0; lb < NPRE; ++lb) load_at(hh, lb);
+  // (requests so far, oldest first: Q tile, LayerNorm / modulation vectors, context operands.  The softmax below needs
+  // only the Q tile: it runs while the context operands are still in flight.)
+  // (raw s_barrier, not __syncthreads(): its fence would wait for the register loads as well)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HPW * NPRE * NKS) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   stamp(1);
 
   // ---- gamma' = gamma (1 + scale), beta' = beta (1 + scale) + shift, in place over gamma | beta (each thread its own
@@ -194,24 +196,25 @@ __global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __re
       }
   }
   stamp(2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the context matrices have landed
-  __syncthreads();
+#pragma unroll
+  for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+    for (int lb = NPRE; lb < NLB; ++lb) load_at(hh, lb);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                 // gamma' / beta' are complete
+  asm volatile("" ::: "memory");
   stamp(3);
   f32x16 acc[HPW][NLB];
   f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};      // this lane's share of sum(y), sum(y^2) over its row
 #pragma unroll
   for (int hh = 0; hh < HPW; ++hh) {
-    const int h = wave + NW * hh;
 #pragma unroll
     for (int lb = 0; lb < NLB; ++lb) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[hh][lb][e] = 0.f;
-      const int row = h * HD + 32 * lb + lr;
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(sAt + row * ATROWB + 16 * ((2 * ks + lh) ^ ((row >> 1) & 7)));
-        acc[hh][lb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pfs[hh][ks], acc[hh][lb], 0, 0, 0);
-      }
+      for (int ks = 0; ks < NKS; ++ks)
+        acc[hh][lb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[hh][lb][ks], pfs[hh][ks], acc[hh][lb], 0, 0, 0);
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
         const f32x2 y = {acc[hh][lb][e], acc[hh][lb][e + 1]};
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int l = 32 * wj + 8 * (e >> 2) + 4 * lh + (e & 3);
-      At16[((int64_t)blockIdx.x * HD + l) * HD + cc] = (__bf16)(acc[e] * inv);
+      At16[(int64_t)blockIdx.x * HD * HD + hig_at16_offset(HD, l, cc)] = (__bf16)(acc[e] * inv);
     }
   }
 }
@@ -479,8 +482,8 @@ extern "C" int hig_linattn_apply_sty_mm16(const void* Q, int64_t ldq, const void
                                           const float* ss, int64_t ss_ld, int32_t ss_shift_off, void* Out, int64_t ldo,
                                           int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream) {
   HIG_REQUIRE(Q && At16 && gamma && beta && ss && Out && B > 0 && rows > 0, "hig_linattn_apply_sty_mm16: bad arguments");
-  if (hd != 64 || (H != 4 && H != 8))
-    return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn_apply_sty_mm16: built for head dim 64 and 4 or 8 heads (got %d, %d)", hd, H);
+  if ((hd != 64 && hd != 128) || (H != 4 && H != 8))
+    return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn_apply_sty_mm16: built for head dim 64 / 128 and 4 or 8 heads (got %d, %d)", hd, H);
   HIG_REQUIRE(ldq % 8 == 0 && ldo % 8 == 0 && ss_ld % 4 == 0 && ss_shift_off % 4 == 0 &&
                   ((reinterpret_cast<uintptr_t>(Q) & 15) | (reinterpret_cast<uintptr_t>(Out) & 15) |
                    (reinterpret_cast<uintptr_t>(At16) & 15) | (reinterpret_cast<uintptr_t>(gamma) & 15) |
@@ -488,16 +491,17 @@ extern "C" int hig_linattn_apply_sty_mm16(const void* Q, int64_t ldq, const void
               "hig_linattn_apply_sty_mm16: alignment");
   const dim3 grid((rows + 31) / 32, B);
   hipStream_t st = hig_stream(stream);
-  static const int nw8 = getenv("HIG_APPLY16_NW") ? atoi(getenv("HIG_APPLY16_NW")) : 8;      // tuning knob: waves per workgroup at 8 heads
-  if (H == 8 && nw8 == 8)
-    hipLaunchKernelGGL((apply_sty16_kernel<64, 8, 8>), grid, dim3(512), 0, st, static_cast<const __bf16*>(Q), ldq, static_cast<const __bf16*>(At16), gamma, beta, ss,
-                       ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo, rows, g_ap_stamps);
-  else if (H == 8)
-    hipLaunchKernelGGL((apply_sty16_kernel<64, 8, 4>), grid, dim3(256), 0, st, static_cast<const __bf16*>(Q), ldq, static_cast<const __bf16*>(At16), gamma, beta, ss,
-                       ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo, rows, g_ap_stamps);
-  else
-    hipLaunchKernelGGL((apply_sty16_kernel<64, 4, 4>), grid, dim3(256), 0, st, static_cast<const __bf16*>(Q), ldq, static_cast<const __bf16*>(At16), gamma, beta, ss,
-                       ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo, rows, g_ap_stamps);
+  static const int nw8 = getenv("HIG_APPLY16_NW") ? atoi(getenv("HIG_APPLY16_NW")) : 8;      // tuning knob: waves per workgroup at 8 heads, head dim 64
+#define HIG_AP16(HD_, H_, NW_)                                                                                                  \
+  hipLaunchKernelGGL((apply_sty16_kernel<HD_, H_, NW_>), grid, dim3(64 * NW_), 0, st, static_cast<const __bf16*>(Q), ldq,      \
+                     static_cast<const __bf16*>(At16), gamma, beta, ss, ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo,   \
+                     rows, g_ap_stamps)
+  if (hd == 64 && H == 8 && nw8 == 8) HIG_AP16(64, 8, 8);
+  else if (hd == 64 && H == 8) HIG_AP16(64, 8, 4);
+  else if (hd == 64) HIG_AP16(64, 4, 4);
+  else if (H == 8) HIG_AP16(128, 8, 8);
+  else HIG_AP16(128, 4, 4);
+#undef HIG_AP16
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

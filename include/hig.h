@@ -440,8 +440,10 @@ int hig_ln_bf16(const void* x, int32_t x_f32, int64_t ldx, int64_t rows, int32_t
                 const float* beta, const float* ss, int64_t ss_ld, int32_t ss_shift_off, int32_t rows_per_sample,
                 void* out, int64_t ldo, hig_stream_t stream);
 /* bf16-storage forms of hig_linattn_ctx / hig_linattn_apply (below): K, V, Q, Y bf16; A, kstat fp32; head dim 64 / 128. */
-/* At16 (nullable): the context matrices once more, transposed and rounded -- At16[b][h][l][c] = bf16(A[b][h][c][l]) --
- * the matrix-core operand of hig_linattn_apply_sty_mm16. */
+/* At16 (nullable): the context matrices once more, transposed and rounded -- At[l][c] = bf16(A[b][h][c][l]) -- the
+ * matrix-core operand of hig_linattn_apply_sty_mm16, hd x hd elements per (b, h) in "fragment-major" order: element (l, c)
+ * at ((((l / 32) (hd / 16) + c / 16) 64 + l % 32 + 32 ((c % 16) / 8)) 8 + c % 8 (hig_at16_offset, csrc/hig_common.h), so
+ * that one 32 x 16 MFMA operand block is one contiguous KiB. */
 int hig_linattn_ctx_bf16(const void* K, const void* V, int64_t ld, int32_t B, int32_t rows, int32_t H, int32_t hd,
                          const int64_t* length, float* A, float* kstat, float* scratch, void* At16, hig_stream_t stream);
 int hig_linattn_apply_bf16(const void* Q, int64_t ldq, const float* A, void* Y, int64_t ldy, int32_t B, int32_t rows,
@@ -458,9 +460,10 @@ int hig_linattn_apply_sty_bf16(const void* Q, int64_t ldq, const float* A, const
                                const float* ss, int64_t ss_ld, int32_t ss_shift_off, void* Out, int64_t ldo,
                                int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
 /* The same operator with the hd x hd products on the bf16 matrix cores (csrc/linattn16.hip): softmax(Q) and A are rounded
- * to bf16 for the product (fp32 accumulate), a workgroup owns 32 whole rows, Q / Out and the context matrices move as
- * whole rows through LDS (DMA).  At16: the transposed bf16 context matrices hig_linattn_ctx_bf16 writes.
- * Head dim 64 with 4 or 8 heads.  Default of the bf16-storage forward (HIG_FUSE_APPLY=2). */
+ * to bf16 for the product (fp32 accumulate), a workgroup owns 32 whole rows, Q / Out move as whole rows through LDS
+ * (DMA), the context operands go global -> registers.  At16: the transposed bf16 context matrices in the order
+ * hig_linattn_ctx_bf16 / hig_linattn_ctx_mm16 write them.  Head dim 64 / 128 with 4 or 8 heads.  Default of the
+ * bf16-storage forward (HIG_FUSE_APPLY=2). */
 int hig_linattn_apply_sty_mm16(const void* Q, int64_t ldq, const void* At16, const float* gamma, const float* beta,
                                const float* ss, int64_t ss_ld, int32_t ss_shift_off, void* Out, int64_t ldo,
                                int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);

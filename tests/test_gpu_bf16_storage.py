@@ -31,6 +31,16 @@ def bf(t):
     return t.to(torch.bfloat16)
 
 
+def at16_order(A):
+    """The transposed, bf16-rounded context matrices in the element order the library keeps them in (hig_at16_offset,
+    csrc/hig_common.h): At[l][c] = bf16(A[c][l]) cut into the 32 (l) x 16 (c) operand blocks of v_mfma_f32_32x32x16_bf16, each
+    block 64 lanes x 8 elements, lane = l % 32 + 32 ((c % 16) / 8).  A: (B, H, hd, hd) indexed [c][l]."""
+    B, H, hd, _ = A.shape
+    At = bf(A.transpose(2, 3)).contiguous()                                   # [l][c]
+    v = At.view(B, H, hd // 32, 32, hd // 16, 2, 8)                           # (lb, l32, ks, half, j)
+    return v.permute(0, 1, 2, 4, 5, 3, 6).contiguous().view(B, H, hd, hd)     # (lb, ks, half, l32, j)
+
+
 EPIS = {"none": _lib.EPI_NONE, "bias": _lib.EPI_BIAS, "gelu": _lib.EPI_BIAS_GELU, "res": _lib.EPI_BIAS_RES,
         "silu": _lib.EPI_BIAS_SILU, "res_silu": _lib.EPI_BIAS_RES_SILU}
 
@@ -226,7 +236,7 @@ def test_linear_attention_bf16_io_matches_fp32_kernels(hd, H, B, T):
     At = torch.full((B, H, hd, hd), float("nan"), device=DEV, dtype=torch.bfloat16)
     _lib.check(L.hig_linattn_ctx_bf16(qkv16.data_ptr() + 2 * d, qkv16.data_ptr() + 4 * d, 3 * d, B, T, H, hd, _lib.ptr(lens),
                                       _lib.ptr(A16), _lib.ptr(k16), _lib.ptr(scr), _lib.ptr(At), _lib.stream_ptr()))
-    assert torch.equal(At, bf(A16.transpose(2, 3)).contiguous())     # the transposed, rounded copy for linattn16.hip
+    assert torch.equal(At, at16_order(A16))     # the transposed, rounded copy for linattn16.hip
     _lib.check(L.hig_linattn_ctx(qkv32.data_ptr() + 4 * d, qkv32.data_ptr() + 8 * d, 3 * d, B, T, H, hd, _lib.ptr(lens),
                                  _lib.ptr(A32), _lib.ptr(k32), _lib.ptr(scr), _lib.stream_ptr()))
     assert torch.equal(A16, A32) and torch.equal(k16, k32)          # identical arithmetic on identical values
@@ -296,23 +306,24 @@ def test_context_build_on_the_bf16_matrix_cores(H, B, T):
     ks = kst.double().cpu().view(B, H, hd, 2)
     assert torch.equal(ks[live][..., 0], mx[live])                            # running maximum == column maximum
     assert rel(ks[live][..., 1], s[live]) < 1e-5
-    assert torch.equal(At.cpu(), bf(A.transpose(2, 3)).contiguous().cpu())
+    assert torch.equal(At.cpu(), at16_order(A).cpu())
 
 
-@pytest.mark.parametrize("H,B,T", [(8, 5, 196), (8, 32, 196), (4, 3, 33), (8, 2, 1), (4, 7, 91)])
-def test_fused_apply_stylization_front_on_the_bf16_matrix_cores(H, B, T):
+@pytest.mark.parametrize("H,B,T,hd", [(8, 5, 196, 64), (8, 32, 196, 64), (4, 3, 33, 64), (8, 2, 1, 64), (4, 7, 91, 64),
+                                      (8, 3, 300, 128), (4, 5, 45, 128), (8, 2, 31, 128)])
+def test_fused_apply_stylization_front_on_the_bf16_matrix_cores(H, B, T, hd):
     """hig_linattn_apply_sty_mm16 (csrc/linattn16.hip): softmax(q) and the context matrices are rounded to bf16 for the
     hd x hd products (fp32 accumulate) -- the rounding the bf16 storage mode applies to every other matrix operand.  Held
     (a) to exactly that arithmetic in fp64 (bf16-rounded p and A, fp64 products, LayerNorm / modulation / SiLU): only the
     accumulation order, the fp32 softmax and the final rounding differ; (b) to the unrounded reference at the bf16 level."""
-    hd, d = 64, H * 64
+    d = H * hd
     g = torch.Generator().manual_seed(H + B + T)
     q16 = bf(torch.randn(B * T, d, generator=g) * 2).to(DEV)
     A = (torch.randn(B, H, hd, hd, generator=g) * 0.5).to(DEV)
     gamma, beta = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV), (0.1 * torch.randn(d, generator=g)).to(DEV)
     ss = (0.3 * torch.randn(B, 2 * d, generator=g)).to(DEV)
     out = torch.full((B * T, d), float("nan"), device=DEV, dtype=torch.bfloat16)
-    At = bf(A.transpose(2, 3)).contiguous()
+    At = at16_order(A)
     _lib.check(_lib.lib().hig_linattn_apply_sty_mm16(_lib.ptr(q16), d, _lib.ptr(At), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(ss),
                                                      2 * d, d, _lib.ptr(out), d, B, T, H, hd, _lib.stream_ptr()))
     q = q16.double().cpu().view(B, T, H, hd)
