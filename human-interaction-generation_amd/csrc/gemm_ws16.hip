@@ -94,12 +94,15 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   constexpr int GK = OCC > 1 ? 2 : 4;          // k-steps per scheduling group
   // X ring: three tiles where LDS allows (a tile requested in iteration t is waited for at the top of iteration t + 2:
   // one tile in flight across every barrier); two at K = 1024 (64 KB tiles)
-  constexpr int RBUF = HAS_RES ? SBUF : 0;     // residual tiles come in by DMA too (two buffers, staged-tile sized)
-  static_assert(!(HAS_RES && KSPLIT > 1), "the K-split variant has no LDS left for residual tiles");
+  // residual tiles come in by DMA too: two buffers, staged-tile sized -- except in the K-split variant, whose 160 KB are
+  // all taken: there the residual of tile t lands IN the staging buffer tile t will be staged in (each lane reads the 8
+  // bytes it is about to overwrite), requested once the stores of tile t - 2 have read that buffer (one more barrier)
+  constexpr bool RES_INPLACE = HAS_RES && KSPLIT > 1;
+  constexpr int RBUF = HAS_RES && !RES_INPLACE ? SBUF : 0;
   constexpr int NXB = (3 * XBUF + 2 * SBUF + 2 * RBUF + PBUF <= LDS_MAX) ? 3 : 2;
   static_assert(2 * XBUF + 2 * SBUF + 2 * RBUF + PBUF <= LDS_MAX, "LDS budget");
-  constexpr int NRQ = RBUF / 1024 / NW;        // residual DMA instructions per wave and tile
-  static_assert(RBUF % (1024 * NW) == 0, "residual DMA instructions must split evenly over the waves");
+  constexpr int NRQ = HAS_RES ? SBUF / 1024 / NW : 0;   // residual DMA instructions per wave and tile
+  static_assert(!HAS_RES || SBUF % (1024 * NW) == 0, "residual DMA instructions must split evenly over the waves");
   // bias: in LDS where there is room (sixteen registers less per lane), else in registers for the workgroup's life
   constexpr bool BIAS_LDS = NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + BN * 4 <= LDS_MAX;
   static_assert(XT != 2 || BIAS_LDS, "the LayerNorm-fold consumer keeps bias' and the column sums in LDS");
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
         const int r = o / SROWB, p = (o % SROWB) / 16;
         [[maybe_unused]] const int voff = (min(i0 + r, a.I - 1) * (int)a.ldr + j0 + 8 * (p ^ (r & 15))) * 2;
 #if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsR, (__attribute__((address_space(3))) void*)(sR + buf * RBUF + n * 1024), 16, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsR, (__attribute__((address_space(3))) void*)((RES_INPLACE ? sS + buf * SBUF : sR + buf * RBUF) + n * 1024), 16, voff, 0, 0, 0);
 #endif
       }
     }
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
     __builtin_amdgcn_s_barrier();               // everyone's share has landed; k-loop(t-1) is over everywhere: its buffer, staging(t-1), parked(t-1) are complete
     asm volatile("" ::: "memory");
     if (t < 9) stamp(3 + t);
-    dma_res(t, t & 1);
+    if constexpr (!RES_INPLACE) dma_res(t, t & 1);
     if constexpr (XT == 2) {
       if (wave == 0) {                           // the statistics of tile t's rows: one 1-KiB DMA (32 rows x 4 panels x 2 floats)
         const int i = min((t0 + t * a.g) * BM + (lane >> 1), a.I - 1);
@@ -395,6 +398,12 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
     }
     if constexpr (XT == 1) statw = sStat + (size_t)((t + 1) & 1) * NW * BM * 2 + wave * BM * 2;
     if (t >= 2) store_tile(t - 2, sS + (t & 1) * SBUF);
+    if constexpr (RES_INPLACE) {                 // that staging buffer is free now: the residual of tile t goes there
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      dma_res(t, t & 1);
+    }
     dma_pend = t + NXB - 1 < nt;                 // its DMA instructions go out between the MFMAs below
     constexpr bool DMA_IN_LOOP = OCC == 1;       // (two workgroups per CU: issued here in one block -- the other workgroup's
                                                  // waves feed the matrix pipe meanwhile, and the k-loop needs fewer registers)
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
     // two waves of a SIMD issue theirs at different k-steps, so one of them keeps the matrix pipe busy)
     const char* xb = sX + (t % NXB) * XBUF;
     char* stg = sS + ((t + 1) & 1) * SBUF;       // staging of tile t-1
-    [[maybe_unused]] const char* rbuf = sR + ((t + 1) & 1) * RBUF;   // its residual
+    [[maybe_unused]] const char* rbuf = RES_INPLACE ? stg : sR + ((t + 1) & 1) * RBUF;   // its residual
     [[maybe_unused]] const float* parked = reinterpret_cast<const float*>(sP) + (wave ^ NWJ) * 512 + lane;
     // The MFMAs of this tile with the epilogue of the previous one (garbage in, nothing stored, at t = 0) riding in their
     // gaps, element by element.  X fragments are read XD k-steps ahead into a register ring: LDS answers a ds_read_b128
@@ -497,7 +506,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   {
     char* stg = sS + ((nt + 1) & 1) * SBUF;
     [[maybe_unused]] const float* parked = reinterpret_cast<const float*>(sP) + (wave ^ NWJ) * 512 + lane;
-    [[maybe_unused]] const char* rbuf = sR + ((nt + 1) & 1) * RBUF;
+    [[maybe_unused]] const char* rbuf = RES_INPLACE ? stg : sR + ((nt + 1) & 1) * RBUF;
 #pragma unroll
     for (int j = 0; j < 4 * NQF * NCB; ++j) epi_elem(j, stg, parked, rbuf);
   }
@@ -563,8 +572,7 @@ int launch_ws_sized(const hig_gemm16_desc& g, int nwj, hipStream_t st) {
   }
   if (g.R == 512) return nwj == 8 ? launch_ws<512, 1, 8, 1, EPI>(g, 32, st) : nwj == 2 ? launch_ws<512, 1, 4, 2, EPI>(g, 32, st) : launch_ws<512, 1, 4, 1, EPI>(g, 32, st);
   if (g.R == 256) return nwj == 8 ? launch_ws<256, 1, 8, 1, EPI>(g, 32, st) : launch_ws<256, 1, 4, 1, EPI>(g, 32, st);
-  if constexpr (EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU) return 1;   // (no LDS left for residual tiles)
-  else return launch_ws<512, 2, 4, 1, EPI>(g, 32, st);   // K = 1024: 8 waves = 4 column slices x 2 halves of the reduce range
+  return launch_ws<512, 2, 4, 1, EPI>(g, 32, st);   // K = 1024: 8 waves = 4 column slices x 2 halves of the reduce range
 }
 
 }  // namespace

@@ -63,7 +63,9 @@ EPIS = {"none": _lib.EPI_NONE, "bias": _lib.EPI_BIAS, "gelu": _lib.EPI_BIAS_GELU
     (6272, 512, 1024, "bias", 0, 0), (9600, 1024, 1024, "res", 0, 0), (4000, 3072, 1024, "gelu", 0, 0),
     (6250, 512, 512, "res", 0, 0), (2049, 256, 256, "gelu", 0, 0), (3001, 384, 512, "res_silu", 0, 0),
     (2100, 1536, 512, "silu", 0, 0), (12544, 512, 512, "none", 0, 0), (2464, 1024, 256, "res", 0, 0),
-    (6272, 1024, 512, "gelu", 0, 0), (2177, 640, 1024, "res", 0, 0)])
+    (6272, 1024, 512, "gelu", 0, 0), (2177, 640, 1024, "res", 0, 0),
+    # K = 1024 with a residual: the residual tile lands in the staging buffer itself (no LDS left for its own)
+    (6250, 512, 1024, "res_silu", 0, 0), (2050, 128, 1024, "res", 0, 0), (12544, 1024, 1024, "res", 0, 0)])
 def test_gemm_bf16_all_epilogues_and_ragged_shapes(I, J, R, epi, c_f32, res_f32):
     g = torch.Generator().manual_seed(I * 7 + J * 3 + R)
     X, Y = bf(torch.randn(I, R, generator=g)), bf(torch.randn(J, R, generator=g) / R ** 0.5)
