@@ -178,8 +178,8 @@ def ffn_gemm_bf16_roofline(c, device, reps=32):
     flops = 2.0 * M * K * Nn
     ach = flops / (ms * 1e-3) / 1e12
     by = (M * K + Nn * K + M * Nn) * 2
-    return {"bound": "mfma (nominal; measured: per-tile fixed costs and the L2->LDS operand path, profiles/r02_notes.md)",
-            "kernel": "gemm_bf16_kernel (FFN linear1, bf16 storage: M=%d K=%d N=%d, bias+GELU)" % (M, K, Nn),
+    return {"bound": "mfma (nominal; measured: instruction issue of one wave per SIMD + LDS operand reads, profiles/r03_notes.md)",
+            "kernel": "gemm_ws16_kernel (weight-stationary; FFN linear1, bf16 storage: M=%d K=%d N=%d, bias+GELU)" % (M, K, Nn),
             "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
             "avg_launch_ms": round(ms, 4), "algorithmic_GB_per_s": round(by / ms / 1e6, 0),
             "how": "%d launches rotating over %d operand sets (%.0f MB > Infinity Cache), HIP events" % (reps, NB, NB * by / 1e6)}
@@ -806,8 +806,10 @@ def main():
     if rank == 0:
         if not a.no_extra and world == 1:
             extra["hbm_bound_kernels"] = hbm_kernel_rooflines(c, device)
-            extra["hbm_bound_kernels"]["counter_based"] = ("FETCH_SIZE / WRITE_SIZE passes of the same kernels: "
-                                                           "profiles/r02_hbm_kernels_pmc.json (not collected in this run)")
+            import glob
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_kernels_pmc.json")))
+            extra["hbm_bound_kernels"]["counter_based"] = ("FETCH_SIZE / WRITE_SIZE passes of the same kernels: %s (not collected "
+                                                           "in this run)" % (os.path.relpath(pm[-1], ROOT) if pm else "none committed"))
             extra["roofline_bf16_ffn_gemm"] = ffn_gemm_bf16_roofline(c, device)
         res["roofline"] = ffn_gemm_roofline(c, device)
         if not a.no_cpu_baseline and world == 1:

@@ -37,6 +37,8 @@ nscr, gn, stp = torch.zeros(_lib.NORM_BLOCKS, device=dev), torch.zeros(1, device
 q16 = qkv.to(torch.bfloat16)
 y16, a16 = torch.empty(M, d, device=dev, dtype=torch.bfloat16), torch.empty(M, d, device=dev, dtype=torch.bfloat16)
 
+At16 = torch.empty(B, H, hd, hd, device=dev, dtype=torch.bfloat16)
+
 cases = [
     lambda: L.hig_linattn_ctx(P(qkv) + 4 * d, P(qkv) + 8 * d, 3 * d, B, T, H, hd, P(lg), P(A), P(kst), P(scr), None, s),
     lambda: L.hig_linattn_apply(P(qkv), 3 * d, P(A), P(y), d, B, T, H, hd, s),
@@ -51,6 +53,9 @@ cases = [
     lambda: L.hig_linattn_apply_bf16(P(q16), 3 * d, P(A), P(y16), d, B, T, H, hd, s),
     lambda: L.hig_ln_bf16(P(y16), 0, d, M, d, P(g), P(be), P(ss), 2 * d, d, T, P(a16), d, s),
     lambda: L.hig_ln_bf16(P(y16), 0, d, M, d, P(g), P(be), None, 0, 0, 0, P(a16), d, s),
+    # round 3: the bf16-matrix-core context build and the fused apply + stylization front (linattn16.hip)
+    lambda: L.hig_linattn_ctx_mm16(P(q16) + 2 * d, P(q16) + 4 * d, 3 * d, B, T, H, hd, P(lg), P(A), P(kst), P(At16), s),
+    lambda: L.hig_linattn_apply_sty_mm16(P(q16), 3 * d, P(At16), P(g), P(be), P(ss), 2 * d, d, P(a16), d, B, T, H, hd, s),
 ]
 L.hig_layernorm(P(y), d, M, d, P(g), P(be), P(a_), d, P(st), s)     # valid stats for ln_bwd
 junk = torch.ones(256 << 20, device=dev)
