@@ -295,7 +295,8 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
   static_assert(HD == 64, "layouts below are written for 128-byte rows");
   constexpr int CHK = 64;                       // rows per chunk
   constexpr int ROWB = HD * 2;                  // 128 bytes per LDS row
-  constexpr int NB = 4;                         // K / V chunks in LDS: the DMA runs three chunks ahead of the arithmetic
+  constexpr int NB = 3;                         // K / V chunks in LDS: the DMA runs two chunks ahead of the arithmetic (65 KB of LDS: two workgroups per CU;
+                                                // four buffers = 83 KB = one, and the B x H = 512 workgroups of a B = 64 launch then ran as two rounds: B = 64 forward -3 %)
   __shared__ __attribute__((aligned(1024))) char sV[NB][CHK * ROWB];  // [r][l] bf16, 16-byte chunk c of row r at c ^ f(r)
   __shared__ __attribute__((aligned(1024))) char sK[NB][CHK * ROWB];  // [r][c] bf16, same layout (K arrives by DMA too: no VGPR load
                                                                       // for hipcc to guard with a vmcnt(0) while a DMA is in flight)
