@@ -880,12 +880,25 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
       HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B), nullptr, 0, 0, 0, xn, d, stream));
       HIG_TRY(hig_gemm16_launch(G16(xn, d, PL16(params16, l, HIG_L_INT_QKV_W), d, qkv, 3 * d, M, 3 * d, d)
                                     .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_INT_QKV_B)).g, st));
-      HIG_TRY(ctx16(D, qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, len_partner, A1, kst1, cscr, nullptr, stream));
+      HIG_TRY(ctx16(D, qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, len_partner, A1, kst1, cscr,
+                    fuse_mm16 ? ws + w.At1 : nullptr, stream));
       const int64_t halfA = (int64_t)Bp * D.H * D.hd * D.hd, halfM = (int64_t)Bp * D.T;
-      HIG_TRY(hig_linattn_apply_bf16(qkv, 3 * d, A1 + halfA, y, d, Bp, D.T, D.H, D.hd, stream));
-      HIG_TRY(hig_linattn_apply_bf16(qkv + halfM * 3 * d * 2, 3 * d, A1, static_cast<char*>(y) + halfM * d * 2, d, Bp, D.T, D.H, D.hd,
-                                     stream));
-      HIG_TRY(stylize(l, 2, HIG_L_INT_STY_NORM_W, HIG_L_INT_STY_NORM_B, HIG_L_INT_STY_OUT_W, HIG_L_INT_STY_OUT_B));
+      if (fuse_mm16) {
+        // each half of the batch against the OTHER half's context matrices, apply + stylization front as one kernel
+        const float* ssl = ss + (int64_t)(D.nsty * l + 2) * 2 * d;
+        const char* At = ws + w.At1;
+        HIG_TRY(hig_linattn_apply_sty_mm16(qkv, 3 * d, At + halfA * 2, PL(params, l, HIG_L_INT_STY_NORM_W), PL(params, l, HIG_L_INT_STY_NORM_B),
+                                           ssl, ss_ld, d, a, d, Bp, D.T, D.H, D.hd, stream));
+        HIG_TRY(hig_linattn_apply_sty_mm16(qkv + halfM * 3 * d * 2, 3 * d, At, PL(params, l, HIG_L_INT_STY_NORM_W),
+                                           PL(params, l, HIG_L_INT_STY_NORM_B), ssl + (int64_t)Bp * ss_ld, ss_ld, d,
+                                           static_cast<char*>(a) + halfM * d * 2, d, Bp, D.T, D.H, D.hd, stream));
+        HIG_TRY(sty_out(l, HIG_L_INT_STY_OUT_W, HIG_L_INT_STY_OUT_B));
+      } else {
+        HIG_TRY(hig_linattn_apply_bf16(qkv, 3 * d, A1 + halfA, y, d, Bp, D.T, D.H, D.hd, stream));
+        HIG_TRY(hig_linattn_apply_bf16(qkv + halfM * 3 * d * 2, 3 * d, A1, static_cast<char*>(y) + halfM * d * 2, d, Bp, D.T, D.H, D.hd,
+                                       stream));
+        HIG_TRY(stylize(l, 2, HIG_L_INT_STY_NORM_W, HIG_L_INT_STY_NORM_B, HIG_L_INT_STY_OUT_W, HIG_L_INT_STY_OUT_B));
+      }
     }
     // ---- FFN (transformer.py:167-170) ----
     HIG_TRY(hig_gemm16_launch(G16(h, d, PL16(params16, l, HIG_L_FFN_W1), d, f1, D.ff, M, D.ff, d)
