@@ -2,8 +2,8 @@
 //   out[m] = LN(x[m]) * gamma + beta                                           (transformer.py:108,144,146)
 //   out[m] = silu( (LN(x[m]) * gamma + beta) * (1 + scale[b]) + shift[b] )     (transformer.py:81-85)
 // with x bf16 (or fp32: the text embeddings arrive in fp32) and out bf16; statistics and arithmetic in fp32.
-// One 64-lane wave per row, 8 elements (16 bytes of bf16) per lane per sweep, the row stays in registers between the
-// statistics and the transform: x is read once, out written once -- HBM-bound at 2 x rows x n x 2 bytes.
+// One 64-lane wave per row (four consecutive rows per wave), 8 elements (16 bytes of bf16) per lane per sweep, the rows stay in
+// registers between the statistics and the transform: x is read once, out written once -- HBM-bound at 2 x rows x n x 2 bytes.
 #include "hig_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -23,73 +23,109 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
-template <int NIT, bool MOD, typename TIN>
+// RPW consecutive rows per wave: the per-column vectors (gamma, beta, and with MOD the sample's scale / shift -- 8 KB of
+// L2 reads per row when fetched per row, against 1 KB of row data) are loaded ONCE per wave and kept in registers, the
+// RPW row loads are all in flight together.  With MOD a workgroup stays inside one sample (blockIdx.y), so the modulation
+// vectors are wave-invariant; without it the rows are one run (gridDim.y == 1).  Arithmetic per element unchanged.
+template <int NIT, bool MOD, typename TIN, int RPW>
 __global__ __launch_bounds__(256) void ln16_kernel(const TIN* __restrict__ x, int64_t ldx, int64_t rows, int n,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ ss, int64_t ss_ld, int shift_off,
                                                    int rows_per_sample, __bf16* __restrict__ out, int64_t ldo) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const TIN* xr = x + row * ldx;
-  float v[NIT][8];
-  float s = 0.f;
+  const int64_t group0 = MOD ? (int64_t)blockIdx.y * rows_per_sample : 0;
+  const int64_t group1 = MOD ? min(group0 + rows_per_sample, rows) : rows;     // this group's rows: [group0, group1)
+  const int64_t row0 = group0 + ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * RPW;
+  if (row0 >= group1) return;
+  float v[RPW][NIT][8];
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int c = 8 * lane + 512 * it;
+  for (int k = 0; k < RPW; ++k) {
+    const TIN* xr = x + min(row0 + k, group1 - 1) * ldx;        // (rows beyond the group: a valid row, result not stored)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[it][e] = 0.f;
-    if (c < n) ld8(xr + c, v[it]);
-    s += ((v[it][0] + v[it][1]) + (v[it][2] + v[it][3])) + ((v[it][4] + v[it][5]) + (v[it][6] + v[it][7]));
-  }
-  const float mean = wave_sum(s) / (float)n;
-  float q = 0.f;
+    for (int it = 0; it < NIT; ++it) {
+      const int c = 8 * lane + 512 * it;
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    if (8 * lane + 512 * it < n) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = v[it][e] - mean;
-        q += d * d;
-      }
+      for (int e = 0; e < 8; ++e) v[k][it][e] = 0.f;
+      if (c < n) ld8(xr + c, v[k][it]);
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)n + 1e-5f);
-  const float* ssrow = MOD ? ss + (row / rows_per_sample) * ss_ld : nullptr;
+  float g[NIT][8], b[NIT][8], sc[MOD ? NIT : 1][8], sh[MOD ? NIT : 1][8];
+  const float* ssrow = MOD ? ss + (int64_t)blockIdx.y * ss_ld : nullptr;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int c = 8 * lane + 512 * it;
     if (c < n) {
-      float g[8], b[8], o[8];
-      ld8(gamma + c, g);
-      ld8(beta + c, b);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (v[it][e] - mean) * rstd * g[e] + b[e];
+      ld8(gamma + c, g[it]);
+      ld8(beta + c, b[it]);
       if (MOD) {
-        float sc[8], sh[8];
-        ld8(ssrow + c, sc);
-        ld8(ssrow + shift_off + c, sh);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = hig_silu_fast(o[e] * (1.0f + sc[e]) + sh[e]);
+        ld8(ssrow + c, sc[it]);
+        ld8(ssrow + shift_off + c, sh[it]);
       }
-      *reinterpret_cast<bf16x8*>(out + row * ldo + c) =
-          bf16x8{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3], (__bf16)o[4], (__bf16)o[5], (__bf16)o[6], (__bf16)o[7]};
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      s += ((v[k][it][0] + v[k][it][1]) + (v[k][it][2] + v[k][it][3])) + ((v[k][it][4] + v[k][it][5]) + (v[k][it][6] + v[k][it][7]));
+    const float mean = wave_sum(s) / (float)n;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (8 * lane + 512 * it < n) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[k][it][e] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)n + 1e-5f);
+    if (row0 + k >= group1) continue;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = 8 * lane + 512 * it;
+      if (c < n) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[k][it][e] - mean) * rstd * g[it][e] + b[it][e];
+        if (MOD) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = hig_silu_fast(o[e] * (1.0f + sc[it][e]) + sh[it][e]);
+        }
+        *reinterpret_cast<bf16x8*>(out + (row0 + k) * ldo + c) =
+            bf16x8{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3], (__bf16)o[4], (__bf16)o[5], (__bf16)o[6], (__bf16)o[7]};
+      }
     }
   }
 }
 
-template <bool MOD, typename TIN>
-int launch_ln16(const TIN* x, int64_t ldx, int64_t rows, int n, const float* gamma, const float* beta, const float* ss,
-                int64_t ss_ld, int shift_off, int rows_per_sample, __bf16* out, int64_t ldo, hipStream_t st) {
-  const dim3 grid((unsigned)((rows + WAVES - 1) / WAVES));
+template <bool MOD, typename TIN, int RPW>
+int launch_ln16_rpw(const TIN* x, int64_t ldx, int64_t rows, int n, const float* gamma, const float* beta, const float* ss,
+                    int64_t ss_ld, int shift_off, int rows_per_sample, __bf16* out, int64_t ldo, hipStream_t st) {
+  const int64_t group = MOD ? rows_per_sample : rows;            // rows that share the per-column vectors
+  const int64_t ngroups = MOD ? (rows + rows_per_sample - 1) / rows_per_sample : 1;
+  if (ngroups > 65535) return hig_set_error(HIG_EUNSUPPORTED, "hig_ln_bf16: more than 65535 samples in one launch");
+  const dim3 grid((unsigned)((group + WAVES * RPW - 1) / (WAVES * RPW)), (unsigned)ngroups);
   if (n <= 512)
-    hipLaunchKernelGGL((ln16_kernel<1, MOD, TIN>), grid, dim3(256), 0, st, x, ldx, rows, n, gamma, beta, ss, ss_ld, shift_off,
+    hipLaunchKernelGGL((ln16_kernel<1, MOD, TIN, RPW>), grid, dim3(256), 0, st, x, ldx, rows, n, gamma, beta, ss, ss_ld, shift_off,
                        rows_per_sample, out, ldo);
   else
-    hipLaunchKernelGGL((ln16_kernel<2, MOD, TIN>), grid, dim3(256), 0, st, x, ldx, rows, n, gamma, beta, ss, ss_ld, shift_off,
+    hipLaunchKernelGGL((ln16_kernel<2, MOD, TIN, RPW>), grid, dim3(256), 0, st, x, ldx, rows, n, gamma, beta, ss, ss_ld, shift_off,
                        rows_per_sample, out, ldo);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
+}
+
+// Rows per wave by size (measured, stylization front at d = 512): four rows per wave keep the per-column vectors in
+// registers -- 55 -> ~40 us at 100 352 rows -- but leave a 6 272-row launch with too few waves (5.9 -> 7.4 us): one row per
+// wave below 32 768 rows.
+template <bool MOD, typename TIN>
+int launch_ln16(const TIN* x, int64_t ldx, int64_t rows, int n, const float* gamma, const float* beta, const float* ss,
+                int64_t ss_ld, int shift_off, int rows_per_sample, __bf16* out, int64_t ldo, hipStream_t st) {
+  if (rows >= 32768) return launch_ln16_rpw<MOD, TIN, 4>(x, ldx, rows, n, gamma, beta, ss, ss_ld, shift_off, rows_per_sample, out, ldo, st);
+  return launch_ln16_rpw<MOD, TIN, 1>(x, ldx, rows, n, gamma, beta, ss, ss_ld, shift_off, rows_per_sample, out, ldo, st);
 }
 
 }  // namespace

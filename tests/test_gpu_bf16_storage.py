@@ -202,7 +202,9 @@ def test_gemm_bf16_rejects_what_it_cannot_run():
 
 
 @pytest.mark.parametrize("rows,n,mod,x_f32", [(392, 512, True, 0), (392, 512, False, 0), (154, 256, False, 1),
-                                               (50, 1024, True, 0), (7, 64, True, 0)])
+                                               (50, 1024, True, 0), (7, 64, True, 0),
+                                               # (>= 32 768 rows: four rows per wave, the per-column vectors in registers)
+                                               (33005, 512, True, 0), (32768, 256, False, 0), (40001, 1024, True, 0)])
 def test_layernorm_and_stylization_front_bf16(rows, n, mod, x_f32):
     g = torch.Generator().manual_seed(rows + n)
     x = torch.randn(rows, n, generator=g) * 2 + 0.3
