@@ -270,19 +270,22 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
 #pragma unroll
     for (int e = 0; e < 16; ++e) old[cb][e] = 0.f;
 
-  // The epilogue of the tile whose accumulators sit in `old`, one ELEMENT at a time (element j = 4 u + e of this
-  // wave's finished quads): the k-loop calls epi_elem(j) between its MFMAs so that the vector work is spread evenly.
-  float ev[4];
+  // The epilogue of the tile whose accumulators sit in `old`, one PAIR of elements at a time (pair jp = elements 2 jp,
+  // 2 jp + 1 of this wave's finished quads, element j = 4 u + e): the k-loop calls epi_pair(jp) between its MFMAs so that the
+  // vector work is spread evenly.  Pairs, because the kernel is bound by instruction issue and v_pk_fma / v_pk_mul / v_pk_add
+  // _f32 finish two elements per slot (gemm16_epi.h).
+  f32x2 ev[2];
   u32x2 rq = u32x2{0u, 0u};                    // residual of the quad in work: four bf16, raw bits
   [[maybe_unused]] float st_s1 = 0.f, st_s2 = 0.f;          // XT = 1: this lane's share of its row's (sum, sum of squares)
   [[maybe_unused]] float* statw = nullptr;                  //         where the wave parks them (set per tile)
   [[maybe_unused]] float ln_rstd = 0.f, ln_mr = 0.f;        // XT = 2: rstd and -mean * rstd of this lane's row
   [[maybe_unused]] f32x4 ln_b4 = f32x4{0.f, 0.f, 0.f, 0.f}, ln_c4 = f32x4{0.f, 0.f, 0.f, 0.f};
   [[maybe_unused]] const char* lnbuf = nullptr;             //         the tile's statistics in LDS (set per tile)
-  auto epi_elem = [&](int j, char* stg, [[maybe_unused]] const float* parked, [[maybe_unused]] const char* rbuf) {
+  auto epi_pair = [&](int jp, char* stg, [[maybe_unused]] const float* parked, [[maybe_unused]] const char* rbuf) {
+    const int j = 2 * jp;
     const int cb = j / (4 * NQF), jj = j % (4 * NQF);
-    const int u = jj >> 2, e = jj & 3;
-    float v = old[cb][jj];
+    const int u = jj >> 2, e = jj & 3;           // e = 0 or 2
+    f32x2 v = {old[cb][jj], old[cb][jj + 1]};
     if constexpr (XT == 2) {
       if (j == 0) {                              // LayerNorm statistics of this lane's row from the four panel partials
         const f32x4 p0 = *reinterpret_cast<const f32x4*>(lnbuf + lr * 32), p1 = *reinterpret_cast<const f32x4*>(lnbuf + lr * 32 + 16);
@@ -295,23 +298,23 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
         ln_b4 = *reinterpret_cast<const f32x4*>(sB + 32 * wj + 8 * u + 4 * lh);
         ln_c4 = *reinterpret_cast<const f32x4*>(sC + 32 * wj + 8 * u + 4 * lh);
       }
-      v = fmaf(v, ln_rstd, fmaf(ln_mr, ln_c4[e], ln_b4[e]));
+      const f32x2 tt = __builtin_elementwise_fma(f32x2{ln_mr, ln_mr}, f32x2{ln_c4[e], ln_c4[e + 1]}, f32x2{ln_b4[e], ln_b4[e + 1]});
+      v = __builtin_elementwise_fma(v, f32x2{ln_rstd, ln_rstd}, tt);
     }
-    if constexpr (KSPLIT > 1) v += parked[jj * 64];
+    if constexpr (KSPLIT > 1) v += f32x2{parked[jj * 64], parked[(jj + 1) * 64]};
     if constexpr (HAS_RES) {
       if (e == 0) rq = *reinterpret_cast<const u32x2*>(rbuf + lr * SROWB + 16 * ((4 * (NCB * wj + cb) + qf0 + u) ^ (lr & 15)) + 8 * lh);
       const unsigned w = e < 2 ? rq.x : rq.y;
-      v += __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));
+      v += f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
     }
-    ev[e] = (DBG & 2) ? v : epi_act<EPI>(v);
-    if (e == 3) {
+    ev[e >> 1] = (DBG & 2) ? v : epi_act_pk<EPI>(v);
+    if (e == 2) {
       const int pos16 = (4 * (NCB * wj + cb) + qf0 + u) ^ (lr & 15);
-      const bf16x4 o4 = bf16x4{(__bf16)ev[0], (__bf16)ev[1], (__bf16)ev[2], (__bf16)ev[3]};
+      const bf16x4 o4 = bf16x4{(__bf16)ev[0][0], (__bf16)ev[0][1], (__bf16)ev[1][0], (__bf16)ev[1][1]};
       *reinterpret_cast<bf16x4*>(stg + lr * SROWB + 16 * pos16 + 8 * lh) = o4;
       if constexpr (XT == 1) {                   // row sums of the ROUNDED outputs (what the consumer will read):
         // v_dot2c_f32_bf16 takes the packed pairs as they are -- x . (1, 1) and x . x, fp32 accumulate: 4 instructions per
-        // quad instead of 12 (unpack, add, fma per element) in a kernel bound by instruction issue (the statistics made
-        // this variant 32 % slower than the plain residual epilogue at M = 100 352)
+        // quad instead of 12 (unpack, add, fma per element)
         typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
         const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
           st_s1 = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, st_s1, false);
           st_s2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, st_s2, false);
         }
-        if (j == 4 * NQF * NCB - 1) {
+        if (j == 4 * NQF * NCB - 2) {
           st_s1 += __shfl_xor(st_s1, 32, 64);
           st_s2 += __shfl_xor(st_s2, 32, 64);
           if (lh == 0) *reinterpret_cast<float2*>(statw + lr * 2) = make_float2(st_s1, st_s2);
@@ -459,15 +462,15 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
         if constexpr (DMA && DMA_IN_LOOP && !(DBG & 8)) {
           if (ks % (NKS / NQ) == DPH) dma_one(rsX, (int)a.ldx, drow0, a.I - 1, dbuf, ks / (NKS / NQ));
         }
-        constexpr int NEL = 4 * NQF * NCB;       // epilogue elements per tile and lane, spread over the NKS k-steps
+        constexpr int NEL = 2 * NQF * NCB;       // epilogue element PAIRS per tile and lane, spread over the NKS k-steps
         if constexpr (NEL >= NKS) {
-          static_assert(NEL % NKS == 0 || NEL < NKS, "epilogue elements per k-step");
+          static_assert(NEL % NKS == 0 || NEL < NKS, "epilogue pairs per k-step");
 #pragma unroll
-          for (int i = 0; i < NEL / NKS; ++i) epi_elem(ks * (NEL / NKS) + i, stg, parked, rbuf);
+          for (int i = 0; i < NEL / NKS; ++i) epi_pair(ks * (NEL / NKS) + i, stg, parked, rbuf);
         } else {
           constexpr int STEP = NKS / NEL;
-          static_assert(NKS % NEL == 0, "k-steps per epilogue element");
-          if (ks % STEP == STEP - 1) epi_elem(ks / STEP, stg, parked, rbuf);
+          static_assert(NKS % NEL == 0, "k-steps per epilogue pair");
+          if (ks % STEP == STEP - 1) epi_pair(ks / STEP, stg, parked, rbuf);
         }
         // nothing moves across the end of a group of GK k-steps; inside a group hipcc interleaves the MFMAs with the
         // group's epilogue elements (several independent chains: one element alone is a chain of ~14 dependent vector
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
     [[maybe_unused]] const float* parked = reinterpret_cast<const float*>(sP) + (wave ^ NWJ) * 512 + lane;
     [[maybe_unused]] const char* rbuf = RES_INPLACE ? stg : sR + ((nt + 1) & 1) * RBUF;
 #pragma unroll
-    for (int j = 0; j < 4 * NQF * NCB; ++j) epi_elem(j, stg, parked, rbuf);
+    for (int jp = 0; jp < 2 * NQF * NCB; ++jp) epi_pair(jp, stg, parked, rbuf);
   }
   __syncthreads();
   store_tile(nt - 1, sS + ((nt + 1) & 1) * SBUF);
