@@ -1,10 +1,5 @@
 cd $GRAFT_REPO_ROOT
-P=human-interaction-generation_amd
-for v in old new old new; do
-  cp $P/libhig_$v.so $P/libhig.so
-  echo "== $v"
-  python tools/gemm16_bench.py 64 2>&1 | grep -v amdgpu.ids | grep -E "ffn1|sty_out|qkv" | tail -3
-  python tools/fwd16_time.py 32 2>&1 | grep -v amdgpu.ids | tail -1
-  python tools/fwd16_time.py 64 2>&1 | grep -v amdgpu.ids | tail -1
+for n in 0 8 4 2 44; do
+  echo "== NWJ=$n"
+  HIG_BF16_WS_NWJ=$n python tools/gemm16_bench.py 64 2>&1 | grep -v amdgpu.ids | grep -E "ffn1|sty_out|qkv|ffn2|ca_q" | tail -5
 done
-cp $P/libhig_new.so $P/libhig.so
