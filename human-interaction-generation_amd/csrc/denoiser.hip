@@ -689,12 +689,12 @@ inline const void* PL16(const void* const* t, int l, int idx) { return t[HIG_NGL
 
 }  // namespace
 
-// Context build of the bf16-storage forward: the bf16-matrix-core kernel of linattn16.hip where it is built (head dim 64),
+// Context build of the bf16-storage forward: the bf16-matrix-core kernel of linattn16.hip where it is built (head dim 64 / 128),
 // else the fp32-MFMA kernels with bf16 loads (HIG_CTX16=0 forces those).
 static int ctx16(const Dims& D, const void* K, const void* V, int64_t ld, int B, int rows, const int64_t* length, float* A,
                  float* kstat, float* scratch, void* At16, hig_stream_t stream) {
   static const int mm16 = getenv("HIG_CTX16") ? atoi(getenv("HIG_CTX16")) : 1;   // tuning knob
-  if (mm16 && D.hd == 64) return hig_linattn_ctx_mm16(K, V, ld, B, rows, D.H, D.hd, length, A, kstat, At16, stream);
+  if (mm16 && (D.hd == 64 || D.hd == 128)) return hig_linattn_ctx_mm16(K, V, ld, B, rows, D.H, D.hd, length, A, kstat, At16, stream);
   return hig_linattn_ctx_bf16(K, V, ld, B, rows, D.H, D.hd, length, A, kstat, scratch, At16, stream);
 }
 

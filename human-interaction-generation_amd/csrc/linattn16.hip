@@ -292,11 +292,18 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
                                                          int rows, int H, const int64_t* __restrict__ length,
                                                          float* __restrict__ A, float* __restrict__ kstat,
                                                          __bf16* __restrict__ At16) {
-  static_assert(HD == 64, "layouts below are written for 128-byte rows");
+  static_assert(HD == 64 || HD == 128, "head dim 64 or 128");
   constexpr int CHK = 64;                       // rows per chunk
-  constexpr int ROWB = HD * 2;                  // 128 bytes per LDS row
-  constexpr int NB = 3;                         // K / V chunks in LDS: the DMA runs two chunks ahead of the arithmetic (65 KB of LDS: two workgroups per CU;
-                                                // four buffers = 83 KB = one, and the B x H = 512 workgroups of a B = 64 launch then ran as two rounds: B = 64 forward -3 %)
+  constexpr int ROWB = HD * 2;                  // bytes per LDS row (128 / 256)
+  constexpr int NB = 3;                         // K / V chunks in LDS: the DMA runs two chunks ahead of the arithmetic (head dim 64: 65 KB of LDS, two
+                                                // workgroups per CU; four buffers = 83 KB = one, and the B x H = 512 workgroups of a B = 64 launch then
+                                                // ran as two rounds: B = 64 forward -3 %.  Head dim 128: 129 KB, one workgroup per CU)
+  constexpr int LPR = HD / 4;                   // lanes per row when a lane holds 4 channels (16 / 32)
+  constexpr int RPP = 64 / LPR;                 // rows a wave covers per pass (4 / 2)
+  constexpr int NI = 16 / RPP;                  // passes: a wave holds rows 16 wave .. 16 wave + 15 of the chunk (4 / 8)
+  constexpr int DPO = CHK * ROWB / 1024 / 4;    // DMA instructions per wave, operand and chunk (2 / 4)
+  constexpr int CPR = ROWB / 16;                // 16-byte chunks per row (8 / 16)
+  constexpr int NBW = HD / 64;                  // 32 x 32 blocks of A per wave and dimension (1 / 2)
   __shared__ __attribute__((aligned(1024))) char sV[NB][CHK * ROWB];  // [r][l] bf16, 16-byte chunk c of row r at c ^ f(r)
   __shared__ __attribute__((aligned(1024))) char sK[NB][CHK * ROWB];  // [r][c] bf16, same layout (K arrives by DMA too: no VGPR load
                                                                       // for hipcc to guard with a vmcnt(0) while a DMA is in flight)
@@ -311,25 +318,25 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
   const __bf16* Kb = K + (int64_t)b * rows * ld + h * HD;
   const __bf16* Vb = V + (int64_t)b * rows * ld + h * HD;
   auto fsw = [](int r) { return ((r >> 1) & 1) << 2; };   // swizzle: rows r, r + 2 of a transpose read use disjoint bank halves
-  // K: thread (wave, rl = lane / 16, c4 = lane % 16) holds channels 4 c4 .. 4 c4 + 3 of rows 16 wave + 4 i + rl, i = 0 .. 3
-  const int rl = lane >> 4, c4 = lane & 15;
-  float kreg[4][4];
+  // K: thread (wave, rl = lane / LPR, c4 = lane % LPR) holds channels 4 c4 .. 4 c4 + 3 of rows 16 wave + RPP i + rl, i = 0 .. NI - 1
+  const int rl = lane / LPR, c4 = lane % LPR;
+  float kreg[NI][4];
   auto read_k = [&](int r0, int buf) {          // this thread's K values of the chunk, from LDS (rows beyond len: -inf)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rr = 16 * wave + 4 * i + rl;
+    for (int i = 0; i < NI; ++i) {
+      const int rr = 16 * wave + RPP * i + rl;
       const u32x2 w = *reinterpret_cast<const u32x2*>(sK[buf] + rr * ROWB + 16 * ((c4 >> 1) ^ fsw(rr)) + 8 * (c4 & 1));
       const bool ok = r0 + rr < len;
       kreg[i][0] = ok ? bf_lo(w.x) : -INFINITY; kreg[i][1] = ok ? bf_hi(w.x) : -INFINITY;
       kreg[i][2] = ok ? bf_lo(w.y) : -INFINITY; kreg[i][3] = ok ? bf_hi(w.y) : -INFINITY;
     }
   };
-  auto dma_chunk = [&](int r0, int buf) {   // K and V rows [r0, r0 + 64) x 128 bytes: 2 x 8 instructions, 4 per wave (rows beyond len:
+  auto dma_chunk = [&](int r0, int buf) {   // K and V rows [r0, r0 + 64) x ROWB bytes: 2 x DPO instructions per wave (rows beyond len:
                                             // any valid row -- they are masked / multiplied by P = 0)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < DPO; ++q) {
       const int n = wave + 4 * q;
-      const int row = 8 * n + (lane >> 3), pos = lane & 7;
+      const int row = (1024 / ROWB) * n + lane / CPR, pos = lane % CPR;
       const int64_t off = (int64_t)min(r0 + row, max(len - 1, 0)) * ld + 8 * (pos ^ fsw(row));
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + off),
                                        (__attribute__((address_space(3))) void*)(sK[buf] + n * 1024), 16, 0, 0);
@@ -337,28 +344,32 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
                                        (__attribute__((address_space(3))) void*)(sV[buf] + n * 1024), 16, 0, 0);
     }
   };
-  // MFMA roles: wave (wi, wj) owns the 32 x 32 block A[32 wi ..][32 wj ..]; first operand V^T (rows l), second P^T (rows c):
-  // accumulator element 4 q + e of lane (lr, lh) is A[c = 32 wi + lr][l = 32 wj + 8 q + 4 lh + e]
+  // MFMA roles: wave (wi, wj) owns the NBW x NBW blocks A[32 (NBW wi + bi) ..][32 (NBW wj + bj) ..]; first operand V^T (rows
+  // l), second P^T (rows c): accumulator element 4 q + e of lane (lr, lh) is A[c = cbase + lr][l = lbase + 8 q + 4 lh + e]
   const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
   const int gi = lane & 15, gg = lane >> 4;     // transpose read: lane gi of 16-lane group gg
   auto tr_addr = [&](int colbase, int rr) {     // byte offset of (row rr, columns colbase + 16 (gg & 1) + 4 (gi & 3) ..) in a chunk image
     const int col = colbase + 16 * (gg & 1) + 4 * (gi & 3);
     return rr * ROWB + 16 * ((col >> 3) ^ fsw(rr)) + 2 * (col & 7);
   };
-  f32x16 acc;
+  f32x16 acc[NBW][NBW];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int bi = 0; bi < NBW; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < NBW; ++bj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[bi][bj][e] = 0.f;
   float mrun[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // running maximum of this thread's 4 channels
   float ksum[4] = {0.f, 0.f, 0.f, 0.f};         // this thread's share of sum_r exp(K - m)
   const int nchunk = (len + CHK - 1) / CHK;
   for (int t = 0; t < NB - 1 && t < nchunk; ++t) dma_chunk(t * CHK, t);
   for (int r0 = 0, it = 0; r0 < len; r0 += CHK, ++it) {
     const int buf = it & 1, kb = it % NB;
-    // chunk `it` has landed once only the younger chunks' requests (4 per wave and chunk) are outstanding
+    // chunk `it` has landed once only the younger chunks' requests (2 DPO per wave and chunk) are outstanding
     {
       const int younger = min(NB - 2, nchunk - 1 - it);
-      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DPO) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPO) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();               // #0: everyone's share of the chunk has landed
@@ -368,9 +379,11 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
     float m4[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      float m = fmaxf(fmaxf(kreg[0][c], kreg[1][c]), fmaxf(kreg[2][c], kreg[3][c]));
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float m = kreg[0][c];
+#pragma unroll
+      for (int i = 1; i < NI; ++i) m = fmaxf(m, kreg[i][c]);
+#pragma unroll
+      for (int off = LPR; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
       m4[c] = m;
     }
     if (rl == 0) *reinterpret_cast<f32x4*>(&sWmax[wave][4 * c4]) = f32x4{m4[0], m4[1], m4[2], m4[3]};
@@ -389,8 +402,8 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
     }
     if (wave == 0 && rl == 0) *reinterpret_cast<f32x4*>(&sScale[4 * c4]) = f32x4{sc[0], sc[1], sc[2], sc[3]};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rr = 16 * wave + 4 * i + rl;
+    for (int i = 0; i < NI; ++i) {
+      const int rr = 16 * wave + RPP * i + rl;
       float pe[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -404,22 +417,34 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
     __builtin_amdgcn_s_barrier();               // #2
     asm volatile("" ::: "memory");
     if (it + NB - 1 < nchunk) dma_chunk((it + NB - 1) * CHK, (it + NB - 1) % NB);   // into the buffer of chunk it - 1: everyone is past it
-    // ---- rescale the accumulator row (channel c = 32 wi + lr), then add this chunk: 4 k-steps of 16 rows ----
-    const float f = sScale[32 * wi + lr];
+    // ---- rescale the accumulator rows (channel c = cbase + lr), then add this chunk: 4 k-steps of 16 rows ----
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] *= f;
+    for (int bi = 0; bi < NBW; ++bi) {
+      const float f = sScale[32 * (NBW * wi + bi) + lr];
+#pragma unroll
+      for (int bj = 0; bj < NBW; ++bj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[bi][bj][e] *= f;
+    }
 #pragma unroll
     for (int ks = 0; ks < CHK / 16; ++ks) {
-      s16x8 vf, pf;
+      s16x8 vf[NBW], pf[NBW];
 #pragma unroll
       for (int part = 0; part < 2; ++part) {
         const int rr = 16 * ks + 8 * (gg >> 1) + 4 * part + (gi >> 2);
-        const s16x4 v4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sV[kb] + tr_addr(32 * wj, rr)));
-        const s16x4 p4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sP[buf] + tr_addr(32 * wi, rr)));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { vf[4 * part + e] = v4[e]; pf[4 * part + e] = p4[e]; }
+        for (int bb = 0; bb < NBW; ++bb) {
+          const s16x4 v4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sV[kb] + tr_addr(32 * (NBW * wj + bb), rr)));
+          const s16x4 p4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sP[buf] + tr_addr(32 * (NBW * wi + bb), rr)));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { vf[bb][4 * part + e] = v4[e]; pf[bb][4 * part + e] = p4[e]; }
+        }
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf), acc, 0, 0, 0);
+#pragma unroll
+      for (int bi = 0; bi < NBW; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < NBW; ++bj)
+          acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[bj]), __builtin_bit_cast(bf16x8, pf[bi]), acc[bi][bj], 0, 0, 0);
     }
   }
   // ---- column sums, normalisation, outputs ----
@@ -430,8 +455,8 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     float t = ksum[c];
-    t += __shfl_xor(t, 16, 64);
-    t += __shfl_xor(t, 32, 64);
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) t += __shfl_xor(t, off, 64);
     t4[c] = t;
   }
   if (rl == 0) *reinterpret_cast<f32x4*>(&sWmax[wave][4 * c4]) = f32x4{t4[0], t4[1], t4[2], t4[3]};
@@ -450,17 +475,24 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
     }
   }
   __syncthreads();
-  const int cc = 32 * wi + lr;
-  const float inv = sScale[cc];
-  float* ap = A + (int64_t)blockIdx.x * HD * HD + cc * HD + 32 * wj + 4 * lh;
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-    *reinterpret_cast<f32x4*>(ap + 8 * q) = f32x4{acc[4 * q] * inv, acc[4 * q + 1] * inv, acc[4 * q + 2] * inv, acc[4 * q + 3] * inv};
-  if (At16) {
+  for (int bi = 0; bi < NBW; ++bi) {
+    const int cc = 32 * (NBW * wi + bi) + lr;
+    const float inv = sScale[cc];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int l = 32 * wj + 8 * (e >> 2) + 4 * lh + (e & 3);
-      At16[(int64_t)blockIdx.x * HD * HD + hig_at16_offset(HD, l, cc)] = (__bf16)(acc[e] * inv);
+    for (int bj = 0; bj < NBW; ++bj) {
+      const int lbase = 32 * (NBW * wj + bj);
+      float* ap = A + (int64_t)blockIdx.x * HD * HD + cc * HD + lbase + 4 * lh;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(ap + 8 * q) = f32x4{acc[bi][bj][4 * q] * inv, acc[bi][bj][4 * q + 1] * inv, acc[bi][bj][4 * q + 2] * inv, acc[bi][bj][4 * q + 3] * inv};
+      if (At16) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int l = lbase + 8 * (e >> 2) + 4 * lh + (e & 3);
+          At16[(int64_t)blockIdx.x * HD * HD + hig_at16_offset(HD, l, cc)] = (__bf16)(acc[bi][bj][e] * inv);
+        }
+      }
     }
   }
 }
@@ -513,12 +545,16 @@ extern "C" int hig_linattn_apply_sty_mm16(const void* Q, int64_t ldq, const void
 extern "C" int hig_linattn_ctx_mm16(const void* K, const void* V, int64_t ld, int32_t B, int32_t rows, int32_t H, int32_t hd,
                                     const int64_t* length, float* A, float* kstat, void* At16, hig_stream_t stream) {
   HIG_REQUIRE(K && V && A && kstat && B > 0 && rows > 0 && H > 0, "hig_linattn_ctx_mm16: bad arguments");
-  if (hd != 64) return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn_ctx_mm16: built for head dim 64 (got %d)", hd);
+  if (hd != 64 && hd != 128) return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn_ctx_mm16: built for head dim 64 / 128 (got %d)", hd);
   HIG_REQUIRE(ld % 8 == 0 && (reinterpret_cast<uintptr_t>(K) & 15) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0 &&
                   (reinterpret_cast<uintptr_t>(A) & 15) == 0,
               "hig_linattn_ctx_mm16: K / V / A must be 16-byte aligned with ld %% 8 == 0");
-  hipLaunchKernelGGL(ctx16_mfma_kernel<64>, dim3(B * H), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(K),
-                     static_cast<const __bf16*>(V), ld, rows, H, length, A, kstat, static_cast<__bf16*>(At16));
+  if (hd == 64)
+    hipLaunchKernelGGL(ctx16_mfma_kernel<64>, dim3(B * H), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(K),
+                       static_cast<const __bf16*>(V), ld, rows, H, length, A, kstat, static_cast<__bf16*>(At16));
+  else
+    hipLaunchKernelGGL(ctx16_mfma_kernel<128>, dim3(B * H), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(K),
+                       static_cast<const __bf16*>(V), ld, rows, H, length, A, kstat, static_cast<__bf16*>(At16));
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

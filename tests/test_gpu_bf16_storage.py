@@ -277,13 +277,14 @@ def test_fused_apply_stylization_front_matches_the_two_kernel_sequence(hd, H, B,
     assert (out.float().cpu() != bf(ref.float()).float()).float().mean().item() < 0.03   # correctly rounded almost everywhere
 
 
-@pytest.mark.parametrize("H,B,T", [(8, 4, 196), (8, 32, 196), (2, 40, 77), (8, 3, 300), (4, 5, 1), (8, 2, 64), (8, 2, 65)])
-def test_context_build_on_the_bf16_matrix_cores(H, B, T):
+@pytest.mark.parametrize("H,B,T,hd", [(8, 4, 196, 64), (8, 32, 196, 64), (2, 40, 77, 64), (8, 3, 300, 64), (4, 5, 1, 64), (8, 2, 64, 64),
+                                      (8, 2, 65, 64), (8, 4, 300, 128), (4, 3, 77, 128), (2, 5, 129, 128), (8, 2, 1, 128)])
+def test_context_build_on_the_bf16_matrix_cores(H, B, T, hd):
     """hig_linattn_ctx_mm16 (csrc/linattn16.hip: online column softmax over row chunks, k^T v on v_mfma_f32_32x32x16_bf16 with
     transpose reads) against the definition in fp64 on the same bf16 K / V -- exp(K - max) and V are rounded to bf16 for the
     product, so A is held at the bf16 level, the statistics (column max, column sum) at the fp32 level -- with ragged and
     zero lengths, one and many chunks, and the transposed bf16 copy checked against the kernel's own A."""
-    hd, d = 64, H * 64
+    d = H * hd
     g = torch.Generator().manual_seed(H + B + T)
     qkv16 = bf(torch.randn(B * T, 3 * d, generator=g) * 1.5).to(DEV)
     lens = torch.randint(0, T + 1, (B,), generator=g)
