@@ -757,8 +757,8 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   static const int joint16 = getenv("HIG_JOINT16") ? atoi(getenv("HIG_JOINT16")) : 1;   // tuning knob
   if (joint16 && d % 128 == 0 && D.F <= 512) {
     // own kernel pair (weight padded / rounded to bf16, x rounded in LDS, bf16 MFMA): 31 -> ~8 us at B = 32
-    if (lnfold && lnfold[6 * D.L])   // (weight padded / rounded once, next to the caller's bf16 shadow)
-      HIG_TRY(hig_joint_embed_bf16_w(x, M, D.F, lnfold[6 * D.L], P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d, D.T,
+    if (lnfold && lnfold[9 * D.L])   // (weight padded / rounded once, next to the caller's bf16 shadow)
+      HIG_TRY(hig_joint_embed_bf16_w(x, M, D.F, lnfold[9 * D.L], P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d, D.T,
                                      D.two ? 1 : 0, ws + w.h, d, d, stream));
     else
       HIG_TRY(hig_joint_embed_bf16(x, M, D.F, P(params, HIG_P_JOINT_W), P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d,
@@ -810,13 +810,14 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
     have_stats = fold && want_stats;
     return hig_gemm16_launch(g.g, st);
   };
-  // xn-free projection of LN(h): out = LN(h) W^T + b through the folded operands (k = 0: q/k/v, k = 1: cross-attention query)
+  // xn-free projection of LN(h): out = LN(h) W^T + b through the folded operands (k = 0: q/k/v, k = 1: cross-attention query,
+  // k = 2: q/k/v of the person <-> person attention)
   auto ln_proj = [&](int l, int k, int norm_w, int norm_b, int lin_w, int lin_b, void* outp, int64_t ncols) -> int {
-    if (have_stats) {
-      G16 g(h, d, lnfold[6 * l + 3 * k], d, outp, ncols, M, ncols, d);
-      g.epi(HIG_EPI_BIAS, static_cast<const float*>(lnfold[6 * l + 3 * k + 2]));
+    if (have_stats && lnfold[9 * l + 3 * k]) {
+      G16 g(h, d, lnfold[9 * l + 3 * k], d, outp, ncols, M, ncols, d);
+      g.epi(HIG_EPI_BIAS, static_cast<const float*>(lnfold[9 * l + 3 * k + 2]));
       g.g.row_stats_in = stats;
-      g.g.ln_colsum = static_cast<const float*>(lnfold[6 * l + 3 * k + 1]);
+      g.g.ln_colsum = static_cast<const float*>(lnfold[9 * l + 3 * k + 1]);
       return hig_gemm16_launch(g.g, st);
     }
     HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, norm_w), PL(params, l, norm_b), nullptr, 0, 0, 0, xn, d, stream));
@@ -865,7 +866,7 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
     }
     // ---- cross attention to the text context (transformer.py:135-155) ----
     HIG_TRY(ln_proj(l, 1, HIG_L_CA_NORM_W, HIG_L_CA_NORM_B, HIG_L_CA_Q_W, HIG_L_CA_Q_B, qc, d));
-    want_stats = false;                          // (cross-attention / interaction stylization blocks: no folded consumer behind them)
+    want_stats = D.two == 1;                     // (its stylization block feeds the interaction LayerNorm of the two-person model, else nothing folded)
     if (D.full) {   // softmax over the N text tokens, no mask (transformer.py:242-262)
       const char* kvl = tc + tl.kv + tl.kv_stride * l;
       HIG_TRY(hig_fullattn_fwd_bf16(qc, d, kvl, kvl + (int64_t)d * 2, 2 * d, D.B, D.T, D.N, D.H, D.hd, nullptr, y, d, stream));
@@ -877,9 +878,8 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
     if (D.two == 1) {
       // ---- person <-> person linear cross attention (interaction_transformer.py:181-205): queries from the own
       // stream, key / value from the partner's (same LayerNorm on both), key softmax masked with the consumer's length
-      HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B), nullptr, 0, 0, 0, xn, d, stream));
-      HIG_TRY(hig_gemm16_launch(G16(xn, d, PL16(params16, l, HIG_L_INT_QKV_W), d, qkv, 3 * d, M, 3 * d, d)
-                                    .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_INT_QKV_B)).g, st));
+      HIG_TRY(ln_proj(l, 2, HIG_L_INT_NORM_W, HIG_L_INT_NORM_B, HIG_L_INT_QKV_W, HIG_L_INT_QKV_B, qkv, 3 * d));
+      want_stats = false;                        // (the interaction stylization block: no folded consumer behind it)
       HIG_TRY(ctx16(D, qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, len_partner, A1, kst1, cscr,
                     fuse_mm16 ? ws + w.At1 : nullptr, stream));
       const int64_t halfA = (int64_t)Bp * D.H * D.hd * D.hd, halfM = (int64_t)Bp * D.T;

@@ -604,36 +604,40 @@ class MotionTransformer(nn.Module):
 
     def _derived16(self, fp):
         """Operands of the bf16-storage forward derived from the parameters, kept next to the bf16 shadow and rebuilt
-        when the parameters change (`derived` of hig_denoiser_fwd_bf16): 6 L + 1 device pointers.
-        [6 l + 0 .. 5] (d = 512 only, else NULL: the library runs its LayerNorm kernel): the LayerNorm-folded q/k/v and
-        cross-attention query projections of layer l -- [W'_qkv (bf16), colsum_qkv, bias'_qkv, W'_q (bf16), colsum_q, bias'_q]
+        when the parameters change (`derived` of hig_denoiser_fwd_bf16): 9 L + 1 device pointers, NULL where a piece does
+        not apply (the library then runs its LayerNorm kernel / pads per call).
+        [9 l + 3 k + 0 .. 2] (d = 512 only): the LayerNorm-folded projection k of layer l -- k = 0 self-attention q/k/v, 1
+        cross-attention query, 2 q/k/v of the person <-> person attention (two-person model) -- as [W' (bf16), colsum, bias']
         with W' = gamma (.) W, colsum[j] = sum_r float(W'[j][r]), bias' = b + W beta: LayerNorm(x) W^T + b == rstd (x W'^T) -
-        rstd mean colsum + bias' (transformer.py:108-110,144); applied wherever the producer of x wrote its row statistics.
-        [6 L]: joint_embed weight (transformer.py:418) rounded to bf16 and padded to a multiple of 32 columns."""
+        rstd mean colsum + bias' (transformer.py:108-110,144; interaction_transformer.py:181-190); applied wherever the
+        producer of x wrote its row statistics.
+        [9 L]: joint_embed weight (transformer.py:418) rounded to bf16 and padded to a multiple of 32 columns."""
         ver = (self._param_version(), fp.flat.data_ptr())
         if getattr(self, "_derived", None) is None or self._derived[0] != ver:
-            d, nl, ng, offs = self.latent_dim, _lib.NLAYER, _lib.NGLOBAL, fp.group_offsets
-            arr, bufs = (C.c_void_p * (6 * self.num_layers + 1))(), []
+            d, nl, ng, offs, L = self.latent_dim, _lib.NLAYER, _lib.NGLOBAL, fp.group_offsets, self.num_layers
+            arr, bufs = (C.c_void_p * (9 * L + 1))(), []
             with torch.no_grad():
-                for l in range(self.num_layers if d == 512 else 0):
+                for l in range(L if d == 512 else 0):
                     def grp(idx, n):
                         o = offs[ng + l * nl + idx]
-                        return fp.flat[o:o + n]
-                    # (norm weight, norm bias, Linear weight, Linear bias, output rows): sa_block q/k/v, ca_block query
-                    for k, (nw, nb, wi, bi, rows) in enumerate(((0, 1, 2, 3, 3 * d), (8, 9, 12, 13, d))):
-                        gamma, beta = grp(nw, d), grp(nb, d)
-                        W, b = grp(wi, rows * d).view(rows, d), grp(bi, rows)
+                        return None if o is None else fp.flat[o:o + n]
+                    # (norm weight, norm bias, Linear weight, Linear bias, output rows) by index in the layer table (hig.h)
+                    for k, (nw, nb, wi, bi, rows) in enumerate(((0, 1, 2, 3, 3 * d), (8, 9, 12, 13, d), (28, 29, 30, 31, 3 * d))):
+                        gamma = grp(nw, d)
+                        if gamma is None:           # (the interaction block exists in the two-person model only)
+                            continue
+                        beta, W, b = grp(nb, d), grp(wi, rows * d).view(rows, d), grp(bi, rows)
                         Wp = (W * gamma[None, :]).to(torch.bfloat16).contiguous()
                         cs = Wp.float().sum(dim=1).contiguous()
                         bp = (b + W @ beta).contiguous()
                         bufs += [Wp, cs, bp]
-                        arr[6 * l + 3 * k], arr[6 * l + 3 * k + 1], arr[6 * l + 3 * k + 2] = Wp.data_ptr(), cs.data_ptr(), bp.data_ptr()
+                        arr[9 * l + 3 * k], arr[9 * l + 3 * k + 1], arr[9 * l + 3 * k + 2] = Wp.data_ptr(), cs.data_ptr(), bp.data_ptr()
                 F = self.input_feats
                 Fp = (F + 31) // 32 * 32
                 wj = torch.zeros(d, Fp, device=fp.flat.device, dtype=torch.bfloat16)
                 wj[:, :F] = self.joint_embed.weight.detach().to(torch.bfloat16)
                 bufs.append(wj)
-                arr[6 * self.num_layers] = wj.data_ptr()
+                arr[9 * L] = wj.data_ptr()
             self._derived = (ver, arr, bufs)
         return self._derived[1]
 

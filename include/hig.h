@@ -178,14 +178,15 @@ int hig_denoiser_fwd(const hig_dims* dims, const void* const* params, const floa
  * Workspace / text-context sizes: hig_workspace_bytes / hig_textctx_bytes with the same dims (training = 0). */
 int hig_text_context_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
                           const float* xf_out, void* textctx, hig_stream_t stream);
-/* derived (nullable): 6 L + 1 device pointers the caller derives from the parameters and keeps next to the bf16 shadow
+/* derived (nullable): 9 L + 1 device pointers the caller derives from the parameters and keeps next to the bf16 shadow
  * (rebuilt when the parameters change); any entry may be NULL (the library then does that piece per call).
- * [6 l + 0 .. 5], all six or none, d == 512: W'_qkv (bf16, 3d x d), colsum_qkv (fp32, 3d), bias'_qkv (fp32, 3d), W'_q
- * (bf16, d x d), colsum_q, bias'_q of the cross-attention query -- W' = gamma (.) W of the LayerNorm in front of the
- * Linear, colsum[j] = sum_r float(W'[j][r]), bias' = b + W beta.  With them (and >= 2048 rows) the LayerNorm kernels in
- * front of the q/k/v and query projections disappear: the stylization-out GEMM that produces the residual stream also
- * writes its row statistics, and the projection applies them in its epilogue (hig_gemm16_desc).
- * [6 L]: joint_embed weight padded and rounded for hig_joint_embed_bf16_w ((d, Fp) bf16, Fp = F rounded up to 32). */
+ * [9 l + 3 k + 0 .. 2], d == 512: W' (bf16, rows x d), colsum (fp32, rows), bias' (fp32, rows) of the LayerNorm + Linear pair
+ * k of layer l -- k = 0 self-attention q/k/v (3d rows), k = 1 cross-attention query (d rows), k = 2 q/k/v of the person <->
+ * person attention (two-person model, 3d rows) -- with W' = gamma (.) W of the LayerNorm in front of the Linear, colsum[j] =
+ * sum_r float(W'[j][r]), bias' = b + W beta.  With them (and >= 2048 rows) the LayerNorm kernels in front of those
+ * projections disappear: the stylization-out GEMM that produces the residual stream also writes its row statistics, and the
+ * projection applies them in its epilogue (hig_gemm16_desc).
+ * [9 L]: joint_embed weight padded and rounded for hig_joint_embed_bf16_w ((d, Fp) bf16, Fp = F rounded up to 32). */
 int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
                           const void* const* derived, const float* x,
                           const int64_t* t, const int64_t* length, const float* xf_proj, const void* textctx,
