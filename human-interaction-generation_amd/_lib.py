@@ -28,7 +28,7 @@ SYMBOLS = (
     "hig_bwd_workspace_bytes", "hig_text_context", "hig_denoiser_fwd", "hig_denoiser_bwd",
     "hig_gemm", "hig_gemm_ws", "hig_gemm_tail_ws_bytes", "hig_gemm_debug_stamps", "hig_rowstats", "hig_ln_mod_silu", "hig_linattn_ctx", "hig_linattn_apply", "hig_linattn_apply_bwd",
     "hig_linattn_ctx_bwd", "hig_linattn_bwd_scratch_floats", "hig_fullattn_fwd", "hig_fullattn_bwd", "hig_ln_bwd", "hig_ln_bwd_partial_floats", "hig_transpose", "hig_colsum", "hig_colsum_chunks",
-    "hig_timestep_embedding", "hig_q_sample", "hig_p_sample_step", "hig_dec_timesteps",
+    "hig_timestep_embedding", "hig_timestep_embedding_bf16", "hig_q_sample", "hig_p_sample_step", "hig_dec_timesteps",
     "hig_masked_mse", "hig_sumsq_partial", "hig_clip_adam",
     "hig_text_head_workspace_bytes", "hig_text_head_bwd_workspace_bytes", "hig_text_head_fwd", "hig_text_head_bwd",
     "hig_layernorm", "hig_gather_rows", "hig_scatter_add_rows", "hig_gather_frames", "hig_recover_joints", "hig_transpose_batch", "hig_linattn_ctx_scratch_floats", "hig_pair_mse",
@@ -143,6 +143,7 @@ def lib():
         L.hig_colsum_chunks.argtypes = [i64]
         L.hig_colsum.argtypes = [vp, i64, i64, i32, vp, vp, vp]
         L.hig_timestep_embedding.argtypes = [vp, i32, i32, vp, vp]
+        L.hig_timestep_embedding_bf16.argtypes = [vp, i32, i32, vp, vp]
         L.hig_q_sample.argtypes = [vp, vp, vp, vp, i32, i32, i64, vp, vp]
         L.hig_p_sample_step.argtypes = [vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, vp]
         L.hig_dec_timesteps.argtypes = [vp, i32, vp]

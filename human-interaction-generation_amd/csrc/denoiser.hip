@@ -744,8 +744,7 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
 
   // K0: emb = time_embed(timestep_embedding(t)) + xf_proj; only silu(emb) is consumed (by every stylization block):
   //     te -> silu(Lin0) -> silu(Lin2 + xf_proj) -> ONE GEMM for all 3L (scale, shift) pairs      (transformer.py:345-349,415,81-83)
-  HIG_TRY(hig_timestep_embedding(t, D.B, d, reinterpret_cast<float*>(ws + w.te32), stream));
-  HIG_TRY(hig_cast_bf16(reinterpret_cast<float*>(ws + w.te32), ws + w.te16, (int64_t)D.B * d, stream));
+  HIG_TRY(hig_timestep_embedding_bf16(t, D.B, d, ws + w.te16, stream));
   HIG_TRY(hig_gemm16_launch(G16(ws + w.te16, d, P16(params16, HIG_P_TE0_W), d, ws + w.teh16, E, D.B, E, d)
                                 .epi(HIG_EPI_BIAS_SILU, P(params, HIG_P_TE0_B)).g, st));
   HIG_TRY(hig_gemm16_launch(G16(ws + w.teh16, E, P16(params16, HIG_P_TE2_W), E, ws + w.semb16, E, D.B, E, E)

@@ -550,7 +550,8 @@ __global__ __launch_bounds__(256) void joint_embed16_kernel(const float* __restr
   // block of every row tile runs at once instead of as a serial chain of load -> MFMA -> store steps per workgroup.
   // Weight block first (independent 16-byte loads, the loop unrolled so they are all in flight together):
   const int c16 = Fp / 8;                                  // 16-byte chunks per padded weight row
-#pragma unroll 4
+  // (12 at a time: the 10 loads per thread of F = 150 are then ONE round trip to L2 / HBM instead of three)
+#pragma unroll 12
   for (int idx = tid; idx < 128 * c16; idx += 256) {
     const int rr = idx / c16, ch = idx % c16;
     *reinterpret_cast<uint4*>(sW + rr * LDX + 8 * ch) = *reinterpret_cast<const uint4*>(Wp + (int64_t)(cb + rr) * Fp + 8 * ch);
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(256) void joint_embed16_kernel(const float* __restr
     const int64_t rows_here = M - m0 < 64 ? M - m0 : 64;
     const int n_el = (int)(rows_here * F);
     const bool vec = (reinterpret_cast<uintptr_t>(xt) & 15) == 0;
-#pragma unroll 4
+#pragma unroll 12
     for (int e0 = 4 * tid; e0 < n_el; e0 += 1024) {
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (vec && e0 + 3 < n_el) {
@@ -583,6 +584,21 @@ __global__ __launch_bounds__(256) void joint_embed16_kernel(const float* __restr
         if (++c == F) { c = 0; ++r; }
       }
     }
+  }
+  // bias and positional rows of the four output pieces this thread will store (piece u: row (tid + 256 u) / 16, columns
+  // cb + 8 (tid % 16) ..): requested HERE, ahead of the products, so that the row pass at the end waits for nothing
+  const int oc8 = 8 * (tid & 15);
+  f32x4 pb[2], pp[4][2];
+  pb[0] = *reinterpret_cast<const f32x4*>(bias + cb + oc8);
+  pb[1] = *reinterpret_cast<const f32x4*>(bias + cb + oc8 + 4);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t m = m0 + ((tid + 256 * u) >> 4);
+    const int tp = (int)(min(m, M - 1) % T) - pos_shift;
+    const float* pr = pos + (int64_t)max(tp, 0) * ldpos + cb + oc8;
+    pp[u][0] = *reinterpret_cast<const f32x4*>(pr);
+    pp[u][1] = *reinterpret_cast<const f32x4*>(pr + 4);
+    if (tp < 0) pp[u][0] = pp[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};    // (init-pose row of the two-person model: no positional term)
   }
   __syncthreads();
   f32x16 acc[2];
@@ -612,18 +628,13 @@ __global__ __launch_bounds__(256) void joint_embed16_kernel(const float* __restr
   // bf16 store per lane = 256 contiguous bytes per row
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const int idx = tid + 256 * u, r = idx >> 4, c8 = 8 * (idx & 15);
+    const int r = (tid + 256 * u) >> 4;
     const int64_t m = m0 + r;
     if (m >= M) continue;
-    const int tp = (int)(m % T) - pos_shift;
-    f32x4 v0 = *reinterpret_cast<const f32x4*>(sC + r * LDC + c8) + *reinterpret_cast<const f32x4*>(bias + cb + c8);
-    f32x4 v1 = *reinterpret_cast<const f32x4*>(sC + r * LDC + c8 + 4) + *reinterpret_cast<const f32x4*>(bias + cb + c8 + 4);
-    if (tp >= 0) {
-      v0 += *reinterpret_cast<const f32x4*>(pos + (int64_t)tp * ldpos + cb + c8);
-      v1 += *reinterpret_cast<const f32x4*>(pos + (int64_t)tp * ldpos + cb + c8 + 4);
-    }
-    *reinterpret_cast<bf16x8*>(out + m * ldo + cb + c8) = bf16x8{(__bf16)v0.x, (__bf16)v0.y, (__bf16)v0.z, (__bf16)v0.w,
-                                                                 (__bf16)v1.x, (__bf16)v1.y, (__bf16)v1.z, (__bf16)v1.w};
+    const f32x4 v0 = (*reinterpret_cast<const f32x4*>(sC + r * LDC + oc8) + pb[0]) + pp[u][0];
+    const f32x4 v1 = (*reinterpret_cast<const f32x4*>(sC + r * LDC + oc8 + 4) + pb[1]) + pp[u][1];
+    *reinterpret_cast<bf16x8*>(out + m * ldo + cb + oc8) = bf16x8{(__bf16)v0.x, (__bf16)v0.y, (__bf16)v0.z, (__bf16)v0.w,
+                                                                  (__bf16)v1.x, (__bf16)v1.y, (__bf16)v1.z, (__bf16)v1.w};
   }
 }
 

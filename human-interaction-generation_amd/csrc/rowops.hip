@@ -426,8 +426,9 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(const TrBatch b) {
   }
 }
 
+template <typename TO>
 __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int B, int d,
-                                          float* __restrict__ out) {
+                                          TO* __restrict__ out) {
   const int half = d / 2;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * d) return;
@@ -441,7 +442,7 @@ __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int B, 
     const float arg = (float)t[b] * freq;
     v = c < half ? cosf(arg) : sinf(arg);
   }
-  out[idx] = v;
+  out[idx] = (TO)v;
 }
 
 int splits_for(int64_t samples) {
@@ -657,8 +658,16 @@ extern "C" int hig_transpose_batch(int32_t n, const float* const* srcs, float* c
 extern "C" int hig_timestep_embedding(const int64_t* t, int32_t B, int32_t d, float* out,
                                       hig_stream_t s) {
   HIG_REQUIRE(t && out && B > 0 && d > 0, "hig_timestep_embedding: bad arguments");
-  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((B * d + 255) / 256), dim3(256), 0, hig_stream(s),
+  hipLaunchKernelGGL(timestep_embedding_kernel<float>, dim3((B * d + 255) / 256), dim3(256), 0, hig_stream(s),
                      t, B, d, out);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+// the same values rounded to bf16 (the bf16-storage forward feeds them to a bf16 GEMM: no fp32 copy, no cast launch)
+extern "C" int hig_timestep_embedding_bf16(const int64_t* t, int32_t B, int32_t d, void* out16, hig_stream_t s) {
+  HIG_REQUIRE(t && out16 && B > 0 && d > 0, "hig_timestep_embedding_bf16: bad arguments");
+  hipLaunchKernelGGL(timestep_embedding_kernel<__bf16>, dim3((B * d + 255) / 256), dim3(256), 0, hig_stream(s),
+                     t, B, d, static_cast<__bf16*>(out16));
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

@@ -574,6 +574,8 @@ int hig_colsum(const float* x, int64_t ldx, int64_t rows, int32_t n, float* out,
 
 /* timestep_embedding (transformer.py:15-32): out[b] = [cos(t*f), sin(t*f)], fp32. */
 int hig_timestep_embedding(const int64_t* t, int32_t B, int32_t d, float* out, hig_stream_t s);
+/* the same values rounded to bf16 (input of the bf16-storage forward's time_embed.0 GEMM) */
+int hig_timestep_embedding_bf16(const int64_t* t, int32_t B, int32_t d, void* out16, hig_stream_t s);
 
 /* ------------------------------------------------------------------------------------------
  * DDPM arithmetic (gaussian_diffusion.py).  `tab` is a device table of 6 x nsteps fp32 rows:

@@ -460,6 +460,10 @@ def test_timestep_embedding_matches_reference_formula():
         _lib.check(_lib.lib().hig_timestep_embedding(P(t.to(DEV)), len(t), d, P(out), _lib.stream_ptr()))
         ref = R.timestep_embedding(t, d)
         assert (out.cpu() - ref).abs().max() < 2e-4  # |arg| <= 999: one fp32 ulp of arg is 6e-5
+        # the bf16 entry of the bf16-storage forward: the same values, rounded once
+        out16 = torch.zeros(len(t), d, device=DEV, dtype=torch.bfloat16)
+        _lib.check(_lib.lib().hig_timestep_embedding_bf16(P(t.to(DEV)), len(t), d, P(out16), _lib.stream_ptr()))
+        assert torch.equal(out16, out.to(torch.bfloat16))
 
 
 def test_ddpm_elementwise_against_golden(gold):
