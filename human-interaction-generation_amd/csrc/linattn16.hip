@@ -428,6 +428,7 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
     }
 #pragma unroll
     for (int ks = 0; ks < CHK / 16; ++ks) {
+      if (r0 + 16 * ks >= len) break;           // (rows beyond the length have P = 0: the short tail chunk of T = 196 is one k-step)
       s16x8 vf[NBW], pf[NBW];
 #pragma unroll
       for (int part = 0; part < 2; ++part) {

@@ -18,3 +18,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_bf16 -- python3
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_train -- python3 $R/tools/train_step_time.py > $O/train_under_rocprof.log 2>&1
 bash $R/tools/pmc_gemm16.sh $TAG/pmc16_ffn1 ffn1 64 > $O/pmc16.log 2>&1
 bash $R/tools/pmc_hbm.sh $TAG/pmc_hbm > $O/pmc_hbm.log 2>&1
+# round 3: s_memtime stamps of the weight-stationary bf16 GEMM (FFN linear1 at M = 12 544, cross-attention query at M = 6 272),
+# of the fused apply + stylization kernel, and the per-shape timings of the bf16 GEMM
+python3 $R/tools/gemm_ws16_stamps.py ffn1 64 2>&1 | grep -v amdgpu.ids | tail -13 > $O/ws16_stamps.txt
+python3 $R/tools/gemm_ws16_stamps.py ca_q 32 2>&1 | grep -v amdgpu.ids | tail -10 >> $O/ws16_stamps.txt
+python3 $R/tools/apply16_stamps.py 32 2>&1 | grep -v amdgpu.ids | tail -10 > $O/apply16_stamps.txt
+python3 $R/tools/gemm16_bench.py 64 2>&1 | grep -v amdgpu.ids | tail -8 > $O/gemm16_shapes.txt
+python3 $R/tools/gemm16_bench.py 32 2>&1 | grep -v amdgpu.ids | tail -8 >> $O/gemm16_shapes.txt
+python3 $R/tools/train_step_time.py 2>&1 | grep -v amdgpu.ids | tail -3 > $O/train_step_eager_vs_captured.txt
+HIG_BWD_OVERLAP=0 python3 $R/tools/train_step_time.py 2>&1 | grep -v amdgpu.ids | tail -2 | sed 's/^/HIG_BWD_OVERLAP=0 /' >> $O/train_step_eager_vs_captured.txt
+

@@ -25,7 +25,9 @@ ks = one("trace/**/*kernel_stats.csv")
 shutil.copy(ks, os.path.join(dst, tag + "_kernel_stats.csv"))
 # round 2: kernel stats of the bf16-storage sampling step and of the fp32 training step, counter summaries of the bf16 FFN
 # GEMM and of the HBM-bound kernels (written by tools/collect_profiles.sh next to the headline's trace)
-for pattern, name in (("trace_bf16/**/*kernel_stats.csv", "_kernel_stats_bf16_sampling_step.csv"),
+for pattern, name in (("ws16_stamps.txt", "_ws16_stamps.txt"), ("apply16_stamps.txt", "_apply16_stamps.txt"),
+                      ("gemm16_shapes.txt", "_gemm16_shapes.txt"), ("train_step_eager_vs_captured.txt", "_train_step_eager_vs_captured.txt"),
+                      ("trace_bf16/**/*kernel_stats.csv", "_kernel_stats_bf16_sampling_step.csv"),
                       ("trace_train/**/*kernel_stats.csv", "_kernel_stats_train_step.csv"),
                       ("pmc_hbm/summary.json", "_hbm_kernels_pmc.json"), ("pmc16_ffn1/summary.json", "_pmc16_ffn1.json")):
     f = one(pattern)
