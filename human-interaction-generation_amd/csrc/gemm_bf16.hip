@@ -477,9 +477,106 @@ __global__ __launch_bounds__(256) void gemm_fewrow16_kernel(const hig_gemm16_des
   }
 }
 
+// The same decomposition with the operands staged through LDS (reduce range a multiple of 256): fragment-shaped global
+// loads (32 rows x 32 bytes per instruction) run at a fraction of the CU's fetch rate -- time_embed.2 at 32 rows took 15 us
+// with them for 256 KB per workgroup.  Here every wave DMA-s ITS quarter of the reduce range in 64-element chunks (whole
+// 128-byte row pieces, 8 rows per instruction, XOR-swizzled on the source address) into a wave-private ring of three (two at 64 rows) chunks:
+// no workgroup barrier until the final reduction, counted vmcnt waits only.
+template <int NRB, int EPI>
+__global__ __launch_bounds__(256) void gemm_fewrow16_lds_kernel(const hig_gemm16_desc g) {
+  constexpr int PLD = 33;
+  constexpr int NCH = NRB == 1 ? 3 : 2;                    // ring depth in chunks of 64 reduce elements (LDS: 96 KB either way)
+  constexpr int CHB = 32 * 128;                            // bytes of one 32-row x 64-element operand block
+  constexpr int WCH = (1 + NRB) * CHB;                     // bytes per chunk and wave: W block, then NRB X blocks
+  constexpr int DPC = (1 + NRB) * 4;                       // DMA instructions per chunk and wave
+  __shared__ __attribute__((aligned(1024))) char sOp[4 * NCH * WCH];
+  __shared__ float sP[4 * NRB * 32 * PLD];
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j0 = blockIdx.x * 32;
+  const __bf16* __restrict__ X = static_cast<const __bf16*>(g.X);
+  const __bf16* __restrict__ Y = static_cast<const __bf16*>(g.Y);
+  const int KW = g.R / 4, nch = KW / 64, k0 = wave * KW;   // this wave's share of the reduce range
+  char* const my = sOp + wave * NCH * WCH;
+  // per-lane DMA sources: instruction q of an operand block covers rows 8 q .. 8 q + 7, lane = (row % 8, 16-byte position)
+  const int drow = lane >> 3, dpos = lane & 7;
+  auto dma_chunk = [&](int c, int buf) {
+    const int kc = k0 + 64 * c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = 8 * q + drow;
+      const __bf16* src = Y + (int64_t)(j0 + r) * g.ldy + kc + 8 * (dpos ^ (r & 7));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(my + buf * WCH + q * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 8 * q + drow;
+        const __bf16* src = X + (int64_t)min(32 * rb + r, g.I - 1) * g.ldx + kc + 8 * (dpos ^ (r & 7));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(my + buf * WCH + (1 + rb) * CHB + q * 1024), 16, 0, 0);
+      }
+  };
+  f32x16 acc[NRB];
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
+  for (int c = 0; c < NCH - 1 && c < nch; ++c) dma_chunk(c, c);
+  for (int c = 0; c < nch; ++c) {
+    if (c + NCH - 1 < nch) dma_chunk(c + NCH - 1, (c + NCH - 1) % NCH);   // (its buffer held chunk c - 1: this wave is done with it)
+    // chunk c has landed once only the younger chunks' requests of THIS wave are outstanding
+    const int younger = min(NCH - 1, nch - 1 - c);
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPC) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPC) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* cb = my + (c % NCH) * WCH;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int off = lr * 128 + 16 * ((2 * ks + lh) ^ (lr & 7));
+      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(cb + off);
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(cb + (1 + rb) * CHB + off);
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[rb], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the fragments are in registers before the buffer is requested again
+  }
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sP[((wave * NRB + rb) * 32 + lr) * PLD + 8 * q + 4 * lh + e] = acc[rb][4 * q + e];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NRB * 4; ++u) {
+    const int idx = tid + 256 * u, r = idx >> 5, c = idx & 31;
+    if (r >= g.I) continue;
+    const int rb = r >> 5, rr = r & 31;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += sP[((w * NRB + rb) * 32 + rr) * PLD + c];
+    const int j = j0 + c;
+    if (EPI != HIG_EPI_NONE) v += g.bias[j];
+    if (EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU)
+      v += g.res_f32 ? static_cast<const float*>(g.res)[(int64_t)r * g.ldr + j] : (float)static_cast<const __bf16*>(g.res)[(int64_t)r * g.ldr + j];
+    v = epi_act<EPI>(v);
+    if (g.c_f32) static_cast<float*>(g.C)[(int64_t)r * g.ldc + j] = v;
+    else static_cast<__bf16*>(g.C)[(int64_t)r * g.ldc + j] = (__bf16)v;
+  }
+}
+
 template <int EPI>
 int launch_fewrow16(const hig_gemm16_desc& g, hipStream_t st) {
-  if (g.I <= 32) hipLaunchKernelGGL((gemm_fewrow16_kernel<1, EPI>), dim3(g.J / 32), dim3(256), 0, st, g);
+  static const int lds_on = getenv("HIG_BF16_FEWROW_LDS") ? atoi(getenv("HIG_BF16_FEWROW_LDS")) : 1;   // tuning knob
+  if (lds_on && g.R % 256 == 0) {               // operands through wave-private LDS rings
+    if (g.I <= 32) hipLaunchKernelGGL((gemm_fewrow16_lds_kernel<1, EPI>), dim3(g.J / 32), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_fewrow16_lds_kernel<2, EPI>), dim3(g.J / 32), dim3(256), 0, st, g);
+  } else if (g.I <= 32) hipLaunchKernelGGL((gemm_fewrow16_kernel<1, EPI>), dim3(g.J / 32), dim3(256), 0, st, g);
   else hipLaunchKernelGGL((gemm_fewrow16_kernel<2, EPI>), dim3(g.J / 32), dim3(256), 0, st, g);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
