@@ -68,7 +68,7 @@ __device__ __forceinline__ void ws_wait_vmcnt_visible() {
 // OCC: workgroups per CU the kernel is laid out for (LDS budget 160 KB / OCC, registers 512 / (OCC waves per SIMD)).
 template <int KW, int KSPLIT, int NWJ, int NCB, int EPI, int DBG = 0, int OCC = 1, int XT = 0>
 __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) void gemm_ws16_kernel(const WsArgs a) {
-  static_assert(XT == 0 || (KSPLIT == 1 && NCB == 1 && OCC == 1 && KW == 512), "LayerNorm fold: K = 512 single-split variants");
+  static_assert(XT == 0 || (KSPLIT == 1 && NCB == 1 && KW == 512 && (OCC == 1 || XT == 1)), "LayerNorm fold: K = 512 single-split variants");
   constexpr int LDS_MAX = 160 * 1024 / OCC;
   static_assert(OCC == 1 || NWJ * KSPLIT == 4, "two workgroups per CU: 4-wave variants only");
   constexpr int NW = NWJ * KSPLIT, NT = 64 * NW;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   // residual tiles come in by DMA too: two buffers, staged-tile sized -- except in the K-split variant, whose 160 KB are
   // all taken: there the residual of tile t lands IN the staging buffer tile t will be staged in (each lane reads the 8
   // bytes it is about to overwrite), requested once the stores of tile t - 2 have read that buffer (one more barrier)
-  constexpr bool RES_INPLACE = HAS_RES && KSPLIT > 1;
+  constexpr bool RES_INPLACE = HAS_RES && (KSPLIT > 1 || OCC > 1);   // (two workgroups per CU: 80 KB each, none to spare either)
   constexpr int RBUF = HAS_RES && !RES_INPLACE ? SBUF : 0;
   constexpr int NXB = (3 * XBUF + 2 * SBUF + 2 * RBUF + PBUF <= LDS_MAX) ? 3 : 2;
   static_assert(2 * XBUF + 2 * SBUF + 2 * RBUF + PBUF <= LDS_MAX, "LDS budget");
@@ -106,11 +106,10 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   // bias: in LDS where there is room (sixteen registers less per lane), else in registers for the workgroup's life
   constexpr bool BIAS_LDS = NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + BN * 4 <= LDS_MAX;
   static_assert(XT != 2 || BIAS_LDS, "the LayerNorm-fold consumer keeps bias' and the column sums in LDS");
-  constexpr int XLDS = XT == 1 ? 2 * NW * BM * 2 * 4 : XT == 2 ? BN * 4 + 2 * 1024 : 0;
+  constexpr int XLDS = XT == 2 ? BN * 4 + 2 * 1024 : 0;   // (XT = 1 needs none: the statistics are taken in the store pass)
   __shared__ __attribute__((aligned(1024))) char smem[NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + (BIAS_LDS ? BN * 4 : 0) + XLDS];
   [[maybe_unused]] float* const sB = reinterpret_cast<float*>(smem + NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF);
   [[maybe_unused]] char* const sXT = smem + NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + (BIAS_LDS ? BN * 4 : 0);
-  [[maybe_unused]] float* const sStat = reinterpret_cast<float*>(sXT);          // XT = 1: [2][NW][32 rows][2]
   [[maybe_unused]] char* const sLn = sXT;                                        // XT = 2: [2][32 rows][4 panels][2] floats
   [[maybe_unused]] float* const sC = reinterpret_cast<float*>(sXT + 2 * 1024);   // XT = 2: column sums of W' of this panel
   char* const sX = smem;
@@ -276,8 +275,6 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   // _f32 finish two elements per slot (gemm16_epi.h).
   f32x2 ev[2];
   u32x2 rq = u32x2{0u, 0u};                    // residual of the quad in work: four bf16, raw bits
-  [[maybe_unused]] float st_s1 = 0.f, st_s2 = 0.f;          // XT = 1: this lane's share of its row's (sum, sum of squares)
-  [[maybe_unused]] float* statw = nullptr;                  //         where the wave parks them (set per tile)
   [[maybe_unused]] float ln_rstd = 0.f, ln_mr = 0.f;        // XT = 2: rstd and -mean * rstd of this lane's row
   [[maybe_unused]] f32x4 ln_b4 = f32x4{0.f, 0.f, 0.f, 0.f}, ln_c4 = f32x4{0.f, 0.f, 0.f, 0.f};
   [[maybe_unused]] const char* lnbuf = nullptr;             //         the tile's statistics in LDS (set per tile)
@@ -312,24 +309,6 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
       const int pos16 = (4 * (NCB * wj + cb) + qf0 + u) ^ (lr & 15);
       const bf16x4 o4 = bf16x4{(__bf16)ev[0][0], (__bf16)ev[0][1], (__bf16)ev[1][0], (__bf16)ev[1][1]};
       *reinterpret_cast<bf16x4*>(stg + lr * SROWB + 16 * pos16 + 8 * lh) = o4;
-      if constexpr (XT == 1) {                   // row sums of the ROUNDED outputs (what the consumer will read):
-        // v_dot2c_f32_bf16 takes the packed pairs as they are -- x . (1, 1) and x . x, fp32 accumulate: 4 instructions per
-        // quad instead of 12 (unpack, add, fma per element)
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const bf16x2_t pr = {o4[2 * k], o4[2 * k + 1]};
-          st_s1 = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, st_s1, false);
-          st_s2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, st_s2, false);
-        }
-        if (j == 4 * NQF * NCB - 2) {
-          st_s1 += __shfl_xor(st_s1, 32, 64);
-          st_s2 += __shfl_xor(st_s2, 32, 64);
-          if (lh == 0) *reinterpret_cast<float2*>(statw + lr * 2) = make_float2(st_s1, st_s2);
-          st_s1 = st_s2 = 0.f;
-        }
-      }
     }
   };
   // Residual tile t -> LDS by DMA, in the layout of the staged output tile (row r, 16-byte chunk c at position
@@ -368,16 +347,27 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
       // whose lanes are all masked would skip the instruction and leave an OLDER request, e.g. a DMA, uncounted).
       const int i = min(i0 + r, a.I - 1);
       *reinterpret_cast<bf16x8*>(a.C + (int64_t)i * a.ldc + j0 + 8 * p) = v;
-    }
-    if constexpr (XT == 1) {
-      if (wave == 0) {                           // (one more store instruction for wave 0, ahead of the k-loop's DMAs like the others)
-        const int r = lane & 31;
-        const float* sp = sStat + (size_t)(t & 1) * NW * BM * 2 + r * 2;
+      if constexpr (XT == 1) {
+        // LayerNorm fold, producer side: (sum, sum of squares) of this row's 128 ROUNDED outputs (what the consumer will
+        // read).  The 16 lanes that hold a row's pieces are consecutive: v_dot2c_f32_bf16 on the packed pairs (x . (1, 1)
+        // and x . x, fp32 accumulate), four shuffle steps, lane 0 of the group writes.  Taken here, in the store pass,
+        // and not in the epilogue between the MFMAs (which is bound by instruction issue); no LDS staging.
+        static_assert(XT != 1 || PPR == 16, "row statistics: 128-column panels");
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { s1 += sp[w * BM * 2]; s2 += sp[w * BM * 2 + 1]; }
-        const int i = min(i0 + r, a.I - 1);
-        if (lane < 32) *reinterpret_cast<float2*>(a.stats_out + ((int64_t)i * a.np + panel) * 2) = make_float2(s1, s2);
+        for (int k = 0; k < 4; ++k) {
+          const bf16x2_t pr = {v[2 * k], v[2 * k + 1]};
+          s1 = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, s1, false);
+          s2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, s2, false);
+        }
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          s1 += __shfl_xor(s1, off, 64);
+          s2 += __shfl_xor(s2, off, 64);
+        }
+        if (p == 0) *reinterpret_cast<float2*>(a.stats_out + ((int64_t)i * a.np + panel) * 2) = make_float2(s1, s2);
       }
     }
   };
@@ -404,7 +394,6 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
       }
       lnbuf = sLn + ((t + 1) & 1) * 1024;        // statistics of tile t - 1, whose epilogue runs in this iteration
     }
-    if constexpr (XT == 1) statw = sStat + (size_t)((t + 1) & 1) * NW * BM * 2 + wave * BM * 2;
     if (t >= 2) store_tile(t - 2, sS + (t & 1) * SBUF);
     if constexpr (RES_INPLACE) {                 // that staging buffer is free now: the residual of tile t goes there
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -509,7 +498,6 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   asm volatile("" ::: "memory");
   stamp(12);
   if constexpr (XT == 2) lnbuf = sLn + ((nt + 1) & 1) * 1024;
-  if constexpr (XT == 1) statw = sStat + (size_t)((nt + 1) & 1) * NW * BM * 2 + wave * BM * 2;
   if (nt >= 2) store_tile(nt - 2, sS + (nt & 1) * SBUF);
   {
     char* stg = sS + ((nt + 1) & 1) * SBUF;
@@ -567,8 +555,15 @@ int launch_ws_sized(const hig_gemm16_desc& g, int nwj, hipStream_t st) {
   // residual tile only)
   constexpr bool has_res = EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU;
   if constexpr (!has_res) {
-    if (nwj == 44 && g.R == 512) return launch_ws<512, 1, 4, 1, EPI, 2>(g, 64, st);
+    if (nwj == 44 && g.R == 512 && !g.row_stats_in) return launch_ws<512, 1, 4, 1, EPI, 2>(g, 64, st);
     if (nwj == 44 && g.R == 256) return launch_ws<256, 1, 4, 1, EPI, 2>(g, 64, st);
+  } else {
+    if (nwj == 44 && g.R == 512) {               // (residual tile lands in the staging buffer: 80 KB of LDS per workgroup)
+      if constexpr (EPI == HIG_EPI_BIAS_RES) {
+        if (g.row_stats_out) return launch_ws<512, 1, 4, 1, EPI, 2, 1>(g, 64, st);
+      }
+      return launch_ws<512, 1, 4, 1, EPI, 2>(g, 64, st);
+    }
   }
   if (nwj == 44) nwj = 4;
   // LayerNorm folded into the next GEMM (K = 512): the producer writes row statistics, the consumer applies them
@@ -584,6 +579,8 @@ int launch_ws_sized(const hig_gemm16_desc& g, int nwj, hipStream_t st) {
 }
 
 }  // namespace
+
+static inline bool has_res_epi(int epi) { return epi == HIG_EPI_BIAS_RES || epi == HIG_EPI_BIAS_RES_SILU; }
 
 // Returns HIG_OK when the launch was made, 1 when this kernel does not serve the shape (the caller falls back to the
 // tiled kernel), a negative HIG_E* code on error.
@@ -619,7 +616,12 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
   // each from one wave); two 4-wave workgroups per CU put a second, independent wave on every SIMD: FFN linear1 at
   // M = 12 544 28.5 -> 25.2 us, at M = 6 272 17.2 -> 15.1 us
   if (g.epi == HIG_EPI_BIAS_GELU && g.R != 1024) nwj = 44;
-  if (g.row_stats_out) nwj = 4;                 // (the statistics are per 128-column panel)
+  // residual epilogues at K = 512: two workgroups per CU from 8 192 rows up (same-call A/B, forward: B = 64 1.630 -> 1.613 ms,
+  // B = 512 8.72 -> 8.55 ms; B = 32 1.056 -> 1.066: the 3-4 tiles of a workgroup there are too few to share a CU)
+  static const int res44 = getenv("HIG_BF16_WS_RES44") ? atoi(getenv("HIG_BF16_WS_RES44")) : 8192;   // tuning knob: rows from which ... (0 = never)
+  if (has_res_epi(g.epi) && g.R == 512 && res44 > 0 && g.I >= res44) nwj = 44;
+  else if (g.row_stats_out) nwj = 4;            // (the statistics are per 128-column panel)
+  if (g.row_stats_out) { if (forced_nwj == 44) nwj = 44; }
   else if (forced_nwj == 4 || (forced_nwj == 8 && g.R != 1024) || (forced_nwj == 2 && g.R == 512) || (forced_nwj == 44 && g.R != 1024)) nwj = forced_nwj;
   const int bn = (nwj == 4 || nwj == 44) ? 128 : 256;
   if (g.J % bn != 0) {
