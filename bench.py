@@ -338,8 +338,18 @@ def oracle_slice_error(c, model, inp, gpu_out, n=2):
     from oracle import denoiser_ref as R
     p = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.startswith("clip.")}
     ci = {k: v[:n].cpu() for k, v in inp.items() if k in ("x", "t", "length", "xf_proj", "xf_out")}
-    with torch.no_grad():
-        ref = R.denoiser_forward(p, ci["x"], ci["t"], ci["length"], ci["xf_proj"], ci["xf_out"], c["H"], c["L"])
+    # (host hygiene: with the default pool -- one thread per core of a 128-256-thread host -- the OpenMP workers keep spinning
+    # for a while after the oracle returns, and on some boxes the launching thread of the NEXT timed GPU region then loses its
+    # core: an eager forward of ~150 launches measured 10 ms instead of 3.3.  A small pool and a pause keep the checker out
+    # of the measurement.)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(nthr, 16))
+    try:
+        with torch.no_grad():
+            ref = R.denoiser_forward(p, ci["x"], ci["t"], ci["length"], ci["xf_proj"], ci["xf_out"], c["H"], c["L"])
+    finally:
+        torch.set_num_threads(nthr)
+    time.sleep(0.3)
     return ((gpu_out[:n].double().cpu() - ref.double()).norm() / ref.double().norm()).item()
 
 
