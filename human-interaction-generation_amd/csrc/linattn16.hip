@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __re
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-template <int HD>
+template <int HD, int NB>
 __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restrict__ K, const __bf16* __restrict__ V, int64_t ld,
                                                          int rows, int H, const int64_t* __restrict__ length,
                                                          float* __restrict__ A, float* __restrict__ kstat,
@@ -295,9 +295,10 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
   static_assert(HD == 64 || HD == 128, "head dim 64 or 128");
   constexpr int CHK = 64;                       // rows per chunk
   constexpr int ROWB = HD * 2;                  // bytes per LDS row (128 / 256)
-  constexpr int NB = 3;                         // K / V chunks in LDS: the DMA runs two chunks ahead of the arithmetic (head dim 64: 65 KB of LDS, two
-                                                // workgroups per CU; four buffers = 83 KB = one, and the B x H = 512 workgroups of a B = 64 launch then
-                                                // ran as two rounds: B = 64 forward -3 %.  Head dim 128: 129 KB, one workgroup per CU)
+  // NB: K / V chunks in LDS, the DMA runs NB - 1 chunks ahead of the arithmetic.  Head dim 64: three buffers = 65 KB of LDS, two
+  // workgroups per CU (four = 83 KB = one, and the B x H = 512 workgroups of a B = 64 launch then ran as two rounds: B = 64
+  // forward -3 %); two buffers = 49 KB, three per CU, for launches of many rounds.  Head dim 128: 129 KB, one per CU.
+  static_assert(NB == 2 || NB == 3, "ring of two or three chunks");
   constexpr int LPR = HD / 4;                   // lanes per row when a lane holds 4 channels (16 / 32)
   constexpr int RPP = 64 / LPR;                 // rows a wave covers per pass (4 / 2)
   constexpr int NI = 16 / RPP;                  // passes: a wave holds rows 16 wave .. 16 wave + 15 of the chunk (4 / 8)
@@ -550,11 +551,16 @@ extern "C" int hig_linattn_ctx_mm16(const void* K, const void* V, int64_t ld, in
   HIG_REQUIRE(ld % 8 == 0 && (reinterpret_cast<uintptr_t>(K) & 15) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0 &&
                   (reinterpret_cast<uintptr_t>(A) & 15) == 0,
               "hig_linattn_ctx_mm16: K / V / A must be 16-byte aligned with ld %% 8 == 0");
-  if (hd == 64)
-    hipLaunchKernelGGL(ctx16_mfma_kernel<64>, dim3(B * H), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(K),
+  // (same-call A/B, forward: B = 64 1.546 -> 1.535 ms, B = 128 2.451 -> 2.420, B = 512 8.45 -> 8.31 with two buffers)
+  static const int nb2_from = getenv("HIG_CTX16_NB2") ? atoi(getenv("HIG_CTX16_NB2")) : 512;   // tuning knob: workgroups from which the ring has two buffers (0 = never)
+  if (hd == 64 && nb2_from > 0 && B * H >= nb2_from)
+    hipLaunchKernelGGL((ctx16_mfma_kernel<64, 2>), dim3(B * H), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(K),
+                       static_cast<const __bf16*>(V), ld, rows, H, length, A, kstat, static_cast<__bf16*>(At16));
+  else if (hd == 64)
+    hipLaunchKernelGGL((ctx16_mfma_kernel<64, 3>), dim3(B * H), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(K),
                        static_cast<const __bf16*>(V), ld, rows, H, length, A, kstat, static_cast<__bf16*>(At16));
   else
-    hipLaunchKernelGGL(ctx16_mfma_kernel<128>, dim3(B * H), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(K),
+    hipLaunchKernelGGL((ctx16_mfma_kernel<128, 3>), dim3(B * H), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(K),
                        static_cast<const __bf16*>(V), ld, rows, H, length, A, kstat, static_cast<__bf16*>(At16));
   HIG_CHECK_LAUNCH();
   return HIG_OK;
