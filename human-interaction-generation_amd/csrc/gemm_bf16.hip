@@ -647,38 +647,74 @@ __global__ __launch_bounds__(256) void joint_embed16_kernel(const float* __restr
   // block of every row tile runs at once instead of as a serial chain of load -> MFMA -> store steps per workgroup.
   // Weight block first (independent 16-byte loads, the loop unrolled so they are all in flight together):
   const int c16 = Fp / 8;                                  // 16-byte chunks per padded weight row
-  // (12 at a time: the 10 loads per thread of F = 150 are then ONE round trip to L2 / HBM instead of three)
+  // (12 at a time: the 10 loads per thread of F = 150 are then ONE round trip to L2 / HBM instead of three.  Row / chunk of
+  // a piece are stepped, not divided out per piece: Fp and F are run-time values, and an emulated integer division is ~40
+  // vector instructions -- the three per piece this kernel used to do were 1 200 of its 1 330 vector instructions per wave,
+  // rocprofv3 SQ_INSTS_VALU, and made it issue-bound: 140 us at M = 100 352 for 163 MB.)
+  {
+    int rr = tid / c16, ch = tid % c16;
+    const int drr = 256 / c16, dch = 256 % c16;
 #pragma unroll 12
-  for (int idx = tid; idx < 128 * c16; idx += 256) {
-    const int rr = idx / c16, ch = idx % c16;
-    *reinterpret_cast<uint4*>(sW + rr * LDX + 8 * ch) = *reinterpret_cast<const uint4*>(Wp + (int64_t)(cb + rr) * Fp + 8 * ch);
+    for (int idx = tid; idx < 128 * c16; idx += 256) {
+      *reinterpret_cast<uint4*>(sW + rr * LDX + 8 * ch) = *reinterpret_cast<const uint4*>(Wp + (int64_t)(cb + rr) * Fp + 8 * ch);
+      rr += drr;
+      ch += dch;
+      if (ch >= c16) { ch -= c16; ++rr; }
+    }
   }
   // x tile: the 64 rows are ONE contiguous run of 64 F floats (the pose rows are dense), read as 16-byte vectors whatever
   // F is, rounded to bf16 and scattered to (row, column) in LDS; columns F .. Fp of every row are zeroed (rows beyond M
   // only produce outputs that are never stored)
   {
     const int padc = Fp - F;
-    for (int idx = tid; idx < 64 * padc; idx += 256) sX[(idx / padc) * LDX + F + idx % padc] = (__bf16)0.f;
+    for (int c = F + (tid & 3); c < Fp; c += 4) sX[(tid >> 2) * LDX + c] = (__bf16)0.f;     // (row tid / 4, every fourth pad column)
+    (void)padc;
     const float* xt = x + m0 * F;
     const int64_t rows_here = M - m0 < 64 ? M - m0 : 64;
     const int n_el = (int)(rows_here * F);
     const bool vec = (reinterpret_cast<uintptr_t>(xt) & 15) == 0;
+    int r0 = (4 * tid) / F, c0 = (4 * tid) % F;             // (row, column) of this thread's first element; stepped by 1024 elements
+    const int dr = 1024 / F, dc = 1024 % F;
+    if (vec && (F & 1) == 0) {
+      // usual case (aligned x, even F): whole 16-byte loads, no per-element guards -- with F even every column index this
+      // thread meets at the start of a pair is even, so a pair never straddles a row end and goes out as one 4-byte LDS write
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      const int n4 = n_el >> 2;                                // (n_el = rows x F is a multiple of 2; a trailing pair is done below)
 #pragma unroll 12
-    for (int e0 = 4 * tid; e0 < n_el; e0 += 1024) {
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (vec && e0 + 3 < n_el) {
-        const float4 q = *reinterpret_cast<const float4*>(xt + e0);
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (e0 + k < n_el) v[k] = xt[e0 + k];
+      for (int i = tid; i < n4; i += 256) {
+        const float4 q = *reinterpret_cast<const float4*>(xt + 4 * i);
+        *reinterpret_cast<bf16x2_t*>(sX + r0 * LDX + c0) = bf16x2_t{(__bf16)q.x, (__bf16)q.y};
+        int r1 = r0, c1 = c0 + 2;
+        if (c1 >= F) { c1 = 0; ++r1; }
+        *reinterpret_cast<bf16x2_t*>(sX + r1 * LDX + c1) = bf16x2_t{(__bf16)q.z, (__bf16)q.w};
+        r0 += dr;
+        c0 += dc;
+        if (c0 >= F) { c0 -= F; ++r0; }
       }
-      int r = e0 / F, c = e0 - r * F;
+      if ((n_el & 3) && tid == 0) {                            // the last pair of an n_el = 4 k + 2 tile
+        const int e = 4 * n4, r = e / F, c = e % F;
+        *reinterpret_cast<bf16x2_t*>(sX + r * LDX + c) = bf16x2_t{(__bf16)xt[e], (__bf16)xt[e + 1]};
+      }
+    } else {
+      for (int e0 = 4 * tid; e0 < n_el; e0 += 1024) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec && e0 + 3 < n_el) {
+          const float4 q = *reinterpret_cast<const float4*>(xt + e0);
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (e0 + k < n_el) sX[r * LDX + c] = (__bf16)v[k];
-        if (++c == F) { c = 0; ++r; }
+          for (int k = 0; k < 4; ++k)
+            if (e0 + k < n_el) v[k] = xt[e0 + k];
+        }
+        int r = r0, c = c0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (e0 + k < n_el) sX[r * LDX + c] = (__bf16)v[k];
+          if (++c == F) { c = 0; ++r; }
+        }
+        r0 += dr;
+        c0 += dc;
+        if (c0 >= F) { c0 -= F; ++r0; }
       }
     }
   }
@@ -688,10 +724,13 @@ __global__ __launch_bounds__(256) void joint_embed16_kernel(const float* __restr
   f32x4 pb[2], pp[4][2];
   pb[0] = *reinterpret_cast<const f32x4*>(bias + cb + oc8);
   pb[1] = *reinterpret_cast<const f32x4*>(bias + cb + oc8 + 4);
+  int tmod = (int)(((unsigned)m0 + (unsigned)(tid >> 4)) % (unsigned)T);   // frame index of piece 0's row; pieces are 16 rows apart
+  const int tstep = 16 % T;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const int64_t m = m0 + ((tid + 256 * u) >> 4);
-    const int tp = (int)(min(m, M - 1) % T) - pos_shift;
+    const int tp = tmod - pos_shift;
+    tmod += tstep;
+    if (tmod >= T) tmod -= T;
     const float* pr = pos + (int64_t)max(tp, 0) * ldpos + cb + oc8;
     pp[u][0] = *reinterpret_cast<const f32x4*>(pr);
     pp[u][1] = *reinterpret_cast<const f32x4*>(pr + 4);
@@ -783,7 +822,7 @@ extern "C" int64_t hig_joint_embed_bf16_scratch_bytes(int32_t F, int32_t d) {
 extern "C" int hig_joint_embed_bf16_w(const float* x, int64_t M, int32_t F, const void* w_padded, const float* bias, const float* pos,
                                       int64_t ldpos, int32_t T, int32_t pos_shift, void* out, int64_t ldo, int32_t d,
                                       hig_stream_t stream) {
-  HIG_REQUIRE(x && w_padded && bias && pos && out && M >= 0 && F > 0 && d > 0 && T > 0, "hig_joint_embed_bf16: bad arguments");
+  HIG_REQUIRE(x && w_padded && bias && pos && out && M >= 0 && M < (1ll << 31) && F > 0 && d > 0 && T > 0, "hig_joint_embed_bf16: bad arguments");
   if (M == 0) return HIG_OK;
   if (d % 128 != 0 || F > 512)
     return hig_set_error(HIG_EUNSUPPORTED, "hig_joint_embed_bf16: needs d %% 128 == 0 and F <= 512 (got %d, %d)", d, F);
