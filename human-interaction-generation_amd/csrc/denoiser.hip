@@ -756,8 +756,8 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   static const int joint16 = getenv("HIG_JOINT16") ? atoi(getenv("HIG_JOINT16")) : 1;   // tuning knob
   if (joint16 && d % 128 == 0 && D.F <= 512) {
     // own kernel pair (weight padded / rounded to bf16, x rounded in LDS, bf16 MFMA): 31 -> ~8 us at B = 32
-    if (lnfold && lnfold[9 * D.L])   // (weight padded / rounded once, next to the caller's bf16 shadow)
-      HIG_TRY(hig_joint_embed_bf16_w(x, M, D.F, lnfold[9 * D.L], P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d, D.T,
+    if (lnfold && lnfold[12 * D.L])   // (weight padded / rounded once, next to the caller's bf16 shadow)
+      HIG_TRY(hig_joint_embed_bf16_w(x, M, D.F, lnfold[12 * D.L], P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d, D.T,
                                      D.two ? 1 : 0, ws + w.h, d, d, stream));
     else
       HIG_TRY(hig_joint_embed_bf16(x, M, D.F, P(params, HIG_P_JOINT_W), P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d,
@@ -812,11 +812,11 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   // xn-free projection of LN(h): out = LN(h) W^T + b through the folded operands (k = 0: q/k/v, k = 1: cross-attention query,
   // k = 2: q/k/v of the person <-> person attention)
   auto ln_proj = [&](int l, int k, int norm_w, int norm_b, int lin_w, int lin_b, void* outp, int64_t ncols) -> int {
-    if (have_stats && lnfold[9 * l + 3 * k]) {
-      G16 g(h, d, lnfold[9 * l + 3 * k], d, outp, ncols, M, ncols, d);
-      g.epi(HIG_EPI_BIAS, static_cast<const float*>(lnfold[9 * l + 3 * k + 2]));
+    if (have_stats && lnfold[12 * l + 3 * k]) {
+      G16 g(h, d, lnfold[12 * l + 3 * k], d, outp, ncols, M, ncols, d);
+      g.epi(HIG_EPI_BIAS, static_cast<const float*>(lnfold[12 * l + 3 * k + 2]));
       g.g.row_stats_in = stats;
-      g.g.ln_colsum = static_cast<const float*>(lnfold[9 * l + 3 * k + 1]);
+      g.g.ln_colsum = static_cast<const float*>(lnfold[12 * l + 3 * k + 1]);
       return hig_gemm16_launch(g.g, st);
     }
     HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, norm_w), PL(params, l, norm_b), nullptr, 0, 0, 0, xn, d, stream));
@@ -836,10 +836,25 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   static const int fuse_env = getenv("HIG_FUSE_APPLY") ? atoi(getenv("HIG_FUSE_APPLY")) : 2;   // tuning knob
   const bool fuse_mm16 = fuse_env == 2 && (D.hd == 64 || D.hd == 128) && (D.H == 4 || D.H == 8);
   const bool fuse_apply = (fuse_env == 1 || fuse_mm16) && (D.H == 4 || D.H == 8);
+  // hig_attn_out16 (apply + stylization front + output projection in one launch) while its workgroups -- one per 32 rows of a
+  // sample, one resident per CU -- fit the chip in ONE round: there the launches are bound by the per-launch floor (~4.4 us)
+  // and a fetch-bound projection.  Same-call A/B, forward: B = 32 (224 workgroups) 1.037 -> 0.970 ms; B = 40 (280) 1.221 ->
+  // 1.239, B = 64 1.557 -> 1.570.  HIG_FUSE_OUT=0 switches it off.
+  static const int fuse_out_env = getenv("HIG_FUSE_OUT") ? atoi(getenv("HIG_FUSE_OUT")) : 1;   // tuning knob
+  const bool fuse_out = fuse_out_env && fuse_mm16 && d == 512 && D.hd == 64 && D.H == 8 && !D.two &&
+                        (int64_t)((D.T + 31) / 32) * D.B <= 256;
   auto attend = [&](int l, int slot, const void* q, int64_t ldq, const float* ctx, const void* ctx_t16, int norm_w, int norm_b,
                     int out_w, int out_b) -> int {
     if (fuse_apply) {
       const float* ssl = ss + (int64_t)(D.nsty * l + slot) * 2 * d;
+      const void* wfrag = (fuse_out && slot < 3 && lnfold) ? lnfold[12 * l + 9 + slot] : nullptr;
+      if (wfrag) {   // apply + stylization front + output projection + residual update as ONE launch
+        const bool st_out = fold && want_stats;
+        HIG_TRY(hig_attn_out16(q, ldq, ctx_t16, PL(params, l, norm_w), PL(params, l, norm_b), ssl, ss_ld, d, wfrag, PL(params, l, out_b),
+                               h, d, st_out ? stats : nullptr, D.B, D.T, D.H, D.hd, stream));
+        have_stats = st_out;
+        return HIG_OK;
+      }
       if (fuse_mm16)
         HIG_TRY(hig_linattn_apply_sty_mm16(q, ldq, ctx_t16, PL(params, l, norm_w), PL(params, l, norm_b), ssl, ss_ld, d, a, d,
                                            D.B, D.T, D.H, D.hd, stream));

@@ -51,12 +51,29 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // Context matrices.  At16 is stored fragment-major (hig_at16_offset): a wave reads the operands of ITS heads global ->
 // registers, one coalesced KiB per MFMA operand, while the Q tile is still landing -- no LDS staging (at head dim 128 the
 // eight matrices are 256 KB; at 64 it leaves LDS for a second workgroup per CU).
-template <int HD, int H, int NW>
+// GEMM = true (hig_attn_out16; d = 512, 8 waves): the workgroup does not store the activated tile but goes on with the
+// stylization block's output projection and the residual update for ITS 32 rows -- h[rows] += a W^T + b -- : the tile sits
+// in LDS in exactly the layout the weight-stationary kernel reads its X tiles from, wave w owns output columns 64 w .. + 63,
+// the weight comes in MFMA-operand order (Y_frag layout of hig_weight_frag16) global -> registers, one coalesced KiB per
+// operand, eight k-steps ahead; the residual rows were fetched by DMA at the start and are updated in place in LDS; the new
+// rows leave as whole KiB, with their (sum, sum of squares) per 128-column panel when the next consumer folds its LayerNorm.
+// Why: at M = 6 272 a launch costs ~4.4 us before its first instruction and the projection is bound by the CU's L2 fetch
+// rate either way (a workgroup streams the whole 512 KB weight here, 128 KB + its X tiles there): the pair apply (9.2 us)
+// + GEMM (10.5 us) becomes one launch.  Same products in the same order as the weight-stationary kernel.
+struct OutGemmArgs {
+  const __bf16* Wf;      // (d, d) weight in operand order
+  const float* bias;     // (d)
+  __bf16* h;             // residual stream, updated in place
+  int64_t ldh;
+  float* stats;          // [rows][4][2] or NULL
+};
+
+template <int HD, int H, int NW, bool GEMM = false>
 __global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __restrict__ Q, int64_t ldq,
                                                               const __bf16* __restrict__ At16, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ ss,
                                                               int64_t ss_ld, int shift_off, __bf16* __restrict__ Out, int64_t ldo,
-                                                              int T, unsigned long long* __restrict__ stamps) {
+                                                              int T, unsigned long long* __restrict__ stamps, const OutGemmArgs og) {
   constexpr int D_ = H * HD;                   // model width
   constexpr int ROWB = D_ * 2;                 // bytes of a Q / Out row
   constexpr int BR = 32;                       // rows per workgroup
@@ -69,9 +86,11 @@ __global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __re
   static_assert(HD == 64 || HD == 128, "head dim 64 or 128");
   static_assert(ROWB == 512 || ROWB == 1024 || ROWB == 2048, "Q rows of 512, 1024 or 2048 bytes");
   static_assert(H % NW == 0, "whole heads per wave");
-  __shared__ __attribute__((aligned(1024))) char smem[QBYTES + 4 * D_ * 4 + NW * BR * 2 * 4];
+  static_assert(!GEMM || (D_ == 512 && NW == 8), "fused output projection: d = 512, 8 waves");
+  __shared__ __attribute__((aligned(1024))) char smem[QBYTES + 4 * D_ * 4 + NW * BR * 2 * 4 + (GEMM ? QBYTES : 0)];
   char* const sQ = smem;                                       // [32][ROWB] bf16, 16-byte chunk c of row r at c ^ (r & 15); later the output tile
   float* const sPar = reinterpret_cast<float*>(smem + QBYTES); // gamma | beta | scale | shift, then gamma' | beta'
+  [[maybe_unused]] char* const sH = smem + QBYTES + 4 * D_ * 4 + NW * BR * 2 * 4;   // GEMM: the residual rows, same layout as sQ
   float* const sRed = sPar + 4 * D_;                           // [NW waves][32 rows][2]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -121,6 +140,16 @@ __global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __re
       const float* base = vec == 0 ? gamma : vec == 1 ? beta : vec == 2 ? ssb : ssb + shift_off;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + part * 256 + lane * 4),
                                        (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(sPar) + n * 1024), 16, 0, 0);
+    }
+  }
+  // ---- GEMM: the 32 residual rows h[b T + r0 ..] by DMA (same swizzle), landed together with the Q tile -----------------
+  if constexpr (GEMM) {
+#pragma unroll
+    for (int q = 0; q < QBYTES / 1024 / NW; ++q) {
+      const int n = wave + NW * q;                // row n of the tile (1 KiB rows)
+      const __bf16* src = og.h + ((int64_t)b * T + min(r0 + n, T - 1)) * og.ldh + 8 * (lane ^ (n & 15));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sH + n * 1024), 16, 0, 0);
     }
   }
   // ---- context matrices of this wave's heads, At16[b][h] in fragment-major order: operand (lb, ks) = bytes
@@ -260,15 +289,83 @@ __global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __re
       }
   __syncthreads();
   stamp(5);
-  // ---- whole rows out ----------------------------------------------------------------------------------------------
   constexpr int PPR = ROWB / 16;
+  if constexpr (GEMM) {
+    // ---- h[rows] += a W^T + bias: wave w owns columns 64 w .. 64 w + 63 (two 32-column blocks), 32 k-steps ---------------
+    constexpr int NK = D_ / 16, PF = 8;          // k-steps; weight operands requested PF k-steps ahead
+    f32x16 acc2[2];
 #pragma unroll
-  for (int u = 0; u < BR * PPR / NT; ++u) {
-    const int idx = tid + NT * u;
-    const int r = idx / PPR, p = idx % PPR;
-    if (r0 + r < T)
-      *reinterpret_cast<bf16x8*>(Out + ((int64_t)b * T + r0 + r) * ldo + 8 * p) =
-          *reinterpret_cast<const bf16x8*>(sQ + r * ROWB + 16 * (p ^ (r & 15)));
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(og.bias + 64 * wave + 32 * cb + 8 * q + 4 * lh);
+        acc2[cb][4 * q] = b4.x; acc2[cb][4 * q + 1] = b4.y; acc2[cb][4 * q + 2] = b4.z; acc2[cb][4 * q + 3] = b4.w;
+      }
+    const __bf16* wbase = og.Wf + ((int64_t)(2 * wave) * NK * 64 + lane) * 8;    // block (2 w + cb, ks) at + ((cb NK + ks) 64) 8
+    bf16x8 wring[PF][2];
+#pragma unroll
+    for (int ks = 0; ks < PF; ++ks)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) wring[ks][cb] = *reinterpret_cast<const bf16x8*>(wbase + (int64_t)(cb * NK + ks) * 512);
+    const int tsw = (lr & 15) ^ lh;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sQ + lr * ROWB + 16 * ((2 * ks) ^ tsw));
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[ks % PF][cb], xf, acc2[cb], 0, 0, 0);
+      if (ks + PF < NK) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) wring[ks % PF][cb] = *reinterpret_cast<const bf16x8*>(wbase + (int64_t)(cb * NK + ks + PF) * 512);
+      }
+    }
+    // residual add in fp32, one rounding, IN PLACE in the residual tile (each lane reads the 8 bytes it overwrites)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        char* hp = sH + lr * ROWB + 16 * ((8 * wave + 4 * cb + q) ^ (lr & 15)) + 8 * lh;
+        const u32x2 rq = *reinterpret_cast<const u32x2*>(hp);
+        const float v0 = acc2[cb][4 * q] + bf_lo(rq.x), v1 = acc2[cb][4 * q + 1] + bf_hi(rq.x);
+        const float v2 = acc2[cb][4 * q + 2] + bf_lo(rq.y), v3 = acc2[cb][4 * q + 3] + bf_hi(rq.y);
+        *reinterpret_cast<bf16x4*>(hp) = bf16x4{(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+      }
+    __syncthreads();
+    // whole rows out (+ the row statistics per 128-column panel for a LayerNorm-folding consumer, as gemm_ws16 writes them)
+#pragma unroll
+    for (int u = 0; u < BR * PPR / NT; ++u) {
+      const int idx = tid + NT * u;
+      const int r = idx / PPR, p = idx % PPR;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(sH + r * ROWB + 16 * (p ^ (r & 15)));
+      const int64_t row = (int64_t)b * T + r0 + r;
+      if (r0 + r < T) *reinterpret_cast<bf16x8*>(og.h + row * og.ldh + 8 * p) = v;
+      if (og.stats) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bf16x2_t pr = {v[2 * k], v[2 * k + 1]};
+          s1 = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, s1, false);
+          s2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, s2, false);
+        }
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          s1 += __shfl_xor(s1, off, 64);
+          s2 += __shfl_xor(s2, off, 64);
+        }
+        if ((p & 15) == 0 && r0 + r < T) *reinterpret_cast<float2*>(og.stats + (row * 4 + (p >> 4)) * 2) = make_float2(s1, s2);
+      }
+    }
+  } else {
+    // ---- whole rows out --------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < BR * PPR / NT; ++u) {
+      const int idx = tid + NT * u;
+      const int r = idx / PPR, p = idx % PPR;
+      if (r0 + r < T)
+        *reinterpret_cast<bf16x8*>(Out + ((int64_t)b * T + r0 + r) * ldo + 8 * p) =
+            *reinterpret_cast<const bf16x8*>(sQ + r * ROWB + 16 * (p ^ (r & 15)));
+    }
   }
   stamp(6);
 }
@@ -530,13 +627,64 @@ extern "C" int hig_linattn_apply_sty_mm16(const void* Q, int64_t ldq, const void
 #define HIG_AP16(HD_, H_, NW_)                                                                                                  \
   hipLaunchKernelGGL((apply_sty16_kernel<HD_, H_, NW_>), grid, dim3(64 * NW_), 0, st, static_cast<const __bf16*>(Q), ldq,      \
                      static_cast<const __bf16*>(At16), gamma, beta, ss, ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo,   \
-                     rows, g_ap_stamps)
+                     rows, g_ap_stamps, OutGemmArgs{nullptr, nullptr, nullptr, 0, nullptr})
   if (hd == 64 && H == 8 && nw8 == 8) HIG_AP16(64, 8, 8);
   else if (hd == 64 && H == 8) HIG_AP16(64, 8, 4);
   else if (hd == 64) HIG_AP16(64, 4, 4);
   else if (H == 8) HIG_AP16(128, 8, 8);
   else HIG_AP16(128, 4, 4);
 #undef HIG_AP16
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+namespace {
+// Y_frag[((j / 32) (R / 16) + r / 16) 512 + (j % 32 + 32 ((r % 16) / 8)) 8 + (r % 8)] = Y[j][r]: one thread per 16-byte piece
+__global__ void weight_frag16_kernel(const __bf16* __restrict__ Y, int64_t ldy, int J, int R, __bf16* __restrict__ out) {
+  const int64_t n = (int64_t)J * R / 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const int64_t blk = i >> 6;
+    const int ks = (int)(blk % (R / 16)), jb = (int)(blk / (R / 16));
+    const int j = 32 * jb + (lane & 31), r = 16 * ks + 8 * (lane >> 5);
+    reinterpret_cast<bf16x8*>(out)[i] = *reinterpret_cast<const bf16x8*>(Y + (int64_t)j * ldy + r);
+  }
+}
+}  // namespace
+
+extern "C" int hig_weight_frag16(const void* Y, int64_t ldy, int32_t J, int32_t R, void* Y_frag, hig_stream_t stream) {
+  HIG_REQUIRE(Y && Y_frag && J > 0 && R > 0, "hig_weight_frag16: bad arguments");
+  HIG_REQUIRE(J % 32 == 0 && R % 16 == 0 && ldy % 8 == 0 && ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(Y_frag)) & 15) == 0,
+              "hig_weight_frag16: J %% 32, R %% 16, 16-byte aligned rows");
+  const int64_t n = (int64_t)J * R / 8;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(weight_frag16_kernel, dim3((unsigned)blocks), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(Y), ldy, J, R,
+                     static_cast<__bf16*>(Y_frag));
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+// hig_linattn_apply_sty_mm16 followed by the stylization block's output projection and residual update, as one kernel:
+//     h[rows] += silu( LN( softmax_hd(Q) . A ) * (1 + scale) + shift ) . W^T + bias          (transformer.py:111-118 then :81-86)
+// W_frag: the (d, d) weight in operand order (hig_weight_frag16); h bf16 (B * rows, d), updated in place; stats (nullable):
+// (sum, sum of squares) of the new rows per 128-column panel, [B * rows][4][2] fp32, for a LayerNorm-folding consumer
+// (hig_gemm16_desc.row_stats_in).  d = 512 with 8 heads of 64.
+extern "C" int hig_attn_out16(const void* Q, int64_t ldq, const void* At16, const float* gamma, const float* beta, const float* ss,
+                              int64_t ss_ld, int32_t ss_shift_off, const void* W_frag, const float* bias, void* h, int64_t ldh,
+                              float* stats, int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream) {
+  HIG_REQUIRE(Q && At16 && gamma && beta && ss && W_frag && bias && h && B > 0 && rows > 0, "hig_attn_out16: bad arguments");
+  if (hd != 64 || H != 8) return hig_set_error(HIG_EUNSUPPORTED, "hig_attn_out16: built for 8 heads of 64 (got %d x %d)", H, hd);
+  HIG_REQUIRE(ldq % 8 == 0 && ldh % 8 == 0 && ss_ld % 4 == 0 && ss_shift_off % 4 == 0 &&
+                  ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(At16) |
+                    reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(ss) |
+                    reinterpret_cast<uintptr_t>(W_frag) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(stats) & 7) == 0,
+              "hig_attn_out16: alignment");
+  const dim3 grid((rows + 31) / 32, B);
+  hipLaunchKernelGGL((apply_sty16_kernel<64, 8, 8, true>), grid, dim3(512), 0, hig_stream(stream), static_cast<const __bf16*>(Q), ldq,
+                     static_cast<const __bf16*>(At16), gamma, beta, ss, ss_ld, ss_shift_off, static_cast<__bf16*>(nullptr), (int64_t)0, rows,
+                     g_ap_stamps, OutGemmArgs{static_cast<const __bf16*>(W_frag), bias, static_cast<__bf16*>(h), ldh, stats});
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

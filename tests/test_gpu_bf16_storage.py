@@ -349,6 +349,58 @@ def test_fused_apply_stylization_front_on_the_bf16_matrix_cores(H, B, T, hd):
     assert rel(out.float(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("B,T,with_stats", [(32, 196, True), (5, 91, False), (3, 1, True), (16, 196, False)])
+def test_attention_output_projection_fused_into_the_apply_kernel(B, T, with_stats):
+    """hig_attn_out16 = hig_linattn_apply_sty_mm16, then the stylization-out GEMM with the residual update (and the row
+    statistics of the LayerNorm fold), as ONE launch: a workgroup keeps its 32 activated rows in LDS and streams the weight in
+    matrix-core operand order.  Same products in the same order as the two-launch sequence: h and the statistics must match it
+    bit for bit."""
+    H, hd, d = 8, 64, 512
+    M = B * T
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    q16 = bf(torch.randn(M, 3 * d, generator=g) * 2).to(DEV)
+    A = (torch.randn(B, H, hd, hd, generator=g) * 0.5).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV), (0.1 * torch.randn(d, generator=g)).to(DEV)
+    ss = (0.3 * torch.randn(B, 2 * d, generator=g)).to(DEV)
+    W = bf(torch.randn(d, d, generator=g) / d ** 0.5).to(DEV)
+    bias = torch.randn(d, generator=g).to(DEV)
+    h0 = bf(torch.randn(M, d, generator=g) * 2).to(DEV)
+    At = at16_order(A)
+    L = _lib.lib()
+    # reference sequence: apply + stylization front, then the weight-stationary (or tiled) GEMM with the in-place residual
+    a = torch.full((M, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _lib.check(L.hig_linattn_apply_sty_mm16(_lib.ptr(q16), 3 * d, _lib.ptr(At), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(ss),
+                                            2 * d, d, _lib.ptr(a), d, B, T, H, hd, _lib.stream_ptr()))
+    h_ref = h0.clone()
+    st_ref = torch.full((M, 4, 2), float("nan"), device=DEV)
+    dsc = _lib.Gemm16Desc()
+    dsc.X, dsc.ldx, dsc.Y, dsc.ldy, dsc.C, dsc.ldc, dsc.c_f32 = a.data_ptr(), d, W.data_ptr(), d, h_ref.data_ptr(), d, 0
+    dsc.I, dsc.J, dsc.R, dsc.epi, dsc.bias = M, d, d, _lib.EPI_BIAS_RES, bias.data_ptr()
+    dsc.res, dsc.ldr, dsc.res_f32 = h_ref.data_ptr(), d, 0
+    if with_stats and M >= 2048:
+        dsc.row_stats_out = st_ref.data_ptr()
+    _lib.check(L.hig_gemm_bf16(C.byref(dsc), _lib.stream_ptr()))
+    # fused
+    Wf = torch.full((d * d,), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _lib.check(L.hig_weight_frag16(_lib.ptr(W), d, d, d, _lib.ptr(Wf), _lib.stream_ptr()))
+    assert torch.equal(Wf, hig_amd.MotionTransformer._frag16(W).reshape(-1))
+    h = h0.clone()
+    st = torch.full((M, 4, 2), float("nan"), device=DEV)
+    _lib.check(L.hig_attn_out16(_lib.ptr(q16), 3 * d, _lib.ptr(At), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(ss), 2 * d, d,
+                                _lib.ptr(Wf), _lib.ptr(bias), _lib.ptr(h), d, _lib.ptr(st) if with_stats else None, B, T, H, hd,
+                                _lib.stream_ptr()))
+    assert torch.isfinite(h.float()).all()
+    if M >= 2048:       # the weight-stationary kernel: same accumulation order, so the same bits
+        assert torch.equal(h, h_ref)
+    else:               # (the tiled kernel adds its bias after the products: equal up to the last rounding)
+        assert (h != h_ref).float().mean().item() < 0.02 and rel(h.float(), h_ref.float()) < 2e-3
+    if with_stats:
+        hp = h.float().double().cpu().view(M, 4, 128)
+        assert rel(st[:, :, 0], hp.sum(-1)) < 1e-5 and rel(st[:, :, 1], (hp * hp).sum(-1)) < 1e-5
+        if M >= 2048:
+            assert torch.equal(st, st_ref)
+
+
 @pytest.mark.parametrize("M,T,F,d,shift", [(6272, 196, 150, 512, 0), (333, 37, 263, 256, 0), (70, 7, 12, 128, 1),
                                            (9600, 300, 150, 1024, 0), (129, 43, 151, 128, 0), (64, 8, 32, 128, 0)])
 def test_joint_embed_bf16_kernel(M, T, F, d, shift):
