@@ -35,7 +35,7 @@ SYMBOLS = (
     "hig_fullattn_fwd_kpad", "hig_eval_encoder_workspace_bytes", "hig_eval_encoder_fwd",
     "hig_clip_adam_lrdev", "hig_shutdown", "hig_gemm_split", "hig_gemm_split_scratch_floats",
     "hig_gemm_bf16", "hig_gemm_bf16_debug_stamps", "hig_gemm_ws16_debug_stamps", "hig_linattn16_debug_stamps", "hig_cast_bf16", "hig_ln_bf16", "hig_linattn_ctx_bf16", "hig_linattn_apply_bf16",
-    "hig_text_context_bf16", "hig_denoiser_fwd_bf16", "hig_linattn_apply_sty_bf16", "hig_linattn_apply_sty_mm16", "hig_linattn_ctx_mm16", "hig_linattn_apply_sty", "hig_joint_embed_bf16", "hig_joint_embed_bf16_w", "hig_attn_out16", "hig_weight_frag16", "hig_joint_embed_bf16_scratch_bytes", "hig_fullattn_fwd_bf16", "hig_denoiser_bwd_hooked",
+    "hig_text_context_bf16", "hig_denoiser_fwd_bf16", "hig_linattn_apply_sty_bf16", "hig_linattn_apply_sty_mm16", "hig_linattn_ctx_mm16", "hig_linattn_apply_sty", "hig_joint_embed_bf16", "hig_joint_embed_bf16_w", "hig_attn_out16", "hig_rows_out16", "hig_weight_frag16", "hig_joint_embed_bf16_scratch_bytes", "hig_fullattn_fwd_bf16", "hig_denoiser_bwd_hooked",
 )
 
 
@@ -169,6 +169,7 @@ def lib():
         L.hig_joint_embed_bf16_scratch_bytes.restype = i64
         L.hig_joint_embed_bf16.argtypes = [vp, i64, i32, vp, vp, vp, i64, i32, i32, vp, i64, i32, vp, vp]
         L.hig_attn_out16.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, vp, vp, vp, i64, vp, i32, i32, i32, i32, vp]
+        L.hig_rows_out16.argtypes = [vp, i64, vp, vp, vp, i64, i32, vp, vp, vp, i64, vp, i32, i32, i32, vp]
         L.hig_weight_frag16.argtypes = [vp, i64, i32, i32, vp, vp]
         L.hig_joint_embed_bf16_w.argtypes = [vp, i64, i32, vp, vp, vp, i64, i32, i32, vp, i64, i32, vp]
         L.hig_linattn_apply_sty.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, vp, i64, i32, i32, i32, i32, vp]

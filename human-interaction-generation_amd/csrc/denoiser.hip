@@ -756,8 +756,8 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   static const int joint16 = getenv("HIG_JOINT16") ? atoi(getenv("HIG_JOINT16")) : 1;   // tuning knob
   if (joint16 && d % 128 == 0 && D.F <= 512) {
     // own kernel pair (weight padded / rounded to bf16, x rounded in LDS, bf16 MFMA): 31 -> ~8 us at B = 32
-    if (lnfold && lnfold[12 * D.L])   // (weight padded / rounded once, next to the caller's bf16 shadow)
-      HIG_TRY(hig_joint_embed_bf16_w(x, M, D.F, lnfold[12 * D.L], P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d, D.T,
+    if (lnfold && lnfold[13 * D.L])   // (weight padded / rounded once, next to the caller's bf16 shadow)
+      HIG_TRY(hig_joint_embed_bf16_w(x, M, D.F, lnfold[13 * D.L], P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d, D.T,
                                      D.two ? 1 : 0, ws + w.h, d, d, stream));
     else
       HIG_TRY(hig_joint_embed_bf16(x, M, D.F, P(params, HIG_P_JOINT_W), P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d,
@@ -812,11 +812,11 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   // xn-free projection of LN(h): out = LN(h) W^T + b through the folded operands (k = 0: q/k/v, k = 1: cross-attention query,
   // k = 2: q/k/v of the person <-> person attention)
   auto ln_proj = [&](int l, int k, int norm_w, int norm_b, int lin_w, int lin_b, void* outp, int64_t ncols) -> int {
-    if (have_stats && lnfold[12 * l + 3 * k]) {
-      G16 g(h, d, lnfold[12 * l + 3 * k], d, outp, ncols, M, ncols, d);
-      g.epi(HIG_EPI_BIAS, static_cast<const float*>(lnfold[12 * l + 3 * k + 2]));
+    if (have_stats && lnfold[13 * l + 3 * k]) {
+      G16 g(h, d, lnfold[13 * l + 3 * k], d, outp, ncols, M, ncols, d);
+      g.epi(HIG_EPI_BIAS, static_cast<const float*>(lnfold[13 * l + 3 * k + 2]));
       g.g.row_stats_in = stats;
-      g.g.ln_colsum = static_cast<const float*>(lnfold[12 * l + 3 * k + 1]);
+      g.g.ln_colsum = static_cast<const float*>(lnfold[13 * l + 3 * k + 1]);
       return hig_gemm16_launch(g.g, st);
     }
     HIG_TRY(hig_ln_bf16(h, 0, d, M, d, PL(params, l, norm_w), PL(params, l, norm_b), nullptr, 0, 0, 0, xn, d, stream));
@@ -847,7 +847,7 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
                     int out_w, int out_b) -> int {
     if (fuse_apply) {
       const float* ssl = ss + (int64_t)(D.nsty * l + slot) * 2 * d;
-      const void* wfrag = (fuse_out && slot < 3 && lnfold) ? lnfold[12 * l + 9 + slot] : nullptr;
+      const void* wfrag = (fuse_out && slot < 3 && lnfold) ? lnfold[13 * l + 9 + slot] : nullptr;
       if (wfrag) {   // apply + stylization front + output projection + residual update as ONE launch
         const bool st_out = fold && want_stats;
         HIG_TRY(hig_attn_out16(q, ldq, ctx_t16, PL(params, l, norm_w), PL(params, l, norm_b), ssl, ss_ld, d, wfrag, PL(params, l, out_b),
@@ -920,7 +920,15 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
     HIG_TRY(hig_gemm16_launch(G16(f1, D.ff, PL16(params16, l, HIG_L_FFN_W2), D.ff, y, d, M, d, D.ff)
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B2)).g, st));
     want_stats = l + 1 < D.L;                    // the FFN stylization block feeds the next layer's self-attention LayerNorm
-    HIG_TRY(stylize(l, D.nsty - 1, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B, HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B));
+    if (fuse_out && lnfold && lnfold[13 * l + 12]) {   // stylization front + output projection + residual update as ONE launch
+      const bool st_out = fold && want_stats;
+      HIG_TRY(hig_rows_out16(y, d, PL(params, l, HIG_L_FFN_STY_NORM_W), PL(params, l, HIG_L_FFN_STY_NORM_B),
+                             ss + (int64_t)(D.nsty * l + D.nsty - 1) * 2 * d, ss_ld, d, lnfold[13 * l + 12], PL(params, l, HIG_L_FFN_STY_OUT_B),
+                             h, d, st_out ? stats : nullptr, D.B, D.T, d, stream));
+      have_stats = st_out;
+    } else {
+      HIG_TRY(stylize(l, D.nsty - 1, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B, HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B));
+    }
   }
   // K6: out = Linear(d, F)(h_L), fp32 (the DDPM update consumes it)
   HIG_TRY(hig_gemm16_launch(G16(h, d, P16(params16, HIG_P_OUT_W), d, out, D.F, M, D.F, d)

@@ -68,6 +68,81 @@ struct OutGemmArgs {
   float* stats;          // [rows][4][2] or NULL
 };
 
+// Output projection + residual update of 32 whole rows, shared by the fused kernels below (8 waves = 512 threads, d = 512):
+// sA = the activated tile, sH = the residual rows, both [32][1 KiB] bf16 with 16-byte chunk c of row r at c ^ (r & 15).
+// Wave w owns output columns 64 w .. 64 w + 63 (two 32-column blocks) over 32 k-steps; the weight comes in operand order
+// global -> registers, PF k-steps ahead; rows r0 .. r0 + 31 of sample b (T rows per sample) are written while r0 + r < T.
+__device__ __forceinline__ void out_gemm_rows(const char* sA, char* sH, const OutGemmArgs& og, int b, int r0, int T) {
+  constexpr int D_ = 512, ROWB = 1024, BR = 32, NT = 512, PPR = ROWB / 16;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // ---- h[rows] += a W^T + bias: wave w owns columns 64 w .. 64 w + 63 (two 32-column blocks), 32 k-steps ---------------
+  constexpr int NK = D_ / 16, PF = 8;          // k-steps; weight operands requested PF k-steps ahead
+  f32x16 acc2[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(og.bias + 64 * wave + 32 * cb + 8 * q + 4 * lh);
+      acc2[cb][4 * q] = b4.x; acc2[cb][4 * q + 1] = b4.y; acc2[cb][4 * q + 2] = b4.z; acc2[cb][4 * q + 3] = b4.w;
+    }
+  const __bf16* wbase = og.Wf + ((int64_t)(2 * wave) * NK * 64 + lane) * 8;    // block (2 w + cb, ks) at + ((cb NK + ks) 64) 8
+  bf16x8 wring[PF][2];
+#pragma unroll
+  for (int ks = 0; ks < PF; ++ks)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) wring[ks][cb] = *reinterpret_cast<const bf16x8*>(wbase + (int64_t)(cb * NK + ks) * 512);
+  const int tsw = (lr & 15) ^ lh;
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sA + lr * ROWB + 16 * ((2 * ks) ^ tsw));
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[ks % PF][cb], xf, acc2[cb], 0, 0, 0);
+    if (ks + PF < NK) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) wring[ks % PF][cb] = *reinterpret_cast<const bf16x8*>(wbase + (int64_t)(cb * NK + ks + PF) * 512);
+    }
+  }
+  // residual add in fp32, one rounding, IN PLACE in the residual tile (each lane reads the 8 bytes it overwrites)
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      char* hp = sH + lr * ROWB + 16 * ((8 * wave + 4 * cb + q) ^ (lr & 15)) + 8 * lh;
+      const u32x2 rq = *reinterpret_cast<const u32x2*>(hp);
+      const float v0 = acc2[cb][4 * q] + bf_lo(rq.x), v1 = acc2[cb][4 * q + 1] + bf_hi(rq.x);
+      const float v2 = acc2[cb][4 * q + 2] + bf_lo(rq.y), v3 = acc2[cb][4 * q + 3] + bf_hi(rq.y);
+      *reinterpret_cast<bf16x4*>(hp) = bf16x4{(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+    }
+  __syncthreads();
+  // whole rows out (+ the row statistics per 128-column panel for a LayerNorm-folding consumer, as gemm_ws16 writes them)
+#pragma unroll
+  for (int u = 0; u < BR * PPR / NT; ++u) {
+    const int idx = tid + NT * u;
+    const int r = idx / PPR, p = idx % PPR;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(sH + r * ROWB + 16 * (p ^ (r & 15)));
+    const int64_t row = (int64_t)b * T + r0 + r;
+    if (r0 + r < T) *reinterpret_cast<bf16x8*>(og.h + row * og.ldh + 8 * p) = v;
+    if (og.stats) {
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bf16x2_t pr = {v[2 * k], v[2 * k + 1]};
+        s1 = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, s1, false);
+        s2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, s2, false);
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+      }
+      if ((p & 15) == 0 && r0 + r < T) *reinterpret_cast<float2*>(og.stats + (row * 4 + (p >> 4)) * 2) = make_float2(s1, s2);
+    }
+  }
+}
+
 template <int HD, int H, int NW, bool GEMM = false>
 __global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __restrict__ Q, int64_t ldq,
                                                               const __bf16* __restrict__ At16, const float* __restrict__ gamma,
@@ -291,71 +366,7 @@ __global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __re
   stamp(5);
   constexpr int PPR = ROWB / 16;
   if constexpr (GEMM) {
-    // ---- h[rows] += a W^T + bias: wave w owns columns 64 w .. 64 w + 63 (two 32-column blocks), 32 k-steps ---------------
-    constexpr int NK = D_ / 16, PF = 8;          // k-steps; weight operands requested PF k-steps ahead
-    f32x16 acc2[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(og.bias + 64 * wave + 32 * cb + 8 * q + 4 * lh);
-        acc2[cb][4 * q] = b4.x; acc2[cb][4 * q + 1] = b4.y; acc2[cb][4 * q + 2] = b4.z; acc2[cb][4 * q + 3] = b4.w;
-      }
-    const __bf16* wbase = og.Wf + ((int64_t)(2 * wave) * NK * 64 + lane) * 8;    // block (2 w + cb, ks) at + ((cb NK + ks) 64) 8
-    bf16x8 wring[PF][2];
-#pragma unroll
-    for (int ks = 0; ks < PF; ++ks)
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) wring[ks][cb] = *reinterpret_cast<const bf16x8*>(wbase + (int64_t)(cb * NK + ks) * 512);
-    const int tsw = (lr & 15) ^ lh;
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sQ + lr * ROWB + 16 * ((2 * ks) ^ tsw));
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) acc2[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[ks % PF][cb], xf, acc2[cb], 0, 0, 0);
-      if (ks + PF < NK) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) wring[ks % PF][cb] = *reinterpret_cast<const bf16x8*>(wbase + (int64_t)(cb * NK + ks + PF) * 512);
-      }
-    }
-    // residual add in fp32, one rounding, IN PLACE in the residual tile (each lane reads the 8 bytes it overwrites)
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        char* hp = sH + lr * ROWB + 16 * ((8 * wave + 4 * cb + q) ^ (lr & 15)) + 8 * lh;
-        const u32x2 rq = *reinterpret_cast<const u32x2*>(hp);
-        const float v0 = acc2[cb][4 * q] + bf_lo(rq.x), v1 = acc2[cb][4 * q + 1] + bf_hi(rq.x);
-        const float v2 = acc2[cb][4 * q + 2] + bf_lo(rq.y), v3 = acc2[cb][4 * q + 3] + bf_hi(rq.y);
-        *reinterpret_cast<bf16x4*>(hp) = bf16x4{(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
-      }
-    __syncthreads();
-    // whole rows out (+ the row statistics per 128-column panel for a LayerNorm-folding consumer, as gemm_ws16 writes them)
-#pragma unroll
-    for (int u = 0; u < BR * PPR / NT; ++u) {
-      const int idx = tid + NT * u;
-      const int r = idx / PPR, p = idx % PPR;
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(sH + r * ROWB + 16 * (p ^ (r & 15)));
-      const int64_t row = (int64_t)b * T + r0 + r;
-      if (r0 + r < T) *reinterpret_cast<bf16x8*>(og.h + row * og.ldh + 8 * p) = v;
-      if (og.stats) {
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const bf16x2_t pr = {v[2 * k], v[2 * k + 1]};
-          s1 = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, s1, false);
-          s2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, s2, false);
-        }
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-          s1 += __shfl_xor(s1, off, 64);
-          s2 += __shfl_xor(s2, off, 64);
-        }
-        if ((p & 15) == 0 && r0 + r < T) *reinterpret_cast<float2*>(og.stats + (row * 4 + (p >> 4)) * 2) = make_float2(s1, s2);
-      }
-    }
+    out_gemm_rows(sQ, sH, og, b, r0, T);
   } else {
     // ---- whole rows out --------------------------------------------------------------------------------------------
 #pragma unroll
@@ -370,6 +381,74 @@ __global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __re
   stamp(6);
 }
 
+
+// The stylization block behind the FFN (and any other block whose input rows Y are already in memory) as ONE launch:
+//     h[rows] += silu( LN(Y[rows]) (1 + scale) + shift ) . W^T + bias                              (transformer.py:81-86)
+// = hig_ln_bf16 (stylization front) + the stylization-out GEMM: 32 whole rows per workgroup, Y tile / residual rows /
+// LayerNorm and modulation vectors by DMA, a wave normalises four rows in registers (8 elements per lane) and writes them
+// back in place, then out_gemm_rows.  grid = (ceil(T / 32), B), 512 threads.
+__global__ __launch_bounds__(512) void rows_out16_kernel(const __bf16* __restrict__ Y, int64_t ldy, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ ss, int64_t ss_ld,
+                                                         int shift_off, int T, const OutGemmArgs og) {
+  constexpr int D_ = 512, ROWB = 1024, BR = 32, NW = 8, NT = 512, QBYTES = BR * ROWB;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * QBYTES + 4 * D_ * 4];
+  char* const sA = smem;                                       // Y tile, then the activated tile (same swizzle as everywhere)
+  char* const sH = smem + QBYTES;                              // residual rows
+  float* const sPar = reinterpret_cast<float*>(smem + 2 * QBYTES);   // gamma | beta | scale | shift, then gamma' | beta'
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y, r0 = blockIdx.x * BR;
+#pragma unroll
+  for (int q = 0; q < QBYTES / 1024 / NW; ++q) {
+    const int n = wave + NW * q;                  // row n of the tile
+    const int64_t row = (int64_t)b * T + min(r0 + n, T - 1);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Y + row * ldy + 8 * (lane ^ (n & 15))),
+                                     (__attribute__((address_space(3))) void*)(sA + n * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(og.h + row * og.ldh + 8 * (lane ^ (n & 15))),
+                                     (__attribute__((address_space(3))) void*)(sH + n * 1024), 16, 0, 0);
+  }
+  {
+    const float* ssb = ss + (int64_t)b * ss_ld;
+    const int vec = wave >> 1, part = wave & 1;   // 8 pieces of 1 KiB: vector wave / 2, half wave % 2
+    const float* base = vec == 0 ? gamma : vec == 1 ? beta : vec == 2 ? ssb : ssb + shift_off;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + part * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(sPar) + wave * 1024), 16, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int c = tid; c < D_; c += NT) {            // gamma' = gamma (1 + scale), beta' = beta (1 + scale) + shift
+    const float g = sPar[c], be = sPar[D_ + c], sc = 1.0f + sPar[2 * D_ + c], sh = sPar[3 * D_ + c];
+    sPar[c] = g * sc;
+    sPar[D_ + c] = fmaf(be, sc, sh);
+  }
+  __syncthreads();
+  {
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(sPar + 8 * lane), g1 = *reinterpret_cast<const f32x4*>(sPar + 8 * lane + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sPar + D_ + 8 * lane), b1 = *reinterpret_cast<const f32x4*>(sPar + D_ + 8 * lane + 4);
+    const float gp[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bp[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int k = 0; k < BR / NW; ++k) {
+      const int r = wave + NW * k;
+      char* rp = sA + r * ROWB + 16 * (lane ^ (r & 15));      // this lane's 8 elements of row r: columns 8 lane .. 8 lane + 7
+      const u32x4 w = *reinterpret_cast<const u32x4*>(rp);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(w[e]); v[2 * e + 1] = bf_hi(w[e]); }
+      float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      const float mean = wave_sum(s) * (1.0f / D_);
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float dlt = v[e] - mean; q = fmaf(dlt, dlt, q); }
+      const float rstd = rsqrtf(wave_sum(q) * (1.0f / D_) + 1e-5f);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)hig_silu_fast(fmaf((v[e] - mean) * rstd, gp[e], bp[e]));
+      *reinterpret_cast<bf16x8*>(rp) = o;
+    }
+  }
+  __syncthreads();
+  out_gemm_rows(sA, sH, og, b, r0, T);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Context build of the bf16-storage forward on the bf16 matrix cores:
@@ -685,6 +764,26 @@ extern "C" int hig_attn_out16(const void* Q, int64_t ldq, const void* At16, cons
   hipLaunchKernelGGL((apply_sty16_kernel<64, 8, 8, true>), grid, dim3(512), 0, hig_stream(stream), static_cast<const __bf16*>(Q), ldq,
                      static_cast<const __bf16*>(At16), gamma, beta, ss, ss_ld, ss_shift_off, static_cast<__bf16*>(nullptr), (int64_t)0, rows,
                      g_ap_stamps, OutGemmArgs{static_cast<const __bf16*>(W_frag), bias, static_cast<__bf16*>(h), ldh, stats});
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+// hig_ln_bf16 (stylization front) followed by the stylization-out projection and the residual update, as one kernel:
+//     h[rows] += silu( LN(Y[rows]) (1 + scale) + shift ) . W^T + bias                               (transformer.py:81-86)
+// Y, h bf16 (B * rows, 512); W_frag / stats as in hig_attn_out16.
+extern "C" int hig_rows_out16(const void* Y, int64_t ldy, const float* gamma, const float* beta, const float* ss, int64_t ss_ld,
+                              int32_t ss_shift_off, const void* W_frag, const float* bias, void* h, int64_t ldh, float* stats,
+                              int32_t B, int32_t rows, int32_t d, hig_stream_t stream) {
+  HIG_REQUIRE(Y && gamma && beta && ss && W_frag && bias && h && B > 0 && rows > 0, "hig_rows_out16: bad arguments");
+  if (d != 512) return hig_set_error(HIG_EUNSUPPORTED, "hig_rows_out16: built for d = 512 (got %d)", d);
+  HIG_REQUIRE(ldy % 8 == 0 && ldh % 8 == 0 && ss_ld % 4 == 0 && ss_shift_off % 4 == 0 &&
+                  ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(gamma) |
+                    reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(ss) | reinterpret_cast<uintptr_t>(W_frag) |
+                    reinterpret_cast<uintptr_t>(bias)) & 15) == 0 && (reinterpret_cast<uintptr_t>(stats) & 7) == 0,
+              "hig_rows_out16: alignment");
+  hipLaunchKernelGGL(rows_out16_kernel, dim3((rows + 31) / 32, B), dim3(512), 0, hig_stream(stream), static_cast<const __bf16*>(Y), ldy,
+                     gamma, beta, ss, ss_ld, ss_shift_off, rows,
+                     OutGemmArgs{static_cast<const __bf16*>(W_frag), bias, static_cast<__bf16*>(h), ldh, stats});
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

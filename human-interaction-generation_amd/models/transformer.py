@@ -611,20 +611,20 @@ class MotionTransformer(nn.Module):
 
     def _derived16(self, fp):
         """Operands of the bf16-storage forward derived from the parameters, kept next to the bf16 shadow and rebuilt
-        when the parameters change (`derived` of hig_denoiser_fwd_bf16): 12 L + 1 device pointers, NULL where a piece does
+        when the parameters change (`derived` of hig_denoiser_fwd_bf16): 13 L + 1 device pointers, NULL where a piece does
         not apply (the library then runs its LayerNorm kernel / pads per call).
-        [12 l + 3 k + 0 .. 2] (d = 512 only): the LayerNorm-folded projection k of layer l -- k = 0 self-attention q/k/v, 1
+        [13 l + 3 k + 0 .. 2] (d = 512 only): the LayerNorm-folded projection k of layer l -- k = 0 self-attention q/k/v, 1
         cross-attention query, 2 q/k/v of the person <-> person attention (two-person model) -- as [W' (bf16), colsum, bias']
         with W' = gamma (.) W, colsum[j] = sum_r float(W'[j][r]), bias' = b + W beta: LayerNorm(x) W^T + b == rstd (x W'^T) -
         rstd mean colsum + bias' (transformer.py:108-110,144; interaction_transformer.py:181-190); applied wherever the
         producer of x wrote its row statistics.
-        [12 l + 9 + s] (d = 512): the stylization-out weight of the self- (s = 0) / cross- (1) / person <-> person (2) attention
-        block in matrix-core operand order (_frag16) for the fused apply + projection kernel hig_attn_out16.
-        [12 L]: joint_embed weight (transformer.py:418) rounded to bf16 and padded to a multiple of 32 columns."""
+        [13 l + 9 + s] (d = 512): the stylization-out weight of the self- (s = 0) / cross- (1) / person <-> person (2) attention /
+        FFN (3) block in matrix-core operand order (_frag16) for the fused kernels hig_attn_out16 / hig_rows_out16.
+        [13 L]: joint_embed weight (transformer.py:418) rounded to bf16 and padded to a multiple of 32 columns."""
         ver = (self._param_version(), fp.flat.data_ptr())
         if getattr(self, "_derived", None) is None or self._derived[0] != ver:
             d, nl, ng, offs, L = self.latent_dim, _lib.NLAYER, _lib.NGLOBAL, fp.group_offsets, self.num_layers
-            arr, bufs = (C.c_void_p * (12 * L + 1))(), []
+            arr, bufs = (C.c_void_p * (13 * L + 1))(), []
             with torch.no_grad():
                 for l in range(L if d == 512 else 0):
                     def grp(idx, n):
@@ -640,20 +640,20 @@ class MotionTransformer(nn.Module):
                         cs = Wp.float().sum(dim=1).contiguous()
                         bp = (b + W @ beta).contiguous()
                         bufs += [Wp, cs, bp]
-                        arr[12 * l + 3 * k], arr[12 * l + 3 * k + 1], arr[12 * l + 3 * k + 2] = Wp.data_ptr(), cs.data_ptr(), bp.data_ptr()
+                        arr[13 * l + 3 * k], arr[13 * l + 3 * k + 1], arr[13 * l + 3 * k + 2] = Wp.data_ptr(), cs.data_ptr(), bp.data_ptr()
                     # stylization-out weights of the attention blocks in matrix-core operand order (hig_attn_out16)
-                    for s, wi in enumerate((6, 18, 34)):
+                    for s, wi in enumerate((6, 18, 34, 26)):
                         w = grp(wi, d * d)
                         if w is not None:
                             wf = self._frag16(w.view(d, d).to(torch.bfloat16))
                             bufs.append(wf)
-                            arr[12 * l + 9 + s] = wf.data_ptr()
+                            arr[13 * l + 9 + s] = wf.data_ptr()
                 F = self.input_feats
                 Fp = (F + 31) // 32 * 32
                 wj = torch.zeros(d, Fp, device=fp.flat.device, dtype=torch.bfloat16)
                 wj[:, :F] = self.joint_embed.weight.detach().to(torch.bfloat16)
                 bufs.append(wj)
-                arr[12 * L] = wj.data_ptr()
+                arr[13 * L] = wj.data_ptr()
             self._derived = (ver, arr, bufs)
         return self._derived[1]
 

@@ -178,17 +178,17 @@ int hig_denoiser_fwd(const hig_dims* dims, const void* const* params, const floa
  * Workspace / text-context sizes: hig_workspace_bytes / hig_textctx_bytes with the same dims (training = 0). */
 int hig_text_context_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
                           const float* xf_out, void* textctx, hig_stream_t stream);
-/* derived (nullable): 12 L + 1 device pointers the caller derives from the parameters and keeps next to the bf16 shadow
+/* derived (nullable): 13 L + 1 device pointers the caller derives from the parameters and keeps next to the bf16 shadow
  * (rebuilt when the parameters change); any entry may be NULL (the library then does that piece per call / unfused).
- * [12 l + 3 k + 0 .. 2], k = 0, 1, 2, d == 512: W' (bf16, rows x d), colsum (fp32, rows), bias' (fp32, rows) of the LayerNorm +
+ * [13 l + 3 k + 0 .. 2], k = 0, 1, 2, d == 512: W' (bf16, rows x d), colsum (fp32, rows), bias' (fp32, rows) of the LayerNorm +
  * Linear pair k of layer l -- k = 0 self-attention q/k/v (3d rows), k = 1 cross-attention query (d rows), k = 2 q/k/v of the
  * person <-> person attention (two-person model, 3d rows) -- with W' = gamma (.) W of the LayerNorm in front of the Linear,
  * colsum[j] = sum_r float(W'[j][r]), bias' = b + W beta.  With them (and >= 2048 rows) the LayerNorm kernels in front of
  * those projections disappear: the GEMM that produces the residual stream also writes its row statistics, and the
  * projection applies them in its epilogue (hig_gemm16_desc).
- * [12 l + 9 + s], s = 0, 1, 2: the stylization-out weight of the self- / cross- / person <-> person attention block in
- * matrix-core operand order (hig_weight_frag16) for hig_attn_out16.
- * [12 L]: joint_embed weight padded and rounded for hig_joint_embed_bf16_w ((d, Fp) bf16, Fp = F rounded up to 32). */
+ * [13 l + 9 + s], s = 0, 1, 2, 3: the stylization-out weight of the self- / cross- / person <-> person attention / FFN block
+ * in matrix-core operand order (hig_weight_frag16) for hig_attn_out16 / hig_rows_out16.
+ * [13 L]: joint_embed weight padded and rounded for hig_joint_embed_bf16_w ((d, Fp) bf16, Fp = F rounded up to 32). */
 int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
                           const void* const* derived, const float* x,
                           const int64_t* t, const int64_t* length, const float* xf_proj, const void* textctx,
@@ -477,6 +477,12 @@ int hig_linattn_apply_sty_bf16(const void* Q, int64_t ldq, const float* A, const
 int hig_attn_out16(const void* Q, int64_t ldq, const void* At16, const float* gamma, const float* beta, const float* ss,
                    int64_t ss_ld, int32_t ss_shift_off, const void* W_frag, const float* bias, void* h, int64_t ldh,
                    float* stats, int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
+/* hig_ln_bf16 (stylization front) + the stylization-out projection + the residual update as one kernel, for a block whose
+ * input rows Y are in memory (the FFN block):  h[rows] += silu( LN(Y[rows]) (1 + scale) + shift ) . W^T + bias
+ * (transformer.py:81-86).  Y, h bf16 (B rows, 512); W_frag / stats as in hig_attn_out16; rows_per_sample == rows. */
+int hig_rows_out16(const void* Y, int64_t ldy, const float* gamma, const float* beta, const float* ss, int64_t ss_ld,
+                   int32_t ss_shift_off, const void* W_frag, const float* bias, void* h, int64_t ldh, float* stats,
+                   int32_t B, int32_t rows, int32_t d, hig_stream_t stream);
 /* Y_frag[((j / 32) (R / 16) + r / 16) 512 + (j % 32 + 32 ((r % 16) / 8)) 8 + r % 8] = Y[j][r] for a (J, R) row-major bf16
  * matrix with leading dimension ldy (J % 32 == 0, R % 16 == 0): a 32 x 16 MFMA operand block = 64 lanes x 8 elements = 1 KiB. */
 int hig_weight_frag16(const void* Y, int64_t ldy, int32_t J, int32_t R, void* Y_frag, hig_stream_t stream);

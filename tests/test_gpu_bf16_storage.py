@@ -401,6 +401,50 @@ def test_attention_output_projection_fused_into_the_apply_kernel(B, T, with_stat
             assert torch.equal(st, st_ref)
 
 
+@pytest.mark.parametrize("B,T,with_stats", [(32, 196, True), (5, 91, False), (3, 1, True)])
+def test_stylization_block_of_stored_rows_as_one_kernel(B, T, with_stats):
+    """hig_rows_out16: LayerNorm -> (1 + scale) / shift -> SiLU -> Linear -> residual add of the stylization block behind the
+    FFN (transformer.py:81-86) as one launch, against the definition in fp64 on the same bf16 operands and against the
+    two-launch sequence (hig_ln_bf16 + hig_gemm_bf16) it replaces."""
+    d = 512
+    M = B * T
+    g = torch.Generator().manual_seed(B * 77 + T)
+    y16 = bf(torch.randn(M, d, generator=g) * 2 + 0.3).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV), (0.1 * torch.randn(d, generator=g)).to(DEV)
+    ss = (0.3 * torch.randn(B, 2 * d, generator=g)).to(DEV)
+    W = bf(torch.randn(d, d, generator=g) / d ** 0.5).to(DEV)
+    bias = torch.randn(d, generator=g).to(DEV)
+    h0 = bf(torch.randn(M, d, generator=g) * 2).to(DEV)
+    L = _lib.lib()
+    Wf = hig_amd.MotionTransformer._frag16(W).reshape(-1).contiguous()
+    h = h0.clone()
+    st = torch.full((M, 4, 2), float("nan"), device=DEV)
+    _lib.check(L.hig_rows_out16(_lib.ptr(y16), d, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(ss), 2 * d, d, _lib.ptr(Wf), _lib.ptr(bias),
+                                _lib.ptr(h), d, _lib.ptr(st) if with_stats else None, B, T, d, _lib.stream_ptr()))
+    # the two launches it replaces
+    a = torch.empty(M, d, device=DEV, dtype=torch.bfloat16)
+    _lib.check(L.hig_ln_bf16(_lib.ptr(y16), 0, d, M, d, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(ss), 2 * d, d, T, _lib.ptr(a), d,
+                             _lib.stream_ptr()))
+    h2 = h0.clone()
+    dsc = _lib.Gemm16Desc()
+    dsc.X, dsc.ldx, dsc.Y, dsc.ldy, dsc.C, dsc.ldc, dsc.c_f32 = a.data_ptr(), d, W.data_ptr(), d, h2.data_ptr(), d, 0
+    dsc.I, dsc.J, dsc.R, dsc.epi, dsc.bias = M, d, d, _lib.EPI_BIAS_RES, bias.data_ptr()
+    dsc.res, dsc.ldr, dsc.res_f32 = h2.data_ptr(), d, 0
+    _lib.check(L.hig_gemm_bf16(C.byref(dsc), _lib.stream_ptr()))
+    # fp64 definition (activations rounded to bf16 where the kernel rounds them)
+    yd = y16.double().cpu()
+    sc = ss[:, :d].double().cpu().repeat_interleave(T, 0)
+    sh = ss[:, d:].double().cpu().repeat_interleave(T, 0)
+    act = torch.nn.functional.silu(torch.nn.functional.layer_norm(yd, (d,), gamma.double().cpu(), beta.double().cpu(), 1e-5) * (1 + sc) + sh)
+    ref = bf(act.float()).double() @ W.double().cpu().t() + bias.double().cpu() + h0.double().cpu()
+    assert torch.isfinite(h.float()).all()
+    assert rel(h.float(), ref) < 3e-3
+    assert rel(h.float(), h2.float()) < 3e-3 and (h != h2).float().mean().item() < 0.05
+    if with_stats:
+        hp = h.float().double().cpu().view(M, 4, 128)
+        assert rel(st[:, :, 0], hp.sum(-1)) < 1e-5 and rel(st[:, :, 1], (hp * hp).sum(-1)) < 1e-5
+
+
 @pytest.mark.parametrize("M,T,F,d,shift", [(6272, 196, 150, 512, 0), (333, 37, 263, 256, 0), (70, 7, 12, 128, 1),
                                            (9600, 300, 150, 1024, 0), (129, 43, 151, 128, 0), (64, 8, 32, 128, 0)])
 def test_joint_embed_bf16_kernel(M, T, F, d, shift):
