@@ -841,7 +841,7 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   // and a fetch-bound projection.  Same-call A/B, forward: B = 32 (224 workgroups) 1.037 -> 0.970 ms; B = 40 (280) 1.221 ->
   // 1.239, B = 64 1.557 -> 1.570.  HIG_FUSE_OUT=0 switches it off.
   static const int fuse_out_env = getenv("HIG_FUSE_OUT") ? atoi(getenv("HIG_FUSE_OUT")) : 1;   // tuning knob
-  const bool fuse_out = fuse_out_env && fuse_mm16 && d == 512 && D.hd == 64 && D.H == 8 && !D.two &&
+  const bool fuse_out = fuse_out_env && fuse_mm16 && d == 512 && D.hd == 64 && D.H == 8 &&
                         (int64_t)((D.T + 31) / 32) * D.B <= 256;
   auto attend = [&](int l, int slot, const void* q, int64_t ldq, const float* ctx, const void* ctx_t16, int norm_w, int norm_b,
                     int out_w, int out_b) -> int {
@@ -897,7 +897,18 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
       HIG_TRY(ctx16(D, qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, len_partner, A1, kst1, cscr,
                     fuse_mm16 ? ws + w.At1 : nullptr, stream));
       const int64_t halfA = (int64_t)Bp * D.H * D.hd * D.hd, halfM = (int64_t)Bp * D.T;
-      if (fuse_mm16) {
+      if (fuse_out && lnfold && lnfold[13 * l + 11]) {
+        // each half of the batch against the OTHER half's context matrices; apply + stylization block + residual update fused
+        const float* ssl = ss + (int64_t)(D.nsty * l + 2) * 2 * d;
+        const char* At = ws + w.At1;
+        char* hb = static_cast<char*>(h);
+        HIG_TRY(hig_attn_out16(qkv, 3 * d, At + halfA * 2, PL(params, l, HIG_L_INT_STY_NORM_W), PL(params, l, HIG_L_INT_STY_NORM_B), ssl,
+                               ss_ld, d, lnfold[13 * l + 11], PL(params, l, HIG_L_INT_STY_OUT_B), hb, d, nullptr, Bp, D.T, D.H, D.hd, stream));
+        HIG_TRY(hig_attn_out16(qkv + halfM * 3 * d * 2, 3 * d, At, PL(params, l, HIG_L_INT_STY_NORM_W), PL(params, l, HIG_L_INT_STY_NORM_B),
+                               ssl + (int64_t)Bp * ss_ld, ss_ld, d, lnfold[13 * l + 11], PL(params, l, HIG_L_INT_STY_OUT_B),
+                               hb + halfM * d * 2, d, nullptr, Bp, D.T, D.H, D.hd, stream));
+        have_stats = false;
+      } else if (fuse_mm16) {
         // each half of the batch against the OTHER half's context matrices, apply + stylization front as one kernel
         const float* ssl = ss + (int64_t)(D.nsty * l + 2) * 2 * d;
         const char* At = ws + w.At1;
