@@ -836,13 +836,14 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   static const int fuse_env = getenv("HIG_FUSE_APPLY") ? atoi(getenv("HIG_FUSE_APPLY")) : 2;   // tuning knob
   const bool fuse_mm16 = fuse_env == 2 && (D.hd == 64 || D.hd == 128) && (D.H == 4 || D.H == 8);
   const bool fuse_apply = (fuse_env == 1 || fuse_mm16) && (D.H == 4 || D.H == 8);
-  // hig_attn_out16 (apply + stylization front + output projection in one launch) while its workgroups -- one per 32 rows of a
-  // sample, one resident per CU -- fit the chip in ONE round: there the launches are bound by the per-launch floor (~4.4 us)
-  // and a fetch-bound projection.  Same-call A/B, forward: B = 32 (224 workgroups) 1.037 -> 0.970 ms; B = 40 (280) 1.221 ->
-  // 1.239, B = 64 1.557 -> 1.570.  HIG_FUSE_OUT=0 switches it off.
+  // hig_attn_out16 / hig_rows_out16 (a whole stylization block as one launch) for the small batches: there the launches are
+  // bound by the per-launch floor (~4.4 us) and a fetch-bound projection.  Two of their workgroups (one per 32 rows of a sample)
+  // are resident per CU; same-call A/B, forward, fused vs not: B = 32 (224 workgroups) 0.996 vs 1.097 ms, B = 40 1.221 vs
+  // 1.262, B = 64 (448) 1.521 vs 1.614, B = 73 1.640 vs 1.733, B = 96 (672) 2.067 vs 2.100, B = 128 (896) 2.512 vs 2.516,
+  // B = 256 4.393 vs 4.377: used up to 768 workgroups.  HIG_FUSE_OUT=0 switches it off, n >= 2 moves the limit to 256 n.
   static const int fuse_out_env = getenv("HIG_FUSE_OUT") ? atoi(getenv("HIG_FUSE_OUT")) : 1;   // tuning knob
   const bool fuse_out = fuse_out_env && fuse_mm16 && d == 512 && D.hd == 64 && D.H == 8 &&
-                        (int64_t)((D.T + 31) / 32) * D.B <= 256;
+                        (int64_t)((D.T + 31) / 32) * D.B <= (fuse_out_env >= 2 ? 256 * fuse_out_env : 768);
   auto attend = [&](int l, int slot, const void* q, int64_t ldq, const float* ctx, const void* ctx_t16, int norm_w, int norm_b,
                     int out_w, int out_b) -> int {
     if (fuse_apply) {

@@ -144,7 +144,7 @@ __device__ __forceinline__ void out_gemm_rows(const char* sA, char* sH, const Ou
 }
 
 template <int HD, int H, int NW, bool GEMM = false>
-__global__ __launch_bounds__(64 * NW) void apply_sty16_kernel(const __bf16* __restrict__ Q, int64_t ldq,
+__global__ __launch_bounds__(64 * NW, (GEMM ? 4 : 1)) void apply_sty16_kernel(const __bf16* __restrict__ Q, int64_t ldq,
                                                               const __bf16* __restrict__ At16, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ ss,
                                                               int64_t ss_ld, int shift_off, __bf16* __restrict__ Out, int64_t ldo,
