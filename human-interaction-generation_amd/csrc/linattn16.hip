@@ -12,13 +12,17 @@
 // global access is a whole 1-KiB row: the Q tile comes in by LDS-DMA (global_load_lds_dwordx4, XOR swizzle on the
 // source address and on the read address), the result leaves through LDS as whole rows.
 //
-// CDNA4 mapping.  256 threads = 4 waves; wave w owns heads w, w + 4 (H = 8) of the 32 rows.  MFMA: the context matrix is
-// the row ("weight") operand, transposed -- At[l][c] = A[c][l], bf16, staged in LDS once per workgroup for all heads --
-// and softmax(q) the column operand straight from registers: the lane that holds row lr of a q fragment (8 channels)
-// shares the row with lane lr + 32, so the row maximum / sum are one cross-lane exchange.  The accumulator leaves a
-// lane 4 consecutive output columns per quad of ONE row: LayerNorm statistics = lane sums + one exchange + a 4-wave
-// LDS reduction.  softmax(q) and A are rounded to bf16 for the product (fp32 accumulate): the same rounding the bf16
-// storage mode applies to every other matrix operand.
+// CDNA4 mapping.  512 threads = 8 waves at 8 heads (one head per wave; 4 waves with two heads each at 4 heads) over the 32
+// rows.  MFMA: the context matrix is the row ("weight") operand, transposed -- At[l][c] = A[c][l], bf16, which the context
+// kernels write in matrix-core operand order (hig_at16_offset) so that a wave fetches its heads' operands global -> registers,
+// one coalesced KiB each -- and softmax(q) the column operand straight from registers: the lane that holds row lr of a q
+// fragment (8 channels) shares the row with lane lr + 32, so the row maximum / sum are one cross-lane exchange.  The
+// accumulator leaves a lane 4 consecutive output columns per quad of ONE row: LayerNorm statistics = lane sums + one
+// exchange + a reduction over the waves through LDS.  softmax(q) and A are rounded to bf16 for the product (fp32
+// accumulate): the same rounding the bf16 storage mode applies to every other matrix operand.
+//
+// Also in this file: ctx16_mfma_kernel (the context build k^T v on the bf16 matrix cores), the fused forms that carry on with
+// the stylization block's output projection (hig_attn_out16 / hig_rows_out16, out_gemm_rows) and hig_weight_frag16.
 #include <stdlib.h>
 
 #include "gemm16_epi.h"
