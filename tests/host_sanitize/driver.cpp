@@ -108,6 +108,20 @@ int main() {
     alignas(16) static unsigned short b16[64 * 48];
     h.X = b16; h.Y = b16; h.C = b16; h.I = 64; h.J = 64; h.R = 48; h.ldx = 48; h.ldy = 48; h.ldc = 64;
     EXPECT(hig_gemm_bf16(&h, nullptr) == HIG_EUNSUPPORTED);            // R % 32 != 0
+    // round-3 entry points: argument validation before any launch
+    alignas(16) static float f32v[512];
+    EXPECT(hig_attn_out16(nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, nullptr, 1, 1, 8, 64, nullptr) != HIG_OK);
+    EXPECT(hig_attn_out16(b16, 1536, b16, f32v, f32v, f32v, 1024, 512, b16, f32v, b16, 512, nullptr, 1, 4, 4, 64, nullptr) == HIG_EUNSUPPORTED);   // 4 heads
+    EXPECT(hig_attn_out16(b16, 1535, b16, f32v, f32v, f32v, 1024, 512, b16, f32v, b16, 512, nullptr, 1, 4, 8, 64, nullptr) != HIG_OK);            // ldq % 8
+    EXPECT(hig_rows_out16(nullptr, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, nullptr, 1, 1, 512, nullptr) != HIG_OK);
+    EXPECT(hig_rows_out16(b16, 512, f32v, f32v, f32v, 1024, 512, b16, f32v, b16, 512, nullptr, 1, 4, 256, nullptr) == HIG_EUNSUPPORTED);          // d != 512
+    EXPECT(hig_weight_frag16(b16, 40, 33, 40, b16, nullptr) != HIG_OK);                                                                           // J % 32 != 0
+    EXPECT(hig_weight_frag16(nullptr, 0, 0, 0, nullptr, nullptr) != HIG_OK);
+    EXPECT(hig_joint_embed_bf16_w(nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr) != HIG_OK);
+    EXPECT(hig_joint_embed_bf16_w(f32v, 4, 600, b16, f32v, f32v, 512, 4, 0, b16, 512, 512, nullptr) == HIG_EUNSUPPORTED);                         // F > 512
+    EXPECT(hig_linattn_ctx_mm16(b16, b16, 1536, 1, 4, 8, 32, nullptr, f32v, f32v, nullptr, nullptr) == HIG_EUNSUPPORTED);                         // head dim 32
+    EXPECT(hig_linattn_apply_sty_mm16(b16, 1536, b16, f32v, f32v, f32v, 1024, 512, b16, 512, 1, 4, 3, 64, nullptr) == HIG_EUNSUPPORTED);         // 3 heads
+    EXPECT(hig_timestep_embedding_bf16(nullptr, 1, 64, nullptr, nullptr) != HIG_OK);
     h.R = 32; h.ldx = 33;
     EXPECT(hig_gemm_bf16(&h, nullptr) == HIG_EINVAL);                  // leading dimension not a multiple of 8
     h.ldx = 48; h.epi = HIG_EPI_BIAS_RES; h.bias = reinterpret_cast<const float*>(dummy);
