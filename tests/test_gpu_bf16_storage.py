@@ -349,7 +349,8 @@ def test_fused_apply_stylization_front_on_the_bf16_matrix_cores(H, B, T, hd):
     assert rel(out.float(), ref) < 1e-2
 
 
-@pytest.mark.parametrize("B,T,with_stats", [(32, 196, True), (5, 91, False), (3, 1, True), (16, 196, False)])
+@pytest.mark.parametrize("B,T,with_stats", [(32, 196, True), (5, 91, False), (3, 1, True), (16, 196, False), (40, 196, True),
+                                            (64, 50, True), (96, 33, False)])
 def test_attention_output_projection_fused_into_the_apply_kernel(B, T, with_stats):
     """hig_attn_out16 = hig_linattn_apply_sty_mm16, then the stylization-out GEMM with the residual update (and the row
     statistics of the LayerNorm fold), as ONE launch: a workgroup keeps its 32 activated rows in LDS and streams the weight in
@@ -401,7 +402,7 @@ def test_attention_output_projection_fused_into_the_apply_kernel(B, T, with_stat
             assert torch.equal(st, st_ref)
 
 
-@pytest.mark.parametrize("B,T,with_stats", [(32, 196, True), (5, 91, False), (3, 1, True)])
+@pytest.mark.parametrize("B,T,with_stats", [(32, 196, True), (5, 91, False), (3, 1, True), (48, 196, True), (70, 65, False)])
 def test_stylization_block_of_stored_rows_as_one_kernel(B, T, with_stats):
     """hig_rows_out16: LayerNorm -> (1 + scale) / shift -> SiLU -> Linear -> residual add of the stylization block behind the
     FFN (transformer.py:81-86) as one launch, against the definition in fp64 on the same bf16 operands and against the
