@@ -590,6 +590,14 @@ def main():
                 by_batch["B%d" % Bg] = {"samples_per_s": round(Bg / (el_s * (1000.0 / nst)), 3),
                                         "ms_per_denoise_step": round(el_s / nst * 1e3, 4),
                                         "finite": bool(torch.isfinite(smp).all())}
+                if not a.no_cpu_baseline:
+                    # the denoiser of THIS batch size (the un-fused regime: more than 3 workgroups of 32 rows per CU) held to
+                    # the CPU oracle on a 2-sample slice of one forward -- the loop itself draws its own noise, so the
+                    # check is on the step's arithmetic, not on the final sample
+                    with torch.no_grad():
+                        og = model(ig["x"], ig["t"], length=ig["length"], xf_proj=ig["xf_proj"], xf_out=ig["xf_out"])
+                    by_batch["B%d" % Bg]["rel_l2_vs_cpu_oracle"] = float("%.2e" % oracle_slice_error(cg, model, ig, og))
+                    del og
                 del ig, kwg, smp
             by_batch["B32"] = {k: extra["ddpm_sampling_bf16s"][k] for k in ("samples_per_s", "ms_per_denoise_step", "finite")}
             by_batch["what"] = "p_sample_loop T=196, bf16 storage, captured step replayed %d times, by batch size" % nst

@@ -442,6 +442,7 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
   const bool fuse_apply = fuse_env && !training && !D.full && (D.H == 4 || D.H == 8) && (D.hd == 64 || D.hd == 128);
   // One decoder layer for the samples [b0, b0 + nb) on stream `s` (every kernel of a layer is row- or sample-local, so a
   // batch range is a pointer offset).  `hin` / the returned pointer are the FULL-batch residual stream of the layer.
+  int layer_rc = HIG_OK;   // the code of the launch that failed inside `layer` (it returns NULL then)
   auto layer = [&](int l, const float* hin_full, int b0, int nb, hipStream_t s, float* cscr) -> const float* {
     hig_stream_t hs = reinterpret_cast<hig_stream_t>(s);
     float* lb = ws + w.layer0 + w.lstride * l;
@@ -452,8 +453,8 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
     const int64_t* len = length ? length + b0 : nullptr;
     const float* hin = hin_full + r0 * d;
     auto R = [&](int64_t off, int64_t ld) { return lb + off + r0 * ld; };  // rows of an (M, ld) buffer of the layer
-    auto fail = [&](int rc) -> const float* { (void)rc; return nullptr; };
-#define HIG_L(expr) do { if ((expr) != HIG_OK) return fail(0); } while (0)
+    auto fail = [&](int rc) -> const float* { layer_rc = rc; return nullptr; };
+#define HIG_L(expr) do { const int rc_ = (expr); if (rc_ != HIG_OK) return fail(rc_); } while (0)
     // ---- self attention -------------------------------------------------------------
     // LayerNorm as its own row kernel: the GEMM then stages plain operands (a fused LN prologue cost
     // the q/k/v GEMM 258 -> 207 us at config 2, the row pass 13 us; profiles/r01_notes.md)
@@ -567,26 +568,37 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
       return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
     if (hipEventRecord(side->ready, st) != hipSuccess || hipStreamWaitEvent(side->s2, side->ready, 0) != hipSuccess)
       return hig_set_error(HIG_EHIP, "forward fork failed");
-    for (int l = 0; l < D.L; ++l) {
+    // Whatever happens inside the forked region, the side stream is joined back into `st` and the thread's GEMM tail
+    // scratch points at this call's own before returning: the caller may recycle `ws` / `out` as soon as `st` gets
+    // there, and a failed launch must not leave s2 writing them (nor a later GEMM parking sums in gtail2).
+    int rc = HIG_OK;
+    for (int l = 0; l < D.L && rc == HIG_OK; ++l) {
       hig_gemm_set_tail_scratch(ws + w.gtail, HIG_GEMM_TAIL_BYTES);
       const float* ha = layer(l, hin, 0, nbA, st, ws + w.cscr);
+      const float* hb = nullptr;
+      if (ha) {
+        hig_gemm_set_tail_scratch(ws + w.gtail2, HIG_GEMM_TAIL_BYTES);
+        hb = layer(l, hin, nbA, nbB, side->s2, ws + w.cscr2);
+      }
+      if (!ha || !hb) rc = layer_rc != HIG_OK ? layer_rc : HIG_EHIP;
+      else hin = ha;
+    }
+    if (rc == HIG_OK) {
+      hig_gemm_set_tail_scratch(ws + w.gtail, HIG_GEMM_TAIL_BYTES);
+      rc = out_proj(hin, 0, nbA, st);
+    }
+    if (rc == HIG_OK) {
       hig_gemm_set_tail_scratch(ws + w.gtail2, HIG_GEMM_TAIL_BYTES);
-      const float* hb = layer(l, hin, nbA, nbB, side->s2, ws + w.cscr2);
-      if (!ha || !hb) return HIG_EHIP;
-      hin = ha;
+      rc = out_proj(hin, nbA, nbB, side->s2);
     }
     hig_gemm_set_tail_scratch(ws + w.gtail, HIG_GEMM_TAIL_BYTES);
-    HIG_TRY(out_proj(hin, 0, nbA, st));
-    hig_gemm_set_tail_scratch(ws + w.gtail2, HIG_GEMM_TAIL_BYTES);
-    HIG_TRY(out_proj(hin, nbA, nbB, side->s2));
-    hig_gemm_set_tail_scratch(ws + w.gtail, HIG_GEMM_TAIL_BYTES);
     if (hipEventRecord(side->done[0], side->s2) != hipSuccess || hipStreamWaitEvent(st, side->done[0], 0) != hipSuccess)
-      return hig_set_error(HIG_EHIP, "forward join failed");
-    return HIG_OK;
+      return rc != HIG_OK ? rc : hig_set_error(HIG_EHIP, "forward join failed");
+    return rc;
   }
   for (int l = 0; l < D.L; ++l) {
     hin = layer(l, hin, 0, D.B, st, ws + w.cscr);
-    if (!hin) return HIG_EHIP;
+    if (!hin) return layer_rc != HIG_OK ? layer_rc : HIG_EHIP;
   }
   HIG_TRY(out_proj(hin, 0, D.B, st));
   if (D.two)  // init-pose rows go through out2 instead (:613-614)
@@ -631,7 +643,7 @@ Fwd16Layout fwd16_layout(const Dims& D) {
   w.f1 = take(D.M * D.ff * 2);
   w.lenp = take((int64_t)D.B * 8);           // two-person: lengths with the two halves swapped (the partner's mask)
   w.tok0 = take((int64_t)D.B * D.d * 4);     // two-person: joint_embed2 of the init-pose rows (fp32) before they enter h
-  w.stats = take(D.M * 4 * 2 * 4);           // LayerNorm fold: (sum, sum of squares) per row and 128-column panel of h
+  w.stats = take(D.M * 4 * 2 * 4);           // LayerNorm fold: (sum, centred sum of squares) per row and 128-column panel of h
   w.total = o;
   return w;
 }
@@ -840,10 +852,10 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   // bound by the per-launch floor (~4.4 us) and a fetch-bound projection.  Two of their workgroups (one per 32 rows of a sample)
   // are resident per CU; same-call A/B, forward, fused vs not: B = 32 (224 workgroups) 0.996 vs 1.097 ms, B = 40 1.221 vs
   // 1.262, B = 64 (448) 1.521 vs 1.614, B = 73 1.640 vs 1.733, B = 96 (672) 2.067 vs 2.100, B = 128 (896) 2.512 vs 2.516,
-  // B = 256 4.393 vs 4.377: used up to 768 workgroups.  HIG_FUSE_OUT=0 switches it off, n >= 2 moves the limit to 256 n.
+  // B = 256 4.393 vs 4.377: used up to 3 workgroups per CU (768).  HIG_FUSE_OUT=0 switches it off, n >= 2 moves the limit to n per CU.
   static const int fuse_out_env = getenv("HIG_FUSE_OUT") ? atoi(getenv("HIG_FUSE_OUT")) : 1;   // tuning knob
   const bool fuse_out = fuse_out_env && fuse_mm16 && d == 512 && D.hd == 64 && D.H == 8 &&
-                        (int64_t)((D.T + 31) / 32) * D.B <= (fuse_out_env >= 2 ? 256 * fuse_out_env : 768);
+                        (int64_t)((D.T + 31) / 32) * D.B <= (int64_t)hig_chip_cus() * (fuse_out_env >= 2 ? fuse_out_env : 3);
   auto attend = [&](int l, int slot, const void* q, int64_t ldq, const float* ctx, const void* ctx_t16, int norm_w, int norm_b,
                     int out_w, int out_b) -> int {
     if (fuse_apply) {

@@ -905,11 +905,12 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
   // 1/s of a tile (see KArgs).  Exact-fp32 products, whole rounds in front, reduce slices of >= 2 k-tiles.
   static const int tail_on = getenv("HIG_GEMM_TAIL") ? atoi(getenv("HIG_GEMM_TAIL")) : 1;   // tuning knob
   if constexpr (!X_RS) {
-    if (tail_on && BI == 64 && BJ == 64 && splits == 1 && fast && g.prec == HIG_PREC_F32 && g_tail.ws && a.ntiles > 256 &&
-        a.ntiles % 256 != 0) {
-      const int rem = a.ntiles % 256, nkt = g.R / BK;
+    const int ncu = hig_chip_cus();
+    if (tail_on && BI == 64 && BJ == 64 && splits == 1 && fast && g.prec == HIG_PREC_F32 && g_tail.ws && a.ntiles > ncu &&
+        a.ntiles % ncu != 0) {
+      const int rem = a.ntiles % ncu, nkt = g.R / BK;
       int s = 1;
-      while (2 * s * rem <= 256 && nkt % (2 * s) == 0 && nkt / (2 * s) >= 2) s *= 2;
+      while (2 * s * rem <= ncu && nkt % (2 * s) == 0 && nkt / (2 * s) >= 2) s *= 2;
       constexpr int64_t unit_bytes = (int64_t)NTHREADS * (BI / 64) * (BJ / 64) * 16 * 4;
       if (s > 1 && rem <= HIG_GEMM_TAIL_CNT_BYTES / 4 && rem * s * unit_bytes <= g_tail.ws_bytes) {
         a.tail_s = s;
@@ -922,7 +923,7 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
       }
     }
   }
-  int gridx = 256 * per_cu;
+  int gridx = hig_chip_cus() * per_cu;
   if (gridx > a.ntiles || forced_per_cu == 0) gridx = a.ntiles;   // 0: one workgroup per tile
   if (a.ntiles > 0 && g.R >= 0) {
     // the bf16 product modes exist for aligned reduce-contiguous operands; anything else
@@ -979,10 +980,11 @@ int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab,
                          {64, 64, bf ? 1.20 : 1.04}};
   int best = 0;
   double best_cost = 1e300;
+  const int ncu = hig_chip_cus();
   static const int forced = getenv("HIG_GEMM_TILE") ? atoi(getenv("HIG_GEMM_TILE")) : -1;  // tuning knob
   for (int c = 0; c < 4 && forced < 0; ++c) {
     const int64_t tiles = (int64_t)((g.I + cands[c].bi - 1) / cands[c].bi) * ((g.J + cands[c].bj - 1) / cands[c].bj);
-    const int64_t rounds = (tiles + 255) / 256;
+    const int64_t rounds = (tiles + ncu - 1) / ncu;
     const double cost = (double)rounds * cands[c].bi * cands[c].bj * cands[c].ovh;
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
@@ -993,7 +995,7 @@ int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab,
   static const int f32_rule = getenv("HIG_F32_TILE_RULE") ? atoi(getenv("HIG_F32_TILE_RULE")) : 1;   // tuning knob
   if (!bf && forced < 0 && f32_rule) {
     const int64_t t64 = (int64_t)((g.I + 63) / 64) * ((g.J + 63) / 64);
-    if (t64 > 256) best = 3;
+    if (t64 > ncu) best = 3;
   }
   if (bf && forced < 0) {
     // bf16 products: the MFMA part is short, so per-tile latency and the number of workgroups in flight decide.
@@ -1019,6 +1021,31 @@ int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab,
 namespace {
 int gemm_dispatch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_t st, const SplitEpilogue& se);
 }
+// hig_host.h: compute units of the current device (cached per device; 256 on an MI355X in SPX mode)
+int hig_chip_cus() {
+  static int cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = __atomic_load_n(&cache[dev], __ATOMIC_RELAXED);
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    static const int forced = getenv("HIG_CHIP_CUS") ? atoi(getenv("HIG_CHIP_CUS")) : 0;   // testing knob: pretend another chip
+    if (forced > 0) v = forced;
+    __atomic_store_n(&cache[dev], v, __ATOMIC_RELAXED);
+  }
+  return v;
+}
+
+int hig_reduce_slabs(const float* slabs, int splits, int64_t slab, int64_t n, float* out, hipStream_t st) {
+  const int64_t n4 = n / 4;
+  const int64_t want = (n4 + 255) / 256;
+  const int blocks = (int)(want > 2048 ? 2048 : (want < 1 ? 1 : want));
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, splits, slab, n4, out, (int64_t)0,
+                     (float*)nullptr, SplitEpilogue{nullptr, nullptr, 0, 1});
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
 int hig_gemm_launch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_t st) {
   return gemm_dispatch(g, splits, slabs, st, SplitEpilogue{nullptr, nullptr, 0, 1});
 }

@@ -26,6 +26,9 @@ namespace {
 struct K16Args {
   hig_gemm16_desc g;
   int nbj, ntiles;
+  int nxy;          // tiles of ONE split (ntiles = nxy * splits)
+  int chunk;        // reduce elements per split (g.R when splits == 1): split s covers [s chunk, (s + 1) chunk)
+  int64_t slab;     // elements between the outputs of consecutive splits (fp32 slabs, summed by hig_reduce_slabs)
   int vec;          // C / res rows allow 16-byte (bf16) / 32-byte (fp32) row pieces
   unsigned long long* stamps;   // HIG_BF16_DBG & 16: per-workgroup s_memtime stamps of the first tile's phases (diagnostic build of the run)
   int dbg;          // timing ablations (HIG_BF16_DBG; results are wrong): 2 = no epilogue, 8 = epilogue without global
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Arg
   const int lr = lane & 31, lh = lane >> 5;
   const __bf16* __restrict__ X = static_cast<const __bf16*>(g.X);
   const __bf16* __restrict__ Y = static_cast<const __bf16*>(g.Y);
-  const int nk = g.R / BK;
+  const int nk = a.chunk / BK;
   // buffer descriptors (SGPRs): whole operand extents, raw (stride 0) buffers; rows are clamped, so nothing is out of range
   [[maybe_unused]] __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(X), 0, (int)(((int64_t)(g.I - 1) * g.ldx + g.R) * 2), 0x00020000);
   [[maybe_unused]] __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Y), 0, (int)(((int64_t)(g.J - 1) * g.ldy + g.R) * 2), 0x00020000);
@@ -100,8 +103,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Arg
     // XCD-aware order: blocks b, b + 8, ... share an XCD (private L2): give each XCD a contiguous run of tiles, column
     // tiles of one row panel next to each other, so the X panel is fetched from HBM once per XCD
     const int q8 = a.ntiles >> 3, r8 = a.ntiles & 7, xcd = lin & 7;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+    const int unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+    // split-R launches (weight gradients of the bf16-storage training step: reduce extent = B T rows): unit = (split, tile),
+    // split-major, so the tiles an XCD walks next to each other share their operand panels
+    const int split = unit / a.nxy, tile = unit - split * a.nxy;
     const int i0 = (tile / a.nbj) * BM, j0 = (tile % a.nbj) * BN;
+    const int64_t k0 = (int64_t)split * a.chunk;      // first reduce element of this unit
 
     // per-lane DMA sources: instruction q of this wave covers RPI rows of the A (X) or B (Y) tile.
     // SRD form: `buffer_load_dwordx4 ... lds` through a buffer descriptor in SGPRs -- the per-lane part is a 32-bit byte
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Arg
     const __bf16* src[NQ];
     int voff[NQ];
     int dst[NQ];
-    [[maybe_unused]] int koff = 0;
+    [[maybe_unused]] int koff = (int)(k0 * 2);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int n = wave + NW * q;                     // instruction index in [A tile | B tile] order
@@ -120,8 +127,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Arg
       if (SRD) {
         voff[q] = isA ? (min(i0 + r, g.I - 1) * (int)g.ldx + 8 * c) * 2 : (min(j0 + r, g.J - 1) * (int)g.ldy + 8 * c) * 2;
       } else {
-        src[q] = isA ? X + (int64_t)min(i0 + r, g.I - 1) * g.ldx + 8 * c
-                     : Y + (int64_t)min(j0 + r, g.J - 1) * g.ldy + 8 * c;
+        src[q] = isA ? X + (int64_t)min(i0 + r, g.I - 1) * g.ldx + 8 * c + k0
+                     : Y + (int64_t)min(j0 + r, g.J - 1) * g.ldy + 8 * c + k0;
       }
       dst[q] = (isA ? 0 : A_BYTES) + (isA ? n : n - NA) * 1024;
     }
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Arg
     for (int u = 0; u < NBS; ++u) {
       const int ju = j0 + 8 * ((tid + NT * u) % Q8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) b8[u][e] = (EPI != HIG_EPI_NONE) ? g.bias[min(ju + e, g.J - 1)] : 0.f;
+      for (int e = 0; e < 8; ++e) b8[u][e] = epi_has_bias(EPI) ? g.bias[min(ju + e, g.J - 1)] : 0.f;
     }
 
     f32x16 acc[TJ][TI];
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Arg
       continue;
     }
     float* sC = reinterpret_cast<float*>(smem);
-    constexpr bool HAS_RES = EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU;
+    constexpr bool HAS_RES = epi_has_res(EPI);
     // LDS-only barrier: the output stores of one pass stay in flight across it (a __syncthreads() would wait vmcnt(0)
     // for them twice per tile: 16 of 43 us at the FFN shape, profiles/r02_notes.md)
     auto lds_barrier = [&]() {
@@ -276,28 +283,34 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Arg
           continue;
         }
         if (HAS_RES) {
+          float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           if (g.res_f32) {
             const float* rp = static_cast<const float*>(g.res) + (int64_t)i * g.ldr + j;
             if (full) {
               const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
-              v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+              rv[0] = r0.x; rv[1] = r0.y; rv[2] = r0.z; rv[3] = r0.w; rv[4] = r1.x; rv[5] = r1.y; rv[6] = r1.z; rv[7] = r1.w;
             } else {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) if (j + e < g.J) v[e] += rp[e];
+              for (int e = 0; e < 8; ++e) if (j + e < g.J) rv[e] = rp[e];
             }
           } else if (full) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)r16[sw][e];
+            for (int e = 0; e < 8; ++e) rv[e] = (float)r16[sw][e];
           } else {
             const __bf16* rp = static_cast<const __bf16*>(g.res) + (int64_t)i * g.ldr + j;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) if (j + e < g.J) v[e] += (float)rp[e];
+            for (int e = 0; e < 8; ++e) if (j + e < g.J) rv[e] = (float)rp[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (EPI == HIG_EPI_DGELU) v[e] *= dgelu_bf16(rv[e]);   // `res` = z of FFN linear1 (data gradient through the GELU)
+            else v[e] += rv[e];
           }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = epi_act<EPI>(v[e]);
         if (g.c_f32) {
-          float* cp = static_cast<float*>(g.C) + (int64_t)i * g.ldc + j;
+          float* cp = static_cast<float*>(g.C) + (int64_t)split * a.slab + (int64_t)i * g.ldc + j;
           if (full) {
             *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -325,14 +338,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Arg
 }
 
 template <int WM, int WN, int TI, int TJ, int BK, int NS, int EPI>
-int launch16(const hig_gemm16_desc& g, hipStream_t st) {
+int launch16(const hig_gemm16_desc& g, hipStream_t st, int splits = 1, int64_t slab = 0) {
   static const int use_srd = getenv("HIG_BF16_SRD") ? atoi(getenv("HIG_BF16_SRD")) : 1;   // tuning knob: 0 = global_load_lds
   constexpr int NT = 64 * WM * WN, BM = 32 * TI * WM, BN = 32 * TJ * WN;
   K16Args a;
   a.g = g;
   const int nbi = (g.I + BM - 1) / BM;
   a.nbj = (g.J + BN - 1) / BN;
-  a.ntiles = nbi * a.nbj;
+  a.nxy = nbi * a.nbj;
+  a.ntiles = a.nxy * splits;
+  a.chunk = g.R / splits;
+  a.slab = slab;
   auto al = [](const void* p, int n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
   a.vec = (g.c_f32 ? (g.ldc % 4 == 0 && al(g.C, 16)) : (g.ldc % 8 == 0 && al(g.C, 16)));
   if (g.res) a.vec = a.vec && (g.res_f32 ? (g.ldr % 4 == 0 && al(g.res, 16)) : (g.ldr % 8 == 0 && al(g.res, 16)));
@@ -344,7 +360,7 @@ int launch16(const hig_gemm16_desc& g, hipStream_t st) {
   static const int dbg = getenv("HIG_BF16_DBG") ? atoi(getenv("HIG_BF16_DBG")) : 0;
   a.dbg = g_stamps ? dbg : (dbg & ~16);
   a.stamps = g_stamps;
-  int grid = 256 * per_cu;
+  int grid = hig_chip_cus() * per_cu;
   if (grid > a.ntiles) grid = a.ntiles;
   // (operands beyond 2 GiB would overflow the 32-bit byte offsets of the descriptor form)
   const bool srd_ok = ((int64_t)g.I * g.ldx < (1ll << 30)) && ((int64_t)g.J * g.ldy < (1ll << 30));
@@ -373,10 +389,11 @@ int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
     // estimated time = rounds x relative cost of one tile (fitted to tools/gemm16_bench.py at M = 6272 and 12544,
     // profiles/r02_notes.md: a 64 x 128 tile costs 0.75 of a 128 x 128 one, not the 0.5 of its area -- it re-reads the
     // same weight panel for half the rows)
-    const double c128 = (double)rounds(t128, 512) * 1.0, c64 = (double)rounds(t64, 768) * 0.75;
+    const int ncu = hig_chip_cus();   // 2 resident 128-row workgroups per CU, 3 of the 64-row ones
+    const double c128 = (double)rounds(t128, 2 * ncu) * 1.0, c64 = (double)rounds(t64, 3 * ncu) * 0.75;
     pick = 128;
     double best = c128;
-    if (t128 < 256 && c64 <= best * 1.25) { pick = 64; best = c64; }        // too few big tiles to occupy the chip
+    if (t128 < ncu && c64 <= best * 1.25) { pick = 64; best = c64; }        // too few big tiles to occupy the chip
     else if (c64 < best) { pick = 64; best = c64; }
     // 256 x 256 (8 waves, ONE workgroup per CU): the launch is bound by the ~30 B/clk each CU can DMA into its LDS, and a
     // 256 x 256 tile does twice the MFMA work per staged byte of two co-resident 128 x 128 tiles -- a round of 256 of
@@ -785,8 +802,8 @@ int hig_gemm16_launch(const hig_gemm16_desc& g, hipStream_t st) {
   HIG_REQUIRE(g.ldx % 8 == 0 && g.ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(g.X) & 15) == 0 &&
                   (reinterpret_cast<uintptr_t>(g.Y) & 15) == 0,
               "hig_gemm_bf16: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
-  if (g.epi != HIG_EPI_NONE) HIG_REQUIRE(g.bias, "hig_gemm_bf16: epilogue %d needs a bias", g.epi);
-  if (g.epi == HIG_EPI_BIAS_RES || g.epi == HIG_EPI_BIAS_RES_SILU) HIG_REQUIRE(g.res, "hig_gemm_bf16: missing residual");
+  if (epi_has_bias(g.epi)) HIG_REQUIRE(g.bias, "hig_gemm_bf16: epilogue %d needs a bias", g.epi);
+  if (epi_has_res(g.epi)) HIG_REQUIRE(g.res, "hig_gemm_bf16: epilogue %d needs `res`", g.epi);
   {   // many rows, short reduce range: the weight-stationary kernel (gemm_ws16.hip) when it serves the shape
     const int rc = hig_gemm_ws16_try(g, st);
     if (rc <= 0) return rc;
@@ -802,8 +819,56 @@ int hig_gemm16_launch(const hig_gemm16_desc& g, hipStream_t st) {
     case HIG_EPI_BIAS_RES: return launch16_sized<HIG_EPI_BIAS_RES>(g, st);
     case HIG_EPI_BIAS_SILU: return launch16_sized<HIG_EPI_BIAS_SILU>(g, st);
     case HIG_EPI_BIAS_RES_SILU: return launch16_sized<HIG_EPI_BIAS_RES_SILU>(g, st);
+    case HIG_EPI_RES: return launch16_sized<HIG_EPI_RES>(g, st);
+    case HIG_EPI_DGELU: return launch16_sized<HIG_EPI_DGELU>(g, st);
     default: return hig_set_error(HIG_EUNSUPPORTED, "hig_gemm_bf16: epilogue %d not built", g.epi);
   }
+}
+
+// Split-R form (weight gradients of the bf16-storage training step, dW = dC^T . act over the M = B T rows: few output tiles,
+// a long reduce range): the reduce range is cut into `splits` chunks, unit (split, tile) writes its partial tile to
+// slabs[split] (fp32, dense J-wide rows), hig_reduce_slabs sums them in split order into C (deterministic, no float
+// atomics).  EPI_NONE, fp32 C with ldc == J, R % (64 splits) == 0.  splits == 0: the library's rule (units fill the two
+// resident workgroups per CU without exceeding them).
+int hig_gemm16_split_splits(const hig_gemm16_desc& g, int64_t slab_floats) {
+  const int64_t tiles = (int64_t)((g.I + 127) / 128) * ((g.J + 127) / 128);
+  const int nk = g.R / 64;
+  int best = 1;
+  for (int s = 1; s <= nk && s <= 64; ++s) {
+    if (nk % s) continue;
+    if (tiles * s > 2 * (int64_t)hig_chip_cus() && s > 1) break;
+    if ((int64_t)s * g.I * g.J > slab_floats) break;
+    if (nk / s < 4 && s > 1) break;               // at least four k-tiles per unit: the DMA ring needs a few to overlap
+    best = s;
+  }
+  return best;
+}
+int hig_gemm16_split_launch(const hig_gemm16_desc& g0, int splits, float* slabs, int64_t slab_floats, hipStream_t st) {
+  HIG_REQUIRE(g0.X && g0.Y && g0.C && slabs, "hig_gemm_bf16_split: null operand");
+  HIG_REQUIRE(g0.epi == HIG_EPI_NONE && g0.c_f32 && g0.ldc == g0.J, "hig_gemm_bf16_split: EPI_NONE, dense fp32 C only");
+  HIG_REQUIRE(g0.R > 0 && g0.R % 64 == 0 && g0.ldx % 8 == 0 && g0.ldy % 8 == 0 &&
+                  (reinterpret_cast<uintptr_t>(g0.X) & 15) == 0 && (reinterpret_cast<uintptr_t>(g0.Y) & 15) == 0,
+              "hig_gemm_bf16_split: 16-byte aligned operands, leading dimensions multiples of 8, R a multiple of 64");
+  HIG_REQUIRE(((int64_t)g0.I * g0.J) % 4 == 0 && (reinterpret_cast<uintptr_t>(g0.C) & 15) == 0 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0,
+              "hig_gemm_bf16_split: I J must be a multiple of 4, C / slabs 16-byte aligned");
+  if (splits <= 0) splits = hig_gemm16_split_splits(g0, slab_floats);
+  HIG_REQUIRE((g0.R / 64) % splits == 0, "hig_gemm_bf16_split: splits=%d does not divide the %d k-tiles", splits, g0.R / 64);
+  const int64_t slab = (int64_t)g0.I * g0.J;
+  HIG_REQUIRE(splits == 1 || slab * splits <= slab_floats, "hig_gemm_bf16_split: slab scratch too small");
+  hig_gemm16_desc g = g0;
+  if (splits > 1) g.C = slabs;
+  // 128 x 128 tiles, two k-tiles of 64 in flight (long reduce range: the ring covers the DMA latency)
+  HIG_TRY((launch16<2, 2, 2, 2, 64, 2, HIG_EPI_NONE>(g, st, splits, slab)));
+  if (splits > 1) return hig_reduce_slabs(slabs, splits, slab, g0.I * (int64_t)g0.J, static_cast<float*>(g0.C), st);
+  return HIG_OK;
+}
+extern "C" int64_t hig_gemm_bf16_split_scratch_floats(const hig_gemm16_desc* g, int32_t splits) {
+  if (!g || g->I <= 0 || g->J <= 0) return -1;
+  return (int64_t)(splits > 0 ? splits : 64) * g->I * g->J;
+}
+extern "C" int hig_gemm_bf16_split(const hig_gemm16_desc* g, int32_t splits, float* slabs, int64_t slab_floats, hig_stream_t stream) {
+  HIG_REQUIRE(g, "hig_gemm_bf16_split: null descriptor");
+  return hig_gemm16_split_launch(*g, splits, slabs, slab_floats, hig_stream(stream));
 }
 
 extern "C" int hig_gemm_bf16(const hig_gemm16_desc* g, hig_stream_t stream) {

@@ -44,7 +44,7 @@ struct WsArgs {
   int g;         // row groups per XCD: slot s of an XCD works on panel s % np, row tiles rg, rg + g, ... (rg = s / np)
   int ntiles;    // 32-row tiles in all
   // LayerNorm folded into the NEXT GEMM (XT template parameter): a producer (XT = 1) also writes, per output row and column
-  // panel, (sum, sum of squares) of its bf16-rounded outputs to stats_out[row][np][2]; a consumer (XT = 2) reads
+  // panel, (sum, centred sum of squares) of its bf16-rounded outputs to stats_out[row][np][2]; a consumer (XT = 2) reads
   // stats_in[row][4][2] of its X rows and computes  rstd (x . W'^T) - rstd mean colsum + bias'  with W' = gamma (.) W.
   float* stats_out;
   const float* stats_in;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   constexpr int PPR = BN / 8;                  // 16-byte pieces per output row
   constexpr int NPC = BM * PPR / NT;           // pieces per thread in the store pass
   static_assert((BM * PPR) % NT == 0, "store pass split");
-  constexpr bool HAS_RES = EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU;
+  constexpr bool HAS_RES = epi_has_res(EPI);
   // 4-wave workgroups (one wave per SIMD, 512 registers each): X fragments are read XD k-steps ahead into a register ring
   // and the k-loop's order is pinned; 8-wave workgroups (256 registers per wave: the ring spills) leave the k-loop to hipcc
   constexpr bool RING = NW < 8 && OCC == 1;   // (two workgroups per CU: 256 registers again, and the other workgroup's waves hide the LDS latency)
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   float bq[BIAS_LDS ? 1 : NCB * 4 * NQF];
   if constexpr (BIAS_LDS) {
     static_assert(BN <= NT, "one thread per bias column");
-    if (tid < BN) sB[tid] = (EPI != HIG_EPI_NONE) ? a.bias[j0 + tid] : 0.f;    // (published by the barriers of the weight rounds)
+    if (tid < BN) sB[tid] = epi_has_bias(EPI) ? a.bias[j0 + tid] : 0.f;    // (published by the barriers of the weight rounds)
     if constexpr (XT == 2) { if (tid < BN) sC[tid] = a.colsum[j0 + tid]; }
   } else {
 #pragma unroll
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
       for (int u = 0; u < NQF; ++u)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          bq[(cb * NQF + u) * 4 + e] = (EPI != HIG_EPI_NONE) ? a.bias[j0 + 32 * (NCB * wj + cb) + 8 * (qf0 + u) + 4 * lh + e] : 0.f;
+          bq[(cb * NQF + u) * 4 + e] = epi_has_bias(EPI) ? a.bias[j0 + 32 * (NCB * wj + cb) + 8 * (qf0 + u) + 4 * lh + e] : 0.f;
   }
 
   // raw (stride 0) buffer descriptors over the whole operands; rows are clamped, so nothing is out of range
@@ -286,8 +286,9 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
     if constexpr (XT == 2) {
       if (j == 0) {                              // LayerNorm statistics of this lane's row from the four panel partials
         const f32x4 p0 = *reinterpret_cast<const f32x4*>(lnbuf + lr * 32), p1 = *reinterpret_cast<const f32x4*>(lnbuf + lr * 32 + 16);
-        const float mean = (p0.x + p0.z + p1.x + p1.z) * (1.0f / K);
-        const float var = fmaxf((p0.y + p0.w + p1.y + p1.w) * (1.0f / K) - mean * mean, 0.f);
+        static_assert(XT != 2 || K == 512, "panel merge: four 128-column panels");
+        float mean, var;
+        hig_ln_merge4(p0, p1, mean, var);
         ln_rstd = rsqrtf(var + 1e-5f);
         ln_mr = -mean * ln_rstd;
       }
@@ -302,7 +303,9 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
     if constexpr (HAS_RES) {
       if (e == 0) rq = *reinterpret_cast<const u32x2*>(rbuf + lr * SROWB + 16 * ((4 * (NCB * wj + cb) + qf0 + u) ^ (lr & 15)) + 8 * lh);
       const unsigned w = e < 2 ? rq.x : rq.y;
-      v += f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+      const f32x2 r2 = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+      if constexpr (EPI == HIG_EPI_DGELU) v = v * f32x2{dgelu_bf16(r2[0]), dgelu_bf16(r2[1])};   // `res` = z of FFN linear1
+      else v += r2;
     }
     ev[e >> 1] = (DBG & 2) ? v : epi_act_pk<EPI>(v);
     if (e == 2) {
@@ -348,25 +351,14 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
       const int i = min(i0 + r, a.I - 1);
       *reinterpret_cast<bf16x8*>(a.C + (int64_t)i * a.ldc + j0 + 8 * p) = v;
       if constexpr (XT == 1) {
-        // LayerNorm fold, producer side: (sum, sum of squares) of this row's 128 ROUNDED outputs (what the consumer will
-        // read).  The 16 lanes that hold a row's pieces are consecutive: v_dot2c_f32_bf16 on the packed pairs (x . (1, 1)
-        // and x . x, fp32 accumulate), four shuffle steps, lane 0 of the group writes.  Taken here, in the store pass,
-        // and not in the epilogue between the MFMAs (which is bound by instruction issue); no LDS staging.
+        // LayerNorm fold, producer side: (sum, sum of squared deviations from the panel mean) of this row's 128 ROUNDED
+        // outputs (what the consumer will read).  The 16 lanes that hold a row's pieces are consecutive: v_dot2c_f32_bf16
+        // on the packed pairs for the sum, four shuffle steps, then the centred squares (hig_panel_stats16); lane 0 of the
+        // group writes.  Taken here, in the store pass, and not in the epilogue between the MFMAs (which is bound by
+        // instruction issue); no LDS staging.
         static_assert(XT != 1 || PPR == 16, "row statistics: 128-column panels");
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const bf16x2_t pr = {v[2 * k], v[2 * k + 1]};
-          s1 = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, s1, false);
-          s2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, s2, false);
-        }
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-          s1 += __shfl_xor(s1, off, 64);
-          s2 += __shfl_xor(s2, off, 64);
-        }
+        float s1, s2;
+        hig_panel_stats16(v, s1, s2);
         if (p == 0) *reinterpret_cast<float2*>(a.stats_out + ((int64_t)i * a.np + panel) * 2) = make_float2(s1, s2);
       }
     }
@@ -553,7 +545,7 @@ int launch_ws_sized(const hig_gemm16_desc& g, int nwj, hipStream_t st) {
   // nwj: 8 = eight waves x 32 columns, 4 = four waves x 32 columns, 2 = four waves x 64 columns (256-column panels),
   // 44 = four waves x 32 columns laid out for TWO workgroups per CU (80 KB of LDS, 256 registers; epilogues without a
   // residual tile only)
-  constexpr bool has_res = EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_RES_SILU;
+  constexpr bool has_res = epi_has_res(EPI);
   if constexpr (!has_res) {
     if (nwj == 44 && g.R == 512 && !g.row_stats_in) return launch_ws<512, 1, 4, 1, EPI, 2>(g, 64, st);
     if (nwj == 44 && g.R == 256) return launch_ws<256, 1, 4, 1, EPI, 2>(g, 64, st);
@@ -580,7 +572,7 @@ int launch_ws_sized(const hig_gemm16_desc& g, int nwj, hipStream_t st) {
 
 }  // namespace
 
-static inline bool has_res_epi(int epi) { return epi == HIG_EPI_BIAS_RES || epi == HIG_EPI_BIAS_RES_SILU; }
+static inline bool has_res_epi(int epi) { return epi_has_res(epi); }
 
 // Returns HIG_OK when the launch was made, 1 when this kernel does not serve the shape (the caller falls back to the
 // tiled kernel), a negative HIG_E* code on error.
@@ -595,15 +587,25 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
                                      : (g.epi == HIG_EPI_BIAS && g.ln_colsum && g.J % 128 == 0));
     if (!ok) return hig_set_error(HIG_EUNSUPPORTED, "hig_gemm_bf16: LayerNorm-fold operands on a shape the weight-stationary kernel does not serve");
   }
-  if (!ws_on) return 1;
-  if (g.c_f32 || (g.res && g.res_f32)) return 1;
-  if (!(g.R == 256 || g.R == 512 || g.R == 1024)) return 1;
-  if (g.I < min_rows) return 1;
+  // `decline`: this kernel does not serve the call.  Without fold operands the caller falls back to the tiled / few-row
+  // kernels; WITH them it must not (those kernels know nothing of row_stats_* / ln_colsum: a producer would silently skip
+  // the statistics, a consumer would multiply un-normalised rows by W'), so every exit below is an error then.
+  auto decline = [&](const char* why) -> int {
+    return fold ? hig_set_error(HIG_EUNSUPPORTED, "hig_gemm_bf16: LayerNorm-fold operands, but %s", why) : 1;
+  };
+  if (!ws_on) return decline("the weight-stationary kernel is switched off (HIG_BF16_WS=0)");
+  // the kernel's work split is compiled for 8 XCDs x 32 CUs (block b -> XCD b & 7, 32 or 64 slots per XCD): another
+  // partitioning of the chip gets the tiled kernel, whose grid follows hig_chip_cus()
+  if (hig_chip_cus() != 256) return decline("the device does not report 256 compute units (8 XCDs x 32)");
+  if (g.c_f32 || (g.res && g.res_f32)) return decline("fp32 output / residual");
+  if (!(g.R == 256 || g.R == 512 || g.R == 1024)) return decline("reduce extent not in {256, 512, 1024}");
+  if (g.I < min_rows) return decline("too few rows");
   auto al = [](const void* p, int n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
-  if (!(g.ldc % 8 == 0 && al(g.C, 16))) return 1;
-  if ((int64_t)g.I * g.ldx >= (1ll << 30) || (int64_t)g.J * g.ldy >= (1ll << 30) || (g.res && (int64_t)g.I * g.ldr >= (1ll << 30))) return 1;   // 32-bit byte offsets of the DMA descriptors
-  const bool has_res = g.epi == HIG_EPI_BIAS_RES || g.epi == HIG_EPI_BIAS_RES_SILU;
-  if (has_res && !(g.ldr % 4 == 0 && al(g.res, 8))) return 1;
+  if (!(g.ldc % 8 == 0 && al(g.C, 16))) return decline("C not 16-byte aligned / ldc not a multiple of 8");
+  if ((int64_t)g.I * g.ldx >= (1ll << 30) || (int64_t)g.J * g.ldy >= (1ll << 30) || (g.res && (int64_t)g.I * g.ldr >= (1ll << 30)))
+    return decline("operand beyond the 32-bit byte offsets of the DMA descriptors");
+  const bool has_res = has_res_epi(g.epi);
+  if (has_res && !(g.ldr % 4 == 0 && al(g.res, 8))) return decline("residual not 8-byte aligned / ldr not a multiple of 4");
   // columns per CU: the weight panel is fetched once per workgroup (cols x K x 2 bytes at the CU's ~30 B/clk), the X
   // rows once per panel -- the sum is smallest near cols = sqrt(M N / 256)
   // (measured, tools/gemm16_bench.py: the 8-wave variant wins for the wide bias-only launches -- q/k/v at M = 12 544: 28 us
@@ -625,9 +627,9 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
   else if (forced_nwj == 4 || (forced_nwj == 8 && g.R != 1024) || (forced_nwj == 2 && g.R == 512) || (forced_nwj == 44 && g.R != 1024)) nwj = forced_nwj;
   const int bn = (nwj == 4 || nwj == 44) ? 128 : 256;
   if (g.J % bn != 0) {
-    if (g.J % 128 == 0) nwj = 4; else return 1;
+    if (g.J % 128 == 0) nwj = 4; else return decline("J not a multiple of 128");
   }
-  if (g.J / ((nwj == 4 || nwj == 44) ? 128 : 256) > 32) return 1;
+  if (g.J / ((nwj == 4 || nwj == 44) ? 128 : 256) > 32) return decline("more than 32 column panels");
   switch (g.epi) {
     case HIG_EPI_NONE: return launch_ws_sized<HIG_EPI_NONE>(g, nwj, st);
     case HIG_EPI_BIAS: return launch_ws_sized<HIG_EPI_BIAS>(g, nwj, st);
@@ -635,7 +637,9 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
     case HIG_EPI_BIAS_RES: return launch_ws_sized<HIG_EPI_BIAS_RES>(g, nwj, st);
     case HIG_EPI_BIAS_SILU: return launch_ws_sized<HIG_EPI_BIAS_SILU>(g, nwj, st);
     case HIG_EPI_BIAS_RES_SILU: return launch_ws_sized<HIG_EPI_BIAS_RES_SILU>(g, nwj, st);
-    default: return 1;
+    case HIG_EPI_RES: return launch_ws_sized<HIG_EPI_RES>(g, nwj, st);
+    case HIG_EPI_DGELU: return launch_ws_sized<HIG_EPI_DGELU>(g, nwj, st);
+    default: return decline("epilogue not built for this kernel");
   }
 }
 

@@ -17,7 +17,18 @@ constexpr int64_t HIG_GEMM_TAIL_CNT_BYTES = 1024;
 constexpr int64_t HIG_GEMM_TAIL_BYTES = HIG_GEMM_TAIL_CNT_BYTES + 256 * 16384;   // 256 slices of a 64x64 tile
 void hig_gemm_set_tail_scratch(void* ws, int64_t bytes);
 
+// Chip geometry of the CURRENT device, read once per device with hipDeviceGetAttribute (never a literal in a launch
+// rule): compute units, and XCDs = CUs / 32 (a gfx950 XCD has 32 active CUs; an MI355X in SPX mode reports 256 -> 8, a
+// CPX partition 32 -> 1).  Round-counting tile rules, persistent grid sizes and the residency limits of the fused
+// kernels are derived from these; kernels whose block -> XCD mapping is compiled for 8 XCDs decline on anything else.
+int hig_chip_cus();
+inline int hig_chip_xcds() { const int c = hig_chip_cus() / 32; return c < 1 ? 1 : c; }
+
 int hig_gemm16_launch(const hig_gemm16_desc& g, hipStream_t st);
+// split-R form of the tiled bf16 kernel + deterministic slab reduction (weight gradients); splits == 0: library rule
+int hig_gemm16_split_launch(const hig_gemm16_desc& g, int splits, float* slabs, int64_t slab_floats, hipStream_t st);
+// out[e] = sum_s slabs[s * slab + e], e < n (n % 4 == 0, 16-byte aligned), in split order (gemm.hip)
+int hig_reduce_slabs(const float* slabs, int splits, int64_t slab, int64_t n, float* out, hipStream_t st);
 // weight-stationary variant (gemm_ws16.hip): HIG_OK = launched, 1 = shape not served (use the tiled kernel), < 0 = error
 int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st);
 bool hig_gemm_ws16_lnfold_ok(int64_t rows, int d);
@@ -69,7 +80,7 @@ inline int wgrad_splits(int64_t I, int64_t J, int64_t R, int64_t slab_floats, in
   const int bi = wgrad_tile(I, J, prec);
   const int64_t tiles = ((I + bi - 1) / bi) * ((J + bi - 1) / bi);
   static const int forced_target = getenv("HIG_WGRAD_TARGET") ? atoi(getenv("HIG_WGRAD_TARGET")) : 0;  // tuning knob
-  const int target = forced_target > 0 ? forced_target : (bi == 128 ? 512 : 1024);
+  const int target = forced_target > 0 ? forced_target : (bi == 128 ? 2 : 4) * hig_chip_cus();
   int64_t s = target / tiles;
   const int64_t maxs = R / 256 > 1 ? R / 256 : 1;
   if (s > maxs) s = maxs;

@@ -14,6 +14,8 @@
 
 #include "hig_common.h"
 
+int hig_chip_cus();   // hig_host.h: compute units of the current device
+
 namespace {
 
 constexpr int CH = 64;  // rows staged per step
@@ -1179,7 +1181,7 @@ int linattn_ctx_t(const TIO* K, const TIO* V, int64_t ld, int32_t B, int32_t row
                   const int64_t* length, float* A, float* kstat, float* scratch, hipStream_t st, __bf16* At16 = nullptr) {
   const int nchunk = (rows + CH - 1) / CH;
   static const int ctx_walk = getenv("HIG_CTX_WALK") ? atoi(getenv("HIG_CTX_WALK")) : 1;   // tuning knob
-  const bool walk = ctx_walk && B * H >= 256;   // enough (sample, head) pairs to fill the chip with walking workgroups
+  const bool walk = ctx_walk && B * H >= hig_chip_cus();   // enough (sample, head) pairs to fill the chip with walking workgroups
   if (!walk && scratch && nchunk > 1) {
     // row chunks in parallel + a merge: 4-5x the workgroups of the one-per-(sample, head) kernel
     if (hd == 64) {
@@ -1211,7 +1213,7 @@ int linattn_apply_t(const TIO* Q, int64_t ldq, const float* A, TIO* Y, int64_t l
   // tools/attn_time.py: 61 -> 47 us at config 5, neutral at hd = 64)
   static const int apply_target = getenv("HIG_APPLY_WGS") ? atoi(getenv("HIG_APPLY_WGS")) : 0;   // tuning knob
   // (re-swept in round 2, profiles/r02_attn_sweep.md: hd = 128 at 256 / 512 / 1024 workgroups: 42.4 / 48.7 / 58.9 us)
-  const int target = apply_target > 0 ? apply_target : (hd == 128 ? 256 : 1024);
+  const int target = apply_target > 0 ? apply_target : (hd == 128 ? 1 : 4) * hig_chip_cus();
   int gy = (target + B * H - 1) / (B * H);
   gy = gy < 1 ? 1 : (gy > nchunk_a ? nchunk_a : gy);
   if (hd == 64)
@@ -1519,7 +1521,7 @@ extern "C" int hig_linattn_apply_bwd(const float* dY, int64_t lddy, const float*
     static const int tgt = getenv("HIG_APPLY_BWD_WGS") ? atoi(getenv("HIG_APPLY_BWD_WGS")) : 0;   // tuning knob
     // measured (tools/attn_time.py): one workgroup per (sample, head) walking all its chunks is fastest once
     // B * H fills the chip (config 2: 49 -> 38 us, config 5: 135 -> 77 us) and needs no partial sums at all
-    const int target = tgt > 0 ? tgt : 256;
+    const int target = tgt > 0 ? tgt : hig_chip_cus();
     nparts = (target + B * H - 1) / (B * H);
     nparts = nparts < 1 ? 1 : (nparts > nchunk ? nchunk : nparts);
     float* part = nparts == 1 ? dA : scratch;
@@ -1558,7 +1560,7 @@ extern "C" int hig_linattn_ctx_bwd(const float* dA, const float* A, const float*
   const int nchunk = (rows + CH - 1) / CH;
   if (hd == 64 || (hd == 128 && allow_big_lds() == 0)) {   // single pass (the column term comes from A and dA)
     static const int tgt = getenv("HIG_CTX_BWD_WGS") ? atoi(getenv("HIG_CTX_BWD_WGS")) : 0;   // tuning knob
-    const int target = tgt > 0 ? tgt : 256;
+    const int target = tgt > 0 ? tgt : hig_chip_cus();
     int gy = (target + B * H - 1) / (B * H);
     gy = gy < 1 ? 1 : (gy > nchunk ? nchunk : gy);
     if (hd == 64)

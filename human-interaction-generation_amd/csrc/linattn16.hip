@@ -60,7 +60,7 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // in LDS in exactly the layout the weight-stationary kernel reads its X tiles from, wave w owns output columns 64 w .. + 63,
 // the weight comes in MFMA-operand order (Y_frag layout of hig_weight_frag16) global -> registers, one coalesced KiB per
 // operand, eight k-steps ahead; the residual rows were fetched by DMA at the start and are updated in place in LDS; the new
-// rows leave as whole KiB, with their (sum, sum of squares) per 128-column panel when the next consumer folds its LayerNorm.
+// rows leave as whole KiB, with their (sum, centred sum of squares) per 128-column panel when the next consumer folds its LayerNorm.
 // Why: at M = 6 272 a launch costs ~4.4 us before its first instruction and the projection is bound by the CU's L2 fetch
 // rate either way (a workgroup streams the whole 512 KB weight here, 128 KB + its X tiles there): the pair apply (9.2 us)
 // + GEMM (10.5 us) becomes one launch.  Same products in the same order as the weight-stationary kernel.
@@ -128,20 +128,8 @@ __device__ __forceinline__ void out_gemm_rows(const char* sA, char* sH, const Ou
     const int64_t row = (int64_t)b * T + r0 + r;
     if (r0 + r < T) *reinterpret_cast<bf16x8*>(og.h + row * og.ldh + 8 * p) = v;
     if (og.stats) {
-      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-      const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bf16x2_t pr = {v[2 * k], v[2 * k + 1]};
-        s1 = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, s1, false);
-        s2 = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, s2, false);
-      }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) {
-        s1 += __shfl_xor(s1, off, 64);
-        s2 += __shfl_xor(s2, off, 64);
-      }
+      float s1, s2;
+      hig_panel_stats16(v, s1, s2);   // (sum, centred sum of squares) of the panel: the arithmetic of gemm_ws16's producer
       if ((p & 15) == 0 && r0 + r < T) *reinterpret_cast<float2*>(og.stats + (row * 4 + (p >> 4)) * 2) = make_float2(s1, s2);
     }
   }
@@ -751,7 +739,7 @@ extern "C" int hig_weight_frag16(const void* Y, int64_t ldy, int32_t J, int32_t 
 // hig_linattn_apply_sty_mm16 followed by the stylization block's output projection and residual update, as one kernel:
 //     h[rows] += silu( LN( softmax_hd(Q) . A ) * (1 + scale) + shift ) . W^T + bias          (transformer.py:111-118 then :81-86)
 // W_frag: the (d, d) weight in operand order (hig_weight_frag16); h bf16 (B * rows, d), updated in place; stats (nullable):
-// (sum, sum of squares) of the new rows per 128-column panel, [B * rows][4][2] fp32, for a LayerNorm-folding consumer
+// (sum, centred sum of squares) of the new rows per 128-column panel, [B * rows][4][2] fp32, for a LayerNorm-folding consumer
 // (hig_gemm16_desc.row_stats_in).  d = 512 with 8 heads of 64.
 extern "C" int hig_attn_out16(const void* Q, int64_t ldq, const void* At16, const float* gamma, const float* beta, const float* ss,
                               int64_t ss_ld, int32_t ss_shift_off, const void* W_frag, const float* bias, void* h, int64_t ldh,

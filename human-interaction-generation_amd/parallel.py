@@ -160,7 +160,8 @@ def run_distributed(fn, rank, world_size, backend=None, *args, set_device=True, 
     """One rank of a data-parallel job: `setup` + `ddp_train` of the reference launcher (tools/train.py:53-90) around
     `fn(rank, world_size, *args, **kwargs)`.  Rendezvous from MASTER_ADDR / MASTER_PORT (torchrun's variables work
     unchanged); backend "nccl" (= RCCL over xGMI) when a GPU is present, else "gloo" (the reference's choice,
-    tools/train.py:55) -- HIG_DIST_BACKEND overrides.  One process per GPU: rank r uses device r % device_count.
+    tools/train.py:55) -- HIG_DIST_BACKEND overrides.  One process per GPU: the device is LOCAL_RANK when the launcher
+    set it (torchrun), else rank % device_count.  Returns what `fn` returns.
     Barrier before `fn`, like the reference after creating its output directories; the group is destroyed afterwards,
     also when `fn` raises."""
     have_gpu = torch.cuda.device_count() > 0
@@ -169,7 +170,8 @@ def run_distributed(fn, rank, world_size, backend=None, *args, set_device=True, 
     os.environ.setdefault("MASTER_PORT", "29500")
     kw = {}
     if have_gpu and set_device:
-        dev = torch.device("cuda", rank % torch.cuda.device_count())
+        local = int(os.environ["LOCAL_RANK"]) if "LOCAL_RANK" in os.environ else rank
+        dev = torch.device("cuda", local % torch.cuda.device_count())
         torch.cuda.set_device(dev)
         if backend == "nccl":
             kw["device_id"] = dev
@@ -186,13 +188,16 @@ def launch(fn, world_size=None, backend=None, args=(), kwargs=None, port=None, s
     """`main` of the reference launcher (tools/train.py:92-102): one process per GPU of this node running
     `fn(rank, world_size, *args)` inside an initialised process group.  Under torchrun (RANK / WORLD_SIZE in the
     environment) the processes already exist: this one just joins as its rank.  Otherwise `world_size` processes
-    (default: one per visible GPU, at least one) are spawned, rendezvous on 127.0.0.1 at a free port.  The parent never
-    touches the GPU."""
+    (default: HIG_WORLD_SIZE, else one per visible GPU, at least one) are spawned, rendezvous on 127.0.0.1 at a free
+    port.  The parent launches no kernel and creates no HIP context of its own; counting the devices
+    (`torch.cuda.device_count()`, only when neither `world_size` nor HIG_WORLD_SIZE is given) is the one query it makes.
+    Return value: `fn`'s result when this process is itself a rank (torchrun), None after spawning (the children's
+    results stay in the children, as with the reference's `mp.spawn`)."""
     kwargs = kwargs or {}
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
         return run_distributed(fn, int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), backend, *args,
                                set_device=set_device, **kwargs)
-    world_size = world_size or max(1, torch.cuda.device_count())
+    world_size = world_size or int(os.environ.get("HIG_WORLD_SIZE", "0")) or max(1, torch.cuda.device_count())
     port = port or _free_port()
     import torch.multiprocessing as mp
     mp.spawn(_launch_entry, args=(fn, world_size, backend, args, kwargs, port, set_device), nprocs=world_size, join=True)

@@ -152,15 +152,35 @@ class DDPMTrainer(object):
         if world == 1 or hasattr(self.encoder, "module"):
             return
         # (under autograd the parameter gradients are tensors of their own -- _DenoiserFn.backward hands out copies of
-        # the flat buffer's views -- so they are packed into one message here, like one DDP bucket)
-        grads = [p.grad for p in self.encoder.parameters() if p.grad is not None]
-        if not grads:
+        # the flat buffer's views -- so they are packed into one message here, like one DDP bucket).  The message has a
+        # FIXED layout -- every trainable parameter in `parameters()` order, zeros where a rank produced no gradient --
+        # so that all ranks pair the same elements (DDP's buckets are laid out once, too); the buffer and its views are
+        # cached across steps.
+        params = [p for p in self.encoder.parameters() if p.requires_grad]
+        if not params:
             return
-        flat = torch._utils._flatten_dense_tensors(grads)
+        key = tuple((id(p), p.numel()) for p in params)
+        cache = getattr(self, "_exchange_cache", None)
+        if cache is None or cache[0] != key or cache[1].device != params[0].device:
+            flat = torch.zeros(sum(p.numel() for p in params), device=params[0].device, dtype=torch.float32)
+            views, o = [], 0
+            for p in params:
+                views.append(flat[o:o + p.numel()].view(p.shape))
+                o += p.numel()
+            cache = self._exchange_cache = (key, flat, views)
+        _, flat, views = cache
+        for p, v in zip(params, views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.mul_(1.0 / world)
-        for g, r in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-            g.copy_(r)
+        for p, v in zip(params, views):
+            if p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
 
     # ---- sampling ----------------------------------------------------------------------------------------------
     def generate_batch(self, caption, m_lens, dim_pose):

@@ -404,8 +404,9 @@ typedef struct hig_gemm16_desc {
   const float* bias;
   const void* res; int64_t ldr; int32_t res_f32;
   /* LayerNorm folded into the NEXT GEMM (weight-stationary kernel only: >= 2048 rows, R == 512; all NULL otherwise):
-   * row_stats_out (EPI_BIAS_RES, J == 512): also write (sum, sum of squares) of the bf16-rounded output rows per 128-column
-   * panel, [I][4][2] fp32.  row_stats_in + ln_colsum (EPI_BIAS): X holds UN-normalised rows whose statistics are in
+   * row_stats_out (EPI_BIAS_RES, J == 512): also write, per 128-column panel of the bf16-rounded output rows, (sum, sum of
+   * squared deviations from the panel's own mean), [I][4][2] fp32 -- the consumer merges the four panels into the row's
+   * mean and variance without forming E[x^2] - mean^2, so a large common offset of a row does not cost it its variance.  row_stats_in + ln_colsum (EPI_BIAS): X holds UN-normalised rows whose statistics are in
    * row_stats_in; Y must be W' = bf16(gamma (.) W), ln_colsum[j] = sum_r float(W'[j][r]), bias[j] = b[j] + sum_r beta[r] W[j][r]:
    * C = rstd (X W'^T) - rstd mean ln_colsum + bias  ==  LayerNorm(X) W^T + b  (transformer.py:108-110,144). */
   float* row_stats_out;
@@ -471,8 +472,8 @@ int hig_linattn_apply_sty_bf16(const void* Q, int64_t ldq, const float* A, const
  * a launch costs ~4.4 us on this part before its first instruction, and the projection is bound by the CU's L2 fetch rate
  * either way):  h[rows] += silu( LN( softmax_hd(Q) . A ) (1 + scale) + shift ) . W^T + bias   (transformer.py:111-118, :81-86).
  * W_frag: the (d, d) bf16 weight in matrix-core operand order: element (j, r) at ((j / 32) (d / 16) + r / 16) 512 + (j % 32 +
- * 32 ((r % 16) / 8)) 8 + r % 8 (hig_weight_frag16 builds it).  h bf16, updated in place.  stats (nullable): (sum, sum of
- * squares) of the new rows per 128-column panel, [B rows][4][2] fp32 -- what hig_gemm16_desc.row_stats_in consumes.  d = 512
+ * 32 ((r % 16) / 8)) 8 + r % 8 (hig_weight_frag16 builds it).  h bf16, updated in place.  stats (nullable): (sum, centred
+ * sum of squares) of the new rows per 128-column panel, [B rows][4][2] fp32 -- what hig_gemm16_desc.row_stats_in consumes.  d = 512
  * with 8 heads of 64. */
 int hig_attn_out16(const void* Q, int64_t ldq, const void* At16, const float* gamma, const float* beta, const float* ss,
                    int64_t ss_ld, int32_t ss_shift_off, const void* W_frag, const float* bias, void* h, int64_t ldh,
