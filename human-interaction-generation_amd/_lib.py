@@ -36,6 +36,10 @@ SYMBOLS = (
     "hig_clip_adam_lrdev", "hig_shutdown", "hig_gemm_split", "hig_gemm_split_scratch_floats",
     "hig_gemm_bf16", "hig_gemm_bf16_debug_stamps", "hig_gemm_ws16_debug_stamps", "hig_linattn16_debug_stamps", "hig_cast_bf16", "hig_ln_bf16", "hig_linattn_ctx_bf16", "hig_linattn_apply_bf16",
     "hig_text_context_bf16", "hig_denoiser_fwd_bf16", "hig_linattn_apply_sty_bf16", "hig_linattn_apply_sty_mm16", "hig_linattn_ctx_mm16", "hig_linattn_apply_sty", "hig_joint_embed_bf16", "hig_joint_embed_bf16_w", "hig_attn_out16", "hig_rows_out16", "hig_weight_frag16", "hig_joint_embed_bf16_scratch_bytes", "hig_fullattn_fwd_bf16", "hig_denoiser_bwd_hooked",
+    # round 4: bf16-storage training step
+    "hig_text_context_bf16_train", "hig_denoiser_fwd_bf16_train", "hig_denoiser_bwd_bf16", "hig_ln_bwd_bf16",
+    "hig_linattn_apply_bwd_bf16", "hig_linattn_ctx_bwd_bf16", "hig_colsum_bf16", "hig_transpose_bf16_batch", "hig_transpose_bf16",
+    "hig_gelu_bf16", "hig_cast_f32", "hig_gemm_bf16_split", "hig_gemm_bf16_split_scratch_floats", "hig_clip_adam_shadow",
 )
 
 
@@ -194,6 +198,22 @@ def lib():
         L.hig_transpose_batch.argtypes = [i32, vp, vp, vp, vp, vp]
         L.hig_recover_joints.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
         L.hig_gather_frames.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+        L.hig_text_context_bf16_train.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, vp]
+        L.hig_denoiser_fwd_bf16_train.argtypes = [C.POINTER(Dims)] + [vp] * 10
+        L.hig_denoiser_bwd_bf16.argtypes = [C.POINTER(Dims)] + [vp] * 15
+        L.hig_ln_bwd_bf16.argtypes = [vp, i64, vp, i32, i64, vp, vp, vp, i64, i32, i32, vp, i64, vp, i32, i64, i64, i32, i32,
+                                      vp, vp, vp, i64, vp, vp]
+        L.hig_linattn_apply_bwd_bf16.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, vp]
+        L.hig_linattn_ctx_bwd_bf16.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+        L.hig_colsum_bf16.argtypes = [vp, i64, i64, i32, vp, vp, vp]
+        L.hig_transpose_bf16_batch.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
+        L.hig_transpose_bf16.argtypes = [vp, i64, i32, i32, vp, i64, vp]
+        L.hig_gelu_bf16.argtypes = [vp, vp, i64, vp]
+        L.hig_cast_f32.argtypes = [vp, vp, i64, vp]
+        L.hig_gemm_bf16_split.argtypes = [C.POINTER(Gemm16Desc), i32, vp, i64, vp]
+        L.hig_gemm_bf16_split_scratch_floats.restype = i64
+        L.hig_gemm_bf16_split_scratch_floats.argtypes = [C.POINTER(Gemm16Desc), i32]
+        L.hig_clip_adam_shadow.argtypes = [vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, f32, vp, vp, vp, vp, i64, vp]
         _lib = L
     return _lib
 

@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
                                                         const float* __restrict__ partial,
                                                         float* __restrict__ gnorm_out,
                                                         const int32_t* __restrict__ step_dev,
-                                                        const float* __restrict__ lr_dev) {
+                                                        const float* __restrict__ lr_dev,
+                                                        __bf16* __restrict__ shadow, int64_t shadow_n) {
   __shared__ float red[256];
   __shared__ float s_coef, s_step_size, s_inv_sqrt_bc2;
   {
@@ -169,6 +170,10 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
       pp[e] -= step_size * (mm[e] / (sqrtf(v2[e]) * isb2 + eps));
     }
     reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    if (shadow && 4 * i + 3 < shadow_n) {   // bf16 shadow of the new parameters (bf16-storage training: no separate cast pass)
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      reinterpret_cast<bf16x4_t*>(shadow)[i] = bf16x4_t{(__bf16)pp[0], (__bf16)pp[1], (__bf16)pp[2], (__bf16)pp[3]};
+    }
     reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
     reinterpret_cast<float4*>(v)[i] = make_float4(v2[0], v2[1], v2[2], v2[3]);
   }
@@ -178,7 +183,9 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
     const float mm = b1 * m[i] + ob1 * gg, v2 = b2 * v[i] + ob2 * gg * gg;
     m[i] = mm;
     v[i] = v2;
-    p[i] -= step_size * (mm / (sqrtf(v2) * isb2 + eps));
+    const float pn = p[i] - step_size * (mm / (sqrtf(v2) * isb2 + eps));
+    p[i] = pn;
+    if (shadow && i < shadow_n) shadow[i] = (__bf16)pn;
   }
 }
 __global__ void inc_step_kernel(int32_t* s) { s[0] += 1; }
@@ -364,12 +371,20 @@ extern "C" int hig_clip_adam_lrdev(float* p, const float* g, float* m, float* v,
                                    const float* lr_dev, float b1, float b2, float eps, float max_norm,
                                    float inv_world, const float* scratch, float* gnorm_out, int32_t* step_dev,
                                    hig_stream_t s) {
+  return hig_clip_adam_shadow(p, g, m, v, n, lr, lr_dev, b1, b2, eps, max_norm, inv_world, scratch, gnorm_out, step_dev, nullptr, 0, s);
+}
+
+extern "C" int hig_clip_adam_shadow(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                                    const float* lr_dev, float b1, float b2, float eps, float max_norm,
+                                    float inv_world, const float* scratch, float* gnorm_out, int32_t* step_dev,
+                                    void* shadow16, int64_t shadow_n, hig_stream_t s) {
   HIG_REQUIRE(p && g && m && v && scratch && step_dev && n > 0, "hig_clip_adam: bad arguments");
   HIG_REQUIRE(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
-                reinterpret_cast<uintptr_t>(v)) & 15) == 0,
-              "hig_clip_adam: buffers must be 16-byte aligned");
+                reinterpret_cast<uintptr_t>(v)) & 15) == 0 && (reinterpret_cast<uintptr_t>(shadow16) & 7) == 0,
+              "hig_clip_adam: buffers must be 16-byte aligned (the bf16 shadow 8-byte)");
+  HIG_REQUIRE(!shadow16 || (shadow_n >= 0 && shadow_n <= n && shadow_n % 4 == 0), "hig_clip_adam: shadow_n must be a multiple of 4, <= n");
   hipLaunchKernelGGL(clip_adam_kernel, dim3(stream_blocks(n / 4 + 1)), dim3(256), 0, hig_stream(s), p, g, m, v,
-                     n, lr, b1, b2, eps, max_norm, inv_world, scratch, gnorm_out, step_dev, lr_dev);
+                     n, lr, b1, b2, eps, max_norm, inv_world, scratch, gnorm_out, step_dev, lr_dev, static_cast<__bf16*>(shadow16), shadow_n);
   HIG_CHECK_LAUNCH();
   hipLaunchKernelGGL(inc_step_kernel, dim3(1), dim3(1), 0, hig_stream(s), step_dev);
   HIG_CHECK_LAUNCH();

@@ -277,9 +277,14 @@ inline float* GL(void* const* t, int l, int idx) {
 namespace {
 int64_t fwd16_total(const Dims& D);
 int64_t text16_total(const Dims& D);
-int bf16_inference_only(const Dims& D, int training) {
-  if (D.bf16 && training) {
-    hig_set_error(HIG_EUNSUPPORTED, "hig: bf16 storage is inference-only (train with fp32 storage)");
+int64_t fwd16t_total(const Dims& D);
+int64_t text16t_total(const Dims& D);
+int64_t bwd16_total(const Dims& D);
+// the bf16-storage TRAINING step is built for the single-person model with linear attention
+int bf16_train_unsupported(const Dims& D, int training) {
+  if (D.bf16 && training && (D.two || D.full)) {
+    hig_set_error(HIG_EUNSUPPORTED, "hig: bf16-storage training is built for the single-person model with linear attention "
+                                    "(two_person=%d, attn_kind=%d: train with fp32 storage)", D.two, D.full);
     return 1;
   }
   return 0;
@@ -287,19 +292,20 @@ int bf16_inference_only(const Dims& D, int training) {
 }  // namespace
 extern "C" int64_t hig_workspace_bytes(const hig_dims* dims, int training) {
   Dims D;
-  if (check_dims(dims, D) != HIG_OK || bf16_inference_only(D, training)) return -1;
-  if (D.bf16) return fwd16_total(D);
+  if (check_dims(dims, D) != HIG_OK || bf16_train_unsupported(D, training)) return -1;
+  if (D.bf16) return training ? fwd16t_total(D) : fwd16_total(D);
   return fwd_layout(D, training).total * 4;
 }
 extern "C" int64_t hig_textctx_bytes(const hig_dims* dims, int training) {
   Dims D;
-  if (check_dims(dims, D) != HIG_OK || bf16_inference_only(D, training)) return -1;
-  if (D.bf16) return text16_total(D);
+  if (check_dims(dims, D) != HIG_OK || bf16_train_unsupported(D, training)) return -1;
+  if (D.bf16) return training ? text16t_total(D) : text16_total(D);
   return text_layout(D, training).total * 4;
 }
 extern "C" int64_t hig_bwd_workspace_bytes(const hig_dims* dims) {
   Dims D;
-  if (check_dims(dims, D) != HIG_OK || bf16_inference_only(D, 1)) return -1;
+  if (check_dims(dims, D) != HIG_OK || bf16_train_unsupported(D, 1)) return -1;
+  if (D.bf16) return bwd16_total(D);
   return bwd_layout(D).total * 4;
 }
 
@@ -1356,5 +1362,447 @@ extern "C" int hig_denoiser_bwd_hooked(const hig_dims* dims, const void* const* 
   HIG_CHECK_LAUNCH();
   HIG_TRY(colsum(b + bw.dte_h, E, D.B, E, GP(grads, HIG_P_TE0_B)));
   HIG_TRY(hig_gemm_launch(G(b + bw.dte_h, E, 1, ws + w.te, d, 1, GP(grads, HIG_P_TE0_W), d, E, d, D.B).g, 1, nullptr, st));
+  return HIG_OK;
+}
+
+
+// ==========================================================================================================
+// bf16-storage TRAINING step (include/hig.h: hig_denoiser_fwd_bf16_train / hig_denoiser_bwd_bf16).
+// Forward = the launch sequence of hig_denoiser_fwd_bf16 without the inference-only fusions (no in-place residual stream, no
+// LayerNorm fold, no fused stylization blocks) and with every layer's activations kept; backward = the adjoint of
+// hig_denoiser_bwd over bf16 rows.  Byte layouts, 256-byte granules.
+// ==========================================================================================================
+namespace {
+
+inline int64_t rup64(int64_t v) { return (v + 63) & ~(int64_t)63; }
+
+struct Fwd16TLayout {
+  int64_t te, te_h, emb, ss, few, few_bytes, h0, cscr, layer0, lstride;
+  int64_t xn1, qkv, A1, At1, kst1, y1, a1, h1, xn2, qc, y2, a2, h2, z1, f1, y3, a3, h3;
+  int64_t total;
+};
+Fwd16TLayout fwd16t_layout(const Dims& D) {
+  Fwd16TLayout w;
+  int64_t o = 0;
+  auto take = [&](int64_t n) { int64_t r = o; o += alb(n); return r; };
+  w.te = take((int64_t)D.B * D.d * 4);       // fp32: the per-sample embedding chain runs on the fp32 few-row kernels
+  w.te_h = take((int64_t)D.B * D.E * 4);
+  w.emb = take((int64_t)D.B * D.E * 4);
+  w.ss = take((int64_t)D.B * D.nsty * D.L * 2 * D.d * 4);
+  w.few_bytes = (int64_t)64 * 1024 * 1024;   // split-R scratch of hig_gemm_few_rows
+  w.few = take(w.few_bytes);
+  w.h0 = take(D.M * D.d * 2);
+  w.cscr = take(hig_linattn_ctx_scratch_floats(D.B, D.T, D.H, D.hd) * 4);
+  w.layer0 = o;
+  o = 0;
+  w.xn1 = take(D.M * D.d * 2);
+  w.qkv = take(D.M * 3 * D.d * 2);
+  w.A1 = take((int64_t)D.B * D.H * D.hd * D.hd * 4);
+  w.At1 = take((int64_t)D.B * D.H * D.hd * D.hd * 2);
+  w.kst1 = take((int64_t)D.B * D.d * 2 * 4);
+  w.y1 = take(D.M * D.d * 2);
+  w.a1 = take(D.M * D.d * 2);
+  w.h1 = take(D.M * D.d * 2);
+  w.xn2 = take(D.M * D.d * 2);
+  w.qc = take(D.M * D.d * 2);
+  w.y2 = take(D.M * D.d * 2);
+  w.a2 = take(D.M * D.d * 2);
+  w.h2 = take(D.M * D.d * 2);
+  w.z1 = take(D.M * D.ff * 2);
+  w.f1 = take(D.M * D.ff * 2);
+  w.y3 = take(D.M * D.d * 2);
+  w.a3 = take(D.M * D.d * 2);
+  w.h3 = take(D.M * D.d * 2);
+  w.lstride = o;
+  w.total = w.layer0 + w.lstride * D.L;
+  return w;
+}
+
+// text side, training: per layer the normalised text rows (operand of the key/value weight gradient), key/value (operands of
+// the context backward), the context matrices and their column-softmax statistics
+struct Text16TLayout {
+  int64_t cscr, layer0, lstride, xfn, kv, Ac, Atc, kstc, total;
+};
+Text16TLayout text16t_layout(const Dims& D) {
+  Text16TLayout t;
+  int64_t o = 0;
+  auto take = [&](int64_t n) { int64_t r = o; o += alb(n); return r; };
+  t.cscr = take(hig_linattn_ctx_scratch_floats(D.B, D.N, D.H, D.hd) * 4);
+  t.layer0 = o;
+  o = 0;
+  t.xfn = take(D.Mt * D.Lt * 2);
+  t.kv = take(D.Mt * 2 * D.d * 2);
+  t.Ac = take((int64_t)D.B * D.H * D.hd * D.hd * 4);
+  t.Atc = take((int64_t)D.B * D.H * D.hd * D.hd * 2);
+  t.kstc = take((int64_t)D.B * D.d * 2 * 4);
+  t.lstride = o;
+  t.total = t.layer0 + t.lstride * D.L;
+  return t;
+}
+
+struct Bwd16Layout {
+  int64_t dhA, dhB, t1, t2, tff, dqkv, dA, dkv, dxfn, dss, demb, dtmp, dte_h, slabs, slab_floats, colpart, colpart_w, lnpart,
+      wT, tA, tB, attn, f32a, f32b, Mp, Mtp, total;
+};
+Bwd16Layout bwd16_layout(const Dims& D) {
+  Bwd16Layout w;
+  int64_t o = 0;
+  auto take = [&](int64_t n) { int64_t r = o; o += alb(n); return r; };
+  w.Mp = rup64(D.M);      // reduce extents of the weight-gradient GEMMs, padded to whole 64-deep k-tiles (zeros behind M)
+  w.Mtp = rup64(D.Mt);
+  w.dhA = take(D.M * D.d * 2);
+  w.dhB = take(D.M * D.d * 2);
+  w.t1 = take(D.M * D.d * 2);
+  w.t2 = take(D.M * D.d * 2);
+  w.tff = take(D.M * D.ff * 2);
+  w.dqkv = take(D.M * 3 * D.d * 2);
+  w.dA = take((int64_t)D.B * D.H * D.hd * D.hd * 4);
+  w.dkv = take(D.Mt * 2 * D.d * 2);
+  w.dxfn = take(D.Mt * D.Lt * 2);
+  w.dss = take((int64_t)D.B * D.nsty * D.L * 2 * D.d * 4);
+  w.demb = take((int64_t)D.B * D.E * 4);
+  w.dtmp = take((int64_t)D.B * D.E * 4);
+  w.dte_h = take((int64_t)D.B * D.E * 4);
+  int64_t biggest = 0;
+  const int64_t outs[] = {(int64_t)3 * D.d * D.d, (int64_t)D.d * D.d, (int64_t)D.ff * D.d, (int64_t)2 * D.d * D.Lt,
+                          (int64_t)D.F * D.d, (int64_t)D.B * D.E, (int64_t)D.E * D.E, (int64_t)D.E * D.d};
+  for (int64_t v : outs) biggest = v > biggest ? v : biggest;
+  w.slab_floats = biggest * 16 > (int64_t)1536 * 128 * 128 ? biggest * 16 : (int64_t)1536 * 128 * 128;
+  w.slabs = take(w.slab_floats * 4);
+  int64_t colp = 0;
+  const int64_t uses[][2] = {{D.M, 3 * D.d}, {D.M, D.ff}, {D.M, D.F}, {D.Mt, 2 * D.d}, {D.B, D.E},
+                             {D.B, (int64_t)D.nsty * D.L * 2 * D.d}, {D.B, (int64_t)D.T * D.d}};
+  for (auto& u : uses) {
+    const int64_t v = (int64_t)hig_colsum_chunks(u[0]) * u[1];
+    colp = v > colp ? v : colp;
+  }
+  w.colpart = take(colp * 4);
+  w.colpart_w = take(colp * 4);
+  const int64_t lp = hig_ln_bwd_partial_floats(D.M, D.d, D.T), lpt = hig_ln_bwd_partial_floats(D.Mt, D.Lt, D.N);
+  w.lnpart = take((lp > lpt ? lp : lpt) * 4);
+  w.wT = take(((int64_t)5 * D.d * D.d + (int64_t)3 * D.d * D.d + (int64_t)2 * D.d * D.ff + (int64_t)2 * D.d * D.Lt) * 2);
+  const int64_t mrows = w.Mp > w.Mtp ? w.Mp : w.Mtp;
+  const int64_t wide = 3 * D.d > D.ff ? 3 * D.d : D.ff;
+  w.tA = take(wide * mrows * 2);
+  w.tB = take((int64_t)(D.ff > D.d ? (D.ff > D.Lt ? D.ff : D.Lt) : (D.d > D.Lt ? D.d : D.Lt)) * mrows * 2);
+  const int64_t as1 = hig_linattn_bwd_scratch_floats(D.B, D.T, D.H, D.hd), as2 = hig_linattn_bwd_scratch_floats(D.B, D.N, D.H, D.hd);
+  w.attn = take((as1 > as2 ? as1 : as2) * 4);
+  w.f32a = take(D.M * D.d * 4);     // fp32 copies at the F-wide edges (input / output projection run on the fp32 kernels)
+  w.f32b = take(D.M * D.d * 4);
+  w.total = o;
+  return w;
+}
+
+int64_t fwd16t_total(const Dims& D) { return fwd16t_layout(D).total; }
+int64_t text16t_total(const Dims& D) { return text16t_layout(D).total; }
+int64_t bwd16_total(const Dims& D) { return bwd16_layout(D).total; }
+
+int require_bf16_train(const Dims& D, const char* who) {
+  if (!D.bf16) return hig_set_error(HIG_EINVAL, "%s: dims->storage must be HIG_STORE_BF16", who);
+  if (bf16_train_unsupported(D, 1)) return HIG_EUNSUPPORTED;
+  return HIG_OK;
+}
+
+}  // namespace
+
+extern "C" int hig_text_context_bf16_train(const hig_dims* dims, const void* const* params, const void* const* params16,
+                                           const float* xf_out, void* textctx, hig_stream_t stream) {
+  Dims D;
+  HIG_TRY(check_dims(dims, D));
+  HIG_TRY(require_bf16_train(D, "hig_text_context_bf16_train"));
+  HIG_REQUIRE(params && params16 && xf_out && textctx, "hig_text_context_bf16_train: null argument");
+  const Text16TLayout tl = text16t_layout(D);
+  char* base = static_cast<char*>(textctx);
+  hipStream_t st = hig_stream(stream);
+  for (int l = 0; l < D.L; ++l) {
+    char* lb = base + tl.layer0 + tl.lstride * l;
+    // text_norm of THIS layer, [key; value] projection, softmax over the N tokens, A_c = k^T v   (transformer.py:146-152)
+    HIG_TRY(hig_ln_bf16(xf_out, 1, D.Lt, D.Mt, D.Lt, PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B), nullptr, 0, 0, 0,
+                        lb + tl.xfn, D.Lt, stream));
+    HIG_TRY(hig_gemm16_launch(G16(lb + tl.xfn, D.Lt, PL16(params16, l, HIG_L_CA_KV_W), D.Lt, lb + tl.kv, 2 * D.d, D.Mt, 2 * D.d, D.Lt)
+                                  .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_KV_B)).g, st));
+    HIG_TRY(ctx16(D, lb + tl.kv, lb + tl.kv + (int64_t)D.d * 2, 2 * D.d, D.B, D.N, nullptr, reinterpret_cast<float*>(lb + tl.Ac),
+                  reinterpret_cast<float*>(lb + tl.kstc), reinterpret_cast<float*>(base + tl.cscr), lb + tl.Atc, stream));
+  }
+  return HIG_OK;
+}
+
+extern "C" int hig_denoiser_fwd_bf16_train(const hig_dims* dims, const void* const* params, const void* const* params16,
+                                           const float* x, const int64_t* t, const int64_t* length, const float* xf_proj,
+                                           const void* textctx, float* out, void* workspace, hig_stream_t stream) {
+  Dims D;
+  HIG_TRY(check_dims(dims, D));
+  HIG_TRY(require_bf16_train(D, "hig_denoiser_fwd_bf16_train"));
+  HIG_REQUIRE(params && params16 && x && t && xf_proj && textctx && out && workspace, "hig_denoiser_fwd_bf16_train: null argument");
+  const Fwd16TLayout w = fwd16t_layout(D);
+  const Text16TLayout tl = text16t_layout(D);
+  char* ws = static_cast<char*>(workspace);
+  const char* tc = static_cast<const char*>(textctx);
+  hipStream_t st = hig_stream(stream);
+  const int d = D.d, E = D.E;
+  const int64_t M = D.M;
+  const int64_t ss_ld = (int64_t)D.nsty * D.L * 2 * d;
+  float* te = reinterpret_cast<float*>(ws + w.te);
+  float* te_h = reinterpret_cast<float*>(ws + w.te_h);
+  float* emb = reinterpret_cast<float*>(ws + w.emb);
+  float* ss = reinterpret_cast<float*>(ws + w.ss);
+  float* few = reinterpret_cast<float*>(ws + w.few);
+  const int64_t few_floats = w.few_bytes / 4;
+  // K0: the per-sample embedding chain in fp32 on the master weights (B rows: weight-bandwidth bound; its backward needs the
+  //     pre-activations te_h and emb in fp32)                                          (transformer.py:345-349,415,81-83)
+  HIG_TRY(hig_timestep_embedding(t, D.B, d, te, stream));
+  HIG_TRY(hig_gemm_few_rows(G(te, d, 0, P(params, HIG_P_TE0_W), d, 0, te_h, E, D.B, E, d).epi(HIG_EPI_BIAS, P(params, HIG_P_TE0_B)).g,
+                            few, few_floats, st));
+  HIG_TRY(hig_gemm_few_rows(G(te_h, E, 0, P(params, HIG_P_TE2_W), E, 0, emb, E, D.B, E, E).silu(0)
+                                .epi(HIG_EPI_BIAS_RES, P(params, HIG_P_TE2_B)).res(xf_proj, E).g, few, few_floats, st));
+  HIG_TRY(hig_gemm_few_rows(G(emb, E, 0, P(params, HIG_P_STY_EMB_W), E, 0, ss, ss_ld, D.B, ss_ld, E).silu(0)
+                                .epi(HIG_EPI_BIAS, P(params, HIG_P_STY_EMB_B)).g, few, few_floats, st));
+  // K1: h0 = joint_embed(x) + sequence_embedding[:T], rounded once into the bf16 residual stream
+  if (d % 128 == 0 && D.F <= 512) {
+    HIG_TRY(hig_joint_embed_bf16(x, M, D.F, P(params, HIG_P_JOINT_W), P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d, D.T, 0,
+                                 ws + w.h0, d, d, few, stream));
+  } else {
+    float* h32 = few;
+    HIG_REQUIRE(M * d * 4 <= w.few_bytes, "hig_denoiser_fwd_bf16_train: d %% 128 != 0 needs M d floats of scratch");
+    G ge(x, D.F, 0, P(params, HIG_P_JOINT_W), D.F, 0, h32, d, M, d, D.F);
+    ge.epi(HIG_EPI_BIAS_POS, P(params, HIG_P_JOINT_B)).pos(P(params, HIG_P_SEQ_EMB), d, D.T);
+    HIG_TRY(hig_gemm_launch(ge.g, 1, nullptr, st));
+    HIG_TRY(hig_cast_bf16(h32, ws + w.h0, M * d, stream));
+  }
+  const void* hin = ws + w.h0;
+  for (int l = 0; l < D.L; ++l) {
+    char* lb = ws + w.layer0 + w.lstride * l;
+    const float* ssl = ss + (int64_t)(D.nsty * l) * 2 * d;
+    // one stylization block: h_out = h_in + Lin_out( silu( LN(y) (1 + scale) + shift ) )     (transformer.py:81-86)
+    auto stylize = [&](int slot, const void* y, void* a, const void* h_in, void* h_out, int norm_w, int norm_b, int out_w, int out_b) -> int {
+      HIG_TRY(hig_ln_bf16(y, 0, d, M, d, PL(params, l, norm_w), PL(params, l, norm_b), ssl + (int64_t)slot * 2 * d, ss_ld, d, D.T, a, d, stream));
+      return hig_gemm16_launch(G16(a, d, PL16(params16, l, out_w), d, h_out, d, M, d, d).epi(HIG_EPI_BIAS_RES, PL(params, l, out_b)).res16(h_in, d).g, st);
+    };
+    // ---- self attention (transformer.py:101-119) ----
+    HIG_TRY(hig_ln_bf16(hin, 0, d, M, d, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B), nullptr, 0, 0, 0, lb + w.xn1, d, stream));
+    HIG_TRY(hig_gemm16_launch(G16(lb + w.xn1, d, PL16(params16, l, HIG_L_SA_QKV_W), d, lb + w.qkv, 3 * d, M, 3 * d, d)
+                                  .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_SA_QKV_B)).g, st));
+    char* qkv = lb + w.qkv;
+    HIG_TRY(ctx16(D, qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, length, reinterpret_cast<float*>(lb + w.A1),
+                  reinterpret_cast<float*>(lb + w.kst1), reinterpret_cast<float*>(ws + w.cscr), lb + w.At1, stream));
+    HIG_TRY(hig_linattn_apply_bf16(qkv, 3 * d, reinterpret_cast<const float*>(lb + w.A1), lb + w.y1, d, D.B, D.T, D.H, D.hd, stream));
+    HIG_TRY(stylize(0, lb + w.y1, lb + w.a1, hin, lb + w.h1, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B));
+    // ---- cross attention to the text context (transformer.py:135-155) ----
+    HIG_TRY(hig_ln_bf16(lb + w.h1, 0, d, M, d, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B), nullptr, 0, 0, 0, lb + w.xn2, d, stream));
+    HIG_TRY(hig_gemm16_launch(G16(lb + w.xn2, d, PL16(params16, l, HIG_L_CA_Q_W), d, lb + w.qc, d, M, d, d)
+                                  .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).g, st));
+    HIG_TRY(hig_linattn_apply_bf16(lb + w.qc, d, reinterpret_cast<const float*>(tc + tl.layer0 + tl.lstride * l + tl.Ac), lb + w.y2, d, D.B,
+                                   D.T, D.H, D.hd, stream));
+    HIG_TRY(stylize(1, lb + w.y2, lb + w.a2, lb + w.h1, lb + w.h2, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B));
+    // ---- FFN (transformer.py:167-170): z = Lin1(h2) kept for gelu'(z), f = gelu(z) is linear2's operand ----
+    HIG_TRY(hig_gemm16_launch(G16(lb + w.h2, d, PL16(params16, l, HIG_L_FFN_W1), d, lb + w.z1, D.ff, M, D.ff, d)
+                                  .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B1)).g, st));
+    HIG_TRY(hig_gelu_bf16(lb + w.z1, lb + w.f1, M * D.ff, stream));
+    HIG_TRY(hig_gemm16_launch(G16(lb + w.f1, D.ff, PL16(params16, l, HIG_L_FFN_W2), D.ff, lb + w.y3, d, M, d, D.ff)
+                                  .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B2)).g, st));
+    HIG_TRY(stylize(2, lb + w.y3, lb + w.a3, lb + w.h2, lb + w.h3, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B, HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B));
+    hin = lb + w.h3;
+  }
+  // K6: out = Linear(d, F)(h_L), fp32
+  return hig_gemm16_launch(G16(hin, d, P16(params16, HIG_P_OUT_W), d, out, D.F, M, D.F, d).epi(HIG_EPI_BIAS, P(params, HIG_P_OUT_B)).out32().g, st);
+}
+
+extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* params, const void* const* params16, const float* x,
+                                     const int64_t* t, const int64_t* length, const float* xf_out, const void* textctx,
+                                     const void* workspace, const float* dout, void* const* grads, float* dx, float* dxf_proj,
+                                     float* dxf_out, void* bwd_workspace, hig_stream_t stream) {
+  (void)t;
+  Dims D;
+  HIG_TRY(check_dims(dims, D));
+  HIG_TRY(require_bf16_train(D, "hig_denoiser_bwd_bf16"));
+  HIG_REQUIRE(params && params16 && x && xf_out && textctx && workspace && dout && grads && dxf_proj && dxf_out && bwd_workspace,
+              "hig_denoiser_bwd_bf16: null argument");
+  const Fwd16TLayout w = fwd16t_layout(D);
+  const Text16TLayout tl = text16t_layout(D);
+  const Bwd16Layout bw = bwd16_layout(D);
+  const char* ws = static_cast<const char*>(workspace);
+  const char* tc = static_cast<const char*>(textctx);
+  char* b = static_cast<char*>(bwd_workspace);
+  hipStream_t st = hig_stream(stream);
+  const int d = D.d, E = D.E, ff = D.ff, F = D.F, Lt = D.Lt;
+  const int64_t M = D.M, Mt = D.Mt;
+  const int64_t ss_ld = (int64_t)D.nsty * D.L * 2 * d;
+  float* slabs = reinterpret_cast<float*>(b + bw.slabs);
+  float* colp = reinterpret_cast<float*>(b + bw.colpart);
+  float* colp_w = reinterpret_cast<float*>(b + bw.colpart_w);
+  float* lnp = reinterpret_cast<float*>(b + bw.lnpart);
+  float* dss = reinterpret_cast<float*>(b + bw.dss);
+  float* dA = reinterpret_cast<float*>(b + bw.dA);
+  float* attn = reinterpret_cast<float*>(b + bw.attn);
+  float* f32a = reinterpret_cast<float*>(b + bw.f32a);
+  float* f32b = reinterpret_cast<float*>(b + bw.f32b);
+  const float* ssf = reinterpret_cast<const float*>(ws + w.ss);
+  char* tA = b + bw.tA;
+  char* tB = b + bw.tB;
+  // the transposed weight-gradient operands are zero behind their M (Mt) valid columns: the transposes never write there
+  if (hipMemsetAsync(tA, 0, (size_t)(bw.tB - bw.tA), st) != hipSuccess || hipMemsetAsync(tB, 0, (size_t)(bw.attn - bw.tB), st) != hipSuccess)
+    return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+
+  WgradFork fork(side_stream_for_current_device(st), st);
+  hig_stream_t wstream = reinterpret_cast<hig_stream_t>(fork.stream());
+  // dW[n][k] = sum_m dC[m][n] act[m][k] (+ the bias gradient = column sums of dC): both operands transposed to
+  // reduce-contiguous bf16 (n_out x Mp), (k_in x Mp), then the split-R bf16 GEMM into the fp32 gradient.  Everything on the
+  // weight-gradient stream (protocol: WgradFork).
+  auto wgrad_act = [&](const void* dC, int n_out, const void* act, int k_in, float* out, int64_t rows, int64_t rows_p, float* dbias) -> int {
+    HIG_TRY(fork.begin());
+    if (dbias) HIG_TRY(hig_colsum_bf16(dC, n_out, rows, n_out, dbias, colp_w, wstream));
+    const void* srcs[2] = {dC, act};
+    void* dsts[2] = {tA, tB};
+    const int64_t lds_[2] = {n_out, k_in}, ldd[2] = {rows_p, rows_p};
+    const int32_t rws[2] = {(int32_t)rows, (int32_t)rows}, cls[2] = {n_out, k_in};
+    HIG_TRY(hig_transpose_bf16_batch(2, srcs, lds_, dsts, ldd, rws, cls, wstream));
+    G16 g(tA, rows_p, tB, rows_p, out, k_in, n_out, k_in, rows_p);
+    g.out32();
+    HIG_TRY(hig_gemm16_split_launch(g.g, 0, slabs, bw.slab_floats, fork.stream()));
+    return fork.end();
+  };
+  // fp32 weight gradients at the F-wide edges (operands fp32, reduce-slow): the fp32 kernel, split over the rows
+  auto wgrad32 = [&](G gd) -> int {
+    HIG_TRY(fork.begin());
+    const int s = wgrad_splits(gd.g.I, gd.g.J, gd.g.R, bw.slab_floats, gd.g.prec);
+    HIG_TRY(hig_gemm_launch(gd.g, s, slabs, fork.stream()));
+    return fork.end();
+  };
+  // one layer's transposed weights (bf16): operands of the data-gradient GEMMs dX = dC . W = dC . (W^T)^T
+  char* wT = b + bw.wT;
+  const int64_t o_sty3 = 0, o_w2t = o_sty3 + (int64_t)d * d * 2, o_w1t = o_w2t + (int64_t)d * ff * 2, o_sty2 = o_w1t + (int64_t)d * ff * 2,
+                o_caq = o_sty2 + (int64_t)d * d * 2, o_kv = o_caq + (int64_t)d * d * 2, o_sty1 = o_kv + (int64_t)2 * d * Lt * 2,
+                o_qkv = o_sty1 + (int64_t)d * d * 2;
+  auto dgrad = [&](const void* dC, int n_out, int64_t wt_off, void* dst, int k_in, int64_t rows, int epi, const void* res, int64_t ldr) -> int {
+    G16 g(dC, n_out, wT + wt_off, n_out, dst, k_in, rows, k_in, n_out);
+    g.g.epi = epi;
+    if (res) g.res16(res, ldr);
+    return hig_gemm16_launch(g.g, st);
+  };
+  auto sty_bwd = [&](int l, int s, const void* dh, const void* y, const void* a_saved, int norm_w, int norm_b, int out_w, int out_b,
+                     int64_t wt_off, void* dy_out) -> int {
+    HIG_TRY(wgrad_act(dh, d, a_saved, d, GL(grads, l, out_w), M, bw.Mp, GL(grads, l, out_b)));
+    HIG_TRY(dgrad(dh, d, wt_off, b + bw.t1, d, M, HIG_EPI_NONE, nullptr, 0));
+    return hig_ln_bwd_bf16(b + bw.t1, d, y, 0, d, PL(params, l, norm_w), PL(params, l, norm_b), ssf + (int64_t)s * 2 * d, ss_ld, d, 1, nullptr, 0,
+                           dy_out, 0, d, M, d, D.T, GL(grads, l, norm_w), GL(grads, l, norm_b), dss + (int64_t)s * 2 * d, ss_ld, lnp, stream);
+  };
+
+  // ---- output projection (F-wide: fp32 kernels) -------------------------------------------------------------------------
+  const char* hL = ws + w.layer0 + w.lstride * (D.L - 1) + w.h3;
+  char* dh = b + bw.dhA;
+  char* dh_alt = b + bw.dhB;
+  HIG_TRY(hig_colsum(dout, F, M, F, GP(grads, HIG_P_OUT_B), colp, stream));
+  HIG_TRY(hig_cast_f32(hL, f32a, M * d, stream));
+  HIG_TRY(wgrad32(G(dout, F, 1, f32a, d, 1, GP(grads, HIG_P_OUT_W), d, F, d, M)));
+  HIG_TRY(hig_gemm_launch(G(dout, F, 0, P(params, HIG_P_OUT_W), d, 1, f32b, d, M, d, F).g, 1, nullptr, st));
+  HIG_TRY(hig_cast_bf16(f32b, dh, M * d, stream));
+
+  for (int l = D.L - 1; l >= 0; --l) {
+    const char* lb = ws + w.layer0 + w.lstride * l;
+    const char* tlb = tc + tl.layer0 + tl.lstride * l;
+    const char* hin = l == 0 ? ws + w.h0 : ws + w.layer0 + w.lstride * (l - 1) + w.h3;
+    {  // all W -> W^T copies of this layer (from the bf16 shadow) in one launch
+      const void* srcs[8];
+      void* dsts[8];
+      int64_t lds_[8], ldd[8];
+      int32_t rws[8], cls[8];
+      int n = 0;
+      auto add = [&](int idx, int out_f, int in_f, int64_t off) {
+        srcs[n] = PL16(params16, l, idx); dsts[n] = wT + off; lds_[n] = in_f; ldd[n] = out_f; rws[n] = out_f; cls[n] = in_f; ++n;
+      };
+      add(HIG_L_FFN_STY_OUT_W, d, d, o_sty3);
+      add(HIG_L_FFN_W2, d, ff, o_w2t);
+      add(HIG_L_FFN_W1, ff, d, o_w1t);
+      add(HIG_L_CA_STY_OUT_W, d, d, o_sty2);
+      add(HIG_L_CA_Q_W, d, d, o_caq);
+      add(HIG_L_CA_KV_W, 2 * d, Lt, o_kv);
+      add(HIG_L_SA_STY_OUT_W, d, d, o_sty1);
+      add(HIG_L_SA_QKV_W, 3 * d, d, o_qkv);
+      HIG_TRY(hig_transpose_bf16_batch(n, srcs, lds_, dsts, ldd, rws, cls, stream));
+    }
+    // ---- FFN --------------------------------------------------------------------------
+    HIG_TRY(sty_bwd(l, D.nsty * l + 2, dh, lb + w.y3, lb + w.a3, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B, HIG_L_FFN_STY_OUT_W,
+                    HIG_L_FFN_STY_OUT_B, o_sty3, b + bw.t2));
+    const char* dy3 = b + bw.t2;
+    HIG_TRY(wgrad_act(dy3, d, lb + w.f1, ff, GL(grads, l, HIG_L_FFN_W2), M, bw.Mp, GL(grads, l, HIG_L_FFN_B2)));
+    HIG_TRY(dgrad(dy3, d, o_w2t, b + bw.tff, ff, M, HIG_EPI_DGELU, lb + w.z1, ff));     // dz = (dy3 . W2) gelu'(z)
+    const char* dz1 = b + bw.tff;
+    HIG_TRY(wgrad_act(dz1, ff, lb + w.h2, d, GL(grads, l, HIG_L_FFN_W1), M, bw.Mp, GL(grads, l, HIG_L_FFN_B1)));
+    HIG_TRY(dgrad(dz1, ff, o_w1t, dh_alt, d, M, HIG_EPI_RES, dh, d));                  // d(h2) = d(h3) + dz . W1
+    { char* tmp = dh; dh = dh_alt; dh_alt = tmp; }
+    // ---- cross attention ---------------------------------------------------------------
+    HIG_TRY(sty_bwd(l, D.nsty * l + 1, dh, lb + w.y2, lb + w.a2, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, HIG_L_CA_STY_OUT_W,
+                    HIG_L_CA_STY_OUT_B, o_sty2, b + bw.t2));
+    const float* Ac = reinterpret_cast<const float*>(tlb + tl.Ac);
+    HIG_TRY(hig_linattn_apply_bwd_bf16(b + bw.t2, d, lb + w.qc, d, Ac, b + bw.t1, d, dA, D.B, D.T, D.H, D.hd, attn, stream));
+    const char* dqc = b + bw.t1;
+    HIG_TRY(wgrad_act(dqc, d, lb + w.xn2, d, GL(grads, l, HIG_L_CA_Q_W), M, bw.Mp, GL(grads, l, HIG_L_CA_Q_B)));
+    HIG_TRY(dgrad(dqc, d, o_caq, b + bw.t2, d, M, HIG_EPI_NONE, nullptr, 0));
+    HIG_TRY(hig_ln_bwd_bf16(b + bw.t2, d, lb + w.h1, 0, d, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B), nullptr, 0, 0, 0, dh, d,
+                            dh_alt, 0, d, M, d, D.T, GL(grads, l, HIG_L_CA_NORM_W), GL(grads, l, HIG_L_CA_NORM_B), nullptr, 0, lnp, stream));
+    { char* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h1)
+    // text side of this layer: d(A_c) -> d(key, value) -> text_norm -> d(xf_out)
+    HIG_TRY(hig_linattn_ctx_bwd_bf16(dA, Ac, tlb + tl.kv, tlb + tl.kv + (int64_t)d * 2, 2 * d, reinterpret_cast<const float*>(tlb + tl.kstc), nullptr,
+                                     b + bw.dkv, b + bw.dkv + (int64_t)d * 2, 2 * d, D.B, D.N, D.H, D.hd, stream));
+    HIG_TRY(wgrad_act(b + bw.dkv, 2 * d, tlb + tl.xfn, Lt, GL(grads, l, HIG_L_CA_KV_W), Mt, bw.Mtp, GL(grads, l, HIG_L_CA_KV_B)));
+    HIG_TRY(dgrad(b + bw.dkv, 2 * d, o_kv, b + bw.dxfn, Lt, Mt, HIG_EPI_NONE, nullptr, 0));
+    HIG_TRY(hig_ln_bwd_bf16(b + bw.dxfn, Lt, xf_out, 1, Lt, PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B), nullptr, 0, 0, 0,
+                            l == D.L - 1 ? nullptr : dxf_out, Lt, dxf_out, 1, Lt, Mt, Lt, D.N, GL(grads, l, HIG_L_CA_TNORM_W),
+                            GL(grads, l, HIG_L_CA_TNORM_B), nullptr, 0, lnp, stream));
+    // ---- self attention ----------------------------------------------------------------
+    HIG_TRY(sty_bwd(l, D.nsty * l, dh, lb + w.y1, lb + w.a1, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W,
+                    HIG_L_SA_STY_OUT_B, o_sty1, b + bw.t2));
+    char* dqkv = b + bw.dqkv;
+    const float* A1 = reinterpret_cast<const float*>(lb + w.A1);
+    HIG_TRY(hig_linattn_apply_bwd_bf16(b + bw.t2, d, lb + w.qkv, 3 * d, A1, dqkv, 3 * d, dA, D.B, D.T, D.H, D.hd, attn, stream));
+    HIG_TRY(hig_linattn_ctx_bwd_bf16(dA, A1, lb + w.qkv + (int64_t)d * 2, lb + w.qkv + (int64_t)2 * d * 2, 3 * d,
+                                     reinterpret_cast<const float*>(lb + w.kst1), length, dqkv + (int64_t)d * 2, dqkv + (int64_t)2 * d * 2, 3 * d,
+                                     D.B, D.T, D.H, D.hd, stream));
+    HIG_TRY(wgrad_act(dqkv, 3 * d, lb + w.xn1, d, GL(grads, l, HIG_L_SA_QKV_W), M, bw.Mp, GL(grads, l, HIG_L_SA_QKV_B)));
+    HIG_TRY(dgrad(dqkv, 3 * d, o_qkv, b + bw.t2, d, M, HIG_EPI_NONE, nullptr, 0));
+    HIG_TRY(hig_ln_bwd_bf16(b + bw.t2, d, hin, 0, d, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B), nullptr, 0, 0, 0, dh, d, dh_alt,
+                            0, d, M, d, D.T, GL(grads, l, HIG_L_SA_NORM_W), GL(grads, l, HIG_L_SA_NORM_B), nullptr, 0, lnp, stream));
+    { char* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h_in of this layer)
+  }
+
+  // ---- joint_embed + sequence_embedding (F-wide: fp32 kernels on an fp32 copy of d(h0)) ---------------------------------------
+  HIG_TRY(hig_colsum_bf16(dh, d, M, d, GP(grads, HIG_P_JOINT_B), colp, stream));
+  HIG_TRY(hig_cast_f32(dh, f32b, M * d, stream));
+  HIG_TRY(wgrad32(G(f32b, d, 1, x, F, 1, GP(grads, HIG_P_JOINT_W), F, d, F, M)));
+  HIG_TRY(hig_colsum(f32b, (int64_t)D.T * d, D.B, D.T * d, GP(grads, HIG_P_SEQ_EMB), colp, stream));
+  if (D.nf > D.T)
+    if (hipMemsetAsync(GP(grads, HIG_P_SEQ_EMB) + (int64_t)D.T * d, 0, (size_t)(D.nf - D.T) * d * 4, st) != hipSuccess)
+      return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+  if (dx) HIG_TRY(hig_gemm_launch(G(f32b, d, 0, P(params, HIG_P_JOINT_W), F, 1, dx, F, M, F, d).g, 1, nullptr, st));
+
+  // ---- time / text embedding path (fp32, as hig_denoiser_bwd) --------------------------------------------------------------
+  HIG_TRY(fork.join());
+  const float* emb = reinterpret_cast<const float*>(ws + w.emb);
+  const float* te_h = reinterpret_cast<const float*>(ws + w.te_h);
+  const float* te = reinterpret_cast<const float*>(ws + w.te);
+  float* demb = reinterpret_cast<float*>(b + bw.demb);
+  float* dtmp = reinterpret_cast<float*>(b + bw.dtmp);
+  float* dte_h = reinterpret_cast<float*>(b + bw.dte_h);
+  HIG_TRY(hig_colsum(dss, ss_ld, D.B, (int)ss_ld, GP(grads, HIG_P_STY_EMB_B), colp, stream));
+  HIG_TRY(hig_gemm_launch(G(dss, ss_ld, 1, emb, E, 1, GP(grads, HIG_P_STY_EMB_W), E, ss_ld, E, D.B).silu(1).g, 1, nullptr, st));
+  {
+    G gd(dss, ss_ld, 0, P(params, HIG_P_STY_EMB_W), E, 1, dtmp, E, D.B, E, ss_ld);
+    int s = (int)(ss_ld / 1024);
+    if (s > 16) s = 16;
+    HIG_TRY(hig_gemm_launch(gd.g, s < 1 ? 1 : s, slabs, st));
+  }
+  const int64_t nBE = (int64_t)D.B * E;
+  const int eb = (int)((nBE + 255) / 256);
+  hipLaunchKernelGGL(mul_dsilu_kernel, dim3(eb), dim3(256), 0, st, dtmp, emb, nBE, demb);
+  HIG_CHECK_LAUNCH();
+  if (hipMemcpyAsync(dxf_proj, demb, (size_t)nBE * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
+  HIG_TRY(hig_colsum(demb, E, D.B, E, GP(grads, HIG_P_TE2_B), colp, stream));
+  HIG_TRY(hig_gemm_launch(G(demb, E, 1, te_h, E, 1, GP(grads, HIG_P_TE2_W), E, E, E, D.B).silu(1).g, 1, nullptr, st));
+  HIG_TRY(hig_gemm_launch(G(demb, E, 0, P(params, HIG_P_TE2_W), E, 1, dtmp, E, D.B, E, E).g, 1, nullptr, st));
+  hipLaunchKernelGGL(mul_dsilu_kernel, dim3(eb), dim3(256), 0, st, dtmp, te_h, nBE, dte_h);
+  HIG_CHECK_LAUNCH();
+  HIG_TRY(hig_colsum(dte_h, E, D.B, E, GP(grads, HIG_P_TE0_B), colp, stream));
+  HIG_TRY(hig_gemm_launch(G(dte_h, E, 1, te, d, 1, GP(grads, HIG_P_TE0_W), d, E, d, D.B).g, 1, nullptr, st));
   return HIG_OK;
 }

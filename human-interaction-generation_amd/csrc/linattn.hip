@@ -878,11 +878,11 @@ __global__ __launch_bounds__(256) void ctx_bwd_finish_kernel(const float* __rest
 // hd = 64 / 128 backward kernels on the matrix cores (same grids, outputs and scratch as the VALU
 // versions above; lane layout as in apply_mfma_kernel).
 // ---------------------------------------------------------------------------------------------
-template <int HD>
-__global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const float* __restrict__ dY, int64_t lddy,
-                                                             const float* __restrict__ Q, int64_t ldq,
+template <int HD, typename TIO = float>
+__global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const TIO* __restrict__ dY, int64_t lddy,
+                                                             const TIO* __restrict__ Q, int64_t ldq,
                                                              const float* __restrict__ A,
-                                                             float* __restrict__ dQ, int64_t lddq,
+                                                             TIO* __restrict__ dQ, int64_t lddq,
                                                              float* __restrict__ dApart, int rows, int H) {
   constexpr int LDP = HD + 4, TB = HD / 64, Q4 = HD / 4, NPRE = CH * Q4 / 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -893,8 +893,8 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const float* __rest
   const int tid = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int nchunk = (rows + CH - 1) / CH;
-  const float* Qb = Q + (int64_t)b * rows * ldq + h * HD;
-  const float* Db = dY + (int64_t)b * rows * lddy + h * HD;
+  const TIO* Qb = Q + (int64_t)b * rows * ldq + h * HD;
+  const TIO* Db = dY + (int64_t)b * rows * lddy + h * HD;
   // The workgroup walks row chunks blockIdx.y, blockIdx.y + gridDim.y, ...: A[b,h] is staged once, the dA
   // accumulators live across chunks (one partial per workgroup instead of one per chunk), and the next Q / dY
   // tiles are requested into registers before the products of the current ones.
@@ -904,8 +904,8 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const float* __rest
     for (int i = 0; i < NPRE; ++i) {
       const int idx = tid + 256 * i, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
       const bool ok = r < rows;
-      preq[i] = ok ? *reinterpret_cast<const float4*>(Qb + (int64_t)r * ldq + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      pred[i] = ok ? *reinterpret_cast<const float4*>(Db + (int64_t)r * lddy + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      preq[i] = ok ? ld4(Qb + (int64_t)r * ldq + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pred[i] = ok ? ld4(Db + (int64_t)r * lddy + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   fetch(blockIdx.y * CH);
@@ -988,15 +988,15 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const float* __rest
     const float sdot = srow[rl] + srow[CH + rl];
     const int r = r0 + rl;
     if (r < rows) {
-      float* op = dQ + ((int64_t)b * rows + r) * lddq + h * HD + wj * (HD / 2) + 4 * lh;
+      TIO* op = dQ + ((int64_t)b * rows + r) * lddq + h * HD + wj * (HD / 2) + 4 * lh;
 #pragma unroll
       for (int tj = 0; tj < TB; ++tj)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float4 qv = *reinterpret_cast<const float4*>(sQ + rl * LDP + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh);
-          *reinterpret_cast<float4*>(op + 32 * tj + 8 * q) =
+          st4(op + 32 * tj + 8 * q,
               make_float4(qv.x * (dq[tj][4 * q] - sdot), qv.y * (dq[tj][4 * q + 1] - sdot),
-                          qv.z * (dq[tj][4 * q + 2] - sdot), qv.w * (dq[tj][4 * q + 3] - sdot));
+                          qv.z * (dq[tj][4 * q + 2] - sdot), qv.w * (dq[tj][4 * q + 3] - sdot)));
         }
     }
     __syncthreads();   // sQ / sD / srow are rewritten by the next chunk
@@ -1012,12 +1012,12 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const float* __rest
 // Single pass: the column term of the column-softmax Jacobian,  S[c] = sum_r k[r][c] dk[r][c],  needs no pass over
 // the rows:  dk[r][c] = sum_l V[r][l] dA[c][l]  gives  S[c] = sum_l dA[c][l] (sum_r k[r][c] V[r][l]) = sum_l dA[c][l] A[c][l],
 // a row-wise dot of the two hd x hd matrices the workgroup already stages -- so dK is finished here.
-template <int HD>
+template <int HD, typename TIO = float>
 __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restrict__ dA, const float* __restrict__ A,
-                                                           const float* __restrict__ K, const float* __restrict__ V,
+                                                           const TIO* __restrict__ K, const TIO* __restrict__ V,
                                                            int64_t ld, const float* __restrict__ kstat,
                                                            const int64_t* __restrict__ length,
-                                                           float* __restrict__ dK, float* __restrict__ dV, int64_t ldd,
+                                                           TIO* __restrict__ dK, TIO* __restrict__ dV, int64_t ldd,
                                                            int rows, int H) {
   constexpr int LDP = HD + 4, TB = HD / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1049,8 +1049,8 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
     smax[tid] = st[0];
     sinv[tid] = 1.0f / st[1];
   }
-  const float* Kb = K + (int64_t)b * rows * ld + h * HD;
-  const float* Vb = V + (int64_t)b * rows * ld + h * HD;
+  const TIO* Kb = K + (int64_t)b * rows * ld + h * HD;
+  const TIO* Vb = V + (int64_t)b * rows * ld + h * HD;
   const int nchunk = (rows + CH - 1) / CH;
   constexpr int Q4 = HD / 4, NPRE = CH * Q4 / 256;
   // chunk-walking like apply_bwd: dA / S staged once per workgroup, next K / V tiles prefetched into registers
@@ -1060,8 +1060,8 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
     for (int i = 0; i < NPRE; ++i) {
       const int idx = tid + 256 * i, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
       const bool ok = r < len;
-      prek[i] = ok ? *reinterpret_cast<const float4*>(Kb + (int64_t)r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      prev[i] = ok ? *reinterpret_cast<const float4*>(Vb + (int64_t)r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      prek[i] = ok ? ld4(Kb + (int64_t)r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      prev[i] = ok ? ld4(Vb + (int64_t)r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   fetch(blockIdx.y * CH);
@@ -1121,17 +1121,17 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
     }
     const int r = r0 + rl;
     if (r < rows) {   // rows in [len, rows) carry k == 0 and V == 0 in LDS: dV == 0 and dK = k * (..) == 0 there
-      float* kp = dK + ((int64_t)b * rows + r) * ldd + h * HD + wj * (HD / 2) + 4 * lh;
-      float* vp = dV + ((int64_t)b * rows + r) * ldd + h * HD + wj * (HD / 2) + 4 * lh;
+      TIO* kp = dK + ((int64_t)b * rows + r) * ldd + h * HD + wj * (HD / 2) + 4 * lh;
+      TIO* vp = dV + ((int64_t)b * rows + r) * ldd + h * HD + wj * (HD / 2) + 4 * lh;
 #pragma unroll
       for (int tj = 0; tj < TB; ++tj) {
         store16(vp + 32 * tj, dv[tj]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float4 k4 = *reinterpret_cast<const float4*>(sK + rl * LDP + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh);
-          *reinterpret_cast<float4*>(kp + 32 * tj + 8 * q) =
+          st4(kp + 32 * tj + 8 * q,
               make_float4(k4.x * (dk[tj][4 * q] - scol[tj][q][0]), k4.y * (dk[tj][4 * q + 1] - scol[tj][q][1]),
-                          k4.z * (dk[tj][4 * q + 2] - scol[tj][q][2]), k4.w * (dk[tj][4 * q + 3] - scol[tj][q][3]));
+                          k4.z * (dk[tj][4 * q + 2] - scol[tj][q][2]), k4.w * (dk[tj][4 * q + 3] - scol[tj][q][3])));
         }
       }
     }
@@ -1152,7 +1152,11 @@ int allow_big_lds() {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&ctx_bwd_mfma_kernel<128>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : 1;
+    hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&apply_bwd_mfma_kernel<128, __bf16>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&ctx_bwd_mfma_kernel<128, __bf16>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess) ? 0 : 1;
   }();
   return rc;
 }
@@ -1577,6 +1581,65 @@ extern "C" int hig_linattn_ctx_bwd(const float* dA, const float* A, const float*
   HIG_CHECK_LAUNCH();
   HD_SWITCH(hd, hipLaunchKernelGGL((ctx_bwd_finish_kernel<HDV>), dim3(B * H, nchunk), dim3(256), 0,
                                    hig_stream(stream), K, ld, kstat, length, dK, ldd, rows, H, scratch));
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+
+// bf16-storage forms of the two backward kernels (training step with hig_dims.storage == HIG_STORE_BF16): dY, Q, dQ and K, V,
+// dK, dV bf16; A, dA, kstat fp32 (the hd x hd matrices and the statistics stay fp32 in this mode); the products run on the
+// fp32 matrix cores after the loads (exact fp32 arithmetic on the bf16 values).  Head dim 64 / 128.
+extern "C" int hig_linattn_apply_bwd_bf16(const void* dY, int64_t lddy, const void* Q, int64_t ldq, const float* A, void* dQ,
+                                          int64_t lddq, float* dA, int32_t B, int32_t rows, int32_t H, int32_t hd, float* scratch,
+                                          hig_stream_t stream) {
+  HIG_REQUIRE(dY && Q && A && dQ && dA && scratch && B > 0 && rows > 0 && H > 0, "hig_linattn_apply_bwd_bf16: bad arguments");
+  if (!(hd == 64 || (hd == 128 && allow_big_lds() == 0)))
+    return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn_apply_bwd_bf16: head dim 64 or 128 (got %d)", hd);
+  HIG_REQUIRE(ldq % 4 == 0 && lddy % 4 == 0 && lddq % 4 == 0 && ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(dY) |
+                                                                   reinterpret_cast<uintptr_t>(dQ)) & 7) == 0,
+              "hig_linattn_apply_bwd_bf16: Q / dY / dQ rows must be 8-byte aligned");
+  const int nchunk = (rows + CH - 1) / CH;
+  int nparts = (hig_chip_cus() + B * H - 1) / (B * H);
+  nparts = nparts < 1 ? 1 : (nparts > nchunk ? nchunk : nparts);
+  float* part = nparts == 1 ? dA : scratch;
+  const __bf16* dy = static_cast<const __bf16*>(dY);
+  const __bf16* q = static_cast<const __bf16*>(Q);
+  __bf16* dq = static_cast<__bf16*>(dQ);
+  if (hd == 64)
+    hipLaunchKernelGGL((apply_bwd_mfma_kernel<64, __bf16>), dim3(B * H, nparts), dim3(256), attn_bwd_lds_bytes<64>(), hig_stream(stream),
+                       dy, lddy, q, ldq, A, dq, lddq, part, rows, H);
+  else
+    hipLaunchKernelGGL((apply_bwd_mfma_kernel<128, __bf16>), dim3(B * H, nparts), dim3(256), attn_bwd_lds_bytes<128>(), hig_stream(stream),
+                       dy, lddy, q, ldq, A, dq, lddq, part, rows, H);
+  HIG_CHECK_LAUNCH();
+  if (nparts == 1) return HIG_OK;
+  const int64_t n = (int64_t)hd * hd, groups = (int64_t)B * H;
+  const int64_t want = (groups * n / 4 + 255) / 256;
+  hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)(want > 2048 ? 2048 : want)), dim3(256), 0, hig_stream(stream), scratch, nparts, n,
+                     groups, dA);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+extern "C" int hig_linattn_ctx_bwd_bf16(const float* dA, const float* A, const void* K, const void* V, int64_t ld, const float* kstat,
+                                        const int64_t* length, void* dK, void* dV, int64_t ldd, int32_t B, int32_t rows, int32_t H,
+                                        int32_t hd, hig_stream_t stream) {
+  HIG_REQUIRE(dA && A && K && V && kstat && dK && dV && B > 0 && rows > 0 && H > 0, "hig_linattn_ctx_bwd_bf16: bad arguments");
+  if (!(hd == 64 || (hd == 128 && allow_big_lds() == 0)))
+    return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn_ctx_bwd_bf16: head dim 64 or 128 (got %d)", hd);
+  HIG_REQUIRE(ld % 4 == 0 && ldd % 4 == 0 && ((reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(dK) |
+                                                reinterpret_cast<uintptr_t>(dV)) & 7) == 0,
+              "hig_linattn_ctx_bwd_bf16: K / V / dK / dV rows must be 8-byte aligned");
+  const int nchunk = (rows + CH - 1) / CH;
+  int gy = (hig_chip_cus() + B * H - 1) / (B * H);
+  gy = gy < 1 ? 1 : (gy > nchunk ? nchunk : gy);
+  const __bf16* k = static_cast<const __bf16*>(K);
+  const __bf16* v = static_cast<const __bf16*>(V);
+  if (hd == 64)
+    hipLaunchKernelGGL((ctx_bwd_mfma_kernel<64, __bf16>), dim3(B * H, gy), dim3(256), attn_bwd_lds_bytes<64>(), hig_stream(stream), dA, A, k, v,
+                       ld, kstat, length, static_cast<__bf16*>(dK), static_cast<__bf16*>(dV), ldd, rows, H);
+  else
+    hipLaunchKernelGGL((ctx_bwd_mfma_kernel<128, __bf16>), dim3(B * H, gy), dim3(256), attn_bwd_lds_bytes<128>(), hig_stream(stream), dA, A, k,
+                       v, ld, kstat, length, static_cast<__bf16*>(dK), static_cast<__bf16*>(dV), ldd, rows, H);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

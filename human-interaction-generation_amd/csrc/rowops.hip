@@ -445,6 +445,233 @@ __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, int B, 
   out[idx] = (TO)v;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row kernels of the bf16-storage TRAINING step (round 4): the same reductions as above over bf16 rows.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __bf16 rbf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 rbf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4g(const __bf16* p) {
+  const rbf16x4 t = *reinterpret_cast<const rbf16x4*>(p);
+  return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+}
+__device__ __forceinline__ void st4g(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4g(__bf16* p, const float4& v) {
+  *reinterpret_cast<rbf16x4*>(p) = rbf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+}
+
+// ln_bwd_kernel with bf16 upstream gradients, rows in TX (bf16 activations, or the fp32 text embeddings), residual /
+// result in TD (bf16: the gradient of the residual stream; fp32: d(xf_out)), and the LayerNorm statistics RECOMPUTED from
+// the row the kernel reads anyway (two passes over the registers: the forward of this mode keeps no statistics).
+template <int NIT, bool MOD_SILU, typename TX, typename TD>
+__global__ __launch_bounds__(256) void ln_bwd16_kernel(
+    const __bf16* __restrict__ da, int64_t ldda, const TX* __restrict__ x, int64_t ldx,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ ss, int64_t ss_ld, int shift_off, const TD* __restrict__ res,
+    int64_t ldr, TD* __restrict__ dx, int64_t lddx, int n, int rows_per_sample,
+    float* __restrict__ partial) {
+  __shared__ float red[WAVES][4][64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+  const float inv_n = 1.0f / (float)n;
+  float4 g4[NIT], b4[NIT], sc4[NIT], sh4[NIT];
+  float4 a_dg[NIT], a_db[NIT], a_dsc[NIT], a_dsh[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = 4 * lane + 256 * it;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    g4[it] = b4[it] = sc4[it] = sh4[it] = z;
+    a_dg[it] = a_db[it] = a_dsc[it] = a_dsh[it] = z;
+    if (c < n) {
+      g4[it] = *reinterpret_cast<const float4*>(gamma + c);
+      b4[it] = *reinterpret_cast<const float4*>(beta + c);
+      if (MOD_SILU) {
+        sc4[it] = *reinterpret_cast<const float4*>(ss + (int64_t)b * ss_ld + c);
+        sh4[it] = *reinterpret_cast<const float4*>(ss + (int64_t)b * ss_ld + shift_off + c);
+      }
+    }
+  }
+  for (int rl = split * WAVES + wave; rl < rows_per_sample; rl += WAVES * nsplit) {
+    const int64_t row = (int64_t)b * rows_per_sample + rl;
+    float4 xv[NIT], dav[NIT];
+    float sx = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = 4 * lane + 256 * it;
+      xv[it] = dav[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < n) {
+        xv[it] = ld4g(x + row * ldx + c);
+        dav[it] = ld4g(da + row * ldda + c);
+        sx += (xv[it].x + xv[it].y) + (xv[it].z + xv[it].w);
+      }
+    }
+    const float mean = wave_sum(sx) * inv_n;
+    float sq = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = 4 * lane + 256 * it;
+      if (c < n) {
+        const float a0 = xv[it].x - mean, a1 = xv[it].y - mean, a2 = xv[it].z - mean, a3 = xv[it].w - mean;
+        sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) * inv_n + 1e-5f);
+    float4 xh[NIT], dxh[NIT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = 4 * lane + 256 * it;
+      xh[it] = dxh[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < n) {
+        const float xs[4] = {xv[it].x, xv[it].y, xv[it].z, xv[it].w}, ds[4] = {dav[it].x, dav[it].y, dav[it].z, dav[it].w};
+        const float gs[4] = {g4[it].x, g4[it].y, g4[it].z, g4[it].w};
+        const float bs[4] = {b4[it].x, b4[it].y, b4[it].z, b4[it].w};
+        const float scs[4] = {sc4[it].x, sc4[it].y, sc4[it].z, sc4[it].w};
+        const float shs[4] = {sh4[it].x, sh4[it].y, sh4[it].z, sh4[it].w};
+        float xho[4], dxo[4], dgo[4], dbo[4], dsco[4], dsho[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xhat = (xs[e] - mean) * rstd;
+          const float nrm = xhat * gs[e] + bs[e];
+          float dn;
+          if (MOD_SILU) {
+            const float u = nrm * (1.0f + scs[e]) + shs[e];
+            const float du = ds[e] * hig_dsilu(u);
+            dsho[e] = du;
+            dsco[e] = du * nrm;
+            dn = du * (1.0f + scs[e]);
+          } else {
+            dsho[e] = dsco[e] = 0.f;
+            dn = ds[e];
+          }
+          dgo[e] = dn * xhat;
+          dbo[e] = dn;
+          xho[e] = xhat;
+          dxo[e] = dn * gs[e];
+          s1 += dxo[e];
+          s2 += dxo[e] * xhat;
+        }
+        xh[it] = make_float4(xho[0], xho[1], xho[2], xho[3]);
+        dxh[it] = make_float4(dxo[0], dxo[1], dxo[2], dxo[3]);
+        a_dg[it].x += dgo[0]; a_dg[it].y += dgo[1]; a_dg[it].z += dgo[2]; a_dg[it].w += dgo[3];
+        a_db[it].x += dbo[0]; a_db[it].y += dbo[1]; a_db[it].z += dbo[2]; a_db[it].w += dbo[3];
+        if (MOD_SILU) {
+          a_dsc[it].x += dsco[0]; a_dsc[it].y += dsco[1]; a_dsc[it].z += dsco[2]; a_dsc[it].w += dsco[3];
+          a_dsh[it].x += dsho[0]; a_dsh[it].y += dsho[1]; a_dsh[it].z += dsho[2]; a_dsh[it].w += dsho[3];
+        }
+      }
+    }
+    s1 = wave_sum(s1) * inv_n;
+    s2 = wave_sum(s2) * inv_n;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = 4 * lane + 256 * it;
+      if (c < n) {
+        float4 o;
+        o.x = rstd * (dxh[it].x - s1 - xh[it].x * s2);
+        o.y = rstd * (dxh[it].y - s1 - xh[it].y * s2);
+        o.z = rstd * (dxh[it].z - s1 - xh[it].z * s2);
+        o.w = rstd * (dxh[it].w - s1 - xh[it].w * s2);
+        if (res) {
+          const float4 r4 = ld4g(res + row * ldr + c);
+          o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
+        }
+        st4g(dx + row * lddx + c, o);
+      }
+    }
+  }
+  float* pout = partial + ((int64_t)b * nsplit + split) * 4 * n;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    __syncthreads();
+    *reinterpret_cast<float4*>(&red[wave][0][4 * lane]) = a_dg[it];
+    *reinterpret_cast<float4*>(&red[wave][1][4 * lane]) = a_db[it];
+    *reinterpret_cast<float4*>(&red[wave][2][4 * lane]) = a_dsc[it];
+    *reinterpret_cast<float4*>(&red[wave][3][4 * lane]) = a_dsh[it];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4 * 256; e += 256) {
+      const int qn = e >> 8, cl = e & 255, c = cl + 256 * it;
+      if (c < n) {
+        float s = red[0][qn][cl];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) s += red[w][qn][cl];
+        pout[(int64_t)qn * n + c] = s;
+      }
+    }
+  }
+}
+
+// partial[chunk][c] = sum over this chunk's rows of x[row][c], x bf16, 8 columns per lane (n % 8 == 0)
+__global__ __launch_bounds__(256) void colsum16_kernel(const __bf16* __restrict__ x, int64_t ldx, int64_t rows, int n,
+                                                       float* __restrict__ partial) {
+  __shared__ float red[WAVES][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 512 + 8 * lane;
+  const int chunk = blockIdx.y, nchunk = gridDim.y;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < n) {
+    for (int64_t r = (int64_t)chunk * WAVES + wave; r < rows; r += (int64_t)WAVES * nchunk) {
+      const rbf16x8 v = *reinterpret_cast<const rbf16x8*>(x + r * ldx + c0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[wave][8 * lane + e] = s[e];
+  __syncthreads();
+  for (int cl = threadIdx.x; cl < 512; cl += 256) {
+    const int c = blockIdx.x * 512 + cl;
+    if (c < n) {
+      float t = red[0][cl];
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) t += red[w][cl];
+      partial[(int64_t)chunk * n + c] = t;
+    }
+  }
+}
+
+// dst[c][r] = src[r][c] for bf16 matrices, 64 x 64 tiles: 16-byte loads along the source rows, the tile stored TRANSPOSED
+// in LDS (two-byte writes), 16-byte loads from there along the destination rows.  cols % 8 == 0; a destination row holds
+// round_up(rows, 8) elements (the last vector of a row carries zeros beyond `rows`).
+struct Tr16Batch {
+  const __bf16* src[12];
+  __bf16* dst[12];
+  int64_t lds_[12], ldd[12];
+  int rows[12], cols[12];
+  int tile0[13];
+  int n;
+};
+__global__ __launch_bounds__(256) void transpose16_kernel(const Tr16Batch b) {
+  __shared__ __attribute__((aligned(16))) __bf16 tile[64][72];   // [c][r], rows padded to 144 bytes
+  int m = 0;
+  while (m + 1 < b.n && (int)blockIdx.x >= b.tile0[m + 1]) ++m;
+  const int rows = b.rows[m], cols = b.cols[m];
+  const int lt = blockIdx.x - b.tile0[m], tcn = (cols + 63) / 64;
+  const int c0 = (lt % tcn) * 64, r0 = (lt / tcn) * 64;
+  const __bf16* __restrict__ src = b.src[m];
+  __bf16* __restrict__ dst = b.dst[m];
+  const int64_t lds_ = b.lds_[m], ldd = b.ldd[m];
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int rr = 32 * pass + (t >> 3), c8 = 8 * (t & 7);
+    rbf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+    if (r0 + rr < rows && c0 + c8 < cols) v = *reinterpret_cast<const rbf16x8*>(src + (int64_t)(r0 + rr) * lds_ + c0 + c8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[c8 + e][rr] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int cc = 32 * pass + (t >> 3), r8 = 8 * (t & 7);
+    if (c0 + cc < cols && r0 + r8 < rows)
+      *reinterpret_cast<rbf16x8*>(dst + (int64_t)(c0 + cc) * ldd + r0 + r8) = *reinterpret_cast<const rbf16x8*>(&tile[cc][r8]);
+  }
+}
+
 int splits_for(int64_t samples) {
   int s = 1;
   while (samples * s < 512 && s < 16) s *= 2;
@@ -617,6 +844,113 @@ extern "C" int hig_colsum(const float* x, int64_t ldx, int64_t rows, int32_t n, 
                      chunks, (int64_t)n, n, out);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
+}
+
+
+// ---- bf16-storage training step: row kernels with bf16 I/O -------------------------------------------------------------
+extern "C" int hig_ln_bwd_bf16(const void* da, int64_t ldda, const void* x, int32_t x_f32, int64_t ldx, const float* gamma,
+                               const float* beta, const float* ss, int64_t ss_ld, int32_t ss_shift_off, int32_t mod_silu,
+                               const void* res, int64_t ldr, void* dx, int32_t dx_f32, int64_t lddx, int64_t rows, int32_t n,
+                               int32_t rows_per_sample, float* dgamma, float* dbeta, float* dss, int64_t dss_ld,
+                               float* partial, hig_stream_t stream) {
+  HIG_REQUIRE(da && x && gamma && beta && dx && partial, "hig_ln_bwd_bf16: null argument");
+  HIG_REQUIRE(n % 4 == 0 && n <= 1024 && ldda % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!res || ldr % 4 == 0),
+              "hig_ln_bwd_bf16: n and the leading dimensions must be multiples of 4, n <= 1024 (got %d)", n);
+  HIG_REQUIRE(((reinterpret_cast<uintptr_t>(da) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
+                reinterpret_cast<uintptr_t>(res)) & 7) == 0, "hig_ln_bwd_bf16: 8-byte aligned rows");
+  HIG_REQUIRE(rows_per_sample > 0 && rows % rows_per_sample == 0, "hig_ln_bwd_bf16: rows %% rows_per_sample");
+  HIG_REQUIRE(!mod_silu || (ss && dss), "hig_ln_bwd_bf16: modulation needs ss / dss");
+  if (mod_silu && (x_f32 || dx_f32))
+    return hig_set_error(HIG_EUNSUPPORTED, "hig_ln_bwd_bf16: the stylization form is built for bf16 rows only");
+  if (rows == 0) return HIG_OK;
+  const int samples = (int)(rows / rows_per_sample);
+  const int nsplit = splits_for(samples);
+  const int nit = (n + 255) / 256;
+  hipStream_t st = hig_stream(stream);
+  dim3 grid(samples, nsplit);
+  const __bf16* dab = static_cast<const __bf16*>(da);
+#define LNB16(NITV, MODV, TXV, TDV)                                                                                              \
+  hipLaunchKernelGGL((ln_bwd16_kernel<NITV, MODV, TXV, TDV>), grid, dim3(256), 0, st, dab, ldda, static_cast<const TXV*>(x), ldx, \
+                     gamma, beta, ss, ss_ld, ss_shift_off, static_cast<const TDV*>(res), ldr, static_cast<TDV*>(dx), lddx, n,    \
+                     rows_per_sample, partial)
+#define LNB16_NIT(MODV, TXV, TDV)                                                    \
+  do {                                                                               \
+    if (nit == 1) LNB16(1, MODV, TXV, TDV);                                          \
+    else if (nit == 2) LNB16(2, MODV, TXV, TDV);                                     \
+    else LNB16(4, MODV, TXV, TDV);                                                   \
+  } while (0)
+  if (mod_silu) LNB16_NIT(true, __bf16, __bf16);
+  else if (!x_f32 && !dx_f32) LNB16_NIT(false, __bf16, __bf16);
+  else if (x_f32 && dx_f32) LNB16_NIT(false, float, float);
+  else if (!x_f32 && dx_f32) LNB16_NIT(false, __bf16, float);
+  else return hig_set_error(HIG_EUNSUPPORTED, "hig_ln_bwd_bf16: fp32 rows with a bf16 result is not built");
+#undef LNB16_NIT
+#undef LNB16
+  HIG_CHECK_LAUNCH();
+  if (dgamma && dbeta && mod_silu) {
+    const int nb_col = (2 * n + 63) / 64;
+    const int nb_dss = (int)(((int64_t)samples * n + 1023) / 1024);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(nb_col + nb_dss), dim3(1024), 0, st, partial, samples, nsplit, n, dgamma,
+                       dbeta, ss_shift_off, dss, dss_ld, nb_col);
+    HIG_CHECK_LAUNCH();
+    return HIG_OK;
+  }
+  if (dgamma && dbeta) {
+    hipLaunchKernelGGL(colreduce_kernel, dim3((2 * n + 63) / 64), dim3(1024), 0, st, partial,
+                       samples * nsplit, (int64_t)4 * n, 2 * n, dgamma, n, dbeta);
+    HIG_CHECK_LAUNCH();
+  }
+  if (mod_silu) {
+    hipLaunchKernelGGL(dss_reduce_kernel, dim3((n + 127) / 128, samples), dim3(128), 0, st, partial,
+                       nsplit, n, ss_shift_off, dss, dss_ld);
+    HIG_CHECK_LAUNCH();
+  }
+  return HIG_OK;
+}
+
+extern "C" int hig_colsum_bf16(const void* x, int64_t ldx, int64_t rows, int32_t n, float* out, float* partial,
+                               hig_stream_t stream) {
+  HIG_REQUIRE(x && out && partial && n > 0, "hig_colsum_bf16: bad arguments");
+  HIG_REQUIRE(n % 8 == 0 && ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "hig_colsum_bf16: n, ldx multiples of 8, 16-byte aligned rows");
+  hipStream_t st = hig_stream(stream);
+  const int chunks = hig_colsum_chunks(rows);
+  hipLaunchKernelGGL(colsum16_kernel, dim3((n + 511) / 512, chunks), dim3(256), 0, st, static_cast<const __bf16*>(x), ldx, rows, n,
+                     partial);
+  HIG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colreduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial, chunks, (int64_t)n, n, out);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+extern "C" int hig_transpose_bf16_batch(int32_t n, const void* const* srcs, const int64_t* lds_, void* const* dsts,
+                                        const int64_t* ldd, const int32_t* rows, const int32_t* cols, hig_stream_t stream) {
+  HIG_REQUIRE(n >= 0 && n <= 12 && (n == 0 || (srcs && dsts && rows && cols && lds_ && ldd)),
+              "hig_transpose_bf16_batch: 0 <= n <= 12 matrices");
+  if (n == 0) return HIG_OK;
+  Tr16Batch b;
+  b.n = n;
+  int t = 0;
+  for (int m = 0; m < n; ++m) {
+    HIG_REQUIRE(srcs[m] && dsts[m] && rows[m] > 0 && cols[m] > 0 && cols[m] % 8 == 0 && lds_[m] % 8 == 0 &&
+                    ldd[m] % 8 == 0 && ldd[m] >= (rows[m] + 7) / 8 * 8 && ((reinterpret_cast<uintptr_t>(srcs[m]) | reinterpret_cast<uintptr_t>(dsts[m])) & 15) == 0,
+                "hig_transpose_bf16_batch: matrix %d: extents / leading dimensions multiples of 8, 16-byte aligned", m);
+    b.src[m] = static_cast<const __bf16*>(srcs[m]); b.dst[m] = static_cast<__bf16*>(dsts[m]);
+    b.lds_[m] = lds_[m]; b.ldd[m] = ldd[m]; b.rows[m] = rows[m]; b.cols[m] = cols[m];
+    b.tile0[m] = t;
+    t += ((rows[m] + 63) / 64) * ((cols[m] + 63) / 64);
+  }
+  b.tile0[n] = t;
+  hipLaunchKernelGGL(transpose16_kernel, dim3(t), dim3(256), 0, hig_stream(stream), b);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+extern "C" int hig_transpose_bf16(const void* src, int64_t ld, int32_t rows, int32_t cols, void* dst, int64_t ldd,
+                                  hig_stream_t stream) {
+  const void* s1[1] = {src};
+  void* d1[1] = {dst};
+  const int64_t l1[1] = {ld}, l2[1] = {ldd};
+  const int32_t r1[1] = {rows}, c1[1] = {cols};
+  return hig_transpose_bf16_batch(1, s1, l1, d1, l2, r1, c1, stream);
 }
 
 extern "C" int hig_transpose(const float* src, int64_t ld, int32_t rows, int32_t cols, float* dst, int64_t ldd,

@@ -154,3 +154,47 @@ extern "C" int hig_ln_bf16(const void* x, int32_t x_f32, int64_t ldx, int64_t ro
   return ss ? launch_ln16<true, __bf16>(xb, ldx, rows, n, gamma, beta, ss, ss_ld, ss_shift_off, rows_per_sample, o, ldo, st)
             : launch_ln16<false, __bf16>(xb, ldx, rows, n, gamma, beta, ss, ss_ld, ss_shift_off, rows_per_sample, o, ldo, st);
 }
+
+// ---- bf16-storage training step: elementwise helpers ---------------------------------------------------------------------
+namespace {
+// exact-erf GELU on bf16 rows (nn.GELU(), transformer.py:160,168): f = gelu(z).  The training forward keeps BOTH z (the
+// backward's gelu'(z)) and f (operand of linear2); the weight-stationary GEMM writes z, this pass derives f.
+__global__ __launch_bounds__(256) void gelu16_kernel(const __bf16* __restrict__ z, __bf16* __restrict__ f, int64_t n8) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const bf16x8 v = reinterpret_cast<const bf16x8*>(z)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)hig_gelu((float)v[e]);
+    reinterpret_cast<bf16x8*>(f)[i] = o;
+  }
+}
+__global__ __launch_bounds__(256) void cast_f32_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, int64_t n8) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const bf16x8 v = reinterpret_cast<const bf16x8*>(src)[i];
+    reinterpret_cast<f32x4*>(dst)[2 * i] = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    reinterpret_cast<f32x4*>(dst)[2 * i + 1] = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+  }
+}
+}  // namespace
+
+extern "C" int hig_gelu_bf16(const void* z, void* f, int64_t n, hig_stream_t stream) {
+  HIG_REQUIRE(z && f && n >= 0 && n % 8 == 0 && ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(f)) & 15) == 0,
+              "hig_gelu_bf16: n %% 8 == 0, 16-byte aligned buffers");
+  if (n == 0) return HIG_OK;
+  int64_t blocks = (n / 8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gelu16_kernel, dim3((unsigned)blocks), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(z),
+                     static_cast<__bf16*>(f), n / 8);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+extern "C" int hig_cast_f32(const void* src, float* dst, int64_t n, hig_stream_t stream) {
+  HIG_REQUIRE(src && dst && n >= 0 && n % 8 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0,
+              "hig_cast_f32: n %% 8 == 0, 16-byte aligned buffers");
+  if (n == 0) return HIG_OK;
+  int64_t blocks = (n / 8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(cast_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(src), dst, n / 8);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}

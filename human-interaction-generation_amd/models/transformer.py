@@ -281,6 +281,16 @@ class _FlatParams:
             self._shadow_version = (version, self.flat.data_ptr())
         return self._stable
 
+    def shadow16_buffer(self):
+        """The bf16 shadow tensor itself (allocated, contents unspecified): hig_clip_adam_shadow writes it."""
+        if getattr(self, "_shadow", None) is None or self._shadow.data_ptr() != getattr(self, "_shadow_ptr", None):
+            self.shadow16(object())       # allocate + one cast; the sentinel version never matches again
+        return self._shadow
+
+    def shadow16_mark_current(self, version):
+        """The optimizer kernel has just written bf16(parameters) into the shadow: `version` is current without a cast pass."""
+        self._shadow_version = (version, self.flat.data_ptr())
+
     def valid(self):
         base, end = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.numel
         return all(p.is_cuda and base <= p.data_ptr() < end for p in self.params[:3] + self.params[-3:]) \
@@ -563,12 +573,18 @@ class MotionTransformer(nn.Module):
             x.requires_grad or xf_proj.requires_grad or xf_out.requires_grad
             or any(p.requires_grad for p in fp.params))
         if needs_grad:
-            if self._bf16():
-                raise NotImplementedError("storage='bf16' is inference-only: run it under torch.no_grad() (training keeps "
-                                          "fp32 storage; precision='bf16x3' / 'bf16' select reduced-precision products)")
+            self._check_bf16_training()
             return _DenoiserFn.apply(self, x, t, length, xf_proj, xf_out, *fp.params)
         out, _ = self._launch_forward(x, t, length, xf_proj, xf_out, training=False)
         return out
+
+    def _check_bf16_training(self):
+        """storage='bf16' trains the single-person model with linear attention (hig_denoiser_fwd_bf16_train / _bwd_bf16:
+        fp32 master weights, gradients and optimizer state; bf16 activations and matrix products)."""
+        if self._bf16() and (self.no_eff or hasattr(self, "joint_embed2")):
+            raise NotImplementedError("storage='bf16' trains the single-person model with linear attention only (no_eff / "
+                                      "the two-person model: train with fp32 storage; precision='bf16x3' / 'bf16' select "
+                                      "reduced-precision products there)")
 
     # ---- launches -----------------------------------------------------------------------
     def _text_context(self, dims, xf_out, training):
@@ -592,7 +608,10 @@ class MotionTransformer(nn.Module):
         else:   # one reusable buffer: the caller's forward consumes it on the same stream before the next call
             buf = self._pool.take("textctx_i", nbytes, xf_out.device)
             self._pool.give("textctx_i", buf, xf_out.device)
-        if self._bf16():
+        if self._bf16() and training:
+            _lib.check(L.hig_text_context_bf16_train(C.byref(dims), fp.param_table(), fp.shadow16(self._param_version()),
+                                                     _lib.ptr(xf_out), _lib.ptr(buf), _lib.stream_ptr()))
+        elif self._bf16():
             _lib.check(L.hig_text_context_bf16(C.byref(dims), fp.param_table(), fp.shadow16(self._param_version()),
                                                _lib.ptr(xf_out), _lib.ptr(buf), _lib.stream_ptr()))
         else:
@@ -663,14 +682,19 @@ class MotionTransformer(nn.Module):
         L = _lib.lib()
         fp = self.flat_params()
         dims = self.dims(B, T, N)
-        if training and self._bf16():
-            raise NotImplementedError("storage='bf16' is inference-only (the training step keeps fp32 storage)")
+        if training:
+            self._check_bf16_training()
         nbytes = L.hig_workspace_bytes(C.byref(dims), int(training))
         if nbytes < 0:
             raise RuntimeError("libhig: " + _lib.last_error())
         textctx = self._text_context(dims, xf_out, training)
         ws = self._pool.take("fwd_t" if training else "fwd_i", nbytes, x.device)
         out = torch.empty(B, T, self.input_feats, device=x.device, dtype=torch.float32)
+        if self._bf16() and training:
+            _lib.check(L.hig_denoiser_fwd_bf16_train(C.byref(dims), fp.param_table(), fp.shadow16(self._param_version()),
+                                                     _lib.ptr(x), _lib.ptr(t), _lib.ptr(length), _lib.ptr(xf_proj),
+                                                     _lib.ptr(textctx), _lib.ptr(out), _lib.ptr(ws), _lib.stream_ptr()))
+            return out, (dims, ws, textctx)
         if self._bf16():
             _lib.check(L.hig_denoiser_fwd_bf16(C.byref(dims), fp.param_table(), fp.shadow16(self._param_version()),
                                                self._derived16(fp), _lib.ptr(x), _lib.ptr(t), _lib.ptr(length),
@@ -701,7 +725,18 @@ class MotionTransformer(nn.Module):
         dx = torch.empty_like(x) if want_dx else None
         dxp = torch.empty(B, self.time_embed_dim, device=dev, dtype=torch.float32)
         dxo = torch.empty(B, N, self.text_latent_dim, device=dev, dtype=torch.float32)
-        if layer_hook is None:
+        if dims.storage == _lib.STORE_BF16:
+            # (no per-layer hook in this mode: a data-parallel caller exchanges the flat gradient after the backward)
+            _lib.check(L.hig_denoiser_bwd_bf16(C.byref(dims), fp.param_table(), fp.shadow16(self._param_version()), _lib.ptr(x),
+                                               _lib.ptr(t), _lib.ptr(length), _lib.ptr(xf_out), _lib.ptr(textctx), _lib.ptr(ws),
+                                               _lib.ptr(dout), gtable, _lib.ptr(dx), _lib.ptr(dxp), _lib.ptr(dxo), _lib.ptr(bws),
+                                               _lib.stream_ptr()))
+            if layer_hook is not None:
+                for l in range(self.num_layers - 1, -1, -1):
+                    if comm_stream is not None:
+                        comm_stream.wait_stream(torch.cuda.current_stream())
+                    layer_hook(l)
+        elif layer_hook is None:
             _lib.check(L.hig_denoiser_bwd(C.byref(dims), fp.param_table(), _lib.ptr(x), _lib.ptr(t),
                                           _lib.ptr(length), _lib.ptr(xf_out), _lib.ptr(textctx), _lib.ptr(ws),
                                           _lib.ptr(dout), gtable, _lib.ptr(dx), _lib.ptr(dxp), _lib.ptr(dxo),

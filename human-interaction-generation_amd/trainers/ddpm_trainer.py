@@ -439,12 +439,19 @@ class DDPMTrainer(object):
         n = self._fused_numel(with_text)
         _lib.check(L.hig_sumsq_partial(_lib.ptr(fp.grad), n, 1.0 / world, _lib.ptr(st["scratch"]),
                                        _lib.stream_ptr()))
-        _lib.check(L.hig_clip_adam_lrdev(_lib.ptr(fp.flat), _lib.ptr(fp.grad), _lib.ptr(st["m"]), _lib.ptr(st["v"]),
-                                         n, st["lr_host"], _lib.ptr(st["lr"]), ADAM_BETAS[0], ADAM_BETAS[1], ADAM_EPS,
-                                         GRAD_CLIP, 1.0 / world, _lib.ptr(st["scratch"]), _lib.ptr(st["gnorm"]),
-                                         _lib.ptr(st["step"]), _lib.stream_ptr()))
+        bf16 = getattr(core, "storage", "f32") == "bf16"
+        # bf16 storage: the update kernel also writes bf16(new parameters) into the weight shadow the next forward reads
+        # (fp32 master weights, no separate cast pass over the 81 M parameters)
+        shadow = fp.shadow16_buffer() if bf16 else None
+        _lib.check(L.hig_clip_adam_shadow(_lib.ptr(fp.flat), _lib.ptr(fp.grad), _lib.ptr(st["m"]), _lib.ptr(st["v"]),
+                                          n, st["lr_host"], _lib.ptr(st["lr"]), ADAM_BETAS[0], ADAM_BETAS[1], ADAM_EPS,
+                                          GRAD_CLIP, 1.0 / world, _lib.ptr(st["scratch"]), _lib.ptr(st["gnorm"]),
+                                          _lib.ptr(st["step"]), _lib.ptr(shadow), fp.core_numel if bf16 else 0,
+                                          _lib.stream_ptr()))
         st["covered"] = max(st["covered"], n)
         core.params_changed()
+        if bf16:
+            fp.shadow16_mark_current(core._param_version())
 
     def train_step_fused(self, x_start, t, length, xf_proj=None, xf_out=None, noise=None, lr=None, clip_out=None,
                          eot=None):
@@ -546,6 +553,9 @@ class DDPMTrainer(object):
                 st["v"].copy_(keep[2])
                 st["step"].copy_(keep[3])
             st["covered"] = keep[4]
+            core.params_changed()
+            if getattr(core, "storage", "f32") == "bf16":   # the warm-up's update also wrote the bf16 shadow: re-derive it
+                fp.shadow16(core._param_version())          # from the restored master weights, eagerly (not inside the capture)
             # thread_local: other threads (the RCCL watchdog polls its events) may call into HIP while we capture
             ga, gb = torch.cuda.CUDAGraph(), None
             if not split:
@@ -573,5 +583,9 @@ class DDPMTrainer(object):
             st["allreduce"](_core(self.encoder).flat_params().grad[:n])
             gb.replay()
         st["covered"] = max(st["covered"], n)
-        _core(self.encoder).params_changed()
+        core = _core(self.encoder)
+        core.params_changed()
+        if getattr(core, "storage", "f32") == "bf16":       # (the replayed update kernel has just written the shadow)
+            fp = core.flat_params()
+            fp.shadow16_mark_current(core._param_version())
         return st["loss"]

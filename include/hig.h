@@ -75,10 +75,10 @@ typedef struct hig_dims {
                          2: the same with no_cross_attn=True (no int_ca_block). */
   int32_t storage;    /* HIG_STORE_F32 (0): fp32 activations and weights.  HIG_STORE_BF16 (1): bf16 activations and a
                          bf16 shadow of the weight matrices, fp32 accumulation / LayerNorm statistics / softmax /
-                         context matrices / modulation vectors -- BASELINE configs 3 and 5.  Inference only
-                         (hig_denoiser_fwd_bf16); single-person model (linear or full attention) and two-person model
-                         (linear attention), head dim 64 or 128,
-                         d, ff, Lt multiples of 32. */
+                         context matrices / modulation vectors -- BASELINE configs 3 and 5.  Inference
+                         (hig_denoiser_fwd_bf16): single-person model (linear or full attention) and two-person model
+                         (linear attention); training (hig_denoiser_fwd_bf16_train / hig_denoiser_bwd_bf16): single-person
+                         model with linear attention.  Head dim 64 or 128, d, ff, Lt multiples of 32. */
 } hig_dims;
 #define HIG_STORE_F32 0
 #define HIG_STORE_BF16 1
@@ -193,6 +193,61 @@ int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* params, const
                           const void* const* derived, const float* x,
                           const int64_t* t, const int64_t* length, const float* xf_proj, const void* textctx,
                           float* out, void* workspace, hig_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * bf16-storage TRAINING step (dims->storage == HIG_STORE_BF16; single-person model, linear attention, head dim 64 / 128).
+ * Reference arithmetic: DDPMTrainer.forward / backward_G / update (trainers/ddpm_trainer.py:97-119,172-187) over
+ * MotionTransformer.forward (models/transformer.py:60-194,407-426); the reference trains in fp32 -- this mode keeps fp32
+ * MASTER parameters, gradients and optimizer state, and runs the step's matrix products on the bf16 matrix cores:
+ *   - activations saved for the backward in bf16 (per layer: LN outputs, q/k/v, attention outputs, stylization inputs /
+ *     outputs, the residual stream, FFN pre-activation z and gelu(z)); hd x hd context matrices, softmax statistics,
+ *     modulation vectors and the per-sample embedding chain (time_embed, emb, scale / shift) in fp32;
+ *   - data gradients dX = dC . W through hig_gemm_bf16 on a transposed bf16 copy of the layer's weights (epilogues
+ *     HIG_EPI_RES: + the incoming residual gradient, HIG_EPI_DGELU: x gelu'(z));
+ *   - weight gradients dW = dC^T . act as split-R bf16 GEMMs over the B T rows into fp32 slabs, summed in a fixed order
+ *     (hig_gemm_bf16_split; operands transposed by hig_transpose_bf16_batch), written to the fp32 gradient table;
+ *   - LayerNorm / stylization / linear-attention backward kernels with bf16 rows (hig_ln_bwd_bf16, hig_linattn_*_bwd_bf16);
+ *   - the F-wide input / output projections and the B-row embedding chain on the fp32 kernels (their operands are fp32).
+ * hig_workspace_bytes / hig_textctx_bytes (training = 1) and hig_bwd_workspace_bytes size the buffers for these dims.
+ * `params` = fp32 master table, `params16` = the same table over the bf16 shadow (hig_cast_bf16 / hig_clip_adam_shadow).
+ * ---------------------------------------------------------------------------------------- */
+int hig_text_context_bf16_train(const hig_dims* dims, const void* const* params, const void* const* params16,
+                                const float* xf_out, void* textctx, hig_stream_t stream);
+int hig_denoiser_fwd_bf16_train(const hig_dims* dims, const void* const* params, const void* const* params16, const float* x,
+                                const int64_t* t, const int64_t* length, const float* xf_proj, const void* textctx,
+                                float* out, void* workspace, hig_stream_t stream);
+/* Writes (does not accumulate) every entry of `grads` (fp32, the layout of `params`), dx (B,T,F) or NULL, dxf_proj (B,4d),
+ * dxf_out (B,N,Lt), all fp32.  Weight gradients run on the library's second stream like hig_denoiser_bwd's. */
+int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* params, const void* const* params16, const float* x,
+                          const int64_t* t, const int64_t* length, const float* xf_out, const void* textctx,
+                          const void* workspace, const float* dout, void* const* grads, float* dx, float* dxf_proj,
+                          float* dxf_out, void* bwd_workspace, hig_stream_t stream);
+/* Pieces of the above (unit-testable).  hig_ln_bwd_bf16: hig_ln_bwd with bf16 upstream gradients `da`, rows `x` bf16 or fp32
+ * (x_f32), residual / result bf16 or fp32 (dx_f32; `res` has the type of `dx`), and the LayerNorm statistics recomputed
+ * from x (no `stats` argument).  partial: hig_ln_bwd_partial_floats(rows, n, rows_per_sample) floats. */
+int hig_ln_bwd_bf16(const void* da, int64_t ldda, const void* x, int32_t x_f32, int64_t ldx, const float* gamma,
+                    const float* beta, const float* ss, int64_t ss_ld, int32_t ss_shift_off, int32_t mod_silu,
+                    const void* res, int64_t ldr, void* dx, int32_t dx_f32, int64_t lddx, int64_t rows, int32_t n,
+                    int32_t rows_per_sample, float* dgamma, float* dbeta, float* dss, int64_t dss_ld, float* partial,
+                    hig_stream_t stream);
+/* hig_linattn_apply_bwd / hig_linattn_ctx_bwd with bf16 dY, Q, dQ / K, V, dK, dV (A, dA, kstat fp32); head dim 64 / 128. */
+int hig_linattn_apply_bwd_bf16(const void* dY, int64_t lddy, const void* Q, int64_t ldq, const float* A, void* dQ,
+                               int64_t lddq, float* dA, int32_t B, int32_t rows, int32_t H, int32_t hd, float* scratch,
+                               hig_stream_t stream);
+int hig_linattn_ctx_bwd_bf16(const float* dA, const float* A, const void* K, const void* V, int64_t ld, const float* kstat,
+                             const int64_t* length, void* dK, void* dV, int64_t ldd, int32_t B, int32_t rows, int32_t H,
+                             int32_t hd, hig_stream_t stream);
+/* out[j] = sum_i x[i][j] over bf16 rows (bias gradients); n, ldx multiples of 8; partial as for hig_colsum. */
+int hig_colsum_bf16(const void* x, int64_t ldx, int64_t rows, int32_t n, float* out, float* partial, hig_stream_t stream);
+/* n <= 12 bf16 transposes in one launch: dsts[m] (cols x rows, leading dimension ldd[m] >= rows rounded up to 8) =
+ * srcs[m] (rows x cols, leading dimension lds[m])^T.  cols, lds, ldd multiples of 8; the pointer / extent arrays are HOST
+ * arrays read before return.  Columns [rows, round_up(rows, 8)) of a destination row receive zeros. */
+int hig_transpose_bf16_batch(int32_t n, const void* const* srcs, const int64_t* lds, void* const* dsts, const int64_t* ldd,
+                             const int32_t* rows, const int32_t* cols, hig_stream_t stream);
+int hig_transpose_bf16(const void* src, int64_t ld, int32_t rows, int32_t cols, void* dst, int64_t ldd, hig_stream_t stream);
+/* f = gelu(z) (exact erf form) elementwise on bf16; dst = float(src) elementwise.  n % 8 == 0. */
+int hig_gelu_bf16(const void* z, void* f, int64_t n, hig_stream_t stream);
+int hig_cast_f32(const void* src, float* dst, int64_t n, hig_stream_t stream);
 
 /* Backward of hig_denoiser_fwd(training=1) for d(out) = dout.  Writes (does not accumulate)
  * every entry of `grads` (same table layout as params; NULL entries are skipped is NOT
@@ -348,7 +403,7 @@ int hig_recover_joints(const float* motion, const float* stats, int32_t rows, in
 #define HIG_EPI_BIAS_RES 3  /* out = res + acc + bias */
 #define HIG_EPI_BIAS_POS 4  /* out = acc + bias + pos[i % T] (joint_embed + sequence_embedding) */
 #define HIG_EPI_RES 5       /* out = res + acc */
-#define HIG_EPI_DGELU 6     /* out = acc * gelu'(aux) */
+#define HIG_EPI_DGELU 6     /* out = acc * gelu'(aux)   (hig_gemm_bf16: the pre-activation z is passed as `res`) */
 #define HIG_EPI_BIAS_SILU 7      /* out = silu(acc + bias)          (hig_gemm_bf16 only) */
 #define HIG_EPI_BIAS_RES_SILU 8  /* out = silu(res + acc + bias)    (hig_gemm_bf16 only) */
 /* Zero-initialise the descriptor (memset) and set what the chosen xf / epi need: optional pointers are tested
@@ -394,7 +449,7 @@ int hig_gemm_split(const hig_gemm_desc* g, int32_t splits, float* slabs, int64_t
  * v_mfma_f32_32x32x16_bf16, operand tiles DMA-ed global -> LDS (no register hop, no conversion).  R % 32 == 0,
  * operands 16-byte aligned, ldx / ldy multiples of 8.  bias fp32 [J]; res / C bf16 or fp32 ([I][J], any ld; rows that
  * are not 16-byte aligned fall back to element stores).  epi: HIG_EPI_NONE, _BIAS, _BIAS_GELU, _BIAS_RES, _BIAS_SILU,
- * _BIAS_RES_SILU. */
+ * _BIAS_RES_SILU, and the data-gradient forms _RES (out = res + acc) and _DGELU (out = acc * gelu'(res)). */
 typedef struct hig_gemm16_desc {
   const void* X; int64_t ldx;
   const void* Y; int64_t ldy;
@@ -414,6 +469,12 @@ typedef struct hig_gemm16_desc {
   const float* ln_colsum;
 } hig_gemm16_desc;
 int hig_gemm_bf16(const hig_gemm16_desc* g, hig_stream_t stream);
+/* hig_gemm_bf16 with the reduce range split over `splits` fp32 slabs and a deterministic (fixed-order) slab reduction: how
+ * hig_denoiser_bwd_bf16 runs dW = dC^T . act (X = dC^T (J_out, rows), Y = act^T (K_in, rows), both reduce-contiguous over
+ * the rows).  EPI_NONE, fp32 C with ldc == J, R % 64 == 0, (R / 64) % splits == 0; splits == 0: the library's rule.
+ * slabs: >= hig_gemm_bf16_split_scratch_floats(g, splits) floats. */
+int64_t hig_gemm_bf16_split_scratch_floats(const hig_gemm16_desc* g, int32_t splits);
+int hig_gemm_bf16_split(const hig_gemm16_desc* g, int32_t splits, float* slabs, int64_t slab_floats, hig_stream_t stream);
 /* Diagnostics (tools/gemm16_stamps.py, tools/gemm_ws16_stamps.py): while buf != NULL, thread 0 of every workgroup of the
  * tiled bf16 kernel (HIG_BF16_DBG & 16; buf[block * 8 + k], block < 4096) / of the weight-stationary kernel
  * (buf[block * 16 + k], 256 blocks) writes s_memtime stamps of its phases.  This pointer is the library's only mutable
@@ -642,6 +703,11 @@ int hig_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, float
 int hig_clip_adam_lrdev(float* p, const float* g, float* m, float* v, int64_t n, float lr, const float* lr_dev,
                         float b1, float b2, float eps, float max_norm, float inv_world, const float* scratch,
                         float* gnorm_out, int32_t* step_dev, hig_stream_t s);
+/* hig_clip_adam_lrdev that also writes the bf16 shadow of the updated parameters, shadow16[i] = bf16(p[i]) for i < shadow_n
+ * (shadow_n <= n, a multiple of 4): the bf16-storage step needs no separate cast pass after the update. */
+int hig_clip_adam_shadow(float* p, const float* g, float* m, float* v, int64_t n, float lr, const float* lr_dev,
+                         float b1, float b2, float eps, float max_norm, float inv_world, const float* scratch,
+                         float* gnorm_out, int32_t* step_dev, void* shadow16, int64_t shadow_n, hig_stream_t s);
 /* Releases what the library itself owns on the calling host thread: the second stream and the events
  * hig_denoiser_bwd forks its weight gradients onto (created lazily, one set per host thread and device).  Call it
  * from the thread that ran the backward, with no launch of this library in flight; later calls re-create them. */

@@ -56,11 +56,14 @@ int main() {
           const bool bf16_ok = (hd == 64 || hd == 128) && !(two && attn);
           for (int training = 0; training <= 1; ++training) {
             const int64_t w = hig_workspace_bytes(&D, training), t = hig_textctx_bytes(&D, training);
-            if (storage == 1 && (training || !bf16_ok)) { EXPECT(w < 0 && t < 0); continue; }
+            // bf16 storage: inference for head dim 64 / 128; training for the single-person model with linear attention
+            const bool bf16_train_ok = bf16_ok && !two && !attn;
+            if (storage == 1 && (!bf16_ok || (training && !bf16_train_ok))) { EXPECT(w < 0 && t < 0); continue; }
             if (two && attn) { EXPECT(w < 0); continue; }
             EXPECT(w > 0 && t > 0);
           }
           if (storage == 0 && !(two && attn)) EXPECT(hig_bwd_workspace_bytes(&D) > 0);
+          if (storage == 1) EXPECT((hig_bwd_workspace_bytes(&D) > 0) == (bf16_ok && !two && !attn));
         }
   // ---- illegal dims: rejected with a message, nothing dereferenced ----
   {
@@ -78,6 +81,21 @@ int main() {
     EXPECT(hig_denoiser_fwd(&D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr) != HIG_OK);
     EXPECT(hig_denoiser_fwd_bf16(&D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != HIG_OK);
     EXPECT(hig_text_context(&D, nullptr, nullptr, nullptr, 0, nullptr) != HIG_OK);
+    // round 4: the bf16-storage training entry points (fp32-storage dims, null arguments, shapes they do not train)
+    EXPECT(hig_denoiser_fwd_bf16_train(&D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != HIG_OK);
+    EXPECT(hig_denoiser_bwd_bf16(&D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != HIG_OK);
+    {
+      hig_dims T16 = dims(2, 60, 150, 512, 8, 1024, 2, 0, 1, 0, 0);
+      EXPECT(hig_text_context_bf16_train(&T16, nullptr, nullptr, nullptr, nullptr, nullptr) != HIG_OK);
+      EXPECT(hig_denoiser_fwd_bf16_train(&T16, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != HIG_OK);
+      T16.attn_kind = HIG_ATTN_FULL;
+      EXPECT(hig_workspace_bytes(&T16, 1) < 0 && hig_workspace_bytes(&T16, 0) > 0);
+    }
+    EXPECT(hig_ln_bwd_bf16(nullptr, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr) != HIG_OK);
+    EXPECT(hig_colsum_bf16(nullptr, 0, 0, 0, nullptr, nullptr, nullptr) != HIG_OK);
+    EXPECT(hig_transpose_bf16_batch(13, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != HIG_OK);
+    EXPECT(hig_gemm_bf16_split(nullptr, 0, nullptr, 0, nullptr) != HIG_OK);
+    EXPECT(hig_clip_adam_shadow(nullptr, nullptr, nullptr, nullptr, 0, 0.f, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, 0, nullptr) != HIG_OK);
   }
   // ---- scratch-size queries ----
   EXPECT(hig_gemm_tail_ws_bytes() > 0);

@@ -618,7 +618,7 @@ def test_bf16_storage_no_eff_forward_against_fp32_oracle(case):
     assert all(1e-4 < e < 3e-2 for e in errs), errs
 
 
-def test_bf16_storage_sees_parameter_updates_and_refuses_training():
+def test_bf16_storage_sees_parameter_updates_and_refuses_unsupported_head_dims():
     c = CASES16["small"]
     m = build(c, storage="bf16").eval()
     gi = {k: v.to(DEV) for k, v in fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"]).items()}
@@ -635,9 +635,6 @@ def test_bf16_storage_sees_parameter_updates_and_refuses_training():
     assert not torch.equal(a, b)
     m.load_state_dict(fill.fill_state_dict(m.state_dict()), strict=True)
     assert torch.equal(a, fwd())
-    m.train()
-    with pytest.raises(NotImplementedError, match="inference-only"):
-        m(gi["x"].clone().requires_grad_(True), gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
     bad = build(fill.CASES["config1"], storage="bf16").eval()             # head dim 16: not built for bf16 storage
     c1 = fill.CASES["config1"]
     g1 = {k: v.to(DEV) for k, v in fill.inputs(c1["B"], c1["T"], c1["F"], c1["d"], c1["N"], c1["Lt"], c1["lengths"], c1["t"]).items()}
