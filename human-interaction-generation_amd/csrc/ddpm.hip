@@ -390,3 +390,16 @@ extern "C" int hig_clip_adam_shadow(float* p, const float* g, float* m, float* v
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
+
+// Diagnostic marker: a one-thread kernel whose only purpose is to show up BY NAME in a rocprofv3 kernel trace, so that a
+// summariser can cut the launches of one region out of the trace (bench.py brackets the roofline microbenchmark with
+// markers 1 / 2: tools/summarize_profiles.py then averages the FFN GEMM launches between them, apart from the same kernel's
+// launches inside the forward).  Writes nothing.
+namespace {
+__global__ void hig_marker_kernel(int id) { (void)id; }
+}
+extern "C" int hig_debug_marker(int32_t id, hig_stream_t s) {
+  hipLaunchKernelGGL(hig_marker_kernel, dim3((unsigned)(id > 0 ? id : 1)), dim3(1), 0, hig_stream(s), id);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}

@@ -1639,9 +1639,6 @@ extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* pa
   const float* ssf = reinterpret_cast<const float*>(ws + w.ss);
   char* tA = b + bw.tA;
   char* tB = b + bw.tB;
-  // the transposed weight-gradient operands are zero behind their M (Mt) valid columns: the transposes never write there
-  if (hipMemsetAsync(tA, 0, (size_t)(bw.tB - bw.tA), st) != hipSuccess || hipMemsetAsync(tB, 0, (size_t)(bw.attn - bw.tB), st) != hipSuccess)
-    return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
 
   WgradFork fork(side_stream_for_current_device(st), st);
   hig_stream_t wstream = reinterpret_cast<hig_stream_t>(fork.stream());
@@ -1655,6 +1652,14 @@ extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* pa
     void* dsts[2] = {tA, tB};
     const int64_t lds_[2] = {n_out, k_in}, ldd[2] = {rows_p, rows_p};
     const int32_t rws[2] = {(int32_t)rows, (int32_t)rows}, cls[2] = {n_out, k_in};
+    if (rows_p != rows) {
+      // the reduce extent is padded to whole 64-deep k-tiles: columns [rows, rows_p) of both transposed operands must be
+      // zero, and the buffers are shared by weight gradients of different shapes (M-row and B N-row ones): clear the pad
+      // columns of THIS layout (nothing to do at the BASELINE shapes: 12 544 and 4 928 are multiples of 64)
+      if (hipMemset2DAsync(tA + rows * 2, (size_t)rows_p * 2, 0, (size_t)(rows_p - rows) * 2, (size_t)n_out, fork.stream()) != hipSuccess ||
+          hipMemset2DAsync(tB + rows * 2, (size_t)rows_p * 2, 0, (size_t)(rows_p - rows) * 2, (size_t)k_in, fork.stream()) != hipSuccess)
+        return hig_set_error(HIG_EHIP, "hipMemset2DAsync failed");
+    }
     HIG_TRY(hig_transpose_bf16_batch(2, srcs, lds_, dsts, ldd, rws, cls, wstream));
     G16 g(tA, rows_p, tB, rows_p, out, k_in, n_out, k_in, rows_p);
     g.out32();

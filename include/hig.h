@@ -708,6 +708,10 @@ int hig_clip_adam_lrdev(float* p, const float* g, float* m, float* v, int64_t n,
 int hig_clip_adam_shadow(float* p, const float* g, float* m, float* v, int64_t n, float lr, const float* lr_dev,
                          float b1, float b2, float eps, float max_norm, float inv_world, const float* scratch,
                          float* gnorm_out, int32_t* step_dev, void* shadow16, int64_t shadow_n, hig_stream_t s);
+/* Diagnostic: launches a one-thread kernel named hig_marker_kernel with a grid of `id` blocks -- a named, numbered mark in a
+ * rocprofv3 kernel trace (bench.py brackets its roofline microbenchmark with markers 1 and 2; tools/summarize_profiles.py
+ * averages the launches between them).  Does nothing else. */
+int hig_debug_marker(int32_t id, hig_stream_t s);
 /* Releases what the library itself owns on the calling host thread: the second stream and the events
  * hig_denoiser_bwd forks its weight gradients onto (created lazily, one set per host thread and device).  Call it
  * from the thread that ran the backward, with no launch of this library in flight; later calls re-create them. */

@@ -200,8 +200,8 @@ def test_bf16_transposes_and_column_sums(rows, cols):
     z = bf(torch.randn(rows * cols, generator=g) * 2).to(DEV)
     f = torch.empty_like(z)
     _lib.check(L.hig_gelu_bf16(_lib.ptr(z), _lib.ptr(f), z.numel(), s))
-    assert torch.equal(f, bf(torch.nn.functional.gelu(z.float().double()).float()).to(DEV)) or \
-        (f != bf(torch.nn.functional.gelu(z.double()).float())).float().mean().item() < 0.01
+    ref_f = torch.nn.functional.gelu(z.double())
+    assert rel(f.float(), ref_f) < 3e-3 and (f != bf(ref_f.float())).float().mean().item() < 0.03   # one rounding of the fp32 erf form
     up = torch.empty(z.numel(), device=DEV)
     _lib.check(L.hig_cast_f32(_lib.ptr(z), _lib.ptr(up), z.numel(), s))
     assert torch.equal(up, z.float())

@@ -41,6 +41,42 @@ for r in list(csv.DictReader(open(ks)))[:12]:
     n = r["Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
     lines.append("| `%s` | %s | %.2f | %.1f | %.2f |" % (n[:100], r["Calls"], int(r["TotalDurationNs"]) / 1e6,
                                                         float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+# ---- the roofline microbenchmark's own launches, cut out of the kernel TRACE by the two hig_marker_kernel marks bench.py puts
+# around it (the same template also runs inside the forward, on two streams and at half the rows: the per-name statistics
+# above mix the two) ----
+kt = one("trace/**/*kernel_trace.csv")
+if kt:
+    rows = list(csv.DictReader(open(kt)))
+    marks = sorted((int(r["Start_Timestamp"]), int(r.get("Grid_Size_X", r.get("Grid_Size", "0")) or 0)) for r in rows
+                   if "hig_marker_kernel" in r["Kernel_Name"])
+    m1 = [t for t, g in marks if g == 1]
+    m2 = [t for t, g in marks if g == 2]
+    if m1 and m2:
+        lo, hi = m1[-1], m2[-1]
+        durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows
+                if "gemm_f32_kernel" in r["Kernel_Name"] and lo < int(r["Start_Timestamp"]) < hi]
+        if durs:
+            avg = sum(durs) / len(durs) / 1e3
+            flops = 2.0 * 12544 * 512 * 1024
+            info = {"avg_us": round(avg, 2), "launches": len(durs), "tflops": round(flops / (avg * 1e-6) / 1e12, 1),
+                    "frac_of_157.3": round(flops / (avg * 1e-6) / 1e12 / 157.3, 4),
+                    "what": "FFN linear1 launches (M=12544, K=512, N=1024, bias+GELU) between hig_marker_kernel 1 and 2 of the "
+                            "profiled bench.py run: the roofline microbenchmark alone"}
+            json.dump(info, open(os.path.join(dst, tag + "_ffn_gemm_trace.json"), "w"), indent=1)
+            lines += ["", "## FFN linear1 launches of the roofline microbenchmark (kernel trace between the two markers)", "",
+                      "%d launches, average %.2f us -> %.1f TFLOP/s = %.3f of the fp32 MFMA peak (`roofline.frac` of the "
+                      "bench line is computed from HIP events over the same launches)" %
+                      (len(durs), avg, info["tflops"], info["frac_of_157.3"])]
+    # per (kernel, grid) statistics: the forward's half-batch launches and the full-batch ones differ in their grids
+    by_grid = collections.defaultdict(list)
+    for r in rows:
+        g = r.get("Grid_Size_X", r.get("Grid_Size", "?"))
+        by_grid[(r["Kernel_Name"], g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(os.path.join(dst, tag + "_kernel_by_grid.csv"), "w") as f:
+        f.write("kernel,grid_x,calls,total_ms,avg_us\n")
+        for (name, g), v in sorted(by_grid.items(), key=lambda kv: -sum(kv[1]))[:60]:
+            n = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+            f.write('"%s",%s,%d,%.3f,%.2f\n' % (n[:160], g, len(v), sum(v) / 1e6, sum(v) / len(v) / 1e3))
 lines += ["", "## PMC passes for the FFN linear1 GEMM (M=12544,K=512,N=1024, cold caches), per launch", ""]
 vals = {}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
