@@ -59,6 +59,8 @@ struct KArgs {
   float* xsum;           // reduce-slow X only: xsum[split * xsum_stride + i] = sum_r X[r][i] over this split, or null
   int64_t xsum_stride;   // (the per-split sums sit right behind each split's slab, so one reduction pass folds both)
   int epi_flags;         // bit 0: LDS-only barriers in the LDS-staged epilogue; bit 1: polynomial erf in the GELU epilogue
+  int store_policy;      // staged epilogue's output stores: 0 plain, 1 `sc1` (write-through: the output leaves during the
+                         // kernel instead of in the end-of-kernel L2 write-back), 2 `nt`; C must span < 2 GiB for 1 / 2
   // Split tail (tail_s > 1): the first `nmain` tiles (a multiple of 256: whole rounds of the chip) are computed as
   // usual; each of the `tail_rem` tiles behind them is cut into tail_s slices of the reduce range (tail_chunk
   // elements each), so that the last, partly filled round costs 1/tail_s of a tile instead of a whole one.  `ntiles`
@@ -224,6 +226,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
     j0 = (tile % a.nbj) * BJ;
   };
   float* __restrict__ C = g.C + (int64_t)split * a.slab;
+  typedef int gi32x4 __attribute__((ext_vector_type(4)));
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C, 0, a.store_policy ? (int)((((int64_t)g.I - 1) * g.ldc + g.J) * 4) : 0, 0x00020000);
   __shared__ unsigned s_ticket;
   int nth = 0;    // tiles this workgroup has started
   auto stamp = [&](int k) {
@@ -670,7 +674,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
         const f32x4 z = *reinterpret_cast<const f32x4*>(g.aux + (int64_t)i * g.ldaux + j);
         v = f32x4{v.x * hig_dgelu(z.x), v.y * hig_dgelu(z.y), v.z * hig_dgelu(z.z), v.w * hig_dgelu(z.w)};
       }
-      *reinterpret_cast<f32x4*>(C + (int64_t)i * g.ldc + j) = v;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (a.store_policy == 1)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gi32x4, v), rsC, (int)(((int64_t)i * g.ldc + j) * 4), 0, 16);
+      else if (a.store_policy == 2)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gi32x4, v), rsC, (int)(((int64_t)i * g.ldc + j) * 4), 0, 2);
+      else
+#endif
+        *reinterpret_cast<f32x4*>(C + (int64_t)i * g.ldc + j) = v;
     }
     stamp(5);
     if (a.epi_flags & 1) lds_barrier(); else __syncthreads();   // the next tile's store_tiles() reuses this LDS
@@ -855,6 +866,8 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
   a.xsum_stride = 0;
   static const int epi_flags = getenv("HIG_GEMM_EPI") ? atoi(getenv("HIG_GEMM_EPI")) : 0;   // tuning knob
   a.epi_flags = epi_flags;
+  static const int store_policy = getenv("HIG_GEMM_STORE") ? atoi(getenv("HIG_GEMM_STORE")) : 0;   // tuning knob
+  a.store_policy = (store_policy && splits == 1 && (((int64_t)g.I - 1) * g.ldc + g.J) * 4 < (1ll << 31) && g.res != g.C) ? store_policy : 0;
   const int nbi = (g.I + BI - 1) / BI;
   a.nbj = (g.J + BJ - 1) / BJ;
   a.ntiles = nbi * a.nbj;

@@ -50,7 +50,21 @@ struct WsArgs {
   const float* stats_in;
   const float* colsum;
   unsigned long long* stamps;   // diagnostic (hig_gemm_ws16_debug_stamps): 16 s_memtime stamps per workgroup, else NULL
+  int store_policy;             // output stores: 0 plain (lines stay dirty in the XCD's L2 until the end-of-kernel write-back),
+                                // 1 `sc1` (write-through: the bytes leave during the kernel), 2 `nt`
 };
+
+typedef int ws_i32x4 __attribute__((ext_vector_type(4)));
+// 16-byte output store through the C buffer descriptor with a cache policy (a compiler builtin, not inline asm: the hazard
+// recogniser and the wait-count pass must see a 128-bit VMEM store)
+__device__ __forceinline__ void ws_store16(__amdgpu_buffer_rsrc_t rsC, int byte_off, const bf16x8& v, int policy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const ws_i32x4 d = __builtin_bit_cast(ws_i32x4, v);
+  if (policy == 1) __builtin_amdgcn_raw_buffer_store_b128(d, rsC, byte_off, 0, 16);        // sc1: write-through
+  else if (policy == 2) __builtin_amdgcn_raw_buffer_store_b128(d, rsC, byte_off, 0, 2);    // nt
+  else __builtin_amdgcn_raw_buffer_store_b128(d, rsC, byte_off, 0, 0);
+#endif
+}
 
 unsigned long long* g_ws_stamps = nullptr;
 
@@ -166,6 +180,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   // raw (stride 0) buffer descriptors over the whole operands; rows are clamped, so nothing is out of range
   [[maybe_unused]] __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.X), 0, (int)(((int64_t)(a.I - 1) * a.ldx + K) * 2), 0x00020000);
   [[maybe_unused]] __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.W), 0, (int)(((int64_t)(a.J - 1) * a.ldy + K) * 2), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)(((int64_t)(a.I - 1) * a.ldc + a.J) * 2), 0x00020000);
   [[maybe_unused]] __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(HAS_RES ? a.res : a.X), 0, (int)(((int64_t)(a.I - 1) * (HAS_RES ? a.ldr : a.ldx) + (HAS_RES ? a.J : K)) * 2), 0x00020000);
   // ---- DMA: instruction n of a tile covers bytes [1024 n, 1024 n + 1024) of the [32][K] image; LDS position p of row r
   // receives the source row's 16-byte chunk p ^ (r & 15) ------------------------------------------------------------
@@ -349,7 +364,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
       // values.  No predicate: every wave must issue exactly NPC stores per tile -- the counted waits assume it (a wave
       // whose lanes are all masked would skip the instruction and leave an OLDER request, e.g. a DMA, uncounted).
       const int i = min(i0 + r, a.I - 1);
-      *reinterpret_cast<bf16x8*>(a.C + (int64_t)i * a.ldc + j0 + 8 * p) = v;
+      ws_store16(rsC, (i * (int)a.ldc + j0 + 8 * p) * 2, v, a.store_policy);
       if constexpr (XT == 1) {
         // LayerNorm fold, producer side: (sum, sum of squared deviations from the panel mean) of this row's 128 ROUNDED
         // outputs (what the consumer will read).  The 16 lanes that hold a row's pieces are consecutive: v_dot2c_f32_bf16
@@ -521,6 +536,10 @@ int launch_ws(const hig_gemm16_desc& g, int slots_per_xcd, hipStream_t st) {
   a.stats_in = g.row_stats_in;
   a.colsum = g.ln_colsum;
   a.stamps = g_ws_stamps;
+  static const int store_policy = getenv("HIG_WS16_STORE") ? atoi(getenv("HIG_WS16_STORE")) : 0;   // tuning knob
+  // in-place residual updates (C aliases res: the inference forward's residual stream) keep plain stores: a later tile's
+  // residual DMA must see this kernel's own earlier stores in the same L2
+  a.store_policy = (g.res && g.res == g.C) ? 0 : store_policy;
   static const int dbg = getenv("HIG_BF16_WS_DBG") ? atoi(getenv("HIG_BF16_WS_DBG")) : 0;   // timing ablations (diagnostic instances only)
   if constexpr (KW == 512 && KSPLIT == 1 && NWJ == 4 && NCB == 2 && EPI == HIG_EPI_BIAS_GELU) {
     const dim3 gr(8 * slots_per_xcd), bl(64 * NWJ * KSPLIT);
@@ -602,7 +621,8 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
   if (g.I < min_rows) return decline("too few rows");
   auto al = [](const void* p, int n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
   if (!(g.ldc % 8 == 0 && al(g.C, 16))) return decline("C not 16-byte aligned / ldc not a multiple of 8");
-  if ((int64_t)g.I * g.ldx >= (1ll << 30) || (int64_t)g.J * g.ldy >= (1ll << 30) || (g.res && (int64_t)g.I * g.ldr >= (1ll << 30)))
+  if ((int64_t)g.I * g.ldx >= (1ll << 30) || (int64_t)g.J * g.ldy >= (1ll << 30) || (g.res && (int64_t)g.I * g.ldr >= (1ll << 30)) ||
+      (int64_t)g.I * g.ldc >= (1ll << 30))
     return decline("operand beyond the 32-bit byte offsets of the DMA descriptors");
   const bool has_res = has_res_epi(g.epi);
   if (has_res && !(g.ldr % 4 == 0 && al(g.res, 8))) return decline("residual not 8-byte aligned / ldr not a multiple of 4");
