@@ -309,15 +309,27 @@ extern "C" int64_t hig_bwd_workspace_bytes(const hig_dims* dims) {
   return bwd_layout(D).total * 4;
 }
 
+namespace {
+struct SideStream;
+int text_context_impl(const Dims& D, const void* const* params, const float* xf_out, void* textctx, int training, hipStream_t st,
+                      hipEvent_t* layer_done);
+}
 extern "C" int hig_text_context(const hig_dims* dims, const void* const* params, const float* xf_out,
                                 void* textctx, int training, hig_stream_t stream) {
   Dims D;
   HIG_TRY(check_dims(dims, D));
   HIG_REQUIRE(params && xf_out && textctx, "hig_text_context: null argument");
   HIG_REQUIRE(!D.bf16, "hig_text_context: bf16 storage goes through hig_text_context_bf16");
+  return text_context_impl(D, params, xf_out, textctx, training, hig_stream(stream), nullptr);
+}
+namespace {
+// layer_done (nullable): event l is recorded on `st` behind layer l's launches (hig_denoiser_fwd_text waits for it in front of
+// layer l's cross-attention)
+int text_context_impl(const Dims& D, const void* const* params, const float* xf_out, void* textctx, int training, hipStream_t st,
+                      hipEvent_t* layer_done) {
+  hig_stream_t stream = reinterpret_cast<hig_stream_t>(st);
   const TextLayout tl = text_layout(D, training);
   float* base = static_cast<float*>(textctx);
-  hipStream_t st = hig_stream(stream);
   float* stt = base + tl.stt;
   HIG_TRY(hig_rowstats(xf_out, D.Lt, D.Mt, D.Lt, stt, stream));
   for (int l = 0; l < D.L; ++l) {
@@ -332,17 +344,23 @@ extern "C" int hig_text_context(const hig_dims* dims, const void* const* params,
     // full attention (:253-259) consumes key/value directly
     if (!D.full)
       HIG_TRY(hig_linattn_ctx(kv, kv + D.d, 2 * D.d, D.B, D.N, D.H, D.hd, nullptr, Ac, kstc, base + tl.cscr, stream));
+    if (layer_done && hipEventRecord(layer_done[l], st) != hipSuccess) return hig_set_error(HIG_EHIP, "hipEventRecord failed");
   }
   return HIG_OK;
 }
+}  // namespace
 
 namespace {
 
 // (the library-owned second stream of the calling thread: protocol described at WgradFork below)
+constexpr int kMaxTextLayers = 32;
 struct SideStream {
   hipStream_t s2 = nullptr;
   hipEvent_t ready = nullptr;
   hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
+  // third stream: the cross-attention text side of hig_denoiser_fwd_text runs next to the first layers (one event per layer)
+  hipStream_t s3 = nullptr;
+  hipEvent_t text_done[kMaxTextLayers] = {};
   bool ok = false, failed = false;
 };
 
@@ -373,6 +391,8 @@ SideStream* side_stream_for_current_device(hipStream_t caller) {
     bool good = hipStreamCreateWithFlags(&s.s2, hipStreamNonBlocking) == hipSuccess;
     good = good && hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 4 && good; ++i) good = hipEventCreateWithFlags(&s.done[i], hipEventDisableTiming) == hipSuccess;
+    good = good && hipStreamCreateWithFlags(&s.s3, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < kMaxTextLayers && good; ++i) good = hipEventCreateWithFlags(&s.text_done[i], hipEventDisableTiming) == hipSuccess;
     if (!good) {   // do not retry (and leak) on every call: stay on the caller's stream for good
       s.failed = true;
       return nullptr;
@@ -384,10 +404,25 @@ SideStream* side_stream_for_current_device(hipStream_t caller) {
 
 }  // namespace
 
+static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, const float* x, const int64_t* t, const int64_t* length,
+                             const float* xf_proj, const float* xf_out_for_text, const void* textctx, float* out, void* workspace,
+                             int training, hig_stream_t stream);
 extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params, const float* x,
                                 const int64_t* t, const int64_t* length, const float* xf_proj,
                                 const void* textctx, float* out, void* workspace, int training,
                                 hig_stream_t stream) {
+  return denoiser_fwd_impl(dims, params, x, t, length, xf_proj, nullptr, textctx, out, workspace, training, stream);
+}
+// hig_text_context + hig_denoiser_fwd as ONE call (include/hig.h): the text side is forked onto a library-owned stream
+extern "C" int hig_denoiser_fwd_text(const hig_dims* dims, const void* const* params, const float* x, const int64_t* t,
+                                     const int64_t* length, const float* xf_proj, const float* xf_out, void* textctx, float* out,
+                                     void* workspace, int training, hig_stream_t stream) {
+  HIG_REQUIRE(xf_out, "hig_denoiser_fwd_text: null argument");
+  return denoiser_fwd_impl(dims, params, x, t, length, xf_proj, xf_out, textctx, out, workspace, training, stream);
+}
+static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, const float* x, const int64_t* t, const int64_t* length,
+                             const float* xf_proj, const float* xf_out_for_text, const void* textctx, float* out, void* workspace,
+                             int training, hig_stream_t stream) {
   Dims D;
   HIG_TRY(check_dims(dims, D));
   HIG_REQUIRE(params && x && t && xf_proj && textctx && out && workspace, "hig_denoiser_fwd: null argument");
@@ -407,6 +442,32 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
     return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
   const TailScratchScope tail_scope(ws + w.gtail);
 
+  // The cross-attention text side (hig_denoiser_fwd_text): layer l's context matrices are first needed in front of layer l's
+  // cross-attention, a third of a layer into the forward -- its 2 L launches (key/value GEMMs over B N rows, context builds)
+  // run on a third stream next to the first layers, one event per layer (events only: eager launches; under capture, or
+  // without the library's streams, they run first on the caller's stream as hig_text_context would).
+  hipEvent_t* text_ev = nullptr;
+  if (xf_out_for_text) {
+    static const int text_fork = getenv("HIG_TEXT_FORK") ? atoi(getenv("HIG_TEXT_FORK")) : 1;   // tuning knob
+    SideStream* ts = (text_fork && D.L <= kMaxTextLayers) ? side_stream_for_current_device(st) : nullptr;
+    if (ts) {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) ts = nullptr;
+    }
+    if (ts) {
+      if (hipEventRecord(ts->ready, st) != hipSuccess || hipStreamWaitEvent(ts->s3, ts->ready, 0) != hipSuccess)
+        return hig_set_error(HIG_EHIP, "text fork failed");
+      const int rc = text_context_impl(D, params, xf_out_for_text, const_cast<void*>(textctx), training, ts->s3, ts->text_done);
+      if (rc != HIG_OK) {   // whatever was enqueued on the text stream is joined before the error leaves
+        (void)hipEventRecord(ts->text_done[0], ts->s3);
+        (void)hipStreamWaitEvent(st, ts->text_done[0], 0);
+        return rc;
+      }
+      text_ev = ts->text_done;
+    } else {
+      HIG_TRY(text_context_impl(D, params, xf_out_for_text, const_cast<void*>(textctx), training, st, nullptr));
+    }
+  }
   // K0: emb = time_embed(timestep_embedding(t)) + xf_proj; all 3L scale/shift pairs in ONE GEMM
   HIG_TRY(hig_timestep_embedding(t, D.B, d, ws + w.te, stream));
   // per-sample (B-row) GEMMs: weight-bandwidth bound; split over the reduce range with the still unused layer
@@ -491,6 +552,7 @@ extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params,
     HIG_L(hig_gemm_launch(G(R(w.xn2, d), d, 0, PL(params, l, HIG_L_CA_Q_W), d, 0, R(w.qc, d), d, Mh, d, d)
                               .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).prec(D.prec).g, 1, nullptr, s));
     const float* Acl = tc + tl.layer0 + tl.lstride * l + tl.Ac + aoff;
+    if (text_ev && hipStreamWaitEvent(s, text_ev[l], 0) != hipSuccess) return fail(hig_set_error(HIG_EHIP, "text join failed"));
     if (D.full) {
       const float* kvl = tc + tl.kv + tl.kv_stride * l + (int64_t)b0 * D.N * 2 * d;
       HIG_L(hig_fullattn_fwd(R(w.qc, d), d, kvl, kvl + d, 2 * d, nb, D.T, D.N, D.H, D.hd, nullptr, R(w.y2, d), d,
@@ -1026,6 +1088,9 @@ extern "C" int hig_shutdown(void) {
     if (hipSetDevice(dev) != hipSuccess) { rc = hig_set_error(HIG_EHIP, "hig_shutdown: hipSetDevice(%d) failed", dev); continue; }
     if (hipStreamSynchronize(s.s2) != hipSuccess) rc = hig_set_error(HIG_EHIP, "hig_shutdown: side stream of device %d is in error", dev);
     for (int i = 0; i < 4; ++i) if (s.done[i]) (void)hipEventDestroy(s.done[i]);
+    if (s.s3 && hipStreamSynchronize(s.s3) != hipSuccess) rc = hig_set_error(HIG_EHIP, "hig_shutdown: text stream of device %d is in error", dev);
+    for (int i = 0; i < kMaxTextLayers; ++i) if (s.text_done[i]) (void)hipEventDestroy(s.text_done[i]);
+    if (s.s3) (void)hipStreamDestroy(s.s3);
     if (s.ready) (void)hipEventDestroy(s.ready);
     if (s.s2) (void)hipStreamDestroy(s.s2);
     s = SideStream();
@@ -1645,8 +1710,13 @@ extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* pa
   // dW[n][k] = sum_m dC[m][n] act[m][k] (+ the bias gradient = column sums of dC): both operands transposed to
   // reduce-contiguous bf16 (n_out x Mp), (k_in x Mp), then the split-R bf16 GEMM into the fp32 gradient.  Everything on the
   // weight-gradient stream (protocol: WgradFork).
+  static const int wg16 = getenv("HIG_WG16") ? atoi(getenv("HIG_WG16")) : 1;   // tuning knob: 0 = transposes + tiled split-R GEMM
   auto wgrad_act = [&](const void* dC, int n_out, const void* act, int k_in, float* out, int64_t rows, int64_t rows_p, float* dbias) -> int {
     HIG_TRY(fork.begin());
+    if (wg16) {   // straight from the row-major operands (transpose reads), bias gradient in the same pass
+      HIG_TRY(hig_wgrad16_launch(dC, n_out, act, k_in, rows, n_out, k_in, out, dbias, 0, slabs, bw.slab_floats, fork.stream()));
+      return fork.end();
+    }
     if (dbias) HIG_TRY(hig_colsum_bf16(dC, n_out, rows, n_out, dbias, colp_w, wstream));
     const void* srcs[2] = {dC, act};
     void* dsts[2] = {tA, tB};

@@ -50,6 +50,7 @@ struct WsArgs {
   const float* stats_in;
   const float* colsum;
   unsigned long long* stamps;   // diagnostic (hig_gemm_ws16_debug_stamps): 16 s_memtime stamps per workgroup, else NULL
+  int store_slack;              // 1: the stores of the last iteration may still be in flight at the top of an iteration
   int store_policy;             // output stores: 0 plain (lines stay dirty in the XCD's L2 until the end-of-kernel write-back),
                                 // 1 `sc1` (write-through: the bytes leave during the kernel), 2 `nt`
 };
@@ -387,7 +388,15 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   if (NXB >= 3 && nt > 1) { dma_tile(1, 1); dma_pend = true; }
   stamp(2);
   for (int t = 0; t < nt; ++t) {
-    if (NXB >= 3 && dma_pend) WS_WAIT_ALL_BUT(NQ); else WS_WAIT_ALL_BUT(0);
+    // (what must have landed here: X(t), requested two iterations ago, and -- residual epilogues -- the residual tile requested
+    // in the last one.  Without a residual, the output stores of the last iteration need not be done either: they have read
+    // their staging buffer (an LDS read, long retired) and nothing waits for their acknowledgement -- a write-through store
+    // takes about as long as an iteration to be acknowledged.  The stores of iteration t - 1 are NPC requests issued ahead of
+    // its NQ DMA requests.)
+    constexpr bool STORE_SLACK = !HAS_RES && XT != 2 && NXB >= 3;
+    if (STORE_SLACK && a.store_slack && dma_pend && t >= 3) WS_WAIT_ALL_BUT(NQ + NPC);
+    else if (NXB >= 3 && dma_pend) WS_WAIT_ALL_BUT(NQ);
+    else WS_WAIT_ALL_BUT(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();               // everyone's share has landed; k-loop(t-1) is over everywhere: its buffer, staging(t-1), parked(t-1) are complete
     asm volatile("" ::: "memory");
@@ -536,10 +545,15 @@ int launch_ws(const hig_gemm16_desc& g, int slots_per_xcd, hipStream_t st) {
   a.stats_in = g.row_stats_in;
   a.colsum = g.ln_colsum;
   a.stamps = g_ws_stamps;
-  static const int store_policy = getenv("HIG_WS16_STORE") ? atoi(getenv("HIG_WS16_STORE")) : 0;   // tuning knob
+  // output stores write through (`sc1`): a launch's 13-39 MB of output otherwise sit dirty in the XCDs' L2s until the
+  // end-of-kernel write-back, during which nothing runs (same-call A/B at M = 12 544: FFN linear1 25.9 -> 23.4 us, q/k/v 28.5
+  // -> 26.4, stylization-out 16.2 -> 15.0; forward B = 64 1.570 -> 1.537 ms; `nt` = 2 is mixed: ca-q 12.6 but FFN linear1 26.9)
+  static const int store_policy = getenv("HIG_WS16_STORE") ? atoi(getenv("HIG_WS16_STORE")) : 1;   // tuning knob
   // in-place residual updates (C aliases res: the inference forward's residual stream) keep plain stores: a later tile's
   // residual DMA must see this kernel's own earlier stores in the same L2
   a.store_policy = (g.res && g.res == g.C) ? 0 : store_policy;
+  static const int store_slack = getenv("HIG_WS16_SLACK") ? atoi(getenv("HIG_WS16_SLACK")) : 0;   // tuning knob
+  a.store_slack = store_slack;
   static const int dbg = getenv("HIG_BF16_WS_DBG") ? atoi(getenv("HIG_BF16_WS_DBG")) : 0;   // timing ablations (diagnostic instances only)
   if constexpr (KW == 512 && KSPLIT == 1 && NWJ == 4 && NCB == 2 && EPI == HIG_EPI_BIAS_GELU) {
     const dim3 gr(8 * slots_per_xcd), bl(64 * NWJ * KSPLIT);

@@ -27,6 +27,9 @@ inline int hig_chip_xcds() { const int c = hig_chip_cus() / 32; return c < 1 ? 1
 int hig_gemm16_launch(const hig_gemm16_desc& g, hipStream_t st);
 // split-R form of the tiled bf16 kernel + deterministic slab reduction (weight gradients); splits == 0: library rule
 int hig_gemm16_split_launch(const hig_gemm16_desc& g, int splits, float* slabs, int64_t slab_floats, hipStream_t st);
+// dW = dC^T . act (+ dbias = column sums of dC) straight from the row-major bf16 operands (wgrad16.hip: transpose reads)
+int hig_wgrad16_launch(const void* dC, int64_t ldd, const void* act, int64_t ldx, int64_t rows, int J, int K, float* dW, float* dbias,
+                       int splits, float* slabs, int64_t slab_floats, hipStream_t st);
 // out[e] = sum_s slabs[s * slab + e], e < n (n % 4 == 0, 16-byte aligned), in split order (gemm.hip)
 int hig_reduce_slabs(const float* slabs, int splits, int64_t slab, int64_t n, float* out, hipStream_t st);
 // weight-stationary variant (gemm_ws16.hip): HIG_OK = launched, 1 = shape not served (use the tiled kernel), < 0 = error

@@ -687,9 +687,23 @@ class MotionTransformer(nn.Module):
         nbytes = L.hig_workspace_bytes(C.byref(dims), int(training))
         if nbytes < 0:
             raise RuntimeError("libhig: " + _lib.last_error())
+        out = torch.empty(B, T, self.input_feats, device=x.device, dtype=torch.float32)
+        if not training and not self._bf16() and not self.cache_text_context:
+            # the reference's per-call forward (text side recomputed every call, transformer.py:144-150) as ONE library call:
+            # the text side runs on a side stream next to the first layers (hig_denoiser_fwd_text)
+            tbytes = L.hig_textctx_bytes(C.byref(dims), 0)
+            if tbytes < 0:
+                raise RuntimeError("libhig: " + _lib.last_error())
+            textctx = self._pool.take("textctx_i", tbytes, x.device)
+            ws = self._pool.take("fwd_i", nbytes, x.device)
+            _lib.check(L.hig_denoiser_fwd_text(C.byref(dims), fp.param_table(), _lib.ptr(x), _lib.ptr(t), _lib.ptr(length),
+                                               _lib.ptr(xf_proj), _lib.ptr(xf_out), _lib.ptr(textctx), _lib.ptr(out), _lib.ptr(ws),
+                                               0, _lib.stream_ptr()))
+            self._pool.give("fwd_i", ws, x.device)
+            self._pool.give("textctx_i", textctx, x.device)
+            return out, None
         textctx = self._text_context(dims, xf_out, training)
         ws = self._pool.take("fwd_t" if training else "fwd_i", nbytes, x.device)
-        out = torch.empty(B, T, self.input_feats, device=x.device, dtype=torch.float32)
         if self._bf16() and training:
             _lib.check(L.hig_denoiser_fwd_bf16_train(C.byref(dims), fp.param_table(), fp.shadow16(self._param_version()),
                                                      _lib.ptr(x), _lib.ptr(t), _lib.ptr(length), _lib.ptr(xf_proj),

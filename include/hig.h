@@ -171,6 +171,15 @@ int hig_denoiser_fwd(const hig_dims* dims, const void* const* params, const floa
                      const void* textctx, float* out, void* workspace, int training,
                      hig_stream_t stream);
 
+/* hig_text_context followed by hig_denoiser_fwd as ONE call -- what MotionTransformer.forward computes per call
+ * (transformer.py:144-150 inside :407-426): the text side (xf_out -> `textctx`, caller-owned scratch of hig_textctx_bytes) is
+ * forked onto a library-owned stream and joined layer by layer (layer l's context matrices are first needed in front of
+ * layer l's cross-attention), so its 2 L small launches run next to the first decoder layers instead of in front of them.
+ * Same results as the two calls, bit for bit.  Under hipGraph capture (or HIG_TEXT_FORK=0) the text side runs first on `stream`. */
+int hig_denoiser_fwd_text(const hig_dims* dims, const void* const* params, const float* x, const int64_t* t,
+                          const int64_t* length, const float* xf_proj, const float* xf_out, void* textctx, float* out,
+                          void* workspace, int training, hig_stream_t stream);
+
 /* bf16-storage forward (dims->storage == HIG_STORE_BF16, inference).  `params` is the fp32 table above (biases,
  * LayerNorm vectors and the F-wide input projection are read from it), `params16` the same table laid over the bf16
  * shadow of the flat parameter buffer (hig_cast_bf16): entry k = shadow base + 2 x (offset of entry k in floats).
@@ -248,6 +257,15 @@ int hig_transpose_bf16(const void* src, int64_t ld, int32_t rows, int32_t cols, 
 /* f = gelu(z) (exact erf form) elementwise on bf16; dst = float(src) elementwise.  n % 8 == 0. */
 int hig_gelu_bf16(const void* z, void* f, int64_t n, hig_stream_t stream);
 int hig_cast_f32(const void* src, float* dst, int64_t n, hig_stream_t stream);
+
+/* Weight gradient of an nn.Linear over bf16 rows WITHOUT transposed operand copies (csrc/wgrad16.hip): dW (J, K) fp32 dense =
+ * dC^T . act, dbias (J) fp32 (nullable) = column sums of dC, from dC (rows, J) and act (rows, K) bf16 row-major.  Row chunks
+ * land row-major in LDS by DMA, ds_read_b64_tr_b16 supplies the matrix-core operands; the rows are split over `splits`
+ * workgroup slices (0 = the library's rule) whose partial tiles are summed in split order (deterministic).  J, K and the
+ * leading dimensions multiples of 8, 16-byte aligned buffers.  slabs: hig_wgrad_bf16_scratch_floats(J, K, splits) floats. */
+int64_t hig_wgrad_bf16_scratch_floats(int32_t J, int32_t K, int32_t splits);
+int hig_wgrad_bf16(const void* dC, int64_t ldd, const void* act, int64_t ldx, int64_t rows, int32_t J, int32_t K, float* dW,
+                   float* dbias, int32_t splits, float* slabs, int64_t slab_floats, hig_stream_t stream);
 
 /* Backward of hig_denoiser_fwd(training=1) for d(out) = dout.  Writes (does not accumulate)
  * every entry of `grads` (same table layout as params; NULL entries are skipped is NOT

@@ -90,6 +90,37 @@ def test_weight_gradient_gemm_split_over_the_rows(I, J, R, splits):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("rows,J,K,splits,bias", [(12544, 512, 512, 0, True), (12544, 1536, 512, 0, True), (12544, 512, 1024, 0, True),
+                                                  (12544, 1024, 512, 0, False), (4928, 1024, 256, 0, True), (66, 384, 128, 0, True),
+                                                  (120, 96, 128, 1, True), (225, 512, 64, 2, True), (154, 256, 32, 0, True),
+                                                  (3001, 128, 96, 3, True), (3001, 128, 96, 0, False), (64, 32, 32, 0, True),
+                                                  (1, 64, 64, 0, True), (700, 264, 40, 0, True)])
+def test_weight_gradient_straight_from_row_major_operands(rows, J, K, splits, bias):
+    """hig_wgrad_bf16 (csrc/wgrad16.hip): dW = dC^T . act and dbias = column sums of dC from the ROW-MAJOR bf16 operands (the
+    transposition happens in the LDS read, ds_read_b64_tr_b16), rows split over workgroup slices, fixed-order slab sum.
+    fp64 reference on the same bf16 operands; ragged row counts (a partly filled last chunk), column counts that are not
+    multiples of the 128-wide tile, forced and automatic splits; two launches give the same bits."""
+    g = torch.Generator().manual_seed(rows + J + K)
+    dC, act = bf(torch.randn(rows, J, generator=g)), bf(torch.randn(rows, K, generator=g))
+    dCd, actd = dC.to(DEV), act.to(DEV)
+    L = _lib.lib()
+    n = L.hig_wgrad_bf16_scratch_floats(J, K, splits)
+    outs = []
+    for _ in range(2):
+        dW = torch.full((J, K), float("nan"), device=DEV)
+        db = torch.full((J,), float("nan"), device=DEV)
+        slabs = torch.full((n,), float("nan"), device=DEV)
+        _lib.check(L.hig_wgrad_bf16(_lib.ptr(dCd), J, _lib.ptr(actd), K, rows, J, K, _lib.ptr(dW), _lib.ptr(db) if bias else None, splits,
+                                    _lib.ptr(slabs), n, _lib.stream_ptr()))
+        outs.append((dW, db))
+    ref = dC.double().t() @ act.double()
+    assert torch.isfinite(outs[0][0]).all()
+    assert rel(outs[0][0], ref) < 2e-6
+    assert torch.equal(outs[0][0], outs[1][0])
+    if bias:
+        assert rel(outs[0][1], dC.double().sum(0)) < 2e-6 and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("rows,n,rps,mod,x_f32,dx_f32,with_res", [(392, 512, 196, True, 0, 0, False), (392, 512, 196, False, 0, 0, True),
                                                                   (154, 256, 77, False, 1, 1, True), (154, 256, 77, False, 1, 1, False),
                                                                   (120, 128, 60, True, 0, 0, False), (600, 1024, 300, False, 0, 0, True),
