@@ -100,8 +100,7 @@ __device__ __forceinline__ void hig_panel_stats16(const bf16x8& v, float& s1, fl
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) s = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{v[2 * k], v[2 * k + 1]}, ones, s, false);
-#pragma unroll
-  for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
+  s = row16_sum(s);
   const float mean = s * (1.0f / 128.0f);
   float q = 0.f;
 #pragma unroll
@@ -109,8 +108,7 @@ __device__ __forceinline__ void hig_panel_stats16(const bf16x8& v, float& s1, fl
     const float t = (float)v[k] - mean;
     q = fmaf(t, t, q);
   }
-#pragma unroll
-  for (int off = 1; off < 16; off <<= 1) q += __shfl_xor(q, off, 64);
+  q = row16_sum(q);
   s1 = s;
   m2 = q;
 }

@@ -51,13 +51,41 @@ __device__ __forceinline__ float hig_dgelu(float x) {
          x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions by DPP (data-parallel primitives: the operand of a VALU instruction comes from another lane of the
+// same 16-lane row, ~one instruction's latency) instead of __shfl_xor, which hipcc lowers to ds_bpermute_b32 -- an LDS-pipe
+// round trip of ~100 cycles per step, six dependent steps per 64-lane sum: the row kernels (one wave per row, two to four
+// dependent reductions per row) spent most of their time there.
+//   row16: butterfly inside each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror): every lane of the row
+//          ends with the row's total;
+//   wave : then the four row totals by row_bcast:15 (rows 1, 3 += lane 15 of the row before) and row_bcast:31 (rows 2, 3 +=
+//          lane 31): lane 63 holds the total, v_readlane_b32 hands it to every lane as a scalar.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float hig_dpp(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += hig_dpp<0xB1, 0xf>(0.f, v);     // quad_perm [1,0,3,2]
+  v += hig_dpp<0x4E, 0xf>(0.f, v);     // quad_perm [2,3,0,1]
+  v += hig_dpp<0x141, 0xf>(0.f, v);    // row_half_mirror
+  v += hig_dpp<0x140, 0xf>(0.f, v);    // row_mirror
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, hig_dpp<0xB1, 0xf>(v, v));
+  v = fmaxf(v, hig_dpp<0x4E, 0xf>(v, v));
+  v = fmaxf(v, hig_dpp<0x141, 0xf>(v, v));
+  v = fmaxf(v, hig_dpp<0x140, 0xf>(v, v));
   return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  v += hig_dpp<0x142, 0xa>(0.f, v);    // row_bcast:15 into rows 1 and 3
+  v += hig_dpp<0x143, 0xc>(0.f, v);    // row_bcast:31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = row16_max(v);
+  v = fmaxf(v, hig_dpp<0x142, 0xa>(v, v));
+  v = fmaxf(v, hig_dpp<0x143, 0xc>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }

@@ -259,6 +259,39 @@ __device__ __forceinline__ void store16(T* p, const f32x16& a, float scale = 1.0
     st4(p + 8 * q, make_float4(a[4 * q] * scale, a[4 * q + 1] * scale, a[4 * q + 2] * scale, a[4 * q + 3] * scale));
 }
 
+// A finished 64-row x HD tile leaves through LDS as WHOLE rows (sT: [64][HD + 4] fp32; HD / VEC lanes of 16 bytes per row,
+// 256 / (HD / VEC) rows per pass): the accumulator layout gives a lane 4 consecutive columns of ONE row per quad, which
+// written directly is 16 (fp32) or 8 (bf16) bytes into each of 32 rows per store instruction -- every 64-byte sector of the
+// output rewritten piecemeal.  Rows at or beyond `rows` are not stored.
+template <int HD, typename TIO>
+__device__ __forceinline__ void store_tile_rows(const float* sT, TIO* gbase, int64_t ld, int r0, int rows) {
+  constexpr int LDP = HD + 4;
+  constexpr int VEC = sizeof(TIO) == 2 ? 8 : 4;          // elements per 16-byte store
+  constexpr int LPR = HD / VEC, RPP = 256 / LPR;         // lanes per row, rows per pass
+  const int c = (threadIdx.x % LPR) * VEC, rr0 = threadIdx.x / LPR;
+#pragma unroll
+  for (int rr = rr0; rr < CH; rr += RPP) {
+    const int r = r0 + rr;
+    if (r >= rows) break;
+    const float4 a = *reinterpret_cast<const float4*>(sT + rr * LDP + c);
+    if constexpr (sizeof(TIO) == 2) {
+      const float4 b = *reinterpret_cast<const float4*>(sT + rr * LDP + c + 4);
+      typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+      *reinterpret_cast<bf16x8_t*>(gbase + (int64_t)r * ld + c) =
+          bf16x8_t{(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+    } else {
+      *reinterpret_cast<float4*>(gbase + (int64_t)r * ld + c) = a;
+    }
+  }
+}
+template <int HD>
+__device__ __forceinline__ void stage16(float* sT, int row, int col, const f32x16& a, float scale = 1.0f) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<float4*>(sT + row * (HD + 4) + col + 8 * q) =
+        make_float4(a[4 * q] * scale, a[4 * q + 1] * scale, a[4 * q + 2] * scale, a[4 * q + 3] * scale);
+}
+
 // Y tile (64 rows) = softmax_c(Q tile) . A[b,h]
 template <int HD, typename TIO>
 __global__ __launch_bounds__(256) void apply_mfma_kernel(const TIO* __restrict__ Q, int64_t ldq,
@@ -312,12 +345,11 @@ __global__ __launch_bounds__(256) void apply_mfma_kernel(const TIO* __restrict__
         acc[tj] = mfma4(acc[tj], ap[0], ap[HD], ap[2 * HD], ap[3 * HD], q4);
       }
     }
-    const int r = r0 + wi * 32 + lr;
-    if (r < rows) {
-      TIO* yp = Y + ((int64_t)b * rows + r) * ldy + h * HD + wj * (HD / 2) + 4 * lh;
+    __syncthreads();   // every wave is done reading sQ: the Y tile is staged there and leaves as whole rows
 #pragma unroll
-      for (int tj = 0; tj < TJ; ++tj) store16(yp + 32 * tj, acc[tj]);
-    }
+    for (int tj = 0; tj < TJ; ++tj) stage16<HD>(sQ, wi * 32 + lr, wj * (HD / 2) + 32 * tj + 4 * lh, acc[tj]);
+    __syncthreads();
+    store_tile_rows<HD, TIO>(sQ, Y + (int64_t)b * rows * ldy + h * HD, ldy, r0, rows);
     __syncthreads();   // sQ is rewritten by the next chunk
   }
 }
@@ -986,19 +1018,18 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const TIO* __restri
     if (lh == 0) srow[wj * CH + rl] = part;
     __syncthreads();
     const float sdot = srow[rl] + srow[CH + rl];
-    const int r = r0 + rl;
-    if (r < rows) {
-      TIO* op = dQ + ((int64_t)b * rows + r) * lddq + h * HD + wj * (HD / 2) + 4 * lh;
+    // (the barrier above also ended every wave's reads of sD: the dQ tile is staged there and leaves as whole rows)
 #pragma unroll
-      for (int tj = 0; tj < TB; ++tj)
+    for (int tj = 0; tj < TB; ++tj)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 qv = *reinterpret_cast<const float4*>(sQ + rl * LDP + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh);
-          st4(op + 32 * tj + 8 * q,
-              make_float4(qv.x * (dq[tj][4 * q] - sdot), qv.y * (dq[tj][4 * q + 1] - sdot),
-                          qv.z * (dq[tj][4 * q + 2] - sdot), qv.w * (dq[tj][4 * q + 3] - sdot)));
-        }
-    }
+      for (int q = 0; q < 4; ++q) {
+        const float4 qv = *reinterpret_cast<const float4*>(sQ + rl * LDP + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh);
+        *reinterpret_cast<float4*>(sD + rl * LDP + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh) =
+            make_float4(qv.x * (dq[tj][4 * q] - sdot), qv.y * (dq[tj][4 * q + 1] - sdot),
+                        qv.z * (dq[tj][4 * q + 2] - sdot), qv.w * (dq[tj][4 * q + 3] - sdot));
+      }
+    __syncthreads();
+    store_tile_rows<HD, TIO>(sD, dQ + (int64_t)b * rows * lddq + h * HD, lddq, r0, rows);
     __syncthreads();   // sQ / sD / srow are rewritten by the next chunk
   }
   float* dAb = dApart + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * HD * HD;
@@ -1119,22 +1150,24 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
         }
       }
     }
-    const int r = r0 + rl;
-    if (r < rows) {   // rows in [len, rows) carry k == 0 and V == 0 in LDS: dV == 0 and dK = k * (..) == 0 there
-      TIO* kp = dK + ((int64_t)b * rows + r) * ldd + h * HD + wj * (HD / 2) + 4 * lh;
-      TIO* vp = dV + ((int64_t)b * rows + r) * ldd + h * HD + wj * (HD / 2) + 4 * lh;
+    // rows in [len, rows) carry k == 0 and V == 0 in LDS: dV == 0 and dK = k * (..) == 0 there.  Both tiles are staged in
+    // place (dV over V, dK over k: each lane rewrites exactly the elements it has just read) and leave as whole rows.
+    __syncthreads();   // every wave is done reading sK / sV
 #pragma unroll
-      for (int tj = 0; tj < TB; ++tj) {
-        store16(vp + 32 * tj, dv[tj]);
+    for (int tj = 0; tj < TB; ++tj) {
+      stage16<HD>(sV, rl, wj * (HD / 2) + 32 * tj + 4 * lh, dv[tj]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 k4 = *reinterpret_cast<const float4*>(sK + rl * LDP + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh);
-          st4(kp + 32 * tj + 8 * q,
-              make_float4(k4.x * (dk[tj][4 * q] - scol[tj][q][0]), k4.y * (dk[tj][4 * q + 1] - scol[tj][q][1]),
-                          k4.z * (dk[tj][4 * q + 2] - scol[tj][q][2]), k4.w * (dk[tj][4 * q + 3] - scol[tj][q][3])));
-        }
+      for (int q = 0; q < 4; ++q) {
+        float* kp = sK + rl * LDP + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh;
+        const float4 k4 = *reinterpret_cast<const float4*>(kp);
+        *reinterpret_cast<float4*>(kp) =
+            make_float4(k4.x * (dk[tj][4 * q] - scol[tj][q][0]), k4.y * (dk[tj][4 * q + 1] - scol[tj][q][1]),
+                        k4.z * (dk[tj][4 * q + 2] - scol[tj][q][2]), k4.w * (dk[tj][4 * q + 3] - scol[tj][q][3]));
       }
     }
+    __syncthreads();
+    store_tile_rows<HD, TIO>(sV, dV + (int64_t)b * rows * ldd + h * HD, ldd, r0, rows);
+    store_tile_rows<HD, TIO>(sK, dK + (int64_t)b * rows * ldd + h * HD, ldd, r0, rows);
     __syncthreads();   // sK / sV are rewritten by the next chunk
   }
 }
@@ -1496,9 +1529,9 @@ extern "C" int hig_linattn_apply_bf16(const void* Q, int64_t ldq, const float* A
   HIG_REQUIRE(Q && A && Y && B > 0 && rows > 0 && H > 0, "hig_linattn_apply_bf16: bad arguments");
   if (hd != 64 && hd != 128)
     return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn: bf16 storage is built for head dim 64 / 128 (got %d)", hd);
-  HIG_REQUIRE(ldq % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 7) == 0 &&
-                  (reinterpret_cast<uintptr_t>(Y) & 7) == 0,
-              "hig_linattn_apply_bf16: Q/Y must be 8-byte aligned");
+  HIG_REQUIRE(ldq % 4 == 0 && ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(Q) & 7) == 0 &&
+                  (reinterpret_cast<uintptr_t>(Y) & 15) == 0,
+              "hig_linattn_apply_bf16: Q rows must be 8-byte aligned, Y rows 16-byte aligned");
   return linattn_apply_t<__bf16>(static_cast<const __bf16*>(Q), ldq, A, static_cast<__bf16*>(Y), ldy, B, rows, H, hd,
                                  hig_stream(stream));
 }
@@ -1595,9 +1628,9 @@ extern "C" int hig_linattn_apply_bwd_bf16(const void* dY, int64_t lddy, const vo
   HIG_REQUIRE(dY && Q && A && dQ && dA && scratch && B > 0 && rows > 0 && H > 0, "hig_linattn_apply_bwd_bf16: bad arguments");
   if (!(hd == 64 || (hd == 128 && allow_big_lds() == 0)))
     return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn_apply_bwd_bf16: head dim 64 or 128 (got %d)", hd);
-  HIG_REQUIRE(ldq % 4 == 0 && lddy % 4 == 0 && lddq % 4 == 0 && ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(dY) |
-                                                                   reinterpret_cast<uintptr_t>(dQ)) & 7) == 0,
-              "hig_linattn_apply_bwd_bf16: Q / dY / dQ rows must be 8-byte aligned");
+  HIG_REQUIRE(ldq % 4 == 0 && lddy % 4 == 0 && lddq % 8 == 0 && ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(dY)) & 7) == 0 &&
+                  (reinterpret_cast<uintptr_t>(dQ) & 15) == 0,
+              "hig_linattn_apply_bwd_bf16: Q / dY rows must be 8-byte aligned, dQ rows 16-byte aligned");
   const int nchunk = (rows + CH - 1) / CH;
   int nparts = (hig_chip_cus() + B * H - 1) / (B * H);
   nparts = nparts < 1 ? 1 : (nparts > nchunk ? nchunk : nparts);
@@ -1626,9 +1659,9 @@ extern "C" int hig_linattn_ctx_bwd_bf16(const float* dA, const float* A, const v
   HIG_REQUIRE(dA && A && K && V && kstat && dK && dV && B > 0 && rows > 0 && H > 0, "hig_linattn_ctx_bwd_bf16: bad arguments");
   if (!(hd == 64 || (hd == 128 && allow_big_lds() == 0)))
     return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn_ctx_bwd_bf16: head dim 64 or 128 (got %d)", hd);
-  HIG_REQUIRE(ld % 4 == 0 && ldd % 4 == 0 && ((reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(dK) |
-                                                reinterpret_cast<uintptr_t>(dV)) & 7) == 0,
-              "hig_linattn_ctx_bwd_bf16: K / V / dK / dV rows must be 8-byte aligned");
+  HIG_REQUIRE(ld % 4 == 0 && ldd % 8 == 0 && ((reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V)) & 7) == 0 &&
+                  ((reinterpret_cast<uintptr_t>(dK) | reinterpret_cast<uintptr_t>(dV)) & 15) == 0,
+              "hig_linattn_ctx_bwd_bf16: K / V rows must be 8-byte aligned, dK / dV rows 16-byte aligned");
   const int nchunk = (rows + CH - 1) / CH;
   int gy = (hig_chip_cus() + B * H - 1) / (B * H);
   gy = gy < 1 ? 1 : (gy > nchunk ? nchunk : gy);

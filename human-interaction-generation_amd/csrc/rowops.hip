@@ -5,6 +5,8 @@
 //
 // Mapping: one 64-lane wave per row, lanes stride the row in float4 (16 B/lane, coalesced 1 KiB
 // per wave-instruction); cross-lane sums by DPP/shuffle butterflies; no LDS for the row itself.
+#include <stdlib.h>
+
 #include "hig_common.h"
 
 namespace {
@@ -464,7 +466,10 @@ __device__ __forceinline__ void st4g(__bf16* p, const float4& v) {
 // ln_bwd_kernel with bf16 upstream gradients, rows in TX (bf16 activations, or the fp32 text embeddings), residual /
 // result in TD (bf16: the gradient of the residual stream; fp32: d(xf_out)), and the LayerNorm statistics RECOMPUTED from
 // the row the kernel reads anyway (two passes over the registers: the forward of this mode keeps no statistics).
-template <int NIT, bool MOD_SILU, typename TX, typename TD>
+// A wave works on RPI rows at a time (independent dependency chains: load -> mean -> variance -> gradients -> two row sums
+// -> store is ~2 us of latency per row, and a workgroup slot holds only a few waves: one row at a time left the kernel at
+// 1.6-1.9 TB/s): all loads of the RPI rows are issued before the first reduction.
+template <int NIT, bool MOD_SILU, typename TX, typename TD, int RPI>
 __global__ __launch_bounds__(256) void ln_bwd16_kernel(
     const __bf16* __restrict__ da, int64_t ldda, const TX* __restrict__ x, int64_t ldx,
     const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -492,92 +497,118 @@ __global__ __launch_bounds__(256) void ln_bwd16_kernel(
       }
     }
   }
-  for (int rl = split * WAVES + wave; rl < rows_per_sample; rl += WAVES * nsplit) {
-    const int64_t row = (int64_t)b * rows_per_sample + rl;
-    float4 xv[NIT], dav[NIT];
-    float sx = 0.f;
+  const int stride = WAVES * nsplit;
+  for (int rl0 = split * WAVES + wave; rl0 < rows_per_sample; rl0 += RPI * stride) {
+    float4 xv[RPI][NIT], dav[RPI][NIT], rv[RPI][NIT];
+    bool live[RPI];
+    int64_t row[RPI];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int c = 4 * lane + 256 * it;
-      xv[it] = dav[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < n) {
-        xv[it] = ld4g(x + row * ldx + c);
-        dav[it] = ld4g(da + row * ldda + c);
-        sx += (xv[it].x + xv[it].y) + (xv[it].z + xv[it].w);
+    for (int u = 0; u < RPI; ++u) {
+      const int rl = rl0 + u * stride;
+      live[u] = rl < rows_per_sample;                 // (wave-uniform)
+      row[u] = (int64_t)b * rows_per_sample + (live[u] ? rl : rl0);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = 4 * lane + 256 * it;
+        xv[u][it] = dav[u][it] = rv[u][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < n && live[u]) {
+          xv[u][it] = ld4g(x + row[u] * ldx + c);
+          dav[u][it] = ld4g(da + row[u] * ldda + c);
+          if (res) rv[u][it] = ld4g(res + row[u] * ldr + c);
+        }
       }
     }
-    const float mean = wave_sum(sx) * inv_n;
-    float sq = 0.f;
+    float mean[RPI], rstd[RPI];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int c = 4 * lane + 256 * it;
-      if (c < n) {
-        const float a0 = xv[it].x - mean, a1 = xv[it].y - mean, a2 = xv[it].z - mean, a3 = xv[it].w - mean;
-        sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-      }
+    for (int u = 0; u < RPI; ++u) {
+      float sx = 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) sx += (xv[u][it].x + xv[u][it].y) + (xv[u][it].z + xv[u][it].w);
+      mean[u] = wave_sum(sx) * inv_n;
     }
-    const float rstd = rsqrtf(wave_sum(sq) * inv_n + 1e-5f);
-    float4 xh[NIT], dxh[NIT];
-    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int c = 4 * lane + 256 * it;
-      xh[it] = dxh[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < n) {
-        const float xs[4] = {xv[it].x, xv[it].y, xv[it].z, xv[it].w}, ds[4] = {dav[it].x, dav[it].y, dav[it].z, dav[it].w};
-        const float gs[4] = {g4[it].x, g4[it].y, g4[it].z, g4[it].w};
-        const float bs[4] = {b4[it].x, b4[it].y, b4[it].z, b4[it].w};
-        const float scs[4] = {sc4[it].x, sc4[it].y, sc4[it].z, sc4[it].w};
-        const float shs[4] = {sh4[it].x, sh4[it].y, sh4[it].z, sh4[it].w};
-        float xho[4], dxo[4], dgo[4], dbo[4], dsco[4], dsho[4];
+    for (int u = 0; u < RPI; ++u) {
+      float sq = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xhat = (xs[e] - mean) * rstd;
-          const float nrm = xhat * gs[e] + bs[e];
-          float dn;
-          if (MOD_SILU) {
-            const float u = nrm * (1.0f + scs[e]) + shs[e];
-            const float du = ds[e] * hig_dsilu(u);
-            dsho[e] = du;
-            dsco[e] = du * nrm;
-            dn = du * (1.0f + scs[e]);
-          } else {
-            dsho[e] = dsco[e] = 0.f;
-            dn = ds[e];
+      for (int it = 0; it < NIT; ++it) {
+        const int c = 4 * lane + 256 * it;
+        if (c < n) {
+          const float a0 = xv[u][it].x - mean[u], a1 = xv[u][it].y - mean[u], a2 = xv[u][it].z - mean[u], a3 = xv[u][it].w - mean[u];
+          sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+      }
+      rstd[u] = rsqrtf(wave_sum(sq) * inv_n + 1e-5f);
+    }
+    float4 xh[RPI][NIT], dxh[RPI][NIT];
+    float s1[RPI], s2[RPI];
+#pragma unroll
+    for (int u = 0; u < RPI; ++u) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = 4 * lane + 256 * it;
+        xh[u][it] = dxh[u][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < n && live[u]) {
+          const float xs[4] = {xv[u][it].x, xv[u][it].y, xv[u][it].z, xv[u][it].w}, ds[4] = {dav[u][it].x, dav[u][it].y, dav[u][it].z, dav[u][it].w};
+          const float gs[4] = {g4[it].x, g4[it].y, g4[it].z, g4[it].w};
+          const float bs[4] = {b4[it].x, b4[it].y, b4[it].z, b4[it].w};
+          const float scs[4] = {sc4[it].x, sc4[it].y, sc4[it].z, sc4[it].w};
+          const float shs[4] = {sh4[it].x, sh4[it].y, sh4[it].z, sh4[it].w};
+          float xho[4], dxo[4], dgo[4], dbo[4], dsco[4], dsho[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xhat = (xs[e] - mean[u]) * rstd[u];
+            const float nrm = xhat * gs[e] + bs[e];
+            float dn;
+            if (MOD_SILU) {
+              const float uu = nrm * (1.0f + scs[e]) + shs[e];
+              const float du = ds[e] * hig_dsilu(uu);
+              dsho[e] = du;
+              dsco[e] = du * nrm;
+              dn = du * (1.0f + scs[e]);
+            } else {
+              dsho[e] = dsco[e] = 0.f;
+              dn = ds[e];
+            }
+            dgo[e] = dn * xhat;
+            dbo[e] = dn;
+            xho[e] = xhat;
+            dxo[e] = dn * gs[e];
+            t1 += dxo[e];
+            t2 += dxo[e] * xhat;
           }
-          dgo[e] = dn * xhat;
-          dbo[e] = dn;
-          xho[e] = xhat;
-          dxo[e] = dn * gs[e];
-          s1 += dxo[e];
-          s2 += dxo[e] * xhat;
-        }
-        xh[it] = make_float4(xho[0], xho[1], xho[2], xho[3]);
-        dxh[it] = make_float4(dxo[0], dxo[1], dxo[2], dxo[3]);
-        a_dg[it].x += dgo[0]; a_dg[it].y += dgo[1]; a_dg[it].z += dgo[2]; a_dg[it].w += dgo[3];
-        a_db[it].x += dbo[0]; a_db[it].y += dbo[1]; a_db[it].z += dbo[2]; a_db[it].w += dbo[3];
-        if (MOD_SILU) {
-          a_dsc[it].x += dsco[0]; a_dsc[it].y += dsco[1]; a_dsc[it].z += dsco[2]; a_dsc[it].w += dsco[3];
-          a_dsh[it].x += dsho[0]; a_dsh[it].y += dsho[1]; a_dsh[it].z += dsho[2]; a_dsh[it].w += dsho[3];
+          xh[u][it] = make_float4(xho[0], xho[1], xho[2], xho[3]);
+          dxh[u][it] = make_float4(dxo[0], dxo[1], dxo[2], dxo[3]);
+          a_dg[it].x += dgo[0]; a_dg[it].y += dgo[1]; a_dg[it].z += dgo[2]; a_dg[it].w += dgo[3];
+          a_db[it].x += dbo[0]; a_db[it].y += dbo[1]; a_db[it].z += dbo[2]; a_db[it].w += dbo[3];
+          if (MOD_SILU) {
+            a_dsc[it].x += dsco[0]; a_dsc[it].y += dsco[1]; a_dsc[it].z += dsco[2]; a_dsc[it].w += dsco[3];
+            a_dsh[it].x += dsho[0]; a_dsh[it].y += dsho[1]; a_dsh[it].z += dsho[2]; a_dsh[it].w += dsho[3];
+          }
         }
       }
+      s1[u] = t1;
+      s2[u] = t2;
     }
-    s1 = wave_sum(s1) * inv_n;
-    s2 = wave_sum(s2) * inv_n;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int c = 4 * lane + 256 * it;
-      if (c < n) {
-        float4 o;
-        o.x = rstd * (dxh[it].x - s1 - xh[it].x * s2);
-        o.y = rstd * (dxh[it].y - s1 - xh[it].y * s2);
-        o.z = rstd * (dxh[it].z - s1 - xh[it].z * s2);
-        o.w = rstd * (dxh[it].w - s1 - xh[it].w * s2);
-        if (res) {
-          const float4 r4 = ld4g(res + row * ldr + c);
-          o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
+    for (int u = 0; u < RPI; ++u) {
+      s1[u] = wave_sum(s1[u]) * inv_n;
+      s2[u] = wave_sum(s2[u]) * inv_n;
+    }
+#pragma unroll
+    for (int u = 0; u < RPI; ++u) {
+      if (!live[u]) continue;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = 4 * lane + 256 * it;
+        if (c < n) {
+          float4 o;
+          o.x = rstd[u] * (dxh[u][it].x - s1[u] - xh[u][it].x * s2[u]) + rv[u][it].x;
+          o.y = rstd[u] * (dxh[u][it].y - s1[u] - xh[u][it].y * s2[u]) + rv[u][it].y;
+          o.z = rstd[u] * (dxh[u][it].z - s1[u] - xh[u][it].z * s2[u]) + rv[u][it].z;
+          o.w = rstd[u] * (dxh[u][it].w - s1[u] - xh[u][it].w * s2[u]) + rv[u][it].w;
+          st4g(dx + row[u] * lddx + c, o);
         }
-        st4g(dx + row * lddx + c, o);
       }
     }
   }
@@ -673,8 +704,9 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const Tr16Batch b) {
 }
 
 int splits_for(int64_t samples) {
+  static const int target = getenv("HIG_LNB_WGS") ? atoi(getenv("HIG_LNB_WGS")) : 512;   // tuning knob: workgroups per launch
   int s = 1;
-  while (samples * s < 512 && s < 16) s *= 2;
+  while (samples * s < target && s < 64) s *= 2;
   return s;
 }
 
@@ -869,8 +901,8 @@ extern "C" int hig_ln_bwd_bf16(const void* da, int64_t ldda, const void* x, int3
   hipStream_t st = hig_stream(stream);
   dim3 grid(samples, nsplit);
   const __bf16* dab = static_cast<const __bf16*>(da);
-#define LNB16(NITV, MODV, TXV, TDV)                                                                                              \
-  hipLaunchKernelGGL((ln_bwd16_kernel<NITV, MODV, TXV, TDV>), grid, dim3(256), 0, st, dab, ldda, static_cast<const TXV*>(x), ldx, \
+#define LNB16(NITV, MODV, TXV, TDV)                                                                                                            \
+  hipLaunchKernelGGL((ln_bwd16_kernel<NITV, MODV, TXV, TDV, (NITV <= 2 ? 2 : 1)>), grid, dim3(256), 0, st, dab, ldda, static_cast<const TXV*>(x), ldx, \
                      gamma, beta, ss, ss_ld, ss_shift_off, static_cast<const TDV*>(res), ldr, static_cast<TDV*>(dx), lddx, n,    \
                      rows_per_sample, partial)
 #define LNB16_NIT(MODV, TXV, TDV)                                                    \
