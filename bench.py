@@ -443,8 +443,30 @@ def main():
     trainer.sync_replicas()
     noise = torch.randn_like(inp["x0"])
 
-    def train_step():
+    def train_step_eager():
         trainer.train_step_fused(inp["x0"], inp["t"], inp["length"], inp["xf_proj"], inp["xf_out"], noise=noise)
+
+    def train_step_graph():
+        trainer.train_step_captured(inp["x0"], inp["t"], inp["length"], inp["xf_proj"], inp["xf_out"], noise=noise)
+
+    train_step, step_form, form_probe = train_step_eager, "eager launches, per-layer all-reduces overlapped with the backward", None
+    if world > 1:
+        # Two forms of the same data-parallel step: (a) eager launches with the gradient exchange issued layer by layer from
+        # inside the backward (RCCL on a side stream), (b) hipGraph A (fwd + bwd) | ONE flat all-reduce | hipGraph B (clip +
+        # Adam).  With a process group alive the eager form pays host-side costs the graphs do not (measured with RCCL at
+        # world 1, profiles/r04_rccl_world1_probe.json: 23.1 vs 21.2 ms without any exchange, +1.0 ms for issuing the 18 bucket
+        # all-reduces from the host hook against +0.1 ms for the flat one), while (a) hides the wire time: which one wins
+        # depends on the node.  Both are timed UNTIMED-region style during warm-up (3 steps each, max over ranks) and the
+        # faster one is the step the K timed steps run.
+        probe = []
+        for fn in (train_step_eager, train_step_graph):
+            probe.append(timed(fn, 3, 2, world))
+        pick = torch.tensor([probe[0], probe[1]], device=device, dtype=torch.float64)
+        dist.all_reduce(pick, op=dist.ReduceOp.MAX)
+        form_probe = {"eager_overlapped_ms": round(pick[0].item() / 3 * 1e3, 3), "graphs_flat_allreduce_ms": round(pick[1].item() / 3 * 1e3, 3)}
+        if pick[1].item() < pick[0].item():
+            train_step, step_form = train_step_graph, "hipGraph A (fwd+bwd) | one flat RCCL all-reduce | hipGraph B (clip+Adam)"
+        trainer.sync_replicas()
 
     def train_what(mode):
         return ("q_sample+fwd+masked-MSE+bwd+%sclip(0.5)+Adam, B=%d/GPU, %s GEMM products, fp32 accumulate/storage/"
@@ -456,7 +478,10 @@ def main():
         ksteps = a.steps if world > 1 else max(3, min(a.steps, 10))
         el_t = timed(train_step, ksteps, max(2, a.warmup if world > 1 else 2), world)
         train_res = {"frames_per_s": round(B * T * ksteps * world / el_t, 1),
-                     "ms_per_step": round(el_t / ksteps * 1e3, 4), "steps": ksteps, "what": train_what("f32")}
+                     "ms_per_step": round(el_t / ksteps * 1e3, 4), "steps": ksteps, "what": train_what("f32"),
+                     "step_form": step_form}
+        if form_probe:
+            train_res["step_form_probe"] = form_probe
     model.eval()
 
     common = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True,

@@ -40,7 +40,7 @@ SYMBOLS = (
     "hig_text_context_bf16_train", "hig_denoiser_fwd_bf16_train", "hig_denoiser_bwd_bf16", "hig_ln_bwd_bf16",
     "hig_linattn_apply_bwd_bf16", "hig_linattn_ctx_bwd_bf16", "hig_colsum_bf16", "hig_transpose_bf16_batch", "hig_transpose_bf16",
     "hig_gelu_bf16", "hig_cast_f32", "hig_gemm_bf16_split", "hig_gemm_bf16_split_scratch_floats", "hig_clip_adam_shadow",
-    "hig_debug_marker", "hig_denoiser_fwd_text", "hig_wgrad_bf16", "hig_wgrad_bf16_scratch_floats",
+    "hig_debug_marker", "hig_denoiser_fwd_text", "hig_wgrad_bf16", "hig_wgrad_bf16_scratch_floats", "hig_denoiser_fwd_x",
 )
 
 
@@ -80,6 +80,7 @@ class GemmDesc(C.Structure):
         ("rows_per_sample", C.c_int32),
         ("pos", C.c_void_p), ("ldpos", C.c_int64), ("T", C.c_int32), ("pos_shift", C.c_int32),
         ("xcolsum", C.c_void_p),
+        ("row_stats_out", C.c_void_p), ("row_stats_in", C.c_void_p), ("ln_colsum", C.c_void_p),
     ]
 
 
@@ -216,6 +217,7 @@ def lib():
         L.hig_gemm_bf16_split_scratch_floats.argtypes = [C.POINTER(Gemm16Desc), i32]
         L.hig_clip_adam_shadow.argtypes = [vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, f32, vp, vp, vp, vp, i64, vp]
         L.hig_debug_marker.argtypes = [i32, vp]
+        L.hig_denoiser_fwd_x.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]
         L.hig_wgrad_bf16.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp, vp, i32, vp, i64, vp]
         L.hig_wgrad_bf16_scratch_floats.restype = i64
         L.hig_wgrad_bf16_scratch_floats.argtypes = [i32, i32, i32]

@@ -110,6 +110,7 @@ struct FwdLayout {
   int64_t st6, iqkv, Ai, ksti, y4, st7, a4, h2b;  // two-person interaction attention block
   int64_t xn1, xn2, xn3;  // LayerNorm outputs feeding the q/k/v GEMMs (kept: wgrad operands)
   int64_t cscr2, gtail2;  // second set of per-stream scratch (two-stream forward)
+  int64_t lnstats;        // LayerNorm fold (inference): (sum, centred sum of squares) per row and 64-column panel of the residual stream
   int64_t total;
 };
 FwdLayout fwd_layout(const Dims& D, int training) {
@@ -126,6 +127,7 @@ FwdLayout fwd_layout(const Dims& D, int training) {
   w.gtail = take(HIG_GEMM_TAIL_BYTES / 4);   // split tail of the fp32 GEMMs (hig_gemm_set_tail_scratch)
   w.cscr2 = take(hig_linattn_ctx_scratch_floats(D.B, D.T, D.H, D.hd));
   w.gtail2 = take(HIG_GEMM_TAIL_BYTES / 4);
+  w.lnstats = take(training ? 0 : D.M * (D.d / 64 + 1) * 2);
   w.layer0 = o;
   o = 0;
   w.st1 = take(D.M * 2);
@@ -404,25 +406,32 @@ SideStream* side_stream_for_current_device(hipStream_t caller) {
 
 }  // namespace
 
-static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, const float* x, const int64_t* t, const int64_t* length,
-                             const float* xf_proj, const float* xf_out_for_text, const void* textctx, float* out, void* workspace,
-                             int training, hig_stream_t stream);
+static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, const void* const* derived32, const float* x, const int64_t* t,
+                             const int64_t* length, const float* xf_proj, const float* xf_out_for_text, const void* textctx, float* out,
+                             void* workspace, int training, hig_stream_t stream);
 extern "C" int hig_denoiser_fwd(const hig_dims* dims, const void* const* params, const float* x,
                                 const int64_t* t, const int64_t* length, const float* xf_proj,
                                 const void* textctx, float* out, void* workspace, int training,
                                 hig_stream_t stream) {
-  return denoiser_fwd_impl(dims, params, x, t, length, xf_proj, nullptr, textctx, out, workspace, training, stream);
+  return denoiser_fwd_impl(dims, params, nullptr, x, t, length, xf_proj, nullptr, textctx, out, workspace, training, stream);
 }
 // hig_text_context + hig_denoiser_fwd as ONE call (include/hig.h): the text side is forked onto a library-owned stream
 extern "C" int hig_denoiser_fwd_text(const hig_dims* dims, const void* const* params, const float* x, const int64_t* t,
                                      const int64_t* length, const float* xf_proj, const float* xf_out, void* textctx, float* out,
                                      void* workspace, int training, hig_stream_t stream) {
   HIG_REQUIRE(xf_out, "hig_denoiser_fwd_text: null argument");
-  return denoiser_fwd_impl(dims, params, x, t, length, xf_proj, xf_out, textctx, out, workspace, training, stream);
+  return denoiser_fwd_impl(dims, params, nullptr, x, t, length, xf_proj, xf_out, textctx, out, workspace, training, stream);
 }
-static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, const float* x, const int64_t* t, const int64_t* length,
-                             const float* xf_proj, const float* xf_out_for_text, const void* textctx, float* out, void* workspace,
-                             int training, hig_stream_t stream) {
+// The general form (include/hig.h): derived32 (nullable) = LayerNorm-folded projection operands, xf_out (nullable) = compute the
+// text side here.
+extern "C" int hig_denoiser_fwd_x(const hig_dims* dims, const void* const* params, const void* const* derived32, const float* x,
+                                  const int64_t* t, const int64_t* length, const float* xf_proj, const float* xf_out, void* textctx,
+                                  float* out, void* workspace, int training, hig_stream_t stream) {
+  return denoiser_fwd_impl(dims, params, derived32, x, t, length, xf_proj, xf_out, textctx, out, workspace, training, stream);
+}
+static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, const void* const* derived32, const float* x, const int64_t* t,
+                             const int64_t* length, const float* xf_proj, const float* xf_out_for_text, const void* textctx, float* out,
+                             void* workspace, int training, hig_stream_t stream) {
   Dims D;
   HIG_TRY(check_dims(dims, D));
   HIG_REQUIRE(params && x && t && xf_proj && textctx && out && workspace, "hig_denoiser_fwd: null argument");
@@ -509,6 +518,9 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
   const bool fuse_apply = fuse_env && !training && !D.full && (D.H == 4 || D.H == 8) && (D.hd == 64 || D.hd == 128);
   // One decoder layer for the samples [b0, b0 + nb) on stream `s` (every kernel of a layer is row- or sample-local, so a
   // batch range is a pointer offset).  `hin` / the returned pointer are the FULL-batch residual stream of the layer.
+  // LayerNorm fold (fp32 storage): inference only, d a multiple of 128, operands derived by the caller per parameter version
+  static const int fold_env = getenv("HIG_LNFOLD32") ? atoi(getenv("HIG_LNFOLD32")) : 1;   // tuning knob
+  const bool fold32 = fold_env && derived32 && !training && d % 128 == 0 && d <= 1024;
   int layer_rc = HIG_OK;   // the code of the launch that failed inside `layer` (it returns NULL then)
   auto layer = [&](int l, const float* hin_full, int b0, int nb, hipStream_t s, float* cscr) -> const float* {
     hig_stream_t hs = reinterpret_cast<hig_stream_t>(s);
@@ -525,10 +537,27 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
     // ---- self attention -------------------------------------------------------------
     // LayerNorm as its own row kernel: the GEMM then stages plain operands (a fused LN prologue cost
     // the q/k/v GEMM 258 -> 207 us at config 2, the row pass 13 us; profiles/r01_notes.md)
-    HIG_L(hig_layernorm(hin, d, Mh, d, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B), R(w.xn1, d), d,
-                        R(w.st1, 2), hs));
-    HIG_L(hig_gemm_launch(G(R(w.xn1, d), d, 0, PL(params, l, HIG_L_SA_QKV_W), d, 0, R(w.qkv, 3 * d), 3 * d, Mh, 3 * d, d)
-                              .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_SA_QKV_B)).prec(D.prec).g, 1, nullptr, s));
+    // LayerNorm fold (inference, `derived32`): LN(h) W^T + b = rstd (h W'^T) - rstd mean colsum + b' with the row statistics
+    // written by the stylization-out GEMM that produced h -- the LayerNorm launch and its (M, d) round trip disappear
+    // (layer 0's first projection has no producer: plain LayerNorm)
+    const int np = d >> 6;
+    float* lnst = ws + w.lnstats + r0 * np * 2;
+    auto folded = [&](int k) { return fold32 && derived32[6 * l + 3 * k] != nullptr; };
+    auto ln_proj = [&](int k, bool have_stats, const float* hrows, int norm_w, int norm_b, int lin_w, int lin_b, float* xn, float* st,
+                       float* outp, int ncols) -> int {
+      if (have_stats && folded(k)) {
+        G gf(hrows, d, 0, static_cast<const float*>(derived32[6 * l + 3 * k]), d, 0, outp, ncols, Mh, ncols, d);
+        gf.epi(HIG_EPI_BIAS, static_cast<const float*>(derived32[6 * l + 3 * k + 2])).prec(D.prec);
+        gf.g.row_stats_in = lnst;
+        gf.g.ln_colsum = static_cast<const float*>(derived32[6 * l + 3 * k + 1]);
+        return hig_gemm_launch(gf.g, 1, nullptr, s);
+      }
+      HIG_TRY(hig_layernorm(hrows, d, Mh, d, PL(params, l, norm_w), PL(params, l, norm_b), xn, d, st, hs));
+      return hig_gemm_launch(G(xn, d, 0, PL(params, l, lin_w), d, 0, outp, ncols, Mh, ncols, d)
+                                 .epi(HIG_EPI_BIAS, PL(params, l, lin_b)).prec(D.prec).g, 1, nullptr, s);
+    };
+    HIG_L(ln_proj(0, l > 0 && folded(0), hin, HIG_L_SA_NORM_W, HIG_L_SA_NORM_B, HIG_L_SA_QKV_W, HIG_L_SA_QKV_B, R(w.xn1, d), R(w.st1, 2),
+                  R(w.qkv, 3 * d), 3 * d));
     if (D.full) {
       HIG_L(hig_fullattn_fwd(R(w.qkv, 3 * d), 3 * d, R(w.qkv, 3 * d) + d, R(w.qkv, 3 * d) + 2 * d, 3 * d, nb, D.T, D.T, D.H, D.hd,
                              len, R(w.y1, d), d, lb + w.lse1 + (int64_t)b0 * D.H * D.T, hs));
@@ -544,13 +573,15 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
     if (!fuse_apply)
       HIG_L(hig_ln_mod_silu(R(w.y1, d), d, Mh, d, PL(params, l, HIG_L_SA_STY_NORM_W), PL(params, l, HIG_L_SA_STY_NORM_B),
                             ssl, ss_ld, d, D.T, R(w.a1, d), d, R(w.st2, 2), hs));
-    HIG_L(hig_gemm_launch(G(R(w.a1, d), d, 0, PL(params, l, HIG_L_SA_STY_OUT_W), d, 0, R(w.h1, d), d, Mh, d, d)
-                              .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_SA_STY_OUT_B)).res(hin, d).prec(D.prec).g, 1, nullptr, s));
+    {
+      G gs(R(w.a1, d), d, 0, PL(params, l, HIG_L_SA_STY_OUT_W), d, 0, R(w.h1, d), d, Mh, d, d);
+      gs.epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_SA_STY_OUT_B)).res(hin, d).prec(D.prec);
+      if (folded(1)) gs.g.row_stats_out = lnst;          // h1's statistics for the cross-attention query projection
+      HIG_L(hig_gemm_launch(gs.g, 1, nullptr, s));
+    }
     // ---- cross attention ------------------------------------------------------------
-    HIG_L(hig_layernorm(R(w.h1, d), d, Mh, d, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B),
-                        R(w.xn2, d), d, R(w.st3, 2), hs));
-    HIG_L(hig_gemm_launch(G(R(w.xn2, d), d, 0, PL(params, l, HIG_L_CA_Q_W), d, 0, R(w.qc, d), d, Mh, d, d)
-                              .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).prec(D.prec).g, 1, nullptr, s));
+    HIG_L(ln_proj(1, folded(1), R(w.h1, d), HIG_L_CA_NORM_W, HIG_L_CA_NORM_B, HIG_L_CA_Q_W, HIG_L_CA_Q_B, R(w.xn2, d), R(w.st3, 2),
+                  R(w.qc, d), d));
     const float* Acl = tc + tl.layer0 + tl.lstride * l + tl.Ac + aoff;
     if (text_ev && hipStreamWaitEvent(s, text_ev[l], 0) != hipSuccess) return fail(hig_set_error(HIG_EHIP, "text join failed"));
     if (D.full) {
@@ -603,8 +634,12 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
                               .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B2)).prec(D.prec).g, 1, nullptr, s));
     HIG_L(hig_ln_mod_silu(R(w.y3, d), d, Mh, d, PL(params, l, HIG_L_FFN_STY_NORM_W), PL(params, l, HIG_L_FFN_STY_NORM_B),
                           ss_ffn, ss_ld, d, D.T, R(w.a3, d), d, R(w.st5, 2), hs));
-    HIG_L(hig_gemm_launch(G(R(w.a3, d), d, 0, PL(params, l, HIG_L_FFN_STY_OUT_W), d, 0, R(w.h3, d), d, Mh, d, d)
-                              .epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_FFN_STY_OUT_B)).res(hffn, d).prec(D.prec).g, 1, nullptr, s));
+    {
+      G gs(R(w.a3, d), d, 0, PL(params, l, HIG_L_FFN_STY_OUT_W), d, 0, R(w.h3, d), d, Mh, d, d);
+      gs.epi(HIG_EPI_BIAS_RES, PL(params, l, HIG_L_FFN_STY_OUT_B)).res(hffn, d).prec(D.prec);
+      if (fold32 && l + 1 < D.L && derived32[6 * (l + 1)] != nullptr) gs.g.row_stats_out = lnst;   // h3's statistics for the next layer's q/k/v
+      HIG_L(hig_gemm_launch(gs.g, 1, nullptr, s));
+    }
 #undef HIG_L
     return lb + w.h3;
   };

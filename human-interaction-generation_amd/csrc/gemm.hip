@@ -647,6 +647,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
         for (int q = 0; q < 4; ++q)
           *reinterpret_cast<f32x4*>(sC + (wi * (32 * TI) + 32 * ti + lr) * CLD + wj * (32 * TJ) + 32 * tj + 8 * q + 4 * lh) =
               f32x4{acc[tj][ti][4 * q], acc[tj][ti][4 * q + 1], acc[tj][ti][4 * q + 2], acc[tj][ti][4 * q + 3]};
+    [[maybe_unused]] float* sStat = sC + BI * CLD;      // LayerNorm fold, consumer: (rstd, -mean rstd) of the tile's rows
+    if constexpr (EPI == HIG_EPI_BIAS && BJ == 64) {
+      if (g.row_stats_in && tid < BI) {
+        // mean / variance of row ei0 + tid from its R / 64 panel statistics (sum, centred sum of squares): pairwise merge,
+        // no E[x^2] - mean^2 cancellation.  Once per row and tile, by one thread: the epilogue below reads two floats.
+        const int i = min(ei0 + tid, g.I - 1);
+        const int np = g.R >> 6;
+        const float* sp = g.row_stats_in + (int64_t)i * np * 2;
+        float tot = 0.f, m2 = 0.f;
+        for (int p2 = 0; p2 < np; p2 += 2) {
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(sp + 2 * p2);
+          tot += t4.x + t4.z;
+          m2 += t4.y + t4.w;
+        }
+        const float mean = tot / (float)g.R;
+        float between = 0.f;
+        for (int p2 = 0; p2 < np; p2 += 2) {
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(sp + 2 * p2);
+          const float d0 = t4.x * (1.0f / 64.0f) - mean, d1 = t4.z * (1.0f / 64.0f) - mean;
+          between += d0 * d0 + d1 * d1;
+        }
+        const float rstd = rsqrtf((m2 + 64.0f * between) / (float)g.R + 1e-5f);
+        sStat[2 * tid] = rstd;
+        sStat[2 * tid + 1] = -mean * rstd;
+      }
+    }
     if (a.epi_flags & 1) lds_barrier(); else __syncthreads();
     stamp(4);
     constexpr int Q4 = BJ / 4, RPP = NTHREADS / Q4;     // float4 per row, rows per pass
@@ -655,11 +681,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (EPI == HIG_EPI_BIAS || EPI == HIG_EPI_BIAS_GELU || EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_POS)
       b4 = *reinterpret_cast<const f32x4*>(g.bias + j);
+    // LayerNorm folded into this GEMM (hig_gemm_desc.row_stats_in / ln_colsum; 64-column tiles only): X holds UN-normalised
+    // rows whose statistics per 64-column panel were written by the GEMM that produced them, Y is W' = gamma (.) W:
+    //   C = rstd (X W'^T) - rstd mean colsum + bias'   ==   LayerNorm(X) W^T + bias       (transformer.py:108-110,144)
+    [[maybe_unused]] f32x4 cs4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == HIG_EPI_BIAS && BJ == 64) {
+      if (g.row_stats_in) cs4 = *reinterpret_cast<const f32x4*>(g.ln_colsum + j);
+    }
 #pragma unroll 4
     for (int rr = rr0; rr < BI; rr += RPP) {
       const int i = ei0 + rr;
       if (i >= g.I) break;
-      f32x4 v = *reinterpret_cast<const f32x4*>(sC + rr * CLD + 4 * c4) + b4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(sC + rr * CLD + 4 * c4);
+      if constexpr (EPI == HIG_EPI_BIAS && BJ == 64) {
+        if (g.row_stats_in) {
+          const float rstd = sStat[2 * rr], mr = sStat[2 * rr + 1];
+          v = f32x4{v.x * rstd + mr * cs4.x, v.y * rstd + mr * cs4.y, v.z * rstd + mr * cs4.z, v.w * rstd + mr * cs4.w};
+        }
+      }
+      v += b4;
       if (EPI == HIG_EPI_BIAS_POS) {
         const int tp = (i % g.T) - g.pos_shift;
         if (tp >= 0) v += *reinterpret_cast<const f32x4*>(g.pos + (int64_t)tp * g.ldpos + j);
@@ -673,6 +713,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
       if (EPI == HIG_EPI_DGELU) {
         const f32x4 z = *reinterpret_cast<const f32x4*>(g.aux + (int64_t)i * g.ldaux + j);
         v = f32x4{v.x * hig_dgelu(z.x), v.y * hig_dgelu(z.y), v.z * hig_dgelu(z.z), v.w * hig_dgelu(z.w)};
+      }
+      if constexpr (EPI == HIG_EPI_BIAS_RES && BJ == 64) {
+        if (g.row_stats_out) {
+          // LayerNorm fold, producer side: (sum, sum of squared deviations from the panel mean) of this row's 64 outputs of
+          // THIS tile -- the row's 16 lanes are one DPP row
+          const float sm = row16_sum((v.x + v.y) + (v.z + v.w));
+          const float pm = sm * (1.0f / 64.0f);
+          const float a0 = v.x - pm, a1 = v.y - pm, a2 = v.z - pm, a3 = v.w - pm;
+          const float qq = row16_sum((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3));
+          if (c4 == 0) *reinterpret_cast<float2*>(g.row_stats_out + ((int64_t)i * (g.J >> 6) + (ej0 >> 6)) * 2) = make_float2(sm, qq);
+        }
       }
 #if defined(__HIP_DEVICE_COMPILE__)
       if (a.store_policy == 1)
@@ -1019,6 +1070,7 @@ int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab,
     best = t128 >= thr ? 0 : 3;
   }
   if (forced >= 0) best = forced;
+  if (g.row_stats_out || g.row_stats_in) best = 3;   // the LayerNorm fold lives in the 64 x 64 tile's staged epilogue
   switch (best) {
     case 0: return launch<128, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st, se);
     case 1: return launch<64, 128, X_RS, Y_RS, XF, XF_ON_Y, EPI>(g, splits, slabs, slab, st, se);
@@ -1089,6 +1141,15 @@ int gemm_dispatch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_t 
                 "hig_gemm: xcolsum needs a reduce-slow X operand, fp32 products, I %% 4 == 0");
   if (splits > 1) HIG_REQUIRE(slabs && g.epi == HIG_EPI_NONE && slab % 4 == 0 && g.ldc == g.J,
                               "hig_gemm: split-R needs slabs, EPI_NONE, dense C");
+  if (g.row_stats_out || g.row_stats_in) {   // LayerNorm fold: only the LDS-staged epilogue of the 64-column tiles implements it
+    auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool ok = splits <= 1 && g.x_rs == 0 && g.y_rs == 0 && g.xf == HIG_XF_NONE && g.J % 64 == 0 && g.R % 32 == 0 && g.ldc % 4 == 0 &&
+                    g.ldx % 4 == 0 && g.ldy % 4 == 0 && a16(g.X) && a16(g.Y) && a16(g.C) && a16(g.bias) &&
+                    (g.row_stats_out ? (g.epi == HIG_EPI_BIAS_RES && !g.row_stats_in && g.res && g.ldr % 4 == 0 && a16(g.res) && (reinterpret_cast<uintptr_t>(g.row_stats_out) & 7) == 0)
+                                     : (g.epi == HIG_EPI_BIAS && g.ln_colsum && g.R % 128 == 0 && a16(g.row_stats_in) && a16(g.ln_colsum)));
+    if (!ok) return hig_set_error(HIG_EUNSUPPORTED, "hig_gemm: LayerNorm-fold operands on a launch that cannot apply them "
+                                                    "(needs reduce-contiguous aligned operands, J %% 64 == 0, EPI_BIAS_RES producer / EPI_BIAS consumer with R %% 128 == 0)");
+  }
 #define CASE(xrs, yrs, xfv, ony, epiv)                                                   \
   if (g.x_rs == xrs && g.y_rs == yrs && g.xf == xfv && (g.xf == HIG_XF_NONE || g.xf_on_y == ony) && \
       g.epi == epiv)                                                                     \

@@ -676,6 +676,35 @@ class MotionTransformer(nn.Module):
             self._derived = (ver, arr, bufs)
         return self._derived[1]
 
+    def _derived32(self, fp):
+        """Operands of the fp32 inference forward derived from the parameters, rebuilt when they change (`derived32` of
+        hig_denoiser_fwd_x): per layer the LayerNorm-folded projections k = 0 (self-attention q/k/v) and k = 1 (cross-attention
+        query) as [W' = gamma (.) W, colsum = row sums of W', bias' = b + W beta] -- LayerNorm(x) W^T + b == rstd (x W'^T) - rstd
+        mean colsum + bias' (transformer.py:108-110,144), applied where the producer of x wrote its row statistics.  fp64
+        arithmetic for the derived vectors, fp32 storage; latent_dim % 128 == 0 only (NULL table otherwise)."""
+        d = self.latent_dim
+        if d % 128 != 0 or d > 1024:
+            return None
+        ver = (self._param_version(), fp.flat.data_ptr())
+        if getattr(self, "_derived_f32", None) is None or self._derived_f32[0] != ver:
+            nl, ng, offs, L = _lib.NLAYER, _lib.NGLOBAL, fp.group_offsets, self.num_layers
+            arr, bufs = (C.c_void_p * (6 * L))(), []
+            with torch.no_grad():
+                for l in range(L):
+                    def grp(idx, n):
+                        o = offs[ng + l * nl + idx]
+                        return fp.flat[o:o + n]
+                    for k, (nw, nb, wi, bi, rows) in enumerate(((0, 1, 2, 3, 3 * d), (8, 9, 12, 13, d))):
+                        gamma, beta = grp(nw, d).double(), grp(nb, d).double()
+                        W, b = grp(wi, rows * d).view(rows, d).double(), grp(bi, rows).double()
+                        Wp = (W * gamma[None, :]).float().contiguous()
+                        cs = Wp.double().sum(dim=1).float().contiguous()
+                        bp = (b + W @ beta).float().contiguous()
+                        bufs += [Wp, cs, bp]
+                        arr[6 * l + 3 * k], arr[6 * l + 3 * k + 1], arr[6 * l + 3 * k + 2] = Wp.data_ptr(), cs.data_ptr(), bp.data_ptr()
+            self._derived_f32 = (ver, arr, bufs)
+        return self._derived_f32[1]
+
     def _launch_forward(self, x, t, length, xf_proj, xf_out, training):
         B, T, N = x.shape[0], x.shape[1], xf_out.shape[1]
         assert xf_out.shape == (B, N, self.text_latent_dim) and xf_proj.shape == (B, self.time_embed_dim)
@@ -696,9 +725,9 @@ class MotionTransformer(nn.Module):
                 raise RuntimeError("libhig: " + _lib.last_error())
             textctx = self._pool.take("textctx_i", tbytes, x.device)
             ws = self._pool.take("fwd_i", nbytes, x.device)
-            _lib.check(L.hig_denoiser_fwd_text(C.byref(dims), fp.param_table(), _lib.ptr(x), _lib.ptr(t), _lib.ptr(length),
-                                               _lib.ptr(xf_proj), _lib.ptr(xf_out), _lib.ptr(textctx), _lib.ptr(out), _lib.ptr(ws),
-                                               0, _lib.stream_ptr()))
+            _lib.check(L.hig_denoiser_fwd_x(C.byref(dims), fp.param_table(), self._derived32(fp), _lib.ptr(x), _lib.ptr(t),
+                                            _lib.ptr(length), _lib.ptr(xf_proj), _lib.ptr(xf_out), _lib.ptr(textctx), _lib.ptr(out),
+                                            _lib.ptr(ws), 0, _lib.stream_ptr()))
             self._pool.give("fwd_i", ws, x.device)
             self._pool.give("textctx_i", textctx, x.device)
             return out, None
@@ -716,12 +745,15 @@ class MotionTransformer(nn.Module):
                                                _lib.stream_ptr()))
             self._pool.give("fwd_i", ws, x.device)
             return out, None
+        if not training:   # inference: the LayerNorm-folded projections (derived per parameter version)
+            _lib.check(L.hig_denoiser_fwd_x(C.byref(dims), fp.param_table(), self._derived32(fp), _lib.ptr(x), _lib.ptr(t),
+                                            _lib.ptr(length), _lib.ptr(xf_proj), None, _lib.ptr(textctx), _lib.ptr(out), _lib.ptr(ws),
+                                            0, _lib.stream_ptr()))
+            self._pool.give("fwd_i", ws, x.device)
+            return out, None
         _lib.check(L.hig_denoiser_fwd(C.byref(dims), fp.param_table(), _lib.ptr(x), _lib.ptr(t),
                                       _lib.ptr(length), _lib.ptr(xf_proj), _lib.ptr(textctx), _lib.ptr(out),
                                       _lib.ptr(ws), int(training), _lib.stream_ptr()))
-        if not training:
-            self._pool.give("fwd_i", ws, x.device)
-            return out, None
         return out, (dims, ws, textctx)
 
     def _launch_backward(self, x, t, length, xf_out, saved, dout, want_dx=False, layer_hook=None, comm_stream=None):

@@ -180,6 +180,17 @@ int hig_denoiser_fwd_text(const hig_dims* dims, const void* const* params, const
                           const int64_t* length, const float* xf_proj, const float* xf_out, void* textctx, float* out,
                           void* workspace, int training, hig_stream_t stream);
 
+/* The general fp32-storage forward.  xf_out (nullable): compute the text side in this call (hig_denoiser_fwd_text), else
+ * `textctx` is an input.  derived32 (nullable; inference only): 6 L device pointers the caller derives from the parameters and
+ * rebuilds when they change -- [6 l + 3 k + 0 .. 2], k = 0 self-attention q/k/v (3d rows), k = 1 cross-attention query (d rows):
+ * W' (fp32, rows x d) = gamma (.) W of the LayerNorm in front of the projection, colsum (rows) = row sums of W', bias' (rows) =
+ * b + W beta.  With them the LayerNorm launches in front of those projections disappear (d % 128 == 0): the stylization-out
+ * GEMM that produces the residual stream writes its row statistics (hig_gemm_desc.row_stats_out), the projection applies them
+ * in its epilogue (row_stats_in).  Any entry may be NULL (that projection then keeps its LayerNorm kernel). */
+int hig_denoiser_fwd_x(const hig_dims* dims, const void* const* params, const void* const* derived32, const float* x,
+                       const int64_t* t, const int64_t* length, const float* xf_proj, const float* xf_out, void* textctx,
+                       float* out, void* workspace, int training, hig_stream_t stream);
+
 /* bf16-storage forward (dims->storage == HIG_STORE_BF16, inference).  `params` is the fp32 table above (biases,
  * LayerNorm vectors and the F-wide input projection are read from it), `params16` the same table laid over the bf16
  * shadow of the flat parameter buffer (hig_cast_bf16): entry k = shadow base + 2 x (offset of entry k in floats).
@@ -442,6 +453,16 @@ typedef struct hig_gemm_desc {
   int32_t pos_shift;                 /* EPI_BIAS_POS adds pos[(i % T) - pos_shift]; rows with a negative index get none */
   float* xcolsum;                    /* optional, x_rs == 1 + fp32 products + I % 4 == 0: xcolsum[i] = sum_r X[r][i] -- the
                                         bias gradient that goes with a weight gradient dW = dC^T . act (X = dC) */
+  /* LayerNorm folded into the NEXT GEMM (fp32 storage, inference forward; all NULL otherwise; both operands reduce-contiguous,
+   * 16-byte aligned, no split):
+   * row_stats_out (EPI_BIAS_RES, J % 64 == 0): also write, per 64-column panel of the output rows, (sum, sum of squared
+   *   deviations from the panel's own mean), [I][J / 64][2] fp32.
+   * row_stats_in + ln_colsum (EPI_BIAS, R % 128 == 0): X holds UN-normalised rows with their statistics [I][R / 64][2] in
+   *   row_stats_in, Y is W' = gamma (.) W, ln_colsum[j] = sum_r W'[j][r], bias[j] = b[j] + sum_r beta[r] W[j][r]:
+   *   C = rstd (X W'^T) - rstd mean ln_colsum + bias  ==  LayerNorm(X) W^T + b   (transformer.py:108-110,144). */
+  float* row_stats_out;
+  const float* row_stats_in;
+  const float* ln_colsum;
 } hig_gemm_desc;
 int hig_gemm(const hig_gemm_desc* g, hig_stream_t stream);
 /* hig_gemm with a scratch for the SPLIT TAIL of the exact-fp32 kernel, as hig_denoiser_fwd runs its GEMMs: when the

@@ -138,7 +138,11 @@ def test_text_context_cache_follows_inplace_parameter_updates():
     fresh = build().eval()
     with torch.no_grad():
         fresh.temporal_decoder_blocks[1].ca_block.key.weight.mul_(1.5)
-    assert torch.equal(b, fresh(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"]).detach())
+    assert torch.equal(b, fwd(fresh))
+    # (through autograd the forward keeps its LayerNorm kernels -- the backward needs their outputs and statistics -- while
+    # the inference forward folds them into the projections: same function, rounding-level difference)
+    tr_out = fresh(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"]).detach()
+    assert ((tr_out - b).norm() / b.norm()).item() < 2e-6
     # load_state_dict and a torch optimizer step invalidate it too
     m.load_state_dict(fill.fill_state_dict(m.state_dict()), strict=True)
     assert torch.equal(fwd(m), a)
