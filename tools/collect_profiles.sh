@@ -28,3 +28,14 @@ python3 $R/tools/gemm16_bench.py 32 2>&1 | grep -v amdgpu.ids | tail -8 >> $O/ge
 python3 $R/tools/train_step_time.py 2>&1 | grep -v amdgpu.ids | tail -3 > $O/train_step_eager_vs_captured.txt
 HIG_BWD_OVERLAP=0 python3 $R/tools/train_step_time.py 2>&1 | grep -v amdgpu.ids | tail -2 | sed 's/^/HIG_BWD_OVERLAP=0 /' >> $O/train_step_eager_vs_captured.txt
 
+
+# round 4: the bf16-storage training step (kernel stats of the eager step; eager vs captured; solo kernel timings), the
+# RCCL world-1 exchange-cost probe, the store-policy / text-fork / LayerNorm-fold A/B lines
+STORAGE=bf16 NO_CAPTURE=1 STEPS=10 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_train16 -- python3 $R/tools/train16_time.py > $O/train16_under_rocprof.log 2>&1
+python3 $R/tools/train16_time.py 2>&1 | grep -v amdgpu.ids | tail -3 > $O/train16_time.txt
+python3 $R/tools/train16_kernels_time.py 2>&1 | grep -v amdgpu.ids > $O/train16_kernels_solo.txt
+python3 $R/tools/rccl_world1_probe.py 2>/dev/null | grep "^{" > $O/rccl_world1_probe.json
+{ for pol in 0 1; do echo "HIG_WS16_STORE=$pol"; HIG_WS16_STORE=$pol python3 $R/tools/gemm16_bench.py 64 2>&1 | grep -v amdgpu.ids | tail -8 | head -5; done; } > $O/ws16_store_policy.txt
+{ for f in 1 0; do HIG_LNFOLD32=$f python3 $R/tools/fwd_text_time.py 2>&1 | grep -v amdgpu.ids | tail -1 | sed "s/^/HIG_LNFOLD32=$f /"; done;
+  for f in 1 0; do HIG_TEXT_FORK=$f python3 $R/tools/fwd_text_time.py 2>&1 | grep -v amdgpu.ids | tail -1; done; } > $O/fwd32_fold_textfork.txt
+python3 $R/tools/fwd_cfg5_time.py 2>&1 | grep -v amdgpu.ids | tail -1 > $O/cfg5_time.txt

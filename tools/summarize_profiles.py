@@ -29,7 +29,11 @@ for pattern, name in (("ws16_stamps.txt", "_ws16_stamps.txt"), ("apply16_stamps.
                       ("gemm16_shapes.txt", "_gemm16_shapes.txt"), ("train_step_eager_vs_captured.txt", "_train_step_eager_vs_captured.txt"),
                       ("trace_bf16/**/*kernel_stats.csv", "_kernel_stats_bf16_sampling_step.csv"),
                       ("trace_train/**/*kernel_stats.csv", "_kernel_stats_train_step.csv"),
-                      ("pmc_hbm/summary.json", "_hbm_kernels_pmc.json"), ("pmc16_ffn1/summary.json", "_pmc16_ffn1.json")):
+                      ("pmc_hbm/summary.json", "_hbm_kernels_pmc.json"), ("pmc16_ffn1/summary.json", "_pmc16_ffn1.json"),
+                      ("trace_train16/**/*kernel_stats.csv", "_kernel_stats_train_step_bf16s.csv"), ("train16_time.txt", "_train16_time.txt"),
+                      ("train16_kernels_solo.txt", "_train16_kernels_solo.txt"), ("rccl_world1_probe.json", "_rccl_world1_probe.json"),
+                      ("ws16_store_policy.txt", "_ws16_store_policy.txt"), ("fwd32_fold_textfork.txt", "_fwd32_fold_textfork.txt"),
+                      ("cfg5_time.txt", "_cfg5_time.txt")):
     f = one(pattern)
     if f:
         shutil.copy(f, os.path.join(dst, tag + name))
