@@ -40,7 +40,7 @@ SYMBOLS = (
     "hig_text_context_bf16_train", "hig_denoiser_fwd_bf16_train", "hig_denoiser_bwd_bf16", "hig_ln_bwd_bf16",
     "hig_linattn_apply_bwd_bf16", "hig_linattn_ctx_bwd_bf16", "hig_colsum_bf16", "hig_transpose_bf16_batch", "hig_transpose_bf16",
     "hig_gelu_bf16", "hig_cast_f32", "hig_gemm_bf16_split", "hig_gemm_bf16_split_scratch_floats", "hig_clip_adam_shadow",
-    "hig_debug_marker", "hig_denoiser_fwd_text", "hig_wgrad_bf16", "hig_wgrad_bf16_scratch_floats", "hig_denoiser_fwd_x",
+    "hig_debug_marker", "hig_denoiser_fwd_text", "hig_wgrad_bf16", "hig_wgrad_bf16_scratch_floats", "hig_denoiser_fwd_x", "hig_denoiser_fwd_bf16_x",
 )
 
 
@@ -181,6 +181,7 @@ def lib():
         L.hig_linattn_apply_sty.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32, vp, i64, i32, i32, i32, i32, vp]
         L.hig_text_context_bf16.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, vp]
         L.hig_denoiser_fwd_bf16.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.hig_denoiser_fwd_bf16_x.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.hig_gemm_split.argtypes = [C.POINTER(GemmDesc), i32, vp, i64, vp]
         L.hig_gemm_split_scratch_floats.restype = i64
         L.hig_gemm_split_scratch_floats.argtypes = [C.POINTER(GemmDesc), i32]

@@ -813,15 +813,22 @@ static int ctx16(const Dims& D, const void* K, const void* V, int64_t ld, int B,
   return hig_linattn_ctx_bf16(K, V, ld, B, rows, D.H, D.hd, length, A, kstat, scratch, At16, stream);
 }
 
+// layer_done (nullable): event l is recorded on `st` behind layer l's launches (the forked form of hig_denoiser_fwd_bf16_x)
+static int text_context16_impl(const Dims& D, const void* const* params, const void* const* params16, const float* xf_out, void* textctx,
+                               hipStream_t st, hipEvent_t* layer_done);
 extern "C" int hig_text_context_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
                                      const float* xf_out, void* textctx, hig_stream_t stream) {
   Dims D;
   HIG_TRY(check_dims(dims, D));
   HIG_REQUIRE(D.bf16, "hig_text_context_bf16: dims->storage must be HIG_STORE_BF16");
   HIG_REQUIRE(params && params16 && xf_out && textctx, "hig_text_context_bf16: null argument");
+  return text_context16_impl(D, params, params16, xf_out, textctx, hig_stream(stream), nullptr);
+}
+static int text_context16_impl(const Dims& D, const void* const* params, const void* const* params16, const float* xf_out, void* textctx,
+                               hipStream_t st, hipEvent_t* layer_done) {
   const Text16Layout tl = text16_layout(D);
   char* base = static_cast<char*>(textctx);
-  hipStream_t st = hig_stream(stream);
+  hig_stream_t stream = reinterpret_cast<hig_stream_t>(st);
   void* xfn = base + tl.xfn;
   for (int l = 0; l < D.L; ++l) {
     char* kv = base + tl.kv + tl.kv_stride * l;
@@ -835,14 +842,31 @@ extern "C" int hig_text_context_bf16(const hig_dims* dims, const void* const* pa
     if (!D.full)
       HIG_TRY(ctx16(D, kv, kv + (int64_t)D.d * 2, 2 * D.d, D.B, D.N, nullptr, Ac, kstc,
                     reinterpret_cast<float*>(base + tl.cscr), base + tl.layer0 + tl.lstride * l + tl.Atc, stream));
+    if (layer_done && hipEventRecord(layer_done[l], st) != hipSuccess) return hig_set_error(HIG_EHIP, "hipEventRecord failed");
   }
   return HIG_OK;
 }
 
+static int denoiser_fwd16_impl(const hig_dims* dims, const void* const* params, const void* const* params16, const void* const* lnfold,
+                               const float* x, const int64_t* t, const int64_t* length, const float* xf_proj, const float* xf_out_for_text,
+                               const void* textctx, float* out, void* workspace, hig_stream_t stream);
 extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
                                      const void* const* lnfold, const float* x, const int64_t* t, const int64_t* length,
                                      const float* xf_proj,
                                      const void* textctx, float* out, void* workspace, hig_stream_t stream) {
+  return denoiser_fwd16_impl(dims, params, params16, lnfold, x, t, length, xf_proj, nullptr, textctx, out, workspace, stream);
+}
+// The general form (include/hig.h): xf_out (nullable) = compute the text side here, on a library-owned stream next to the
+// first layers.
+extern "C" int hig_denoiser_fwd_bf16_x(const hig_dims* dims, const void* const* params, const void* const* params16,
+                                       const void* const* lnfold, const float* x, const int64_t* t, const int64_t* length,
+                                       const float* xf_proj, const float* xf_out, void* textctx, float* out, void* workspace,
+                                       hig_stream_t stream) {
+  return denoiser_fwd16_impl(dims, params, params16, lnfold, x, t, length, xf_proj, xf_out, textctx, out, workspace, stream);
+}
+static int denoiser_fwd16_impl(const hig_dims* dims, const void* const* params, const void* const* params16, const void* const* lnfold,
+                               const float* x, const int64_t* t, const int64_t* length, const float* xf_proj, const float* xf_out_for_text,
+                               const void* textctx, float* out, void* workspace, hig_stream_t stream) {
   Dims D;
   HIG_TRY(check_dims(dims, D));
   HIG_REQUIRE(D.bf16, "hig_denoiser_fwd_bf16: dims->storage must be HIG_STORE_BF16");
@@ -857,15 +881,62 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
   const int64_t ss_ld = (int64_t)D.nsty * D.L * 2 * d;
   float* ss = reinterpret_cast<float*>(ws + w.ss);
 
+  // Everything that hangs off the B conditioning rows instead of the M frame rows -- the embedding chain (its last GEMM reads
+  // every stylization block's (2 d, E) weight: 604 MB at the config-5 shape, HBM-bound) and the cross-attention text side --
+  // is first needed a few launches into layer 0 / in front of layer l's cross-attention.  Launched eagerly with the library's
+  // streams available, both run on the third stream next to the frame-row launches (events only; HIG_FWD16_FORK=0, a capture
+  // in progress or no side streams: everything in order on the caller's stream).
+  // Measured (tools/fwd16_fork.sh, same call, per-call text: off / text / both): config 2 B = 64 1.718 / 1.667 / 1.657-1.672 ms,
+  // B = 32 1.158 / 1.134 / 1.121; config-5 shape 4.83 / 4.71 / 4.66-4.70; with the text side cached, forking the embedding
+  // chain alone COSTS 2-6 % at config 2 (its 35 us of launches are shorter than the two event waits they add): it is forked
+  // only when its modulation weight is large (>= 256 MB: the d = 1024 models).
+  static const int fork_knob = getenv("HIG_FWD16_FORK") ? atoi(getenv("HIG_FWD16_FORK")) : -1;   // tuning knob: bit 0 embedding chain, bit 1 text side
+  const int fork_env = fork_knob >= 0 ? fork_knob : (2 | (((int64_t)E * ss_ld * 2 >= (256ll << 20)) ? 1 : 0));
+  SideStream* fs = (fork_env && D.L < kMaxTextLayers) ? side_stream_for_current_device(st) : nullptr;
+  if (fs) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) fs = nullptr;
+  }
+  const bool fork_emb = fs && (fork_env & 1), fork_text = fs && (fork_env & 2) && xf_out_for_text;
+  if (fork_emb || fork_text)
+    if (hipEventRecord(fs->ready, st) != hipSuccess || hipStreamWaitEvent(fs->s3, fs->ready, 0) != hipSuccess)
+      return hig_set_error(HIG_EHIP, "forward fork failed");
+  hipStream_t se = fork_emb ? fs->s3 : st;
+  hig_stream_t hse = reinterpret_cast<hig_stream_t>(se);
+  hipEvent_t emb_ev = fork_emb ? fs->text_done[kMaxTextLayers - 1] : nullptr;
+  // whatever was enqueued on the third stream is joined before an error leaves
+  auto join_side = [&](int rc) -> int {
+    if (fork_emb || fork_text) {
+      (void)hipEventRecord(fs->text_done[kMaxTextLayers - 1], fs->s3);
+      (void)hipStreamWaitEvent(st, fs->text_done[kMaxTextLayers - 1], 0);
+    }
+    return rc;
+  };
+#define HIG_TRY_SIDE(expr) do { const int rc_ = (expr); if (rc_ != HIG_OK) return join_side(rc_); } while (0)
+
   // K0: emb = time_embed(timestep_embedding(t)) + xf_proj; only silu(emb) is consumed (by every stylization block):
   //     te -> silu(Lin0) -> silu(Lin2 + xf_proj) -> ONE GEMM for all 3L (scale, shift) pairs      (transformer.py:345-349,415,81-83)
-  HIG_TRY(hig_timestep_embedding_bf16(t, D.B, d, ws + w.te16, stream));
-  HIG_TRY(hig_gemm16_launch(G16(ws + w.te16, d, P16(params16, HIG_P_TE0_W), d, ws + w.teh16, E, D.B, E, d)
-                                .epi(HIG_EPI_BIAS_SILU, P(params, HIG_P_TE0_B)).g, st));
-  HIG_TRY(hig_gemm16_launch(G16(ws + w.teh16, E, P16(params16, HIG_P_TE2_W), E, ws + w.semb16, E, D.B, E, E)
-                                .epi(HIG_EPI_BIAS_RES_SILU, P(params, HIG_P_TE2_B)).res32(xf_proj, E).g, st));
-  HIG_TRY(hig_gemm16_launch(G16(ws + w.semb16, E, P16(params16, HIG_P_STY_EMB_W), E, ss, ss_ld, D.B, ss_ld, E)
-                                .epi(HIG_EPI_BIAS, P(params, HIG_P_STY_EMB_B)).out32().g, st));
+  HIG_TRY_SIDE(hig_timestep_embedding_bf16(t, D.B, d, ws + w.te16, hse));
+  HIG_TRY_SIDE(hig_gemm16_launch(G16(ws + w.te16, d, P16(params16, HIG_P_TE0_W), d, ws + w.teh16, E, D.B, E, d)
+                                     .epi(HIG_EPI_BIAS_SILU, P(params, HIG_P_TE0_B)).g, se));
+  HIG_TRY_SIDE(hig_gemm16_launch(G16(ws + w.teh16, E, P16(params16, HIG_P_TE2_W), E, ws + w.semb16, E, D.B, E, E)
+                                     .epi(HIG_EPI_BIAS_RES_SILU, P(params, HIG_P_TE2_B)).res32(xf_proj, E).g, se));
+  HIG_TRY_SIDE(hig_gemm16_launch(G16(ws + w.semb16, E, P16(params16, HIG_P_STY_EMB_W), E, ss, ss_ld, D.B, ss_ld, E)
+                                     .epi(HIG_EPI_BIAS, P(params, HIG_P_STY_EMB_B)).out32().g, se));
+  if (fork_emb && hipEventRecord(emb_ev, se) != hipSuccess) return join_side(hig_set_error(HIG_EHIP, "hipEventRecord failed"));
+  hipEvent_t* text_ev = nullptr;
+  if (xf_out_for_text) {
+    HIG_TRY_SIDE(text_context16_impl(D, params, params16, xf_out_for_text, const_cast<void*>(textctx), fork_text ? fs->s3 : st,
+                                     fork_text ? fs->text_done : nullptr));
+    if (fork_text) text_ev = fs->text_done;
+  }
+  bool emb_joined = !fork_emb;
+  auto need_emb = [&]() -> int {   // in front of the first launch that reads the (scale, shift) table
+    if (emb_joined) return HIG_OK;
+    emb_joined = true;
+    return hipStreamWaitEvent(st, emb_ev, 0) == hipSuccess ? HIG_OK : hig_set_error(HIG_EHIP, "embedding join failed");
+  };
+  auto frame_rows = [&]() -> int {
   // K1: h0 = joint_embed(x) + sequence_embedding[:T]: fp32 operands (x is the fp32 DDPM state, F = 150 rows are not
   //     16-byte aligned), result rounded once into the bf16 residual stream
   static const int joint16 = getenv("HIG_JOINT16") ? atoi(getenv("HIG_JOINT16")) : 1;   // tuning knob
@@ -938,6 +1009,7 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
     return hig_gemm16_launch(G16(xn, d, PL16(params16, l, lin_w), d, outp, ncols, M, ncols, d).epi(HIG_EPI_BIAS, PL(params, l, lin_b)).g, st);
   };
   auto stylize = [&](int l, int slot, int norm_w, int norm_b, int out_w, int out_b) -> int {
+    HIG_TRY(need_emb());
     const float* ssl = ss + (int64_t)(D.nsty * l + slot) * 2 * d;
     HIG_TRY(hig_ln_bf16(y, 0, d, M, d, PL(params, l, norm_w), PL(params, l, norm_b), ssl, ss_ld, d, D.T, a, d, stream));
     return sty_out(l, out_w, out_b);
@@ -961,6 +1033,7 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
                         (int64_t)((D.T + 31) / 32) * D.B <= (int64_t)hig_chip_cus() * (fuse_out_env >= 2 ? fuse_out_env : 3);
   auto attend = [&](int l, int slot, const void* q, int64_t ldq, const float* ctx, const void* ctx_t16, int norm_w, int norm_b,
                     int out_w, int out_b) -> int {
+    HIG_TRY(need_emb());
     if (fuse_apply) {
       const float* ssl = ss + (int64_t)(D.nsty * l + slot) * 2 * d;
       const void* wfrag = (fuse_out && slot < 3 && lnfold) ? lnfold[13 * l + 9 + slot] : nullptr;
@@ -997,6 +1070,7 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
     // ---- cross attention to the text context (transformer.py:135-155) ----
     HIG_TRY(ln_proj(l, 1, HIG_L_CA_NORM_W, HIG_L_CA_NORM_B, HIG_L_CA_Q_W, HIG_L_CA_Q_B, qc, d));
     want_stats = D.two == 1;                     // (its stylization block feeds the interaction LayerNorm of the two-person model, else nothing folded)
+    if (text_ev && hipStreamWaitEvent(st, text_ev[l], 0) != hipSuccess) return hig_set_error(HIG_EHIP, "text join failed");
     if (D.full) {   // softmax over the N text tokens, no mask (transformer.py:242-262)
       const char* kvl = tc + tl.kv + tl.kv_stride * l;
       HIG_TRY(hig_fullattn_fwd_bf16(qc, d, kvl, kvl + (int64_t)d * 2, 2 * d, D.B, D.T, D.N, D.H, D.hd, nullptr, y, d, stream));
@@ -1064,6 +1138,10 @@ extern "C" int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* pa
     HIG_TRY(hig_gemm16_launch(G16(h, (int64_t)D.T * d, P16(params16, HIG_P_OUT2_W), d, out, (int64_t)D.T * D.F, D.B, D.F, d)
                                   .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT2_B)).out32().g, st));
   return HIG_OK;
+  };
+  const int rc = frame_rows();
+  return rc == HIG_OK ? rc : join_side(rc);
+#undef HIG_TRY_SIDE
 }
 
 namespace {

@@ -401,6 +401,7 @@ int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
     // (measured, profiles/r02_notes.md: FFN1 34.2 us against 36.1, q/k/v 47.5 against 42.6 -- no clear win, so it stays a
     // forced option: HIG_BF16_TILE=256)
     (void)t256;
+    if (hig_gemm16_wide_k1024(g)) pick = 256;   // (the one shape class where it wins clearly, gemm_ws16.hip)
   }
   // (ring shape, re-measured with per-phase stamps at the FFN linear1 shape, profiles/r02_notes.md section 7: the main
   // loops of two co-resident workgroups move 2 x 256 KB in ~19.3K cycles = 27 B/clk per CU, which IS the CU's L2 -> LDS

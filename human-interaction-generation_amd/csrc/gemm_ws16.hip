@@ -633,6 +633,9 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
   if (g.c_f32 || (g.res && g.res_f32)) return decline("fp32 output / residual");
   if (!(g.R == 256 || g.R == 512 || g.R == 1024)) return decline("reduce extent not in {256, 512, 1024}");
   if (g.I < min_rows) return decline("too few rows");
+  // wide K = 1024 launches (q/k/v at d = 1024: 9600 x 3072 x 1024) can go to the 256 x 256 tiled kernel instead (opt-in,
+  // HIG_BF16_WIDE256=1; hig_host.h); at J = 1024 this kernel wins clearly (29-32 against 37-44 us)
+  if (!forced_nwj && hig_gemm16_wide_k1024(g)) return decline("wide K = 1024 launch (served by the 256 x 256 tiled kernel)");
   auto al = [](const void* p, int n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
   if (!(g.ldc % 8 == 0 && al(g.C, 16))) return decline("C not 16-byte aligned / ldc not a multiple of 8");
   if ((int64_t)g.I * g.ldx >= (1ll << 30) || (int64_t)g.J * g.ldy >= (1ll << 30) || (g.res && (int64_t)g.I * g.ldr >= (1ll << 30)) ||

@@ -292,6 +292,23 @@ __device__ __forceinline__ void stage16(float* sT, int row, int col, const f32x1
         make_float4(a[4 * q] * scale, a[4 * q + 1] * scale, a[4 * q + 2] * scale, a[4 * q + 3] * scale);
 }
 
+// bf16 PRODUCTS for the bf16-storage backward (TIO = __bf16): the hd x hd contractions of apply_bwd / ctx_bwd run on
+// v_mfma_f32_32x32x16_bf16 (1/16 of the fp32 MFMA time -- the fp32 forms of these kernels are bound by the fp32 matrix rate,
+// 1.6 GFLOP per launch) with the operands rounded to bf16 while they are read from the fp32 LDS tiles: the rounding the bf16
+// storage mode applies to every other matrix operand; accumulation, softmax and the Jacobians stay fp32.  Same accumulator
+// layout as v_mfma_f32_32x32x2_f32 (lane (lr, lh): rows 8 q + 4 lh + e, column lr), so everything around the products is shared.
+typedef __bf16 la_bf16x8 __attribute__((ext_vector_type(8)));
+// 8 consecutive floats of one LDS row -> MFMA operand (k contiguous)
+__device__ __forceinline__ la_bf16x8 frag_row8(const float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  return la_bf16x8{(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+}
+// one column over 8 consecutive LDS rows (stride ld floats) -> MFMA operand (k = row)
+__device__ __forceinline__ la_bf16x8 frag_col8(const float* p, int ld) {
+  return la_bf16x8{(__bf16)p[0], (__bf16)p[ld], (__bf16)p[2 * ld], (__bf16)p[3 * ld],
+                   (__bf16)p[4 * ld], (__bf16)p[5 * ld], (__bf16)p[6 * ld], (__bf16)p[7 * ld]};
+}
+
 // Y tile (64 rows) = softmax_c(Q tile) . A[b,h]
 template <int HD, typename TIO>
 __global__ __launch_bounds__(256) void apply_mfma_kernel(const TIO* __restrict__ Q, int64_t ldq,
@@ -970,7 +987,17 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const TIO* __restri
     f32x16 dq[TB];
 #pragma unroll
     for (int tj = 0; tj < TB; ++tj) zero16(dq[tj]);
-    {
+    if constexpr (sizeof(TIO) == 2) {      // bf16 products: k = l, 16 per MFMA, lane (lr, lh) supplies l = 16 ks + 8 lh .. + 7
+      const float* xrow = sD + rl * LDP + 8 * lh;
+      const float* yrow = sA + (wj * (HD / 2) + lr) * LDP + 8 * lh;
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks) {
+        const la_bf16x8 xf = frag_row8(xrow + 16 * ks);
+#pragma unroll
+        for (int tj = 0; tj < TB; ++tj)
+          dq[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row8(yrow + 32 * tj * LDP + 16 * ks), xf, dq[tj], 0, 0, 0);
+      }
+    } else {
       const float* xrow = sD + rl * LDP + 4 * lh;
       const float* yrow = sA + (wj * (HD / 2) + lr) * LDP + 4 * lh;
 #pragma unroll 4
@@ -984,7 +1011,24 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const TIO* __restri
       }
     }
     // dA[c][l] += sum_r q[r][c] dY[r][l]   (HD x HD, reduce over the 64 rows; rows past `rows` are zero in sD)
-    {
+    if constexpr (sizeof(TIO) == 2) {      // bf16 products: k = row, lane (lr, lh) supplies rows 16 ks + 8 lh .. + 7 of its column
+      const float* xcol = sQ + (8 * lh) * LDP + wi * (HD / 2) + lr;
+      const float* ycol = sD + (8 * lh) * LDP + wj * (HD / 2) + lr;
+#pragma unroll
+      for (int ks = 0; ks < CH / 16; ++ks) {
+        la_bf16x8 xf[TB], yf[TB];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+          xf[t] = frag_col8(xcol + 16 * ks * LDP + 32 * t, LDP);
+          yf[t] = frag_col8(ycol + 16 * ks * LDP + 32 * t, LDP);
+        }
+#pragma unroll
+        for (int ti = 0; ti < TB; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TB; ++tj)
+            da[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[tj], xf[ti], da[ti][tj], 0, 0, 0);
+      }
+    } else {
       const float* xcol = sQ + (4 * lh) * LDP + wi * (HD / 2) + lr;
       const float* ycol = sD + (4 * lh) * LDP + wj * (HD / 2) + lr;
 #pragma unroll 2
@@ -1132,7 +1176,21 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
       zero16(dv[tj]);
       zero16(dk[tj]);
     }
-    {
+    if constexpr (sizeof(TIO) == 2) {      // bf16 products (see frag_row8 / frag_col8)
+      const float* krow = sK + rl * LDP + 8 * lh;                          // dV: k[r][c], reduce over c (contiguous)
+      const float* acol = sdA + (8 * lh) * LDP + wj * (HD / 2) + lr;       //     dA[c][l], k = row c of the tile
+      const float* vrow = sV + rl * LDP + 8 * lh;                          // dk: V[r][l], reduce over l (contiguous)
+      const float* arow = sdA + (wj * (HD / 2) + lr) * LDP + 8 * lh;       //     dA[c][l] by rows of c
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks) {
+        const la_bf16x8 kf = frag_row8(krow + 16 * ks), vf = frag_row8(vrow + 16 * ks);
+#pragma unroll
+        for (int tj = 0; tj < TB; ++tj) {
+          dv[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_col8(acol + 16 * ks * LDP + 32 * tj, LDP), kf, dv[tj], 0, 0, 0);
+          dk[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row8(arow + 32 * tj * LDP + 16 * ks), vf, dk[tj], 0, 0, 0);
+        }
+      }
+    } else {
       const float* krow = sK + rl * LDP + 4 * lh;                          // X of dV: k[r][c], reduce over c
       const float* acol = sdA + (4 * lh) * LDP + wj * (HD / 2) + lr;       // Y of dV: dA[c][l] by rows of c
       const float* vrow = sV + rl * LDP + 4 * lh;                          // X of dk: V[r][l], reduce over l

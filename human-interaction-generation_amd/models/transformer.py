@@ -731,6 +731,19 @@ class MotionTransformer(nn.Module):
             self._pool.give("fwd_i", ws, x.device)
             self._pool.give("textctx_i", textctx, x.device)
             return out, None
+        if not training and self._bf16() and not self.cache_text_context:
+            # same for bf16 storage (hig_denoiser_fwd_bf16_x): embedding chain and text side next to the frame-row launches
+            tbytes = L.hig_textctx_bytes(C.byref(dims), 0)
+            if tbytes < 0:
+                raise RuntimeError("libhig: " + _lib.last_error())
+            textctx = self._pool.take("textctx_i", tbytes, x.device)
+            ws = self._pool.take("fwd_i", nbytes, x.device)
+            _lib.check(L.hig_denoiser_fwd_bf16_x(C.byref(dims), fp.param_table(), fp.shadow16(self._param_version()),
+                                                 self._derived16(fp), _lib.ptr(x), _lib.ptr(t), _lib.ptr(length), _lib.ptr(xf_proj),
+                                                 _lib.ptr(xf_out), _lib.ptr(textctx), _lib.ptr(out), _lib.ptr(ws), _lib.stream_ptr()))
+            self._pool.give("fwd_i", ws, x.device)
+            self._pool.give("textctx_i", textctx, x.device)
+            return out, None
         textctx = self._text_context(dims, xf_out, training)
         ws = self._pool.take("fwd_t" if training else "fwd_i", nbytes, x.device)
         if self._bf16() and training:
@@ -739,10 +752,10 @@ class MotionTransformer(nn.Module):
                                                      _lib.ptr(textctx), _lib.ptr(out), _lib.ptr(ws), _lib.stream_ptr()))
             return out, (dims, ws, textctx)
         if self._bf16():
-            _lib.check(L.hig_denoiser_fwd_bf16(C.byref(dims), fp.param_table(), fp.shadow16(self._param_version()),
-                                               self._derived16(fp), _lib.ptr(x), _lib.ptr(t), _lib.ptr(length),
-                                               _lib.ptr(xf_proj), _lib.ptr(textctx), _lib.ptr(out), _lib.ptr(ws),
-                                               _lib.stream_ptr()))
+            _lib.check(L.hig_denoiser_fwd_bf16_x(C.byref(dims), fp.param_table(), fp.shadow16(self._param_version()),
+                                                 self._derived16(fp), _lib.ptr(x), _lib.ptr(t), _lib.ptr(length),
+                                                 _lib.ptr(xf_proj), None, _lib.ptr(textctx), _lib.ptr(out), _lib.ptr(ws),
+                                                 _lib.stream_ptr()))
             self._pool.give("fwd_i", ws, x.device)
             return out, None
         if not training:   # inference: the LayerNorm-folded projections (derived per parameter version)

@@ -213,6 +213,16 @@ int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* params, const
                           const void* const* derived, const float* x,
                           const int64_t* t, const int64_t* length, const float* xf_proj, const void* textctx,
                           float* out, void* workspace, hig_stream_t stream);
+/* hig_text_context_bf16 + hig_denoiser_fwd_bf16 as ONE call, the reference's per-call forward (transformer.py:144-150 inside
+ * :415-430): xf_out (nullable; NULL = textctx is already built, exactly hig_denoiser_fwd_bf16) is the (B, N, Lt) fp32 text
+ * encoding, textctx is WRITTEN.  Launched eagerly, the B-row work -- the timestep-embedding chain with its one GEMM over every
+ * stylization block's modulation weight, and the text side (one event per layer) -- runs on a library-owned stream next to
+ * the frame-row launches and is joined where its results are first read; under stream capture, or without the library's
+ * streams, everything runs in order on `stream`.  Results are identical either way (same kernels, same operands). */
+int hig_denoiser_fwd_bf16_x(const hig_dims* dims, const void* const* params, const void* const* params16,
+                            const void* const* derived, const float* x, const int64_t* t, const int64_t* length,
+                            const float* xf_proj, const float* xf_out, void* textctx, float* out, void* workspace,
+                            hig_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * bf16-storage TRAINING step (dims->storage == HIG_STORE_BF16; single-person model, linear attention, head dim 64 / 128).

@@ -642,6 +642,36 @@ def test_bf16_storage_sees_parameter_updates_and_refuses_unsupported_head_dims()
         bad(g1["x"], g1["t"], length=g1["length"], xf_proj=g1["xf_proj"], xf_out=g1["xf_out"])
 
 
+@pytest.mark.parametrize("case", ["width16", "config5", "small"])
+def test_bf16_per_call_text_side_on_the_side_stream_equals_the_cached_form(case):
+    """hig_denoiser_fwd_bf16_x with xf_out (the reference's per-call forward: text side and, for the d = 1024 models, the
+    embedding chain on a library-owned stream next to the frame-row launches) against the text context built first on the
+    caller's stream (cache_text_context=True): same kernels and operands, so the same bits -- on every one of a run of
+    back-to-back calls with changing inputs (a missing join would show as a stale or half-written context)."""
+    c = CASES16[case]
+    m = build(c, storage="bf16").eval()
+    base = fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"])
+    g = torch.Generator().manual_seed(11)
+    outs = {}
+    for cached in (True, False):
+        m.cache_text_context = cached
+        res = []
+        for k in range(6):
+            gi = {key: v.to(DEV) for key, v in base.items()}
+            gk = torch.Generator().manual_seed(100 + k)
+            gi["xf_out"] = (base["xf_out"] + 0.5 * torch.randn(base["xf_out"].shape, generator=gk)).to(DEV)
+            gi["xf_proj"] = (base["xf_proj"] + 0.5 * torch.randn(base["xf_proj"].shape, generator=gk)).to(DEV)
+            gi["x"] = (base["x"] + 0.1 * k).to(DEV)
+            with torch.no_grad():
+                res.append(m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"]))
+        torch.cuda.synchronize()
+        outs[cached] = res
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.isfinite(b).all() and torch.equal(a, b)
+    assert not torch.equal(outs[False][0], outs[False][1])
+    del g
+
+
 def test_config3_bf16_storage_captured_1000_step_loop():
     """BASELINE config 3 as specified: 1000-step p_sample_loop, B=32, T=196, bf16 storage, hipGraph-captured; against the
     eager loop with the noise zeroed on both sides (same kernels in the same order), finite over the whole chain."""

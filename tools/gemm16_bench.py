@@ -1,6 +1,6 @@
 """Times hig_gemm_bf16 on the denoiser's shapes (bf16 storage), rotating over operand sets larger than the Infinity
 Cache.  Tuning knobs are read by the library from the environment (HIG_BF16_TILE=64|128, HIG_BF16_PERCU, HIG_BF16_THR):
-run one process per setting.  usage: gemm16_bench.py [B]"""
+run one process per setting.  usage: gemm16_bench.py [B] [cfg5]"""
 import ctypes as C
 import os
 import sys
@@ -15,6 +15,11 @@ SHAPES = [("qkv", M, 1536, 512, _lib.EPI_BIAS), ("sty_out", M, 512, 512, _lib.EP
           ("ffn1", M, 1024, 512, _lib.EPI_BIAS_GELU), ("ffn2", M, 512, 1024, _lib.EPI_BIAS), ("ca_q", M, 512, 512, _lib.EPI_BIAS),
           ("text_kv", B * 77, 1024, 256, _lib.EPI_BIAS), ("emb_ss", B, 24576, 2048, _lib.EPI_BIAS),
           ("te2", B, 2048, 2048, _lib.EPI_BIAS_SILU)]
+if len(sys.argv) > 2 and sys.argv[2] == "cfg5":   # BASELINE config 5: B = 32, T = 300, d = 1024, ff = 1024
+    M = B * 300
+    SHAPES = [("qkv", M, 3072, 1024, _lib.EPI_BIAS), ("sty_out", M, 1024, 1024, _lib.EPI_BIAS_RES),
+              ("ffn1", M, 1024, 1024, _lib.EPI_BIAS_GELU), ("ffn2", M, 1024, 1024, _lib.EPI_BIAS),
+              ("text_kv", B * 77, 2048, 256, _lib.EPI_BIAS)]
 L = _lib.lib()
 dev = "cuda"
 tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("HIG_BF16_TILE", "HIG_BF16_PERCU", "HIG_BF16_THR", "HIG_BF16_WS", "HIG_BF16_WS_NWJ", "HIG_BF16_WS_SLOTS") if k in os.environ)
