@@ -469,14 +469,14 @@ __device__ __forceinline__ void st4g(__bf16* p, const float4& v) {
 // A wave works on RPI rows at a time (independent dependency chains: load -> mean -> variance -> gradients -> two row sums
 // -> store is ~2 us of latency per row, and a workgroup slot holds only a few waves: one row at a time left the kernel at
 // 1.6-1.9 TB/s): all loads of the RPI rows are issued before the first reduction.
-template <int NIT, bool MOD_SILU, typename TX, typename TD, int RPI>
-__global__ __launch_bounds__(256) void ln_bwd16_kernel(
+template <int NIT, bool MOD_SILU, typename TX, typename TD, int RPI, int NWV = WAVES>
+__global__ __launch_bounds__(64 * NWV) void ln_bwd16_kernel(
     const __bf16* __restrict__ da, int64_t ldda, const TX* __restrict__ x, int64_t ldx,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ ss, int64_t ss_ld, int shift_off, const TD* __restrict__ res,
     int64_t ldr, TD* __restrict__ dx, int64_t lddx, int n, int rows_per_sample,
     float* __restrict__ partial) {
-  __shared__ float red[WAVES][4][64 * 4];
+  __shared__ float red[NWV][4][64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
   const float inv_n = 1.0f / (float)n;
@@ -497,8 +497,8 @@ __global__ __launch_bounds__(256) void ln_bwd16_kernel(
       }
     }
   }
-  const int stride = WAVES * nsplit;
-  for (int rl0 = split * WAVES + wave; rl0 < rows_per_sample; rl0 += RPI * stride) {
+  const int stride = NWV * nsplit;
+  for (int rl0 = split * NWV + wave; rl0 < rows_per_sample; rl0 += RPI * stride) {
     float4 xv[RPI][NIT], dav[RPI][NIT], rv[RPI][NIT];
     bool live[RPI];
     int64_t row[RPI];
@@ -621,12 +621,12 @@ __global__ __launch_bounds__(256) void ln_bwd16_kernel(
     *reinterpret_cast<float4*>(&red[wave][2][4 * lane]) = a_dsc[it];
     *reinterpret_cast<float4*>(&red[wave][3][4 * lane]) = a_dsh[it];
     __syncthreads();
-    for (int e = threadIdx.x; e < 4 * 256; e += 256) {
+    for (int e = threadIdx.x; e < 4 * 256; e += 64 * NWV) {
       const int qn = e >> 8, cl = e & 255, c = cl + 256 * it;
       if (c < n) {
         float s = red[0][qn][cl];
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) s += red[w][qn][cl];
+        for (int w = 1; w < NWV; ++w) s += red[w][qn][cl];
         pout[(int64_t)qn * n + c] = s;
       }
     }
@@ -896,15 +896,26 @@ extern "C" int hig_ln_bwd_bf16(const void* da, int64_t ldda, const void* x, int3
     return hig_set_error(HIG_EUNSUPPORTED, "hig_ln_bwd_bf16: the stylization form is built for bf16 rows only");
   if (rows == 0) return HIG_OK;
   const int samples = (int)(rows / rows_per_sample);
-  const int nsplit = splits_for(samples);
+  // waves per workgroup: 8, in half as many workgroups (the partial sums -- one set per WORKGROUP -- halve, the rows are shared
+  // by as many waves as before).  Same call, config 2 (tools/train16_kernels_time.py): 4 waves x 512 workgroups 25.4 / 22.8 us
+  // (stylization / plain + residual form), 8 x 256: 24.0 / 21.1, 8 x 512: 28.3 / 19.1, 4 x 256: 32.6 / 30.4
+  static const int nwv = getenv("HIG_LNB_WAVES") ? atoi(getenv("HIG_LNB_WAVES")) : 8;   // tuning knob: 4 / 8
+  static const bool wgs_forced = getenv("HIG_LNB_WGS") != nullptr;
   const int nit = (n + 255) / 256;
+  int nsplit = splits_for(samples);             // (hig_ln_bwd_partial_floats sizes `partial` for this many)
+  if (nwv == 8 && nit <= 2 && !wgs_forced && nsplit > 1) nsplit /= 2;
   hipStream_t st = hig_stream(stream);
   dim3 grid(samples, nsplit);
   const __bf16* dab = static_cast<const __bf16*>(da);
-#define LNB16(NITV, MODV, TXV, TDV)                                                                                                            \
-  hipLaunchKernelGGL((ln_bwd16_kernel<NITV, MODV, TXV, TDV, (NITV <= 2 ? 2 : 1)>), grid, dim3(256), 0, st, dab, ldda, static_cast<const TXV*>(x), ldx, \
+#define LNB16_W(NITV, MODV, TXV, TDV, NWVV)                                                                                                     \
+  hipLaunchKernelGGL((ln_bwd16_kernel<NITV, MODV, TXV, TDV, (NITV <= 2 ? 2 : 1), NWVV>), grid, dim3(64 * NWVV), 0, st, dab, ldda, static_cast<const TXV*>(x), ldx, \
                      gamma, beta, ss, ss_ld, ss_shift_off, static_cast<const TDV*>(res), ldr, static_cast<TDV*>(dx), lddx, n,    \
                      rows_per_sample, partial)
+#define LNB16(NITV, MODV, TXV, TDV)                                              \
+  do {                                                                           \
+    if (nwv == 8 && NITV <= 2) LNB16_W(NITV, MODV, TXV, TDV, 8);                 \
+    else LNB16_W(NITV, MODV, TXV, TDV, 4);                                       \
+  } while (0)
 #define LNB16_NIT(MODV, TXV, TDV)                                                    \
   do {                                                                               \
     if (nit == 1) LNB16(1, MODV, TXV, TDV);                                          \
@@ -918,6 +929,7 @@ extern "C" int hig_ln_bwd_bf16(const void* da, int64_t ldda, const void* x, int3
   else return hig_set_error(HIG_EUNSUPPORTED, "hig_ln_bwd_bf16: fp32 rows with a bf16 result is not built");
 #undef LNB16_NIT
 #undef LNB16
+#undef LNB16_W
   HIG_CHECK_LAUNCH();
   if (dgamma && dbeta && mod_silu) {
     const int nb_col = (2 * n + 63) / 64;

@@ -35,13 +35,23 @@ struct Wg16Args {
   int J, K, rows, rows_per_split, ntk, ntiles, want_bias;
 };
 
-template <int NB>
-__global__ __launch_bounds__(256, 2) void wgrad16_kernel(const Wg16Args a) {
-  constexpr int CHK = 64, ROWB = 256, CPR = 16, DPO = 4, NBW = 2;
-  __shared__ __attribute__((aligned(1024))) char sD[NB][CHK * ROWB];   // dC chunk [r][j]  bf16, 16-byte chunk c of row r at c ^ f(r)
-  __shared__ __attribute__((aligned(1024))) char sX[NB][CHK * ROWB];   // act chunk [r][k]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// NSG sub-groups of four waves per workgroup (NSG = 2: 512 threads, one workgroup per CU -- the same eight waves per CU as two
+// 4-wave workgroups): sub-group g walks the row chunks g, g + NSG, ... of the workgroup's slice with its own DMA ring and its
+// own accumulators, and the sub-groups' tiles are summed through LDS before ONE partial tile leaves.  The partial tiles are
+// what a small weight gradient costs: tiles x splits x 64 KB = 32 MB written and read back per launch at two workgroups per
+// CU -- more than the operands (25.7 MB for a 512 x 512 weight) -- and NSG = 2 halves them.
+template <int NB, int CHK = 64, int NSG = 1>
+__global__ __launch_bounds__(256 * NSG, (NSG > 1 ? 2 : (NB * CHK <= 128 ? 2 : 1))) void wgrad16_kernel(const Wg16Args a) {
+  constexpr int ROWB = 256, CPR = 16, DPO = CHK / 16, NBW = 2;   // DPO: DMA instructions per wave, operand and chunk
+  static_assert(CHK == 32 || CHK == 64, "row chunks of 32 or 64");
+  static_assert(NSG == 1 || NSG * NB * CHK * ROWB * 2 >= 4 * NBW * NBW * 16 * 64 * 4, "the rings double as the reduction buffer");
+  __shared__ __attribute__((aligned(1024))) char sDall[NSG][NB][CHK * ROWB];   // dC chunk [r][j]  bf16, 16-byte chunk c of row r at c ^ f(r)
+  __shared__ __attribute__((aligned(1024))) char sXall[NSG][NB][CHK * ROWB];   // act chunk [r][k]
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                   // wave inside its sub-group
+  const int sg = NSG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+  char (*sD)[CHK * ROWB] = sDall[sg];
+  char (*sX)[CHK * ROWB] = sXall[sg];
   const int split = blockIdx.x / a.ntiles, tile = blockIdx.x - split * a.ntiles;
   const int tj = tile / a.ntk, tk = tile - tj * a.ntk;
   const int j0 = tj * 128, k0 = tk * 128;
@@ -82,28 +92,38 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const Wg16Args a) {
   float cs[NBW] = {0.f, 0.f};                       // column sums of dC: this lane's 8 rows of column 32 (NBW wi + bi) + lr per k-step
   const bool do_bias = a.want_bias && tk == 0 && wj == 0;
   const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
-  const int nchunk = (len + CHK - 1) / CHK;
-  for (int t = 0; t < NB - 1 && t < nchunk; ++t) dma_chunk(t * CHK, t);
-  for (int it = 0; it < nchunk; ++it) {
-    const int r0 = it * CHK, buf = it % NB;
+  const int nchunk_all = (len + CHK - 1) / CHK;                 // chunks of the slice; this sub-group's: sg, sg + NSG, ...
+  const int nchunk = (nchunk_all - sg + NSG - 1) / NSG;
+  const int nround = (nchunk_all + NSG - 1) / NSG;               // loop trips (uniform over the workgroup: barriers inside)
+  for (int t = 0; t < NB - 1 && t < nchunk; ++t) dma_chunk((t * NSG + sg) * CHK, t);
+  for (int it = 0; it < nround; ++it) {
+    const int r0 = (it * NSG + sg) * CHK, buf = it % NB;
+    const bool mine = it < nchunk;                               // (wave-uniform)
     {   // chunk `it` has landed once only the younger chunks' requests (2 DPO per wave and chunk) are outstanding
       const int younger = min(NB - 2, nchunk - 1 - it);
-      if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPO) : "memory");
+      static_assert(NB <= 6, "ring depth");
+      if (younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * DPO) : "memory");
+      else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * DPO) : "memory");
+      else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DPO) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPO) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();               // everyone's share of the chunk has landed; chunk it - 1's buffer is free
     asm volatile("" ::: "memory");
-    if (it + NB - 1 < nchunk) dma_chunk((it + NB - 1) * CHK, (it + NB - 1) % NB);
-    if (r0 + CHK > len) {
+    if (it + NB - 1 < nchunk) dma_chunk(((it + NB - 1) * NSG + sg) * CHK, (it + NB - 1) % NB);
+    if (it == nround - 1 && len % CHK != 0) {   // (uniform over the workgroup)
       // last, partly filled chunk: rows beyond the slice hold copies of its last row -- zero them in the dC image (one zero
       // operand is enough), whole 16-byte pieces, then publish
-      const int first = len - r0;               // 1 .. 63
-      for (int idx = tid; idx < (CHK - first) * CPR; idx += 256)
-        *reinterpret_cast<wu32x4*>(sD[buf] + (first + idx / CPR) * ROWB + 16 * (idx % CPR)) = wu32x4{0u, 0u, 0u, 0u};
+      if (mine && r0 + CHK > len) {
+        const int first = len - r0;             // 1 .. CHK - 1
+        for (int idx = tid; idx < (CHK - first) * CPR; idx += 256)
+          *reinterpret_cast<wu32x4*>(sD[buf] + (first + idx / CPR) * ROWB + 16 * (idx % CPR)) = wu32x4{0u, 0u, 0u, 0u};
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
+    if (!mine) continue;
 #pragma unroll
     for (int ks = 0; ks < CHK / 16; ++ks) {
       if (r0 + 16 * ks >= len) break;
@@ -132,6 +152,37 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const Wg16Args a) {
 #pragma unroll
         for (int bj = 0; bj < NBW; ++bj)
           acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xf[bj]), __builtin_bit_cast(bf16x8, df[bi]), acc[bi][bj], 0, 0, 0);
+    }
+  }
+  if constexpr (NSG > 1) {
+    // ---- the sub-groups' tiles summed through LDS (the rings are idle: every DMA was waited for, the barrier ends every read) ----
+    static_assert(NSG <= 2, "reduction written for two sub-groups");
+    float* red = reinterpret_cast<float*>(&sDall[0][0][0]);      // [wave][bi][bj][16][64 lanes] fp32 = 64 KB, then [4][2][64] column sums
+    float* redb = reinterpret_cast<float*>(&sXall[0][0][0]);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (sg == 1) {
+#pragma unroll
+      for (int bi = 0; bi < NBW; ++bi) {
+#pragma unroll
+        for (int bj = 0; bj < NBW; ++bj)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) red[(((wave * NBW + bi) * NBW + bj) * 16 + e) * 64 + lane] = acc[bi][bj][e];
+        redb[(wave * NBW + bi) * 64 + lane] = cs[bi];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (sg != 0) return;
+#pragma unroll
+    for (int bi = 0; bi < NBW; ++bi) {
+#pragma unroll
+      for (int bj = 0; bj < NBW; ++bj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[bi][bj][e] += red[(((wave * NBW + bi) * NBW + bj) * 16 + e) * 64 + lane];
+      cs[bi] += redb[(wave * NBW + bi) * 64 + lane];
     }
   }
   // ---- partial tile out: accumulator element 4 q + e of lane (lr, lh) is dW[j = jb + lr][k = kb + 8 q + 4 lh + e] ----
@@ -181,6 +232,11 @@ int hig_wgrad16_launch(const void* dC, int64_t ldd, const void* act, int64_t ldx
                     reinterpret_cast<uintptr_t>(dbias) | reinterpret_cast<uintptr_t>(slabs)) & 15) == 0,
               "hig_wgrad_bf16: J, K and the leading dimensions must be multiples of 8, buffers 16-byte aligned");
   HIG_REQUIRE(rows < (1ll << 31), "hig_wgrad_bf16: too many rows");
+  // DMA ring (tuning knob HIG_WG16_RING = depth x 100 + chunk rows): 264 = two 64-row chunks (64 KB, two workgroups per CU),
+  // 364 / 464 = three / four (one per CU), 432 / 632 = four / six 32-row chunks (64 / 96 KB)
+  static const int ring = getenv("HIG_WG16_RING") ? atoi(getenv("HIG_WG16_RING")) : 264;
+  static const int percu_knob = getenv("HIG_WG16_PERCU") ? atoi(getenv("HIG_WG16_PERCU")) : 0;
+  const int per_cu = percu_knob > 0 ? percu_knob : ((ring == 264 || ring == 432) ? 2 : 1);   // (2642 = 264 with two sub-groups: one)
   const int ntj = (J + 127) / 128, ntk = (K + 127) / 128, ntiles = ntj * ntk;
   const int64_t slab = (int64_t)J * K + J;
   const int nchunks = (int)((rows + 63) / 64);
@@ -188,7 +244,7 @@ int hig_wgrad16_launch(const void* dC, int64_t ldd, const void* act, int64_t ldx
     // units = tiles x splits fill, without exceeding, the two resident workgroups per CU; at least four 64-row chunks per
     // unit (the DMA ring needs a few to overlap); the slabs must fit
     splits = 1;
-    const int target = 2 * hig_chip_cus();
+    const int target = per_cu * hig_chip_cus();
     for (int s = 2; s <= 64; ++s) {
       const int cps = (nchunks + s - 1) / s;                    // chunks per split
       if (cps < 4 || (int64_t)ntiles * s > target || !slabs || slab * s > slab_floats) break;
@@ -205,7 +261,14 @@ int hig_wgrad16_launch(const void* dC, int64_t ldd, const void* act, int64_t ldx
   a.dbias = dbias;
   a.slab = splits == 1 ? 0 : slab;
   a.J = J; a.K = K; a.rows = (int)rows; a.rows_per_split = cps * 64; a.ntk = ntk; a.ntiles = ntiles; a.want_bias = dbias != nullptr;
-  hipLaunchKernelGGL((wgrad16_kernel<2>), dim3(ntiles * splits), dim3(256), 0, st, a);
+  switch (ring) {
+    case 364: hipLaunchKernelGGL((wgrad16_kernel<3, 64>), dim3(ntiles * splits), dim3(256), 0, st, a); break;
+    case 432: hipLaunchKernelGGL((wgrad16_kernel<4, 32>), dim3(ntiles * splits), dim3(256), 0, st, a); break;
+    case 632: hipLaunchKernelGGL((wgrad16_kernel<6, 32>), dim3(ntiles * splits), dim3(256), 0, st, a); break;
+    case 464: hipLaunchKernelGGL((wgrad16_kernel<4, 64>), dim3(ntiles * splits), dim3(256), 0, st, a); break;
+    case 2642: hipLaunchKernelGGL((wgrad16_kernel<2, 64, 2>), dim3(ntiles * splits), dim3(512), 0, st, a); break;
+    default: hipLaunchKernelGGL((wgrad16_kernel<2, 64>), dim3(ntiles * splits), dim3(256), 0, st, a); break;
+  }
   HIG_CHECK_LAUNCH();
   if (splits > 1) {
     const int64_t n4 = (int64_t)J * K / 4, nb4 = dbias ? J / 4 : 0;

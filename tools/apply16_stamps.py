@@ -1,10 +1,10 @@
-"""Where a workgroup of apply_sty16_kernel (csrc/linattn16.hip) spends its time: s_memtime stamps.  usage: apply16_stamps.py [B]"""
+"""Where a workgroup of apply_sty16_kernel (csrc/linattn16.hip) spends its time: s_memtime stamps.  usage: apply16_stamps.py [B] [T H hd]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from hig_amd import _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-T, H, hd = 196, 8, 64
+T, H, hd = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (196, 8, 64)
 d = H * hd
 dev = "cuda"
 q16 = torch.randn(B * T, d, device=dev).to(torch.bfloat16)
