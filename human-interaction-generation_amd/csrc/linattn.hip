@@ -179,6 +179,38 @@ __device__ __forceinline__ void row_softmax_tile(float* __restrict__ sQ) {
   for (int e = 0; e < PER; ++e) p[e] = x[e] * inv;
 }
 
+// Barrier for the chunk-walking kernels: LDS traffic of this wave is done (lgkmcnt), then s_barrier -- but NOT the vmcnt(0) a
+// __syncthreads() carries.  These kernels request the next chunk's tiles into registers right after the first barrier of a
+// chunk; a __syncthreads() further down the chunk waits for those loads to land (s_memtime stamps of apply_bwd: 7.5K of a
+// chunk's 11K cycles went into the first such barrier), so the prefetch hid nothing.  The registers are first read at the top of
+// the next chunk, where the compiler places its own counted wait; LDS reuse needs LDS ordering only.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// The same softmax on a tile still in REGISTERS, in the layout the chunk-walking kernels fetch it in: a thread holds 4 consecutive
+// channels of NPRE rows, a row's HD channels sit in HD / 4 consecutive lanes (16 = one DPP row for head dim 64).  Row max and row
+// sum by DPP (hig_common.h) -- no LDS pass, no barrier.  (s_memtime stamps of apply_bwd at config 2: the LDS form took 7.5K of a
+// chunk's 11K cycles: 32 four-way-conflicting scalar LDS accesses per thread and four ds_bpermute round trips.)
+template <int HD, int NPRE>
+__device__ __forceinline__ void row_softmax_regs(float4 (&v)[NPRE]) {
+  static_assert(HD == 64 || HD == 128, "a row in 16 or 32 consecutive lanes");
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) {
+    float m = fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w));
+    m = row16_max(m);
+    if constexpr (HD == 128) m = fmaxf(m, __shfl_xor(m, 16, 64));
+    v[i].x = __expf(v[i].x - m); v[i].y = __expf(v[i].y - m); v[i].z = __expf(v[i].z - m); v[i].w = __expf(v[i].w - m);
+    float s = (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    s = row16_sum(s);
+    if constexpr (HD == 128) s += __shfl_xor(s, 16, 64);
+    const float inv = 1.0f / s;
+    v[i].x *= inv; v[i].y *= inv; v[i].z *= inv; v[i].w *= inv;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // apply: Y[r, h*HD + l] = sum_c softmax_c(Q[r, h*HD + :])[c] * A[b,h][c][l]
 // grid = (B*H, ceil(rows / 64))
@@ -235,6 +267,22 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ float4 ld4(const __bf16* p) {
   const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
   return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+// The chunk prefetch keeps what it loaded RAW (bf16: two dwords) and converts when the chunk is consumed: a conversion next
+// to the load is the load's first use -- the compiler waits for the data right there, and the "prefetch" of the next chunk
+// became a blocking load in front of the current chunk's products (s_memtime stamps: 6.9K of a chunk's 7K cycles).
+typedef unsigned int la_u32x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct RawOf;
+template <> struct RawOf<float> { typedef float4 type; };
+template <> struct RawOf<__bf16> { typedef la_u32x2 type; };
+__device__ __forceinline__ float4 ld4raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ la_u32x2 ld4raw(const __bf16* p) { return *reinterpret_cast<const la_u32x2*>(p); }
+__device__ __forceinline__ void raw_zero(float4& r) { r = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void raw_zero(la_u32x2& r) { r = la_u32x2{0u, 0u}; }
+__device__ __forceinline__ float4 raw_cvt(const float4& r) { return r; }
+__device__ __forceinline__ float4 raw_cvt(const la_u32x2& r) {
+  return make_float4(__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                     __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u));
 }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void st4(__bf16* p, float4 v) {
@@ -323,15 +371,22 @@ __global__ __launch_bounds__(256) void apply_mfma_kernel(const TIO* __restrict__
   const TIO* Qb = Q + (int64_t)b * rows * ldq + h * HD;
   // A workgroup walks chunks blockIdx.y, blockIdx.y + gridDim.y, ...: A[b,h] is staged once, and the next Q tile
   // is requested into registers before the softmax / MFMA of the current one (no exposed load per chunk).
-  float4 pre[NPRE];
-  auto fetch = [&](int r0) {
+  // TWO chunks are in flight (register sets 0 / 1, the chunk loop unrolled by two): with one, a workgroup had 8-16 KB
+  // outstanding against a loaded memory latency of several microseconds -- the kernel ran at ~1.3 TB/s on latency alone.
+  typedef typename RawOf<TIO>::type raw_t;
+  raw_t pre0[NPRE], pre1[NPRE];
+  auto fetch = [&](int chunk, raw_t (&pre)[NPRE]) {
+    const int r0 = chunk * CH;
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
       const int idx = tid + 256 * i, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
-      pre[i] = r < rows ? ld4(Qb + (int64_t)r * ldq + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (chunk < nchunk && r < rows) pre[i] = ld4raw(Qb + (int64_t)r * ldq + 4 * c4);
+      else raw_zero(pre[i]);
     }
   };
-  fetch(blockIdx.y * CH);
+  const int gstep = gridDim.y;
+  fetch(blockIdx.y, pre0);
+  fetch(blockIdx.y + gstep, pre1);
   const float* Ab = A + (int64_t)blockIdx.x * HD * HD;
   for (int idx = tid; idx < HD * HD / 4; idx += 256)
     reinterpret_cast<float4*>(sA)[idx] = reinterpret_cast<const float4*>(Ab)[idx];
@@ -339,35 +394,62 @@ __global__ __launch_bounds__(256) void apply_mfma_kernel(const TIO* __restrict__
   const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
   const float* qrow = sQ + (wi * 32 + lr) * LDP + 4 * lh;
   const float* acol = sA + (4 * lh) * HD + wj * (HD / 2) + lr;
-  for (int chunk = blockIdx.y; chunk < nchunk; chunk += gridDim.y) {
+  // bf16 rows (TIO = __bf16): the product runs on the bf16 matrix cores like every other product of the bf16-storage mode
+  // (p and A rounded to bf16 as they are read from LDS); the A operands are chunk-invariant and stay in registers
+  [[maybe_unused]] la_bf16x8 afr[TJ][HD / 16];
+  if constexpr (sizeof(TIO) == 2) {
+    lds_barrier();                               // sA is complete
+    const float* ac8 = sA + (8 * lh) * HD + wj * (HD / 2) + lr;
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks) afr[tj][ks] = frag_col8(ac8 + 16 * ks * HD + 32 * tj, HD);
+  }
+  auto do_chunk = [&](int chunk, raw_t (&pre)[NPRE]) {
     const int r0 = chunk * CH;
+    float4 qv[NPRE];
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) qv[i] = raw_cvt(pre[i]);
+    row_softmax_regs<HD, NPRE>(qv);
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
       const int idx = tid + 256 * i;
-      *reinterpret_cast<float4*>(sQ + (idx / Q4) * LDP + 4 * (idx % Q4)) = pre[i];
+      *reinterpret_cast<float4*>(sQ + (idx / Q4) * LDP + 4 * (idx % Q4)) = qv[i];
     }
-    __syncthreads();
-    if (chunk + (int)gridDim.y < nchunk) fetch((chunk + gridDim.y) * CH);
-    row_softmax_tile<HD>(sQ);
-    __syncthreads();
+    lds_barrier();
+    fetch(chunk + 2 * gstep, pre);               // (this set is free again: two chunks ahead)
     f32x16 acc[TJ];
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) zero16(acc[tj]);
-#pragma unroll 4
-    for (int ks = 0; ks < HD / 8; ++ks) {
-      const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * ks);
+    if constexpr (sizeof(TIO) == 2) {
+      const float* q8 = sQ + (wi * 32 + lr) * LDP + 8 * lh;
 #pragma unroll
-      for (int tj = 0; tj < TJ; ++tj) {
-        const float* ap = acol + (8 * ks) * HD + 32 * tj;
-        acc[tj] = mfma4(acc[tj], ap[0], ap[HD], ap[2 * HD], ap[3 * HD], q4);
+      for (int ks = 0; ks < HD / 16; ++ks) {
+        const la_bf16x8 pf = frag_row8(q8 + 16 * ks);
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tj][ks], pf, acc[tj], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int ks = 0; ks < HD / 8; ++ks) {
+        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * ks);
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+          const float* ap = acol + (8 * ks) * HD + 32 * tj;
+          acc[tj] = mfma4(acc[tj], ap[0], ap[HD], ap[2 * HD], ap[3 * HD], q4);
+        }
       }
     }
-    __syncthreads();   // every wave is done reading sQ: the Y tile is staged there and leaves as whole rows
+    lds_barrier();   // every wave is done reading sQ: the Y tile is staged there and leaves as whole rows
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) stage16<HD>(sQ, wi * 32 + lr, wj * (HD / 2) + 32 * tj + 4 * lh, acc[tj]);
-    __syncthreads();
+    lds_barrier();
     store_tile_rows<HD, TIO>(sQ, Y + (int64_t)b * rows * ldy + h * HD, ldy, r0, rows);
-    __syncthreads();   // sQ is rewritten by the next chunk
+    lds_barrier();   // sQ is rewritten by the next chunk
+  };
+  for (int chunk = blockIdx.y; chunk < nchunk; chunk += 2 * gstep) {
+    do_chunk(chunk, pre0);
+    if (chunk + gstep < nchunk) do_chunk(chunk + gstep, pre1);
   }
 }
 
@@ -426,7 +508,7 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const TIO* __restrict__ K
       m4.z = fmaxf(m4.z, kreg[i].z); m4.w = fmaxf(m4.w, kreg[i].w);
     }
     *reinterpret_cast<float4*>(sred + rgrp * HD + 4 * c4) = m4;
-    __syncthreads();
+    lds_barrier();
     if (tid < HD) {
       float m = smax[tid];
       const float mo = m;
@@ -434,7 +516,7 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const TIO* __restrict__ K
       sscale[tid] = mo == -INFINITY ? 0.f : __expf(mo - m);   // (nothing accumulated yet while mo == -inf)
       smax[tid] = m;
     }
-    __syncthreads();
+    lds_barrier();
     const float4 cm = *reinterpret_cast<const float4*>(smax + 4 * c4);
     const float4 sc = *reinterpret_cast<const float4*>(sscale + 4 * c4);
     ks4.x *= sc.x; ks4.y *= sc.y; ks4.z *= sc.z; ks4.w *= sc.w;
@@ -457,7 +539,7 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const TIO* __restrict__ K
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[ti][tj][e] *= f;
     }
-    __syncthreads();
+    lds_barrier();
     if (r0 + CH < len) fetch(r0 + CH);
     const int nk = (min(CH, len - r0) + 7) / 8;   // 8-row groups holding valid rows (the rest are zeros)
     for (int g = 0; g < nk; ++g) {
@@ -476,10 +558,10 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const TIO* __restrict__ K
             acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[tj], pv[ti], acc[ti][tj], 0, 0, 0);
       }
     }
-    __syncthreads();   // sP / sV / sred / sscale are rewritten by the next chunk
+    lds_barrier();   // sP / sV / sred / sscale are rewritten by the next chunk
   }
   *reinterpret_cast<float4*>(sred + rgrp * HD + 4 * c4) = ks4;
-  __syncthreads();
+  lds_barrier();
   if (tid < HD) {
     float t = 0.f;
     for (int g2 = 0; g2 < NRG; ++g2) t += sred[g2 * HD + tid];
@@ -488,7 +570,7 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const TIO* __restrict__ K
     st[0] = len > 0 ? smax[tid] : 0.f;
     st[1] = len > 0 ? t : 1.f;
   }
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int ti = 0; ti < TB; ++ti) {
     const int cc = wi * (HD / 2) + 32 * ti + lr;      // lane's context row (channel c)
@@ -947,17 +1029,26 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const TIO* __restri
   // The workgroup walks row chunks blockIdx.y, blockIdx.y + gridDim.y, ...: A[b,h] is staged once, the dA
   // accumulators live across chunks (one partial per workgroup instead of one per chunk), and the next Q / dY
   // tiles are requested into registers before the products of the current ones.
-  float4 preq[NPRE], pred[NPRE];
-  auto fetch = [&](int r0) {
+  // (two chunks in flight, register sets 0 / 1: see apply_mfma_kernel)
+  typedef typename RawOf<TIO>::type raw_t;
+  raw_t preq0[NPRE], pred0[NPRE], preq1[NPRE], pred1[NPRE];
+  auto fetch = [&](int chunk, raw_t (&preq)[NPRE], raw_t (&pred)[NPRE]) {
+    const int r0 = chunk * CH;
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
       const int idx = tid + 256 * i, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
-      const bool ok = r < rows;
-      preq[i] = ok ? ld4(Qb + (int64_t)r * ldq + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      pred[i] = ok ? ld4(Db + (int64_t)r * lddy + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (chunk < nchunk && r < rows) {
+        preq[i] = ld4raw(Qb + (int64_t)r * ldq + 4 * c4);
+        pred[i] = ld4raw(Db + (int64_t)r * lddy + 4 * c4);
+      } else {
+        raw_zero(preq[i]);
+        raw_zero(pred[i]);
+      }
     }
   };
-  fetch(blockIdx.y * CH);
+  const int gstep = gridDim.y;
+  fetch(blockIdx.y, preq0, pred0);
+  fetch(blockIdx.y + gstep, preq1, pred1);
   const float* Ab = A + (int64_t)blockIdx.x * HD * HD;
   for (int idx = tid; idx < HD * HD / 4; idx += 256) {
     const int c = idx / (HD / 4), l4 = idx % (HD / 4);
@@ -971,31 +1062,42 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const TIO* __restri
   for (int ti = 0; ti < TB; ++ti)
 #pragma unroll
     for (int tj = 0; tj < TB; ++tj) zero16(da[ti][tj]);
-  for (int chunk = blockIdx.y; chunk < nchunk; chunk += gridDim.y) {
+  // bf16 products: the operands of dq_pre that come from A[b,h] do not change over the chunks -- rounded and kept in registers
+  [[maybe_unused]] la_bf16x8 afrag[TB][HD / 16];
+  if constexpr (sizeof(TIO) == 2) {
+    lds_barrier();                             // sA is complete
+    const float* yrow = sA + (wj * (HD / 2) + lr) * LDP + 8 * lh;
+#pragma unroll
+    for (int tj = 0; tj < TB; ++tj)
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks) afrag[tj][ks] = frag_row8(yrow + 32 * tj * LDP + 16 * ks);
+  }
+  auto do_chunk = [&](int chunk, raw_t (&preq)[NPRE], raw_t (&pred)[NPRE]) {
     const int r0 = chunk * CH;
+    float4 qv[NPRE];
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) qv[i] = raw_cvt(preq[i]);
+    row_softmax_regs<HD, NPRE>(qv);
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
       const int idx = tid + 256 * i;
-      *reinterpret_cast<float4*>(sQ + (idx / Q4) * LDP + 4 * (idx % Q4)) = preq[i];
-      *reinterpret_cast<float4*>(sD + (idx / Q4) * LDP + 4 * (idx % Q4)) = pred[i];
+      *reinterpret_cast<float4*>(sQ + (idx / Q4) * LDP + 4 * (idx % Q4)) = qv[i];
+      *reinterpret_cast<float4*>(sD + (idx / Q4) * LDP + 4 * (idx % Q4)) = raw_cvt(pred[i]);
     }
-    __syncthreads();
-    if (chunk + (int)gridDim.y < nchunk) fetch((chunk + gridDim.y) * CH);
-    row_softmax_tile<HD>(sQ);
-    __syncthreads();
+    lds_barrier();
+    fetch(chunk + 2 * gstep, preq, pred);        // (this set is free again: two chunks ahead)
     // dq_pre[r][c] = sum_l dY[r][l] A[c][l]   (64 x HD, reduce over HD)
     f32x16 dq[TB];
 #pragma unroll
     for (int tj = 0; tj < TB; ++tj) zero16(dq[tj]);
     if constexpr (sizeof(TIO) == 2) {      // bf16 products: k = l, 16 per MFMA, lane (lr, lh) supplies l = 16 ks + 8 lh .. + 7
       const float* xrow = sD + rl * LDP + 8 * lh;
-      const float* yrow = sA + (wj * (HD / 2) + lr) * LDP + 8 * lh;
 #pragma unroll
       for (int ks = 0; ks < HD / 16; ++ks) {
         const la_bf16x8 xf = frag_row8(xrow + 16 * ks);
 #pragma unroll
         for (int tj = 0; tj < TB; ++tj)
-          dq[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row8(yrow + 32 * tj * LDP + 16 * ks), xf, dq[tj], 0, 0, 0);
+          dq[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[tj][ks], xf, dq[tj], 0, 0, 0);
       }
     } else {
       const float* xrow = sD + rl * LDP + 4 * lh;
@@ -1060,7 +1162,7 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const TIO* __restri
       }
     part += __shfl_xor(part, 32, 64);
     if (lh == 0) srow[wj * CH + rl] = part;
-    __syncthreads();
+    lds_barrier();
     const float sdot = srow[rl] + srow[CH + rl];
     // (the barrier above also ended every wave's reads of sD: the dQ tile is staged there and leaves as whole rows)
 #pragma unroll
@@ -1072,9 +1174,13 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const TIO* __restri
             make_float4(qv.x * (dq[tj][4 * q] - sdot), qv.y * (dq[tj][4 * q + 1] - sdot),
                         qv.z * (dq[tj][4 * q + 2] - sdot), qv.w * (dq[tj][4 * q + 3] - sdot));
       }
-    __syncthreads();
+    lds_barrier();
     store_tile_rows<HD, TIO>(sD, dQ + (int64_t)b * rows * lddq + h * HD, lddq, r0, rows);
-    __syncthreads();   // sQ / sD / srow are rewritten by the next chunk
+    lds_barrier();   // sQ / sD / srow are rewritten by the next chunk
+  };
+  for (int chunk = blockIdx.y; chunk < nchunk; chunk += 2 * gstep) {
+    do_chunk(chunk, preq0, pred0);
+    if (chunk + gstep < nchunk) do_chunk(chunk + gstep, preq1, pred1);
   }
   float* dAb = dApart + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * HD * HD;
 #pragma unroll
@@ -1129,18 +1235,27 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
   const int nchunk = (rows + CH - 1) / CH;
   constexpr int Q4 = HD / 4, NPRE = CH * Q4 / 256;
   // chunk-walking like apply_bwd: dA / S staged once per workgroup, next K / V tiles prefetched into registers
-  float4 prek[NPRE], prev[NPRE];
-  auto fetch = [&](int r0) {
+  // (two chunks in flight, raw register images: see apply_mfma_kernel / RawOf)
+  typedef typename RawOf<TIO>::type raw_t;
+  raw_t prek0[NPRE], prev0[NPRE], prek1[NPRE], prev1[NPRE];
+  auto fetch = [&](int chunk, raw_t (&prek)[NPRE], raw_t (&prev)[NPRE]) {
+    const int r0 = chunk * CH;
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
       const int idx = tid + 256 * i, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
-      const bool ok = r < len;
-      prek[i] = ok ? ld4(Kb + (int64_t)r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      prev[i] = ok ? ld4(Vb + (int64_t)r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (chunk < nchunk && r < len) {
+        prek[i] = ld4raw(Kb + (int64_t)r * ld + 4 * c4);
+        prev[i] = ld4raw(Vb + (int64_t)r * ld + 4 * c4);
+      } else {
+        raw_zero(prek[i]);
+        raw_zero(prev[i]);
+      }
     }
   };
-  fetch(blockIdx.y * CH);
-  __syncthreads();
+  const int gstep = gridDim.y;
+  fetch(blockIdx.y, prek0, prev0);
+  fetch(blockIdx.y + gstep, prek1, prev1);
+  lds_barrier();
   float scol[TB][4][4];   // S[c] for the lane's columns (read before sK is overwritten)
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
@@ -1152,8 +1267,21 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
       const float4 s4 = *reinterpret_cast<const float4*>(sK + wj * (HD / 2) + 32 * tj + 8 * q + 4 * lh);
       scol[tj][q][0] = s4.x; scol[tj][q][1] = s4.y; scol[tj][q][2] = s4.z; scol[tj][q][3] = s4.w;
     }
-  __syncthreads();
-  for (int chunk = blockIdx.y; chunk < nchunk; chunk += gridDim.y) {
+  // bf16 products: the dA operands do not change over the chunks -- rounded once, kept in registers
+  [[maybe_unused]] la_bf16x8 dacol[TB][HD / 16], darow[TB][HD / 16];
+  if constexpr (sizeof(TIO) == 2) {
+    const float* acol = sdA + (8 * lh) * LDP + wj * (HD / 2) + lr;       // dV: dA[c][l], k = row c of the tile
+    const float* arow = sdA + (wj * (HD / 2) + lr) * LDP + 8 * lh;       // dk: dA[c][l] by rows of c
+#pragma unroll
+    for (int tj = 0; tj < TB; ++tj)
+#pragma unroll
+      for (int ks = 0; ks < HD / 16; ++ks) {
+        dacol[tj][ks] = frag_col8(acol + 16 * ks * LDP + 32 * tj, LDP);
+        darow[tj][ks] = frag_row8(arow + 32 * tj * LDP + 16 * ks);
+      }
+  }
+  lds_barrier();
+  auto do_chunk = [&](int chunk, raw_t (&prek)[NPRE], raw_t (&prev)[NPRE]) {
     const int r0 = chunk * CH;
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {   // k = exp(K - max) / sum on valid rows, 0 (with V = 0) beyond `len`
@@ -1162,14 +1290,14 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
       if (r0 + rr < len) {
         const float4 mx = *reinterpret_cast<const float4*>(smax + 4 * c4);
         const float4 iv = *reinterpret_cast<const float4*>(sinv + 4 * c4);
-        kk = make_float4(__expf(prek[i].x - mx.x) * iv.x, __expf(prek[i].y - mx.y) * iv.y,
-                         __expf(prek[i].z - mx.z) * iv.z, __expf(prek[i].w - mx.w) * iv.w);
+        const float4 kr = raw_cvt(prek[i]);
+        kk = make_float4(__expf(kr.x - mx.x) * iv.x, __expf(kr.y - mx.y) * iv.y, __expf(kr.z - mx.z) * iv.z, __expf(kr.w - mx.w) * iv.w);
       }
       *reinterpret_cast<float4*>(sK + rr * LDP + 4 * c4) = kk;
-      *reinterpret_cast<float4*>(sV + rr * LDP + 4 * c4) = prev[i];
+      *reinterpret_cast<float4*>(sV + rr * LDP + 4 * c4) = raw_cvt(prev[i]);
     }
-    __syncthreads();
-    if (chunk + (int)gridDim.y < nchunk) fetch((chunk + gridDim.y) * CH);
+    lds_barrier();
+    fetch(chunk + 2 * gstep, prek, prev);        // (this set is free again: two chunks ahead)
     f32x16 dv[TB], dk[TB];
 #pragma unroll
     for (int tj = 0; tj < TB; ++tj) {
@@ -1178,16 +1306,14 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
     }
     if constexpr (sizeof(TIO) == 2) {      // bf16 products (see frag_row8 / frag_col8)
       const float* krow = sK + rl * LDP + 8 * lh;                          // dV: k[r][c], reduce over c (contiguous)
-      const float* acol = sdA + (8 * lh) * LDP + wj * (HD / 2) + lr;       //     dA[c][l], k = row c of the tile
       const float* vrow = sV + rl * LDP + 8 * lh;                          // dk: V[r][l], reduce over l (contiguous)
-      const float* arow = sdA + (wj * (HD / 2) + lr) * LDP + 8 * lh;       //     dA[c][l] by rows of c
 #pragma unroll
       for (int ks = 0; ks < HD / 16; ++ks) {
         const la_bf16x8 kf = frag_row8(krow + 16 * ks), vf = frag_row8(vrow + 16 * ks);
 #pragma unroll
         for (int tj = 0; tj < TB; ++tj) {
-          dv[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_col8(acol + 16 * ks * LDP + 32 * tj, LDP), kf, dv[tj], 0, 0, 0);
-          dk[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row8(arow + 32 * tj * LDP + 16 * ks), vf, dk[tj], 0, 0, 0);
+          dv[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dacol[tj][ks], kf, dv[tj], 0, 0, 0);
+          dk[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(darow[tj][ks], vf, dk[tj], 0, 0, 0);
         }
       }
     } else {
@@ -1210,7 +1336,7 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
     }
     // rows in [len, rows) carry k == 0 and V == 0 in LDS: dV == 0 and dK = k * (..) == 0 there.  Both tiles are staged in
     // place (dV over V, dK over k: each lane rewrites exactly the elements it has just read) and leave as whole rows.
-    __syncthreads();   // every wave is done reading sK / sV
+    lds_barrier();   // every wave is done reading sK / sV
 #pragma unroll
     for (int tj = 0; tj < TB; ++tj) {
       stage16<HD>(sV, rl, wj * (HD / 2) + 32 * tj + 4 * lh, dv[tj]);
@@ -1223,10 +1349,14 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
                         k4.z * (dk[tj][4 * q + 2] - scol[tj][q][2]), k4.w * (dk[tj][4 * q + 3] - scol[tj][q][3]));
       }
     }
-    __syncthreads();
+    lds_barrier();
     store_tile_rows<HD, TIO>(sV, dV + (int64_t)b * rows * ldd + h * HD, ldd, r0, rows);
     store_tile_rows<HD, TIO>(sK, dK + (int64_t)b * rows * ldd + h * HD, ldd, r0, rows);
-    __syncthreads();   // sK / sV are rewritten by the next chunk
+    lds_barrier();   // sK / sV are rewritten by the next chunk
+  };
+  for (int chunk = blockIdx.y; chunk < nchunk; chunk += 2 * gstep) {
+    do_chunk(chunk, prek0, prev0);
+    if (chunk + gstep < nchunk) do_chunk(chunk + gstep, prek1, prev1);
   }
 }
 
@@ -1690,7 +1820,9 @@ extern "C" int hig_linattn_apply_bwd_bf16(const void* dY, int64_t lddy, const vo
                   (reinterpret_cast<uintptr_t>(dQ) & 15) == 0,
               "hig_linattn_apply_bwd_bf16: Q / dY rows must be 8-byte aligned, dQ rows 16-byte aligned");
   const int nchunk = (rows + CH - 1) / CH;
-  int nparts = (hig_chip_cus() + B * H - 1) / (B * H);
+  static const int tgt16 = getenv("HIG_APPLY_BWD16_WGS") ? atoi(getenv("HIG_APPLY_BWD16_WGS")) : 0;   // tuning knob
+  const int target16 = tgt16 > 0 ? tgt16 : hig_chip_cus();
+  int nparts = (target16 + B * H - 1) / (B * H);
   nparts = nparts < 1 ? 1 : (nparts > nchunk ? nchunk : nparts);
   float* part = nparts == 1 ? dA : scratch;
   const __bf16* dy = static_cast<const __bf16*>(dY);
@@ -1721,7 +1853,9 @@ extern "C" int hig_linattn_ctx_bwd_bf16(const float* dA, const float* A, const v
                   ((reinterpret_cast<uintptr_t>(dK) | reinterpret_cast<uintptr_t>(dV)) & 15) == 0,
               "hig_linattn_ctx_bwd_bf16: K / V rows must be 8-byte aligned, dK / dV rows 16-byte aligned");
   const int nchunk = (rows + CH - 1) / CH;
-  int gy = (hig_chip_cus() + B * H - 1) / (B * H);
+  static const int tgt16 = getenv("HIG_CTX_BWD16_WGS") ? atoi(getenv("HIG_CTX_BWD16_WGS")) : 0;   // tuning knob
+  const int target16 = tgt16 > 0 ? tgt16 : hig_chip_cus();
+  int gy = (target16 + B * H - 1) / (B * H);
   gy = gy < 1 ? 1 : (gy > nchunk ? nchunk : gy);
   const __bf16* k = static_cast<const __bf16*>(K);
   const __bf16* v = static_cast<const __bf16*>(V);

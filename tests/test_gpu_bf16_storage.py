@@ -227,7 +227,9 @@ def test_layernorm_and_stylization_front_bf16(rows, n, mod, x_f32):
 
 @pytest.mark.parametrize("hd,H,B,T", [(64, 8, 4, 196), (128, 4, 3, 300), (64, 2, 40, 77), (64, 8, 64, 50)])
 def test_linear_attention_bf16_io_matches_fp32_kernels(hd, H, B, T):
-    """Same kernels, bf16 loads / stores: against the fp32 entry points fed the bf16-rounded values."""
+    """bf16 loads / stores against the fp32 entry points fed the bf16-rounded values: the context build is the same arithmetic
+    (bit-equal); `apply` runs its product on the bf16 matrix cores (p and A rounded to bf16, fp32 accumulation, fp32 softmax):
+    equal to the operand rounding."""
     d = H * hd
     g = torch.Generator().manual_seed(hd + B + T)
     qkv16 = bf(torch.randn(B * T, 3 * d, generator=g)).to(DEV)
@@ -248,7 +250,9 @@ def test_linear_attention_bf16_io_matches_fp32_kernels(hd, H, B, T):
     y32 = torch.empty(B * T, d, device=DEV)
     _lib.check(L.hig_linattn_apply_bf16(_lib.ptr(qkv16), 3 * d, _lib.ptr(A16), _lib.ptr(y16), d, B, T, H, hd, _lib.stream_ptr()))
     _lib.check(L.hig_linattn_apply(_lib.ptr(qkv32), 3 * d, _lib.ptr(A32), _lib.ptr(y32), d, B, T, H, hd, _lib.stream_ptr()))
-    assert torch.equal(y16, bf(y32))
+    torch.cuda.synchronize()
+    assert torch.isfinite(y16.float()).all()
+    assert rel(y16.float(), y32) < 5e-3, rel(y16.float(), y32)
 
 
 @pytest.mark.parametrize("hd,H,B,T", [(64, 8, 5, 196), (128, 8, 2, 300), (64, 4, 3, 33), (128, 4, 2, 64)])
