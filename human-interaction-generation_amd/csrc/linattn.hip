@@ -385,11 +385,16 @@ __global__ __launch_bounds__(256) void apply_mfma_kernel(const TIO* __restrict__
     }
   };
   const int gstep = gridDim.y;
+  // A[b,h] is requested FIRST (returns are in order: staged into LDS it would otherwise wait behind both chunk prefetches)
+  const float* Ab = A + (int64_t)blockIdx.x * HD * HD;
+  constexpr int NA4 = HD * HD / 4 / 256;
+  float4 areg[NA4];
+#pragma unroll
+  for (int i = 0; i < NA4; ++i) areg[i] = reinterpret_cast<const float4*>(Ab)[tid + 256 * i];
   fetch(blockIdx.y, pre0);
   fetch(blockIdx.y + gstep, pre1);
-  const float* Ab = A + (int64_t)blockIdx.x * HD * HD;
-  for (int idx = tid; idx < HD * HD / 4; idx += 256)
-    reinterpret_cast<float4*>(sA)[idx] = reinterpret_cast<const float4*>(Ab)[idx];
+#pragma unroll
+  for (int i = 0; i < NA4; ++i) reinterpret_cast<float4*>(sA)[tid + 256 * i] = areg[i];
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
   const float* qrow = sQ + (wi * 32 + lr) * LDP + 4 * lh;
@@ -1047,12 +1052,18 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const TIO* __restri
     }
   };
   const int gstep = gridDim.y;
+  // A[b,h] is requested FIRST (returns are in order: staged into LDS it would otherwise wait behind both chunk prefetches)
+  const float* Ab = A + (int64_t)blockIdx.x * HD * HD;
+  constexpr int NA4 = HD * HD / 4 / 256;
+  float4 areg[NA4];
+#pragma unroll
+  for (int i = 0; i < NA4; ++i) areg[i] = reinterpret_cast<const float4*>(Ab)[tid + 256 * i];
   fetch(blockIdx.y, preq0, pred0);
   fetch(blockIdx.y + gstep, preq1, pred1);
-  const float* Ab = A + (int64_t)blockIdx.x * HD * HD;
-  for (int idx = tid; idx < HD * HD / 4; idx += 256) {
-    const int c = idx / (HD / 4), l4 = idx % (HD / 4);
-    *reinterpret_cast<float4*>(sA + c * LDP + 4 * l4) = reinterpret_cast<const float4*>(Ab)[idx];
+#pragma unroll
+  for (int i = 0; i < NA4; ++i) {
+    const int idx = tid + 256 * i, c = idx / (HD / 4), l4 = idx % (HD / 4);
+    *reinterpret_cast<float4*>(sA + c * LDP + 4 * l4) = areg[i];
   }
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1, lr = lane & 31, lh = lane >> 5;
@@ -1213,22 +1224,13 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
   if (length) len = (int)min<int64_t>(max<int64_t>(length[b], 0), rows);
   const float* dAb = dA + (int64_t)blockIdx.x * HD * HD;
   const float* Ab = A + (int64_t)blockIdx.x * HD * HD;
-  for (int idx = tid; idx < HD * HD / 4; idx += 256) {
-    const int c = idx / (HD / 4), l4 = idx % (HD / 4);
-    const float4 d4 = reinterpret_cast<const float4*>(dAb)[idx];
-    const float4 a4 = reinterpret_cast<const float4*>(Ab)[idx];
-    *reinterpret_cast<float4*>(sdA + c * LDP + 4 * l4) = d4;
-    const float pr = d4.x * a4.x + d4.y * a4.y + d4.z * a4.z + d4.w * a4.w;
-    // HD / 4 consecutive threads (16 or 32 lanes of one wave) hold one row of this sweep: reduce inside the group
-    float t = pr;
+  // dA / A are requested first, the chunk prefetches right behind them (below), and only then are they consumed
+  constexpr int NA4 = HD * HD / 4 / 256;
+  float4 dreg[NA4], areg[NA4];
 #pragma unroll
-    for (int o = HD / 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-    if (l4 == 0) sK[c] = t;          // sK is free until the staging loop below: park S there
-  }
-  if (tid < HD) {
-    const float* st = kstat + ((int64_t)blockIdx.x * HD + tid) * 2;
-    smax[tid] = st[0];
-    sinv[tid] = 1.0f / st[1];
+  for (int i = 0; i < NA4; ++i) {
+    dreg[i] = reinterpret_cast<const float4*>(dAb)[tid + 256 * i];
+    areg[i] = reinterpret_cast<const float4*>(Ab)[tid + 256 * i];
   }
   const TIO* Kb = K + (int64_t)b * rows * ld + h * HD;
   const TIO* Vb = V + (int64_t)b * rows * ld + h * HD;
@@ -1255,6 +1257,25 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
   const int gstep = gridDim.y;
   fetch(blockIdx.y, prek0, prev0);
   fetch(blockIdx.y + gstep, prek1, prev1);
+#pragma unroll
+  for (int i = 0; i < NA4; ++i) {
+    const int idx = tid + 256 * i;
+    const int c = idx / (HD / 4), l4 = idx % (HD / 4);
+    const float4 d4 = dreg[i];
+    const float4 a4 = areg[i];
+    *reinterpret_cast<float4*>(sdA + c * LDP + 4 * l4) = d4;
+    const float pr = d4.x * a4.x + d4.y * a4.y + d4.z * a4.z + d4.w * a4.w;
+    // HD / 4 consecutive threads (16 or 32 lanes of one wave) hold one row of this sweep: reduce inside the group
+    float t = pr;
+#pragma unroll
+    for (int o = HD / 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (l4 == 0) sK[c] = t;          // sK is free until the staging loop below: park S there
+  }
+  if (tid < HD) {
+    const float* st = kstat + ((int64_t)blockIdx.x * HD + tid) * 2;
+    smax[tid] = st[0];
+    sinv[tid] = 1.0f / st[1];
+  }
   lds_barrier();
   float scol[TB][4][4];   // S[c] for the lane's columns (read before sK is overwritten)
   const int lane = tid & 63, wave = tid >> 6;
