@@ -375,12 +375,15 @@ __global__ __launch_bounds__(256) void apply_mfma_kernel(const TIO* __restrict__
   // outstanding against a loaded memory latency of several microseconds -- the kernel ran at ~1.3 TB/s on latency alone.
   typedef typename RawOf<TIO>::type raw_t;
   raw_t pre0[NPRE], pre1[NPRE];
+  const TIO* qsrc[NPRE];                        // this thread's piece of row (tid + 256 i) / Q4 of chunk 0: a chunk adds CH rows
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) qsrc[i] = Qb + (int64_t)((tid + 256 * i) / Q4) * ldq + 4 * ((tid + 256 * i) % Q4);
+  const int64_t chunk_q = (int64_t)CH * ldq;
   auto fetch = [&](int chunk, raw_t (&pre)[NPRE]) {
-    const int r0 = chunk * CH;
+    const int rleft = chunk < nchunk ? rows - chunk * CH : 0;   // rows of this chunk that exist
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
-      const int idx = tid + 256 * i, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
-      if (chunk < nchunk && r < rows) pre[i] = ld4raw(Qb + (int64_t)r * ldq + 4 * c4);
+      if ((tid + 256 * i) / Q4 < rleft) pre[i] = ld4raw(qsrc[i] + chunk * chunk_q);
       else raw_zero(pre[i]);
     }
   };
@@ -1037,14 +1040,21 @@ __global__ __launch_bounds__(256) void apply_bwd_mfma_kernel(const TIO* __restri
   // (two chunks in flight, register sets 0 / 1: see apply_mfma_kernel)
   typedef typename RawOf<TIO>::type raw_t;
   raw_t preq0[NPRE], pred0[NPRE], preq1[NPRE], pred1[NPRE];
+  const TIO* qsrc[NPRE];                        // this thread's pieces of row (tid + 256 i) / Q4 of chunk 0: a chunk adds CH rows
+  const TIO* dsrc[NPRE];
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) {
+    qsrc[i] = Qb + (int64_t)((tid + 256 * i) / Q4) * ldq + 4 * ((tid + 256 * i) % Q4);
+    dsrc[i] = Db + (int64_t)((tid + 256 * i) / Q4) * lddy + 4 * ((tid + 256 * i) % Q4);
+  }
+  const int64_t chunk_q = (int64_t)CH * ldq, chunk_d = (int64_t)CH * lddy;
   auto fetch = [&](int chunk, raw_t (&preq)[NPRE], raw_t (&pred)[NPRE]) {
-    const int r0 = chunk * CH;
+    const int rleft = chunk < nchunk ? rows - chunk * CH : 0;   // rows of this chunk that exist
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
-      const int idx = tid + 256 * i, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
-      if (chunk < nchunk && r < rows) {
-        preq[i] = ld4raw(Qb + (int64_t)r * ldq + 4 * c4);
-        pred[i] = ld4raw(Db + (int64_t)r * lddy + 4 * c4);
+      if ((tid + 256 * i) / Q4 < rleft) {
+        preq[i] = ld4raw(qsrc[i] + chunk * chunk_q);
+        pred[i] = ld4raw(dsrc[i] + chunk * chunk_d);
       } else {
         raw_zero(preq[i]);
         raw_zero(pred[i]);
@@ -1240,14 +1250,17 @@ __global__ __launch_bounds__(256) void ctx_bwd_mfma_kernel(const float* __restri
   // (two chunks in flight, raw register images: see apply_mfma_kernel / RawOf)
   typedef typename RawOf<TIO>::type raw_t;
   raw_t prek0[NPRE], prev0[NPRE], prek1[NPRE], prev1[NPRE];
+  int64_t kvoff[NPRE];                           // this thread's piece of row (tid + 256 i) / Q4 of chunk 0: a chunk adds CH rows
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) kvoff[i] = (int64_t)((tid + 256 * i) / Q4) * ld + 4 * ((tid + 256 * i) % Q4);
+  const int64_t chunk_kv = (int64_t)CH * ld;
   auto fetch = [&](int chunk, raw_t (&prek)[NPRE], raw_t (&prev)[NPRE]) {
-    const int r0 = chunk * CH;
+    const int rleft = chunk < nchunk ? len - chunk * CH : 0;    // valid rows of this chunk
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
-      const int idx = tid + 256 * i, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
-      if (chunk < nchunk && r < len) {
-        prek[i] = ld4raw(Kb + (int64_t)r * ld + 4 * c4);
-        prev[i] = ld4raw(Vb + (int64_t)r * ld + 4 * c4);
+      if ((tid + 256 * i) / Q4 < rleft) {
+        prek[i] = ld4raw(Kb + kvoff[i] + chunk * chunk_kv);
+        prev[i] = ld4raw(Vb + kvoff[i] + chunk * chunk_kv);
       } else {
         raw_zero(prek[i]);
         raw_zero(prev[i]);
