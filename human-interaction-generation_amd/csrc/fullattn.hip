@@ -320,25 +320,40 @@ __device__ __forceinline__ void st4f(__bf16* p, float4 v) {
   *reinterpret_cast<bf16x4_fa*>(p) = bf16x4_fa{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
 }
 // NW = waves per workgroup (2 / 4 / 8: 64 / 128 / 256 rows of the register side share one staged chunk)
-template <int HD, int NW>
-struct Chunk32 { float4 v[MC * (HD / 4) / (64 * NW)]; };
+// The prefetched chunk stays RAW in registers (bf16 rows: two dwords per piece) and is converted by put32: a conversion next
+// to the load is the load's first use, i.e. a wait for the data in front of the current chunk's products (linattn.hip, RawOf).
+typedef unsigned int fa_u32x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct RawFa;
+template <> struct RawFa<float> { typedef float4 type; };
+template <> struct RawFa<__bf16> { typedef fa_u32x2 type; };
+__device__ __forceinline__ void raw_ld(float4& r, const float* p) { r = *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void raw_ld(fa_u32x2& r, const __bf16* p) { r = *reinterpret_cast<const fa_u32x2*>(p); }
+__device__ __forceinline__ void raw_clear(float4& r) { r = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void raw_clear(fa_u32x2& r) { r = fa_u32x2{0u, 0u}; }
+__device__ __forceinline__ float4 raw_f4(const float4& r) { return r; }
+__device__ __forceinline__ float4 raw_f4(const fa_u32x2& r) {
+  return make_float4(__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                     __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u));
+}
+template <int HD, int NW, typename T = float>
+struct Chunk32 { typename RawFa<T>::type v[MC * (HD / 4) / (64 * NW)]; };
 template <int HD, int NW, typename T>
-__device__ __forceinline__ void fetch32(const T* __restrict__ src, int64_t ld, int r0, int rows, Chunk32<HD, NW>& c) {
+__device__ __forceinline__ void fetch32(const T* __restrict__ src, int64_t ld, int r0, int rows, Chunk32<HD, NW, T>& c) {
   constexpr int Q4 = HD / 4, NT = 64 * NW;
 #pragma unroll
   for (int it = 0; it < MC * Q4 / NT; ++it) {
     const int idx = threadIdx.x + NT * it, rr = idx / Q4, c4 = idx % Q4, r = r0 + rr;
-    c.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < rows) c.v[it] = ld4f(src + (int64_t)r * ld + 4 * c4);
+    raw_clear(c.v[it]);
+    if (r < rows) raw_ld(c.v[it], src + (int64_t)r * ld + 4 * c4);
   }
 }
-template <int HD, int LD, int NW>
-__device__ __forceinline__ void put32(const Chunk32<HD, NW>& c, float* __restrict__ dst) {
+template <int HD, int LD, int NW, typename T>
+__device__ __forceinline__ void put32(const Chunk32<HD, NW, T>& c, float* __restrict__ dst) {
   constexpr int Q4 = HD / 4, NT = 64 * NW;
 #pragma unroll
   for (int it = 0; it < MC * Q4 / NT; ++it) {
     const int idx = threadIdx.x + NT * it, rr = idx / Q4, c4 = idx % Q4;
-    *reinterpret_cast<float4*>(dst + rr * LD + 4 * c4) = c.v[it];
+    *reinterpret_cast<float4*>(dst + rr * LD + 4 * c4) = raw_f4(c.v[it]);
   }
 }
 // the lane's half of its own row in the permuted reduce order: r[j][e] = row[8j + 4g + e]
@@ -419,7 +434,7 @@ __global__ __launch_bounds__(64 * NW) void full_fwd_mfma_kernel(const TIO* __res
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[cb][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  Chunk32<HD, NW> ck, cv;
+  Chunk32<HD, NW, TIO> ck, cv;
   fetch32<HD, NW>(Kb, ldk, 0, Tk, ck);
   fetch32<HD, NW>(Vb, ldk, 0, Tk, cv);
   for (int kc = 0; kc < Tk; kc += MC) {
