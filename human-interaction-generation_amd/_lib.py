@@ -39,7 +39,7 @@ SYMBOLS = (
     # round 4: bf16-storage training step
     "hig_text_context_bf16_train", "hig_denoiser_fwd_bf16_train", "hig_denoiser_bwd_bf16", "hig_ln_bwd_bf16",
     "hig_linattn_apply_bwd_bf16", "hig_linattn_ctx_bwd_bf16", "hig_colsum_bf16", "hig_transpose_bf16_batch", "hig_transpose_bf16",
-    "hig_gelu_bf16", "hig_cast_f32", "hig_gemm_bf16_split", "hig_gemm_bf16_split_scratch_floats", "hig_clip_adam_shadow",
+    "hig_gelu_bf16", "hig_cast_f32", "hig_cast_pad_bf16", "hig_gemm_bf16_split", "hig_gemm_bf16_split_scratch_floats", "hig_clip_adam_shadow",
     "hig_debug_marker", "hig_denoiser_fwd_text", "hig_wgrad_bf16", "hig_wgrad_bf16_scratch_floats", "hig_denoiser_fwd_x", "hig_denoiser_fwd_bf16_x",
 )
 
@@ -213,6 +213,7 @@ def lib():
         L.hig_transpose_bf16.argtypes = [vp, i64, i32, i32, vp, i64, vp]
         L.hig_gelu_bf16.argtypes = [vp, vp, i64, vp]
         L.hig_cast_f32.argtypes = [vp, vp, i64, vp]
+        L.hig_cast_pad_bf16.argtypes = [vp, i64, i64, i32, vp, i64, vp]
         L.hig_gemm_bf16_split.argtypes = [C.POINTER(Gemm16Desc), i32, vp, i64, vp]
         L.hig_gemm_bf16_split_scratch_floats.restype = i64
         L.hig_gemm_bf16_split_scratch_floats.argtypes = [C.POINTER(Gemm16Desc), i32]

@@ -1875,15 +1875,51 @@ extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* pa
                            dy_out, 0, d, M, d, D.T, GL(grads, l, norm_w), GL(grads, l, norm_b), dss + (int64_t)s * 2 * d, ss_ld, lnp, stream);
   };
 
-  // ---- output projection (F-wide: fp32 kernels) -------------------------------------------------------------------------
+  // ---- output projection ---------------------------------------------------------------------------------------------------
+  // The F-wide edges on the bf16 matrix kernels too (HIG_EDGE16=0: the fp32 kernels on fp32 copies, as before): d(out) and x
+  // are rounded to bf16 rows padded to Fp = F rounded up to 32 (hig_cast_pad_bf16), the data gradient d(h_L) = d(out) W_out is a
+  // bf16 GEMM over Fp (W_out^T padded with zero columns), the two weight gradients run on wgrad16 into padded fp32 scratch
+  // and are copied into place.  Scratch: the first of the two (M, d) fp32 buffers the fp32 path needs.
   const char* hL = ws + w.layer0 + w.lstride * (D.L - 1) + w.h3;
   char* dh = b + bw.dhA;
   char* dh_alt = b + bw.dhB;
-  HIG_TRY(hig_colsum(dout, F, M, F, GP(grads, HIG_P_OUT_B), colp, stream));
-  HIG_TRY(hig_cast_f32(hL, f32a, M * d, stream));
-  HIG_TRY(wgrad32(G(dout, F, 1, f32a, d, 1, GP(grads, HIG_P_OUT_W), d, F, d, M)));
-  HIG_TRY(hig_gemm_launch(G(dout, F, 0, P(params, HIG_P_OUT_W), d, 1, f32b, d, M, d, F).g, 1, nullptr, st));
-  HIG_TRY(hig_cast_bf16(f32b, dh, M * d, stream));
+  static const int edge16_env = getenv("HIG_EDGE16") ? atoi(getenv("HIG_EDGE16")) : 1;   // tuning knob
+  const int Fp = (F + 31) / 32 * 32;
+  auto up256 = [](int64_t v) { return (v + 255) / 256 * 256; };
+  const int64_t e_dout = 0, e_x = e_dout + up256(M * Fp * 2), e_wot = e_x + up256(M * Fp * 2), e_dwo = e_wot + up256((int64_t)d * Fp * 2),
+                e_dwj = e_dwo + up256((int64_t)Fp * d * 4), e_dbo = e_dwj + up256((int64_t)d * Fp * 4), e_end = e_dbo + up256((int64_t)Fp * 4);
+  const bool edge16 = edge16_env && wg16 && d % 8 == 0 && e_end <= M * d * 4 && M * (int64_t)Fp < (1ll << 30);
+  char* edgeb = reinterpret_cast<char*>(f32a);
+  // weight gradient on wgrad16 into a padded scratch, then the real rows / columns into the gradient (weight-gradient stream)
+  auto wgrad_edge = [&](const void* dC, int n_out, const void* act, int k_in, float* scratch, float* sbias, float* out, int out_rows, int out_cols,
+                        float* out_bias, int nbias) -> int {
+    HIG_TRY(fork.begin());
+    HIG_TRY(hig_wgrad16_launch(dC, n_out, act, k_in, M, n_out, k_in, scratch, sbias, 0, slabs, bw.slab_floats, fork.stream()));
+    if (hipMemcpy2DAsync(out, (size_t)out_cols * 4, scratch, (size_t)k_in * 4, (size_t)out_cols * 4, (size_t)out_rows, hipMemcpyDeviceToDevice,
+                         fork.stream()) != hipSuccess)
+      return hig_set_error(HIG_EHIP, "hipMemcpy2DAsync failed");
+    if (out_bias && sbias != out_bias &&
+        hipMemcpyAsync(out_bias, sbias, (size_t)nbias * 4, hipMemcpyDeviceToDevice, fork.stream()) != hipSuccess)
+      return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
+    return fork.end();
+  };
+  if (edge16) {
+    HIG_TRY(hig_cast_pad_bf16(dout, F, M, F, edgeb + e_dout, Fp, stream));
+    HIG_TRY(hig_cast_pad_bf16(x, F, M, F, edgeb + e_x, Fp, stream));
+    if (hipMemsetAsync(edgeb + e_wot, 0, (size_t)d * Fp * 2, st) != hipSuccess) return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+    HIG_TRY(hig_transpose_bf16(P16(params16, HIG_P_OUT_W), d, F, d, edgeb + e_wot, Fp, stream));   // (F, d) -> (d, Fp), pad columns zero
+    // d(W_out) (F, d) and d(b_out) (F) = d(out)^T h_L and its column sums
+    HIG_TRY(wgrad_edge(edgeb + e_dout, Fp, hL, d, reinterpret_cast<float*>(edgeb + e_dwo), reinterpret_cast<float*>(edgeb + e_dbo), GP(grads, HIG_P_OUT_W), F, d,
+                       GP(grads, HIG_P_OUT_B), F));
+    // d(h_L) = d(out) W_out
+    HIG_TRY(hig_gemm16_launch(G16(edgeb + e_dout, Fp, edgeb + e_wot, Fp, dh, d, M, d, Fp).g, st));
+  } else {
+    HIG_TRY(hig_colsum(dout, F, M, F, GP(grads, HIG_P_OUT_B), colp, stream));
+    HIG_TRY(hig_cast_f32(hL, f32a, M * d, stream));
+    HIG_TRY(wgrad32(G(dout, F, 1, f32a, d, 1, GP(grads, HIG_P_OUT_W), d, F, d, M)));
+    HIG_TRY(hig_gemm_launch(G(dout, F, 0, P(params, HIG_P_OUT_W), d, 1, f32b, d, M, d, F).g, 1, nullptr, st));
+    HIG_TRY(hig_cast_bf16(f32b, dh, M * d, stream));
+  }
 
   for (int l = D.L - 1; l >= 0; --l) {
     const char* lb = ws + w.layer0 + w.lstride * l;
@@ -1954,14 +1990,24 @@ extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* pa
   }
 
   // ---- joint_embed + sequence_embedding (F-wide: fp32 kernels on an fp32 copy of d(h0)) ---------------------------------------
-  HIG_TRY(hig_colsum_bf16(dh, d, M, d, GP(grads, HIG_P_JOINT_B), colp, stream));
-  HIG_TRY(hig_cast_f32(dh, f32b, M * d, stream));
-  HIG_TRY(wgrad32(G(f32b, d, 1, x, F, 1, GP(grads, HIG_P_JOINT_W), F, d, F, M)));
-  HIG_TRY(hig_colsum(f32b, (int64_t)D.T * d, D.B, D.T * d, GP(grads, HIG_P_SEQ_EMB), colp, stream));
+  if (edge16) {
+    // d(W_joint) (d, F) and d(b_joint) (d) = d(h_0)^T x and its column sums; the position table's gradient = d(h_0) summed over samples
+    HIG_TRY(wgrad_edge(dh, d, edgeb + e_x, Fp, reinterpret_cast<float*>(edgeb + e_dwj), GP(grads, HIG_P_JOINT_B), GP(grads, HIG_P_JOINT_W), d, F,
+                       GP(grads, HIG_P_JOINT_B), d));
+    HIG_TRY(hig_colsum_bf16(dh, (int64_t)D.T * d, D.B, D.T * d, GP(grads, HIG_P_SEQ_EMB), colp, stream));
+  } else {
+    HIG_TRY(hig_colsum_bf16(dh, d, M, d, GP(grads, HIG_P_JOINT_B), colp, stream));
+    HIG_TRY(hig_cast_f32(dh, f32b, M * d, stream));
+    HIG_TRY(wgrad32(G(f32b, d, 1, x, F, 1, GP(grads, HIG_P_JOINT_W), F, d, F, M)));
+    HIG_TRY(hig_colsum(f32b, (int64_t)D.T * d, D.B, D.T * d, GP(grads, HIG_P_SEQ_EMB), colp, stream));
+  }
   if (D.nf > D.T)
     if (hipMemsetAsync(GP(grads, HIG_P_SEQ_EMB) + (int64_t)D.T * d, 0, (size_t)(D.nf - D.T) * d * 4, st) != hipSuccess)
       return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
-  if (dx) HIG_TRY(hig_gemm_launch(G(f32b, d, 0, P(params, HIG_P_JOINT_W), F, 1, dx, F, M, F, d).g, 1, nullptr, st));
+  if (dx) {   // (input gradient: asked for by tests only -- the fp32 kernel on an fp32 copy of d(h_0))
+    if (edge16) HIG_TRY(hig_cast_f32(dh, f32b, M * d, stream));
+    HIG_TRY(hig_gemm_launch(G(f32b, d, 0, P(params, HIG_P_JOINT_W), F, 1, dx, F, M, F, d).g, 1, nullptr, st));
+  }
 
   // ---- time / text embedding path (fp32, as hig_denoiser_bwd) --------------------------------------------------------------
   HIG_TRY(fork.join());

@@ -188,6 +188,35 @@ extern "C" int hig_gelu_bf16(const void* z, void* f, int64_t n, hig_stream_t str
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
+// dst[r][c] = bf16(src[r][c]) for c < cols, 0 for cols <= c < ldd: fp32 rows -> bf16 rows padded to a width the bf16 matrix
+// kernels take (the F = 150-wide motion features / their gradients at the edges of the bf16-storage training step).
+// One thread per 8 output columns.
+__global__ __launch_bounds__(256) void cast_pad16_kernel(const float* __restrict__ src, int64_t lds, int64_t rows, int cols,
+                                                         __bf16* __restrict__ dst, int64_t ldd) {
+  const int64_t p8 = ldd / 8, n = rows * p8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / p8;
+    const int c0 = (int)(i % p8) * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)(c0 + e < cols ? src[r * lds + c0 + e] : 0.f);
+    *reinterpret_cast<bf16x8*>(dst + r * ldd + c0) = o;
+  }
+}
+extern "C" int hig_cast_pad_bf16(const float* src, int64_t ld_src, int64_t rows, int32_t cols, void* dst, int64_t ld_dst,
+                                 hig_stream_t stream) {
+  HIG_REQUIRE(src && dst && rows >= 0 && cols > 0 && ld_src >= cols && ld_dst >= cols && ld_dst % 8 == 0 &&
+                  (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
+              "hig_cast_pad_bf16: ld_dst must be a multiple of 8 and >= cols, dst 16-byte aligned");
+  if (rows == 0) return HIG_OK;
+  int64_t blocks = (rows * (ld_dst / 8) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cast_pad16_kernel, dim3((unsigned)blocks), dim3(256), 0, hig_stream(stream), src, ld_src, rows, cols,
+                     static_cast<__bf16*>(dst), ld_dst);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
 extern "C" int hig_cast_f32(const void* src, float* dst, int64_t n, hig_stream_t stream) {
   HIG_REQUIRE(src && dst && n >= 0 && n % 8 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0,
               "hig_cast_f32: n %% 8 == 0, 16-byte aligned buffers");

@@ -278,6 +278,10 @@ int hig_transpose_bf16(const void* src, int64_t ld, int32_t rows, int32_t cols, 
 /* f = gelu(z) (exact erf form) elementwise on bf16; dst = float(src) elementwise.  n % 8 == 0. */
 int hig_gelu_bf16(const void* z, void* f, int64_t n, hig_stream_t stream);
 int hig_cast_f32(const void* src, float* dst, int64_t n, hig_stream_t stream);
+/* dst (rows, ld_dst) bf16 = src (rows, ld_src) fp32 rounded, columns [cols, ld_dst) zero: the F-wide rows (motion features x,
+ * the loss gradient d(out)) as operands of the bf16 matrix kernels in the bf16-storage backward -- the reference's
+ * joint_embed / out Linear layers (transformer.py:343,425) under autograd.  ld_dst a multiple of 8, dst 16-byte aligned. */
+int hig_cast_pad_bf16(const float* src, int64_t ld_src, int64_t rows, int32_t cols, void* dst, int64_t ld_dst, hig_stream_t stream);
 
 /* Weight gradient of an nn.Linear over bf16 rows WITHOUT transposed operand copies (csrc/wgrad16.hip): dW (J, K) fp32 dense =
  * dC^T . act, dbias (J) fp32 (nullable) = column sums of dC, from dC (rows, J) and act (rows, K) bf16 row-major.  Row chunks
