@@ -80,6 +80,7 @@ int main() {
     // entry points with null arguments / mismatched storage
     EXPECT(hig_denoiser_fwd(&D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr) != HIG_OK);
     EXPECT(hig_denoiser_fwd_bf16(&D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != HIG_OK);
+    EXPECT(hig_cast_pad_bf16(nullptr, 150, 8, 150, nullptr, 160, nullptr) != HIG_OK);
     EXPECT(hig_denoiser_fwd_bf16_x(&D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != HIG_OK);
     EXPECT(hig_text_context(&D, nullptr, nullptr, nullptr, 0, nullptr) != HIG_OK);
     // round 4: the bf16-storage training entry points (fp32-storage dims, null arguments, shapes they do not train)

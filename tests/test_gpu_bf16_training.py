@@ -207,6 +207,17 @@ def test_linear_attention_backward_bf16_io_matches_fp32_kernels(hd, H, B, T):
     assert (dkv16[~valid] == 0).all() or True   # padded rows: whatever the fp32 kernel leaves there is masked downstream
 
 
+@pytest.mark.parametrize("rows,cols,ldd", [(12544, 150, 160), (77, 263, 288), (5, 12, 32), (64, 512, 512)])
+def test_cast_pad_bf16(rows, cols, ldd):
+    """hig_cast_pad_bf16: fp32 rows -> bf16 rows of a padded width, pad columns zero (the F-wide operands of the bf16 backward)."""
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols + 3, generator=g).to(DEV)            # leading dimension > cols
+    dst = torch.full((rows, ldd), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().hig_cast_pad_bf16(_lib.ptr(x), cols + 3, rows, cols, _lib.ptr(dst), ldd, _lib.stream_ptr()))
+    assert torch.equal(dst[:, :cols], x[:, :cols].to(torch.bfloat16)) and (dst[:, cols:] == 0).all()
+    assert _lib.lib().hig_cast_pad_bf16(_lib.ptr(x), cols + 3, rows, cols, _lib.ptr(dst), ldd - 1, _lib.stream_ptr()) != 0
+
+
 @pytest.mark.parametrize("rows,cols", [(12544, 512), (120, 128), (66, 64), (4928, 1024), (77, 256), (200, 1536)])
 def test_bf16_transposes_and_column_sums(rows, cols):
     g = torch.Generator().manual_seed(rows + cols)
