@@ -746,7 +746,7 @@ Fwd16Layout fwd16_layout(const Dims& D) {
   w.f1 = take(D.M * D.ff * 2);
   w.lenp = take((int64_t)D.B * 8);           // two-person: lengths with the two halves swapped (the partner's mask)
   w.tok0 = take((int64_t)D.B * D.d * 4);     // two-person: joint_embed2 of the init-pose rows (fp32) before they enter h
-  w.stats = take(D.M * 4 * 2 * 4);           // LayerNorm fold: (sum, centred sum of squares) per row and 128-column panel of h
+  w.stats = take(D.M * (D.d / 128 > 4 ? D.d / 128 : 4) * 2 * 4);   // LayerNorm fold: (sum, centred sum of squares) per row and 128-column panel of h
   w.total = o;
   return w;
 }

@@ -83,7 +83,7 @@ __device__ __forceinline__ void ws_wait_vmcnt_visible() {
 // OCC: workgroups per CU the kernel is laid out for (LDS budget 160 KB / OCC, registers 512 / (OCC waves per SIMD)).
 template <int KW, int KSPLIT, int NWJ, int NCB, int EPI, int DBG = 0, int OCC = 1, int XT = 0>
 __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) void gemm_ws16_kernel(const WsArgs a) {
-  static_assert(XT == 0 || (KSPLIT == 1 && NCB == 1 && KW == 512 && (OCC == 1 || XT == 1)), "LayerNorm fold: K = 512 single-split variants");
+  static_assert(XT == 0 || (NCB == 1 && KW == 512 && (KSPLIT == 1 || OCC == 1) && (OCC == 1 || XT == 1)), "LayerNorm fold: K = 512 / K = 1024 (two K halves) variants");
   constexpr int LDS_MAX = 160 * 1024 / OCC;
   static_assert(OCC == 1 || NWJ * KSPLIT == 4, "two workgroups per CU: 4-wave variants only");
   constexpr int NW = NWJ * KSPLIT, NT = 64 * NW;
@@ -114,23 +114,30 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   // bytes it is about to overwrite), requested once the stores of tile t - 2 have read that buffer (one more barrier)
   constexpr bool RES_INPLACE = HAS_RES && (KSPLIT > 1 || OCC > 1);   // (two workgroups per CU: 80 KB each, none to spare either)
   constexpr int RBUF = HAS_RES && !RES_INPLACE ? SBUF : 0;
-  constexpr int NXB = (3 * XBUF + 2 * SBUF + 2 * RBUF + PBUF <= LDS_MAX) ? 3 : 2;
-  static_assert(2 * XBUF + 2 * SBUF + 2 * RBUF + PBUF <= LDS_MAX, "LDS budget");
+  // staging buffers: two (tile t - 1 is staged while tile t - 2 leaves) -- ONE in the K-split LayerNorm-fold consumer, whose
+  // 160 KB are otherwise all taken (two 64 KB X tiles, staging, parked halves): the tile staged during k-loop t leaves right
+  // behind that k-loop's closing barrier, and the 8 KB hold the consumer's statistics / vectors instead
+  constexpr int NSB = (XT == 2 && KSPLIT > 1) ? 1 : 2;
+  constexpr int NPAN = K / 128;                 // 128-column panels of an X row (LayerNorm-fold statistics per panel)
+  constexpr int STATB = BM * NPAN * 8;          // statistics of one tile's rows: [32][NPAN][2] floats
+  constexpr int NXB = (3 * XBUF + NSB * SBUF + 2 * RBUF + PBUF <= LDS_MAX) ? 3 : 2;
+  static_assert(2 * XBUF + NSB * SBUF + 2 * RBUF + PBUF <= LDS_MAX, "LDS budget");
   constexpr int NRQ = HAS_RES ? SBUF / 1024 / NW : 0;   // residual DMA instructions per wave and tile
   static_assert(!HAS_RES || SBUF % (1024 * NW) == 0, "residual DMA instructions must split evenly over the waves");
   // bias: in LDS where there is room (sixteen registers less per lane), else in registers for the workgroup's life
-  constexpr bool BIAS_LDS = NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + BN * 4 <= LDS_MAX;
+  constexpr bool BIAS_LDS = NXB * XBUF + NSB * SBUF + 2 * RBUF + PBUF + BN * 4 <= LDS_MAX;
   static_assert(XT != 2 || BIAS_LDS, "the LayerNorm-fold consumer keeps bias' and the column sums in LDS");
-  constexpr int XLDS = XT == 2 ? BN * 4 + 2 * 1024 : 0;   // (XT = 1 needs none: the statistics are taken in the store pass)
-  __shared__ __attribute__((aligned(1024))) char smem[NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + (BIAS_LDS ? BN * 4 : 0) + XLDS];
-  [[maybe_unused]] float* const sB = reinterpret_cast<float*>(smem + NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF);
-  [[maybe_unused]] char* const sXT = smem + NXB * XBUF + 2 * SBUF + 2 * RBUF + PBUF + (BIAS_LDS ? BN * 4 : 0);
-  [[maybe_unused]] char* const sLn = sXT;                                        // XT = 2: [2][32 rows][4 panels][2] floats
-  [[maybe_unused]] float* const sC = reinterpret_cast<float*>(sXT + 2 * 1024);   // XT = 2: column sums of W' of this panel
+  constexpr int XLDS = XT == 2 ? BN * 4 + 2 * STATB : 0;   // (XT = 1 needs none: the statistics are taken in the store pass)
+  static_assert(NXB * XBUF + NSB * SBUF + 2 * RBUF + PBUF + (BIAS_LDS ? BN * 4 : 0) + XLDS <= LDS_MAX, "LDS budget (LayerNorm-fold consumer)");
+  __shared__ __attribute__((aligned(1024))) char smem[NXB * XBUF + NSB * SBUF + 2 * RBUF + PBUF + (BIAS_LDS ? BN * 4 : 0) + XLDS];
+  [[maybe_unused]] float* const sB = reinterpret_cast<float*>(smem + NXB * XBUF + NSB * SBUF + 2 * RBUF + PBUF);
+  [[maybe_unused]] char* const sXT = smem + NXB * XBUF + NSB * SBUF + 2 * RBUF + PBUF + (BIAS_LDS ? BN * 4 : 0);
+  [[maybe_unused]] char* const sLn = sXT;                                        // XT = 2: [2][32 rows][NPAN panels][2] floats
+  [[maybe_unused]] float* const sC = reinterpret_cast<float*>(sXT + 2 * STATB);  // XT = 2: column sums of W' of this panel
   char* const sX = smem;
   char* const sS = smem + NXB * XBUF;
-  [[maybe_unused]] char* const sR = smem + NXB * XBUF + 2 * SBUF;
-  [[maybe_unused]] char* const sP = smem + NXB * XBUF + 2 * SBUF + 2 * RBUF;
+  [[maybe_unused]] char* const sR = smem + NXB * XBUF + NSB * SBUF;
+  [[maybe_unused]] char* const sP = smem + NXB * XBUF + NSB * SBUF + 2 * RBUF;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: row / buffer arithmetic of the DMA stays scalar
@@ -299,23 +306,41 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
     const int cb = j / (4 * NQF), jj = j % (4 * NQF);
     const int u = jj >> 2, e = jj & 3;           // e = 0 or 2
     f32x2 v = {old[cb][jj], old[cb][jj + 1]};
+    if constexpr (KSPLIT > 1) v += f32x2{parked[jj * 64], parked[(jj + 1) * 64]};   // (the whole product before any row scaling)
     if constexpr (XT == 2) {
-      if (j == 0) {                              // LayerNorm statistics of this lane's row from the four panel partials
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(lnbuf + lr * 32), p1 = *reinterpret_cast<const f32x4*>(lnbuf + lr * 32 + 16);
-        static_assert(XT != 2 || K == 512, "panel merge: four 128-column panels");
+      if (j == 0) {                              // LayerNorm statistics of this lane's row from its NPAN panel partials
         float mean, var;
-        hig_ln_merge4(p0, p1, mean, var);
+        if constexpr (NPAN == 4) {
+          const f32x4 p0 = *reinterpret_cast<const f32x4*>(lnbuf + lr * 32), p1 = *reinterpret_cast<const f32x4*>(lnbuf + lr * 32 + 16);
+          hig_ln_merge4(p0, p1, mean, var);
+        } else {                                 // the same pairwise merge over NPAN panels
+          f32x4 pp[NPAN / 2];
+          float ssum = 0.f, m2 = 0.f;
+#pragma unroll
+          for (int q = 0; q < NPAN / 2; ++q) {
+            pp[q] = *reinterpret_cast<const f32x4*>(lnbuf + lr * (NPAN * 8) + 16 * q);
+            ssum += pp[q].x + pp[q].z;
+            m2 += pp[q].y + pp[q].w;
+          }
+          mean = ssum * (1.0f / K);
+          float between = 0.f;
+#pragma unroll
+          for (int q = 0; q < NPAN / 2; ++q) {
+            const float d0 = fmaf(pp[q].x, 1.0f / 128.0f, -mean), d1 = fmaf(pp[q].z, 1.0f / 128.0f, -mean);
+            between = fmaf(d0, d0, fmaf(d1, d1, between));
+          }
+          var = fmaf(between, 128.0f, m2) * (1.0f / K);
+        }
         ln_rstd = rsqrtf(var + 1e-5f);
         ln_mr = -mean * ln_rstd;
       }
       if (e == 0) {
-        ln_b4 = *reinterpret_cast<const f32x4*>(sB + 32 * wj + 8 * u + 4 * lh);
-        ln_c4 = *reinterpret_cast<const f32x4*>(sC + 32 * wj + 8 * u + 4 * lh);
+        ln_b4 = *reinterpret_cast<const f32x4*>(sB + 32 * wj + 8 * (qf0 + u) + 4 * lh);
+        ln_c4 = *reinterpret_cast<const f32x4*>(sC + 32 * wj + 8 * (qf0 + u) + 4 * lh);
       }
       const f32x2 tt = __builtin_elementwise_fma(f32x2{ln_mr, ln_mr}, f32x2{ln_c4[e], ln_c4[e + 1]}, f32x2{ln_b4[e], ln_b4[e + 1]});
       v = __builtin_elementwise_fma(v, f32x2{ln_rstd, ln_rstd}, tt);
     }
-    if constexpr (KSPLIT > 1) v += f32x2{parked[jj * 64], parked[(jj + 1) * 64]};
     if constexpr (HAS_RES) {
       if (e == 0) rq = *reinterpret_cast<const u32x2*>(rbuf + lr * SROWB + 16 * ((4 * (NCB * wj + cb) + qf0 + u) ^ (lr & 15)) + 8 * lh);
       const unsigned w = e < 2 ? rq.x : rq.y;
@@ -396,21 +421,25 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
     constexpr bool STORE_SLACK = !HAS_RES && XT != 2 && NXB >= 3;
     if (STORE_SLACK && a.store_slack && dma_pend && t >= 3) WS_WAIT_ALL_BUT(NQ + NPC);
     else if (NXB >= 3 && dma_pend) WS_WAIT_ALL_BUT(NQ);
-    else WS_WAIT_ALL_BUT(0);
+    else if (NSB == 1 && t >= 2) WS_WAIT_ALL_BUT(NPC);   // (one staging buffer: the NPC stores of tile t - 2 went out behind k-loop t - 1,
+    else WS_WAIT_ALL_BUT(0);                              //  younger than everything this iteration needs: they stay in flight)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();               // everyone's share has landed; k-loop(t-1) is over everywhere: its buffer, staging(t-1), parked(t-1) are complete
     asm volatile("" ::: "memory");
     if (t < 9) stamp(3 + t);
     if constexpr (!RES_INPLACE) dma_res(t, t & 1);
     if constexpr (XT == 2) {
-      if (wave == 0) {                           // the statistics of tile t's rows: one 1-KiB DMA (32 rows x 4 panels x 2 floats)
-        const int i = min((t0 + t * a.g) * BM + (lane >> 1), a.I - 1);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.stats_in + (int64_t)i * 8 + 4 * (lane & 1)),
-                                         (__attribute__((address_space(3))) void*)(sLn + (t & 1) * 1024), 16, 0, 0);
+      // the statistics of tile t's rows: STATB / 1024 DMA instructions of 1 KiB (a row's NPAN x (sum, centred squares) floats are
+      // PPS = NPAN / 2 pieces of 16 bytes, 64 / PPS rows per instruction), one per wave
+      constexpr int PPS = NPAN / 2;
+      if (wave < STATB / 1024) {
+        const int i = min((t0 + t * a.g) * BM + wave * (64 / PPS) + lane / PPS, a.I - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.stats_in + (int64_t)i * (2 * NPAN) + 4 * (lane % PPS)),
+                                         (__attribute__((address_space(3))) void*)(sLn + (t & 1) * STATB + wave * 1024), 16, 0, 0);
       }
-      lnbuf = sLn + ((t + 1) & 1) * 1024;        // statistics of tile t - 1, whose epilogue runs in this iteration
+      lnbuf = sLn + ((t + 1) & 1) * STATB;       // statistics of tile t - 1, whose epilogue runs in this iteration
     }
-    if (t >= 2) store_tile(t - 2, sS + (t & 1) * SBUF);
+    if constexpr (NSB == 2) { if (t >= 2) store_tile(t - 2, sS + (t & 1) * SBUF); }
     if constexpr (RES_INPLACE) {                 // that staging buffer is free now: the residual of tile t goes there
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -426,7 +455,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
     // and issued in a block ahead of the k-loop that was 600-1200 cycles per tile in which the wave fed no MFMA; the
     // two waves of a SIMD issue theirs at different k-steps, so one of them keeps the matrix pipe busy)
     const char* xb = sX + (t % NXB) * XBUF;
-    char* stg = sS + ((t + 1) & 1) * SBUF;       // staging of tile t-1
+    char* stg = NSB == 1 ? sS : sS + ((t + 1) & 1) * SBUF;   // staging of tile t-1
     [[maybe_unused]] const char* rbuf = RES_INPLACE ? stg : sR + ((t + 1) & 1) * RBUF;   // its residual
     [[maybe_unused]] const float* parked = reinterpret_cast<const float*>(sP) + (wave ^ NWJ) * 512 + lane;
     // The MFMAs of this tile with the epilogue of the previous one (garbage in, nothing stored, at t = 0) riding in their
@@ -497,6 +526,7 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if constexpr (NSB == 1) { if (t >= 1) store_tile(t - 1, sS); }   // (staged by every wave during this k-loop; next written in the next one, behind the top barrier)
       float* mine = reinterpret_cast<float*>(sP) + wave * 512 + lane;
 #pragma unroll
       for (int u = 0; u < 2; ++u)
@@ -513,17 +543,17 @@ __global__ __launch_bounds__(64 * NWJ * KSPLIT, (NWJ * KSPLIT >= 8 ? 2 : OCC)) v
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   stamp(12);
-  if constexpr (XT == 2) lnbuf = sLn + ((nt + 1) & 1) * 1024;
-  if (nt >= 2) store_tile(nt - 2, sS + (nt & 1) * SBUF);
+  if constexpr (XT == 2) lnbuf = sLn + ((nt + 1) & 1) * STATB;
+  if constexpr (NSB == 2) { if (nt >= 2) store_tile(nt - 2, sS + (nt & 1) * SBUF); }
   {
-    char* stg = sS + ((nt + 1) & 1) * SBUF;
+    char* stg = NSB == 1 ? sS : sS + ((nt + 1) & 1) * SBUF;
     [[maybe_unused]] const float* parked = reinterpret_cast<const float*>(sP) + (wave ^ NWJ) * 512 + lane;
     [[maybe_unused]] const char* rbuf = RES_INPLACE ? stg : sR + ((nt + 1) & 1) * RBUF;
 #pragma unroll
     for (int jp = 0; jp < 2 * NQF * NCB; ++jp) epi_pair(jp, stg, parked, rbuf);
   }
   __syncthreads();
-  store_tile(nt - 1, sS + ((nt + 1) & 1) * SBUF);
+  store_tile(nt - 1, NSB == 1 ? sS : sS + ((nt + 1) & 1) * SBUF);
   stamp(13);
   if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + 14] = (unsigned long long)nt;
 }
@@ -591,12 +621,14 @@ int launch_ws_sized(const hig_gemm16_desc& g, int nwj, hipStream_t st) {
     }
   }
   if (nwj == 44) nwj = 4;
-  // LayerNorm folded into the next GEMM (K = 512): the producer writes row statistics, the consumer applies them
+  // LayerNorm folded into the next GEMM (K = 512, K = 1024): the producer writes row statistics, the consumer applies them
   if constexpr (EPI == HIG_EPI_BIAS_RES) {
-    if (g.row_stats_out) return launch_ws<512, 1, 4, 1, EPI, 1, 1>(g, 32, st);
+    if (g.row_stats_out && g.R == 512) return launch_ws<512, 1, 4, 1, EPI, 1, 1>(g, 32, st);
+    if (g.row_stats_out && g.R == 1024) return launch_ws<512, 2, 4, 1, EPI, 1, 1>(g, 32, st);
   }
   if constexpr (EPI == HIG_EPI_BIAS) {
-    if (g.row_stats_in) return nwj == 8 ? launch_ws<512, 1, 8, 1, EPI, 1, 2>(g, 32, st) : launch_ws<512, 1, 4, 1, EPI, 1, 2>(g, 32, st);
+    if (g.row_stats_in && g.R == 512) return nwj == 8 ? launch_ws<512, 1, 8, 1, EPI, 1, 2>(g, 32, st) : launch_ws<512, 1, 4, 1, EPI, 1, 2>(g, 32, st);
+    if (g.row_stats_in && g.R == 1024) return launch_ws<512, 2, 4, 1, EPI, 1, 2>(g, 32, st);
   }
   if (g.R == 512) return nwj == 8 ? launch_ws<512, 1, 8, 1, EPI>(g, 32, st) : nwj == 2 ? launch_ws<512, 1, 4, 2, EPI>(g, 32, st) : launch_ws<512, 1, 4, 1, EPI>(g, 32, st);
   if (g.R == 256) return nwj == 8 ? launch_ws<256, 1, 8, 1, EPI>(g, 32, st) : launch_ws<256, 1, 4, 1, EPI>(g, 32, st);
@@ -615,8 +647,9 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
   static const int min_rows = getenv("HIG_BF16_WS_ROWS") ? atoi(getenv("HIG_BF16_WS_ROWS")) : 2048;
   const bool fold = g.row_stats_out || g.row_stats_in;
   if (fold) {   // only this kernel implements the LayerNorm fold: the caller checks hig_gemm_ws16_lnfold_ok() first
-    const bool ok = ws_on && !g.c_f32 && !(g.res && g.res_f32) && g.R == 512 && g.I >= min_rows &&
-                    (g.row_stats_out ? (g.epi == HIG_EPI_BIAS_RES && g.J == 512 && !g.row_stats_in)
+    // (a producer's rows are the consumer's X rows: J of the one = K of the other, 512 or 1024)
+    const bool ok = ws_on && !g.c_f32 && !(g.res && g.res_f32) && (g.R == 512 || g.R == 1024) && g.I >= min_rows &&
+                    (g.row_stats_out ? (g.epi == HIG_EPI_BIAS_RES && g.J == g.R && !g.row_stats_in)
                                      : (g.epi == HIG_EPI_BIAS && g.ln_colsum && g.J % 128 == 0));
     if (!ok) return hig_set_error(HIG_EUNSUPPORTED, "hig_gemm_bf16: LayerNorm-fold operands on a shape the weight-stationary kernel does not serve");
   }
@@ -695,5 +728,6 @@ bool hig_gemm_ws16_lnfold_ok(int64_t rows, int d) {
   static const int ws_on = getenv("HIG_BF16_WS") ? atoi(getenv("HIG_BF16_WS")) : 1;
   static const int min_rows = getenv("HIG_BF16_WS_ROWS") ? atoi(getenv("HIG_BF16_WS_ROWS")) : 2048;
   static const int forced_nwj = getenv("HIG_BF16_WS_NWJ") ? atoi(getenv("HIG_BF16_WS_NWJ")) : 0;
-  return on && ws_on && !forced_nwj && d == 512 && rows >= min_rows;
+  static const int on1024 = getenv("HIG_LNFOLD1024") ? atoi(getenv("HIG_LNFOLD1024")) : 1;   // tuning knob
+  return on && ws_on && !forced_nwj && (d == 512 || (d == 1024 && on1024)) && rows >= min_rows;
 }

@@ -632,7 +632,7 @@ class MotionTransformer(nn.Module):
         """Operands of the bf16-storage forward derived from the parameters, kept next to the bf16 shadow and rebuilt
         when the parameters change (`derived` of hig_denoiser_fwd_bf16): 13 L + 1 device pointers, NULL where a piece does
         not apply (the library then runs its LayerNorm kernel / pads per call).
-        [13 l + 3 k + 0 .. 2] (d = 512 only): the LayerNorm-folded projection k of layer l -- k = 0 self-attention q/k/v, 1
+        [13 l + 3 k + 0 .. 2] (d = 512 or 1024): the LayerNorm-folded projection k of layer l -- k = 0 self-attention q/k/v, 1
         cross-attention query, 2 q/k/v of the person <-> person attention (two-person model) -- as [W' (bf16), colsum, bias']
         with W' = gamma (.) W, colsum[j] = sum_r float(W'[j][r]), bias' = b + W beta: LayerNorm(x) W^T + b == rstd (x W'^T) -
         rstd mean colsum + bias' (transformer.py:108-110,144; interaction_transformer.py:181-190); applied wherever the
@@ -645,7 +645,7 @@ class MotionTransformer(nn.Module):
             d, nl, ng, offs, L = self.latent_dim, _lib.NLAYER, _lib.NGLOBAL, fp.group_offsets, self.num_layers
             arr, bufs = (C.c_void_p * (13 * L + 1))(), []
             with torch.no_grad():
-                for l in range(L if d == 512 else 0):
+                for l in range(L if d in (512, 1024) else 0):
                     def grp(idx, n):
                         o = offs[ng + l * nl + idx]
                         return None if o is None else fp.flat[o:o + n]
@@ -660,9 +660,9 @@ class MotionTransformer(nn.Module):
                         bp = (b + W @ beta).contiguous()
                         bufs += [Wp, cs, bp]
                         arr[13 * l + 3 * k], arr[13 * l + 3 * k + 1], arr[13 * l + 3 * k + 2] = Wp.data_ptr(), cs.data_ptr(), bp.data_ptr()
-                    # stylization-out weights of the attention blocks in matrix-core operand order (hig_attn_out16)
+                    # stylization-out weights of the attention blocks in matrix-core operand order (hig_attn_out16: d = 512)
                     for s, wi in enumerate((6, 18, 34, 26)):
-                        w = grp(wi, d * d)
+                        w = grp(wi, d * d) if d == 512 else None
                         if w is not None:
                             wf = self._frag16(w.view(d, d).to(torch.bfloat16))
                             bufs.append(wf)

@@ -200,7 +200,7 @@ int hig_text_context_bf16(const hig_dims* dims, const void* const* params, const
                           const float* xf_out, void* textctx, hig_stream_t stream);
 /* derived (nullable): 13 L + 1 device pointers the caller derives from the parameters and keeps next to the bf16 shadow
  * (rebuilt when the parameters change); any entry may be NULL (the library then does that piece per call / unfused).
- * [13 l + 3 k + 0 .. 2], k = 0, 1, 2, d == 512: W' (bf16, rows x d), colsum (fp32, rows), bias' (fp32, rows) of the LayerNorm +
+ * [13 l + 3 k + 0 .. 2], k = 0, 1, 2, d == 512 or 1024: W' (bf16, rows x d), colsum (fp32, rows), bias' (fp32, rows) of the LayerNorm +
  * Linear pair k of layer l -- k = 0 self-attention q/k/v (3d rows), k = 1 cross-attention query (d rows), k = 2 q/k/v of the
  * person <-> person attention (two-person model, 3d rows) -- with W' = gamma (.) W of the LayerNorm in front of the Linear,
  * colsum[j] = sum_r float(W'[j][r]), bias' = b + W beta.  With them (and >= 2048 rows) the LayerNorm kernels in front of
@@ -511,9 +511,9 @@ typedef struct hig_gemm16_desc {
   int32_t epi;
   const float* bias;
   const void* res; int64_t ldr; int32_t res_f32;
-  /* LayerNorm folded into the NEXT GEMM (weight-stationary kernel only: >= 2048 rows, R == 512; all NULL otherwise):
-   * row_stats_out (EPI_BIAS_RES, J == 512): also write, per 128-column panel of the bf16-rounded output rows, (sum, sum of
-   * squared deviations from the panel's own mean), [I][4][2] fp32 -- the consumer merges the four panels into the row's
+  /* LayerNorm folded into the NEXT GEMM (weight-stationary kernel only: >= 2048 rows, R == 512 or 1024; all NULL otherwise):
+   * row_stats_out (EPI_BIAS_RES, J == R): also write, per 128-column panel of the bf16-rounded output rows, (sum, sum of
+   * squared deviations from the panel's own mean), [I][J / 128][2] fp32 -- the consumer (R = that J) merges the panels into the row's
    * mean and variance without forming E[x^2] - mean^2, so a large common offset of a row does not cost it its variance.  row_stats_in + ln_colsum (EPI_BIAS): X holds UN-normalised rows whose statistics are in
    * row_stats_in; Y must be W' = bf16(gamma (.) W), ln_colsum[j] = sum_r float(W'[j][r]), bias[j] = b[j] + sum_r beta[r] W[j][r]:
    * C = rstd (X W'^T) - rstd mean ln_colsum + bias  ==  LayerNorm(X) W^T + b  (transformer.py:108-110,144). */

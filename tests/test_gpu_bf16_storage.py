@@ -143,13 +143,14 @@ def test_gemm_ws16_every_variant(I, J, R, epi, nwj, monkeypatch):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("I,J", [(6272, 1536), (12544, 512), (2049, 512), (3000, 1536)])
-def test_layernorm_folded_into_the_weight_stationary_gemm(I, J):
+@pytest.mark.parametrize("I,J,d", [(6272, 1536, 512), (12544, 512, 512), (2049, 512, 512), (3000, 1536, 512),
+                                   (9600, 3072, 1024), (2400, 1024, 1024), (2077, 3072, 1024)])
+def test_layernorm_folded_into_the_weight_stationary_gemm(I, J, d):
     """LayerNorm(x) W^T + b without a LayerNorm kernel (hig_gemm16_desc.row_stats_*): the GEMM that PRODUCES x also writes
     (sum, centred sum of squares) of its bf16 output rows per 128-column panel; the consumer runs on the un-normalised x with
     W' = gamma (.) W and applies rstd / mean / column sums / bias' in its epilogue.  Checked: the statistics against the
-    producer's own output, the consumer against the fp64 LayerNorm + Linear of the same bf16 x (transformer.py:108-110)."""
-    d = 512
+    producer's own output, the consumer against the fp64 LayerNorm + Linear of the same bf16 x (transformer.py:108-110).
+    d = 1024: the K-split variants of the kernel (eight panels per row; the consumer with one staging buffer)."""
     g = torch.Generator().manual_seed(I + J)
     L = _lib.lib()
     # producer: h = a Wo^T + bo + h_old (a stylization-out GEMM), with statistics
@@ -158,7 +159,7 @@ def test_layernorm_folded_into_the_weight_stationary_gemm(I, J):
     hold = bf(torch.randn(I, d, generator=g) * 3 + 1.5)               # (a mean far from zero: the fold must cancel it)
     ad, Wod, bod = a16.to(DEV), Wo.to(DEV), bo.to(DEV)
     h = hold.to(DEV).clone()
-    stats = torch.full((I, 4, 2), float("nan"), device=DEV)
+    stats = torch.full((I, d // 128, 2), float("nan"), device=DEV)
     dsc = _lib.Gemm16Desc()
     dsc.X, dsc.ldx, dsc.Y, dsc.ldy, dsc.C, dsc.ldc, dsc.c_f32 = ad.data_ptr(), d, Wod.data_ptr(), d, h.data_ptr(), d, 0
     dsc.I, dsc.J, dsc.R, dsc.epi, dsc.bias = I, d, d, _lib.EPI_BIAS_RES, bod.data_ptr()
@@ -167,7 +168,7 @@ def test_layernorm_folded_into_the_weight_stationary_gemm(I, J):
     _lib.check(L.hig_gemm_bf16(C.byref(dsc), _lib.stream_ptr()))
     ref_h = a16.double() @ Wo.double().t() + bo.double() + hold.double()
     assert rel(h.float(), ref_h) < 3e-3
-    hp = h.float().double().cpu().view(I, 4, 128)
+    hp = h.float().double().cpu().view(I, d // 128, 128)
     assert rel(stats[:, :, 0], hp.sum(-1)) < 1e-5 and rel(stats[:, :, 1], ((hp - hp.mean(-1, keepdim=True)) ** 2).sum(-1)) < 1e-5
     # consumer: LN(h) W^T + b through the folded operands
     gamma, beta = 1 + 0.2 * torch.randn(d, generator=g), 0.3 * torch.randn(d, generator=g)
