@@ -41,3 +41,34 @@ with torch.no_grad():
 i2 = bench.make_inputs(c2, dev, 0)
 i2["length"] = (torch.arange(64, device=dev) * 7 % 92).long()       # ragged, incl. an empty sample
 soak("two-person, ragged lengths", m2.to(dev), i2)
+
+# bf16 storage (round 4): the training step's own kernels (wgrad16 on the side stream, bf16 row / attention backward, the F-wide
+# edges) and the per-call inference forward with its B-row work on the library's third stream, at config 2 and at the
+# config-5 width (LayerNorm fold at K = 1024: one staging buffer in the K-split GEMM)
+def soak16(name, c, layers=None):
+    cc = dict(c) if layers is None else dict(c, L=layers)
+    m = bench.build_model(cc, dev)
+    bench.set_mode(m, "bf16s")
+    i = bench.make_inputs(cc, dev, 0)
+    i["length"] = (torch.arange(cc["B"], device=dev) * 37 % cc["T"] + 1).long()
+    m.train()
+    ref = None
+    for it in range(n):
+        m.zero_grad(set_to_none=True)
+        out, saved = m._launch_forward(i["x"], i["t"], i["length"], i["xf_proj"], i["xf_out"], training=True)
+        dx, dxp, dxo = m._launch_backward(i["x"], i["t"], i["length"], i["xf_out"], saved, i["x0"], want_dx=True)
+        cur = [out.clone(), dx.clone(), dxp.clone(), dxo.clone(), m.flat_params().grad[:m.flat_params().core_numel].clone()]
+        m.eval(); m.cache_text_context = False
+        with torch.no_grad():
+            cur.append(m(i["x"], i["t"], length=i["length"], xf_proj=i["xf_proj"], xf_out=i["xf_out"]).clone())
+        m.train()
+        if ref is None:
+            ref = cur
+            assert all(torch.isfinite(t.float()).all() for t in cur)
+        else:
+            for k, (a, b) in enumerate(zip(ref, cur)):
+                assert torch.equal(a, b), (name, it, k, (a.float() - b.float()).abs().max().item())
+    print("%s: %d identical iterations" % (name, n))
+
+soak16("bf16 storage, config 2 (training step + per-call inference forward)", bench.CFG)
+soak16("bf16 storage, config-5 width (B=32 T=300 d=1024 H=8, 3 layers)", dict(bench.CFG, B=32, T=300, d=1024, H=8, ff=1024), layers=3)
