@@ -539,56 +539,65 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd16_kernel(
       }
       rstd[u] = rsqrtf(wave_sum(sq) * inv_n + 1e-5f);
     }
-    float4 xh[RPI][NIT], dxh[RPI][NIT];
+    // Packed fp32 arithmetic (v_pk_fma / v_pk_mul / v_pk_add_f32: two elements per issue slot) and the 1-ulp reciprocal in
+    // the SiLU derivative: the kernel is bound by vector instruction issue (~350 instructions per row in the stylization form
+    // with scalar arithmetic and a correctly rounded division), not by its 38-51 MB of traffic
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    v2 xh[RPI][NIT][2], dxh[RPI][NIT][2];
     float s1[RPI], s2[RPI];
 #pragma unroll
     for (int u = 0; u < RPI; ++u) {
-      float t1 = 0.f, t2 = 0.f;
+      v2 t1 = {0.f, 0.f}, t2 = {0.f, 0.f};
+      const v2 rs2 = {rstd[u], rstd[u]}, nm2 = {-mean[u] * rstd[u], -mean[u] * rstd[u]};
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int c = 4 * lane + 256 * it;
-        xh[u][it] = dxh[u][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xh[u][it][0] = xh[u][it][1] = dxh[u][it][0] = dxh[u][it][1] = v2{0.f, 0.f};
         if (c < n && live[u]) {
-          const float xs[4] = {xv[u][it].x, xv[u][it].y, xv[u][it].z, xv[u][it].w}, ds[4] = {dav[u][it].x, dav[u][it].y, dav[u][it].z, dav[u][it].w};
-          const float gs[4] = {g4[it].x, g4[it].y, g4[it].z, g4[it].w};
-          const float bs[4] = {b4[it].x, b4[it].y, b4[it].z, b4[it].w};
-          const float scs[4] = {sc4[it].x, sc4[it].y, sc4[it].z, sc4[it].w};
-          const float shs[4] = {sh4[it].x, sh4[it].y, sh4[it].z, sh4[it].w};
-          float xho[4], dxo[4], dgo[4], dbo[4], dsco[4], dsho[4];
+          const v2 xs[2] = {{xv[u][it].x, xv[u][it].y}, {xv[u][it].z, xv[u][it].w}};
+          const v2 ds[2] = {{dav[u][it].x, dav[u][it].y}, {dav[u][it].z, dav[u][it].w}};
+          const v2 gs[2] = {{g4[it].x, g4[it].y}, {g4[it].z, g4[it].w}};
+          const v2 bs[2] = {{b4[it].x, b4[it].y}, {b4[it].z, b4[it].w}};
+          const v2 sc1[2] = {{1.0f + sc4[it].x, 1.0f + sc4[it].y}, {1.0f + sc4[it].z, 1.0f + sc4[it].w}};
+          const v2 shs[2] = {{sh4[it].x, sh4[it].y}, {sh4[it].z, sh4[it].w}};
+          v2 dgo[2], dbo[2], dsco[2], dsho[2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float xhat = (xs[e] - mean[u]) * rstd[u];
-            const float nrm = xhat * gs[e] + bs[e];
-            float dn;
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const v2 xhat = __builtin_elementwise_fma(xs[h2], rs2, nm2);
+            const v2 nrm = __builtin_elementwise_fma(xhat, gs[h2], bs[h2]);
+            v2 dn;
             if (MOD_SILU) {
-              const float uu = nrm * (1.0f + scs[e]) + shs[e];
-              const float du = ds[e] * hig_dsilu(uu);
-              dsho[e] = du;
-              dsco[e] = du * nrm;
-              dn = du * (1.0f + scs[e]);
+              const v2 uu = __builtin_elementwise_fma(nrm, sc1[h2], shs[h2]);
+              const v2 w = uu * -1.4426950408889634f;
+              const v2 den = v2{__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])} + 1.0f;
+              const v2 sg = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};         // sigmoid(u)
+              const v2 dsil = sg * __builtin_elementwise_fma(uu, 1.0f - sg, v2{1.0f, 1.0f});          // silu'(u) = s (1 + u (1 - s))
+              const v2 du = ds[h2] * dsil;
+              dsho[h2] = du;
+              dsco[h2] = du * nrm;
+              dn = du * sc1[h2];
             } else {
-              dsho[e] = dsco[e] = 0.f;
-              dn = ds[e];
+              dsho[h2] = dsco[h2] = v2{0.f, 0.f};
+              dn = ds[h2];
             }
-            dgo[e] = dn * xhat;
-            dbo[e] = dn;
-            xho[e] = xhat;
-            dxo[e] = dn * gs[e];
-            t1 += dxo[e];
-            t2 += dxo[e] * xhat;
+            dgo[h2] = dn * xhat;
+            dbo[h2] = dn;
+            const v2 dxo = dn * gs[h2];
+            xh[u][it][h2] = xhat;
+            dxh[u][it][h2] = dxo;
+            t1 += dxo;
+            t2 = __builtin_elementwise_fma(dxo, xhat, t2);
           }
-          xh[u][it] = make_float4(xho[0], xho[1], xho[2], xho[3]);
-          dxh[u][it] = make_float4(dxo[0], dxo[1], dxo[2], dxo[3]);
-          a_dg[it].x += dgo[0]; a_dg[it].y += dgo[1]; a_dg[it].z += dgo[2]; a_dg[it].w += dgo[3];
-          a_db[it].x += dbo[0]; a_db[it].y += dbo[1]; a_db[it].z += dbo[2]; a_db[it].w += dbo[3];
+          a_dg[it].x += dgo[0][0]; a_dg[it].y += dgo[0][1]; a_dg[it].z += dgo[1][0]; a_dg[it].w += dgo[1][1];
+          a_db[it].x += dbo[0][0]; a_db[it].y += dbo[0][1]; a_db[it].z += dbo[1][0]; a_db[it].w += dbo[1][1];
           if (MOD_SILU) {
-            a_dsc[it].x += dsco[0]; a_dsc[it].y += dsco[1]; a_dsc[it].z += dsco[2]; a_dsc[it].w += dsco[3];
-            a_dsh[it].x += dsho[0]; a_dsh[it].y += dsho[1]; a_dsh[it].z += dsho[2]; a_dsh[it].w += dsho[3];
+            a_dsc[it].x += dsco[0][0]; a_dsc[it].y += dsco[0][1]; a_dsc[it].z += dsco[1][0]; a_dsc[it].w += dsco[1][1];
+            a_dsh[it].x += dsho[0][0]; a_dsh[it].y += dsho[0][1]; a_dsh[it].z += dsho[1][0]; a_dsh[it].w += dsho[1][1];
           }
         }
       }
-      s1[u] = t1;
-      s2[u] = t2;
+      s1[u] = t1[0] + t1[1];
+      s2[u] = t2[0] + t2[1];
     }
 #pragma unroll
     for (int u = 0; u < RPI; ++u) {
@@ -598,16 +607,16 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd16_kernel(
 #pragma unroll
     for (int u = 0; u < RPI; ++u) {
       if (!live[u]) continue;
+      const v2 rs2 = {rstd[u], rstd[u]}, ns1 = {-s1[u], -s1[u]}, ns2 = {-s2[u], -s2[u]};
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int c = 4 * lane + 256 * it;
         if (c < n) {
-          float4 o;
-          o.x = rstd[u] * (dxh[u][it].x - s1[u] - xh[u][it].x * s2[u]) + rv[u][it].x;
-          o.y = rstd[u] * (dxh[u][it].y - s1[u] - xh[u][it].y * s2[u]) + rv[u][it].y;
-          o.z = rstd[u] * (dxh[u][it].z - s1[u] - xh[u][it].z * s2[u]) + rv[u][it].z;
-          o.w = rstd[u] * (dxh[u][it].w - s1[u] - xh[u][it].w * s2[u]) + rv[u][it].w;
-          st4g(dx + row[u] * lddx + c, o);
+          const v2 r0 = {rv[u][it].x, rv[u][it].y}, r1 = {rv[u][it].z, rv[u][it].w};
+          // rstd (dxh - s1 - xh s2) + res
+          const v2 o0 = __builtin_elementwise_fma(__builtin_elementwise_fma(xh[u][it][0], ns2, dxh[u][it][0] + ns1), rs2, r0);
+          const v2 o1 = __builtin_elementwise_fma(__builtin_elementwise_fma(xh[u][it][1], ns2, dxh[u][it][1] + ns1), rs2, r1);
+          st4g(dx + row[u] * lddx + c, make_float4(o0[0], o0[1], o1[0], o1[1]));
         }
       }
     }
