@@ -677,6 +677,35 @@ def test_bf16_per_call_text_side_on_the_side_stream_equals_the_cached_form(case)
     del g
 
 
+@pytest.mark.parametrize("storage", ["bf16", "f32"])
+def test_per_call_forward_under_stream_capture_equals_eager(storage):
+    """The per-call forward (text side inside the call) forks its B-row work onto library-owned streams when launched eagerly and
+    must run in order on the capturing stream under hipGraph capture: captured and replayed == eager, bit for bit."""
+    c = CASES16["width16"]
+    m = build(c, storage=storage).eval()
+    m.cache_text_context = False
+    gi = {k: v.to(DEV) for k, v in fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"]).items()}
+
+    def fwd():
+        with torch.no_grad():
+            return m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+
+    ref = fwd().clone()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fwd()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fwd()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.equal(out, ref)
+
+
 def test_config3_bf16_storage_captured_1000_step_loop():
     """BASELINE config 3 as specified: 1000-step p_sample_loop, B=32, T=196, bf16 storage, hipGraph-captured; against the
     eager loop with the noise zeroed on both sides (same kernels in the same order), finite over the whole chain."""
