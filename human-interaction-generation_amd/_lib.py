@@ -34,7 +34,7 @@ SYMBOLS = (
     "hig_layernorm", "hig_gather_rows", "hig_scatter_add_rows", "hig_gather_frames", "hig_recover_joints", "hig_transpose_batch", "hig_linattn_ctx_scratch_floats", "hig_pair_mse",
     "hig_fullattn_fwd_kpad", "hig_eval_encoder_workspace_bytes", "hig_eval_encoder_fwd",
     "hig_clip_adam_lrdev", "hig_shutdown", "hig_gemm_split", "hig_gemm_split_scratch_floats",
-    "hig_gemm_bf16", "hig_gemm_bf16_debug_stamps", "hig_gemm_ws16_debug_stamps", "hig_linattn16_debug_stamps", "hig_cast_bf16", "hig_ln_bf16", "hig_linattn_ctx_bf16", "hig_linattn_apply_bf16",
+    "hig_gemm_bf16", "hig_gemm_bf16_debug_stamps", "hig_gemm_ws16_debug_stamps", "hig_gemm_wsp16_debug_stamps", "hig_linattn16_debug_stamps", "hig_cast_bf16", "hig_ln_bf16", "hig_linattn_ctx_bf16", "hig_linattn_apply_bf16",
     "hig_text_context_bf16", "hig_denoiser_fwd_bf16", "hig_linattn_apply_sty_bf16", "hig_linattn_apply_sty_mm16", "hig_linattn_ctx_mm16", "hig_linattn_apply_sty", "hig_joint_embed_bf16", "hig_joint_embed_bf16_w", "hig_attn_out16", "hig_rows_out16", "hig_weight_frag16", "hig_joint_embed_bf16_scratch_bytes", "hig_fullattn_fwd_bf16", "hig_denoiser_bwd_hooked",
     # round 4: bf16-storage training step
     "hig_text_context_bf16_train", "hig_denoiser_fwd_bf16_train", "hig_denoiser_bwd_bf16", "hig_ln_bwd_bf16",
@@ -81,6 +81,7 @@ class GemmDesc(C.Structure):
         ("pos", C.c_void_p), ("ldpos", C.c_int64), ("T", C.c_int32), ("pos_shift", C.c_int32),
         ("xcolsum", C.c_void_p),
         ("row_stats_out", C.c_void_p), ("row_stats_in", C.c_void_p), ("ln_colsum", C.c_void_p),
+        ("aux", C.c_void_p), ("ldaux", C.c_int64),
     ]
 
 
@@ -94,6 +95,7 @@ class Gemm16Desc(C.Structure):
         ("bias", C.c_void_p),
         ("res", C.c_void_p), ("ldr", C.c_int64), ("res_f32", C.c_int32),
         ("row_stats_out", C.c_void_p), ("row_stats_in", C.c_void_p), ("ln_colsum", C.c_void_p),
+        ("aux", C.c_void_p), ("ldaux", C.c_int64),
     ]
 
 
@@ -162,6 +164,7 @@ def lib():
         L.hig_gemm_bf16.argtypes = [C.POINTER(Gemm16Desc), vp]
         L.hig_gemm_bf16_debug_stamps.argtypes = [vp]
         L.hig_gemm_ws16_debug_stamps.argtypes = [vp]
+        L.hig_gemm_wsp16_debug_stamps.argtypes = [vp]
         L.hig_linattn16_debug_stamps.argtypes = [vp]
         L.hig_cast_bf16.argtypes = [vp, vp, i64, vp]
         L.hig_ln_bf16.argtypes = [vp, i32, i64, i64, i32, vp, vp, vp, i64, i32, i32, vp, i64, vp]

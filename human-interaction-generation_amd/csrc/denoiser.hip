@@ -110,6 +110,7 @@ struct FwdLayout {
   int64_t st6, iqkv, Ai, ksti, y4, st7, a4, h2b;  // two-person interaction attention block
   int64_t xn1, xn2, xn3;  // LayerNorm outputs feeding the q/k/v GEMMs (kept: wgrad operands)
   int64_t cscr2, gtail2;  // second set of per-stream scratch (two-stream forward)
+  int64_t gtail3;         // split-tail scratch of the text side when it runs on the third stream (hig_denoiser_fwd_text)
   int64_t lnstats;        // LayerNorm fold (inference): (sum, centred sum of squares) per row and 64-column panel of the residual stream
   int64_t total;
 };
@@ -127,6 +128,7 @@ FwdLayout fwd_layout(const Dims& D, int training) {
   w.gtail = take(HIG_GEMM_TAIL_BYTES / 4);   // split tail of the fp32 GEMMs (hig_gemm_set_tail_scratch)
   w.cscr2 = take(hig_linattn_ctx_scratch_floats(D.B, D.T, D.H, D.hd));
   w.gtail2 = take(HIG_GEMM_TAIL_BYTES / 4);
+  w.gtail3 = take(HIG_GEMM_TAIL_BYTES / 4);
   w.lnstats = take(training ? 0 : D.M * (D.d / 64 + 1) * 2);
   w.layer0 = o;
   o = 0;
@@ -456,6 +458,19 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
   // run on a third stream next to the first layers, one event per layer (events only: eager launches; under capture, or
   // without the library's streams, they run first on the caller's stream as hig_text_context would).
   hipEvent_t* text_ev = nullptr;
+  // Whatever the text fork has enqueued on the third stream is joined back into `st` on every exit that does not reach the
+  // last layer's own wait (the caller recycles `textctx` / `xf_out` as soon as `st` gets there): disarmed on success.
+  struct TextJoin {
+    hipStream_t s3 = nullptr, st = nullptr;
+    hipEvent_t ev = nullptr;
+    bool armed = false;
+    void arm(hipStream_t s3_, hipEvent_t ev_, hipStream_t st_) { s3 = s3_; ev = ev_; st = st_; armed = true; }
+    ~TextJoin() {
+      if (!armed) return;
+      (void)hipEventRecord(ev, s3);
+      (void)hipStreamWaitEvent(st, ev, 0);
+    }
+  } text_join;
   if (xf_out_for_text) {
     static const int text_fork = getenv("HIG_TEXT_FORK") ? atoi(getenv("HIG_TEXT_FORK")) : 1;   // tuning knob
     SideStream* ts = (text_fork && D.L <= kMaxTextLayers) ? side_stream_for_current_device(st) : nullptr;
@@ -464,14 +479,18 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
       if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) ts = nullptr;
     }
     if (ts) {
+      // The text side's key/value GEMMs run NEXT TO the GEMMs on `st`: they get a split-tail scratch of their own (tickets and
+      // partial sums shared between two concurrent launches would hand a workgroup another GEMM's "last arriver" ticket or
+      // slices: B = 32, N = 77 text rows qualify for the split tail just like the q/k/v launch beside them).
+      if (hipMemsetAsync(ws + w.gtail3, 0, HIG_GEMM_TAIL_CNT_BYTES, st) != hipSuccess)
+        return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
       if (hipEventRecord(ts->ready, st) != hipSuccess || hipStreamWaitEvent(ts->s3, ts->ready, 0) != hipSuccess)
         return hig_set_error(HIG_EHIP, "text fork failed");
+      hig_gemm_set_tail_scratch(ws + w.gtail3, HIG_GEMM_TAIL_BYTES);
       const int rc = text_context_impl(D, params, xf_out_for_text, const_cast<void*>(textctx), training, ts->s3, ts->text_done);
-      if (rc != HIG_OK) {   // whatever was enqueued on the text stream is joined before the error leaves
-        (void)hipEventRecord(ts->text_done[0], ts->s3);
-        (void)hipStreamWaitEvent(st, ts->text_done[0], 0);
-        return rc;
-      }
+      hig_gemm_set_tail_scratch(ws + w.gtail, HIG_GEMM_TAIL_BYTES);
+      text_join.arm(ts->s3, ts->text_done[0], st);   // every error exit below joins the text stream first
+      if (rc != HIG_OK) return rc;
       text_ev = ts->text_done;
     } else {
       HIG_TRY(text_context_impl(D, params, xf_out_for_text, const_cast<void*>(textctx), training, st, nullptr));
@@ -697,6 +716,7 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
     hig_gemm_set_tail_scratch(ws + w.gtail, HIG_GEMM_TAIL_BYTES);
     if (hipEventRecord(side->done[0], side->s2) != hipSuccess || hipStreamWaitEvent(st, side->done[0], 0) != hipSuccess)
       return rc != HIG_OK ? rc : hig_set_error(HIG_EHIP, "forward join failed");
+    if (rc == HIG_OK) text_join.armed = false;   // (both halves waited for the last layer's text event)
     return rc;
   }
   for (int l = 0; l < D.L; ++l) {
@@ -707,6 +727,7 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
   if (D.two)  // init-pose rows go through out2 instead (:613-614)
     HIG_TRY(hig_gemm_launch(G(hin, (int64_t)D.T * d, 0, P(params, HIG_P_OUT2_W), d, 0, out, (int64_t)D.T * D.F, D.B, D.F, d)
                                 .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT2_B)).g, 1, nullptr, st));
+  text_join.armed = false;
   return HIG_OK;
 }
 

@@ -805,6 +805,11 @@ int hig_gemm16_launch(const hig_gemm16_desc& g, hipStream_t st) {
               "hig_gemm_bf16: operands must be 16-byte aligned with leading dimensions that are multiples of 8");
   if (epi_has_bias(g.epi)) HIG_REQUIRE(g.bias, "hig_gemm_bf16: epilogue %d needs a bias", g.epi);
   if (epi_has_res(g.epi)) HIG_REQUIRE(g.res, "hig_gemm_bf16: epilogue %d needs `res`", g.epi);
+  {   // many rows, K = 512: the weight-stationary kernel with specialised waves (gemm_wsp16.hip)
+    const int rc = hig_gemm_wsp16_try(g, st);
+    if (rc <= 0) return rc;
+    if (g.aux) return hig_set_error(HIG_EUNSUPPORTED, "hig_gemm_bf16: `aux` (pre-activation output) on a shape gemm_wsp16 does not serve");
+  }
   {   // many rows, short reduce range: the weight-stationary kernel (gemm_ws16.hip) when it serves the shape
     const int rc = hig_gemm_ws16_try(g, st);
     if (rc <= 0) return rc;

@@ -34,6 +34,8 @@ int hig_wgrad16_launch(const void* dC, int64_t ldd, const void* act, int64_t ldx
 int hig_reduce_slabs(const float* slabs, int splits, int64_t slab, int64_t n, float* out, hipStream_t st);
 // weight-stationary variant (gemm_ws16.hip): HIG_OK = launched, 1 = shape not served (use the tiled kernel), < 0 = error
 int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st);
+// weight-stationary kernel with specialised matrix / service waves (gemm_wsp16.hip: K = 512, J % 128 == 0, >= 2048 rows); same codes
+int hig_gemm_wsp16_try(const hig_gemm16_desc& g, hipStream_t st);
 // the shape class the 256 x 256 tiled bf16 kernel serves better than the weight-stationary one (gemm_ws16.hip, gemm_bf16.hip)
 inline bool hig_gemm16_wide_k1024(const hig_gemm16_desc& g) {
   // opt-in: alone (tools/gemm16_bench.py 32 cfg5) the 256 x 256 tile wins the q/k/v shape of the d = 1024 model 77 against 89 us,

@@ -520,6 +520,9 @@ typedef struct hig_gemm16_desc {
   float* row_stats_out;
   const float* row_stats_in;
   const float* ln_colsum;
+  /* EPI_BIAS_GELU only (nullable): the pre-activation acc + bias as bf16 as well, from the same launch -- FFN linear1 of the
+   * training forward keeps both z and gelu(z) (transformer.py:168).  16-byte aligned, ldaux % 8 == 0. */
+  void* aux; int64_t ldaux;
 } hig_gemm16_desc;
 int hig_gemm_bf16(const hig_gemm16_desc* g, hig_stream_t stream);
 /* hig_gemm_bf16 with the reduce range split over `splits` fp32 slabs and a deterministic (fixed-order) slab reduction: how
@@ -534,6 +537,7 @@ int hig_gemm_bf16_split(const hig_gemm16_desc* g, int32_t splits, float* slabs, 
  * global state besides what hig_shutdown() releases; it is NULL unless a tool sets it, and is never set during a timed run. */
 int hig_gemm_bf16_debug_stamps(void* buf);
 int hig_gemm_ws16_debug_stamps(void* buf);
+int hig_gemm_wsp16_debug_stamps(void* buf);   /* gemm_wsp16.hip: buf[block * 16 + k], 256 blocks */
 /* the same for hig_linattn_apply_sty_mm16: 8 stamps per workgroup (see linattn16.hip) */
 int hig_linattn16_debug_stamps(void* buf);
 /* dst[i] = bf16(src[i]) (round to nearest even): builds the bf16 shadow of the flat fp32 parameter buffer. */
