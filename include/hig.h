@@ -538,6 +538,7 @@ int hig_gemm_bf16_split(const hig_gemm16_desc* g, int32_t splits, float* slabs, 
 int hig_gemm_bf16_debug_stamps(void* buf);
 int hig_gemm_ws16_debug_stamps(void* buf);
 int hig_gemm_wsp16_debug_stamps(void* buf);   /* gemm_wsp16.hip: buf[block * 16 + k], 256 blocks */
+int hig_wgrad16_debug_stamps(void* buf);      /* wgrad16.hip (see there): 8192 x 8 bytes */
 /* the same for hig_linattn_apply_sty_mm16: 8 stamps per workgroup (see linattn16.hip) */
 int hig_linattn16_debug_stamps(void* buf);
 /* dst[i] = bf16(src[i]) (round to nearest even): builds the bf16 shadow of the flat fp32 parameter buffer. */

@@ -396,15 +396,14 @@ def test_attention_output_projection_fused_into_the_apply_kernel(B, T, with_stat
                                 _lib.ptr(Wf), _lib.ptr(bias), _lib.ptr(h), d, _lib.ptr(st) if with_stats else None, B, T, H, hd,
                                 _lib.stream_ptr()))
     assert torch.isfinite(h.float()).all()
-    if M >= 2048:       # the weight-stationary kernel: same accumulation order, so the same bits
-        assert torch.equal(h, h_ref)
-    else:               # (the tiled kernel adds its bias after the products: equal up to the last rounding)
-        assert (h != h_ref).float().mean().item() < 0.02 and rel(h.float(), h_ref.float()) < 2e-3
+    # (the stand-alone GEMM -- gemm_wsp16.hip from 2048 rows up, else the tiled kernel -- sums the products of a row in another
+    # order than the fused kernel and adds its bias after them: equal up to the last rounding, not bit for bit)
+    assert (h != h_ref).float().mean().item() < 0.02 and rel(h.float(), h_ref.float()) < 2e-3
     if with_stats:
         hp = h.float().double().cpu().view(M, 4, 128)
         assert rel(st[:, :, 0], hp.sum(-1)) < 1e-5 and rel(st[:, :, 1], ((hp - hp.mean(-1, keepdim=True)) ** 2).sum(-1)) < 1e-5
-        if M >= 2048:
-            assert torch.equal(st, st_ref)
+        if M >= 2048:   # the stand-alone GEMM's statistics describe ITS rounded rows: close, not identical
+            assert rel(st, st_ref) < 5e-3
 
 
 @pytest.mark.parametrize("B,T", [(32, 196), (5, 91), (3, 1), (64, 50)])
