@@ -729,5 +729,9 @@ bool hig_gemm_ws16_lnfold_ok(int64_t rows, int d) {
   static const int min_rows = getenv("HIG_BF16_WS_ROWS") ? atoi(getenv("HIG_BF16_WS_ROWS")) : 2048;
   static const int forced_nwj = getenv("HIG_BF16_WS_NWJ") ? atoi(getenv("HIG_BF16_WS_NWJ")) : 0;
   static const int on1024 = getenv("HIG_LNFOLD1024") ? atoi(getenv("HIG_LNFOLD1024")) : 1;   // tuning knob
-  return on && ws_on && !forced_nwj && (d == 512 || (d == 1024 && on1024)) && rows >= min_rows;
+  // the same predicates as hig_gemm_ws16_try / hig_gemm_wsp16_try, so that a fold is only chosen where one of those kernels will
+  // accept it (they turn a decline into an error once fold operands are present): the 8 x 32 chip geometry their work split
+  // is compiled for, and the 32-bit byte offsets of their DMA descriptors for the widest consumer (q/k/v: 3 d columns)
+  return on && ws_on && !forced_nwj && (d == 512 || (d == 1024 && on1024)) && rows >= min_rows && hig_chip_cus() == 256 &&
+         rows * (int64_t)3 * d < (1ll << 30);
 }

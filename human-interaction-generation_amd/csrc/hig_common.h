@@ -77,6 +77,9 @@ __device__ __forceinline__ float row16_max(float v) {
   v = fmaxf(v, hig_dpp<0x140, 0xf>(v, v));
   return v;
 }
+// PRECONDITION of wave_sum / wave_max: all 64 lanes of the wave are active (the row_bcast steps and the v_readlane of lane 63
+// read lanes that an EXEC mask would have left unwritten; the __shfl_xor form they replaced saw zeros there).  Every caller
+// runs whole waves; a kernel that calls them under a divergent branch or with a block size that is not a multiple of 64 is wrong.
 __device__ __forceinline__ float wave_sum(float v) {
   v = row16_sum(v);
   v += hig_dpp<0x142, 0xa>(0.f, v);    // row_bcast:15 into rows 1 and 3

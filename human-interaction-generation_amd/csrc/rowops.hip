@@ -901,6 +901,8 @@ extern "C" int hig_ln_bwd_bf16(const void* da, int64_t ldda, const void* x, int3
                 reinterpret_cast<uintptr_t>(res)) & 7) == 0, "hig_ln_bwd_bf16: 8-byte aligned rows");
   HIG_REQUIRE(rows_per_sample > 0 && rows % rows_per_sample == 0, "hig_ln_bwd_bf16: rows %% rows_per_sample");
   HIG_REQUIRE(!mod_silu || (ss && dss), "hig_ln_bwd_bf16: modulation needs ss / dss");
+  // (the parameter gradients are reduced as a pair: one pointer alone would return HIG_OK and leave that gradient unwritten)
+  HIG_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "hig_ln_bwd_bf16: dgamma and dbeta must both be given or both be NULL");
   if (mod_silu && (x_f32 || dx_f32))
     return hig_set_error(HIG_EUNSUPPORTED, "hig_ln_bwd_bf16: the stylization form is built for bf16 rows only");
   if (rows == 0) return HIG_OK;

@@ -36,6 +36,55 @@ def build(c, **kw):
     return m.to(DEV)
 
 
+def test_config2_size_bf16_storage_backward_every_gradient_against_oracle_autograd():
+    """The bf16-storage training forward + backward at BASELINE config 2 itself (B=64, T=196, d=512, L=8: 12 544 rows -- the
+    row count at which the weight-gradient kernel runs sixteen row slices per tile and the weight-stationary GEMMs their
+    full-size work split), EVERY parameter gradient (329 tensors at L = 8) and the three input gradients against torch autograd of the fp32 CPU
+    oracle.  Same gates as tests/test_gpu_bf16_training.py (which stops at 3 136 rows): loss 1e-2, global gradient norm 2e-2,
+    direction of the whole gradient 1 - 1e-3, median tensor 3e-2, no tensor beyond 0.15 (trainers/ddpm_trainer.py:172-187)."""
+    c = CONFIG2
+    m = build(c, storage="bf16").train()
+    inp = fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"])
+    gi = {k: v.to(DEV) for k, v in inp.items()}
+    target = fill.tensor_for("full.target", inp["x"].shape) * 10.0
+    x, xp, xo = (gi[k].clone().requires_grad_(True) for k in ("x", "xf_proj", "xf_out"))
+    out = m(x, gi["t"], length=gi["length"], xf_proj=xp, xf_out=xo)
+    mask = m.generate_src_mask(c["T"], gi["length"]).to(DEV)
+    loss = (((out - target.to(DEV)) ** 2).mean(-1) * mask).sum() / mask.sum()
+    loss.backward()
+    names = fill.core_param_shapes(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"])
+    p = {k: v.clone().requires_grad_(True) for k, v in
+         fill.core_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"]).items()}
+    xr, xpr, xor_ = (inp[k].clone().requires_grad_(True) for k in ("x", "xf_proj", "xf_out"))
+    ref = R.denoiser_forward(p, xr, inp["t"], inp["length"], xpr, xor_, c["H"], c["L"])
+    ref_loss = D.masked_mse(ref, target, R.src_mask(c["T"], inp["length"]))
+    ref_loss.backward()
+    named = dict(m.named_parameters())
+    e_out = rel(out, ref)
+    assert 1e-4 < e_out < 3e-2, e_out                       # the bf16 path really ran, at the bf16 level
+    assert abs(loss.item() - ref_loss.item()) < 1e-2 * abs(ref_loss.item())
+    zero_grad = [k for k in names if k.endswith(".key.bias")]          # exactly zero in the reference (softmax over tokens)
+    live = [k for k in names if k not in zero_grad]
+    for k in live:
+        assert named[k].grad is not None and torch.isfinite(named[k].grad).all(), k
+    gn = torch.sqrt(sum((named[k].grad.double() ** 2).sum() for k in live)).item()
+    gn_ref = torch.sqrt(sum((p[k].grad.double() ** 2).sum() for k in live)).item()
+    dot = sum((named[k].grad.double().cpu() * p[k].grad.double()).sum() for k in live).item()
+    errs = sorted(((rel(named[k].grad, p[k].grad), k) for k in live), reverse=True)
+    print("bf16-storage backward at config 2: out %.2e, loss %.6f vs %.6f, grad norm %.6e vs %.6e (rel %.2e), cosine %.6f" %
+          (e_out, loss.item(), ref_loss.item(), gn, gn_ref, abs(gn - gn_ref) / gn_ref, dot / (gn * gn_ref)))
+    print("   worst tensors: " + ", ".join("%s %.2e" % (k, e) for e, k in errs[:5]))
+    print("   median rel-L2 over %d tensors: %.2e" % (len(errs), errs[len(errs) // 2][0]))
+    assert abs(gn - gn_ref) < 2e-2 * gn_ref, (gn, gn_ref)
+    assert dot / (gn * gn_ref) > 1 - 1e-3
+    assert errs[0][0] < 0.15, errs[0]                       # no tensor is garbage / unwritten
+    assert errs[len(errs) // 2][0] < 3e-2
+    for a, b in ((x.grad, xr.grad), (xp.grad, xpr.grad), (xo.grad, xor_.grad)):
+        assert rel(a, b) < 5e-2
+    for k in zero_grad:
+        assert named[k].grad.norm().item() < 2e-2 * gn_ref, k
+
+
 def test_config2_size_backward_against_oracle_autograd():
     """B=64, T=196, d=512, L=8, ragged lengths: loss = masked MSE against a fixed target (the training loss,
     ddpm_trainer.py:172-178); every gradient the product computes at this size comes from 16-32 split-R slabs on two
