@@ -533,7 +533,7 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
   // 83.8 against 71.1 us at head dim 128, forward 6.24 against 6.26 ms -- the fused kernel's fp32 MFMAs and its
   // LayerNorm / SiLU arithmetic share the SIMD lanes and a workgroup's chain (load, 2 heads, statistics, epilogue,
   // store) is 26K cycles long with two workgroups per CU to hide it (profiles/r02_notes.md section 9)
-  static const int fuse_env = getenv("HIG_FUSE_APPLY_F32") ? atoi(getenv("HIG_FUSE_APPLY_F32")) : 0;   // tuning knob
+  constexpr int fuse_env = 0;   // (a former tuning knob, fixed at the value that won its A/B)
   const bool fuse_apply = fuse_env && !training && !D.full && (D.H == 4 || D.H == 8) && (D.hd == 64 || D.hd == 128);
   // One decoder layer for the samples [b0, b0 + nb) on stream `s` (every kernel of a layer is row- or sample-local, so a
   // batch range is a pointer offset).  `hin` / the returned pointer are the FULL-batch residual stream of the layer.
@@ -1844,7 +1844,7 @@ extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* pa
   // dW[n][k] = sum_m dC[m][n] act[m][k] (+ the bias gradient = column sums of dC): both operands transposed to
   // reduce-contiguous bf16 (n_out x Mp), (k_in x Mp), then the split-R bf16 GEMM into the fp32 gradient.  Everything on the
   // weight-gradient stream (protocol: WgradFork).
-  static const int wg16 = getenv("HIG_WG16") ? atoi(getenv("HIG_WG16")) : 1;   // tuning knob: 0 = transposes + tiled split-R GEMM
+  constexpr int wg16 = 1;   // (a former tuning knob, fixed at the value that won its A/B): 0 = transposes + tiled split-R GEMM
   auto wgrad_act = [&](const void* dC, int n_out, const void* act, int k_in, float* out, int64_t rows, int64_t rows_p, float* dbias) -> int {
     HIG_TRY(fork.begin());
     if (wg16) {   // straight from the row-major operands (transpose reads), bias gradient in the same pass
@@ -1909,7 +1909,7 @@ extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* pa
   auto up256 = [](int64_t v) { return (v + 255) / 256 * 256; };
   const int64_t e_dout = 0, e_x = e_dout + up256(M * Fp * 2), e_wot = e_x + up256(M * Fp * 2), e_dwo = e_wot + up256((int64_t)d * Fp * 2),
                 e_dwj = e_dwo + up256((int64_t)Fp * d * 4), e_dbo = e_dwj + up256((int64_t)d * Fp * 4), e_end = e_dbo + up256((int64_t)Fp * 4);
-  const bool edge16 = edge16_env && wg16 && d % 8 == 0 && e_end <= M * d * 4 && M * (int64_t)Fp < (1ll << 30);
+  const bool edge16 = edge16_env && d % 8 == 0 && e_end <= M * d * 4 && M * (int64_t)Fp < (1ll << 30);
   char* edgeb = reinterpret_cast<char*>(f32a);
   // weight gradient on wgrad16 into a padded scratch, then the real rows / columns into the gradient (weight-gradient stream)
   auto wgrad_edge = [&](const void* dC, int n_out, const void* act, int k_in, float* scratch, float* sbias, float* out, int out_rows, int out_cols,

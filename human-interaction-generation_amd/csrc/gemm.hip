@@ -226,7 +226,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(const KArgs a) {
     j0 = (tile % a.nbj) * BJ;
   };
   float* __restrict__ C = g.C + (int64_t)split * a.slab;
-  typedef int gi32x4 __attribute__((ext_vector_type(4)));
+  typedef int gi32x4 [[maybe_unused]] __attribute__((ext_vector_type(4)));
   [[maybe_unused]] __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(C, 0, a.store_policy ? (int)((((int64_t)g.I - 1) * g.ldc + g.J) * 4) : 0, 0x00020000);
   __shared__ unsigned s_ticket;
   int nth = 0;    // tiles this workgroup has started
@@ -925,9 +925,9 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
   a.stamps = g_gemm_stamps;
   a.xsum = nullptr;
   a.xsum_stride = 0;
-  static const int epi_flags = getenv("HIG_GEMM_EPI") ? atoi(getenv("HIG_GEMM_EPI")) : 0;   // tuning knob
+  constexpr int epi_flags = 0;   // (a former tuning knob, fixed at the value that won its A/B)
   a.epi_flags = epi_flags;
-  static const int store_policy = getenv("HIG_GEMM_STORE") ? atoi(getenv("HIG_GEMM_STORE")) : 0;   // tuning knob
+  constexpr int store_policy = 0;   // (a former tuning knob, fixed at the value that won its A/B)
   a.store_policy = (store_policy && splits == 1 && (((int64_t)g.I - 1) * g.ldc + g.J) * 4 < (1ll << 31) && g.res != g.C) ? store_policy : 0;
   const int nbi = (g.I + BI - 1) / BI;
   a.nbj = (g.J + BJ - 1) / BJ;
@@ -970,7 +970,7 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
   per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
   const int max_vgpr_blocks = (BI * BJ >= 128 * 128) ? 2 : 4;   // 128x128: <=256 VGPRs -> 2 waves/SIMD
   if (per_cu > max_vgpr_blocks) per_cu = max_vgpr_blocks;
-  static const int forced_per_cu = getenv("HIG_GEMM_PERCU") ? atoi(getenv("HIG_GEMM_PERCU")) : -1;  // tuning knob
+  constexpr int forced_per_cu = -1;  // (a former tuning knob, fixed at the value that won its A/B)
   if (forced_per_cu > 0) per_cu = forced_per_cu;
   const bool fast = a.vecx && a.vecy && (g.R % BK == 0) && g.R > 0 &&
                     (!X_RS || (g.I % 4 == 0 && g.I >= 4)) && (!Y_RS || (g.J % 4 == 0 && g.J >= 4));
@@ -1066,7 +1066,7 @@ int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab,
   // model's shapes -- B = 32 / 64 forwards, tools/fwd_time.py with HIG_GEMM_TILE forced: 4.07 / 6.90 ms against
   // 4.19-4.67 / 7.5-7.6 ms -- the round-counting model above mis-ranks them by a few per cent, so it only
   // breaks ties for shapes with at most one tile per CU
-  static const int f32_rule = getenv("HIG_F32_TILE_RULE") ? atoi(getenv("HIG_F32_TILE_RULE")) : 1;   // tuning knob
+  constexpr int f32_rule = 1;   // (a former tuning knob, fixed at the value that won its A/B)
   if (!bf && forced < 0 && f32_rule) {
     const int64_t t64 = (int64_t)((g.I + 63) / 64) * ((g.J + 63) / 64);
     if (t64 > ncu) best = 3;
@@ -1075,7 +1075,7 @@ int launch_sized(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab,
     // bf16 products: the MFMA part is short, so per-tile latency and the number of workgroups in flight decide.
     // Measured (tools/fwd_time.py, B = 32 / 64): mixed 64x128 / 128x64 tiles are the worst choice, 128x128 wins
     // once it yields enough tiles to occupy the chip, 64x64 below that.
-    static const int thr = getenv("HIG_BF_THR") ? atoi(getenv("HIG_BF_THR")) : 300;   // tuning knob
+    constexpr int thr = 300;   // (a former tuning knob, fixed at the value that won its A/B)
     const int64_t t128 = (int64_t)((g.I + 127) / 128) * ((g.J + 127) / 128);
     best = t128 >= thr ? 0 : 3;
   }

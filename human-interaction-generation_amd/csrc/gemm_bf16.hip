@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(const K16Arg
 
 template <int WM, int WN, int TI, int TJ, int BK, int NS, int EPI>
 int launch16(const hig_gemm16_desc& g, hipStream_t st, int splits = 1, int64_t slab = 0) {
-  static const int use_srd = getenv("HIG_BF16_SRD") ? atoi(getenv("HIG_BF16_SRD")) : 1;   // tuning knob: 0 = global_load_lds
+  constexpr int use_srd = 1;   // (a former tuning knob, fixed at the value that won its A/B): 0 = global_load_lds
   constexpr int NT = 64 * WM * WN, BM = 32 * TI * WM, BN = 32 * TJ * WN;
   K16Args a;
   a.g = g;
@@ -355,7 +355,7 @@ int launch16(const hig_gemm16_desc& g, hipStream_t st, int splits = 1, int64_t s
   constexpr int lds = NS * (BM + BN) * BK * 2;
   int per_cu = 160 * 1024 / (lds > 64 * (BN + 4) * 4 ? lds : 64 * (BN + 4) * 4);
   if (per_cu > 4) per_cu = 4;
-  static const int forced_per_cu = getenv("HIG_BF16_PERCU") ? atoi(getenv("HIG_BF16_PERCU")) : 0;   // tuning knob
+  constexpr int forced_per_cu = 0;   // (a former tuning knob, fixed at the value that won its A/B)
   if (forced_per_cu > 0) per_cu = forced_per_cu;
   static const int dbg = getenv("HIG_BF16_DBG") ? atoi(getenv("HIG_BF16_DBG")) : 0;
   a.dbg = g_stamps ? dbg : (dbg & ~16);
@@ -413,13 +413,13 @@ int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
   // two workgroups per CU) hides it: stylization-out 14.9 -> 12.8 us, FFN linear2 21.4 -> 18.2 us, config-3 forward
   // 1.515 -> 1.409 ms (B = 64: 2.30 -> 2.28 ms).  Not for K = 256 (4 k-tiles: 8.8 -> 15.4 us) and not for the 128-row
   // tile (96 KB = one workgroup per CU: FFN linear1 20.6 -> 24.2 us).  HIG_BF16_RING3=0 switches it off.
-  static const int ring3 = getenv("HIG_BF16_RING3") ? atoi(getenv("HIG_BF16_RING3")) : 1;   // tuning knob
+  constexpr int ring3 = 1;   // (a former tuning knob, fixed at the value that won its A/B)
   if (ring3 && pick == 64 && g.R % 64 == 0 && g.R >= 512) return launch16<1, 4, 2, 1, 64, 3, EPI>(g, st);
   // 128 x 128 tiles over several rounds (M >= 8192: every launch of the B = 64 forward): four stages of BK = 32 (the
   // same 64 KB) keep one more k-tile in flight than two of BK = 64: B = 64 forward 2.308 -> 2.261 ms (q/k/v 44.2 ->
   // 41.8 us); at M = 6272, where these launches are single partly filled rounds, it is neutral to slightly slower
   // (1.425 -> 1.435 ms), so the rule is on the row count.  HIG_BF16_RING4_ROWS moves the threshold (0 = never).
-  static const int ring4_rows = getenv("HIG_BF16_RING4_ROWS") ? atoi(getenv("HIG_BF16_RING4_ROWS")) : 8192;   // tuning knob
+  constexpr int ring4_rows = 8192;   // (a former tuning knob, fixed at the value that won its A/B)
   if (ring4_rows > 0 && pick == 128 && g.I >= ring4_rows && g.R >= 512) return launch16<2, 2, 2, 2, 32, 4, EPI>(g, st);
   if (g.R % 64 == 0) {
     if (pick == 256) return launch16<2, 4, 4, 2, 64, 2, EPI>(g, st);
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void gemm_fewrow16_lds_kernel(const hig_gemm16
 
 template <int EPI>
 int launch_fewrow16(const hig_gemm16_desc& g, hipStream_t st) {
-  static const int lds_on = getenv("HIG_BF16_FEWROW_LDS") ? atoi(getenv("HIG_BF16_FEWROW_LDS")) : 1;   // tuning knob
+  constexpr int lds_on = 1;   // (a former tuning knob, fixed at the value that won its A/B)
   if (lds_on && g.R % 256 == 0) {               // operands through wave-private LDS rings
     if (g.I <= 32) hipLaunchKernelGGL((gemm_fewrow16_lds_kernel<1, EPI>), dim3(g.J / 32), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((gemm_fewrow16_lds_kernel<2, EPI>), dim3(g.J / 32), dim3(256), 0, st, g);

@@ -578,26 +578,12 @@ int launch_ws(const hig_gemm16_desc& g, int slots_per_xcd, hipStream_t st) {
   // output stores write through (`sc1`): a launch's 13-39 MB of output otherwise sit dirty in the XCDs' L2s until the
   // end-of-kernel write-back, during which nothing runs (same-call A/B at M = 12 544: FFN linear1 25.9 -> 23.4 us, q/k/v 28.5
   // -> 26.4, stylization-out 16.2 -> 15.0; forward B = 64 1.570 -> 1.537 ms; `nt` = 2 is mixed: ca-q 12.6 but FFN linear1 26.9)
-  static const int store_policy = getenv("HIG_WS16_STORE") ? atoi(getenv("HIG_WS16_STORE")) : 1;   // tuning knob
+  constexpr int store_policy = 1;   // (a former tuning knob, fixed at the value that won its A/B)
   // in-place residual updates (C aliases res: the inference forward's residual stream) keep plain stores: a later tile's
   // residual DMA must see this kernel's own earlier stores in the same L2
   a.store_policy = (g.res && g.res == g.C) ? 0 : store_policy;
-  static const int store_slack = getenv("HIG_WS16_SLACK") ? atoi(getenv("HIG_WS16_SLACK")) : 0;   // tuning knob
+  constexpr int store_slack = 0;   // (a former tuning knob, fixed at the value that won its A/B)
   a.store_slack = store_slack;
-  static const int dbg = getenv("HIG_BF16_WS_DBG") ? atoi(getenv("HIG_BF16_WS_DBG")) : 0;   // timing ablations (diagnostic instances only)
-  if constexpr (KW == 512 && KSPLIT == 1 && NWJ == 4 && NCB == 2 && EPI == HIG_EPI_BIAS_GELU) {
-    const dim3 gr(8 * slots_per_xcd), bl(64 * NWJ * KSPLIT);
-    switch (dbg) {
-      case 1: hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 1>), gr, bl, 0, st, a); HIG_CHECK_LAUNCH(); return HIG_OK;
-      case 2: hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 2>), gr, bl, 0, st, a); HIG_CHECK_LAUNCH(); return HIG_OK;
-      case 4: hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 4>), gr, bl, 0, st, a); HIG_CHECK_LAUNCH(); return HIG_OK;
-      case 8: hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 8>), gr, bl, 0, st, a); HIG_CHECK_LAUNCH(); return HIG_OK;
-      case 3: hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 3>), gr, bl, 0, st, a); HIG_CHECK_LAUNCH(); return HIG_OK;
-      case 14: hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 14>), gr, bl, 0, st, a); HIG_CHECK_LAUNCH(); return HIG_OK;
-      case 15: hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 15>), gr, bl, 0, st, a); HIG_CHECK_LAUNCH(); return HIG_OK;
-      default: break;
-    }
-  }
   hipLaunchKernelGGL((gemm_ws16_kernel<KW, KSPLIT, NWJ, NCB, EPI, 0, OCC, XT>), dim3(8 * slots_per_xcd), dim3(64 * NWJ * KSPLIT), 0, st, a);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
@@ -690,7 +676,7 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
   if (g.epi == HIG_EPI_BIAS_GELU && g.R != 1024) nwj = 44;
   // residual epilogues at K = 512: two workgroups per CU from 8 192 rows up (same-call A/B, forward: B = 64 1.630 -> 1.613 ms,
   // B = 512 8.72 -> 8.55 ms; B = 32 1.056 -> 1.066: the 3-4 tiles of a workgroup there are too few to share a CU)
-  static const int res44 = getenv("HIG_BF16_WS_RES44") ? atoi(getenv("HIG_BF16_WS_RES44")) : 8192;   // tuning knob: rows from which ... (0 = never)
+  constexpr int res44 = 8192;   // (a former tuning knob, fixed at the value that won its A/B): rows from which ... (0 = never)
   if (has_res_epi(g.epi) && g.R == 512 && res44 > 0 && g.I >= res44) nwj = 44;
   else if (g.row_stats_out) nwj = 4;            // (the statistics are per 128-column panel)
   if (g.row_stats_out) { if (forced_nwj == 44) nwj = 44; }

@@ -40,7 +40,7 @@ int hig_gemm_wsp16_try(const hig_gemm16_desc& g, hipStream_t st);
 inline bool hig_gemm16_wide_k1024(const hig_gemm16_desc& g) {
   // opt-in: alone (tools/gemm16_bench.py 32 cfg5) the 256 x 256 tile wins the q/k/v shape of the d = 1024 model 77 against 89 us,
   // inside the forward it does not (config-5 forward 4.61-4.64 against 4.57 ms, same call)
-  static const int on = getenv("HIG_BF16_WIDE256") ? atoi(getenv("HIG_BF16_WIDE256")) : 0;   // tuning knob
+  constexpr int on = 0;   // (a former tuning knob, fixed at the value that won its A/B)
   return on && g.R == 1024 && g.J >= 2048 && g.J % 256 == 0 && g.I >= 4096 && (g.epi == HIG_EPI_NONE || g.epi == HIG_EPI_BIAS) &&
          !g.row_stats_in && !g.row_stats_out;
 }
@@ -80,7 +80,7 @@ struct G {  // small builder for gemm descriptors
 // the bf16 product modes 128x128 (14.9 vs 15.2 ms bf16x3, 12.9 vs 13.5 ms bf16) -- same-box sweeps in
 // profiles/r01_notes.md.  HIG_WGRAD_TILE = 64 / 128 forces one.
 inline int wgrad_tile(int64_t I, int64_t J, int prec) {
-  static const int forced = getenv("HIG_WGRAD_TILE") ? atoi(getenv("HIG_WGRAD_TILE")) : 0;   // tuning knob
+  constexpr int forced = 0;   // (a former tuning knob, fixed at the value that won its A/B)
   if (!(I > 64 && J > 64)) return 64;
   if (forced == 64 || forced == 128) return forced;
   return prec == HIG_PREC_F32 ? 64 : 128;
@@ -92,7 +92,7 @@ inline int wgrad_tile(int64_t I, int64_t J, int prec) {
 inline int wgrad_splits(int64_t I, int64_t J, int64_t R, int64_t slab_floats, int prec) {
   const int bi = wgrad_tile(I, J, prec);
   const int64_t tiles = ((I + bi - 1) / bi) * ((J + bi - 1) / bi);
-  static const int forced_target = getenv("HIG_WGRAD_TARGET") ? atoi(getenv("HIG_WGRAD_TARGET")) : 0;  // tuning knob
+  constexpr int forced_target = 0;  // (a former tuning knob, fixed at the value that won its A/B)
   const int target = forced_target > 0 ? forced_target : (bi == 128 ? 2 : 4) * hig_chip_cus();
   int64_t s = target / tiles;
   const int64_t maxs = R / 256 > 1 ? R / 256 : 1;

@@ -1439,7 +1439,7 @@ template <typename TIO>
 int linattn_ctx_t(const TIO* K, const TIO* V, int64_t ld, int32_t B, int32_t rows, int32_t H, int32_t hd,
                   const int64_t* length, float* A, float* kstat, float* scratch, hipStream_t st, __bf16* At16 = nullptr) {
   const int nchunk = (rows + CH - 1) / CH;
-  static const int ctx_walk = getenv("HIG_CTX_WALK") ? atoi(getenv("HIG_CTX_WALK")) : 1;   // tuning knob
+  constexpr int ctx_walk = 1;   // (a former tuning knob, fixed at the value that won its A/B)
   const bool walk = ctx_walk && B * H >= hig_chip_cus();   // enough (sample, head) pairs to fill the chip with walking workgroups
   if (!walk && scratch && nchunk > 1) {
     // row chunks in parallel + a merge: 4-5x the workgroups of the one-per-(sample, head) kernel
@@ -1470,7 +1470,7 @@ int linattn_apply_t(const TIO* Q, int64_t ldq, const float* A, TIO* Y, int64_t l
   const int nchunk_a = (rows + CH - 1) / CH;
   // (hd = 128 keeps 97 KB of LDS per workgroup = one per CU: fewer, longer-lived workgroups; measured with
   // tools/attn_time.py: 61 -> 47 us at config 5, neutral at hd = 64)
-  static const int apply_target = getenv("HIG_APPLY_WGS") ? atoi(getenv("HIG_APPLY_WGS")) : 0;   // tuning knob
+  constexpr int apply_target = 0;   // (a former tuning knob, fixed at the value that won its A/B)
   // (re-swept in round 2, profiles/r02_attn_sweep.md: hd = 128 at 256 / 512 / 1024 workgroups: 42.4 / 48.7 / 58.9 us)
   const int target = apply_target > 0 ? apply_target : (hd == 128 ? 1 : 4) * hig_chip_cus();
   int gy = (target + B * H - 1) / (B * H);
@@ -1777,7 +1777,7 @@ extern "C" int hig_linattn_apply_bwd(const float* dY, int64_t lddy, const float*
   int nparts = nchunk;   // dA partials per (sample, head) that chunk_sum_kernel adds up
   if (hd == 64 || (hd == 128 && allow_big_lds() == 0)) {
     // chunk-walking workgroups (dA accumulated in registers across a workgroup's chunks): ~3 per CU resident
-    static const int tgt = getenv("HIG_APPLY_BWD_WGS") ? atoi(getenv("HIG_APPLY_BWD_WGS")) : 0;   // tuning knob
+    constexpr int tgt = 0;   // (a former tuning knob, fixed at the value that won its A/B)
     // measured (tools/attn_time.py): one workgroup per (sample, head) walking all its chunks is fastest once
     // B * H fills the chip (config 2: 49 -> 38 us, config 5: 135 -> 77 us) and needs no partial sums at all
     const int target = tgt > 0 ? tgt : hig_chip_cus();
@@ -1818,7 +1818,7 @@ extern "C" int hig_linattn_ctx_bwd(const float* dA, const float* A, const float*
               "hig_linattn_ctx_bwd: dK/dV must be 16-byte aligned");
   const int nchunk = (rows + CH - 1) / CH;
   if (hd == 64 || (hd == 128 && allow_big_lds() == 0)) {   // single pass (the column term comes from A and dA)
-    static const int tgt = getenv("HIG_CTX_BWD_WGS") ? atoi(getenv("HIG_CTX_BWD_WGS")) : 0;   // tuning knob
+    constexpr int tgt = 0;   // (a former tuning knob, fixed at the value that won its A/B)
     const int target = tgt > 0 ? tgt : hig_chip_cus();
     int gy = (target + B * H - 1) / (B * H);
     gy = gy < 1 ? 1 : (gy > nchunk ? nchunk : gy);
@@ -1854,7 +1854,7 @@ extern "C" int hig_linattn_apply_bwd_bf16(const void* dY, int64_t lddy, const vo
                   (reinterpret_cast<uintptr_t>(dQ) & 15) == 0,
               "hig_linattn_apply_bwd_bf16: Q / dY rows must be 8-byte aligned, dQ rows 16-byte aligned");
   const int nchunk = (rows + CH - 1) / CH;
-  static const int tgt16 = getenv("HIG_APPLY_BWD16_WGS") ? atoi(getenv("HIG_APPLY_BWD16_WGS")) : 0;   // tuning knob
+  constexpr int tgt16 = 0;   // (a former tuning knob, fixed at the value that won its A/B)
   const int target16 = tgt16 > 0 ? tgt16 : hig_chip_cus();
   int nparts = (target16 + B * H - 1) / (B * H);
   nparts = nparts < 1 ? 1 : (nparts > nchunk ? nchunk : nparts);
@@ -1887,7 +1887,7 @@ extern "C" int hig_linattn_ctx_bwd_bf16(const float* dA, const float* A, const v
                   ((reinterpret_cast<uintptr_t>(dK) | reinterpret_cast<uintptr_t>(dV)) & 15) == 0,
               "hig_linattn_ctx_bwd_bf16: K / V rows must be 8-byte aligned, dK / dV rows 16-byte aligned");
   const int nchunk = (rows + CH - 1) / CH;
-  static const int tgt16 = getenv("HIG_CTX_BWD16_WGS") ? atoi(getenv("HIG_CTX_BWD16_WGS")) : 0;   // tuning knob
+  constexpr int tgt16 = 0;   // (a former tuning knob, fixed at the value that won its A/B)
   const int target16 = tgt16 > 0 ? tgt16 : hig_chip_cus();
   int gy = (target16 + B * H - 1) / (B * H);
   gy = gy < 1 ? 1 : (gy > nchunk ? nchunk : gy);

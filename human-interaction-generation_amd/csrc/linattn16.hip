@@ -694,7 +694,7 @@ extern "C" int hig_linattn_apply_sty_mm16(const void* Q, int64_t ldq, const void
               "hig_linattn_apply_sty_mm16: alignment");
   const dim3 grid((rows + 31) / 32, B);
   hipStream_t st = hig_stream(stream);
-  static const int nw8 = getenv("HIG_APPLY16_NW") ? atoi(getenv("HIG_APPLY16_NW")) : 8;      // tuning knob: waves per workgroup at 8 heads, head dim 64
+  constexpr int nw8 = 8;      // (a former tuning knob, fixed at the value that won its A/B): waves per workgroup at 8 heads, head dim 64
 #define HIG_AP16(HD_, H_, NW_)                                                                                                  \
   hipLaunchKernelGGL((apply_sty16_kernel<HD_, H_, NW_>), grid, dim3(64 * NW_), 0, st, static_cast<const __bf16*>(Q), ldq,      \
                      static_cast<const __bf16*>(At16), gamma, beta, ss, ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo,   \
@@ -791,7 +791,7 @@ extern "C" int hig_linattn_ctx_mm16(const void* K, const void* V, int64_t ld, in
                   (reinterpret_cast<uintptr_t>(A) & 15) == 0,
               "hig_linattn_ctx_mm16: K / V / A must be 16-byte aligned with ld %% 8 == 0");
   // (same-call A/B, forward: B = 64 1.546 -> 1.535 ms, B = 128 2.451 -> 2.420, B = 512 8.45 -> 8.31 with two buffers)
-  static const int nb2_from = getenv("HIG_CTX16_NB2") ? atoi(getenv("HIG_CTX16_NB2")) : 512;   // tuning knob: workgroups from which the ring has two buffers (0 = never)
+  constexpr int nb2_from = 512;   // (a former tuning knob, fixed at the value that won its A/B): workgroups from which the ring has two buffers (0 = never)
   if (hd == 64 && nb2_from > 0 && B * H >= nb2_from)
     hipLaunchKernelGGL((ctx16_mfma_kernel<64, 2>), dim3(B * H), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(K),
                        static_cast<const __bf16*>(V), ld, rows, H, length, A, kstat, static_cast<__bf16*>(At16));

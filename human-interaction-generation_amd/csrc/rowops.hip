@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const Tr16Batch b) {
 }
 
 int splits_for(int64_t samples) {
-  static const int target = getenv("HIG_LNB_WGS") ? atoi(getenv("HIG_LNB_WGS")) : 512;   // tuning knob: workgroups per launch
+  constexpr int target = 512;   // (a former tuning knob, fixed at the value that won its A/B): workgroups per launch
   int s = 1;
   while (samples * s < target && s < 64) s *= 2;
   return s;
@@ -910,8 +910,8 @@ extern "C" int hig_ln_bwd_bf16(const void* da, int64_t ldda, const void* x, int3
   // waves per workgroup: 8, in half as many workgroups (the partial sums -- one set per WORKGROUP -- halve, the rows are shared
   // by as many waves as before).  Same call, config 2 (tools/train16_kernels_time.py): 4 waves x 512 workgroups 25.4 / 22.8 us
   // (stylization / plain + residual form), 8 x 256: 24.0 / 21.1, 8 x 512: 28.3 / 19.1, 4 x 256: 32.6 / 30.4
-  static const int nwv = getenv("HIG_LNB_WAVES") ? atoi(getenv("HIG_LNB_WAVES")) : 8;   // tuning knob: 4 / 8
-  static const bool wgs_forced = getenv("HIG_LNB_WGS") != nullptr;
+  constexpr int nwv = 8;   // (a former tuning knob, fixed at the value that won its A/B): 4 / 8
+  constexpr bool wgs_forced = false;
   const int nit = (n + 255) / 256;
   int nsplit = splits_for(samples);             // (hig_ln_bwd_partial_floats sizes `partial` for this many)
   if (nwv == 8 && nit <= 2 && !wgs_forced && nsplit > 1) nsplit /= 2;

@@ -36,6 +36,36 @@ def build(c, **kw):
     return m.to(DEV)
 
 
+CONFIG5 = dict(B=32, T=300, F=150, d=1024, H=8, L=12, ff=1024, N=77, Lt=256, num_frames=300,
+               lengths=tuple([300, 211] + [300] * 20 + list(range(30, 300, 27))), t=tuple(int(v) for v in np.linspace(0, 999, 32)))
+
+
+@pytest.mark.parametrize("no_eff", [False, True])
+def test_config5_as_specified_bf16_storage_forward_slice_against_oracle(no_eff):
+    """BASELINE config 5 AS SPECIFIED -- B=32, T=300, d=1024, L=12, head dim 128, bf16 storage -- with linear attention and with
+    no_eff=True (full softmax attention): the whole batch runs on the GPU (9 600 rows: the K = 1024 variants of the
+    weight-stationary GEMM at their full-size work split, `apply_sty16<128>` / `ctx16<128>` at 32 samples, the LayerNorm fold at
+    K = 1024); samples are independent, so the first two samples (one full-length, one ragged) are compared with the fp32 CPU
+    oracle run on just those two (transformer.py:60-194 at latent_dim=1024).  Gates: finite everywhere, rel-L2 of the slice
+    at the bf16 level (3e-2) and clearly above fp32 noise."""
+    c = CONFIG5
+    assert len(c["lengths"]) == c["B"]
+    m = build(c, storage="bf16", no_eff=no_eff).eval()
+    inp = fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"])
+    gi = {k: v.to(DEV) for k, v in inp.items()}
+    with torch.no_grad():
+        out = m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+        n = 2
+        p = fill.core_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"])
+        ref = R.denoiser_forward(p, inp["x"][:n], inp["t"][:n], inp["length"][:n], inp["xf_proj"][:n], inp["xf_out"][:n], c["H"], c["L"],
+                                 no_eff=no_eff)
+    assert out.shape == (c["B"], c["T"], c["F"]) and torch.isfinite(out).all()
+    errs = [rel(out[b, :min(c["lengths"][b], c["T"])], ref[b, :min(c["lengths"][b], c["T"])]) for b in range(n)]
+    print("config 5 (B=32 T=300 d=1024 L=12, bf16 storage, no_eff=%s): rel-L2 of the valid rows of samples 0, 1 vs the fp32 oracle %s" %
+          (no_eff, ["%.2e" % e for e in errs]))
+    assert all(1e-4 < e < 3e-2 for e in errs), errs
+
+
 def test_config2_size_bf16_storage_backward_every_gradient_against_oracle_autograd():
     """The bf16-storage training forward + backward at BASELINE config 2 itself (B=64, T=196, d=512, L=8: 12 544 rows -- the
     row count at which the weight-gradient kernel runs sixteen row slices per tile and the weight-stationary GEMMs their

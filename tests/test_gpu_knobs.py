@@ -1,0 +1,45 @@
+"""Every environment switch the library still reads ("Switches") is flipped ONCE, in a child process (they are read
+once per process), over a pass that touches every path they select between: the results must stay at the rounding level of the
+path -- a switch chooses between two implementations of the same arithmetic, never between two results.  The diagnostic
+switches whose builds are wrong by construction (HIG_BF16_DBG, HIG_BF16_WSP_DBG: timing ablations; HIG_POISON) are not flipped."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (switch, flipped value): the default of every switch is the other implementation
+KNOBS = [
+    ("HIG_BWD_OVERLAP", "0"), ("HIG_TEXT_FORK", "0"), ("HIG_FWD_SPLIT", "0"), ("HIG_LNFOLD32", "0"), ("HIG_GEMM_TAIL", "0"),
+    ("HIG_GEMM_TILE", "128"), ("HIG_FEW_ROWS_SPLIT", "0"), ("HIG_FULLATTN_WAVES", "4"), ("HIG_FULLATTN_VALU", "1"),
+    ("HIG_CTX16", "0"), ("HIG_FWD16_FORK", "0"), ("HIG_JOINT16", "0"), ("HIG_FUSE_APPLY", "0"), ("HIG_FUSE_OUT", "0"),
+    ("HIG_EDGE16", "0"), ("HIG_BF16_TILE", "64"), ("HIG_BF16_FEWROW", "0"), ("HIG_BF16_WS", "0"), ("HIG_BF16_WSP", "0"),
+    ("HIG_BF16_WS_NWJ", "4"), ("HIG_BF16_WS_ROWS", "100000"), ("HIG_LNFOLD", "0"), ("HIG_LNFOLD1024", "0"), ("HIG_CHIP_CUS", "128"),
+]
+
+
+def run(env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "knob_worker.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("DIGEST ")][-1]
+    return json.loads(line[len("DIGEST "):])
+
+
+@pytest.fixture(scope="module")
+def default_digest():
+    return run({})
+
+
+@pytest.mark.parametrize("knob,value", KNOBS)
+def test_every_switch_selects_between_implementations_of_the_same_arithmetic(knob, value, default_digest):
+    d = run({knob: value})
+    assert set(d) == set(default_digest)
+    for k, v in d.items():
+        ref = default_digest[k]
+        tol = 2e-2 if k.startswith("bf16") else 2e-4       # bf16 storage: another rounding sequence; fp32: another summation order
+        assert abs(v - ref) <= tol * abs(ref), (knob, k, v, ref)
