@@ -284,11 +284,10 @@ int64_t text16_total(const Dims& D);
 int64_t fwd16t_total(const Dims& D);
 int64_t text16t_total(const Dims& D);
 int64_t bwd16_total(const Dims& D);
-// the bf16-storage TRAINING step is built for the single-person model with linear attention
+// the bf16-storage TRAINING step is built for linear attention (single-person and two-person model)
 int bf16_train_unsupported(const Dims& D, int training) {
-  if (D.bf16 && training && (D.two || D.full)) {
-    hig_set_error(HIG_EUNSUPPORTED, "hig: bf16-storage training is built for the single-person model with linear attention "
-                                    "(two_person=%d, attn_kind=%d: train with fp32 storage)", D.two, D.full);
+  if (D.bf16 && training && D.full) {
+    hig_set_error(HIG_EUNSUPPORTED, "hig: bf16-storage training is built for linear attention (attn_kind=%d: train with fp32 storage)", D.full);
     return 1;
   }
   return 0;
@@ -780,6 +779,17 @@ __global__ void cast_rows_bf16_kernel(const float* __restrict__ src, int64_t lds
     const int64_t r = i / n, c = i % n;
     dst[r * ldd + c] = (__bf16)src[r * lds + c];
   }
+}
+
+// tok0[b][0..n) = float(buf[b][0][0..n)) for a bf16 buf [B][T][n] (if tok0), then zeroes that row in buf (if zero): the init-pose
+// rows of the two-person model's residual-stream gradient
+__global__ void tok0_bf16_kernel(__bf16* __restrict__ buf, int64_t sample_stride, int B, int n, float* __restrict__ tok0, int zero) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * n) return;
+  const int b = idx / n, c = idx % n;
+  __bf16* p = buf + (int64_t)b * sample_stride + c;
+  if (tok0) tok0[idx] = (float)*p;
+  if (zero) *p = (__bf16)0.f;
 }
 
 struct Text16Layout {
@@ -1578,6 +1588,8 @@ inline int64_t rup64(int64_t v) { return (v + 63) & ~(int64_t)63; }
 struct Fwd16TLayout {
   int64_t te, te_h, emb, ss, few, few_bytes, h0, cscr, layer0, lstride;
   int64_t xn1, qkv, A1, At1, kst1, y1, a1, h1, xn2, qc, y2, a2, h2, z1, f1, y3, a3, h3;
+  int64_t xn3, iqkv, Ai, Ati, ksti, y4, a4, h2b;   // two-person: person <-> person attention block (interaction_transformer.py:167-207)
+  int64_t tok0, lenp;                               // two-person: init-pose rows (fp32, B x d), partner lengths (int64)
   int64_t total;
 };
 Fwd16TLayout fwd16t_layout(const Dims& D) {
@@ -1592,6 +1604,8 @@ Fwd16TLayout fwd16t_layout(const Dims& D) {
   w.few = take(w.few_bytes);
   w.h0 = take(D.M * D.d * 2);
   w.cscr = take(hig_linattn_ctx_scratch_floats(D.B, D.T, D.H, D.hd) * 4);
+  w.tok0 = take(D.two ? (int64_t)D.B * D.d * 4 : 0);
+  w.lenp = take(D.two ? (int64_t)D.B * 8 : 0);
   w.layer0 = o;
   o = 0;
   w.xn1 = take(D.M * D.d * 2);
@@ -1612,6 +1626,17 @@ Fwd16TLayout fwd16t_layout(const Dims& D) {
   w.y3 = take(D.M * D.d * 2);
   w.a3 = take(D.M * D.d * 2);
   w.h3 = take(D.M * D.d * 2);
+  w.xn3 = w.iqkv = w.Ai = w.Ati = w.ksti = w.y4 = w.a4 = w.h2b = 0;
+  if (D.two == 1) {
+    w.xn3 = take(D.M * D.d * 2);
+    w.iqkv = take(D.M * 3 * D.d * 2);
+    w.Ai = take((int64_t)D.B * D.H * D.hd * D.hd * 4);
+    w.Ati = take((int64_t)D.B * D.H * D.hd * D.hd * 2);
+    w.ksti = take((int64_t)D.B * D.d * 2 * 4);
+    w.y4 = take(D.M * D.d * 2);
+    w.a4 = take(D.M * D.d * 2);
+    w.h2b = take(D.M * D.d * 2);
+  }
   w.lstride = o;
   w.total = w.layer0 + w.lstride * D.L;
   return w;
@@ -1642,6 +1667,7 @@ Text16TLayout text16t_layout(const Dims& D) {
 struct Bwd16Layout {
   int64_t dhA, dhB, t1, t2, tff, dqkv, dA, dkv, dxfn, dss, demb, dtmp, dte_h, slabs, slab_floats, colpart, colpart_w, lnpart,
       wT, tA, tB, attn, f32a, f32b, Mp, Mtp, total;
+  int64_t tok0, hl0, postmp;   // two-person (fp32): init-pose rows of a gradient (B x max(d, F)), of h_L (B x d); d(sequence_embedding) before its shift (T x d)
 };
 Bwd16Layout bwd16_layout(const Dims& D) {
   Bwd16Layout w;
@@ -1679,7 +1705,8 @@ Bwd16Layout bwd16_layout(const Dims& D) {
   w.colpart_w = take(colp * 4);
   const int64_t lp = hig_ln_bwd_partial_floats(D.M, D.d, D.T), lpt = hig_ln_bwd_partial_floats(D.Mt, D.Lt, D.N);
   w.lnpart = take((lp > lpt ? lp : lpt) * 4);
-  w.wT = take(((int64_t)5 * D.d * D.d + (int64_t)3 * D.d * D.d + (int64_t)2 * D.d * D.ff + (int64_t)2 * D.d * D.Lt) * 2);
+  w.wT = take(((int64_t)5 * D.d * D.d + (int64_t)3 * D.d * D.d + (int64_t)2 * D.d * D.ff + (int64_t)2 * D.d * D.Lt +
+               (D.two == 1 ? (int64_t)4 * D.d * D.d : 0)) * 2);
   const int64_t mrows = w.Mp > w.Mtp ? w.Mp : w.Mtp;
   const int64_t wide = 3 * D.d > D.ff ? 3 * D.d : D.ff;
   w.tA = take(wide * mrows * 2);
@@ -1688,6 +1715,9 @@ Bwd16Layout bwd16_layout(const Dims& D) {
   w.attn = take((as1 > as2 ? as1 : as2) * 4);
   w.f32a = take(D.M * D.d * 4);     // fp32 copies at the F-wide edges (input / output projection run on the fp32 kernels)
   w.f32b = take(D.M * D.d * 4);
+  w.tok0 = take(D.two ? (int64_t)D.B * (D.d > D.F ? D.d : D.F) * 4 : 0);
+  w.hl0 = take(D.two ? (int64_t)D.B * D.d * 4 : 0);
+  w.postmp = take(D.two ? (int64_t)D.T * D.d * 4 : 0);
   w.total = o;
   return w;
 }
@@ -1758,15 +1788,32 @@ extern "C" int hig_denoiser_fwd_bf16_train(const hig_dims* dims, const void* con
                                 .epi(HIG_EPI_BIAS, P(params, HIG_P_STY_EMB_B)).g, few, few_floats, st));
   // K1: h0 = joint_embed(x) + sequence_embedding[:T], rounded once into the bf16 residual stream
   if (d % 128 == 0 && D.F <= 512) {
-    HIG_TRY(hig_joint_embed_bf16(x, M, D.F, P(params, HIG_P_JOINT_W), P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d, D.T, 0,
-                                 ws + w.h0, d, d, few, stream));
+    HIG_TRY(hig_joint_embed_bf16(x, M, D.F, P(params, HIG_P_JOINT_W), P(params, HIG_P_JOINT_B), P(params, HIG_P_SEQ_EMB), d, D.T,
+                                 D.two ? 1 : 0, ws + w.h0, d, d, few, stream));   // two-person: frame t >= 1 gets sequence_embedding[t - 1]
   } else {
     float* h32 = few;
     HIG_REQUIRE(M * d * 4 <= w.few_bytes, "hig_denoiser_fwd_bf16_train: d %% 128 != 0 needs M d floats of scratch");
     G ge(x, D.F, 0, P(params, HIG_P_JOINT_W), D.F, 0, h32, d, M, d, D.F);
     ge.epi(HIG_EPI_BIAS_POS, P(params, HIG_P_JOINT_B)).pos(P(params, HIG_P_SEQ_EMB), d, D.T);
+    ge.g.pos_shift = D.two ? 1 : 0;
     HIG_TRY(hig_gemm_launch(ge.g, 1, nullptr, st));
     HIG_TRY(hig_cast_bf16(h32, ws + w.h0, M * d, stream));
+  }
+  const int64_t* len_partner = nullptr;
+  const int Bp = D.B / 2;
+  if (D.two) {
+    // token 0 is the init-pose row: joint_embed2 on its first 4 features, no positional term (interaction_transformer.py:596);
+    // fp32 GEMM over the B rows, then into the bf16 residual stream.  The partner's lengths mask the person <-> person keys.
+    float* tok0 = reinterpret_cast<float*>(ws + w.tok0);
+    HIG_TRY(hig_gemm_launch(G(x, (int64_t)D.T * D.F, 0, P(params, HIG_P_JOINT2_W), 4, 0, tok0, d, D.B, d, 4)
+                                .epi(HIG_EPI_BIAS, P(params, HIG_P_JOINT2_B)).g, 1, nullptr, st));
+    hipLaunchKernelGGL(cast_rows_bf16_kernel, dim3((unsigned)(((int64_t)D.B * d + 255) / 256)), dim3(256), 0, st, tok0, (int64_t)d,
+                       reinterpret_cast<__bf16*>(ws + w.h0), (int64_t)D.T * d, D.B, d);
+    HIG_CHECK_LAUNCH();
+    int64_t* lp = reinterpret_cast<int64_t*>(ws + w.lenp);
+    hipLaunchKernelGGL(swap_halves_i64_kernel, dim3((D.B + 255) / 256), dim3(256), 0, st, length, D.B, (int64_t)D.T, lp);
+    HIG_CHECK_LAUNCH();
+    len_partner = lp;
   }
   const void* hin = ws + w.h0;
   for (int l = 0; l < D.L; ++l) {
@@ -1793,17 +1840,38 @@ extern "C" int hig_denoiser_fwd_bf16_train(const hig_dims* dims, const void* con
     HIG_TRY(hig_linattn_apply_bf16(lb + w.qc, d, reinterpret_cast<const float*>(tc + tl.layer0 + tl.lstride * l + tl.Ac), lb + w.y2, d, D.B,
                                    D.T, D.H, D.hd, stream));
     HIG_TRY(stylize(1, lb + w.y2, lb + w.a2, lb + w.h1, lb + w.h2, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B));
+    const void* hffn = lb + w.h2;
+    if (D.two == 1) {
+      // ---- person <-> person linear cross attention (interaction_transformer.py:181-205): queries from the own stream, key /
+      // value from the partner's (same LayerNorm on both), key softmax masked with the consumer's length ----
+      HIG_TRY(hig_ln_bf16(lb + w.h2, 0, d, M, d, PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B), nullptr, 0, 0, 0, lb + w.xn3, d, stream));
+      HIG_TRY(hig_gemm16_launch(G16(lb + w.xn3, d, PL16(params16, l, HIG_L_INT_QKV_W), d, lb + w.iqkv, 3 * d, M, 3 * d, d)
+                                    .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_INT_QKV_B)).g, st));
+      char* iqkv = lb + w.iqkv;
+      float* Ai = reinterpret_cast<float*>(lb + w.Ai);
+      HIG_TRY(ctx16(D, iqkv + (int64_t)d * 2, iqkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, len_partner, Ai, reinterpret_cast<float*>(lb + w.ksti),
+                    reinterpret_cast<float*>(ws + w.cscr), lb + w.Ati, stream));
+      const int64_t halfA = (int64_t)Bp * D.H * D.hd * D.hd, halfM = (int64_t)Bp * D.T;
+      HIG_TRY(hig_linattn_apply_bf16(iqkv, 3 * d, Ai + halfA, lb + w.y4, d, Bp, D.T, D.H, D.hd, stream));
+      HIG_TRY(hig_linattn_apply_bf16(iqkv + halfM * 3 * d * 2, 3 * d, Ai, lb + w.y4 + halfM * d * 2, d, Bp, D.T, D.H, D.hd, stream));
+      HIG_TRY(stylize(2, lb + w.y4, lb + w.a4, lb + w.h2, lb + w.h2b, HIG_L_INT_STY_NORM_W, HIG_L_INT_STY_NORM_B, HIG_L_INT_STY_OUT_W, HIG_L_INT_STY_OUT_B));
+      hffn = lb + w.h2b;
+    }
     // ---- FFN (transformer.py:167-170): z = Lin1(h2) kept for gelu'(z), f = gelu(z) is linear2's operand ----
-    HIG_TRY(hig_gemm16_launch(G16(lb + w.h2, d, PL16(params16, l, HIG_L_FFN_W1), d, lb + w.z1, D.ff, M, D.ff, d)
+    HIG_TRY(hig_gemm16_launch(G16(hffn, d, PL16(params16, l, HIG_L_FFN_W1), d, lb + w.z1, D.ff, M, D.ff, d)
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B1)).g, st));
     HIG_TRY(hig_gelu_bf16(lb + w.z1, lb + w.f1, M * D.ff, stream));
     HIG_TRY(hig_gemm16_launch(G16(lb + w.f1, D.ff, PL16(params16, l, HIG_L_FFN_W2), D.ff, lb + w.y3, d, M, d, D.ff)
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B2)).g, st));
-    HIG_TRY(stylize(2, lb + w.y3, lb + w.a3, lb + w.h2, lb + w.h3, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B, HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B));
+    HIG_TRY(stylize(D.nsty - 1, lb + w.y3, lb + w.a3, hffn, lb + w.h3, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B, HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B));
     hin = lb + w.h3;
   }
   // K6: out = Linear(d, F)(h_L), fp32
-  return hig_gemm16_launch(G16(hin, d, P16(params16, HIG_P_OUT_W), d, out, D.F, M, D.F, d).epi(HIG_EPI_BIAS, P(params, HIG_P_OUT_B)).out32().g, st);
+  HIG_TRY(hig_gemm16_launch(G16(hin, d, P16(params16, HIG_P_OUT_W), d, out, D.F, M, D.F, d).epi(HIG_EPI_BIAS, P(params, HIG_P_OUT_B)).out32().g, st));
+  if (D.two)  // init-pose rows go through out2 instead (interaction_transformer.py:613-614)
+    HIG_TRY(hig_gemm16_launch(G16(hin, (int64_t)D.T * d, P16(params16, HIG_P_OUT2_W), d, out, (int64_t)D.T * D.F, D.B, D.F, d)
+                                  .epi(HIG_EPI_BIAS, P(params, HIG_P_OUT2_B)).out32().g, st));
+  return HIG_OK;
 }
 
 extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* params, const void* const* params16, const float* x,
@@ -1881,7 +1949,8 @@ extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* pa
   char* wT = b + bw.wT;
   const int64_t o_sty3 = 0, o_w2t = o_sty3 + (int64_t)d * d * 2, o_w1t = o_w2t + (int64_t)d * ff * 2, o_sty2 = o_w1t + (int64_t)d * ff * 2,
                 o_caq = o_sty2 + (int64_t)d * d * 2, o_kv = o_caq + (int64_t)d * d * 2, o_sty1 = o_kv + (int64_t)2 * d * Lt * 2,
-                o_qkv = o_sty1 + (int64_t)d * d * 2;
+                o_qkv = o_sty1 + (int64_t)d * d * 2, o_isty = o_qkv + (int64_t)3 * d * d * 2, o_iqkv = o_isty + (int64_t)d * d * 2;
+  const int Bp = D.B / 2;
   auto dgrad = [&](const void* dC, int n_out, int64_t wt_off, void* dst, int k_in, int64_t rows, int epi, const void* res, int64_t ldr) -> int {
     G16 g(dC, n_out, wT + wt_off, n_out, dst, k_in, rows, k_in, n_out);
     g.g.epi = epi;
@@ -1924,8 +1993,30 @@ extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* pa
       return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
     return fork.end();
   };
+  float* tok0 = reinterpret_cast<float*>(b + bw.tok0);
+  if (D.two) {
+    // init-pose rows went through out2 (interaction_transformer.py:613): B rows -- the fp32 kernels on fp32 copies.
+    // d(b_out2) = column sums of d(out)[:, 0, :], d(W_out2) = d(out)[:, 0, :]^T h_L[:, 0, :]
+    float* hl0 = reinterpret_cast<float*>(b + bw.hl0);
+    hipLaunchKernelGGL(tok0_bf16_kernel, dim3((D.B * d + 255) / 256), dim3(256), 0, st, reinterpret_cast<__bf16*>(const_cast<char*>(hL)),
+                       (int64_t)D.T * d, D.B, d, hl0, 0);
+    HIG_CHECK_LAUNCH();
+    HIG_TRY(hig_colsum(dout, (int64_t)D.T * F, D.B, F, GP(grads, HIG_P_OUT2_B), colp, stream));
+    HIG_TRY(wgrad32(G(dout, (int64_t)D.T * F, 1, hl0, d, 1, GP(grads, HIG_P_OUT2_W), d, F, d, D.B)));
+  }
+  // dh[:, 0, :] = d(out)[:, 0, :] W_out2 over the exact zeros the `out` adjoint leaves there (two-person)
+  auto out2_rows = [&](char* dh_bf16) -> int {
+    HIG_TRY(hig_gemm_launch(G(dout, (int64_t)D.T * F, 0, P(params, HIG_P_OUT2_W), d, 1, tok0, d, D.B, d, F).g, 1, nullptr, st));
+    hipLaunchKernelGGL(cast_rows_bf16_kernel, dim3((unsigned)(((int64_t)D.B * d + 255) / 256)), dim3(256), 0, st, tok0, (int64_t)d,
+                       reinterpret_cast<__bf16*>(dh_bf16), (int64_t)D.T * d, D.B, d);
+    HIG_CHECK_LAUNCH();
+    return HIG_OK;
+  };
   if (edge16) {
     HIG_TRY(hig_cast_pad_bf16(dout, F, M, F, edgeb + e_dout, Fp, stream));
+    if (D.two &&   // the `out` adjoints must not see the init-pose rows: zero them in the rounded copy
+        hipMemset2DAsync(edgeb + e_dout, (size_t)D.T * Fp * 2, 0, (size_t)Fp * 2, (size_t)D.B, st) != hipSuccess)
+      return hig_set_error(HIG_EHIP, "hipMemset2DAsync failed");
     HIG_TRY(hig_cast_pad_bf16(x, F, M, F, edgeb + e_x, Fp, stream));
     if (hipMemsetAsync(edgeb + e_wot, 0, (size_t)d * Fp * 2, st) != hipSuccess) return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
     HIG_TRY(hig_transpose_bf16(P16(params16, HIG_P_OUT_W), d, F, d, edgeb + e_wot, Fp, stream));   // (F, d) -> (d, Fp), pad columns zero
@@ -1934,12 +2025,22 @@ extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* pa
                        GP(grads, HIG_P_OUT_B), F));
     // d(h_L) = d(out) W_out
     HIG_TRY(hig_gemm16_launch(G16(edgeb + e_dout, Fp, edgeb + e_wot, Fp, dh, d, M, d, Fp).g, st));
+    if (D.two) HIG_TRY(out2_rows(dh));
   } else {
-    HIG_TRY(hig_colsum(dout, F, M, F, GP(grads, HIG_P_OUT_B), colp, stream));
+    const float* dout_m = dout;   // rows that went through `out`
+    if (D.two) {                  // (the fp32 edge: a copy of d(out) with the init-pose rows zeroed, in the second fp32 scratch)
+      if (hipMemcpyAsync(f32b, dout, (size_t)M * F * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
+      hipLaunchKernelGGL(tok0_kernel, dim3((D.B * F + 255) / 256), dim3(256), 0, st, f32b, (int64_t)D.T * F, D.B, F, (float*)nullptr, 1);
+      HIG_CHECK_LAUNCH();
+      dout_m = f32b;
+    }
+    HIG_TRY(hig_colsum(dout_m, F, M, F, GP(grads, HIG_P_OUT_B), colp, stream));
     HIG_TRY(hig_cast_f32(hL, f32a, M * d, stream));
-    HIG_TRY(wgrad32(G(dout, F, 1, f32a, d, 1, GP(grads, HIG_P_OUT_W), d, F, d, M)));
-    HIG_TRY(hig_gemm_launch(G(dout, F, 0, P(params, HIG_P_OUT_W), d, 1, f32b, d, M, d, F).g, 1, nullptr, st));
-    HIG_TRY(hig_cast_bf16(f32b, dh, M * d, stream));
+    HIG_TRY(wgrad32(G(dout_m, F, 1, f32a, d, 1, GP(grads, HIG_P_OUT_W), d, F, d, M)));
+    float* dh32 = D.two ? reinterpret_cast<float*>(tA) : f32b;   // (two-person: f32b holds d(out) with zeroed rows; the transpose scratch is idle)
+    HIG_TRY(hig_gemm_launch(G(dout_m, F, 0, P(params, HIG_P_OUT_W), d, 1, dh32, d, M, d, F).g, 1, nullptr, st));
+    HIG_TRY(hig_cast_bf16(dh32, dh, M * d, stream));
+    if (D.two) HIG_TRY(out2_rows(dh));
   }
 
   for (int l = D.L - 1; l >= 0; --l) {
@@ -1947,10 +2048,10 @@ extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* pa
     const char* tlb = tc + tl.layer0 + tl.lstride * l;
     const char* hin = l == 0 ? ws + w.h0 : ws + w.layer0 + w.lstride * (l - 1) + w.h3;
     {  // all W -> W^T copies of this layer (from the bf16 shadow) in one launch
-      const void* srcs[8];
-      void* dsts[8];
-      int64_t lds_[8], ldd[8];
-      int32_t rws[8], cls[8];
+      const void* srcs[10];
+      void* dsts[10];
+      int64_t lds_[10], ldd[10];
+      int32_t rws[10], cls[10];
       int n = 0;
       auto add = [&](int idx, int out_f, int in_f, int64_t off) {
         srcs[n] = PL16(params16, l, idx); dsts[n] = wT + off; lds_[n] = in_f; ldd[n] = out_f; rws[n] = out_f; cls[n] = in_f; ++n;
@@ -1963,18 +2064,44 @@ extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* pa
       add(HIG_L_CA_KV_W, 2 * d, Lt, o_kv);
       add(HIG_L_SA_STY_OUT_W, d, d, o_sty1);
       add(HIG_L_SA_QKV_W, 3 * d, d, o_qkv);
+      if (D.two == 1) {
+        add(HIG_L_INT_STY_OUT_W, d, d, o_isty);
+        add(HIG_L_INT_QKV_W, 3 * d, d, o_iqkv);
+      }
       HIG_TRY(hig_transpose_bf16_batch(n, srcs, lds_, dsts, ldd, rws, cls, stream));
     }
+    const char* hffn = D.two == 1 ? lb + w.h2b : lb + w.h2;
     // ---- FFN --------------------------------------------------------------------------
-    HIG_TRY(sty_bwd(l, D.nsty * l + 2, dh, lb + w.y3, lb + w.a3, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B, HIG_L_FFN_STY_OUT_W,
+    HIG_TRY(sty_bwd(l, D.nsty * l + D.nsty - 1, dh, lb + w.y3, lb + w.a3, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B, HIG_L_FFN_STY_OUT_W,
                     HIG_L_FFN_STY_OUT_B, o_sty3, b + bw.t2));
     const char* dy3 = b + bw.t2;
     HIG_TRY(wgrad_act(dy3, d, lb + w.f1, ff, GL(grads, l, HIG_L_FFN_W2), M, bw.Mp, GL(grads, l, HIG_L_FFN_B2)));
     HIG_TRY(dgrad(dy3, d, o_w2t, b + bw.tff, ff, M, HIG_EPI_DGELU, lb + w.z1, ff));     // dz = (dy3 . W2) gelu'(z)
     const char* dz1 = b + bw.tff;
-    HIG_TRY(wgrad_act(dz1, ff, lb + w.h2, d, GL(grads, l, HIG_L_FFN_W1), M, bw.Mp, GL(grads, l, HIG_L_FFN_B1)));
+    HIG_TRY(wgrad_act(dz1, ff, hffn, d, GL(grads, l, HIG_L_FFN_W1), M, bw.Mp, GL(grads, l, HIG_L_FFN_B1)));
     HIG_TRY(dgrad(dz1, ff, o_w1t, dh_alt, d, M, HIG_EPI_RES, dh, d));                  // d(h2) = d(h3) + dz . W1
-    { char* tmp = dh; dh = dh_alt; dh_alt = tmp; }
+    { char* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h2), or d(h2b) in the interaction model
+    if (D.two == 1) {
+      // ---- person <-> person cross attention (adjoint of interaction_transformer.py:181-205) ------------------------------------
+      HIG_TRY(sty_bwd(l, D.nsty * l + 2, dh, lb + w.y4, lb + w.a4, HIG_L_INT_STY_NORM_W, HIG_L_INT_STY_NORM_B, HIG_L_INT_STY_OUT_W,
+                      HIG_L_INT_STY_OUT_B, o_isty, b + bw.t2));
+      const int64_t* len_partner = reinterpret_cast<const int64_t*>(ws + w.lenp);
+      const int64_t halfA = (int64_t)Bp * D.H * D.hd * D.hd, halfM = (int64_t)Bp * D.T;
+      char* dqkv = b + bw.dqkv;
+      const float* Ai = reinterpret_cast<const float*>(lb + w.Ai);
+      const char* iqkv = lb + w.iqkv;
+      // consumer sample s read the context of producer (s + B/2) % B: route d(A) back the same way
+      HIG_TRY(hig_linattn_apply_bwd_bf16(b + bw.t2, d, iqkv, 3 * d, Ai + halfA, dqkv, 3 * d, dA + halfA, Bp, D.T, D.H, D.hd, attn, stream));
+      HIG_TRY(hig_linattn_apply_bwd_bf16(b + bw.t2 + halfM * d * 2, d, iqkv + halfM * 3 * d * 2, 3 * d, Ai, dqkv + halfM * 3 * d * 2, 3 * d, dA, Bp,
+                                         D.T, D.H, D.hd, attn, stream));
+      HIG_TRY(hig_linattn_ctx_bwd_bf16(dA, Ai, iqkv + (int64_t)d * 2, iqkv + (int64_t)2 * d * 2, 3 * d, reinterpret_cast<const float*>(lb + w.ksti),
+                                       len_partner, dqkv + (int64_t)d * 2, dqkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, D.H, D.hd, stream));
+      HIG_TRY(wgrad_act(dqkv, 3 * d, lb + w.xn3, d, GL(grads, l, HIG_L_INT_QKV_W), M, bw.Mp, GL(grads, l, HIG_L_INT_QKV_B)));
+      HIG_TRY(dgrad(dqkv, 3 * d, o_iqkv, b + bw.t2, d, M, HIG_EPI_NONE, nullptr, 0));
+      HIG_TRY(hig_ln_bwd_bf16(b + bw.t2, d, lb + w.h2, 0, d, PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B), nullptr, 0, 0, 0, dh, d,
+                              dh_alt, 0, d, M, d, D.T, GL(grads, l, HIG_L_INT_NORM_W), GL(grads, l, HIG_L_INT_NORM_B), nullptr, 0, lnp, stream));
+      { char* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h2)
+    }
     // ---- cross attention ---------------------------------------------------------------
     HIG_TRY(sty_bwd(l, D.nsty * l + 1, dh, lb + w.y2, lb + w.a2, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, HIG_L_CA_STY_OUT_W,
                     HIG_L_CA_STY_OUT_B, o_sty2, b + bw.t2));
@@ -2011,23 +2138,37 @@ extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* pa
   }
 
   // ---- joint_embed + sequence_embedding (F-wide: fp32 kernels on an fp32 copy of d(h0)) ---------------------------------------
+  if (D.two) {
+    // init-pose rows came from joint_embed2 (no positional term): move them aside (fp32, B rows), leaving zeros so that the
+    // joint_embed / sequence_embedding adjoints below see only the motion rows                 (interaction_transformer.py:596)
+    hipLaunchKernelGGL(tok0_bf16_kernel, dim3((D.B * d + 255) / 256), dim3(256), 0, st, reinterpret_cast<__bf16*>(dh), (int64_t)D.T * d, D.B, d, tok0, 1);
+    HIG_CHECK_LAUNCH();
+    HIG_TRY(hig_colsum(tok0, d, D.B, d, GP(grads, HIG_P_JOINT2_B), colp, stream));
+    HIG_TRY(wgrad32(G(tok0, d, 1, x, (int64_t)D.T * F, 1, GP(grads, HIG_P_JOINT2_W), 4, d, 4, D.B)));
+  }
+  const int Tpos = D.two ? D.T - 1 : D.T;        // rows of sequence_embedding that were used (two-person: frame t used row t - 1)
+  float* dpos = D.two ? reinterpret_cast<float*>(b + bw.postmp) : GP(grads, HIG_P_SEQ_EMB);
   if (edge16) {
     // d(W_joint) (d, F) and d(b_joint) (d) = d(h_0)^T x and its column sums; the position table's gradient = d(h_0) summed over samples
     HIG_TRY(wgrad_edge(dh, d, edgeb + e_x, Fp, reinterpret_cast<float*>(edgeb + e_dwj), GP(grads, HIG_P_JOINT_B), GP(grads, HIG_P_JOINT_W), d, F,
                        GP(grads, HIG_P_JOINT_B), d));
-    HIG_TRY(hig_colsum_bf16(dh, (int64_t)D.T * d, D.B, D.T * d, GP(grads, HIG_P_SEQ_EMB), colp, stream));
+    HIG_TRY(hig_colsum_bf16(dh, (int64_t)D.T * d, D.B, D.T * d, dpos, colp, stream));
   } else {
     HIG_TRY(hig_colsum_bf16(dh, d, M, d, GP(grads, HIG_P_JOINT_B), colp, stream));
     HIG_TRY(hig_cast_f32(dh, f32b, M * d, stream));
     HIG_TRY(wgrad32(G(f32b, d, 1, x, F, 1, GP(grads, HIG_P_JOINT_W), F, d, F, M)));
-    HIG_TRY(hig_colsum(f32b, (int64_t)D.T * d, D.B, D.T * d, GP(grads, HIG_P_SEQ_EMB), colp, stream));
+    HIG_TRY(hig_colsum(f32b, (int64_t)D.T * d, D.B, D.T * d, dpos, colp, stream));
   }
-  if (D.nf > D.T)
-    if (hipMemsetAsync(GP(grads, HIG_P_SEQ_EMB) + (int64_t)D.T * d, 0, (size_t)(D.nf - D.T) * d * 4, st) != hipSuccess)
+  if (D.two && hipMemcpyAsync(GP(grads, HIG_P_SEQ_EMB), dpos + d, (size_t)Tpos * d * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
+  if (D.nf > Tpos)
+    if (hipMemsetAsync(GP(grads, HIG_P_SEQ_EMB) + (int64_t)Tpos * d, 0, (size_t)(D.nf - Tpos) * d * 4, st) != hipSuccess)
       return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
   if (dx) {   // (input gradient: asked for by tests only -- the fp32 kernel on an fp32 copy of d(h_0))
     if (edge16) HIG_TRY(hig_cast_f32(dh, f32b, M * d, stream));
     HIG_TRY(hig_gemm_launch(G(f32b, d, 0, P(params, HIG_P_JOINT_W), F, 1, dx, F, M, F, d).g, 1, nullptr, st));
+    if (D.two)  // d(x[:, 0, :4]) through joint_embed2; the other features of the init-pose row are unused
+      HIG_TRY(hig_gemm_launch(G(tok0, d, 0, P(params, HIG_P_JOINT2_W), 4, 1, dx, (int64_t)D.T * F, D.B, 4, d).g, 1, nullptr, st));
   }
 
   // ---- time / text embedding path (fp32, as hig_denoiser_bwd) --------------------------------------------------------------

@@ -579,12 +579,11 @@ class MotionTransformer(nn.Module):
         return out
 
     def _check_bf16_training(self):
-        """storage='bf16' trains the single-person model with linear attention (hig_denoiser_fwd_bf16_train / _bwd_bf16:
-        fp32 master weights, gradients and optimizer state; bf16 activations and matrix products)."""
-        if self._bf16() and (self.no_eff or hasattr(self, "joint_embed2")):
-            raise NotImplementedError("storage='bf16' trains the single-person model with linear attention only (no_eff / "
-                                      "the two-person model: train with fp32 storage; precision='bf16x3' / 'bf16' select "
-                                      "reduced-precision products there)")
+        """storage='bf16' trains the single-person AND the two-person model with linear attention (hig_denoiser_fwd_bf16_train /
+        _bwd_bf16: fp32 master weights, gradients and optimizer state; bf16 activations and matrix products)."""
+        if self._bf16() and self.no_eff:
+            raise NotImplementedError("storage='bf16' trains with linear attention only (no_eff: train with fp32 storage; "
+                                      "precision='bf16x3' / 'bf16' select reduced-precision products there)")
 
     # ---- launches -----------------------------------------------------------------------
     def _text_context(self, dims, xf_out, training):

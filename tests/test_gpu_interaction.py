@@ -129,6 +129,120 @@ def test_bf16_storage_two_person_forward_against_oracle(case, nocross):
     assert 1e-4 < rel(out[:, 0], ref[:, 0]) < 3e-2          # init-pose rows (joint_embed2 -> ... -> out2)
 
 
+BF16_TRAIN_CASES = {
+    "hd64": dict(B=2, T=33, F=20, d=256, H=4, L=2, ff=256, N=77, Lt=64, num_frames=40, lengths=(33, 12), t=(4, 700)),
+    "hd128": dict(B=1, T=61, F=150, d=256, H=2, L=3, ff=512, N=77, Lt=64, num_frames=60, lengths=(45,), t=(250,)),
+    # the reference's two-person shape (91 tokens x 263 features, d = 512, 8 heads) on 24 x 91 = 2 184 rows: the
+    # weight-stationary GEMMs and the sliced weight-gradient kernel serve the step as they do at full size
+    "rows2184": dict(B=12, T=91, F=263, d=512, H=8, L=2, ff=1024, N=77, Lt=256, num_frames=100,
+                     lengths=(91, 40, 91, 2, 77, 91, 13, 91, 60, 91, 91, 5), t=(0, 999, 500, 250, 7, 650, 313, 900, 77, 42, 810, 123)),
+}
+
+
+@pytest.mark.parametrize("case,nocross", [("hd64", False), ("hd64", True), ("hd128", False), ("rows2184", False)])
+def test_bf16_storage_two_person_backward_every_gradient_against_oracle_autograd(case, nocross):
+    """storage='bf16' TRAINING of the two-person model (what the reference's tools/train.py trains: trainers/mul_ddpm_trainer.py
+    :91-163 over models/interaction_transformer.py:167-207,334-367): forward with kept bf16 activations, backward through the
+    person <-> person attention (the partner's context matrices, the consumer's length), the joint_embed2 / out2 edges of the
+    init-pose rows and the shifted positional table -- EVERY parameter gradient and the three input gradients against torch
+    autograd of the fp32 CPU oracle.  Gates as for the single-person model (tests/test_gpu_bf16_training.py): loss 1e-2,
+    global gradient norm 2e-2, direction 1 - 1e-3, median tensor 3e-2, no tensor beyond 0.15."""
+    c = BF16_TRAIN_CASES[case]
+    m = build(c, no_cross_attn=nocross, storage="bf16").train()
+    inp, gi = case_inputs(c)
+    x, xp, xo = (gi[k].clone().requires_grad_(True) for k in ("x", "xf_proj", "xf_out"))
+    out = m(x, gi["t"], length=gi["length"], xf_proj=xp, xf_out=xo)
+    target = fill.tensor_for("full.target2", inp["x"].shape) * 10.0
+    mask = m.generate_src_mask(c["T"], gi["length"]).to(DEV)
+    loss = (((out - target.to(DEV)) ** 2).mean(-1) * mask).sum() / mask.sum()
+    loss.backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in
+         fill.interaction_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"]).items()}
+    xr, xpr, xor_ = (inp[k].clone().requires_grad_(True) for k in ("x", "xf_proj", "xf_out"))
+    ref = IR.interaction_forward(p, xr, inp["t"], inp["length"], xpr, xor_, c["H"], c["L"], no_cross_attn=nocross)
+    ref_loss = (((ref - target) ** 2).mean(-1) * mask.cpu()).sum() / mask.cpu().sum()
+    ref_loss.backward()
+    named = dict(m.named_parameters())
+    e_out = rel(out, ref)
+    assert 1e-4 < e_out < 3e-2, e_out
+    assert abs(loss.item() - ref_loss.item()) < 1e-2 * abs(ref_loss.item())
+    names = [k for k in p if p[k].grad is not None]
+    zero_grad = [k for k in names if k.endswith(".key.bias")]          # exactly zero in the reference (softmax over tokens)
+    live = [k for k in names if k not in zero_grad]
+    assert any("int_ca_block" in k for k in live) != nocross and "joint_embed2.weight" in live and "out2.weight" in live
+    for k in live:
+        assert named[k].grad is not None and torch.isfinite(named[k].grad).all(), k
+    gn = torch.sqrt(sum((named[k].grad.double() ** 2).sum() for k in live)).item()
+    gn_ref = torch.sqrt(sum((p[k].grad.double() ** 2).sum() for k in live)).item()
+    dot = sum((named[k].grad.double().cpu() * p[k].grad.double()).sum() for k in live).item()
+    errs = sorted(((rel(named[k].grad, p[k].grad), k) for k in live), reverse=True)
+    print("two-person bf16-storage backward %s nocross=%s: out %.2e, loss %.6f vs %.6f, grad norm %.6e vs %.6e (rel %.2e), cosine %.6f" %
+          (case, nocross, e_out, loss.item(), ref_loss.item(), gn, gn_ref, abs(gn - gn_ref) / gn_ref, dot / (gn * gn_ref)))
+    print("   worst tensors: " + ", ".join("%s %.2e" % (k, e) for e, k in errs[:5]))
+    print("   median rel-L2 over %d tensors: %.2e; joint_embed2.weight %.2e, out2.weight %.2e, sequence_embedding %.2e" %
+          (len(errs), errs[len(errs) // 2][0], rel(named["joint_embed2.weight"].grad, p["joint_embed2.weight"].grad),
+           rel(named["out2.weight"].grad, p["out2.weight"].grad), rel(named["sequence_embedding"].grad, p["sequence_embedding"].grad)))
+    assert abs(gn - gn_ref) < 2e-2 * gn_ref, (gn, gn_ref)
+    assert dot / (gn * gn_ref) > 1 - 1e-3
+    assert errs[0][0] < 0.15, errs[0]
+    assert errs[len(errs) // 2][0] < 3e-2
+    if c["num_frames"] > c["T"] - 1:
+        assert named["sequence_embedding"].grad[c["T"] - 1:].abs().max().item() == 0.0  # rows >= T - 1 are never read
+    for a, b in ((x.grad, xr.grad), (xp.grad, xpr.grad), (xo.grad, xor_.grad)):
+        assert rel(a, b) < 5e-2
+    for k in zero_grad:
+        assert named[k].grad.norm().item() < 2e-2 * gn_ref, k
+
+
+@pytest.mark.parametrize("with_label", [False, True])
+def test_fused_two_person_step_with_bf16_storage_tracks_the_fp32_step(with_label):
+    """DDPMMulTrainer.train_step_fused with storage='bf16' (PIT and labelled mode) next to the same steps with fp32 storage:
+    loss within 1e-2, clipped-gradient norm within 2e-2 over three steps; the bf16 weight shadow equals bf16(master) after
+    every step; the hipGraph-captured step replays the eager one bit for bit."""
+    c = BF16_TRAIN_CASES["hd64"]
+    B, T, Fd = c["B"], c["T"], c["F"]
+    rows = 2 * B if with_label else 4 * B
+    x0 = (fill.tensor_for("fused2b.x0", (2 * B, T, Fd)) * 10).to(DEV)
+    g = torch.Generator().manual_seed(11)
+    noises = [torch.randn(x0.shape, generator=g).to(DEV) for _ in range(3)]
+    tt = torch.tensor(c["t"], device=DEV)
+    length = torch.tensor(c["lengths"], device=DEV)
+    xf_proj = (fill.tensor_for("fused2b.xp", (rows, 4 * c["d"])) * 10).to(DEV)
+    xf_out = (fill.tensor_for("fused2b.xo", (rows, c["N"], c["Lt"])) * 10).to(DEV)
+    label = "labels/" if with_label else None
+    runs = {}
+    for storage in ("f32", "bf16"):
+        m = build(c, storage=storage).train()
+        tr = _trainer(c, m, label_path=label)
+        losses, gns = [], []
+        for k in range(3):
+            l = tr.train_step_fused(x0, tt, length, xf_proj, xf_out, noise=noises[k])
+            losses.append(l.item())
+            gns.append(tr.fused_state()["gnorm"].item())
+            if storage == "bf16":
+                fp = m.flat_params()
+                sh = fp.shadow16_buffer()
+                assert torch.equal(sh[:fp.core_numel], fp.flat[:fp.core_numel].to(torch.bfloat16))
+        runs[storage] = (losses, gns)
+    print("two-person fused step, with_label=%s: losses f32 %s bf16 %s, gnorm f32 %s bf16 %s" % (with_label, *[
+        ["%.5f" % v for v in runs[s][i]] for i in (0, 1) for s in ("f32", "bf16")]))
+    for a, b in zip(runs["f32"][0], runs["bf16"][0]):
+        assert abs(a - b) < 1e-2 * abs(a)
+    for a, b in zip(runs["f32"][1], runs["bf16"][1]):
+        assert abs(a - b) < 2e-2 * abs(a)
+    # captured == eager, bit for bit
+    outs = []
+    for captured in (False, True):
+        m = build(c, storage="bf16").train()
+        tr = _trainer(c, m, label_path=label)
+        step = tr.train_step_captured if captured else tr.train_step_fused
+        ls = [step(x0, tt, length, xf_proj, xf_out, noise=noises[k]).item() for k in range(2)]
+        outs.append((ls, {k: v.clone() for k, v in m.state_dict().items()}))
+    assert outs[0][0] == outs[1][0]
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
 def test_swapping_the_two_persons_swaps_the_outputs():
     """Size-independent property at a production-like size: the model is symmetric in the two
     persons, so model(cat[x2, x1]) == swap(model(cat[x1, x2])) when both share text / t / length."""
