@@ -730,6 +730,20 @@ def main():
                 tr2.train_step_captured(x0p, tp, lp, i2["xf_proj"], i2["xf_out"], noise=nz2)
 
             e_pit = timed(pit_step, k2, 2, 1)
+            # the same PIT step with bf16 storage (fp32 master weights + bf16 shadow / activations): its own trainer over a copy
+            # of the model, so that the fp32 step's captured graph and Adam state stay untouched
+            m2b = hig_amd.MotionInteractionTransformer(input_feats=c2["F"], num_frames=196, latent_dim=c2["d"], ff_size=c2["ff"],
+                                                       num_layers=c2["L"], num_heads=c2["H"], text_latent_dim=c2["Lt"], storage="bf16")
+            m2b.load_state_dict(m2.state_dict())
+            m2b = m2b.to(device)
+            tr2b = hig_amd.DDPMMulTrainer(args2, m2b.train())
+
+            def pit_step16():
+                tr2b.train_step_captured(x0p, tp, lp, i2["xf_proj"], i2["xf_out"], noise=nz2)
+
+            e_pit16 = timed(pit_step16, k2, 2, 1)
+            loss_pit32, loss_pit16 = tr2.fused_state()["loss"].item(), tr2b.fused_state()["loss"].item()
+            del tr2b, m2b
             m2.eval()
             m2.storage = "bf16"          # bf16 storage of the two-person forward (inference)
             e_f16 = timed(fwd2, k2, 2, 1)
@@ -754,6 +768,9 @@ def main():
                                                  "captured step replayed %d times; keys = storage" % nst),
                 "pit_train_step_ms": round(e_pit / k2 * 1e3, 3),
                 "pit_train_pairs_per_s": round(16 * k2 / e_pit, 1),
+                "pit_train_step_ms_bf16_storage": round(e_pit16 / k2 * 1e3, 3),
+                "pit_train_pairs_per_s_bf16_storage": round(16 * k2 / e_pit16, 1),
+                "pit_loss_after_the_timed_steps": {"f32": round(loss_pit32, 5), "bf16_storage": round(loss_pit16, 5)},
                 "fwd_frames_per_s": round(c2["B"] * c2["T"] * k2 / e_f, 1), "fwd_ms": round(e_f / k2 * 1e3, 3),
                 "fwd_ms_bf16_storage": round(e_f16 / k2 * 1e3, 3),
                 "fwd_bwd_frames_per_s": round(c2["B"] * c2["T"] * k2 / e_fb, 1), "fwd_bwd_ms": round(e_fb / k2 * 1e3, 3),

@@ -1874,10 +1874,37 @@ extern "C" int hig_denoiser_fwd_bf16_train(const hig_dims* dims, const void* con
   return HIG_OK;
 }
 
+static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* params, const void* const* params16, const float* x,
+                                  const int64_t* t, const int64_t* length, const float* xf_out, const void* textctx,
+                                  const void* workspace, const float* dout, void* const* grads, float* dx, float* dxf_proj,
+                                  float* dxf_out, void* bwd_workspace, hig_stream_t stream, hig_layer_hook hook, void* hook_user,
+                                  hig_stream_t comm_stream);
 extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* params, const void* const* params16, const float* x,
                                      const int64_t* t, const int64_t* length, const float* xf_out, const void* textctx,
                                      const void* workspace, const float* dout, void* const* grads, float* dx, float* dxf_proj,
                                      float* dxf_out, void* bwd_workspace, hig_stream_t stream) {
+  return denoiser_bwd_bf16_impl(dims, params, params16, x, t, length, xf_out, textctx, workspace, dout, grads, dx, dxf_proj, dxf_out,
+                                bwd_workspace, stream, nullptr, nullptr, nullptr);
+}
+// hig_denoiser_bwd_bf16 with the per-layer hook of hig_denoiser_bwd_hooked (include/hig.h): hook(user, l) is called on the host once
+// every parameter gradient of decoder layer l -- its rows of the stacked stylization matrix included -- is enqueued, after
+// `comm_stream` has been made to wait for both of the backward's streams: a data-parallel caller starts the all-reduce of
+// layer l's gradients there, while layers l - 1 ... 0 are still in backward.  Events only, so the call (and the collectives
+// its hook enqueues) can be captured into a hipGraph.
+extern "C" int hig_denoiser_bwd_bf16_hooked(const hig_dims* dims, const void* const* params, const void* const* params16, const float* x,
+                                            const int64_t* t, const int64_t* length, const float* xf_out, const void* textctx,
+                                            const void* workspace, const float* dout, void* const* grads, float* dx, float* dxf_proj,
+                                            float* dxf_out, void* bwd_workspace, hig_stream_t stream, hig_layer_hook hook,
+                                            void* hook_user, hig_stream_t comm_stream) {
+  HIG_REQUIRE(hook, "hig_denoiser_bwd_bf16_hooked: null hook");
+  return denoiser_bwd_bf16_impl(dims, params, params16, x, t, length, xf_out, textctx, workspace, dout, grads, dx, dxf_proj, dxf_out,
+                                bwd_workspace, stream, hook, hook_user, comm_stream);
+}
+static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* params, const void* const* params16, const float* x,
+                                  const int64_t* t, const int64_t* length, const float* xf_out, const void* textctx,
+                                  const void* workspace, const float* dout, void* const* grads, float* dx, float* dxf_proj,
+                                  float* dxf_out, void* bwd_workspace, hig_stream_t stream, hig_layer_hook hook, void* hook_user,
+                                  hig_stream_t comm_stream) {
   (void)t;
   Dims D;
   HIG_TRY(check_dims(dims, D));
@@ -2135,6 +2162,25 @@ extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* pa
     HIG_TRY(hig_ln_bwd_bf16(b + bw.t2, d, hin, 0, d, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B), nullptr, 0, 0, 0, dh, d, dh_alt,
                             0, d, M, d, D.T, GL(grads, l, HIG_L_SA_NORM_W), GL(grads, l, HIG_L_SA_NORM_B), nullptr, 0, lnp, stream));
     { char* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h_in of this layer)
+    if (hook) {
+      // Every parameter gradient of layer l exists once this layer's rows of the stacked stylization matrix are done too (they
+      // only need this layer's columns of dss): d(W_emb)[l] = dss[:, l]^T . silu(emb), one more request on the weight-gradient
+      // stream (hig_denoiser_bwd_hooked does the same).  Then `comm_stream` waits for both streams and the caller is told.
+      const int64_t rows_l = (int64_t)D.nsty * 2 * d;
+      HIG_TRY(wgrad32(G(dss + (int64_t)l * rows_l, ss_ld, 1, reinterpret_cast<const float*>(ws + w.emb), E, 1,
+                        GP(grads, HIG_P_STY_EMB_W) + (int64_t)l * rows_l * E, E, rows_l, E, D.B).silu(1)));
+      if (comm_stream) {
+        hipStream_t cs = hig_stream(comm_stream);
+        hipEvent_t& ev_layer = layer_event();
+        if (!ev_layer && hipEventCreateWithFlags(&ev_layer, hipEventDisableTiming) != hipSuccess)
+          return hig_set_error(HIG_EHIP, "hipEventCreate failed");
+        if (hipEventRecord(ev_layer, st) != hipSuccess || hipStreamWaitEvent(cs, ev_layer, 0) != hipSuccess)
+          return hig_set_error(HIG_EHIP, "layer hook: event on the caller's stream failed");
+        if (fork.side && fork.k > 0 && hipStreamWaitEvent(cs, fork.side->done[(fork.k - 1) & 3], 0) != hipSuccess)
+          return hig_set_error(HIG_EHIP, "layer hook: event on the weight-gradient stream failed");
+      }
+      hook(hook_user, l);
+    }
   }
 
   // ---- joint_embed + sequence_embedding (F-wide: fp32 kernels on an fp32 copy of d(h0)) ---------------------------------------
@@ -2180,7 +2226,8 @@ extern "C" int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* pa
   float* dtmp = reinterpret_cast<float*>(b + bw.dtmp);
   float* dte_h = reinterpret_cast<float*>(b + bw.dte_h);
   HIG_TRY(hig_colsum(dss, ss_ld, D.B, (int)ss_ld, GP(grads, HIG_P_STY_EMB_B), colp, stream));
-  HIG_TRY(hig_gemm_launch(G(dss, ss_ld, 1, emb, E, 1, GP(grads, HIG_P_STY_EMB_W), E, ss_ld, E, D.B).silu(1).g, 1, nullptr, st));
+  if (!hook)   // (with a layer hook the rows of each layer were produced inside that layer's backward)
+    HIG_TRY(hig_gemm_launch(G(dss, ss_ld, 1, emb, E, 1, GP(grads, HIG_P_STY_EMB_W), E, ss_ld, E, D.B).silu(1).g, 1, nullptr, st));
   {
     G gd(dss, ss_ld, 0, P(params, HIG_P_STY_EMB_W), E, 1, dtmp, E, D.B, E, ss_ld);
     int s = (int)(ss_ld / 1024);

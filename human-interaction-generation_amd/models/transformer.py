@@ -783,17 +783,27 @@ class MotionTransformer(nn.Module):
         dx = torch.empty_like(x) if want_dx else None
         dxp = torch.empty(B, self.time_embed_dim, device=dev, dtype=torch.float32)
         dxo = torch.empty(B, N, self.text_latent_dim, device=dev, dtype=torch.float32)
-        if dims.storage == _lib.STORE_BF16:
-            # (no per-layer hook in this mode: a data-parallel caller exchanges the flat gradient after the backward)
+        if dims.storage == _lib.STORE_BF16 and layer_hook is None:
             _lib.check(L.hig_denoiser_bwd_bf16(C.byref(dims), fp.param_table(), fp.shadow16(self._param_version()), _lib.ptr(x),
                                                _lib.ptr(t), _lib.ptr(length), _lib.ptr(xf_out), _lib.ptr(textctx), _lib.ptr(ws),
                                                _lib.ptr(dout), gtable, _lib.ptr(dx), _lib.ptr(dxp), _lib.ptr(dxo), _lib.ptr(bws),
                                                _lib.stream_ptr()))
-            if layer_hook is not None:
-                for l in range(self.num_layers - 1, -1, -1):
-                    if comm_stream is not None:
-                        comm_stream.wait_stream(torch.cuda.current_stream())
-                    layer_hook(l)
+        elif dims.storage == _lib.STORE_BF16:
+            errors = []
+
+            def _hook16(_user, layer):        # an exception must not unwind through the C frames
+                try:
+                    layer_hook(int(layer))
+                except BaseException as e:  # noqa: BLE001
+                    errors.append(e)
+
+            cb = _lib.LAYER_HOOK(_hook16)
+            _lib.check(L.hig_denoiser_bwd_bf16_hooked(
+                C.byref(dims), fp.param_table(), fp.shadow16(self._param_version()), _lib.ptr(x), _lib.ptr(t), _lib.ptr(length),
+                _lib.ptr(xf_out), _lib.ptr(textctx), _lib.ptr(ws), _lib.ptr(dout), gtable, _lib.ptr(dx), _lib.ptr(dxp), _lib.ptr(dxo),
+                _lib.ptr(bws), _lib.stream_ptr(), cb, None, None if comm_stream is None else C.c_void_p(comm_stream.cuda_stream)))
+            if errors:
+                raise errors[0]
         elif layer_hook is None:
             _lib.check(L.hig_denoiser_bwd(C.byref(dims), fp.param_table(), _lib.ptr(x), _lib.ptr(t),
                                           _lib.ptr(length), _lib.ptr(xf_out), _lib.ptr(textctx), _lib.ptr(ws),

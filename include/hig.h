@@ -252,6 +252,15 @@ int hig_denoiser_bwd_bf16(const hig_dims* dims, const void* const* params, const
                           const int64_t* t, const int64_t* length, const float* xf_out, const void* textctx,
                           const void* workspace, const float* dout, void* const* grads, float* dx, float* dxf_proj,
                           float* dxf_out, void* bwd_workspace, hig_stream_t stream);
+/* hig_denoiser_bwd_bf16 with the per-layer hook of hig_denoiser_bwd_hooked below (same contract: hook(user, l) once layer l's
+ * parameter gradients -- its rows of HIG_P_STY_EMB_W included -- are enqueued and `comm_stream` waits for them).  Events
+ * only: capturable into a hipGraph together with the collectives its hook enqueues. */
+typedef void (*hig_layer_hook)(void* user, int32_t layer);
+int hig_denoiser_bwd_bf16_hooked(const hig_dims* dims, const void* const* params, const void* const* params16, const float* x,
+                                 const int64_t* t, const int64_t* length, const float* xf_out, const void* textctx,
+                                 const void* workspace, const float* dout, void* const* grads, float* dx, float* dxf_proj,
+                                 float* dxf_out, void* bwd_workspace, hig_stream_t stream, hig_layer_hook hook, void* hook_user,
+                                 hig_stream_t comm_stream);
 /* Pieces of the above (unit-testable).  hig_ln_bwd_bf16: hig_ln_bwd with bf16 upstream gradients `da`, rows `x` bf16 or fp32
  * (x_f32), residual / result bf16 or fp32 (dx_f32; `res` has the type of `dx`), and the LayerNorm statistics recomputed
  * from x (no `stats` argument).  partial: hig_ln_bwd_partial_floats(rows, n, rows_per_sample) floats. */
@@ -311,8 +320,9 @@ int64_t hig_bwd_workspace_bytes(const hig_dims* dims);
  * gradient, which this variant computes per layer instead of once at the end -- `comm_stream` (optional) is made to
  * wait for them and `hook(user, l)` is called on the host: every entry of `grads` that belongs to layer l, and rows
  * [l * nsty * 2d, (l+1) * nsty * 2d) of HIG_P_STY_EMB_W, are final once `comm_stream` gets there.  The remaining
- * (global) gradients are final when the call's launches on `stream` have completed.  Not for hipGraph capture. */
-typedef void (*hig_layer_hook)(void* user, int32_t layer);
+ * (global) gradients are final when the call's launches on `stream` have completed.  Events only: capturable into a hipGraph
+ * together with what the hook enqueues, once the library's streams / events exist (an eager warm-up call creates them). */
+/* (hig_layer_hook: declared above, next to hig_denoiser_bwd_bf16_hooked) */
 int hig_denoiser_bwd_hooked(const hig_dims* dims, const void* const* params, const float* x,
                             const int64_t* t, const int64_t* length, const float* xf_out,
                             const void* textctx, const void* workspace, const float* dout,

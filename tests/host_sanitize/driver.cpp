@@ -56,14 +56,14 @@ int main() {
           const bool bf16_ok = (hd == 64 || hd == 128) && !(two && attn);
           for (int training = 0; training <= 1; ++training) {
             const int64_t w = hig_workspace_bytes(&D, training), t = hig_textctx_bytes(&D, training);
-            // bf16 storage: inference for head dim 64 / 128; training for the single-person model with linear attention
-            const bool bf16_train_ok = bf16_ok && !two && !attn;
+            // bf16 storage: inference for head dim 64 / 128; training with linear attention (single-person and two-person)
+            const bool bf16_train_ok = bf16_ok && !attn;
             if (storage == 1 && (!bf16_ok || (training && !bf16_train_ok))) { EXPECT(w < 0 && t < 0); continue; }
             if (two && attn) { EXPECT(w < 0); continue; }
             EXPECT(w > 0 && t > 0);
           }
           if (storage == 0 && !(two && attn)) EXPECT(hig_bwd_workspace_bytes(&D) > 0);
-          if (storage == 1) EXPECT((hig_bwd_workspace_bytes(&D) > 0) == (bf16_ok && !two && !attn));
+          if (storage == 1) EXPECT((hig_bwd_workspace_bytes(&D) > 0) == (bf16_ok && !attn));
         }
   // ---- illegal dims: rejected with a message, nothing dereferenced ----
   {
