@@ -467,23 +467,42 @@ def main():
     def train_step_graph():
         trainer.train_step_captured(inp["x0"], inp["t"], inp["length"], inp["xf_proj"], inp["xf_out"], noise=noise)
 
+    def train_step_graph_split():
+        trainer.opt.capture_exchange = False
+        train_step_graph()
+
+    def train_step_graph_overlapped():
+        trainer.opt.capture_exchange = True
+        train_step_graph()
+
     train_step, step_form, form_probe = train_step_eager, "eager launches, per-layer all-reduces overlapped with the backward", None
     if world > 1:
-        # Two forms of the same data-parallel step: (a) eager launches with the gradient exchange issued layer by layer from
-        # inside the backward (RCCL on a side stream), (b) hipGraph A (fwd + bwd) | ONE flat all-reduce | hipGraph B (clip +
-        # Adam).  With a process group alive the eager form pays host-side costs the graphs do not (measured with RCCL at
-        # world 1, profiles/r04_rccl_world1_probe.json: 23.1 vs 21.2 ms without any exchange, +1.0 ms for issuing the 18 bucket
-        # all-reduces from the host hook against +0.1 ms for the flat one), while (a) hides the wire time: which one wins
-        # depends on the node.  Both are timed UNTIMED-region style during warm-up (3 steps each, max over ranks) and the
-        # faster one is the step the K timed steps run.
+        # Three forms of the same data-parallel step: (a) eager launches with the gradient exchange issued layer by layer from
+        # inside the backward (RCCL on a side stream); (b) hipGraph A (fwd + bwd) | ONE flat all-reduce | hipGraph B (clip +
+        # Adam); (c) ONE hipGraph holding the step AND the per-layer all-reduces of (a) -- the overlap without the host cost
+        # (RCCL at world 1, profiles/r05_rccl_world1_probe.json: (a) pays +1.0 ms of host time for the 18 collectives, (c)
+        # +0.04 ms).  All are timed during warm-up (3 steps each, max over ranks) and the fastest one is the step the K timed
+        # steps run; (c) is probed last, and a refused capture leaves the choice between (a) and (b).
+        forms = [(train_step_eager, step_form, "eager_overlapped_ms"),
+                 (train_step_graph_split, "hipGraph A (fwd+bwd) | one flat RCCL all-reduce | hipGraph B (clip+Adam)", "graphs_flat_allreduce_ms"),
+                 (train_step_graph_overlapped, "one hipGraph: fwd + bwd with the per-layer RCCL all-reduces captured beside it + clip + Adam",
+                  "one_graph_overlapped_ms")]
         probe = []
-        for fn in (train_step_eager, train_step_graph):
-            probe.append(timed(fn, 3, 2, world))
-        pick = torch.tensor([probe[0], probe[1]], device=device, dtype=torch.float64)
+        for fn, _, _ in forms:
+            try:
+                probe.append(timed(fn, 3, 2, world))
+            except Exception as e:       # noqa: BLE001  (reported in the line; every rank fails alike or the max below is inf)
+                probe.append(float("inf"))
+                print("bench: step form refused on rank %d: %s" % (rank, e), file=sys.stderr)
+        pick = torch.tensor(probe, device=device, dtype=torch.float64)
         dist.all_reduce(pick, op=dist.ReduceOp.MAX)
-        form_probe = {"eager_overlapped_ms": round(pick[0].item() / 3 * 1e3, 3), "graphs_flat_allreduce_ms": round(pick[1].item() / 3 * 1e3, 3)}
-        if pick[1].item() < pick[0].item():
-            train_step, step_form = train_step_graph, "hipGraph A (fwd+bwd) | one flat RCCL all-reduce | hipGraph B (clip+Adam)"
+        form_probe = {k: (round(pick[j].item() / 3 * 1e3, 3) if pick[j].item() != float("inf") else None)
+                      for j, (_, _, k) in enumerate(forms)}
+        if trainer.fused_state().get("captured_form") != "one graph, exchange inside":
+            form_probe["one_graph_overlapped_ms"] = None            # (the trainer fell back to the split form)
+            pick[2] = float("inf")
+        best = int(torch.argmin(pick).item())
+        train_step, step_form = forms[best][0], forms[best][1]
         trainer.sync_replicas()
 
     def train_what(mode):

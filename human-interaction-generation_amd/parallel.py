@@ -51,20 +51,30 @@ class FlatGradAllReduce:
 
 class OverlappedGradAllReduce:
     """The same exchange, started per decoder layer WHILE the backward is still running (what the reference's DDP
-    reducer does with its buckets, tools/train.py:77-82): hig_denoiser_bwd_hooked reports each layer as soon as its
-    gradients are final, the layer's two flat ranges (its own parameters ~15 MB, its rows of the stacked stylization
-    matrix ~25 MB at config 2) are all-reduced from a side stream, and only the global parameters (+ text head) are
-    left for the end.  xGMI is point-to-point, so ~20-40 MB messages still run at link bandwidth; the exposed part of
-    the exchange shrinks from the whole 324 MB to the last layer's bucket + the tail.
+    reducer does with its buckets, tools/train.py:77-82): hig_denoiser_bwd_hooked / hig_denoiser_bwd_bf16_hooked report
+    each layer as soon as its gradients are final, the layer's two flat ranges (its own parameters ~15 MB, its rows of
+    the stacked stylization matrix ~25 MB at config 2) are all-reduced from a side stream, and only the global
+    parameters (+ text head) are left for the end.  xGMI is point-to-point, so ~20-40 MB messages still run at link
+    bandwidth; the exposed part of the exchange shrinks from the whole 324 MB to the last layer's bucket + the tail.
 
         ex = OverlappedGradAllReduce(); ex.begin(flat_grad, per_layer, tail)
         backward(layer_hook=ex.layer_done, comm_stream=ex.stream)
         world = ex.finish(extra_ranges)     # current stream now waits for every bucket
-    """
 
-    def __init__(self, group=None):
+    The whole sequence may run under stream capture (DDPMTrainer.train_step_captured): the side stream joins the
+    capture through the library's "layer done" event, RCCL's kernels become graph nodes, finish() joins everything back,
+    and a replay costs the host nothing per collective.
+
+    wire="bf16": each bucket travels as bf16 (half the bytes): cast into a staging buffer, all-reduce, cast back -- one
+    extra rounding of every gradient element before the sum over ranks.  Opt-in (the reference's DDP exchanges fp32);
+    tests/test_gpu_rccl.py pins what it does to the clip norm."""
+
+    def __init__(self, group=None, wire="f32"):
+        assert wire in ("f32", "bf16")
         self.group = group
+        self.wire = wire
         self.stream = None
+        self.stage = None
         self.works = []
 
     @staticmethod
@@ -75,11 +85,23 @@ class OverlappedGradAllReduce:
         if self.stream is None or self.stream.device != flat_grad.device:
             self.stream = torch.cuda.Stream(device=flat_grad.device)
         self.grad, self.per_layer, self.tail, self.works = flat_grad, per_layer, tail, []
+        if self.wire == "bf16" and (self.stage is None or self.stage.numel() != flat_grad.numel()
+                                    or self.stage.device != flat_grad.device):
+            self.stage = torch.empty(flat_grad.numel(), device=flat_grad.device, dtype=torch.bfloat16)
 
     def _reduce(self, ranges):
+        """Called with self.stream current."""
         for a, b in ranges:
-            if b > a:
+            if b <= a:
+                continue
+            if self.wire == "f32":
                 self.works.append(dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                continue
+            from . import _lib
+            sp = _lib.stream_ptr()
+            _lib.check(_lib.lib().hig_cast_bf16(_lib.ptr(self.grad[a:b]), _lib.ptr(self.stage[a:b]), b - a, sp))
+            dist.all_reduce(self.stage[a:b], op=dist.ReduceOp.SUM, group=self.group)      # (self.stream waits for RCCL's)
+            _lib.check(_lib.lib().hig_cast_f32(_lib.ptr(self.stage[a:b]), _lib.ptr(self.grad[a:b]), b - a, sp))
 
     def layer_done(self, layer):
         with torch.cuda.stream(self.stream):       # (the library already made this stream wait for the layer)

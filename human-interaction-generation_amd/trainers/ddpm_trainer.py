@@ -360,7 +360,8 @@ class DDPMTrainer(object):
                 "step": torch.zeros(1, device=dev, dtype=torch.int32),
                 "lr": torch.full((1,), float(self.opt.lr), device=dev, dtype=torch.float32),
                 "lr_host": float(self.opt.lr), "covered": 0, "graphs": {}, "ptrs": ptrs,
-                "allreduce": FlatGradAllReduce(), "overlap": OverlappedGradAllReduce(),
+                "allreduce": FlatGradAllReduce(),
+                "overlap": OverlappedGradAllReduce(wire=getattr(self.opt, "grad_wire", "f32")),
             }
         return st
 
@@ -413,6 +414,21 @@ class DDPMTrainer(object):
                                                 layer_hook=exchange.layer_done, comm_stream=exchange.stream)
         if tstate is not None:
             self._text_backward(tstate, dxp, dxo)
+
+    def _fwd_bwd_overlapped_exchange(self, x_start, t, length, xf_proj, xf_out, noise, clip_out, eot):
+        """_fused_fwd_bwd with the gradient exchange of layer l issued while layers l-1 ... 0 are still in backward
+        (RCCL on a side stream); returns the world size.  Capturable: see OverlappedGradAllReduce."""
+        st = self.fused_state()
+        core = _core(self.encoder)
+        fp = core.flat_params()
+        n = self._fused_numel(clip_out is not None)
+        ex = st["overlap"]
+        nsty = 4 if int(getattr(core.dims(1, 1, 1), "two_person", 0)) == 1 else 3   # stylization blocks per layer
+        per_layer, tail = fp.layer_buckets(core.num_layers, nsty, core.latent_dim, core.time_embed_dim)
+        assert per_layer[-1][1][1] - per_layer[0][1][0] == core.num_layers * nsty * 2 * core.latent_dim * core.time_embed_dim
+        ex.begin(fp.grad, per_layer, tail)
+        self._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise, clip_out=clip_out, eot=eot, exchange=ex)
+        return ex.finish([(fp.core_numel, n)] if n > fp.core_numel else ())
 
     def _fused_numel(self, with_text):
         """Floats of the flat buffers one fused step covers: the core, or core + text head."""
@@ -469,16 +485,8 @@ class DDPMTrainer(object):
         self._set_lr(lr)
         core = _core(self.encoder)
         fp = core.flat_params()
-        if (OverlappedGradAllReduce.active() and getattr(self.opt, "overlap_allreduce", True)
-                and type(self)._fused_fwd_bwd is DDPMTrainer._fused_fwd_bwd):
-            # gradient exchange of layer l while layers l-1 ... 0 are still in backward (RCCL on a side stream)
-            ex = st["overlap"]
-            nsty = 4 if int(getattr(core.dims(1, 1, 1), "two_person", 0)) == 1 else 3   # stylization blocks per layer
-            per_layer, tail = fp.layer_buckets(core.num_layers, nsty, core.latent_dim, core.time_embed_dim)
-            assert per_layer[-1][1][1] - per_layer[0][1][0] == core.num_layers * nsty * 2 * core.latent_dim * core.time_embed_dim
-            ex.begin(fp.grad, per_layer, tail)
-            self._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise, clip_out=clip_out, eot=eot, exchange=ex)
-            world = ex.finish([(fp.core_numel, n)] if n > fp.core_numel else ())
+        if OverlappedGradAllReduce.active() and getattr(self.opt, "overlap_allreduce", True):
+            world = self._fwd_bwd_overlapped_exchange(x_start, t, length, xf_proj, xf_out, noise, clip_out, eot)
         else:
             self._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise, clip_out=clip_out, eot=eot)
             world = st["allreduce"](fp.grad[:n])                                  # one all-reduce after the backward
@@ -505,38 +513,46 @@ class DDPMTrainer(object):
 
     def train_step_captured(self, x_start, t, length, xf_proj=None, xf_out=None, noise=None, lr=None, clip_out=None,
                             eot=None):
-        """The same step as hipGraphs.  Captured once per batch shape: graph A = q_sample [+ text head] + forward
-        + loss + backward, graph B = clip + Adam; the RCCL all-reduce of the flat gradient runs between them on
-        the same stream (world == 1: A and B are one graph).  Inputs are copied into static device buffers, so
-        the host cost per step is two graph launches whatever the ~600 kernels inside; `t` arrives from the
-        host sampler through the same staging copy (the reference draws it with numpy,
-        gaussian_diffusion.py:47-62), the learning rate through a device scalar (`_set_lr`).  A graph is keyed on
-        the shapes AND on the flat parameter / gradient buffers it was captured against.  Text inputs as in
-        `train_step_fused`: embeddings, or CLIP features."""
+        """The same step as hipGraphs.  Captured once per batch shape.  One rank: ONE graph (q_sample [+ text head] +
+        forward + loss + backward + clip + Adam).  With a gradient exchange (more than one rank, or HIG_FORCE_EXCHANGE)
+        still ONE graph: the per-layer RCCL all-reduces of `OverlappedGradAllReduce` are captured with the backward they
+        overlap (RCCL's kernels are graph nodes on the communication stream's branch), so a replay costs the host one
+        launch and no per-collective work.  Fallback, taken when `opt.capture_exchange` is False or the capture of the
+        collectives fails: graph A = ... + backward, the all-reduce of the flat gradient enqueued eagerly on the same
+        stream, graph B = clip + Adam.  Inputs are copied into static device buffers; `t` arrives from the host
+        sampler through the same staging copy (the reference draws it with numpy, gaussian_diffusion.py:47-62), the
+        learning rate through a device scalar (`_set_lr`).  A graph is keyed on the shapes AND on the flat parameter /
+        gradient buffers it was captured against.  Text inputs as in `train_step_fused`: embeddings, or CLIP
+        features."""
         st = self.fused_state()
         world = _dist_world()
-        split = exchange_active()         # graph A | all-reduce | graph B (more than one rank, or HIG_FORCE_EXCHANGE)
+        split = exchange_active()         # there is an exchange to run (more than one rank, or HIG_FORCE_EXCHANGE)
+        # (gloo stages through the host: its collectives cannot be captured -- that backend always takes the split form)
+        in_graph = (split and getattr(self.opt, "capture_exchange", True) and getattr(self.opt, "overlap_allreduce", True)
+                    and dist.get_backend() == "nccl")
         with_text = clip_out is not None
         text_in = (clip_out, eot) if with_text else (xf_proj, xf_out)
         n = self._fused_numel(with_text)
         self._set_lr(lr)
         key = (tuple(x_start.shape), tuple(text_in[0].shape), tuple(text_in[1].shape), with_text, noise is None,
-               world, split, st["ptrs"])
+               world, split, in_graph, st["ptrs"])
         cap = st["graphs"].get(key)
         if cap is None:
             static = {"x0": x_start.clone(), "t": t.clone(), "length": length.clone(),
                       "ta": text_in[0].clone(), "tb": text_in[1].clone(),
                       "noise": None if noise is None else noise.clone()}
+            sargs = ((static["x0"], static["t"], static["length"], None, None, static["noise"], static["ta"], static["tb"])
+                     if with_text else
+                     (static["x0"], static["t"], static["length"], static["ta"], static["tb"], static["noise"], None, None))
 
             def part_a():
-                if with_text:
-                    self._fused_fwd_bwd(static["x0"], static["t"], static["length"], None, None, static["noise"],
-                                        clip_out=static["ta"], eot=static["tb"])
-                else:
-                    self._fused_fwd_bwd(static["x0"], static["t"], static["length"], static["ta"], static["tb"],
-                                        static["noise"])
+                self._fused_fwd_bwd(*sargs[:6], clip_out=sargs[6], eot=sargs[7])
 
-            # warm-up (allocations, workspace pools) on a side stream, as torch.cuda.graph requires;
+            def whole_step_with_exchange():
+                w = self._fwd_bwd_overlapped_exchange(*sargs)
+                self._fused_clip_adam(w, with_text)
+
+            # warm-up (allocations, workspace pools, RCCL's communicator) on a side stream, as torch.cuda.graph requires;
             # it runs a real step, so restore parameters / moments / step counter afterwards
             core = _core(self.encoder)
             fp = core.flat_params()
@@ -544,31 +560,49 @@ class DDPMTrainer(object):
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                part_a()
-                self._fused_clip_adam(1, with_text)
+                if in_graph:
+                    whole_step_with_exchange()
+                else:
+                    part_a()
+                    self._fused_clip_adam(1, with_text)
             torch.cuda.current_stream().wait_stream(s)
-            with torch.no_grad():
-                fp.flat.copy_(keep[0])
-                st["m"].copy_(keep[1])
-                st["v"].copy_(keep[2])
-                st["step"].copy_(keep[3])
-            st["covered"] = keep[4]
-            core.params_changed()
-            if getattr(core, "storage", "f32") == "bf16":   # the warm-up's update also wrote the bf16 shadow: re-derive it
-                fp.shadow16(core._param_version())          # from the restored master weights, eagerly (not inside the capture)
+
+            def restore():
+                with torch.no_grad():
+                    fp.flat.copy_(keep[0])
+                    st["m"].copy_(keep[1])
+                    st["v"].copy_(keep[2])
+                    st["step"].copy_(keep[3])
+                st["covered"] = keep[4]
+                core.params_changed()
+                if getattr(core, "storage", "f32") == "bf16":   # the warm-up's update also wrote the bf16 shadow: re-derive it
+                    fp.shadow16(core._param_version())          # from the restored master weights, eagerly (not inside the capture)
+            restore()
             # thread_local: other threads (the RCCL watchdog polls its events) may call into HIP while we capture
             ga, gb = torch.cuda.CUDAGraph(), None
+            if in_graph:
+                try:
+                    with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                        whole_step_with_exchange()
+                except Exception as e:      # RCCL refused the capture: fall back to graph A | eager all-reduce | graph B
+                    torch.cuda.synchronize()
+                    st["capture_exchange_error"] = "%s: %s" % (type(e).__name__, e)
+                    in_graph = False
+                    ga = torch.cuda.CUDAGraph()
+                    restore()
             if not split:
                 with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                     part_a()
                     self._fused_clip_adam(1, with_text)
-            else:
+            elif not in_graph:
                 with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                     part_a()
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
                     self._fused_clip_adam(world, with_text)
             cap = st["graphs"][key] = (static, ga, gb)
+            st["captured_form"] = "one graph" if not split else ("one graph, exchange inside" if in_graph
+                                                                 else "graph A | all-reduce | graph B")
         static, ga, gb = cap
         with torch.no_grad():
             static["x0"].copy_(x_start)

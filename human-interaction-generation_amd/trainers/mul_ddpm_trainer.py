@@ -82,14 +82,15 @@ class DDPMMulTrainer(DDPMTrainer):
         return OrderedDict({'loss_mot_rec': self.loss_mot_rec.item()})
 
     # ---- MI355X fused step (inherits train_step_fused / train_step_captured) ---------------------
-    def _fused_fwd_bwd(self, x_start, t, length, xf_proj, xf_out, noise, clip_out=None, eot=None):
+    def _fused_fwd_bwd(self, x_start, t, length, xf_proj, xf_out, noise, clip_out=None, eot=None, exchange=None):
         """Two-person version of the fused forward/backward: x_start = cat([motion1, motion2]) (2B, T, F),
         t (B,) or (2B,), length (B,) per pair.  PIT mode (no label file): the noised motions run twice,
         rows [m1|c1, m1|c2, m2|c2, m2|c1] -- xf_proj / xf_out must hold the 4B text embeddings in that
         order (2B rows [c1 | c2] with a label file) -- and `hig_pair_mse` picks the cheaper caption
         assignment per pair (mul_ddpm_trainer.py:96-131, 223-247)."""
         if not self.multi:
-            return super()._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise, clip_out=clip_out, eot=eot)
+            return super()._fused_fwd_bwd(x_start, t, length, xf_proj, xf_out, noise, clip_out=clip_out, eot=eot,
+                                          exchange=exchange)
         core = _core(self.encoder)
         L = _lib.lib()
         st = self.fused_state()
@@ -117,7 +118,8 @@ class DDPMMulTrainer(DDPMTrainer):
             scr = st["pair_scratch"] = torch.zeros(2 * rows, device=pred.device, dtype=torch.float32)
         _lib.check(L.hig_pair_mse(_lib.ptr(pred), _lib.ptr(noise.contiguous()), _lib.ptr(len_rows), rows, T, F, int(pit),
                                   _lib.ptr(st["loss"]), _lib.ptr(dpred), _lib.ptr(scr), _lib.stream_ptr()))
-        _, dxp, dxo = core._launch_backward(x_t, t2, len_rows, xf_out, saved, dpred, want_dx=False)
+        hook = {} if exchange is None else dict(layer_hook=exchange.layer_done, comm_stream=exchange.stream)
+        _, dxp, dxo = core._launch_backward(x_t, t2, len_rows, xf_out, saved, dpred, want_dx=False, **hook)
         if tstate is not None:
             self._text_backward(tstate, dxp, dxo)
 

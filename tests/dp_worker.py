@@ -13,14 +13,17 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
-def build_and_inputs():
+def build_and_inputs(storage="f32"):
     import hig_amd
     from oracle import fill
-    c = fill.CASES["config1"]
+    c = dict(fill.CASES["config1"])
+    if storage == "bf16":              # bf16 storage serves head dims 64 / 128: config 1 with d = 256 over 4 heads
+        c.update(d=256, H=4)
     m = hig_amd.MotionTransformer(input_feats=c["F"], num_frames=c["num_frames"], latent_dim=c["d"], ff_size=c["ff"],
                                   num_layers=c["L"], num_heads=c["H"], text_latent_dim=c["Lt"])
     m.load_state_dict(fill.fill_state_dict(m.state_dict()), strict=True)
     m = m.to("cuda").train()
+    m.storage = storage
     B = 4      # global batch; every rank owns B / world samples
     inp = fill.inputs(B, c["T"], c["F"], c["d"], c["N"], c["Lt"], (60, 41, 17, 60), (0, 500, 999, 250))
     gi = {k: v.to("cuda") for k, v in inp.items()}

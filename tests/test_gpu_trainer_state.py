@@ -220,13 +220,37 @@ def test_shutdown_releases_and_recreates_the_side_stream():
     assert _lib.lib().hig_shutdown() == 0
 
 
-def test_backward_with_layer_hook_equals_plain_backward():
-    """hig_denoiser_bwd_hooked: the hook fires once per decoder layer, last layer first, with that layer's gradients
-    final on the comm stream; the whole gradient buffer equals the plain backward's (the stylization emb_layers
-    gradient is computed per layer instead of once at the end: same products, same order)."""
-    c = fill.CASES["width"]
-    m = build(c).train()
-    gi = {k: v.to(DEV) for k, v in fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"]).items()}
+HOOK_CASES = {
+    # name: (oracle case, two-person kind (0 single / 1 interaction block / 2 no_cross_attn), storage)
+    "single-f32": ("width", 0, "f32"), "single-bf16": ("width", 0, "bf16"),
+    "pair-f32": ("config1", 1, "f32"), "pair-bf16": ("width", 1, "bf16"), "pair-nocross-bf16": ("width", 2, "bf16"),
+}
+
+
+@pytest.mark.parametrize("name", list(HOOK_CASES))
+def test_backward_with_layer_hook_equals_plain_backward(name):
+    """hig_denoiser_bwd_hooked / hig_denoiser_bwd_bf16_hooked: the hook fires once per decoder layer, last layer first,
+    with that layer's gradients final on the comm stream; the whole gradient buffer equals the plain backward's (the
+    stylization emb_layers gradient is computed per layer instead of once at the end: same products, same order).
+    Both storage modes, single-person and two-person models (4 stylization blocks per layer with the interaction
+    block)."""
+    case, two, storage = HOOK_CASES[name]
+    c = dict(fill.CASES[case])
+    if two:
+        c["L"] = min(c["L"], 3)
+        m = hig_amd.MotionInteractionTransformer(input_feats=c["F"], num_frames=c["num_frames"], latent_dim=c["d"], ff_size=c["ff"],
+                                                 num_layers=c["L"], num_heads=c["H"], text_latent_dim=c["Lt"],
+                                                 no_cross_attn=(two == 2), storage=storage)
+        m.load_state_dict(fill.fill_state_dict(m.state_dict()), strict=True)
+        m = m.to(DEV).train()
+        T = c["T"]
+        inp = fill.inputs(2 * c["B"], T, c["F"], c["d"], c["N"], c["Lt"], tuple(min(x, T - 1) for x in c["lengths"]) * 2, c["t"] * 2)
+    else:
+        m = build(c).train()
+        m.storage = storage
+        inp = fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"])
+    nsty = 4 if two == 1 else 3
+    gi = {k: v.to(DEV) for k, v in inp.items()}
     dout = (fill.tensor_for("hook.dout", gi["x"].shape) * 10).to(DEV)
     fp = m.flat_params()
 
@@ -241,7 +265,7 @@ def test_backward_with_layer_hook_equals_plain_backward():
         return torch.nan_to_num(fp.grad[:fp.core_numel], nan=0.0)               # (alignment gaps between groups are not)
 
     plain = run()
-    per_layer, tail = fp.layer_buckets(c["L"], 3, c["d"], 4 * c["d"])
+    per_layer, tail = fp.layer_buckets(c["L"], nsty, c["d"], 4 * c["d"])
     covered = torch.zeros(fp.core_numel, dtype=torch.bool)
     for a, b in [r for lay in per_layer for r in lay] + list(tail):
         assert not covered[a:b].any()                   # the buckets partition the flat buffer
