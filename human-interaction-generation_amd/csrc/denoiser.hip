@@ -1209,10 +1209,15 @@ struct WgradFork {
     ++k;
     return HIG_OK;
   }
-  int join() {
+  // `other` waits for everything requested so far (the side stream is in order: the latest event)
+  int wait_on(hipStream_t other) const {
     if (!side || k == 0) return HIG_OK;
-    if (hipStreamWaitEvent(main, side->done[(k - 1) & 3], 0) != hipSuccess)
+    if (hipStreamWaitEvent(other, side->done[(k - 1) & 3], 0) != hipSuccess)
       return hig_set_error(HIG_EHIP, "weight-gradient join failed");
+    return HIG_OK;
+  }
+  int join() {
+    HIG_TRY(wait_on(main));
     k = 0;
     return HIG_OK;
   }
@@ -1507,8 +1512,7 @@ extern "C" int hig_denoiser_bwd_hooked(const hig_dims* dims, const void* const* 
           return hig_set_error(HIG_EHIP, "hipEventCreate failed");
         if (hipEventRecord(ev_layer, st) != hipSuccess || hipStreamWaitEvent(cs, ev_layer, 0) != hipSuccess)
           return hig_set_error(HIG_EHIP, "layer hook: event on the caller's stream failed");
-        if (fork.side && fork.k > 0 && hipStreamWaitEvent(cs, fork.side->done[(fork.k - 1) & 3], 0) != hipSuccess)
-          return hig_set_error(HIG_EHIP, "layer hook: event on the weight-gradient stream failed");
+        HIG_TRY(fork.wait_on(cs));       // (and for everything on the weight-gradient stream)
       }
       hook(hook_user, l);
     }
@@ -1858,9 +1862,20 @@ extern "C" int hig_denoiser_fwd_bf16_train(const hig_dims* dims, const void* con
       hffn = lb + w.h2b;
     }
     // ---- FFN (transformer.py:167-170): z = Lin1(h2) kept for gelu'(z), f = gelu(z) is linear2's operand ----
-    HIG_TRY(hig_gemm16_launch(G16(hffn, d, PL16(params16, l, HIG_L_FFN_W1), d, lb + w.z1, D.ff, M, D.ff, d)
-                                  .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B1)).g, st));
-    HIG_TRY(hig_gelu_bf16(lb + w.z1, lb + w.f1, M * D.ff, stream));
+    // (one launch where the specialised-wave kernel serves the shape: it writes f and, as its second output, z -- both from the
+    // fp32 pre-activation, f exactly as the inference forward computes it; else linear1 and a GELU pass over z)
+    {
+      G16 g1(hffn, d, PL16(params16, l, HIG_L_FFN_W1), d, lb + w.f1, D.ff, M, D.ff, d);
+      g1.epi(HIG_EPI_BIAS_GELU, PL(params, l, HIG_L_FFN_B1));
+      g1.g.aux = lb + w.z1; g1.g.ldaux = D.ff;
+      const int rc = hig_gemm_wsp16_try(g1.g, st);
+      if (rc < 0) return rc;
+      if (rc == 1) {
+        HIG_TRY(hig_gemm16_launch(G16(hffn, d, PL16(params16, l, HIG_L_FFN_W1), d, lb + w.z1, D.ff, M, D.ff, d)
+                                      .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B1)).g, st));
+        HIG_TRY(hig_gelu_bf16(lb + w.z1, lb + w.f1, M * D.ff, stream));
+      }
+    }
     HIG_TRY(hig_gemm16_launch(G16(lb + w.f1, D.ff, PL16(params16, l, HIG_L_FFN_W2), D.ff, lb + w.y3, d, M, d, D.ff)
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_FFN_B2)).g, st));
     HIG_TRY(stylize(D.nsty - 1, lb + w.y3, lb + w.a3, hffn, lb + w.h3, HIG_L_FFN_STY_NORM_W, HIG_L_FFN_STY_NORM_B, HIG_L_FFN_STY_OUT_W, HIG_L_FFN_STY_OUT_B));
@@ -1934,7 +1949,13 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
   char* tA = b + bw.tA;
   char* tB = b + bw.tB;
 
-  WgradFork fork(side_stream_for_current_device(st), st);
+  // bf16 storage: the weight gradients stay on the caller's stream unless HIG_BWD_OVERLAP=1 asks for the fork.  The kernels of
+  // this mode are one-workgroup-per-CU designs (gemm_wsp16: 159 KB of LDS, wgrad16x: 128 KB + twelve waves): two of them cannot
+  // share a CU, so a weight gradient on the second stream delays the workgroups of the data-gradient GEMM CU by CU instead of
+  // filling idle slots -- config 2, captured step: 7.27 ms on one stream, 7.40 forked (7.72 with the LayerNorm reductions
+  // forked as well).  The fp32 step keeps the fork (tiled kernels, several workgroups per CU: 20.4 vs 21.4 ms eager).
+  static const int fork16 = getenv("HIG_BWD_OVERLAP") ? atoi(getenv("HIG_BWD_OVERLAP")) : 0;
+  WgradFork fork(fork16 ? side_stream_for_current_device(st) : nullptr, st);
   hig_stream_t wstream = reinterpret_cast<hig_stream_t>(fork.stream());
   // dW[n][k] = sum_m dC[m][n] act[m][k] (+ the bias gradient = column sums of dC): both operands transposed to
   // reduce-contiguous bf16 (n_out x Mp), (k_in x Mp), then the split-R bf16 GEMM into the fp32 gradient.  Everything on the
@@ -2176,8 +2197,7 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
           return hig_set_error(HIG_EHIP, "hipEventCreate failed");
         if (hipEventRecord(ev_layer, st) != hipSuccess || hipStreamWaitEvent(cs, ev_layer, 0) != hipSuccess)
           return hig_set_error(HIG_EHIP, "layer hook: event on the caller's stream failed");
-        if (fork.side && fork.k > 0 && hipStreamWaitEvent(cs, fork.side->done[(fork.k - 1) & 3], 0) != hipSuccess)
-          return hig_set_error(HIG_EHIP, "layer hook: event on the weight-gradient stream failed");
+        HIG_TRY(fork.wait_on(cs));       // (and for everything on the weight-gradient stream)
       }
       hook(hook_user, l);
     }

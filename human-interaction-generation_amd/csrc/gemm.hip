@@ -881,18 +881,15 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit,
        e += (int64_t)gridDim.x * blockDim.x) {
     // (eight slabs requested before the first is added -- same order of additions, so the same bits: with one load per trip of
     //  a loop whose count the compiler does not know, every split paid a full L2 latency: 13-17 us per reduction of 16-28 MB)
+    // (the last, partial batch as well: loads clamped to the last slab, the surplus not added)
     float4 s = reinterpret_cast<const float4*>(slabs)[e];
-    int k = 1;
-    for (; k + 8 <= nsplit; k += 8) {
+    for (int k = 1; k < nsplit; k += 8) {
       float4 t[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) t[j] = reinterpret_cast<const float4*>(slabs + (int64_t)(k + j) * slab)[e];
+      for (int j = 0; j < 8; ++j) t[j] = reinterpret_cast<const float4*>(slabs + (int64_t)min(k + j, nsplit - 1) * slab)[e];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { s.x += t[j].x; s.y += t[j].y; s.z += t[j].z; s.w += t[j].w; }
-    }
-    for (; k < nsplit; ++k) {
-      const float4 t = reinterpret_cast<const float4*>(slabs + (int64_t)k * slab)[e];
-      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      for (int j = 0; j < 8; ++j)
+        if (k + j < nsplit) { s.x += t[j].x; s.y += t[j].y; s.z += t[j].z; s.w += t[j].w; }
     }
     if (e < n4) {
       if (se.bias) {

@@ -7,6 +7,8 @@
 // per wave-instruction); cross-lane sums by DPP/shuffle butterflies; no LDS for the row itself.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "hig_common.h"
 
 namespace {
@@ -458,6 +460,35 @@ __device__ __forceinline__ float4 ld4g(const __bf16* p) {
   const rbf16x4 t = *reinterpret_cast<const rbf16x4*>(p);
   return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
 }
+// (raw quads: what a lane holds between the request and the first use of a row -- bf16 stays packed)
+template <typename T> struct RawQuad;
+template <> struct RawQuad<float> { typedef float4 type; };
+template <> struct RawQuad<__bf16> { typedef uint2 type; };
+__device__ __forceinline__ float4 ldraw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ uint2 ldraw(const __bf16* p) { return *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ float4 cvtraw(const float4& v) { return v; }
+__device__ __forceinline__ float4 cvtraw(const uint2& v) {
+  return make_float4(__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
+                     __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u));
+}
+typedef unsigned int ru32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int ru32x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ typename RawQuad<T>::type ldraw_buf(__amdgpu_buffer_rsrc_t rs, int byte_off);
+template <> __device__ __forceinline__ uint2 ldraw_buf<__bf16>(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+  const ru32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 0);
+  return make_uint2(v.x, v.y);
+}
+template <> __device__ __forceinline__ float4 ldraw_buf<float>(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+}
+template <typename T> __device__ __forceinline__ void straw_buf(__amdgpu_buffer_rsrc_t rs, int byte_off, const float4& v);
+template <> __device__ __forceinline__ void straw_buf<float>(__amdgpu_buffer_rsrc_t rs, int byte_off, const float4& v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ru32x4, v), rs, byte_off, 0, 0);
+}
+template <> __device__ __forceinline__ void straw_buf<__bf16>(__amdgpu_buffer_rsrc_t rs, int byte_off, const float4& v) {
+  const rbf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ru32x2, o), rs, byte_off, 0, 0);
+}
 __device__ __forceinline__ void st4g(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void st4g(__bf16* p, const float4& v) {
   *reinterpret_cast<rbf16x4*>(p) = rbf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
@@ -498,26 +529,61 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd16_kernel(
     }
   }
   const int stride = NWV * nsplit;
-  for (int rl0 = split * NWV + wave; rl0 < rows_per_sample; rl0 += RPI * stride) {
-    float4 xv[RPI][NIT], dav[RPI][NIT], rv[RPI][NIT];
-    bool live[RPI];
-    int64_t row[RPI];
+  // Software pipeline: the rows of iteration i + 1 are requested (raw: bf16 quads stay packed, two registers) before iteration i
+  // is worked on -- with two waves per SIMD and no prefetch the memory pipe idled during the ~1.5 us of arithmetic and
+  // reductions per iteration and the kernel ran at ~2.4 TB/s.  The loop body is BRANCH-FREE: rows through buffer descriptors of
+  // the sample (an offset beyond the range loads zeros / drops the store without touching memory: rows past the sample's
+  // end, columns past n, and a null `res` as a descriptor of zero bytes), so every iteration issues the same number of
+  // vector-memory instructions and the compiler's s_waitcnt counts are exact -- with branches around the loads it fell back to
+  // vmcnt(0) in front of the arithmetic, i.e. waited for the prefetch it had just issued.
+  const int64_t sample0 = (int64_t)b * rows_per_sample;
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<TX*>(x + sample0 * ldx), 0,
+                                                                        (int)(((int64_t)(rows_per_sample - 1) * ldx + n) * sizeof(TX)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(da + sample0 * ldda), 0,
+                                                                        (int)(((int64_t)(rows_per_sample - 1) * ldda + n) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<TD*>(res ? res + sample0 * ldr : dx), 0,
+                                                                        res ? (int)(((int64_t)(rows_per_sample - 1) * ldr + n) * sizeof(TD)) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(dx + sample0 * lddx, 0,
+                                                                        (int)(((int64_t)(rows_per_sample - 1) * lddx + n) * sizeof(TD)), 0x00020000);
+  constexpr int OOB = 0x7ffffff0;                     // (beyond every range: returns zeros, writes nothing)
+  bool cok[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) cok[it] = 4 * lane + 256 * it < n;
+  typename RawQuad<TX>::type rx[RPI][NIT];
+  typename RawQuad<__bf16>::type rda[RPI][NIT];
+  typename RawQuad<TD>::type rr[RPI][NIT];
+  auto request = [&](int rl0) {
 #pragma unroll
     for (int u = 0; u < RPI; ++u) {
       const int rl = rl0 + u * stride;
-      live[u] = rl < rows_per_sample;                 // (wave-uniform)
-      row[u] = (int64_t)b * rows_per_sample + (live[u] ? rl : rl0);
+      const bool lv = rl < rows_per_sample;             // (wave-uniform)
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int c = 4 * lane + 256 * it;
-        xv[u][it] = dav[u][it] = rv[u][it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < n && live[u]) {
-          xv[u][it] = ld4g(x + row[u] * ldx + c);
-          dav[u][it] = ld4g(da + row[u] * ldda + c);
-          if (res) rv[u][it] = ld4g(res + row[u] * ldr + c);
-        }
+        const bool ok = lv && cok[it];
+        rx[u][it] = ldraw_buf<TX>(rsx, ok ? (int)((rl * (int)ldx + c) * sizeof(TX)) : OOB);
+        rda[u][it] = ldraw_buf<__bf16>(rsd, ok ? (rl * (int)ldda + c) * 2 : OOB);
+        rr[u][it] = ldraw_buf<TD>(rsr, ok ? (int)((rl * (int)ldr + c) * sizeof(TD)) : OOB);
       }
     }
+  };
+  const int rl_first = split * NWV + wave;
+  request(rl_first);
+  for (int rl0 = rl_first; rl0 < rows_per_sample; rl0 += RPI * stride) {
+    float4 xv[RPI][NIT], dav[RPI][NIT], rv[RPI][NIT];
+    bool live[RPI];
+#pragma unroll
+    for (int u = 0; u < RPI; ++u) {
+      live[u] = rl0 + u * stride < rows_per_sample;                 // (wave-uniform)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        xv[u][it] = cvtraw(rx[u][it]);            // (zeros where the request was out of range)
+        dav[u][it] = cvtraw(rda[u][it]);
+        rv[u][it] = cvtraw(rr[u][it]);
+      }
+    }
+    request(rl0 + RPI * stride);
+    __builtin_amdgcn_sched_barrier(0);      // (the scheduler would sink the requests to the end of the body: no prefetch at all)
     float mean[RPI], rstd[RPI];
 #pragma unroll
     for (int u = 0; u < RPI; ++u) {
@@ -531,17 +597,17 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd16_kernel(
       float sq = 0.f;
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const int c = 4 * lane + 256 * it;
-        if (c < n) {
-          const float a0 = xv[u][it].x - mean[u], a1 = xv[u][it].y - mean[u], a2 = xv[u][it].z - mean[u], a3 = xv[u][it].w - mean[u];
-          sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-        }
+        const float a0 = xv[u][it].x - mean[u], a1 = xv[u][it].y - mean[u], a2 = xv[u][it].z - mean[u], a3 = xv[u][it].w - mean[u];
+        const float q = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        sq += cok[it] ? q : 0.f;
       }
       rstd[u] = rsqrtf(wave_sum(sq) * inv_n + 1e-5f);
     }
     // Packed fp32 arithmetic (v_pk_fma / v_pk_mul / v_pk_add_f32: two elements per issue slot) and the 1-ulp reciprocal in
     // the SiLU derivative: the kernel is bound by vector instruction issue (~350 instructions per row in the stylization form
-    // with scalar arithmetic and a correctly rounded division), not by its 38-51 MB of traffic
+    // with scalar arithmetic and a correctly rounded division), not by its 38-51 MB of traffic.
+    // Dead lanes (columns past n) and dead rows hold zeros in `dav`: every product below that reaches an accumulator or a row
+    // sum has the upstream gradient as a factor, so they add exact zeros.
     typedef float v2 __attribute__((ext_vector_type(2)));
     v2 xh[RPI][NIT][2], dxh[RPI][NIT][2];
     float s1[RPI], s2[RPI];
@@ -551,49 +617,45 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd16_kernel(
       const v2 rs2 = {rstd[u], rstd[u]}, nm2 = {-mean[u] * rstd[u], -mean[u] * rstd[u]};
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const int c = 4 * lane + 256 * it;
-        xh[u][it][0] = xh[u][it][1] = dxh[u][it][0] = dxh[u][it][1] = v2{0.f, 0.f};
-        if (c < n && live[u]) {
-          const v2 xs[2] = {{xv[u][it].x, xv[u][it].y}, {xv[u][it].z, xv[u][it].w}};
-          const v2 ds[2] = {{dav[u][it].x, dav[u][it].y}, {dav[u][it].z, dav[u][it].w}};
-          const v2 gs[2] = {{g4[it].x, g4[it].y}, {g4[it].z, g4[it].w}};
-          const v2 bs[2] = {{b4[it].x, b4[it].y}, {b4[it].z, b4[it].w}};
-          const v2 sc1[2] = {{1.0f + sc4[it].x, 1.0f + sc4[it].y}, {1.0f + sc4[it].z, 1.0f + sc4[it].w}};
-          const v2 shs[2] = {{sh4[it].x, sh4[it].y}, {sh4[it].z, sh4[it].w}};
-          v2 dgo[2], dbo[2], dsco[2], dsho[2];
+        const v2 xs[2] = {{xv[u][it].x, xv[u][it].y}, {xv[u][it].z, xv[u][it].w}};
+        const v2 ds[2] = {{dav[u][it].x, dav[u][it].y}, {dav[u][it].z, dav[u][it].w}};
+        const v2 gs[2] = {{g4[it].x, g4[it].y}, {g4[it].z, g4[it].w}};
+        const v2 bs[2] = {{b4[it].x, b4[it].y}, {b4[it].z, b4[it].w}};
+        const v2 sc1[2] = {{1.0f + sc4[it].x, 1.0f + sc4[it].y}, {1.0f + sc4[it].z, 1.0f + sc4[it].w}};
+        const v2 shs[2] = {{sh4[it].x, sh4[it].y}, {sh4[it].z, sh4[it].w}};
+        v2 dgo[2], dbo[2], dsco[2], dsho[2];
 #pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            const v2 xhat = __builtin_elementwise_fma(xs[h2], rs2, nm2);
-            const v2 nrm = __builtin_elementwise_fma(xhat, gs[h2], bs[h2]);
-            v2 dn;
-            if (MOD_SILU) {
-              const v2 uu = __builtin_elementwise_fma(nrm, sc1[h2], shs[h2]);
-              const v2 w = uu * -1.4426950408889634f;
-              const v2 den = v2{__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])} + 1.0f;
-              const v2 sg = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};         // sigmoid(u)
-              const v2 dsil = sg * __builtin_elementwise_fma(uu, 1.0f - sg, v2{1.0f, 1.0f});          // silu'(u) = s (1 + u (1 - s))
-              const v2 du = ds[h2] * dsil;
-              dsho[h2] = du;
-              dsco[h2] = du * nrm;
-              dn = du * sc1[h2];
-            } else {
-              dsho[h2] = dsco[h2] = v2{0.f, 0.f};
-              dn = ds[h2];
-            }
-            dgo[h2] = dn * xhat;
-            dbo[h2] = dn;
-            const v2 dxo = dn * gs[h2];
-            xh[u][it][h2] = xhat;
-            dxh[u][it][h2] = dxo;
-            t1 += dxo;
-            t2 = __builtin_elementwise_fma(dxo, xhat, t2);
-          }
-          a_dg[it].x += dgo[0][0]; a_dg[it].y += dgo[0][1]; a_dg[it].z += dgo[1][0]; a_dg[it].w += dgo[1][1];
-          a_db[it].x += dbo[0][0]; a_db[it].y += dbo[0][1]; a_db[it].z += dbo[1][0]; a_db[it].w += dbo[1][1];
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const v2 xhat = __builtin_elementwise_fma(xs[h2], rs2, nm2);
+          const v2 nrm = __builtin_elementwise_fma(xhat, gs[h2], bs[h2]);
+          v2 dn;
           if (MOD_SILU) {
-            a_dsc[it].x += dsco[0][0]; a_dsc[it].y += dsco[0][1]; a_dsc[it].z += dsco[1][0]; a_dsc[it].w += dsco[1][1];
-            a_dsh[it].x += dsho[0][0]; a_dsh[it].y += dsho[0][1]; a_dsh[it].z += dsho[1][0]; a_dsh[it].w += dsho[1][1];
+            const v2 uu = __builtin_elementwise_fma(nrm, sc1[h2], shs[h2]);
+            const v2 w = uu * -1.4426950408889634f;
+            const v2 den = v2{__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])} + 1.0f;
+            const v2 sg = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};         // sigmoid(u)
+            const v2 dsil = sg * __builtin_elementwise_fma(uu, 1.0f - sg, v2{1.0f, 1.0f});          // silu'(u) = s (1 + u (1 - s))
+            const v2 du = ds[h2] * dsil;
+            dsho[h2] = du;
+            dsco[h2] = du * nrm;
+            dn = du * sc1[h2];
+          } else {
+            dsho[h2] = dsco[h2] = v2{0.f, 0.f};
+            dn = ds[h2];
           }
+          dgo[h2] = dn * xhat;
+          dbo[h2] = dn;
+          const v2 dxo = dn * gs[h2];
+          xh[u][it][h2] = xhat;
+          dxh[u][it][h2] = dxo;
+          t1 += dxo;
+          t2 = __builtin_elementwise_fma(dxo, xhat, t2);
+        }
+        a_dg[it].x += dgo[0][0]; a_dg[it].y += dgo[0][1]; a_dg[it].z += dgo[1][0]; a_dg[it].w += dgo[1][1];
+        a_db[it].x += dbo[0][0]; a_db[it].y += dbo[0][1]; a_db[it].z += dbo[1][0]; a_db[it].w += dbo[1][1];
+        if (MOD_SILU) {
+          a_dsc[it].x += dsco[0][0]; a_dsc[it].y += dsco[0][1]; a_dsc[it].z += dsco[1][0]; a_dsc[it].w += dsco[1][1];
+          a_dsh[it].x += dsho[0][0]; a_dsh[it].y += dsho[0][1]; a_dsh[it].z += dsho[1][0]; a_dsh[it].w += dsho[1][1];
         }
       }
       s1[u] = t1[0] + t1[1];
@@ -606,18 +668,16 @@ __global__ __launch_bounds__(64 * NWV) void ln_bwd16_kernel(
     }
 #pragma unroll
     for (int u = 0; u < RPI; ++u) {
-      if (!live[u]) continue;
+      const int rl = rl0 + u * stride;
       const v2 rs2 = {rstd[u], rstd[u]}, ns1 = {-s1[u], -s1[u]}, ns2 = {-s2[u], -s2[u]};
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int c = 4 * lane + 256 * it;
-        if (c < n) {
-          const v2 r0 = {rv[u][it].x, rv[u][it].y}, r1 = {rv[u][it].z, rv[u][it].w};
-          // rstd (dxh - s1 - xh s2) + res
-          const v2 o0 = __builtin_elementwise_fma(__builtin_elementwise_fma(xh[u][it][0], ns2, dxh[u][it][0] + ns1), rs2, r0);
-          const v2 o1 = __builtin_elementwise_fma(__builtin_elementwise_fma(xh[u][it][1], ns2, dxh[u][it][1] + ns1), rs2, r1);
-          st4g(dx + row[u] * lddx + c, make_float4(o0[0], o0[1], o1[0], o1[1]));
-        }
+        const v2 r0 = {rv[u][it].x, rv[u][it].y}, r1 = {rv[u][it].z, rv[u][it].w};
+        // rstd (dxh - s1 - xh s2) + res
+        const v2 o0 = __builtin_elementwise_fma(__builtin_elementwise_fma(xh[u][it][0], ns2, dxh[u][it][0] + ns1), rs2, r0);
+        const v2 o1 = __builtin_elementwise_fma(__builtin_elementwise_fma(xh[u][it][1], ns2, dxh[u][it][1] + ns1), rs2, r1);
+        straw_buf<TD>(rso, (live[u] && cok[it]) ? (int)((rl * (int)lddx + c) * sizeof(TD)) : OOB, make_float4(o0[0], o0[1], o1[0], o1[1]));
       }
     }
   }
@@ -900,6 +960,11 @@ extern "C" int hig_ln_bwd_bf16(const void* da, int64_t ldda, const void* x, int3
   HIG_REQUIRE(((reinterpret_cast<uintptr_t>(da) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
                 reinterpret_cast<uintptr_t>(res)) & 7) == 0, "hig_ln_bwd_bf16: 8-byte aligned rows");
   HIG_REQUIRE(rows_per_sample > 0 && rows % rows_per_sample == 0, "hig_ln_bwd_bf16: rows %% rows_per_sample");
+  {  // the kernel addresses a sample's rows through buffer descriptors with 32-bit byte offsets
+    const int64_t ldmax = std::max(std::max(ldda, ldx), std::max(lddx, res ? ldr : (int64_t)0));
+    if ((int64_t)rows_per_sample * ldmax * 4 >= (1ll << 31))
+      return hig_set_error(HIG_EUNSUPPORTED, "hig_ln_bwd_bf16: a sample of more than 2 GiB");
+  }
   HIG_REQUIRE(!mod_silu || (ss && dss), "hig_ln_bwd_bf16: modulation needs ss / dss");
   // (the parameter gradients are reduced as a pair: one pointer alone would return HIG_OK and leave that gradient unwritten)
   HIG_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "hig_ln_bwd_bf16: dgamma and dbeta must both be given or both be NULL");

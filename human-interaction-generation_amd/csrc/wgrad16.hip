@@ -269,17 +269,18 @@ __global__ __launch_bounds__(768, 3) void wgrad16x_kernel(const Wg2Args a) {
 __global__ __launch_bounds__(256) void wg16_reduce_kernel(const float* __restrict__ slabs, int nsplit, int64_t slab, int64_t n4,
                                                           float* __restrict__ out, int64_t nb4, float* __restrict__ dbias) {
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n4 + nb4; e += (int64_t)gridDim.x * blockDim.x) {
-    // (eight slabs in flight before the first addition; additions in split order: see reduce_slabs_kernel, gemm.hip)
+    // (eight slabs in flight before the first addition; additions in split order: see reduce_slabs_kernel, gemm.hip.  The last,
+    // partial batch too: its loads are clamped to the last slab and the surplus is not added -- a sequential tail was up to
+    // seven DEPENDENT loads, 20 us for the 8 slabs of an FFN weight against 7 us for the 16 slabs of a 512 x 512 one)
     f32x4 s = reinterpret_cast<const f32x4*>(slabs)[e];
-    int k = 1;
-    for (; k + 8 <= nsplit; k += 8) {
+    for (int k = 1; k < nsplit; k += 8) {
       f32x4 t[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) t[j] = reinterpret_cast<const f32x4*>(slabs + (int64_t)(k + j) * slab)[e];
+      for (int j = 0; j < 8; ++j) t[j] = reinterpret_cast<const f32x4*>(slabs + (int64_t)min(k + j, nsplit - 1) * slab)[e];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += t[j];
+      for (int j = 0; j < 8; ++j)
+        if (k + j < nsplit) s += t[j];
     }
-    for (; k < nsplit; ++k) s += reinterpret_cast<const f32x4*>(slabs + (int64_t)k * slab)[e];
     if (e < n4) reinterpret_cast<f32x4*>(out)[e] = s;
     else reinterpret_cast<f32x4*>(dbias)[e - n4] = s;
   }

@@ -35,7 +35,15 @@ STORAGE=bf16 NO_CAPTURE=1 STEPS=10 rocprofv3 --kernel-trace --stats --output-for
 python3 $R/tools/train16_time.py 2>&1 | grep -v amdgpu.ids | tail -3 > $O/train16_time.txt
 python3 $R/tools/train16_kernels_time.py 2>&1 | grep -v amdgpu.ids > $O/train16_kernels_solo.txt
 python3 $R/tools/rccl_world1_probe.py 2>/dev/null | grep "^{" > $O/rccl_world1_probe.json
-{ for pol in 0 1; do echo "HIG_WS16_STORE=$pol"; HIG_WS16_STORE=$pol python3 $R/tools/gemm16_bench.py 64 2>&1 | grep -v amdgpu.ids | tail -8 | head -5; done; } > $O/ws16_store_policy.txt
 { for f in 1 0; do HIG_LNFOLD32=$f python3 $R/tools/fwd_text_time.py 2>&1 | grep -v amdgpu.ids | tail -1 | sed "s/^/HIG_LNFOLD32=$f /"; done;
   for f in 1 0; do HIG_TEXT_FORK=$f python3 $R/tools/fwd_text_time.py 2>&1 | grep -v amdgpu.ids | tail -1; done; } > $O/fwd32_fold_textfork.txt
 python3 $R/tools/fwd_cfg5_time.py 2>&1 | grep -v amdgpu.ids | tail -1 > $O/cfg5_time.txt
+
+# round 5: micro-probes behind the specialised-wave kernels (L2 -> CU fetch, VALU next to MFMA, LDS read rate), stamps of
+# gemm_wsp16 and of the sliced weight-gradient kernel, per-shape weight-gradient timings, the two-person bf16 step
+for p in l2_fetch_probe coissue_probe lds_read_probe; do [ -x $R/tools/$p ] && $R/tools/$p > $O/$p.txt 2>&1; done
+python3 $R/tools/gemm_wsp16_stamps.py ffn1 64 2>&1 | grep -v amdgpu.ids | tail -14 > $O/wsp16_stamps.txt
+python3 $R/tools/gemm_wsp16_stamps.py qkv 64 2>&1 | grep -v amdgpu.ids | tail -14 >> $O/wsp16_stamps.txt
+python3 $R/tools/wgrad_stamps.py 2>&1 | grep -v amdgpu.ids | tail -12 > $O/wgrad_stamps.txt
+python3 $R/tools/wgrad_time.py 2>&1 | grep -v amdgpu.ids | tail -8 > $O/wgrad_time.txt
+python3 $R/tools/two_person16_time.py 2>&1 | grep -v amdgpu.ids | tail -4 > $O/two_person16_time.txt

@@ -20,6 +20,9 @@ print("B=%d T=%d d=%d L=%d" % (c["B"], c["T"], c["d"], c["L"]))
 for storage in (os.environ.get("STORAGE", "f32,bf16").split(",")):
     m = bench.build_model(c, dev).train(); m.storage = storage
     tr = hig_amd.DDPMTrainer(args, m)
+    if os.environ.get("ONLY_CAPTURED"):
+        g = t(lambda: tr.train_step_captured(i["x0"], i["t"], i["length"], i["xf_proj"], i["xf_out"], noise=noise))
+        print("storage %-5s captured %.3f ms" % (storage, g)); continue
     e = t(lambda: tr.train_step_fused(i["x0"], i["t"], i["length"], i["xf_proj"], i["xf_out"], noise=noise))
     loss = tr.fused_state()["loss"].item()
     if os.environ.get("NO_CAPTURE"):
