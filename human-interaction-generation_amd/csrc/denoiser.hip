@@ -1669,7 +1669,7 @@ Text16TLayout text16t_layout(const Dims& D) {
 }
 
 struct Bwd16Layout {
-  int64_t dhA, dhB, t1, t2, tff, dqkv, dA, dkv, dxfn, dss, demb, dtmp, dte_h, slabs, slab_floats, colpart, colpart_w, lnpart,
+  int64_t dhA, dhB, t1, t2, tff, dqkv, dA, dkv, dxfn, dss, demb, dtmp, dte_h, slabs, slab_floats, colpart, colpart_w, lnpart, lnpart_slot,
       wT, tA, tB, attn, f32a, f32b, Mp, Mtp, total;
   int64_t tok0, hl0, postmp;   // two-person (fp32): init-pose rows of a gradient (B x max(d, F)), of h_L (B x d); d(sequence_embedding) before its shift (T x d)
 };
@@ -1708,7 +1708,8 @@ Bwd16Layout bwd16_layout(const Dims& D) {
   w.colpart = take(colp * 4);
   w.colpart_w = take(colp * 4);
   const int64_t lp = hig_ln_bwd_partial_floats(D.M, D.d, D.T), lpt = hig_ln_bwd_partial_floats(D.Mt, D.Lt, D.N);
-  w.lnpart = take((lp > lpt ? lp : lpt) * 4);
+  w.lnpart_slot = (lp > lpt ? lp : lpt) * 4;      // one partial table per pending LayerNorm backward of a layer (ln_flush)
+  w.lnpart = take(w.lnpart_slot * HIG_LN_RB_MAX);
   w.wT = take(((int64_t)5 * D.d * D.d + (int64_t)3 * D.d * D.d + (int64_t)2 * D.d * D.ff + (int64_t)2 * D.d * D.Lt +
                (D.two == 1 ? (int64_t)4 * D.d * D.d : 0)) * 2);
   const int64_t mrows = w.Mp > w.Mtp ? w.Mp : w.Mtp;
@@ -1961,12 +1962,55 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
   // reduce-contiguous bf16 (n_out x Mp), (k_in x Mp), then the split-R bf16 GEMM into the fp32 gradient.  Everything on the
   // weight-gradient stream (protocol: WgradFork).
   constexpr int wg16 = 1;   // (a former tuning knob, fixed at the value that won its A/B): 0 = transposes + tiled split-R GEMM
-  auto wgrad_act = [&](const void* dC, int n_out, const void* act, int k_in, float* out, int64_t rows, int64_t rows_p, float* dbias) -> int {
+  // The same batching for the LayerNorm / stylization backward: each call of a layer writes its own partial table and
+  // ln_flush() reduces them all (dgamma, dbeta, d(scale, shift)) in one launch at the end of the layer.
+  hig_ln_reduce ln_pending[HIG_LN_RB_MAX];
+  int ln_n = 0;
+  auto ln_flush = [&]() -> int {
+    if (ln_n == 0) return HIG_OK;
+    HIG_TRY(hig_ln_bwd16_reduce_batch(ln_pending, ln_n, st));
+    ln_n = 0;
+    return HIG_OK;
+  };
+  auto ln_bwd16 = [&](const void* da, int64_t ldda, const void* x_, int32_t x_f32, int64_t ldx_, const float* gamma, const float* beta,
+                      const float* ss_, int64_t ss_ld_, int32_t shift_off, int32_t mod, const void* res, int64_t ldr, void* dx_, int32_t dx_f32,
+                      int64_t lddx, int64_t rows, int32_t n, int32_t rps, float* dgamma, float* dbeta, float* dss_, int64_t dss_ld_) -> int {
+    if (ln_n == HIG_LN_RB_MAX) HIG_TRY(ln_flush());
+    float* part = lnp + (int64_t)ln_n * (bw.lnpart_slot / 4);
+    HIG_TRY(hig_ln_bwd16_launch(da, ldda, x_, x_f32, ldx_, gamma, beta, ss_, ss_ld_, shift_off, mod, res, ldr, dx_, dx_f32, lddx, rows, n, rps,
+                                dgamma, dbeta, dss_, dss_ld_, part, stream, &ln_pending[ln_n]));
+    if (ln_pending[ln_n].nsplit > 0) ++ln_n;
+    return HIG_OK;
+  };
+  // The slab reductions of the weight gradients are batched: each gradient keeps its own range of the slab scratch and
+  // wg_flush() sums everything pending in one launch -- at the end of every decoder layer (before the layer hook), before
+  // another user of the slab scratch, when the scratch or the batch is full.  (Inside the captured step a launch costs
+  // 2-3 us of dependency latency whatever it does: 66 reductions of ~5 us were 0.32 ms of the 7.0 ms step.)
+  hig_wg_reduce wg_pending[HIG_WG_RB_MAX];
+  int wg_n = 0;
+  int64_t wg_used = 0;
+  auto wg_flush = [&]() -> int {
+    if (wg_n == 0) { wg_used = 0; return HIG_OK; }
     HIG_TRY(fork.begin());
+    HIG_TRY(hig_wgrad16_reduce_batch(wg_pending, wg_n, fork.stream()));
+    wg_n = 0; wg_used = 0;
+    return fork.end();
+  };
+  auto wgrad_act = [&](const void* dC, int n_out, const void* act, int k_in, float* out, int64_t rows, int64_t rows_p, float* dbias) -> int {
     if (wg16) {   // straight from the row-major operands (transpose reads), bias gradient in the same pass
-      HIG_TRY(hig_wgrad16_launch(dC, n_out, act, k_in, rows, n_out, k_in, out, dbias, 0, slabs, bw.slab_floats, fork.stream()));
+      const int64_t want = hig_wgrad16_rule_floats(rows, n_out, k_in, bw.slab_floats);    // (what the split rule takes of an empty scratch)
+      if (wg_n == HIG_WG_RB_MAX || wg_used + want > bw.slab_floats) HIG_TRY(wg_flush());
+      const int64_t room = bw.slab_floats - wg_used;
+      HIG_TRY(fork.begin());
+      HIG_TRY(hig_wgrad16_launch(dC, n_out, act, k_in, rows, n_out, k_in, out, dbias, 0, slabs + wg_used, room, fork.stream(), &wg_pending[wg_n]));
+      if (wg_pending[wg_n].nsplit > 1) {
+        wg_used += (wg_pending[wg_n].slab * wg_pending[wg_n].nsplit + 63) / 64 * 64;     // (16-byte aligned ranges)
+        ++wg_n;
+      }
       return fork.end();
     }
+    HIG_TRY(wg_flush());
+    HIG_TRY(fork.begin());
     if (dbias) HIG_TRY(hig_colsum_bf16(dC, n_out, rows, n_out, dbias, colp_w, wstream));
     const void* srcs[2] = {dC, act};
     void* dsts[2] = {tA, tB};
@@ -1988,6 +2032,7 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
   };
   // fp32 weight gradients at the F-wide edges (operands fp32, reduce-slow): the fp32 kernel, split over the rows
   auto wgrad32 = [&](G gd) -> int {
+    HIG_TRY(wg_flush());
     HIG_TRY(fork.begin());
     const int s = wgrad_splits(gd.g.I, gd.g.J, gd.g.R, bw.slab_floats, gd.g.prec);
     HIG_TRY(hig_gemm_launch(gd.g, s, slabs, fork.stream()));
@@ -2009,8 +2054,8 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
                      int64_t wt_off, void* dy_out) -> int {
     HIG_TRY(wgrad_act(dh, d, a_saved, d, GL(grads, l, out_w), M, bw.Mp, GL(grads, l, out_b)));
     HIG_TRY(dgrad(dh, d, wt_off, b + bw.t1, d, M, HIG_EPI_NONE, nullptr, 0));
-    return hig_ln_bwd_bf16(b + bw.t1, d, y, 0, d, PL(params, l, norm_w), PL(params, l, norm_b), ssf + (int64_t)s * 2 * d, ss_ld, d, 1, nullptr, 0,
-                           dy_out, 0, d, M, d, D.T, GL(grads, l, norm_w), GL(grads, l, norm_b), dss + (int64_t)s * 2 * d, ss_ld, lnp, stream);
+    return ln_bwd16(b + bw.t1, d, y, 0, d, PL(params, l, norm_w), PL(params, l, norm_b), ssf + (int64_t)s * 2 * d, ss_ld, d, 1, nullptr, 0,
+                           dy_out, 0, d, M, d, D.T, GL(grads, l, norm_w), GL(grads, l, norm_b), dss + (int64_t)s * 2 * d, ss_ld);
   };
 
   // ---- output projection ---------------------------------------------------------------------------------------------------
@@ -2031,6 +2076,7 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
   // weight gradient on wgrad16 into a padded scratch, then the real rows / columns into the gradient (weight-gradient stream)
   auto wgrad_edge = [&](const void* dC, int n_out, const void* act, int k_in, float* scratch, float* sbias, float* out, int out_rows, int out_cols,
                         float* out_bias, int nbias) -> int {
+    HIG_TRY(wg_flush());
     HIG_TRY(fork.begin());
     HIG_TRY(hig_wgrad16_launch(dC, n_out, act, k_in, M, n_out, k_in, scratch, sbias, 0, slabs, bw.slab_floats, fork.stream()));
     if (hipMemcpy2DAsync(out, (size_t)out_cols * 4, scratch, (size_t)k_in * 4, (size_t)out_cols * 4, (size_t)out_rows, hipMemcpyDeviceToDevice,
@@ -2146,8 +2192,8 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
                                        len_partner, dqkv + (int64_t)d * 2, dqkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, D.H, D.hd, stream));
       HIG_TRY(wgrad_act(dqkv, 3 * d, lb + w.xn3, d, GL(grads, l, HIG_L_INT_QKV_W), M, bw.Mp, GL(grads, l, HIG_L_INT_QKV_B)));
       HIG_TRY(dgrad(dqkv, 3 * d, o_iqkv, b + bw.t2, d, M, HIG_EPI_NONE, nullptr, 0));
-      HIG_TRY(hig_ln_bwd_bf16(b + bw.t2, d, lb + w.h2, 0, d, PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B), nullptr, 0, 0, 0, dh, d,
-                              dh_alt, 0, d, M, d, D.T, GL(grads, l, HIG_L_INT_NORM_W), GL(grads, l, HIG_L_INT_NORM_B), nullptr, 0, lnp, stream));
+      HIG_TRY(ln_bwd16(b + bw.t2, d, lb + w.h2, 0, d, PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B), nullptr, 0, 0, 0, dh, d,
+                              dh_alt, 0, d, M, d, D.T, GL(grads, l, HIG_L_INT_NORM_W), GL(grads, l, HIG_L_INT_NORM_B), nullptr, 0));
       { char* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h2)
     }
     // ---- cross attention ---------------------------------------------------------------
@@ -2158,17 +2204,17 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
     const char* dqc = b + bw.t1;
     HIG_TRY(wgrad_act(dqc, d, lb + w.xn2, d, GL(grads, l, HIG_L_CA_Q_W), M, bw.Mp, GL(grads, l, HIG_L_CA_Q_B)));
     HIG_TRY(dgrad(dqc, d, o_caq, b + bw.t2, d, M, HIG_EPI_NONE, nullptr, 0));
-    HIG_TRY(hig_ln_bwd_bf16(b + bw.t2, d, lb + w.h1, 0, d, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B), nullptr, 0, 0, 0, dh, d,
-                            dh_alt, 0, d, M, d, D.T, GL(grads, l, HIG_L_CA_NORM_W), GL(grads, l, HIG_L_CA_NORM_B), nullptr, 0, lnp, stream));
+    HIG_TRY(ln_bwd16(b + bw.t2, d, lb + w.h1, 0, d, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B), nullptr, 0, 0, 0, dh, d,
+                            dh_alt, 0, d, M, d, D.T, GL(grads, l, HIG_L_CA_NORM_W), GL(grads, l, HIG_L_CA_NORM_B), nullptr, 0));
     { char* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h1)
     // text side of this layer: d(A_c) -> d(key, value) -> text_norm -> d(xf_out)
     HIG_TRY(hig_linattn_ctx_bwd_bf16(dA, Ac, tlb + tl.kv, tlb + tl.kv + (int64_t)d * 2, 2 * d, reinterpret_cast<const float*>(tlb + tl.kstc), nullptr,
                                      b + bw.dkv, b + bw.dkv + (int64_t)d * 2, 2 * d, D.B, D.N, D.H, D.hd, stream));
     HIG_TRY(wgrad_act(b + bw.dkv, 2 * d, tlb + tl.xfn, Lt, GL(grads, l, HIG_L_CA_KV_W), Mt, bw.Mtp, GL(grads, l, HIG_L_CA_KV_B)));
     HIG_TRY(dgrad(b + bw.dkv, 2 * d, o_kv, b + bw.dxfn, Lt, Mt, HIG_EPI_NONE, nullptr, 0));
-    HIG_TRY(hig_ln_bwd_bf16(b + bw.dxfn, Lt, xf_out, 1, Lt, PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B), nullptr, 0, 0, 0,
+    HIG_TRY(ln_bwd16(b + bw.dxfn, Lt, xf_out, 1, Lt, PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B), nullptr, 0, 0, 0,
                             l == D.L - 1 ? nullptr : dxf_out, Lt, dxf_out, 1, Lt, Mt, Lt, D.N, GL(grads, l, HIG_L_CA_TNORM_W),
-                            GL(grads, l, HIG_L_CA_TNORM_B), nullptr, 0, lnp, stream));
+                            GL(grads, l, HIG_L_CA_TNORM_B), nullptr, 0));
     // ---- self attention ----------------------------------------------------------------
     HIG_TRY(sty_bwd(l, D.nsty * l, dh, lb + w.y1, lb + w.a1, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W,
                     HIG_L_SA_STY_OUT_B, o_sty1, b + bw.t2));
@@ -2180,9 +2226,11 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
                                      D.B, D.T, D.H, D.hd, stream));
     HIG_TRY(wgrad_act(dqkv, 3 * d, lb + w.xn1, d, GL(grads, l, HIG_L_SA_QKV_W), M, bw.Mp, GL(grads, l, HIG_L_SA_QKV_B)));
     HIG_TRY(dgrad(dqkv, 3 * d, o_qkv, b + bw.t2, d, M, HIG_EPI_NONE, nullptr, 0));
-    HIG_TRY(hig_ln_bwd_bf16(b + bw.t2, d, hin, 0, d, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B), nullptr, 0, 0, 0, dh, d, dh_alt,
-                            0, d, M, d, D.T, GL(grads, l, HIG_L_SA_NORM_W), GL(grads, l, HIG_L_SA_NORM_B), nullptr, 0, lnp, stream));
+    HIG_TRY(ln_bwd16(b + bw.t2, d, hin, 0, d, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B), nullptr, 0, 0, 0, dh, d, dh_alt,
+                            0, d, M, d, D.T, GL(grads, l, HIG_L_SA_NORM_W), GL(grads, l, HIG_L_SA_NORM_B), nullptr, 0));
     { char* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h_in of this layer)
+    HIG_TRY(wg_flush());      // the layer's weight gradients are final from here on
+    HIG_TRY(ln_flush());
     if (hook) {
       // Every parameter gradient of layer l exists once this layer's rows of the stacked stylization matrix are done too (they
       // only need this layer's columns of dss): d(W_emb)[l] = dss[:, l]^T . silu(emb), one more request on the weight-gradient
@@ -2238,6 +2286,8 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
   }
 
   // ---- time / text embedding path (fp32, as hig_denoiser_bwd) --------------------------------------------------------------
+  HIG_TRY(wg_flush());
+  HIG_TRY(ln_flush());
   HIG_TRY(fork.join());
   const float* emb = reinterpret_cast<const float*>(ws + w.emb);
   const float* te_h = reinterpret_cast<const float*>(ws + w.te_h);

@@ -28,8 +28,17 @@ int hig_gemm16_launch(const hig_gemm16_desc& g, hipStream_t st);
 // split-R form of the tiled bf16 kernel + deterministic slab reduction (weight gradients); splits == 0: library rule
 int hig_gemm16_split_launch(const hig_gemm16_desc& g, int splits, float* slabs, int64_t slab_floats, hipStream_t st);
 // dW = dC^T . act (+ dbias = column sums of dC) straight from the row-major bf16 operands (wgrad16.hip: transpose reads)
+// (deferred != NULL: the slab reduction is left to hig_wgrad16_reduce_batch, which sums up to HIG_WG_RB_MAX gradients in one launch)
+struct hig_wg_reduce {
+  const float* slabs; int nsplit; int64_t slab;   // nsplit slabs of `slab` floats: [J x K | J] each
+  int64_t n4; float* out;                          // J K / 4 float4 of dW
+  int64_t nb4; float* dbias;                       // J / 4 float4 of dbias (0: none)
+};
+constexpr int HIG_WG_RB_MAX = 12;
 int hig_wgrad16_launch(const void* dC, int64_t ldd, const void* act, int64_t ldx, int64_t rows, int J, int K, float* dW, float* dbias,
-                       int splits, float* slabs, int64_t slab_floats, hipStream_t st);
+                       int splits, float* slabs, int64_t slab_floats, hipStream_t st, hig_wg_reduce* deferred = nullptr);
+int hig_wgrad16_reduce_batch(const hig_wg_reduce* entries, int n, hipStream_t st);
+int64_t hig_wgrad16_rule_floats(int64_t rows, int J, int K, int64_t room);   // slab floats the split rule takes, given `room`
 // out[e] = sum_s slabs[s * slab + e], e < n (n % 4 == 0, 16-byte aligned), in split order (gemm.hip)
 int hig_reduce_slabs(const float* slabs, int splits, int64_t slab, int64_t n, float* out, hipStream_t st);
 // weight-stationary variant (gemm_ws16.hip): HIG_OK = launched, 1 = shape not served (use the tiled kernel), < 0 = error
@@ -103,3 +112,19 @@ inline int wgrad_splits(int64_t I, int64_t J, int64_t R, int64_t slab_floats, in
 }
 
 }  // namespace
+
+// rowops.hip: hig_ln_bwd_bf16 with the reductions of its partial table left to hig_ln_bwd16_reduce_batch (one launch for up to
+// HIG_LN_RB_MAX calls; each call needs its own partial table until then)
+struct hig_ln_reduce {
+  const float* partial; int samples, nsplit, n;
+  float* dgamma; float* dbeta;
+  int shift_off; float* dss; int64_t dss_ld;       // dss == NULL: a plain LayerNorm (no modulation gradients)
+  int nb_col, nb_dss;
+};
+constexpr int HIG_LN_RB_MAX = 8;
+int hig_ln_bwd16_launch(const void* da, int64_t ldda, const void* x, int32_t x_f32, int64_t ldx, const float* gamma,
+                        const float* beta, const float* ss, int64_t ss_ld, int32_t ss_shift_off, int32_t mod_silu,
+                        const void* res, int64_t ldr, void* dx, int32_t dx_f32, int64_t lddx, int64_t rows, int32_t n,
+                        int32_t rows_per_sample, float* dgamma, float* dbeta, float* dss, int64_t dss_ld,
+                        float* partial, hig_stream_t stream, hig_ln_reduce* deferred);
+int hig_ln_bwd16_reduce_batch(const hig_ln_reduce* entries, int n, hipStream_t st);

@@ -10,6 +10,7 @@
 #include <algorithm>
 
 #include "hig_common.h"
+#include "hig_host.h"
 
 namespace {
 
@@ -335,6 +336,61 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __rest
   }
   dss[(int64_t)b * dss_ld + c] = s2;
   dss[(int64_t)b * dss_ld + shift_off + c] = s3;
+}
+
+// ln_bwd_reduce_kernel for up to HIG_LN_RB_MAX LayerNorm backward calls in ONE launch (the bf16 training step: a decoder layer's
+// five or six calls keep their partial tables and are reduced together at the end of the layer: inside the captured step every
+// launch costs 2-3 us of dependency latency, and these reductions are ~1 us of work each).  Entries without `dss` (the plain
+// LayerNorms) have no blocks of the second kind.
+struct LnReduceBatch {
+  hig_ln_reduce e[HIG_LN_RB_MAX];
+  int block0[HIG_LN_RB_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_batch_kernel(const LnReduceBatch bt) {
+  int m = 0;
+  while (m + 1 < bt.n && (int)blockIdx.x >= bt.block0[m + 1]) ++m;
+  const hig_ln_reduce& q = bt.e[m];
+  const int blk = blockIdx.x - bt.block0[m];
+  const float* __restrict__ partial = q.partial;
+  const int n = q.n;
+  if (blk < q.nb_col) {
+    __shared__ float red[16][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blk * 64 + cx, nr = q.samples * q.nsplit;
+    const int64_t rstride = (int64_t)4 * n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < 2 * n) {
+      int r = ry;
+      for (; r + 48 < nr; r += 64) {
+        s0 += partial[(int64_t)r * rstride + c];
+        s1 += partial[(int64_t)(r + 16) * rstride + c];
+        s2 += partial[(int64_t)(r + 32) * rstride + c];
+        s3 += partial[(int64_t)(r + 48) * rstride + c];
+      }
+      for (; r < nr; r += 16) s0 += partial[(int64_t)r * rstride + c];
+    }
+    red[ry][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ry == 0 && c < 2 * n) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[k][cx];
+      if (c < n) q.dgamma[c] = t; else q.dbeta[c - n] = t;
+    }
+    return;
+  }
+  const int64_t idx = (int64_t)(blk - q.nb_col) * 1024 + threadIdx.x;
+  const int b = (int)(idx / n), c = (int)(idx % n);
+  if (b >= q.samples) return;
+  float s2 = 0.f, s3 = 0.f;
+  for (int s = 0; s < q.nsplit; ++s) {
+    const float* p = partial + ((int64_t)b * q.nsplit + s) * 4 * n;
+    s2 += p[2 * (int64_t)n + c];
+    s3 += p[3 * (int64_t)n + c];
+  }
+  q.dss[(int64_t)b * q.dss_ld + c] = s2;
+  q.dss[(int64_t)b * q.dss_ld + q.shift_off + c] = s3;
 }
 
 // partial[chunk][c] = sum over this chunk's rows of x[row][c]
@@ -949,11 +1005,14 @@ extern "C" int hig_colsum(const float* x, int64_t ldx, int64_t rows, int32_t n, 
 
 
 // ---- bf16-storage training step: row kernels with bf16 I/O -------------------------------------------------------------
-extern "C" int hig_ln_bwd_bf16(const void* da, int64_t ldda, const void* x, int32_t x_f32, int64_t ldx, const float* gamma,
-                               const float* beta, const float* ss, int64_t ss_ld, int32_t ss_shift_off, int32_t mod_silu,
-                               const void* res, int64_t ldr, void* dx, int32_t dx_f32, int64_t lddx, int64_t rows, int32_t n,
-                               int32_t rows_per_sample, float* dgamma, float* dbeta, float* dss, int64_t dss_ld,
-                               float* partial, hig_stream_t stream) {
+// deferred (nullable; needs dgamma and dbeta): the reductions of the partial table are NOT launched -- *deferred describes them for
+// hig_ln_bwd16_reduce_batch, and `partial` must stay untouched until then.
+int hig_ln_bwd16_launch(const void* da, int64_t ldda, const void* x, int32_t x_f32, int64_t ldx, const float* gamma,
+                        const float* beta, const float* ss, int64_t ss_ld, int32_t ss_shift_off, int32_t mod_silu,
+                        const void* res, int64_t ldr, void* dx, int32_t dx_f32, int64_t lddx, int64_t rows, int32_t n,
+                        int32_t rows_per_sample, float* dgamma, float* dbeta, float* dss, int64_t dss_ld,
+                        float* partial, hig_stream_t stream, hig_ln_reduce* deferred) {
+  if (deferred) deferred->nsplit = 0;
   HIG_REQUIRE(da && x && gamma && beta && dx && partial, "hig_ln_bwd_bf16: null argument");
   HIG_REQUIRE(n % 4 == 0 && n <= 1024 && ldda % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && (!res || ldr % 4 == 0),
               "hig_ln_bwd_bf16: n and the leading dimensions must be multiples of 4, n <= 1024 (got %d)", n);
@@ -1007,6 +1066,14 @@ extern "C" int hig_ln_bwd_bf16(const void* da, int64_t ldda, const void* x, int3
 #undef LNB16
 #undef LNB16_W
   HIG_CHECK_LAUNCH();
+  if (deferred && dgamma && dbeta) {
+    deferred->partial = partial; deferred->samples = samples; deferred->nsplit = nsplit; deferred->n = n;
+    deferred->dgamma = dgamma; deferred->dbeta = dbeta; deferred->shift_off = ss_shift_off;
+    deferred->dss = mod_silu ? dss : nullptr; deferred->dss_ld = dss_ld;
+    deferred->nb_col = (2 * n + 63) / 64;
+    deferred->nb_dss = mod_silu ? (int)(((int64_t)samples * n + 1023) / 1024) : 0;
+    return HIG_OK;
+  }
   if (dgamma && dbeta && mod_silu) {
     const int nb_col = (2 * n + 63) / 64;
     const int nb_dss = (int)(((int64_t)samples * n + 1023) / 1024);
@@ -1025,6 +1092,34 @@ extern "C" int hig_ln_bwd_bf16(const void* da, int64_t ldda, const void* x, int3
                        nsplit, n, ss_shift_off, dss, dss_ld);
     HIG_CHECK_LAUNCH();
   }
+  return HIG_OK;
+}
+
+extern "C" int hig_ln_bwd_bf16(const void* da, int64_t ldda, const void* x, int32_t x_f32, int64_t ldx, const float* gamma,
+                               const float* beta, const float* ss, int64_t ss_ld, int32_t ss_shift_off, int32_t mod_silu,
+                               const void* res, int64_t ldr, void* dx, int32_t dx_f32, int64_t lddx, int64_t rows, int32_t n,
+                               int32_t rows_per_sample, float* dgamma, float* dbeta, float* dss, int64_t dss_ld,
+                               float* partial, hig_stream_t stream) {
+  return hig_ln_bwd16_launch(da, ldda, x, x_f32, ldx, gamma, beta, ss, ss_ld, ss_shift_off, mod_silu, res, ldr, dx, dx_f32, lddx, rows, n,
+                             rows_per_sample, dgamma, dbeta, dss, dss_ld, partial, stream, nullptr);
+}
+
+int hig_ln_bwd16_reduce_batch(const hig_ln_reduce* entries, int n, hipStream_t st) {
+  HIG_REQUIRE(n >= 0 && n <= HIG_LN_RB_MAX, "hig_ln_bwd16_reduce_batch: at most %d entries", HIG_LN_RB_MAX);
+  LnReduceBatch b;
+  b.n = 0;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (entries[i].nsplit <= 0) continue;
+    b.e[b.n] = entries[i];
+    b.block0[b.n] = blocks;
+    blocks += entries[i].nb_col + entries[i].nb_dss;
+    ++b.n;
+  }
+  if (b.n == 0) return HIG_OK;
+  b.block0[b.n] = blocks;
+  hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, b);
+  HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
 

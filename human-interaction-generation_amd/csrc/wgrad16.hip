@@ -286,14 +286,65 @@ __global__ __launch_bounds__(256) void wg16_reduce_kernel(const float* __restric
   }
 }
 
+// The same reduction for up to WG_RB_MAX weight gradients in ONE launch (the training step's backward: a decoder layer's eight
+// gradients wait in their own slab ranges and are summed together at the end of the layer -- 66 launches of ~5 us, mostly
+// launch latency inside the captured step, become 8).  Block -> (entry, block of the entry) through a prefix table.
+struct WgReduceBatch {
+  hig_wg_reduce e[HIG_WG_RB_MAX];
+  int block0[HIG_WG_RB_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void wg16_reduce_batch_kernel(const WgReduceBatch b) {
+  int m = 0;
+  while (m + 1 < b.n && (int)blockIdx.x >= b.block0[m + 1]) ++m;
+  const hig_wg_reduce& r = b.e[m];
+  const float* __restrict__ slabs = r.slabs;
+  const int nsplit = r.nsplit;
+  const int64_t slab = r.slab, n4 = r.n4, total = r.n4 + r.nb4;
+  const int nblk = b.block0[m + 1] - b.block0[m];
+  for (int64_t e = (blockIdx.x - b.block0[m]) * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)nblk * blockDim.x) {
+    f32x4 s = reinterpret_cast<const f32x4*>(slabs)[e];
+    for (int k = 1; k < nsplit; k += 8) {
+      f32x4 t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = reinterpret_cast<const f32x4*>(slabs + (int64_t)min(k + j, nsplit - 1) * slab)[e];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k + j < nsplit) s += t[j];
+    }
+    if (e < n4) reinterpret_cast<f32x4*>(r.out)[e] = s;
+    else reinterpret_cast<f32x4*>(r.dbias)[e - n4] = s;
+  }
+}
+
 }  // namespace
 
 // dW (J, K) fp32 dense and dbias (J) fp32 (nullable) from dC (rows, J) and act (rows, K), bf16 row-major.  J, K multiples of 8
 // (J K and J multiples of 4 for the slab reduction), 16-byte aligned operands, leading dimensions multiples of 8.
 // splits == 0: the library's rule.  slabs: hig_wgrad_bf16_scratch_floats(J, K, splits) floats.
+// The library's split rule: floats of slab scratch a gradient of this shape uses (splits x (J K + J); J K + J means "one split, no
+// slabs").  units = tiles x splits fill, without exceeding, the CUs (128 KB of LDS, twelve waves: one workgroup per CU); at least
+// four 64-row chunks per unit (the DMA ring needs a few to overlap); the slabs must fit into `room` floats.
+int64_t hig_wgrad16_rule_floats(int64_t rows, int J, int K, int64_t room) {
+  const int ntiles = ((J + 127) / 128) * ((K + 127) / 128);
+  const int64_t slab = (int64_t)J * K + J;
+  const int nchunks = (int)((rows + 63) / 64);
+  int splits = 1;
+  const int target = hig_chip_cus();
+  for (int s = 2; s <= 64; ++s) {
+    const int cps = (nchunks + s - 1) / s;                    // chunks per split
+    if (cps < 4 || (int64_t)ntiles * s > target || slab * s > room) break;
+    splits = s;
+  }
+  return slab * splits;
+}
+
+// deferred (nullable): the slab reduction is NOT launched; *deferred describes it for hig_wgrad16_reduce_batch (nsplit = 0 when
+// the gradient needed no slabs) and the slabs must stay untouched until then.
 int hig_wgrad16_launch(const void* dC, int64_t ldd, const void* act, int64_t ldx, int64_t rows, int J, int K, float* dW, float* dbias,
-                       int splits, float* slabs, int64_t slab_floats, hipStream_t st) {
+                       int splits, float* slabs, int64_t slab_floats, hipStream_t st, hig_wg_reduce* deferred) {
   HIG_REQUIRE(dC && act && dW && rows > 0 && J > 0 && K > 0, "hig_wgrad_bf16: bad arguments");
+  if (deferred) deferred->nsplit = 0;
   HIG_REQUIRE(J % 8 == 0 && K % 8 == 0 && ldd % 8 == 0 && ldx % 8 == 0 &&
                   ((reinterpret_cast<uintptr_t>(dC) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(dW) |
                     reinterpret_cast<uintptr_t>(dbias) | reinterpret_cast<uintptr_t>(slabs)) & 15) == 0,
@@ -305,17 +356,7 @@ int hig_wgrad16_launch(const void* dC, int64_t ldd, const void* act, int64_t ldx
   // the buffer descriptors of the loader waves address the rows with 32-bit byte offsets
   if (rows * ldd * 2 >= (1ll << 31) || rows * ldx * 2 >= (1ll << 31))
     return hig_set_error(HIG_EUNSUPPORTED, "hig_wgrad_bf16: an operand of more than 2 GiB");
-  if (splits <= 0) {
-    // units = tiles x splits fill, without exceeding, the CUs (128 KB of LDS, twelve waves: one workgroup per CU); at least
-    // four 64-row chunks per unit (the DMA ring needs a few to overlap); the slabs must fit
-    splits = 1;
-    const int target = hig_chip_cus();
-    for (int s = 2; s <= 64; ++s) {
-      const int cps = (nchunks + s - 1) / s;                    // chunks per split
-      if (cps < 4 || (int64_t)ntiles * s > target || !slabs || slab * s > slab_floats) break;
-      splits = s;
-    }
-  }
+  if (splits <= 0) splits = (int)(hig_wgrad16_rule_floats(rows, J, K, slabs ? slab_floats : 0) / slab);
   if (splits > nchunks) splits = nchunks;        // (slices are chunk ranges of near-equal length: none is empty)
   HIG_REQUIRE(splits == 1 || (slabs && slab * splits <= slab_floats), "hig_wgrad_bf16: slab scratch too small");
   Wg2Args a;
@@ -332,11 +373,37 @@ int hig_wgrad16_launch(const void* dC, int64_t ldd, const void* act, int64_t ldx
   if (splits > 1) {
     const int64_t n4 = (int64_t)J * K / 4, nb4 = dbias ? J / 4 : 0;
     HIG_REQUIRE(((int64_t)J * K) % 4 == 0 && J % 4 == 0, "hig_wgrad_bf16: J K and J must be multiples of 4");
+    if (deferred) {
+      deferred->slabs = slabs; deferred->nsplit = splits; deferred->slab = slab; deferred->n4 = n4; deferred->out = dW;
+      deferred->nb4 = nb4; deferred->dbias = dbias;
+      return HIG_OK;
+    }
     int64_t blocks = (n4 + nb4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(wg16_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slabs, splits, slab, n4, dW, nb4, dbias);
     HIG_CHECK_LAUNCH();
   }
+  return HIG_OK;
+}
+
+int hig_wgrad16_reduce_batch(const hig_wg_reduce* entries, int n, hipStream_t st) {
+  HIG_REQUIRE(n >= 0 && n <= HIG_WG_RB_MAX, "hig_wgrad16_reduce_batch: at most %d entries", HIG_WG_RB_MAX);
+  WgReduceBatch b;
+  b.n = 0;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (entries[i].nsplit <= 1) continue;
+    b.e[b.n] = entries[i];
+    b.block0[b.n] = blocks;
+    int64_t nb = (entries[i].n4 + entries[i].nb4 + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    blocks += (int)nb;
+    ++b.n;
+  }
+  if (b.n == 0) return HIG_OK;
+  b.block0[b.n] = blocks;
+  hipLaunchKernelGGL(wg16_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+  HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
 
@@ -353,5 +420,5 @@ extern "C" int64_t hig_wgrad_bf16_scratch_floats(int32_t J, int32_t K, int32_t s
 }
 extern "C" int hig_wgrad_bf16(const void* dC, int64_t ldd, const void* act, int64_t ldx, int64_t rows, int32_t J, int32_t K, float* dW,
                               float* dbias, int32_t splits, float* slabs, int64_t slab_floats, hig_stream_t stream) {
-  return hig_wgrad16_launch(dC, ldd, act, ldx, rows, J, K, dW, dbias, splits, slabs, slab_floats, hig_stream(stream));
+  return hig_wgrad16_launch(dC, ldd, act, ldx, rows, J, K, dW, dbias, splits, slabs, slab_floats, hig_stream(stream), nullptr);
 }
