@@ -81,7 +81,6 @@ class GemmDesc(C.Structure):
         ("pos", C.c_void_p), ("ldpos", C.c_int64), ("T", C.c_int32), ("pos_shift", C.c_int32),
         ("xcolsum", C.c_void_p),
         ("row_stats_out", C.c_void_p), ("row_stats_in", C.c_void_p), ("ln_colsum", C.c_void_p),
-        ("aux", C.c_void_p), ("ldaux", C.c_int64),
     ]
 
 

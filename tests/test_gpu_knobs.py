@@ -12,9 +12,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# (switch, flipped value): the default of every switch is the other implementation
+# (switch, flipped value): the default of every switch is the other implementation (HIG_BWD_OVERLAP: unset = weight gradients of
+# the fp32 backward on the second stream, of the bf16-storage backward on the caller's; 0 / 1 = neither / both)
 KNOBS = [
-    ("HIG_BWD_OVERLAP", "0"), ("HIG_TEXT_FORK", "0"), ("HIG_FWD_SPLIT", "0"), ("HIG_LNFOLD32", "0"), ("HIG_GEMM_TAIL", "0"),
+    ("HIG_BWD_OVERLAP", "0"), ("HIG_BWD_OVERLAP", "1"), ("HIG_TEXT_FORK", "0"), ("HIG_FWD_SPLIT", "0"), ("HIG_LNFOLD32", "0"), ("HIG_GEMM_TAIL", "0"),
     ("HIG_GEMM_TILE", "128"), ("HIG_FEW_ROWS_SPLIT", "0"), ("HIG_FULLATTN_WAVES", "4"), ("HIG_FULLATTN_VALU", "1"),
     ("HIG_CTX16", "0"), ("HIG_FWD16_FORK", "0"), ("HIG_JOINT16", "0"), ("HIG_FUSE_APPLY", "0"), ("HIG_FUSE_OUT", "0"),
     ("HIG_EDGE16", "0"), ("HIG_BF16_TILE", "64"), ("HIG_BF16_FEWROW", "0"), ("HIG_BF16_WS", "0"), ("HIG_BF16_WSP", "0"),
@@ -36,14 +37,14 @@ def digests():
     """Every child once, four at a time (a child is mostly interpreter start-up and parameter generation on the host; the GPU
     passes are milliseconds): {"": default digest, switch: digest with that switch flipped}."""
     from concurrent.futures import ThreadPoolExecutor
-    jobs = [("", {})] + [(k, {k: v}) for k, v in KNOBS]
+    jobs = [("", {})] + [("%s=%s" % (k, v), {k: v}) for k, v in KNOBS]
     with ThreadPoolExecutor(max_workers=4) as pool:
         return dict(zip([j[0] for j in jobs], pool.map(lambda j: run(j[1]), jobs)))
 
 
 @pytest.mark.parametrize("knob,value", KNOBS)
 def test_every_switch_selects_between_implementations_of_the_same_arithmetic(knob, value, digests):
-    default_digest, d = digests[""], digests[knob]
+    default_digest, d = digests[""], digests["%s=%s" % (knob, value)]
     assert "error" not in default_digest, default_digest.get("error")
     assert "error" not in d, (knob, d.get("error"))
     assert set(d) == set(default_digest)
