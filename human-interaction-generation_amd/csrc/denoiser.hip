@@ -1824,10 +1824,27 @@ extern "C" int hig_denoiser_fwd_bf16_train(const hig_dims* dims, const void* con
   for (int l = 0; l < D.L; ++l) {
     char* lb = ws + w.layer0 + w.lstride * l;
     const float* ssl = ss + (int64_t)(D.nsty * l) * 2 * d;
+    static const int fuse_env = getenv("HIG_FUSE_APPLY") ? atoi(getenv("HIG_FUSE_APPLY")) : 2;   // tuning knob (as the inference forward)
+    const bool fuse_front = fuse_env == 2 && (D.hd == 64 || D.hd == 128) && (D.H == 4 || D.H == 8);
     // one stylization block: h_out = h_in + Lin_out( silu( LN(y) (1 + scale) + shift ) )     (transformer.py:81-86)
+    auto sty_out = [&](const void* a, const void* h_in, void* h_out, int out_w, int out_b) -> int {
+      return hig_gemm16_launch(G16(a, d, PL16(params16, l, out_w), d, h_out, d, M, d, d).epi(HIG_EPI_BIAS_RES, PL(params, l, out_b)).res16(h_in, d).g, st);
+    };
     auto stylize = [&](int slot, const void* y, void* a, const void* h_in, void* h_out, int norm_w, int norm_b, int out_w, int out_b) -> int {
       HIG_TRY(hig_ln_bf16(y, 0, d, M, d, PL(params, l, norm_w), PL(params, l, norm_b), ssl + (int64_t)slot * 2 * d, ss_ld, d, D.T, a, d, stream));
-      return hig_gemm16_launch(G16(a, d, PL16(params16, l, out_w), d, h_out, d, M, d, d).epi(HIG_EPI_BIAS_RES, PL(params, l, out_b)).res16(h_in, d).g, st);
+      return sty_out(a, h_in, h_out, out_w, out_b);
+    };
+    // attention output -> stylization front: y = softmax(q) . A, LayerNorm, modulation, SiLU as ONE kernel that also writes y (the
+    // backward needs it); Bq samples starting at sample b0 (the person <-> person block runs the two halves against swapped contexts)
+    auto attn_front = [&](int slot, const void* q, int64_t ldq, const float* A32, const void* At16_, char* y, char* a, int norm_w, int norm_b,
+                          int b0, int Bq) -> int {
+      const int64_t r0 = (int64_t)b0 * D.T;
+      const float* ssb = ssl + (int64_t)slot * 2 * d + (int64_t)b0 * ss_ld;
+      if (fuse_front)
+        return hig_linattn_apply_sty_mm16_y(static_cast<const char*>(q) + r0 * ldq * 2, ldq, At16_, PL(params, l, norm_w), PL(params, l, norm_b), ssb,
+                                            ss_ld, d, a + r0 * d * 2, d, y + r0 * d * 2, d, Bq, D.T, D.H, D.hd, stream);
+      HIG_TRY(hig_linattn_apply_bf16(static_cast<const char*>(q) + r0 * ldq * 2, ldq, A32, y + r0 * d * 2, d, Bq, D.T, D.H, D.hd, stream));
+      return hig_ln_bf16(y + r0 * d * 2, 0, d, (int64_t)Bq * D.T, d, PL(params, l, norm_w), PL(params, l, norm_b), ssb, ss_ld, d, D.T, a + r0 * d * 2, d, stream);
     };
     // ---- self attention (transformer.py:101-119) ----
     HIG_TRY(hig_ln_bf16(hin, 0, d, M, d, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B), nullptr, 0, 0, 0, lb + w.xn1, d, stream));
@@ -1836,15 +1853,15 @@ extern "C" int hig_denoiser_fwd_bf16_train(const hig_dims* dims, const void* con
     char* qkv = lb + w.qkv;
     HIG_TRY(ctx16(D, qkv + (int64_t)d * 2, qkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, length, reinterpret_cast<float*>(lb + w.A1),
                   reinterpret_cast<float*>(lb + w.kst1), reinterpret_cast<float*>(ws + w.cscr), lb + w.At1, stream));
-    HIG_TRY(hig_linattn_apply_bf16(qkv, 3 * d, reinterpret_cast<const float*>(lb + w.A1), lb + w.y1, d, D.B, D.T, D.H, D.hd, stream));
-    HIG_TRY(stylize(0, lb + w.y1, lb + w.a1, hin, lb + w.h1, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B));
+    HIG_TRY(attn_front(0, qkv, 3 * d, reinterpret_cast<const float*>(lb + w.A1), lb + w.At1, lb + w.y1, lb + w.a1, HIG_L_SA_STY_NORM_W, HIG_L_SA_STY_NORM_B, 0, D.B));
+    HIG_TRY(sty_out(lb + w.a1, hin, lb + w.h1, HIG_L_SA_STY_OUT_W, HIG_L_SA_STY_OUT_B));
     // ---- cross attention to the text context (transformer.py:135-155) ----
     HIG_TRY(hig_ln_bf16(lb + w.h1, 0, d, M, d, PL(params, l, HIG_L_CA_NORM_W), PL(params, l, HIG_L_CA_NORM_B), nullptr, 0, 0, 0, lb + w.xn2, d, stream));
     HIG_TRY(hig_gemm16_launch(G16(lb + w.xn2, d, PL16(params16, l, HIG_L_CA_Q_W), d, lb + w.qc, d, M, d, d)
                                   .epi(HIG_EPI_BIAS, PL(params, l, HIG_L_CA_Q_B)).g, st));
-    HIG_TRY(hig_linattn_apply_bf16(lb + w.qc, d, reinterpret_cast<const float*>(tc + tl.layer0 + tl.lstride * l + tl.Ac), lb + w.y2, d, D.B,
-                                   D.T, D.H, D.hd, stream));
-    HIG_TRY(stylize(1, lb + w.y2, lb + w.a2, lb + w.h1, lb + w.h2, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B));
+    HIG_TRY(attn_front(1, lb + w.qc, d, reinterpret_cast<const float*>(tc + tl.layer0 + tl.lstride * l + tl.Ac), tc + tl.layer0 + tl.lstride * l + tl.Atc,
+                       lb + w.y2, lb + w.a2, HIG_L_CA_STY_NORM_W, HIG_L_CA_STY_NORM_B, 0, D.B));
+    HIG_TRY(sty_out(lb + w.a2, lb + w.h1, lb + w.h2, HIG_L_CA_STY_OUT_W, HIG_L_CA_STY_OUT_B));
     const void* hffn = lb + w.h2;
     if (D.two == 1) {
       // ---- person <-> person linear cross attention (interaction_transformer.py:181-205): queries from the own stream, key /
@@ -1857,9 +1874,10 @@ extern "C" int hig_denoiser_fwd_bf16_train(const hig_dims* dims, const void* con
       HIG_TRY(ctx16(D, iqkv + (int64_t)d * 2, iqkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, len_partner, Ai, reinterpret_cast<float*>(lb + w.ksti),
                     reinterpret_cast<float*>(ws + w.cscr), lb + w.Ati, stream));
       const int64_t halfA = (int64_t)Bp * D.H * D.hd * D.hd, halfM = (int64_t)Bp * D.T;
-      HIG_TRY(hig_linattn_apply_bf16(iqkv, 3 * d, Ai + halfA, lb + w.y4, d, Bp, D.T, D.H, D.hd, stream));
-      HIG_TRY(hig_linattn_apply_bf16(iqkv + halfM * 3 * d * 2, 3 * d, Ai, lb + w.y4 + halfM * d * 2, d, Bp, D.T, D.H, D.hd, stream));
-      HIG_TRY(stylize(2, lb + w.y4, lb + w.a4, lb + w.h2, lb + w.h2b, HIG_L_INT_STY_NORM_W, HIG_L_INT_STY_NORM_B, HIG_L_INT_STY_OUT_W, HIG_L_INT_STY_OUT_B));
+      // (person 1's queries against person 2's context and vice versa: the halves of A / At swapped)
+      HIG_TRY(attn_front(2, iqkv, 3 * d, Ai + halfA, lb + w.Ati + halfA * 2, lb + w.y4, lb + w.a4, HIG_L_INT_STY_NORM_W, HIG_L_INT_STY_NORM_B, 0, Bp));
+      HIG_TRY(attn_front(2, iqkv, 3 * d, Ai, lb + w.Ati, lb + w.y4, lb + w.a4, HIG_L_INT_STY_NORM_W, HIG_L_INT_STY_NORM_B, Bp, Bp));
+      HIG_TRY(sty_out(lb + w.a4, lb + w.h2, lb + w.h2b, HIG_L_INT_STY_OUT_W, HIG_L_INT_STY_OUT_B));
       hffn = lb + w.h2b;
     }
     // ---- FFN (transformer.py:167-170): z = Lin1(h2) kept for gelu'(z), f = gelu(z) is linear2's operand ----

@@ -135,7 +135,9 @@ __device__ __forceinline__ void out_gemm_rows(const char* sA, char* sH, const Ou
   }
 }
 
-template <int HD, int H, int NW, bool GEMM = false>
+// YOUT (training forward; not with GEMM): the attention output y = softmax(q) . A (bf16, the input of the LayerNorm) leaves as
+// a second output through og.h / og.ldh -- the backward of the stylization block needs it.
+template <int HD, int H, int NW, bool GEMM = false, bool YOUT = false>
 __global__ __launch_bounds__(64 * NW, (GEMM ? 4 : 1)) void apply_sty16_kernel(const __bf16* __restrict__ Q, int64_t ldq,
                                                               const __bf16* __restrict__ At16, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ ss,
@@ -154,10 +156,11 @@ __global__ __launch_bounds__(64 * NW, (GEMM ? 4 : 1)) void apply_sty16_kernel(co
   static_assert(ROWB == 512 || ROWB == 1024 || ROWB == 2048, "Q rows of 512, 1024 or 2048 bytes");
   static_assert(H % NW == 0, "whole heads per wave");
   static_assert(!GEMM || (D_ == 512 && NW == 8), "fused output projection: d = 512, 8 waves");
-  __shared__ __attribute__((aligned(1024))) char smem[QBYTES + 4 * D_ * 4 + NW * BR * 2 * 4 + (GEMM ? QBYTES : 0)];
+  static_assert(!(GEMM && YOUT), "the second output is for the unfused (training) form");
+  __shared__ __attribute__((aligned(1024))) char smem[QBYTES + 4 * D_ * 4 + NW * BR * 2 * 4 + ((GEMM || YOUT) ? QBYTES : 0)];
   char* const sQ = smem;                                       // [32][ROWB] bf16, 16-byte chunk c of row r at c ^ (r & 15); later the output tile
   float* const sPar = reinterpret_cast<float*>(smem + QBYTES); // gamma | beta | scale | shift, then gamma' | beta'
-  [[maybe_unused]] char* const sH = smem + QBYTES + 4 * D_ * 4 + NW * BR * 2 * 4;   // GEMM: the residual rows, same layout as sQ
+  [[maybe_unused]] char* const sH = smem + QBYTES + 4 * D_ * 4 + NW * BR * 2 * 4;   // GEMM: the residual rows, same layout as sQ; YOUT: the y tile
   float* const sRed = sPar + 4 * D_;                           // [NW waves][32 rows][2]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -353,6 +356,9 @@ __global__ __launch_bounds__(64 * NW, (GEMM ? 4 : 1)) void apply_sty16_kernel(co
         }
         *reinterpret_cast<bf16x4*>(sQ + lr * ROWB + 16 * ((col >> 3) ^ (lr & 15)) + 2 * (col & 7)) =
             bf16x4{(__bf16)o[0][0], (__bf16)o[0][1], (__bf16)o[1][0], (__bf16)o[1][1]};
+        if constexpr (YOUT)
+          *reinterpret_cast<bf16x4*>(sH + lr * ROWB + 16 * ((col >> 3) ^ (lr & 15)) + 2 * (col & 7)) =
+              bf16x4{(__bf16)acc[hh][lb][4 * q], (__bf16)acc[hh][lb][4 * q + 1], (__bf16)acc[hh][lb][4 * q + 2], (__bf16)acc[hh][lb][4 * q + 3]};
       }
   __syncthreads();
   stamp(5);
@@ -365,9 +371,13 @@ __global__ __launch_bounds__(64 * NW, (GEMM ? 4 : 1)) void apply_sty16_kernel(co
     for (int u = 0; u < BR * PPR / NT; ++u) {
       const int idx = tid + NT * u;
       const int r = idx / PPR, p = idx % PPR;
-      if (r0 + r < T)
+      if (r0 + r < T) {
         *reinterpret_cast<bf16x8*>(Out + ((int64_t)b * T + r0 + r) * ldo + 8 * p) =
             *reinterpret_cast<const bf16x8*>(sQ + r * ROWB + 16 * (p ^ (r & 15)));
+        if constexpr (YOUT)
+          *reinterpret_cast<bf16x8*>(og.h + ((int64_t)b * T + r0 + r) * og.ldh + 8 * p) =
+              *reinterpret_cast<const bf16x8*>(sH + r * ROWB + 16 * (p ^ (r & 15)));
+      }
     }
   }
   stamp(6);
@@ -681,32 +691,44 @@ extern "C" int hig_linattn16_debug_stamps(void* buf) {
   return HIG_OK;
 }
 
-extern "C" int hig_linattn_apply_sty_mm16(const void* Q, int64_t ldq, const void* At16, const float* gamma, const float* beta,
-                                          const float* ss, int64_t ss_ld, int32_t ss_shift_off, void* Out, int64_t ldo,
-                                          int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream) {
+// Yout (nullable): y = softmax(q) . A as bf16 rows as well (the training forward keeps it for the backward of the LayerNorm)
+extern "C" int hig_linattn_apply_sty_mm16_y(const void* Q, int64_t ldq, const void* At16, const float* gamma, const float* beta,
+                                            const float* ss, int64_t ss_ld, int32_t ss_shift_off, void* Out, int64_t ldo, void* Yout,
+                                            int64_t ldy, int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream) {
   HIG_REQUIRE(Q && At16 && gamma && beta && ss && Out && B > 0 && rows > 0, "hig_linattn_apply_sty_mm16: bad arguments");
   if ((hd != 64 && hd != 128) || (H != 4 && H != 8))
     return hig_set_error(HIG_EUNSUPPORTED, "hig_linattn_apply_sty_mm16: built for head dim 64 / 128 and 4 or 8 heads (got %d, %d)", hd, H);
-  HIG_REQUIRE(ldq % 8 == 0 && ldo % 8 == 0 && ss_ld % 4 == 0 && ss_shift_off % 4 == 0 &&
-                  ((reinterpret_cast<uintptr_t>(Q) & 15) | (reinterpret_cast<uintptr_t>(Out) & 15) |
+  HIG_REQUIRE(ldq % 8 == 0 && ldo % 8 == 0 && ss_ld % 4 == 0 && ss_shift_off % 4 == 0 && (!Yout || ldy % 8 == 0) &&
+                  ((reinterpret_cast<uintptr_t>(Q) & 15) | (reinterpret_cast<uintptr_t>(Out) & 15) | (reinterpret_cast<uintptr_t>(Yout) & 15) |
                    (reinterpret_cast<uintptr_t>(At16) & 15) | (reinterpret_cast<uintptr_t>(gamma) & 15) |
                    (reinterpret_cast<uintptr_t>(beta) & 15) | (reinterpret_cast<uintptr_t>(ss) & 15)) == 0,
               "hig_linattn_apply_sty_mm16: alignment");
   const dim3 grid((rows + 31) / 32, B);
   hipStream_t st = hig_stream(stream);
-  constexpr int nw8 = 8;      // (a former tuning knob, fixed at the value that won its A/B): waves per workgroup at 8 heads, head dim 64
-#define HIG_AP16(HD_, H_, NW_)                                                                                                  \
-  hipLaunchKernelGGL((apply_sty16_kernel<HD_, H_, NW_>), grid, dim3(64 * NW_), 0, st, static_cast<const __bf16*>(Q), ldq,      \
-                     static_cast<const __bf16*>(At16), gamma, beta, ss, ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo,   \
-                     rows, g_ap_stamps, OutGemmArgs{nullptr, nullptr, nullptr, 0, nullptr})
-  if (hd == 64 && H == 8 && nw8 == 8) HIG_AP16(64, 8, 8);
-  else if (hd == 64 && H == 8) HIG_AP16(64, 8, 4);
+  const OutGemmArgs og{nullptr, nullptr, static_cast<__bf16*>(Yout), ldy, nullptr};
+#define HIG_AP16(HD_, H_, NW_)                                                                                                        \
+  do {                                                                                                                                \
+    if (Yout)                                                                                                                         \
+      hipLaunchKernelGGL((apply_sty16_kernel<HD_, H_, NW_, false, true>), grid, dim3(64 * NW_), 0, st, static_cast<const __bf16*>(Q), \
+                         ldq, static_cast<const __bf16*>(At16), gamma, beta, ss, ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo, \
+                         rows, g_ap_stamps, og);                                                                                      \
+    else                                                                                                                              \
+      hipLaunchKernelGGL((apply_sty16_kernel<HD_, H_, NW_>), grid, dim3(64 * NW_), 0, st, static_cast<const __bf16*>(Q), ldq,         \
+                         static_cast<const __bf16*>(At16), gamma, beta, ss, ss_ld, ss_shift_off, static_cast<__bf16*>(Out), ldo,      \
+                         rows, g_ap_stamps, og);                                                                                      \
+  } while (0)
+  if (hd == 64 && H == 8) HIG_AP16(64, 8, 8);
   else if (hd == 64) HIG_AP16(64, 4, 4);
   else if (H == 8) HIG_AP16(128, 8, 8);
   else HIG_AP16(128, 4, 4);
 #undef HIG_AP16
   HIG_CHECK_LAUNCH();
   return HIG_OK;
+}
+extern "C" int hig_linattn_apply_sty_mm16(const void* Q, int64_t ldq, const void* At16, const float* gamma, const float* beta,
+                                          const float* ss, int64_t ss_ld, int32_t ss_shift_off, void* Out, int64_t ldo,
+                                          int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream) {
+  return hig_linattn_apply_sty_mm16_y(Q, ldq, At16, gamma, beta, ss, ss_ld, ss_shift_off, Out, ldo, nullptr, 0, B, rows, H, hd, stream);
 }
 
 namespace {

@@ -619,6 +619,11 @@ int hig_weight_frag16(const void* Y, int64_t ldy, int32_t J, int32_t R, void* Y_
 int hig_linattn_apply_sty_mm16(const void* Q, int64_t ldq, const void* At16, const float* gamma, const float* beta,
                                const float* ss, int64_t ss_ld, int32_t ss_shift_off, void* Out, int64_t ldo,
                                int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
+/* ... with the attention output y = softmax(q) . A itself (bf16 rows, the input of the LayerNorm) as a second output: the
+ * training forward keeps y for the backward of the stylization block (transformer.py:111-118 + :81-85).  Yout NULL: the above. */
+int hig_linattn_apply_sty_mm16_y(const void* Q, int64_t ldq, const void* At16, const float* gamma, const float* beta,
+                                 const float* ss, int64_t ss_ld, int32_t ss_shift_off, void* Out, int64_t ldo, void* Yout, int64_t ldy,
+                                 int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
 /* The same fused kernel with fp32 storage (hig_denoiser_fwd uses it for inference when HIG_FUSE_APPLY_F32=1; by default
  * it runs hig_linattn_apply + hig_ln_mod_silu, which measured equal).  Q, Out fp32, 16-byte aligned. */
 int hig_linattn_apply_sty(const float* Q, int64_t ldq, const float* A, const float* gamma, const float* beta,

@@ -352,6 +352,14 @@ def test_fused_apply_stylization_front_on_the_bf16_matrix_cores(H, B, T, hd):
     assert rel(out.float(), ref16) < 3e-3
     assert (out.float().cpu() != bf(ref16.float()).float()).float().mean().item() < 0.05
     assert rel(out.float(), ref) < 1e-2
+    # the training form: the same activated rows, bit for bit, and y = softmax(q) . A itself as a second output
+    out2 = torch.full((B * T, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    y16 = torch.full((B * T, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().hig_linattn_apply_sty_mm16_y(_lib.ptr(q16), d, _lib.ptr(At), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(ss),
+                                                       2 * d, d, _lib.ptr(out2), d, _lib.ptr(y16), d, B, T, H, hd, _lib.stream_ptr()))
+    assert torch.equal(out2, out)
+    yref = torch.einsum("bthc,bhcl->bthl", bf(p.float()).double(), bf(Ad.float()).double()).reshape(B * T, d)
+    assert torch.isfinite(y16.float()).all() and rel(y16.float(), yref) < 3e-3
 
 
 @pytest.mark.parametrize("B,T,with_stats", [(32, 196, True), (5, 91, False), (3, 1, True), (16, 196, False), (40, 196, True),
