@@ -378,10 +378,11 @@ int launch16(const hig_gemm16_desc& g, hipStream_t st, int splits = 1, int64_t s
 // equals the larger tile when it still gives every CU a workgroup, else the smaller one (more CUs busy).
 template <int EPI>
 int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
-  static const int forced = getenv("HIG_BF16_TILE") ? atoi(getenv("HIG_BF16_TILE")) : 0;   // tuning knob: 64 / 128 / 256
+  static const int forced_env = getenv("HIG_BF16_TILE") ? atoi(getenv("HIG_BF16_TILE")) : 0;   // tuning knob: 64 / 128
+  const int forced = (forced_env == 64 || forced_env == 128) ? forced_env : 0;
   auto tiles = [&](int bm, int bn) { return (int64_t)((g.I + bm - 1) / bm) * ((g.J + bn - 1) / bn); };
   auto rounds = [](int64_t t, int slots) { return (t + slots - 1) / slots; };
-  const int64_t t128 = tiles(128, 128), t64 = tiles(64, 128), t256 = tiles(256, 256);
+  const int64_t t128 = tiles(128, 128), t64 = tiles(64, 128);
   int pick = 64;
   if (forced) {
     pick = forced;
@@ -395,13 +396,8 @@ int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
     double best = c128;
     if (t128 < ncu && c64 <= best * 1.25) { pick = 64; best = c64; }        // too few big tiles to occupy the chip
     else if (c64 < best) { pick = 64; best = c64; }
-    // 256 x 256 (8 waves, ONE workgroup per CU): the launch is bound by the ~30 B/clk each CU can DMA into its LDS, and a
-    // 256 x 256 tile does twice the MFMA work per staged byte of two co-resident 128 x 128 tiles -- a round of 256 of
-    // them takes about as long as a round of 512 of those and covers twice the output.  Worth it when it saves a round.
-    // (measured, profiles/r02_notes.md: FFN1 34.2 us against 36.1, q/k/v 47.5 against 42.6 -- no clear win, so it stays a
-    // forced option: HIG_BF16_TILE=256)
-    (void)t256;
-    if (hig_gemm16_wide_k1024(g)) pick = 256;   // (the one shape class where it wins clearly, gemm_ws16.hip)
+    // (a 256 x 256 tile -- 8 waves, one workgroup per CU -- won the wide K = 1024 launches of the d = 1024 model alone, 77 against 89 us,
+    // and lost inside the forward, 4.61-4.64 against 4.57 ms: not built any more)
   }
   // (ring shape, re-measured with per-phase stamps at the FFN linear1 shape, profiles/r02_notes.md section 7: the main
   // loops of two co-resident workgroups move 2 x 256 KB in ~19.3K cycles = 27 B/clk per CU, which IS the CU's L2 -> LDS
@@ -422,7 +418,6 @@ int launch16_sized(const hig_gemm16_desc& g, hipStream_t st) {
   constexpr int ring4_rows = 8192;   // (a former tuning knob, fixed at the value that won its A/B)
   if (ring4_rows > 0 && pick == 128 && g.I >= ring4_rows && g.R >= 512) return launch16<2, 2, 2, 2, 32, 4, EPI>(g, st);
   if (g.R % 64 == 0) {
-    if (pick == 256) return launch16<2, 4, 4, 2, 64, 2, EPI>(g, st);
     if (pick == 128) return launch16<2, 2, 2, 2, 64, 2, EPI>(g, st);
     return launch16<1, 4, 2, 1, 64, 2, EPI>(g, st);
   }

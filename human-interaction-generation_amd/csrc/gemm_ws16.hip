@@ -613,11 +613,16 @@ int launch_ws_sized(const hig_gemm16_desc& g, int nwj, hipStream_t st) {
     if (g.row_stats_out && g.R == 1024) return launch_ws<512, 2, 4, 1, EPI, 1, 1>(g, 32, st);
   }
   if constexpr (EPI == HIG_EPI_BIAS) {
-    if (g.row_stats_in && g.R == 512) return nwj == 8 ? launch_ws<512, 1, 8, 1, EPI, 1, 2>(g, 32, st) : launch_ws<512, 1, 4, 1, EPI, 1, 2>(g, 32, st);
+    if (g.row_stats_in && g.R == 512) return launch_ws<512, 1, 4, 1, EPI, 1, 2>(g, 32, st);   // (the 8-wave consumer spilled registers: not built)
     if (g.row_stats_in && g.R == 1024) return launch_ws<512, 2, 4, 1, EPI, 1, 2>(g, 32, st);
   }
-  if (g.R == 512) return nwj == 8 ? launch_ws<512, 1, 8, 1, EPI>(g, 32, st) : nwj == 2 ? launch_ws<512, 1, 4, 2, EPI>(g, 32, st) : launch_ws<512, 1, 4, 1, EPI>(g, 32, st);
-  if (g.R == 256) return nwj == 8 ? launch_ws<256, 1, 8, 1, EPI>(g, 32, st) : launch_ws<256, 1, 4, 1, EPI>(g, 32, st);
+  // (8 waves x 32 columns: bias-only epilogues only -- with GELU / residual epilogues that variant spills at 256 registers per wave)
+  if constexpr (EPI == HIG_EPI_NONE || EPI == HIG_EPI_BIAS) {
+    if (g.R == 512 && nwj == 8) return launch_ws<512, 1, 8, 1, EPI>(g, 32, st);
+    if (g.R == 256 && nwj == 8) return launch_ws<256, 1, 8, 1, EPI>(g, 32, st);
+  }
+  if (g.R == 512) return nwj == 2 ? launch_ws<512, 1, 4, 2, EPI>(g, 32, st) : launch_ws<512, 1, 4, 1, EPI>(g, 32, st);
+  if (g.R == 256) return launch_ws<256, 1, 4, 1, EPI>(g, 32, st);
   return launch_ws<512, 2, 4, 1, EPI>(g, 32, st);   // K = 1024: 8 waves = 4 column slices x 2 halves of the reduce range
 }
 
@@ -652,9 +657,6 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
   if (g.c_f32 || (g.res && g.res_f32)) return decline("fp32 output / residual");
   if (!(g.R == 256 || g.R == 512 || g.R == 1024)) return decline("reduce extent not in {256, 512, 1024}");
   if (g.I < min_rows) return decline("too few rows");
-  // wide K = 1024 launches (q/k/v at d = 1024: 9600 x 3072 x 1024) can go to the 256 x 256 tiled kernel instead (opt-in,
-  // HIG_BF16_WIDE256=1; hig_host.h); at J = 1024 this kernel wins clearly (29-32 against 37-44 us)
-  if (!forced_nwj && hig_gemm16_wide_k1024(g)) return decline("wide K = 1024 launch (served by the 256 x 256 tiled kernel)");
   auto al = [](const void* p, int n) { return (reinterpret_cast<uintptr_t>(p) & (n - 1)) == 0; };
   if (!(g.ldc % 8 == 0 && al(g.C, 16))) return decline("C not 16-byte aligned / ldc not a multiple of 8");
   if ((int64_t)g.I * g.ldx >= (1ll << 30) || (int64_t)g.J * g.ldy >= (1ll << 30) || (g.res && (int64_t)g.I * g.ldr >= (1ll << 30)) ||
@@ -681,6 +683,8 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st) {
   else if (g.row_stats_out) nwj = 4;            // (the statistics are per 128-column panel)
   if (g.row_stats_out) { if (forced_nwj == 44) nwj = 44; }
   else if (forced_nwj == 4 || (forced_nwj == 8 && g.R != 1024) || (forced_nwj == 2 && g.R == 512) || (forced_nwj == 44 && g.R != 1024)) nwj = forced_nwj;
+  if (nwj == 8 && !(g.epi == HIG_EPI_NONE || g.epi == HIG_EPI_BIAS)) nwj = 4;   // (a forced 8-wave variant: bias-only epilogues only)
+  if (nwj == 8 && g.row_stats_in) nwj = 4;
   const int bn = (nwj == 4 || nwj == 44) ? 128 : 256;
   if (g.J % bn != 0) {
     if (g.J % 128 == 0) nwj = 4; else return decline("J not a multiple of 128");

@@ -480,9 +480,9 @@ int launch_wsp(const hig_gemm16_desc& g, hipStream_t st) {
   const dim3 gr(256), bl(512);
   if constexpr (!AUX && XT == 0 && (EPI == HIG_EPI_BIAS || EPI == HIG_EPI_BIAS_GELU || EPI == HIG_EPI_BIAS_RES)) {
     if (a.stamps || dbg) {                       // diagnostic instances (tools/gemm_wsp16_stamps.py)
-      if (dbg & 16) hipLaunchKernelGGL((gemm_wsp16_kernel<EPI, XT, AUX, 1, 3>), gr, bl, 0, st, a);         // no MFMAs
-      else if (dbg & 32) hipLaunchKernelGGL((gemm_wsp16_kernel<EPI, XT, AUX, 1, 5>), gr, bl, 0, st, a);    // no fragment reads
-      else hipLaunchKernelGGL((gemm_wsp16_kernel<EPI, XT, AUX, 1, 1>), gr, bl, 0, st, a);
+      // (the no-MFMA / no-fragment-read ablations of profiles/r05_notes.md section 2 were separate instances, DIAG = 3 / 5; they
+      // spilled registers and are no longer built)
+      hipLaunchKernelGGL((gemm_wsp16_kernel<EPI, XT, AUX, 1, 1>), gr, bl, 0, st, a);
       HIG_CHECK_LAUNCH();
       return HIG_OK;
     }

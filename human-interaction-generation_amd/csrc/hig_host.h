@@ -45,14 +45,6 @@ int hig_reduce_slabs(const float* slabs, int splits, int64_t slab, int64_t n, fl
 int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st);
 // weight-stationary kernel with specialised matrix / service waves (gemm_wsp16.hip: K = 512, J % 128 == 0, >= 2048 rows); same codes
 int hig_gemm_wsp16_try(const hig_gemm16_desc& g, hipStream_t st);
-// the shape class the 256 x 256 tiled bf16 kernel serves better than the weight-stationary one (gemm_ws16.hip, gemm_bf16.hip)
-inline bool hig_gemm16_wide_k1024(const hig_gemm16_desc& g) {
-  // opt-in: alone (tools/gemm16_bench.py 32 cfg5) the 256 x 256 tile wins the q/k/v shape of the d = 1024 model 77 against 89 us,
-  // inside the forward it does not (config-5 forward 4.61-4.64 against 4.57 ms, same call)
-  constexpr int on = 0;   // (a former tuning knob, fixed at the value that won its A/B)
-  return on && g.R == 1024 && g.J >= 2048 && g.J % 256 == 0 && g.I >= 4096 && (g.epi == HIG_EPI_NONE || g.epi == HIG_EPI_BIAS) &&
-         !g.row_stats_in && !g.row_stats_out;
-}
 bool hig_gemm_ws16_lnfold_ok(int64_t rows, int d);
 
 namespace {

@@ -81,7 +81,7 @@ __device__ __forceinline__ void out_gemm_rows(const char* sA, char* sH, const Ou
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // ---- h[rows] += a W^T + bias: wave w owns columns 64 w .. 64 w + 63 (two 32-column blocks), 32 k-steps ---------------
-  constexpr int NK = D_ / 16, PF = 8;          // k-steps; weight operands requested PF k-steps ahead
+  constexpr int NK = D_ / 16, PF = 7;          // k-steps; weight operands requested PF k-steps ahead (8: one fragment spilled, with a vmcnt(0) in the loop)
   f32x16 acc2[2];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)

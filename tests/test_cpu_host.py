@@ -308,3 +308,36 @@ def test_host_entry_points_under_asan_ubsan():
     r = subprocess.run([os.path.join(ROOT, "build", "host_sanitize", "driver")], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "host entry points clean" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+
+
+def test_no_kernel_of_the_built_library_spills_registers(tmp_path):
+    """Every gfx950 kernel in libhig.so, by its code-object metadata: no VGPR spill (a spilled fragment in a matrix loop
+    costs a vmcnt(0) there: the fused stylization block ran 2 % slower with one), and scratch memory only where a kernel keeps a
+    dynamically indexed private array (the VALU `no_eff` backward for head dim 64, reachable through HIG_FULLATTN_VALU=1 only).
+    (SGPR "spills" are scalar values parked in lanes of a vector register -- no memory traffic -- and are not counted.)"""
+    import re
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not all(os.path.exists(os.path.join(tools, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
+        pytest.skip("LLVM object tools not found")
+    fat = str(tmp_path / "fat.bin")
+    subprocess.run([os.path.join(tools, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", _lib.LIB_PATH, fat], check=True)
+    data = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), data)]
+    assert starts, "no offload bundle in libhig.so"
+    kernels, offenders = 0, []
+    for n, (a, b) in enumerate(zip(starts, starts[1:] + [len(data)])):
+        bundle, obj = str(tmp_path / ("b%d.bin" % n)), str(tmp_path / ("co%d.o" % n))
+        open(bundle, "wb").write(data[a:b])
+        subprocess.run([os.path.join(tools, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + bundle,
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + obj], check=True, capture_output=True)
+        notes = subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", obj], check=True, capture_output=True, text=True).stdout
+        names = re.findall(r"\.name:\s+(\S+)", notes)
+        vs, ss = re.findall(r"\.vgpr_spill_count:\s+(\d+)", notes), re.findall(r"\.sgpr_spill_count:\s+(\d+)", notes)
+        scratch = re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)
+        assert len(names) == len(vs) == len(ss) == len(scratch)
+        kernels += len(names)
+        for nm, v, sg, sc in zip(names, vs, ss, scratch):
+            if int(v) or (int(sc) and "full_bwd_q_kernelILi64E" not in nm):
+                offenders.append((nm, int(v), int(sg), int(sc)))
+    assert kernels > 300
+    assert not offenders, offenders
