@@ -757,8 +757,11 @@ def main():
             m2b = m2b.to(device)
             tr2b = hig_amd.DDPMMulTrainer(args2, m2b.train())
 
+            traj16 = []
+
             def pit_step16():
                 tr2b.train_step_captured(x0p, tp, lp, i2["xf_proj"], i2["xf_out"], noise=nz2)
+                traj16.append(tr2b.fused_state()["loss"].clone())      # (a device copy: no host synchronisation in the timed loop)
 
             e_pit16 = timed(pit_step16, k2, 2, 1)
             loss_pit32, loss_pit16 = tr2.fused_state()["loss"].item(), tr2b.fused_state()["loss"].item()
@@ -790,6 +793,7 @@ def main():
                 "pit_train_step_ms_bf16_storage": round(e_pit16 / k2 * 1e3, 3),
                 "pit_train_pairs_per_s_bf16_storage": round(16 * k2 / e_pit16, 1),
                 "pit_loss_after_the_timed_steps": {"f32": round(loss_pit32, 5), "bf16_storage": round(loss_pit16, 5)},
+                "pit_loss_by_step_bf16_storage": [round(v.item(), 4) for v in traj16],
                 "fwd_frames_per_s": round(c2["B"] * c2["T"] * k2 / e_f, 1), "fwd_ms": round(e_f / k2 * 1e3, 3),
                 "fwd_ms_bf16_storage": round(e_f16 / k2 * 1e3, 3),
                 "fwd_bwd_frames_per_s": round(c2["B"] * c2["T"] * k2 / e_fb, 1), "fwd_bwd_ms": round(e_fb / k2 * 1e3, 3),

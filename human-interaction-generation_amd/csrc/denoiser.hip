@@ -781,6 +781,18 @@ __global__ void cast_rows_bf16_kernel(const float* __restrict__ src, int64_t lds
   }
 }
 
+__global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+__global__ void copy2d_f32_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows, int cols) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i % cols);
+  dst[(int64_t)r * ldd + c] = src[(int64_t)r * lds + c];
+}
+
 // tok0[b][0..n) = float(buf[b][0][0..n)) for a bf16 buf [B][T][n] (if tok0), then zeroes that row in buf (if zero): the init-pose
 // rows of the two-person model's residual-stream gradient
 __global__ void tok0_bf16_kernel(__bf16* __restrict__ buf, int64_t sample_stride, int B, int n, float* __restrict__ tok0, int zero) {
@@ -1873,7 +1885,7 @@ extern "C" int hig_denoiser_fwd_bf16_train(const hig_dims* dims, const void* con
       float* Ai = reinterpret_cast<float*>(lb + w.Ai);
       HIG_TRY(ctx16(D, iqkv + (int64_t)d * 2, iqkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, len_partner, Ai, reinterpret_cast<float*>(lb + w.ksti),
                     reinterpret_cast<float*>(ws + w.cscr), lb + w.Ati, stream));
-      const int64_t halfA = (int64_t)Bp * D.H * D.hd * D.hd, halfM = (int64_t)Bp * D.T;
+      const int64_t halfA = (int64_t)Bp * D.H * D.hd * D.hd;
       // (person 1's queries against person 2's context and vice versa: the halves of A / At swapped)
       HIG_TRY(attn_front(2, iqkv, 3 * d, Ai + halfA, lb + w.Ati + halfA * 2, lb + w.y4, lb + w.a4, HIG_L_INT_STY_NORM_W, HIG_L_INT_STY_NORM_B, 0, Bp));
       HIG_TRY(attn_front(2, iqkv, 3 * d, Ai, lb + w.Ati, lb + w.y4, lb + w.a4, HIG_L_INT_STY_NORM_W, HIG_L_INT_STY_NORM_B, Bp, Bp));
@@ -1957,7 +1969,6 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
   const int64_t ss_ld = (int64_t)D.nsty * D.L * 2 * d;
   float* slabs = reinterpret_cast<float*>(b + bw.slabs);
   float* colp = reinterpret_cast<float*>(b + bw.colpart);
-  float* colp_w = reinterpret_cast<float*>(b + bw.colpart_w);
   float* lnp = reinterpret_cast<float*>(b + bw.lnpart);
   float* dss = reinterpret_cast<float*>(b + bw.dss);
   float* dA = reinterpret_cast<float*>(b + bw.dA);
@@ -1966,7 +1977,6 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
   float* f32b = reinterpret_cast<float*>(b + bw.f32b);
   const float* ssf = reinterpret_cast<const float*>(ws + w.ss);
   char* tA = b + bw.tA;
-  char* tB = b + bw.tB;
 
   // bf16 storage: the weight gradients stay on the caller's stream unless HIG_BWD_OVERLAP=1 asks for the fork.  The kernels of
   // this mode are one-workgroup-per-CU designs (gemm_wsp16: 159 KB of LDS, wgrad16x: 128 KB + twelve waves): two of them cannot
@@ -1975,11 +1985,9 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
   // forked as well).  The fp32 step keeps the fork (tiled kernels, several workgroups per CU: 20.4 vs 21.4 ms eager).
   static const int fork16 = getenv("HIG_BWD_OVERLAP") ? atoi(getenv("HIG_BWD_OVERLAP")) : 0;
   WgradFork fork(fork16 ? side_stream_for_current_device(st) : nullptr, st);
-  hig_stream_t wstream = reinterpret_cast<hig_stream_t>(fork.stream());
   // dW[n][k] = sum_m dC[m][n] act[m][k] (+ the bias gradient = column sums of dC): both operands transposed to
   // reduce-contiguous bf16 (n_out x Mp), (k_in x Mp), then the split-R bf16 GEMM into the fp32 gradient.  Everything on the
   // weight-gradient stream (protocol: WgradFork).
-  constexpr int wg16 = 1;   // (a former tuning knob, fixed at the value that won its A/B): 0 = transposes + tiled split-R GEMM
   // The same batching for the LayerNorm / stylization backward: each call of a layer writes its own partial table and
   // ln_flush() reduces them all (dgamma, dbeta, d(scale, shift)) in one launch at the end of the layer.
   hig_ln_reduce ln_pending[HIG_LN_RB_MAX];
@@ -2007,46 +2015,42 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
   hig_wg_reduce wg_pending[HIG_WG_RB_MAX];
   int wg_n = 0;
   int64_t wg_used = 0;
-  auto wg_flush = [&]() -> int {
+  // ... and the gradients themselves are grouped: wgrad_act() only queues a problem; wg_launch() puts the two to four whose dC
+  // operands exist at the same time into ONE launch of the kernel (FFN: stylization out + linear2 + linear1; cross attention:
+  // stylization out + query + text key/value; self attention: stylization out + q/k/v; person <-> person the same) -- a third of
+  // the slices per gradient, i.e. a third of the slab traffic, and a workgroup's prologue / tail spread over three times the
+  // chunks.  It is called where the last operand of a group has been produced and before any of them is overwritten (walk of
+  // the layer loop below).  With the weight-gradient fork (HIG_BWD_OVERLAP=1) every gradient is launched at once, as before: the
+  // fork's buffer rule counts requests.
+  hig_wg_problem wg_q[HIG_WG_GROUP_MAX];
+  int wg_qn = 0;
+  auto wg_reduce = [&]() -> int {
     if (wg_n == 0) { wg_used = 0; return HIG_OK; }
     HIG_TRY(fork.begin());
     HIG_TRY(hig_wgrad16_reduce_batch(wg_pending, wg_n, fork.stream()));
     wg_n = 0; wg_used = 0;
     return fork.end();
   };
-  auto wgrad_act = [&](const void* dC, int n_out, const void* act, int k_in, float* out, int64_t rows, int64_t rows_p, float* dbias) -> int {
-    if (wg16) {   // straight from the row-major operands (transpose reads), bias gradient in the same pass
-      const int64_t want = hig_wgrad16_rule_floats(rows, n_out, k_in, bw.slab_floats);    // (what the split rule takes of an empty scratch)
-      if (wg_n == HIG_WG_RB_MAX || wg_used + want > bw.slab_floats) HIG_TRY(wg_flush());
-      const int64_t room = bw.slab_floats - wg_used;
-      HIG_TRY(fork.begin());
-      HIG_TRY(hig_wgrad16_launch(dC, n_out, act, k_in, rows, n_out, k_in, out, dbias, 0, slabs + wg_used, room, fork.stream(), &wg_pending[wg_n]));
-      if (wg_pending[wg_n].nsplit > 1) {
-        wg_used += (wg_pending[wg_n].slab * wg_pending[wg_n].nsplit + 63) / 64 * 64;     // (16-byte aligned ranges)
-        ++wg_n;
-      }
-      return fork.end();
-    }
-    HIG_TRY(wg_flush());
+  auto wg_launch = [&]() -> int {
+    if (wg_qn == 0) return HIG_OK;
+    if (wg_n + wg_qn > HIG_WG_RB_MAX || wg_used > bw.slab_floats / 2) HIG_TRY(wg_reduce());
+    int64_t used = 0;
     HIG_TRY(fork.begin());
-    if (dbias) HIG_TRY(hig_colsum_bf16(dC, n_out, rows, n_out, dbias, colp_w, wstream));
-    const void* srcs[2] = {dC, act};
-    void* dsts[2] = {tA, tB};
-    const int64_t lds_[2] = {n_out, k_in}, ldd[2] = {rows_p, rows_p};
-    const int32_t rws[2] = {(int32_t)rows, (int32_t)rows}, cls[2] = {n_out, k_in};
-    if (rows_p != rows) {
-      // the reduce extent is padded to whole 64-deep k-tiles: columns [rows, rows_p) of both transposed operands must be
-      // zero, and the buffers are shared by weight gradients of different shapes (M-row and B N-row ones): clear the pad
-      // columns of THIS layout (nothing to do at the BASELINE shapes: 12 544 and 4 928 are multiples of 64)
-      if (hipMemset2DAsync(tA + rows * 2, (size_t)rows_p * 2, 0, (size_t)(rows_p - rows) * 2, (size_t)n_out, fork.stream()) != hipSuccess ||
-          hipMemset2DAsync(tB + rows * 2, (size_t)rows_p * 2, 0, (size_t)(rows_p - rows) * 2, (size_t)k_in, fork.stream()) != hipSuccess)
-        return hig_set_error(HIG_EHIP, "hipMemset2DAsync failed");
-    }
-    HIG_TRY(hig_transpose_bf16_batch(2, srcs, lds_, dsts, ldd, rws, cls, wstream));
-    G16 g(tA, rows_p, tB, rows_p, out, k_in, n_out, k_in, rows_p);
-    g.out32();
-    HIG_TRY(hig_gemm16_split_launch(g.g, 0, slabs, bw.slab_floats, fork.stream()));
+    HIG_TRY(hig_wgrad16_launch_group(wg_q, wg_qn, slabs + wg_used, bw.slab_floats - wg_used, fork.stream(), &wg_pending[wg_n], &used));
+    wg_n += wg_qn;
+    wg_used += (used + 63) / 64 * 64;          // (16-byte aligned ranges)
+    wg_qn = 0;
     return fork.end();
+  };
+  auto wg_flush = [&]() -> int {
+    HIG_TRY(wg_launch());
+    return wg_reduce();
+  };
+  auto wgrad_act = [&](const void* dC, int n_out, const void* act, int k_in, float* out, int64_t rows, [[maybe_unused]] int64_t rows_p, float* dbias) -> int {
+    // straight from the row-major operands (transpose reads), bias gradient in the same pass (wgrad16.hip)
+    wg_q[wg_qn++] = hig_wg_problem{dC, n_out, act, k_in, rows, n_out, k_in, out, dbias, 0};
+    if (wg_qn == HIG_WG_GROUP_MAX || fork.side) return wg_launch();
+    return HIG_OK;
   };
   // fp32 weight gradients at the F-wide edges (operands fp32, reduce-slow): the fp32 kernel, split over the rows
   auto wgrad32 = [&](G gd) -> int {
@@ -2097,12 +2101,14 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
     HIG_TRY(wg_flush());
     HIG_TRY(fork.begin());
     HIG_TRY(hig_wgrad16_launch(dC, n_out, act, k_in, M, n_out, k_in, scratch, sbias, 0, slabs, bw.slab_floats, fork.stream()));
-    if (hipMemcpy2DAsync(out, (size_t)out_cols * 4, scratch, (size_t)k_in * 4, (size_t)out_cols * 4, (size_t)out_rows, hipMemcpyDeviceToDevice,
-                         fork.stream()) != hipSuccess)
-      return hig_set_error(HIG_EHIP, "hipMemcpy2DAsync failed");
-    if (out_bias && sbias != out_bias &&
-        hipMemcpyAsync(out_bias, sbias, (size_t)nbias * 4, hipMemcpyDeviceToDevice, fork.stream()) != hipSuccess)
-      return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
+    // (kernels, not hipMemcpy2DAsync / hipMemcpyAsync nodes: see the init-pose rows below)
+    hipLaunchKernelGGL(copy2d_f32_kernel, dim3((unsigned)(((int64_t)out_rows * out_cols + 255) / 256)), dim3(256), 0, fork.stream(), scratch, k_in, out,
+                       out_cols, out_rows, out_cols);
+    HIG_CHECK_LAUNCH();
+    if (out_bias && sbias != out_bias) {
+      hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)((nbias + 255) / 256)), dim3(256), 0, fork.stream(), sbias, out_bias, (int64_t)nbias);
+      HIG_CHECK_LAUNCH();
+    }
     return fork.end();
   };
   float* tok0 = reinterpret_cast<float*>(b + bw.tok0);
@@ -2126,9 +2132,13 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
   };
   if (edge16) {
     HIG_TRY(hig_cast_pad_bf16(dout, F, M, F, edgeb + e_dout, Fp, stream));
-    if (D.two &&   // the `out` adjoints must not see the init-pose rows: zero them in the rounded copy
-        hipMemset2DAsync(edgeb + e_dout, (size_t)D.T * Fp * 2, 0, (size_t)Fp * 2, (size_t)D.B, st) != hipSuccess)
-      return hig_set_error(HIG_EHIP, "hipMemset2DAsync failed");
+    if (D.two) {   // the `out` adjoints must not see the init-pose rows: zero them in the rounded copy
+      // (a kernel, not hipMemset2DAsync: as a node of the captured step the 2-D memset ran out of order with its neighbours
+      // whenever the graph was launched onto an idle GPU -- tools/sync_pattern_probe.py, profiles/r05_notes.md section 8)
+      hipLaunchKernelGGL(tok0_bf16_kernel, dim3((D.B * Fp + 255) / 256), dim3(256), 0, st, reinterpret_cast<__bf16*>(edgeb + e_dout), (int64_t)D.T * Fp,
+                         D.B, Fp, static_cast<float*>(nullptr), 1);
+      HIG_CHECK_LAUNCH();
+    }
     HIG_TRY(hig_cast_pad_bf16(x, F, M, F, edgeb + e_x, Fp, stream));
     if (hipMemsetAsync(edgeb + e_wot, 0, (size_t)d * Fp * 2, st) != hipSuccess) return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
     HIG_TRY(hig_transpose_bf16(P16(params16, HIG_P_OUT_W), d, F, d, edgeb + e_wot, Fp, stream));   // (F, d) -> (d, Fp), pad columns zero
@@ -2191,6 +2201,7 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
     HIG_TRY(dgrad(dy3, d, o_w2t, b + bw.tff, ff, M, HIG_EPI_DGELU, lb + w.z1, ff));     // dz = (dy3 . W2) gelu'(z)
     const char* dz1 = b + bw.tff;
     HIG_TRY(wgrad_act(dz1, ff, hffn, d, GL(grads, l, HIG_L_FFN_W1), M, bw.Mp, GL(grads, l, HIG_L_FFN_B1)));
+    HIG_TRY(wg_launch());     // FFN group: d(h3) (dh), dy3 (t2) and dz (tff) all exist and none has been overwritten yet
     HIG_TRY(dgrad(dz1, ff, o_w1t, dh_alt, d, M, HIG_EPI_RES, dh, d));                  // d(h2) = d(h3) + dz . W1
     { char* tmp = dh; dh = dh_alt; dh_alt = tmp; }  // dh = d(h2), or d(h2b) in the interaction model
     if (D.two == 1) {
@@ -2209,6 +2220,7 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
       HIG_TRY(hig_linattn_ctx_bwd_bf16(dA, Ai, iqkv + (int64_t)d * 2, iqkv + (int64_t)2 * d * 2, 3 * d, reinterpret_cast<const float*>(lb + w.ksti),
                                        len_partner, dqkv + (int64_t)d * 2, dqkv + (int64_t)2 * d * 2, 3 * d, D.B, D.T, D.H, D.hd, stream));
       HIG_TRY(wgrad_act(dqkv, 3 * d, lb + w.xn3, d, GL(grads, l, HIG_L_INT_QKV_W), M, bw.Mp, GL(grads, l, HIG_L_INT_QKV_B)));
+      HIG_TRY(wg_launch());   // person <-> person group: d(h2b) (dh) and dqkv
       HIG_TRY(dgrad(dqkv, 3 * d, o_iqkv, b + bw.t2, d, M, HIG_EPI_NONE, nullptr, 0));
       HIG_TRY(ln_bwd16(b + bw.t2, d, lb + w.h2, 0, d, PL(params, l, HIG_L_INT_NORM_W), PL(params, l, HIG_L_INT_NORM_B), nullptr, 0, 0, 0, dh, d,
                               dh_alt, 0, d, M, d, D.T, GL(grads, l, HIG_L_INT_NORM_W), GL(grads, l, HIG_L_INT_NORM_B), nullptr, 0));
@@ -2229,6 +2241,7 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
     HIG_TRY(hig_linattn_ctx_bwd_bf16(dA, Ac, tlb + tl.kv, tlb + tl.kv + (int64_t)d * 2, 2 * d, reinterpret_cast<const float*>(tlb + tl.kstc), nullptr,
                                      b + bw.dkv, b + bw.dkv + (int64_t)d * 2, 2 * d, D.B, D.N, D.H, D.hd, stream));
     HIG_TRY(wgrad_act(b + bw.dkv, 2 * d, tlb + tl.xfn, Lt, GL(grads, l, HIG_L_CA_KV_W), Mt, bw.Mtp, GL(grads, l, HIG_L_CA_KV_B)));
+    HIG_TRY(wg_launch());     // cross-attention group: d(h2) (the buffer dh pointed to when it was queued), dqc (t1), dkv
     HIG_TRY(dgrad(b + bw.dkv, 2 * d, o_kv, b + bw.dxfn, Lt, Mt, HIG_EPI_NONE, nullptr, 0));
     HIG_TRY(ln_bwd16(b + bw.dxfn, Lt, xf_out, 1, Lt, PL(params, l, HIG_L_CA_TNORM_W), PL(params, l, HIG_L_CA_TNORM_B), nullptr, 0, 0, 0,
                             l == D.L - 1 ? nullptr : dxf_out, Lt, dxf_out, 1, Lt, Mt, Lt, D.N, GL(grads, l, HIG_L_CA_TNORM_W),
@@ -2243,6 +2256,7 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
                                      reinterpret_cast<const float*>(lb + w.kst1), length, dqkv + (int64_t)d * 2, dqkv + (int64_t)2 * d * 2, 3 * d,
                                      D.B, D.T, D.H, D.hd, stream));
     HIG_TRY(wgrad_act(dqkv, 3 * d, lb + w.xn1, d, GL(grads, l, HIG_L_SA_QKV_W), M, bw.Mp, GL(grads, l, HIG_L_SA_QKV_B)));
+    HIG_TRY(wg_launch());     // self-attention group: d(h1) (dh) and dqkv
     HIG_TRY(dgrad(dqkv, 3 * d, o_qkv, b + bw.t2, d, M, HIG_EPI_NONE, nullptr, 0));
     HIG_TRY(ln_bwd16(b + bw.t2, d, hin, 0, d, PL(params, l, HIG_L_SA_NORM_W), PL(params, l, HIG_L_SA_NORM_B), nullptr, 0, 0, 0, dh, d, dh_alt,
                             0, d, M, d, D.T, GL(grads, l, HIG_L_SA_NORM_W), GL(grads, l, HIG_L_SA_NORM_B), nullptr, 0));
@@ -2291,8 +2305,11 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
     HIG_TRY(wgrad32(G(f32b, d, 1, x, F, 1, GP(grads, HIG_P_JOINT_W), F, d, F, M)));
     HIG_TRY(hig_colsum(f32b, (int64_t)D.T * d, D.B, D.T * d, dpos, colp, stream));
   }
-  if (D.two && hipMemcpyAsync(GP(grads, HIG_P_SEQ_EMB), dpos + d, (size_t)Tpos * d * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
+  if (D.two) {   // (frame t used row t - 1 of the table: shift by one row; a kernel for the same reason as the init-pose rows above)
+    const int64_t nsh = (int64_t)Tpos * d;
+    hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, st, dpos + d, GP(grads, HIG_P_SEQ_EMB), nsh);
+    HIG_CHECK_LAUNCH();
+  }
   if (D.nf > Tpos)
     if (hipMemsetAsync(GP(grads, HIG_P_SEQ_EMB) + (int64_t)Tpos * d, 0, (size_t)(D.nf - Tpos) * d * 4, st) != hipSuccess)
       return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");

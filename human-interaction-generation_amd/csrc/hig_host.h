@@ -38,6 +38,13 @@ constexpr int HIG_WG_RB_MAX = 12;
 int hig_wgrad16_launch(const void* dC, int64_t ldd, const void* act, int64_t ldx, int64_t rows, int J, int K, float* dW, float* dbias,
                        int splits, float* slabs, int64_t slab_floats, hipStream_t st, hig_wg_reduce* deferred = nullptr);
 int hig_wgrad16_reduce_batch(const hig_wg_reduce* entries, int n, hipStream_t st);
+// up to HIG_WG_GROUP_MAX gradients in one launch of the kernel (wgrad16.hip)
+struct hig_wg_problem {
+  const void* dC; int64_t ldd; const void* act; int64_t ldx; int64_t rows; int J, K; float* dW; float* dbias; int splits;   // splits 0: the rule
+};
+constexpr int HIG_WG_GROUP_MAX = 4;
+int hig_wgrad16_launch_group(const hig_wg_problem* probs, int n, float* slabs, int64_t slab_floats, hipStream_t st, hig_wg_reduce* deferred,
+                             int64_t* used_floats);
 int64_t hig_wgrad16_rule_floats(int64_t rows, int J, int K, int64_t room);   // slab floats the split rule takes, given `room`
 // out[e] = sum_s slabs[s * slab + e], e < n (n % 4 == 0, 16-byte aligned), in split order (gemm.hip)
 int hig_reduce_slabs(const float* slabs, int splits, int64_t slab, int64_t n, float* out, hipStream_t st);

@@ -52,7 +52,17 @@ struct Wg2Args {
 };
 unsigned long long* g_wg_stamps = nullptr;
 
-__global__ __launch_bounds__(768, 3) void wgrad16x_kernel(const Wg2Args a) {
+// Up to HIG_WG_GROUP_MAX weight gradients in ONE launch (the training step's backward: the two or three gradients whose dC
+// operands exist at the same time -- stylization out + FFN linear2 + linear1, ... -- share the chip): unit u belongs to problem
+// p with unit0[p] <= u < unit0[p + 1].  One launch of 240-256 units instead of three of 256 means a third of the slices per
+// gradient: a third of the fp32 slabs, and the prologue / tail of a workgroup amortised over three times as many chunks.
+struct WgGroupArgs {
+  Wg2Args p[HIG_WG_GROUP_MAX];
+  int unit0[HIG_WG_GROUP_MAX + 1];
+  int np, units;
+};
+
+__global__ __launch_bounds__(768, 3) void wgrad16x_kernel(const WgGroupArgs grp) {
   constexpr int CHK = 64, ROWB = 256, NB = 4, OPB = CHK * ROWB;   // 16 KB per operand and chunk
   __shared__ __attribute__((aligned(1024))) char smem[NB * 2 * OPB];   // [slot][dC | act][64 rows][256 bytes]: 128 KB
   const int tid = threadIdx.x, lane = tid & 63;
@@ -60,8 +70,12 @@ __global__ __launch_bounds__(768, 3) void wgrad16x_kernel(const Wg2Args a) {
   // every tile of a split streams the SAME rows of dC and act: they sit on one XCD (blocks b, b + 8, ... share one: unit
   // u = (b % 8) (grid / 8) + b / 8 is contiguous per XCD; speed only), so a row is fetched from HBM once and served to the
   // other tiles by that XCD's L2 -- in blockIdx order a 256-byte piece of dC went to four XCDs (3x the HBM traffic)
-  const int u = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  if (u >= a.units) return;
+  const int ug = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (ug >= grp.units) return;
+  int pi = 0;
+  while (pi + 1 < grp.np && ug >= grp.unit0[pi + 1]) ++pi;
+  const Wg2Args& a = grp.p[pi];                  // (workgroup-uniform: scalar loads from the kernel arguments)
+  const int u = ug - grp.unit0[pi];
   const int split = u / a.ntiles, tile = u - split * a.ntiles;
   const int tj = tile / a.ntk, tk = tile - tj * a.ntk;
   const int j0 = tj * 128, k0 = tk * 128;
@@ -339,51 +353,112 @@ int64_t hig_wgrad16_rule_floats(int64_t rows, int J, int K, int64_t room) {
   return slab * splits;
 }
 
-// deferred (nullable): the slab reduction is NOT launched; *deferred describes it for hig_wgrad16_reduce_batch (nsplit = 0 when
-// the gradient needed no slabs) and the slabs must stay untouched until then.
-int hig_wgrad16_launch(const void* dC, int64_t ldd, const void* act, int64_t ldx, int64_t rows, int J, int K, float* dW, float* dbias,
-                       int splits, float* slabs, int64_t slab_floats, hipStream_t st, hig_wg_reduce* deferred) {
-  HIG_REQUIRE(dC && act && dW && rows > 0 && J > 0 && K > 0, "hig_wgrad_bf16: bad arguments");
-  if (deferred) deferred->nsplit = 0;
-  HIG_REQUIRE(J % 8 == 0 && K % 8 == 0 && ldd % 8 == 0 && ldx % 8 == 0 &&
-                  ((reinterpret_cast<uintptr_t>(dC) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(dW) |
-                    reinterpret_cast<uintptr_t>(dbias) | reinterpret_cast<uintptr_t>(slabs)) & 15) == 0,
-              "hig_wgrad_bf16: J, K and the leading dimensions must be multiples of 8, buffers 16-byte aligned");
-  HIG_REQUIRE(rows < (1ll << 31), "hig_wgrad_bf16: too many rows");
-  const int ntj = (J + 127) / 128, ntk = (K + 127) / 128, ntiles = ntj * ntk;
-  const int64_t slab = (int64_t)J * K + J;
-  const int nchunks = (int)((rows + 63) / 64);
-  // the buffer descriptors of the loader waves address the rows with 32-bit byte offsets
-  if (rows * ldd * 2 >= (1ll << 31) || rows * ldx * 2 >= (1ll << 31))
-    return hig_set_error(HIG_EUNSUPPORTED, "hig_wgrad_bf16: an operand of more than 2 GiB");
-  if (splits <= 0) splits = (int)(hig_wgrad16_rule_floats(rows, J, K, slabs ? slab_floats : 0) / slab);
-  if (splits > nchunks) splits = nchunks;        // (slices are chunk ranges of near-equal length: none is empty)
-  HIG_REQUIRE(splits == 1 || (slabs && slab * splits <= slab_floats), "hig_wgrad_bf16: slab scratch too small");
-  Wg2Args a;
-  a.dC = static_cast<const __bf16*>(dC); a.ldd = ldd;
-  a.X = static_cast<const __bf16*>(act); a.ldx = ldx;
-  a.out = splits == 1 ? dW : slabs;
-  a.dbias = dbias;
-  a.slab = splits == 1 ? 0 : slab;
-  a.J = J; a.K = K; a.rows = (int)rows; a.nsplit = splits; a.ntk = ntk; a.ntiles = ntiles; a.want_bias = dbias != nullptr;
-  a.units = ntiles * splits;
-  a.stamps = g_wg_stamps;
-  hipLaunchKernelGGL(wgrad16x_kernel, dim3((a.units + 7) / 8 * 8), dim3(768), 0, st, a);
-  HIG_CHECK_LAUNCH();
-  if (splits > 1) {
-    const int64_t n4 = (int64_t)J * K / 4, nb4 = dbias ? J / 4 : 0;
-    HIG_REQUIRE(((int64_t)J * K) % 4 == 0 && J % 4 == 0, "hig_wgrad_bf16: J K and J must be multiples of 4");
-    if (deferred) {
-      deferred->slabs = slabs; deferred->nsplit = splits; deferred->slab = slab; deferred->n4 = n4; deferred->out = dW;
-      deferred->nb4 = nb4; deferred->dbias = dbias;
-      return HIG_OK;
+// A group of weight gradients in one launch.  splits_p (0: the rule below) slices per problem; the slabs of the problems that
+// need them are laid out one after the other in `slabs` (16-byte aligned ranges); *used_floats (nullable) receives the floats taken.
+// deferred (nullable, n entries): the slab reductions are NOT launched; deferred[p] describes problem p's for
+// hig_wgrad16_reduce_batch (nsplit = 0 when it needed no slabs) and the slabs must stay untouched until then.
+// Rule: every problem starts with one slice; the slice count of the problem with the most rows per slice grows while the units
+// still fit the CUs (128 KB of LDS, twelve waves: one workgroup per CU), at least four 64-row chunks stay in a slice and
+// the slabs fit.
+int hig_wgrad16_launch_group(const hig_wg_problem* probs, int n, float* slabs, int64_t slab_floats, hipStream_t st,
+                             hig_wg_reduce* deferred, int64_t* used_floats) {
+  HIG_REQUIRE(probs && n >= 1 && n <= HIG_WG_GROUP_MAX, "hig_wgrad_bf16: 1 .. %d problems per launch", HIG_WG_GROUP_MAX);
+  int ntiles[HIG_WG_GROUP_MAX], nchunks[HIG_WG_GROUP_MAX], splits[HIG_WG_GROUP_MAX];
+  int64_t slab[HIG_WG_GROUP_MAX];
+  int units = 0;
+  bool forced = false;
+  for (int p = 0; p < n; ++p) {
+    const hig_wg_problem& q = probs[p];
+    HIG_REQUIRE(q.dC && q.act && q.dW && q.rows > 0 && q.J > 0 && q.K > 0, "hig_wgrad_bf16: bad arguments");
+    HIG_REQUIRE(q.J % 8 == 0 && q.K % 8 == 0 && q.ldd % 8 == 0 && q.ldx % 8 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(q.dC) | reinterpret_cast<uintptr_t>(q.act) | reinterpret_cast<uintptr_t>(q.dW) |
+                      reinterpret_cast<uintptr_t>(q.dbias) | reinterpret_cast<uintptr_t>(slabs)) & 15) == 0,
+                "hig_wgrad_bf16: J, K and the leading dimensions must be multiples of 8, buffers 16-byte aligned");
+    HIG_REQUIRE(q.rows < (1ll << 31), "hig_wgrad_bf16: too many rows");
+    // the buffer descriptors of the loader waves address the rows with 32-bit byte offsets
+    if (q.rows * q.ldd * 2 >= (1ll << 31) || q.rows * q.ldx * 2 >= (1ll << 31))
+      return hig_set_error(HIG_EUNSUPPORTED, "hig_wgrad_bf16: an operand of more than 2 GiB");
+    ntiles[p] = ((q.J + 127) / 128) * ((q.K + 127) / 128);
+    nchunks[p] = (int)((q.rows + 63) / 64);
+    slab[p] = ((int64_t)q.J * q.K + q.J + 3) / 4 * 4;
+    splits[p] = q.splits > 0 ? (q.splits < nchunks[p] ? q.splits : nchunks[p]) : 1;
+    forced = forced || q.splits > 0;
+    units += ntiles[p] * splits[p];
+  }
+  auto slab_need = [&]() {
+    int64_t f = 0;
+    for (int p = 0; p < n; ++p) f += splits[p] > 1 ? slab[p] * splits[p] : 0;
+    return f;
+  };
+  if (!forced) {
+    const int target = hig_chip_cus();
+    for (;;) {
+      int best = -1;
+      double most = 0;
+      for (int p = 0; p < n; ++p) {
+        const int s1 = splits[p] + 1;
+        if (s1 > 64 || (nchunks[p] + s1 - 1) / s1 < 4 || units + ntiles[p] > target) continue;
+        if (!slabs) continue;
+        const double per = (double)nchunks[p] / splits[p];
+        if (per > most) { most = per; best = p; }
+      }
+      if (best < 0) break;
+      ++splits[best];
+      if (slab_need() > slab_floats) { --splits[best]; break; }
+      units += ntiles[best];
     }
-    int64_t blocks = (n4 + nb4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(wg16_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slabs, splits, slab, n4, dW, nb4, dbias);
-    HIG_CHECK_LAUNCH();
+  }
+  HIG_REQUIRE(slab_need() == 0 || (slabs && slab_need() <= slab_floats), "hig_wgrad_bf16: slab scratch too small");
+  WgGroupArgs g;
+  g.np = n;
+  int64_t off = 0;
+  int u0 = 0;
+  for (int p = 0; p < n; ++p) {
+    const hig_wg_problem& q = probs[p];
+    Wg2Args& a = g.p[p];
+    a.dC = static_cast<const __bf16*>(q.dC); a.ldd = q.ldd;
+    a.X = static_cast<const __bf16*>(q.act); a.ldx = q.ldx;
+    a.out = splits[p] == 1 ? q.dW : slabs + off;
+    a.dbias = q.dbias;
+    a.slab = splits[p] == 1 ? 0 : slab[p];
+    a.J = q.J; a.K = q.K; a.rows = (int)q.rows; a.nsplit = splits[p]; a.ntk = (q.K + 127) / 128; a.ntiles = ntiles[p]; a.want_bias = q.dbias != nullptr;
+    a.units = ntiles[p] * splits[p];
+    a.stamps = g_wg_stamps;
+    g.unit0[p] = u0;
+    u0 += a.units;
+    if (deferred) deferred[p].nsplit = 0;
+    if (splits[p] > 1) {
+      HIG_REQUIRE(((int64_t)q.J * q.K) % 4 == 0 && q.J % 4 == 0, "hig_wgrad_bf16: J K and J must be multiples of 4");
+      if (deferred) {
+        deferred[p].slabs = slabs + off; deferred[p].nsplit = splits[p]; deferred[p].slab = slab[p]; deferred[p].n4 = (int64_t)q.J * q.K / 4;
+        deferred[p].out = q.dW; deferred[p].nb4 = q.dbias ? q.J / 4 : 0; deferred[p].dbias = q.dbias;
+      }
+      off += slab[p] * splits[p];
+    }
+  }
+  g.unit0[n] = u0;
+  g.units = u0;
+  if (used_floats) *used_floats = off;
+  hipLaunchKernelGGL(wgrad16x_kernel, dim3((g.units + 7) / 8 * 8), dim3(768), 0, st, g);
+  HIG_CHECK_LAUNCH();
+  if (!deferred) {
+    for (int p = 0; p < n; ++p) {
+      if (g.p[p].nsplit <= 1) continue;
+      const hig_wg_problem& q = probs[p];
+      const int64_t n4 = (int64_t)q.J * q.K / 4, nb4 = q.dbias ? q.J / 4 : 0;
+      int64_t blocks = (n4 + nb4 + 255) / 256;
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(wg16_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g.p[p].out, g.p[p].nsplit, g.p[p].slab, n4, q.dW, nb4, q.dbias);
+      HIG_CHECK_LAUNCH();
+    }
   }
   return HIG_OK;
+}
+
+int hig_wgrad16_launch(const void* dC, int64_t ldd, const void* act, int64_t ldx, int64_t rows, int J, int K, float* dW, float* dbias,
+                       int splits, float* slabs, int64_t slab_floats, hipStream_t st, hig_wg_reduce* deferred) {
+  const hig_wg_problem q{dC, ldd, act, ldx, rows, J, K, dW, dbias, splits};
+  return hig_wgrad16_launch_group(&q, 1, slabs, slab_floats, st, deferred, nullptr);
 }
 
 int hig_wgrad16_reduce_batch(const hig_wg_reduce* entries, int n, hipStream_t st) {

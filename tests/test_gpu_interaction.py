@@ -243,6 +243,37 @@ def test_fused_two_person_step_with_bf16_storage_tracks_the_fp32_step(with_label
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
 
 
+def test_captured_pit_step_with_bf16_storage_does_not_depend_on_when_the_host_synchronises():
+    """Regression (round 5): at bench.py's two-person size the captured bf16 PIT step diverged (loss 1.97 -> 2.6 -> 3.3 ... -> NaN) when the
+    graph was replayed onto an IDLE device -- two warm-up steps, torch.cuda.synchronize(), then steps back to back, i.e. exactly
+    bench.py's timed() -- and trained normally without the synchronisation: a hipMemset2DAsync / hipMemcpyAsync pair of the
+    two-person bf16 backward (init-pose rows, shifted positional table) ran out of order as graph nodes.  They are kernels now;
+    the loss trajectory must not depend on the synchronisation pattern."""
+    import hig_amd.trainers  # noqa: F401
+    c = dict(B=64, T=91, F=263, d=512, H=8, L=8, ff=1024, N=77, Lt=256, num_frames=196)
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(32, c["T"], c["F"], generator=g).to(DEV)
+    nz = torch.randn(32, c["T"], c["F"], generator=g).to(DEV)
+    tt = torch.randint(0, 1000, (16,), generator=g).to(DEV)
+    ln = torch.randint(20, c["T"], (16,), generator=g).to(DEV)
+    xp = torch.randn(64, 4 * c["d"], generator=g).to(DEV)
+    xo = torch.randn(64, c["N"], c["Lt"], generator=g).to(DEV)
+    runs = []
+    for sync_after in (None, 1):
+        m = build(c, storage="bf16").train()
+        tr = _trainer(dict(c, B=16), m)
+        losses = []
+        for k in range(6):
+            tr.train_step_captured(x0, tt, ln, xp, xo, noise=nz)
+            losses.append(tr.fused_state()["loss"].clone())
+            if sync_after is not None and k == sync_after:
+                torch.cuda.synchronize()
+        runs.append([v.item() for v in losses])
+        del tr, m
+    assert runs[0] == runs[1], runs
+    assert all(v == v and abs(v) < float("inf") for v in runs[0]), runs[0]
+
+
 def test_swapping_the_two_persons_swaps_the_outputs():
     """Size-independent property at a production-like size: the model is symmetric in the two
     persons, so model(cat[x2, x1]) == swap(model(cat[x1, x2])) when both share text / t / length."""
