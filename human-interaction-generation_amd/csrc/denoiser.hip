@@ -781,6 +781,10 @@ __global__ void cast_rows_bf16_kernel(const float* __restrict__ src, int64_t lds
   }
 }
 
+__global__ void zero_u32_kernel(unsigned* __restrict__ p, int64_t n) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
 __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
@@ -2140,7 +2144,8 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
       HIG_CHECK_LAUNCH();
     }
     HIG_TRY(hig_cast_pad_bf16(x, F, M, F, edgeb + e_x, Fp, stream));
-    if (hipMemsetAsync(edgeb + e_wot, 0, (size_t)d * Fp * 2, st) != hipSuccess) return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)(((int64_t)d * Fp / 2 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(edgeb + e_wot), (int64_t)d * Fp / 2);
+    HIG_CHECK_LAUNCH();
     HIG_TRY(hig_transpose_bf16(P16(params16, HIG_P_OUT_W), d, F, d, edgeb + e_wot, Fp, stream));   // (F, d) -> (d, Fp), pad columns zero
     // d(W_out) (F, d) and d(b_out) (F) = d(out)^T h_L and its column sums
     HIG_TRY(wgrad_edge(edgeb + e_dout, Fp, hL, d, reinterpret_cast<float*>(edgeb + e_dwo), reinterpret_cast<float*>(edgeb + e_dbo), GP(grads, HIG_P_OUT_W), F, d,
@@ -2151,7 +2156,8 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
   } else {
     const float* dout_m = dout;   // rows that went through `out`
     if (D.two) {                  // (the fp32 edge: a copy of d(out) with the init-pose rows zeroed, in the second fp32 scratch)
-      if (hipMemcpyAsync(f32b, dout, (size_t)M * F * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
+      hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)((M * F + 255) / 256)), dim3(256), 0, st, dout, f32b, M * F);
+      HIG_CHECK_LAUNCH();
       hipLaunchKernelGGL(tok0_kernel, dim3((D.B * F + 255) / 256), dim3(256), 0, st, f32b, (int64_t)D.T * F, D.B, F, (float*)nullptr, 1);
       HIG_CHECK_LAUNCH();
       dout_m = f32b;
@@ -2310,9 +2316,11 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
     hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)((nsh + 255) / 256)), dim3(256), 0, st, dpos + d, GP(grads, HIG_P_SEQ_EMB), nsh);
     HIG_CHECK_LAUNCH();
   }
-  if (D.nf > Tpos)
-    if (hipMemsetAsync(GP(grads, HIG_P_SEQ_EMB) + (int64_t)Tpos * d, 0, (size_t)(D.nf - Tpos) * d * 4, st) != hipSuccess)
-      return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+  if (D.nf > Tpos) {
+    const int64_t nz = (int64_t)(D.nf - Tpos) * d;
+    hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(GP(grads, HIG_P_SEQ_EMB) + (int64_t)Tpos * d), nz);
+    HIG_CHECK_LAUNCH();
+  }
   if (dx) {   // (input gradient: asked for by tests only -- the fp32 kernel on an fp32 copy of d(h_0))
     if (edge16) HIG_TRY(hig_cast_f32(dh, f32b, M * d, stream));
     HIG_TRY(hig_gemm_launch(G(f32b, d, 0, P(params, HIG_P_JOINT_W), F, 1, dx, F, M, F, d).g, 1, nullptr, st));
@@ -2343,8 +2351,8 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
   const int eb = (int)((nBE + 255) / 256);
   hipLaunchKernelGGL(mul_dsilu_kernel, dim3(eb), dim3(256), 0, st, dtmp, emb, nBE, demb);
   HIG_CHECK_LAUNCH();
-  if (hipMemcpyAsync(dxf_proj, demb, (size_t)nBE * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
+  hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)((nBE + 255) / 256)), dim3(256), 0, st, demb, dxf_proj, nBE);
+  HIG_CHECK_LAUNCH();
   HIG_TRY(hig_colsum(demb, E, D.B, E, GP(grads, HIG_P_TE2_B), colp, stream));
   HIG_TRY(hig_gemm_launch(G(demb, E, 1, te_h, E, 1, GP(grads, HIG_P_TE2_W), E, E, E, D.B).silu(1).g, 1, nullptr, st));
   HIG_TRY(hig_gemm_launch(G(demb, E, 0, P(params, HIG_P_TE2_W), E, 1, dtmp, E, D.B, E, E).g, 1, nullptr, st));
