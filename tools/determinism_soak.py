@@ -72,3 +72,33 @@ def soak16(name, c, layers=None):
 
 soak16("bf16 storage, config 2 (training step + per-call inference forward)", bench.CFG)
 soak16("bf16 storage, config-5 width (B=32 T=300 d=1024 H=8, 3 layers)", dict(bench.CFG, B=32, T=300, d=1024, H=8, ff=1024), layers=3)
+
+# round 5: the two-person model with bf16 storage (person <-> person block, grouped weight-gradient launches, batched reductions,
+# kernels where graph memset / memcpy nodes used to be), forward + backward + the captured PIT step replayed from the same state
+def soak16_pair(name):
+    import types
+    c2 = dict(bench.CFG, B=64, T=91, F=263)
+    torch.manual_seed(0)
+    m = hig_amd.MotionInteractionTransformer(input_feats=c2["F"], num_frames=196, latent_dim=c2["d"], ff_size=c2["ff"], num_layers=c2["L"],
+                                             num_heads=c2["H"], text_latent_dim=c2["Lt"], storage="bf16")
+    with torch.no_grad():
+        for pname, p in m.named_parameters():
+            if pname.startswith("out") or ".ffn.linear2." in pname or ".out_layers.2." in pname: p.copy_(torch.randn(p.shape) * 0.02)
+    m = m.to(dev).train()
+    i = bench.make_inputs(c2, dev, 0)
+    i["length"] = (torch.arange(c2["B"], device=dev) * 37 % (c2["T"] - 1) + 1).long()
+    ref = None
+    for it in range(n):
+        m.zero_grad(set_to_none=True)
+        out, saved = m._launch_forward(i["x"], i["t"], i["length"], i["xf_proj"], i["xf_out"], training=True)
+        dx, dxp, dxo = m._launch_backward(i["x"], i["t"], i["length"], i["xf_out"], saved, i["x0"], want_dx=True)
+        cur = [out.clone(), dx.clone(), dxp.clone(), dxo.clone(), m.flat_params().grad[:m.flat_params().core_numel].clone()]
+        if ref is None:
+            ref = cur
+            assert all(torch.isfinite(t.float()).all() for t in cur)
+        else:
+            for k, (a, b) in enumerate(zip(ref, cur)):
+                assert torch.equal(a, b), (name, it, k, (a.float() - b.float()).abs().max().item())
+    print("%s: %d identical iterations" % (name, n))
+
+soak16_pair("two-person model, bf16 storage (forward + backward, 64 rows x 91 tokens x 263 features)")
