@@ -424,6 +424,7 @@ def main():
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")   # (collectives are captured into the step's graph: parallel.py)
         backend = os.environ.get("HIG_DIST_BACKEND", "nccl")  # "nccl" == RCCL over xGMI; gloo: 1-GPU self-test
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)

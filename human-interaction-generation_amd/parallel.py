@@ -197,6 +197,9 @@ def run_distributed(fn, rank, world_size, backend=None, *args, set_device=True, 
         torch.cuda.set_device(dev)
         if backend == "nccl":
             kw["device_id"] = dev
+    # (RCCL collectives are captured into the training step's hipGraph: do not let the process group recycle events that were last
+    # recorded under capture -- its watchdog thread may still poll a collective that holds one)
+    os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
     dist.init_process_group(backend, rank=rank, world_size=world_size, **kw)
     try:
         if world_size > 1:

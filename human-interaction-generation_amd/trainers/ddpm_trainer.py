@@ -581,6 +581,11 @@ class DDPMTrainer(object):
             # thread_local: other threads (the RCCL watchdog polls its events) may call into HIP while we capture
             ga, gb = torch.cuda.CUDAGraph(), None
             if in_graph:
+                # Let the process group's watchdog thread retire the warm-up's collectives before events are recorded under capture:
+                # once, under a loaded box, it queried an event "last recorded in a capturing stream" and took the process down
+                # (profiles/r05_notes.md section 5).  It polls every 100 ms; captures happen once per batch shape.
+                torch.cuda.synchronize()
+                time.sleep(0.3)
                 try:
                     with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                         whole_step_with_exchange()

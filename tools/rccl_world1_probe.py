@@ -10,6 +10,7 @@ Runs in ONE process: the process group is created before anything touches the GP
 import json, os, sys, time, types
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29631"), RANK="0", WORLD_SIZE="1")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
