@@ -528,7 +528,7 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
   }
   // inference + linear attention: `apply` and the stylization front that follows it can run as ONE kernel (the (M, d)
   // attention output never reaches HBM); training keeps the pair -- the backward reads y and the LayerNorm statistics.
-  // Opt-in (HIG_FUSE_APPLY_F32=1): measured 34.0 against 36.0 us per attention at B = 64 (head dim 64), equal at B = 32,
+  // Not used (a switch until round 5): measured 34.0 against 36.0 us per attention at B = 64 (head dim 64), equal at B = 32,
   // 83.8 against 71.1 us at head dim 128, forward 6.24 against 6.26 ms -- the fused kernel's fp32 MFMAs and its
   // LayerNorm / SiLU arithmetic share the SIMD lanes and a workgroup's chain (load, 2 heads, statistics, epilogue,
   // store) is 26K cycles long with two workgroups per CU to hide it (profiles/r02_notes.md section 9)

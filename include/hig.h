@@ -624,8 +624,8 @@ int hig_linattn_apply_sty_mm16(const void* Q, int64_t ldq, const void* At16, con
 int hig_linattn_apply_sty_mm16_y(const void* Q, int64_t ldq, const void* At16, const float* gamma, const float* beta,
                                  const float* ss, int64_t ss_ld, int32_t ss_shift_off, void* Out, int64_t ldo, void* Yout, int64_t ldy,
                                  int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
-/* The same fused kernel with fp32 storage (hig_denoiser_fwd uses it for inference when HIG_FUSE_APPLY_F32=1; by default
- * it runs hig_linattn_apply + hig_ln_mod_silu, which measured equal).  Q, Out fp32, 16-byte aligned. */
+/* The same fused kernel with fp32 storage (a standalone entry point: hig_denoiser_fwd runs hig_linattn_apply +
+ * hig_ln_mod_silu, which measured equal).  Q, Out fp32, 16-byte aligned. */
 int hig_linattn_apply_sty(const float* Q, int64_t ldq, const float* A, const float* gamma, const float* beta,
                           const float* ss, int64_t ss_ld, int32_t ss_shift_off, float* Out, int64_t ldo,
                           int32_t B, int32_t rows, int32_t H, int32_t hd, hig_stream_t stream);
