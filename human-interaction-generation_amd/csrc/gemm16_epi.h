@@ -7,44 +7,41 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-// Exact-erf GELU (nn.GELU(), transformer.py:160) for a result that is rounded to bf16 (2^-9) right away: erf by
-// Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7: one exp, one rcp, five FMAs) instead of the 30-instruction libm erff --
-// the epilogue's VALU work was 10 of the 43 us of the FFN linear1 launch (profiles/r02_notes.md).
+// Exact-erf GELU (nn.GELU(), transformer.py:160) for a result that is rounded to bf16 (2^-9) right away:
+//     gelu(x) = x Phi(x) = max(x, 0) - |x| Q(|x|),      Q(t) = 1 - Phi(t) = erfc(t / sqrt 2) / 2 = exp2(p(t))
+// with p a degree-6 fit of log2 Q on [0, 6.5] (|error| <= 2.5e-4, i.e. Q to 1.7e-4 RELATIVE -- also in the tails, where an
+// erf with an absolute error loses the small negative outputs; beyond 6.5 Q < 5e-11 and t is clamped).  Ten vector
+// instructions, ONE of them quarter-rate (v_exp_f32): 52 cycles of the SIMD's vector ALU per 64 outputs against 76 for the
+// Abramowitz-Stegun 7.1.26 form used until round 5 (rcp + exp + 11 others) -- the GELU epilogue of the weight-stationary GEMMs
+// is bound by exactly that ALU (profiles/r05_notes.md section 7).  Against gelu evaluated in double and rounded to bf16, on a
+// uniform grid over [-8, 8]: 9.7 % of the rounded outputs differ by one ulp (the old form: 15.5 %).
+constexpr float HIG_GELU_Q0 = -1.00025339f, HIG_GELU_Q1 = -1.14901738f, HIG_GELU_Q2 = -0.463114774f, HIG_GELU_Q3 = -0.0499779109f,
+                HIG_GELU_Q4 = 0.00682028804f, HIG_GELU_Q5 = -0.000556051072f, HIG_GELU_Q6 = 1.99234738e-05f, HIG_GELU_TMAX = 6.5f;
 __device__ __forceinline__ float gelu_bf16(float x) {
-  // 13 vector instructions (|.| and negation are operand modifiers): the epilogue of FFN linear1 is bound by the vector
-  // unit, not by the matrix pipe (4 outputs per clock and CU leave 16 lane-operations per output)
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
-  float p = fmaf(t, 1.061405429f, -1.453152027f);
-  p = fmaf(t, p, 1.421413741f);
-  p = fmaf(t, p, -0.284496736f);
-  p = fmaf(t, p, 0.254829592f);
-  p *= t;
-  const float zz = ax * (0.70710678118654752440f * 1.2011224087864498f);   // z sqrt(log2 e): exp(-z^2) = exp2(-zz^2)
-  const float erf_abs = fmaf(-p, __builtin_amdgcn_exp2f(-(zz * zz)), 1.0f);
-  const float h = 0.5f * x;
-  return fmaf(fabsf(h), erf_abs, h);             // 0.5 x (1 + sign(x) erf|z|)
+  const float t = fminf(fabsf(x), HIG_GELU_TMAX);
+  float p = fmaf(t, HIG_GELU_Q6, HIG_GELU_Q5);
+  p = fmaf(t, p, HIG_GELU_Q4);
+  p = fmaf(t, p, HIG_GELU_Q3);
+  p = fmaf(t, p, HIG_GELU_Q2);
+  p = fmaf(t, p, HIG_GELU_Q1);
+  p = fmaf(t, p, HIG_GELU_Q0);
+  return fmaf(-fabsf(x), __builtin_amdgcn_exp2f(p), fmaxf(x, 0.f));
 }
 
-// The same on a pair of outputs with packed fp32 arithmetic (v_pk_fma / v_pk_mul_f32: two elements per issue slot): the
-// epilogues of the weight-stationary kernel are bound by instruction issue, and of the 13 instructions above only the
-// reciprocal and the exponential have no packed form -- 7 packed + 2 x 2 transcendental + 2 (|x|) per pair instead of 26.
-// (exp(-z^2) from x^2 directly: no |x| needed there.)
+// The same on a pair of outputs (gemm_ws16.hip: packed fp32 arithmetic, the exponential per element): the same operations in
+// the same order, so the same bits as gelu_bf16.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_bf16_pk(f32x2 x) {
   const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
-  const f32x2 den = __builtin_elementwise_fma(ax, f32x2{0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f}, f32x2{1.0f, 1.0f});
-  const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-  f32x2 p = __builtin_elementwise_fma(t, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
-  p = __builtin_elementwise_fma(t, p, f32x2{1.421413741f, 1.421413741f});
-  p = __builtin_elementwise_fma(t, p, f32x2{-0.284496736f, -0.284496736f});
-  p = __builtin_elementwise_fma(t, p, f32x2{0.254829592f, 0.254829592f});
-  p *= t;
-  constexpr float K2 = -(0.70710678118654752440f * 1.2011224087864498f) * (0.70710678118654752440f * 1.2011224087864498f);   // -(z^2 log2 e) / x^2
-  const f32x2 arg = (x * x) * K2;
-  const f32x2 ex = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
-  const f32x2 erf_abs = __builtin_elementwise_fma(-p, ex, f32x2{1.0f, 1.0f});
-  return __builtin_elementwise_fma(ax * 0.5f, erf_abs, x * 0.5f);      // 0.5 x (1 + sign(x) erf|z|)
+  const f32x2 t = {fminf(ax[0], HIG_GELU_TMAX), fminf(ax[1], HIG_GELU_TMAX)};
+  f32x2 p = __builtin_elementwise_fma(t, f32x2{HIG_GELU_Q6, HIG_GELU_Q6}, f32x2{HIG_GELU_Q5, HIG_GELU_Q5});
+  p = __builtin_elementwise_fma(t, p, f32x2{HIG_GELU_Q4, HIG_GELU_Q4});
+  p = __builtin_elementwise_fma(t, p, f32x2{HIG_GELU_Q3, HIG_GELU_Q3});
+  p = __builtin_elementwise_fma(t, p, f32x2{HIG_GELU_Q2, HIG_GELU_Q2});
+  p = __builtin_elementwise_fma(t, p, f32x2{HIG_GELU_Q1, HIG_GELU_Q1});
+  p = __builtin_elementwise_fma(t, p, f32x2{HIG_GELU_Q0, HIG_GELU_Q0});
+  const f32x2 q = {__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
+  return __builtin_elementwise_fma(-ax, q, f32x2{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)});
 }
 __device__ __forceinline__ f32x2 silu_fast_pk(f32x2 x) {
   const f32x2 w = x * -1.4426950408889634f;

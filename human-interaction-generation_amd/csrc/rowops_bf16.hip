@@ -5,6 +5,7 @@
 // One 64-lane wave per row (four consecutive rows per wave), 8 elements (16 bytes of bf16) per lane per sweep, the rows stay in
 // registers between the statistics and the transform: x is read once, out written once -- HBM-bound at 2 x rows x n x 2 bytes.
 #include "hig_common.h"
+#include "gemm16_epi.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -157,14 +158,14 @@ extern "C" int hig_ln_bf16(const void* x, int32_t x_f32, int64_t ldx, int64_t ro
 
 // ---- bf16-storage training step: elementwise helpers ---------------------------------------------------------------------
 namespace {
-// exact-erf GELU on bf16 rows (nn.GELU(), transformer.py:160,168): f = gelu(z).  The training forward keeps BOTH z (the
+// erf GELU on bf16 rows (nn.GELU(), transformer.py:160,168; gelu_bf16 of gemm16_epi.h: the arithmetic of the GEMM epilogues): f = gelu(z).  The training forward keeps BOTH z (the
 // backward's gelu'(z)) and f (operand of linear2); the weight-stationary GEMM writes z, this pass derives f.
 __global__ __launch_bounds__(256) void gelu16_kernel(const __bf16* __restrict__ z, __bf16* __restrict__ f, int64_t n8) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
     const bf16x8 v = reinterpret_cast<const bf16x8*>(z)[i];
     bf16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (__bf16)hig_gelu((float)v[e]);
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)gelu_bf16((float)v[e]);
     reinterpret_cast<bf16x8*>(f)[i] = o;
   }
 }
