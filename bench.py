@@ -202,11 +202,11 @@ def ffn_gemm_bf16_roofline(c, device, reps=32):
     flops = 2.0 * M * K * Nn
     ach = flops / (ms * 1e-3) / 1e12
     by = (M * K + Nn * K + M * Nn) * 2
-    return {"bound": "mfma (nominal).  Measured (profiles/r05_notes.md sections 2 and 7: s_memtime stamps, tools/coissue_probe.hip, "
-                     "lds_read_probe.hip, and a K-split variant with twice the waves that did NOT get faster): a 32 x 128 tile costs "
-                     "~2.0 K cycles against 1.0 K of MFMA issue -- the exact-erf GELU epilogue keeps each SIMD's vector ALU busy "
-                     "~1.5 K cycles per tile (11 full-rate + 2 quarter-rate instructions per element), and without it the tile "
-                     "sits at ~1.4 K cycles on the CU's LDS pipe (128 KB of fragment reads + 32 KB of DMA writes + the fp32 hand-off per tile)",
+    return {"bound": "mfma (nominal).  Measured (profiles/r05_notes.md sections 2, 7 and 9: s_memtime stamps, tools/coissue_probe.hip, "
+                     "lds_read_probe.hip, a K-split variant with twice the waves that did NOT get faster): a 32 x 128 tile costs "
+                     "~2.2 K cycles against 1.0 K of MFMA issue -- per tile the four service waves spend ~780 cycles issuing the "
+                     "eight LDS-DMA instructions of the next X tile (the CU's fetch path takes ~11 B/clk per wave) and ~1.5 K on the "
+                     "GELU epilogue, in order; without an epilogue the tile sits at ~1.4 K cycles on the CU's LDS pipe",
             "kernel": "gemm_wsp16_kernel<EPI_BIAS_GELU> (weight-stationary, specialised matrix / service waves; FFN linear1, bf16 "
                       "storage: M=%d K=%d N=%d, bias+GELU)" % (M, K, Nn),
             "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
