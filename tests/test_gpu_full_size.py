@@ -40,6 +40,31 @@ CONFIG5 = dict(B=32, T=300, F=150, d=1024, H=8, L=12, ff=1024, N=77, Lt=256, num
                lengths=tuple([300, 211] + [300] * 20 + list(range(30, 300, 27))), t=tuple(int(v) for v in np.linspace(0, 999, 32)))
 
 
+@pytest.mark.parametrize("B", [32, 64])
+def test_fp32_per_call_forward_at_config2_size_equals_the_cached_form(B):
+    """hig_denoiser_fwd_text at the size where BOTH the frame-row GEMMs and the forked text-side key/value GEMMs (B x 77 rows: 624
+    tiles of 64 x 64 at B = 32) take the split tail of the fp32 GEMM: each side has its own ticket / partial-sum scratch (ADVICE r04:
+    shared, a workgroup could draw another launch's "last" ticket).  The cached context is built WITHOUT a split tail (another
+    summation order of the last round's tiles), so the two forms agree to rounding, not bitwise; the per-call form must repeat bit
+    for bit -- tickets or partial sums shared between the two concurrent launches would show as run-to-run differences."""
+    c = dict(CONFIG2, B=B, lengths=CONFIG2["lengths"][:B], t=CONFIG2["t"][:B])
+    m = build(c).eval()
+    gi = {k: v.to(DEV) for k, v in fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"]).items()}
+
+    def fwd():
+        with torch.no_grad():
+            return m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+
+    m.cache_text_context = True
+    ref = fwd()
+    assert torch.isfinite(ref).all()
+    m.cache_text_context = False
+    first = fwd()
+    assert rel(first, ref) < 2e-6
+    for _ in range(12):
+        assert torch.equal(fwd(), first)
+
+
 @pytest.mark.parametrize("no_eff", [False, True])
 def test_config5_as_specified_bf16_storage_forward_slice_against_oracle(no_eff):
     """BASELINE config 5 AS SPECIFIED -- B=32, T=300, d=1024, L=12, head dim 128, bf16 storage -- with linear attention and with
