@@ -341,3 +341,23 @@ def test_no_kernel_of_the_built_library_spills_registers(tmp_path):
                 offenders.append((nm, int(v), int(sg), int(sc)))
     assert kernels > 300
     assert not offenders, offenders
+
+
+def test_every_environment_switch_of_the_library_is_documented_and_flipped_by_a_test():
+    """The switch surface stays closed: every getenv("HIG_...") in csrc/ is a row of DESIGN.md's "Switches" table and -- unless it is one
+    of the diagnostic switches whose builds are wrong by construction -- an entry of tests/test_gpu_knobs.py."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, "human-interaction-generation_amd", "csrc", "*.h*")):
+        names |= set(re.findall(r'getenv\("(HIG_[A-Z0-9_]+)"\)', open(f).read()))
+    assert len(names) >= 20
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    table = design[design.index("**Switches.**"):]
+    knobs = open(os.path.join(root, "tests", "test_gpu_knobs.py")).read()
+    diagnostic = {"HIG_BF16_DBG", "HIG_BF16_WSP_DBG"}
+    for n in sorted(names):
+        assert "`%s`" % n in table, "%s is read by the library but missing from DESIGN.md's switch table" % n
+        if n not in diagnostic:
+            assert '("%s"' % n in knobs, "%s is not flipped by tests/test_gpu_knobs.py" % n
