@@ -350,7 +350,8 @@ def test_every_environment_switch_of_the_library_is_documented_and_flipped_by_a_
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     names = set()
-    for f in glob.glob(os.path.join(root, "human-interaction-generation_amd", "csrc", "*.h*")):
+    csrc = os.path.join(root, "human-interaction-generation_amd", "csrc")
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
         names |= set(re.findall(r'getenv\("(HIG_[A-Z0-9_]+)"\)', open(f).read()))
     assert len(names) >= 20
     design = open(os.path.join(root, "DESIGN.md")).read()
