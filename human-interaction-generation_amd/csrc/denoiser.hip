@@ -1310,7 +1310,14 @@ extern "C" int hig_denoiser_bwd_hooked(const hig_dims* dims, const void* const* 
     return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
   const TailScratchScope tail_scope(b + bw.gtail);
 
-  WgradFork fork(side_stream_for_current_device(st), st);
+  // Eager launches: the weight gradients go to the second stream.  Under stream capture they stay on the caller's (unless
+  // HIG_BWD_OVERLAP=1): the replayed graph did not turn the fork into overlap -- config 2, captured fp32 step 21.6-21.7 ms forked
+  // against 21.2 on one stream, while eager launches gain a millisecond from it (20.4 against 21.3).
+  static const int fork_env = getenv("HIG_BWD_OVERLAP") ? atoi(getenv("HIG_BWD_OVERLAP")) : -1;
+  hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap_status) != hipSuccess) cap_status = hipStreamCaptureStatusNone;
+  const bool want_fork = fork_env == 1 || (fork_env != 0 && cap_status == hipStreamCaptureStatusNone);
+  WgradFork fork(want_fork ? side_stream_for_current_device(st) : nullptr, st);
   hig_stream_t wstream = reinterpret_cast<hig_stream_t>(fork.stream());
   auto wgrad_on = [&](G gd) -> int {  // X, Y both reduce-slow; split over the reduce rows
     const int s = wgrad_splits(gd.g.I, gd.g.J, gd.g.R, bw.slab_floats, gd.g.prec);
