@@ -448,8 +448,7 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
   const int Bp = D.B / 2;  // pairs (two-person)
 
   // the forward's GEMMs all run on `st`: they share one split-tail scratch (tickets zeroed here, left zero by each launch)
-  if (hipMemsetAsync(ws + w.gtail, 0, HIG_GEMM_TAIL_CNT_BYTES, st) != hipSuccess)
-    return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+  HIG_TRY(hig_zero_async(ws + w.gtail, HIG_GEMM_TAIL_CNT_BYTES, st));
   const TailScratchScope tail_scope(ws + w.gtail);
 
   // The cross-attention text side (hig_denoiser_fwd_text): layer l's context matrices are first needed in front of layer l's
@@ -481,8 +480,7 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
       // The text side's key/value GEMMs run NEXT TO the GEMMs on `st`: they get a split-tail scratch of their own (tickets and
       // partial sums shared between two concurrent launches would hand a workgroup another GEMM's "last arriver" ticket or
       // slices: B = 32, N = 77 text rows qualify for the split tail just like the q/k/v launch beside them).
-      if (hipMemsetAsync(ws + w.gtail3, 0, HIG_GEMM_TAIL_CNT_BYTES, st) != hipSuccess)
-        return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+      HIG_TRY(hig_zero_async(ws + w.gtail3, HIG_GEMM_TAIL_CNT_BYTES, st));
       if (hipEventRecord(ts->ready, st) != hipSuccess || hipStreamWaitEvent(ts->s3, ts->ready, 0) != hipSuccess)
         return hig_set_error(HIG_EHIP, "text fork failed");
       hig_gemm_set_tail_scratch(ws + w.gtail3, HIG_GEMM_TAIL_BYTES);
@@ -685,8 +683,7 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
   const float* hin = ws + w.h0;
   if (side) {
     const int nbA = D.B / 2, nbB = D.B - nbA;
-    if (hipMemsetAsync(ws + w.gtail2, 0, HIG_GEMM_TAIL_CNT_BYTES, st) != hipSuccess)
-      return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+    HIG_TRY(hig_zero_async(ws + w.gtail2, HIG_GEMM_TAIL_CNT_BYTES, st));
     if (hipEventRecord(side->ready, st) != hipSuccess || hipStreamWaitEvent(side->s2, side->ready, 0) != hipSuccess)
       return hig_set_error(HIG_EHIP, "forward fork failed");
     // Whatever happens inside the forked region, the side stream is joined back into `st` and the thread's GEMM tail
@@ -1306,8 +1303,7 @@ extern "C" int hig_denoiser_bwd_hooked(const hig_dims* dims, const void* const* 
 
   // data-gradient GEMMs (caller's stream) may split their tail; the weight gradients on the side stream never do
   // (reduce-slow X operand or split-R: excluded by the rule in gemm.hip), so one scratch serves the whole backward
-  if (hipMemsetAsync(b + bw.gtail, 0, HIG_GEMM_TAIL_CNT_BYTES, st) != hipSuccess)
-    return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+  HIG_TRY(hig_zero_async(b + bw.gtail, HIG_GEMM_TAIL_CNT_BYTES, st));
   const TailScratchScope tail_scope(b + bw.gtail);
 
   // Eager launches: the weight gradients go to the second stream.  Under stream capture they stay on the caller's (unless
@@ -1386,8 +1382,7 @@ extern "C" int hig_denoiser_bwd_hooked(const hig_dims* dims, const void* const* 
   if (D.two) {
     // init-pose rows went through out2 (:613): separate them from the `out` adjoint
     float* dm = b + bw.doutm;
-    if (hipMemcpyAsync(dm, dout, (size_t)M * F * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
-      return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
+    HIG_TRY(hig_copy_async(dm, dout, (size_t)M * F * 4, st));
     hipLaunchKernelGGL(tok0_kernel, dim3((D.B * F + 255) / 256), dim3(256), 0, st, dm, (int64_t)D.T * F, D.B, F,
                        (float*)nullptr, 1);
     HIG_CHECK_LAUNCH();
@@ -1557,15 +1552,12 @@ extern "C" int hig_denoiser_bwd_hooked(const hig_dims* dims, const void* const* 
   const int Tpos = D.two ? D.T - 1 : D.T;  // rows of sequence_embedding that were used
   if (D.two) {  // frame t used row t-1
     HIG_TRY(colsum(dh, (int64_t)D.T * d, D.B, D.T * d, b + bw.postmp));
-    if (hipMemcpyAsync(GP(grads, HIG_P_SEQ_EMB), b + bw.postmp + d, (size_t)Tpos * d * 4, hipMemcpyDeviceToDevice, st) !=
-        hipSuccess)
-      return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
+    HIG_TRY(hig_copy_async(GP(grads, HIG_P_SEQ_EMB), b + bw.postmp + d, (size_t)Tpos * d * 4, st));
   } else {
     HIG_TRY(colsum(dh, (int64_t)D.T * d, D.B, D.T * d, GP(grads, HIG_P_SEQ_EMB)));
   }
   if (D.nf > Tpos)
-    if (hipMemsetAsync(GP(grads, HIG_P_SEQ_EMB) + (int64_t)Tpos * d, 0, (size_t)(D.nf - Tpos) * d * 4, st) != hipSuccess)
-      return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+    HIG_TRY(hig_zero_async(GP(grads, HIG_P_SEQ_EMB) + (int64_t)Tpos * d, (size_t)(D.nf - Tpos) * d * 4, st));
   if (dx) {
     HIG_TRY(hig_gemm_launch(G(dh, d, 0, P(params, HIG_P_JOINT_W), F, 1, dx, F, M, F, d).g, 1, nullptr, st));
     if (D.two)  // d(x[:, 0, :4]) through joint_embed2; the other features of the init-pose row are unused
@@ -1589,8 +1581,7 @@ extern "C" int hig_denoiser_bwd_hooked(const hig_dims* dims, const void* const* 
   const int eb = (int)((nBE + 255) / 256);
   hipLaunchKernelGGL(mul_dsilu_kernel, dim3(eb), dim3(256), 0, st, b + bw.dtmp, emb, nBE, b + bw.demb);
   HIG_CHECK_LAUNCH();
-  if (hipMemcpyAsync(dxf_proj, b + bw.demb, (size_t)nBE * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
+  HIG_TRY(hig_copy_async(dxf_proj, b + bw.demb, (size_t)nBE * 4, st));
   HIG_TRY(colsum(b + bw.demb, E, D.B, E, GP(grads, HIG_P_TE2_B)));
   HIG_TRY(hig_gemm_launch(G(b + bw.demb, E, 1, ws + w.te_h, E, 1, GP(grads, HIG_P_TE2_W), E, E, E, D.B).silu(1).g, 1, nullptr, st));
   HIG_TRY(hig_gemm_launch(G(b + bw.demb, E, 0, P(params, HIG_P_TE2_W), E, 1, b + bw.dtmp, E, D.B, E, E).g, 1, nullptr, st));

@@ -127,3 +127,7 @@ int hig_ln_bwd16_launch(const void* da, int64_t ldda, const void* x, int32_t x_f
                         int32_t rows_per_sample, float* dgamma, float* dbeta, float* dss, int64_t dss_ld,
                         float* partial, hig_stream_t stream, hig_ln_reduce* deferred);
 int hig_ln_bwd16_reduce_batch(const hig_ln_reduce* entries, int n, hipStream_t st);
+
+// rowops.hip: fill / copy as kernels (never hipMemsetAsync / hipMemcpyAsync on a stream that may be under capture: see there)
+int hig_zero_async(void* p, int64_t bytes, hipStream_t st);
+int hig_copy_async(void* dst, const void* src, int64_t bytes, hipStream_t st);

@@ -1004,6 +1004,44 @@ extern "C" int hig_colsum(const float* x, int64_t ldx, int64_t rows, int32_t n, 
 }
 
 
+// Device-side fill / copy as KERNELS.  The library does not put hipMemsetAsync / hipMemcpyAsync (1-D or 2-D) into streams that may be
+// under capture: as nodes of a replayed hipGraph they were seen to run out of order with the neighbouring kernel nodes when the graph
+// was launched onto an idle device (the two-person training steps diverged: profiles/r05_notes.md section 8).
+namespace {
+__global__ void zero_words_kernel(unsigned* __restrict__ p, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+__global__ void copy_words_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void copy_quads_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+int hig_zero_async(void* p, int64_t bytes, hipStream_t st) {
+  HIG_REQUIRE(bytes >= 0 && bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 3) == 0, "hig_zero_async: whole 4-byte words");
+  if (bytes == 0) return HIG_OK;
+  const int64_t n = bytes / 4;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<unsigned*>(p), n);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+int hig_copy_async(void* dst, const void* src, int64_t bytes, hipStream_t st) {
+  HIG_REQUIRE(bytes >= 0 && bytes % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 3) == 0,
+              "hig_copy_async: whole 4-byte words");
+  if (bytes == 0) return HIG_OK;
+  const bool quads = bytes % 16 == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+  const int64_t n = quads ? bytes / 16 : bytes / 4;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (quads) hipLaunchKernelGGL(copy_quads_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const uint4*>(src), static_cast<uint4*>(dst), n);
+  else hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const unsigned*>(src), static_cast<unsigned*>(dst), n);
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
 // ---- bf16-storage training step: row kernels with bf16 I/O -------------------------------------------------------------
 // deferred (nullable; needs dgamma and dbeta): the reductions of the partial table are NOT launched -- *deferred describes them for
 // hig_ln_bwd16_reduce_batch, and `partial` must stay untouched until then.

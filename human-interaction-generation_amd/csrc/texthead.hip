@@ -234,10 +234,9 @@ extern "C" int hig_text_head_bwd(const hig_text_dims* dims, const void* const* p
   float* dC = b + bw.dC;
   // ---- d(xf_out) total = upstream + scatter of d(text_proj input) at the EOT rows -------------
   if (dxf_out) {
-    if (hipMemcpyAsync(dA, dxf_out, (size_t)M * Lt * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
-      return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
-  } else if (hipMemsetAsync(dA, 0, (size_t)M * Lt * 4, st) != hipSuccess) {
-    return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+    HIG_TRY(hig_copy_async(dA, dxf_out, (size_t)M * Lt * 4, st));
+  } else {
+    HIG_TRY(hig_zero_async(dA, (size_t)M * Lt * 4, st));
   }
   if (dxf_proj) {
     HIG_TRY(colsum(dxf_proj, E, D.B, E, TG(grads, HIG_T_PROJ_B)));
@@ -245,9 +244,8 @@ extern "C" int hig_text_head_bwd(const hig_text_dims* dims, const void* const* p
     HIG_TRY(hig_gemm_launch(G(dxf_proj, E, 0, TP(params, HIG_T_PROJ_W), Lt, 1, b + bw.dgath, Lt, D.B, Lt, E).g, 1, nullptr, st));
     HIG_TRY(hig_scatter_add_rows(b + bw.dgath, Lt, D.B, D.N, eot, Lt, dA, Lt, stream));
   } else {
-    if (hipMemsetAsync(TG(grads, HIG_T_PROJ_B), 0, (size_t)E * 4, st) != hipSuccess ||
-        hipMemsetAsync(TG(grads, HIG_T_PROJ_W), 0, (size_t)E * Lt * 4, st) != hipSuccess)
-      return hig_set_error(HIG_EHIP, "hipMemsetAsync failed");
+    HIG_TRY(hig_zero_async(TG(grads, HIG_T_PROJ_B), (size_t)E * 4, st));
+    HIG_TRY(hig_zero_async(TG(grads, HIG_T_PROJ_W), (size_t)E * Lt * 4, st));
   }
   // ---- text_ln ---------------------------------------------------------------------------
   const float* xL = ws + w.layer0 + w.lstride * (D.L - 1) + w.x2;
@@ -291,8 +289,7 @@ extern "C" int hig_text_head_bwd(const hig_text_dims* dims, const void* const* p
     HIG_TRY(wgrad_act(d, Lt, clip_out, D.W, TG(grads, HIG_T_PRE_W), M, TG(grads, HIG_T_PRE_B)));
     if (dclip) HIG_TRY(dgrad(d, TP(params, HIG_T_PRE_W), Lt, D.W, M, dclip, HIG_EPI_NONE, nullptr, nullptr));
   } else if (dclip) {
-    if (hipMemcpyAsync(dclip, d, (size_t)M * Lt * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
-      return hig_set_error(HIG_EHIP, "hipMemcpyAsync failed");
+    HIG_TRY(hig_copy_async(dclip, d, (size_t)M * Lt * 4, st));
   }
   return HIG_OK;
 }
