@@ -34,7 +34,7 @@ SYMBOLS = (
     "hig_layernorm", "hig_gather_rows", "hig_scatter_add_rows", "hig_gather_frames", "hig_recover_joints", "hig_transpose_batch", "hig_linattn_ctx_scratch_floats", "hig_pair_mse",
     "hig_fullattn_fwd_kpad", "hig_eval_encoder_workspace_bytes", "hig_eval_encoder_fwd",
     "hig_clip_adam_lrdev", "hig_shutdown", "hig_gemm_split", "hig_gemm_split_scratch_floats",
-    "hig_gemm_bf16", "hig_gemm_bf16_debug_stamps", "hig_gemm_ws16_debug_stamps", "hig_gemm_wsp16_debug_stamps", "hig_wgrad16_debug_stamps", "hig_linattn16_debug_stamps", "hig_cast_bf16", "hig_ln_bf16", "hig_linattn_ctx_bf16", "hig_linattn_apply_bf16",
+    "hig_gemm_bf16", "hig_gemm_bf16_debug_stamps", "hig_gemm_ws16_debug_stamps", "hig_gemm_wsp16_debug_stamps", "hig_gemm_wsp32_debug_stamps", "hig_gemm_wsp32_launches", "hig_wgrad16_debug_stamps", "hig_linattn16_debug_stamps", "hig_cast_bf16", "hig_ln_bf16", "hig_linattn_ctx_bf16", "hig_linattn_apply_bf16",
     "hig_text_context_bf16", "hig_denoiser_fwd_bf16", "hig_linattn_apply_sty_bf16", "hig_linattn_apply_sty_mm16", "hig_linattn_apply_sty_mm16_y", "hig_linattn_ctx_mm16", "hig_linattn_apply_sty", "hig_joint_embed_bf16", "hig_joint_embed_bf16_w", "hig_attn_out16", "hig_rows_out16", "hig_weight_frag16", "hig_joint_embed_bf16_scratch_bytes", "hig_fullattn_fwd_bf16", "hig_denoiser_bwd_hooked", "hig_denoiser_bwd_bf16_hooked",
     # round 4: bf16-storage training step
     "hig_text_context_bf16_train", "hig_denoiser_fwd_bf16_train", "hig_denoiser_bwd_bf16", "hig_ln_bwd_bf16",
@@ -165,6 +165,9 @@ def lib():
         L.hig_gemm_bf16_debug_stamps.argtypes = [vp]
         L.hig_gemm_ws16_debug_stamps.argtypes = [vp]
         L.hig_gemm_wsp16_debug_stamps.argtypes = [vp]
+        L.hig_gemm_wsp32_debug_stamps.argtypes = [vp]
+        L.hig_gemm_wsp32_launches.argtypes = []
+        L.hig_gemm_wsp32_launches.restype = i64
         L.hig_wgrad16_debug_stamps.argtypes = [vp]
         L.hig_linattn16_debug_stamps.argtypes = [vp]
         L.hig_cast_bf16.argtypes = [vp, vp, i64, vp]

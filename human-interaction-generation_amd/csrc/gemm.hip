@@ -1157,6 +1157,11 @@ int gemm_dispatch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_t 
     if (!ok) return hig_set_error(HIG_EUNSUPPORTED, "hig_gemm: LayerNorm-fold operands on a launch that cannot apply them "
                                                     "(needs reduce-contiguous aligned operands, J %% 64 == 0, EPI_BIAS_RES producer / EPI_BIAS consumer with R %% 128 == 0)");
   }
+  // exact-fp32 products, K = 512 / 1024, many rows: the weight-stationary kernel with specialised waves (gemm_wsp32.hip)
+  if (splits <= 1 && !se.bias) {
+    const int rc = hig_gemm_wsp32_try(g, st);
+    if (rc != 1) return rc;
+  }
 #define CASE(xrs, yrs, xfv, ony, epiv)                                                   \
   if (g.x_rs == xrs && g.y_rs == yrs && g.xf == xfv && (g.xf == HIG_XF_NONE || g.xf_on_y == ony) && \
       g.epi == epiv)                                                                     \

@@ -53,6 +53,9 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st);
 // weight-stationary kernel with specialised matrix / service waves (gemm_wsp16.hip: K = 512, J % 128 == 0, >= 2048 rows); same codes
 int hig_gemm_wsp16_try(const hig_gemm16_desc& g, hipStream_t st);
 bool hig_gemm_ws16_lnfold_ok(int64_t rows, int d);
+// exact-fp32 weight-stationary kernel with specialised waves (gemm_wsp32.hip: K = 512 / 1024, reduce-contiguous aligned
+// operands, >= 2048 rows); same return codes
+int hig_gemm_wsp32_try(const hig_gemm_desc& g, hipStream_t st);
 
 namespace {
 

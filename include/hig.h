@@ -548,6 +548,10 @@ int hig_gemm_bf16_split(const hig_gemm16_desc* g, int32_t splits, float* slabs, 
 int hig_gemm_bf16_debug_stamps(void* buf);
 int hig_gemm_ws16_debug_stamps(void* buf);
 int hig_gemm_wsp16_debug_stamps(void* buf);   /* gemm_wsp16.hip: buf[block * 16 + k], 256 blocks */
+int hig_gemm_wsp32_debug_stamps(void* buf);   /* gemm_wsp32.hip: buf[block * 16 + k] matrix wave 0, buf[4096 + block * 16 + k] service wave 4 */
+/* Launches served by the exact-fp32 weight-stationary kernel (gemm_wsp32.hip) since the library was loaded: hig_gemm routes
+ * K = 512 / 1024 products with >= 2048 rows there (HIG_F32_WSP=0 switches it off); a test reads the difference around a call. */
+int64_t hig_gemm_wsp32_launches(void);
 int hig_wgrad16_debug_stamps(void* buf);      /* wgrad16.hip (see there): 8192 x 8 bytes */
 /* the same for hig_linattn_apply_sty_mm16: 8 stamps per workgroup (see linattn16.hip) */
 int hig_linattn16_debug_stamps(void* buf);

@@ -1,0 +1,136 @@
+"""Exact-fp32 weight-stationary GEMM with specialised waves (csrc/gemm_wsp32.hip) through hig_gemm: every epilogue it
+serves against the fp64 product, at the model's shapes (K = 512 / 1024, many rows), ragged row counts, the LayerNorm-fold
+producer -> consumer pair against F.layer_norm, bitwise repeatability and independence of the batch split.
+hig_gemm_wsp32_launches() proves that the launch went to this kernel and not to the tiled one."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import hig_amd  # noqa: E402,F401
+from hig_amd import _lib  # noqa: E402
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def launch(X, W, epi=0, bias=None, res=None, aux=None, stats_out=None, stats_in=None, colsum=None, out=None, expect_wsp=True):
+    I, R = X.shape
+    J = W.shape[0]
+    out = torch.full((I, J), float("nan"), device=DEV) if out is None else out
+    d = _lib.GemmDesc()
+    d.X, d.ldx, d.Y, d.ldy, d.C, d.ldc = X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), out.data_ptr(), out.stride(0)
+    d.I, d.J, d.R, d.epi = I, J, R, epi
+    if bias is not None:
+        d.bias = bias.data_ptr()
+    if res is not None:
+        d.res, d.ldr = res.data_ptr(), res.stride(0)
+    if aux is not None:
+        d.aux, d.ldaux = aux.data_ptr(), aux.stride(0)
+    if stats_out is not None:
+        d.row_stats_out = stats_out.data_ptr()
+    if stats_in is not None:
+        d.row_stats_in, d.ln_colsum = stats_in.data_ptr(), colsum.data_ptr()
+    L = _lib.lib()
+    before = L.hig_gemm_wsp32_launches()
+    _lib.check(L.hig_gemm(C.byref(d), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    ran = L.hig_gemm_wsp32_launches() - before == 1
+    assert ran == expect_wsp, "launch %s the weight-stationary fp32 kernel" % ("did not reach" if expect_wsp else "reached")
+    return out
+
+
+CASES = [(12544, 512, 512), (12544, 1024, 512), (12544, 1536, 512), (12544, 512, 1024), (6272, 512, 512), (6272, 1536, 512),
+         (12539, 512, 512), (2050, 1024, 512), (5824, 1536, 512), (5824, 512, 1024), (2051, 512, 1024), (4096, 1792, 512),
+         (9600, 1024, 1024)]
+
+
+@pytest.mark.parametrize("I,J,R", CASES)
+def test_every_epilogue_against_fp64(I, J, R):
+    X, W, b, r = rnd(I, R).to(DEV), rnd(J, R, seed=1, scale=0.05).to(DEV), rnd(J, seed=2).to(DEV), rnd(I, J, seed=3).to(DEV)
+    prod = X.double() @ W.double().T
+    assert rel(launch(X, W), prod) < 2e-6
+    assert rel(launch(X, W, epi=_lib.EPI_BIAS, bias=b), prod + b.double()) < 2e-6
+    assert rel(launch(X, W, epi=_lib.EPI_BIAS_RES, bias=b, res=r), prod + b.double() + r.double()) < 2e-6
+    assert rel(launch(X, W, epi=_lib.EPI_RES, res=r), prod + r.double()) < 2e-6
+    z = torch.full((I, J), float("nan"), device=DEV)
+    o = launch(X, W, epi=_lib.EPI_BIAS_GELU, bias=b, aux=z)
+    assert rel(o, F.gelu(prod + b.double())) < 2e-6
+    assert rel(z, prod + b.double()) < 2e-6
+    assert torch.equal(launch(X, W, epi=_lib.EPI_BIAS_GELU, bias=b), o)          # with and without the second output
+    zz = r.double()
+    dg = 0.5 * (1 + torch.erf(zz / 2 ** 0.5)) + zz * torch.exp(-0.5 * zz * zz) / (2 * torch.pi) ** 0.5
+    assert rel(launch(X, W, epi=_lib.EPI_DGELU, aux=r), prod * dg) < 2e-6
+
+
+@pytest.mark.parametrize("I,J,R", [(12544, 512, 512), (6272, 1536, 512), (5824, 512, 1024)])
+def test_exact_on_small_integers_and_bitwise_repeatable(I, J, R):
+    g = torch.Generator().manual_seed(5)
+    Xi = torch.randint(-4, 5, (I, R), generator=g).float()
+    Wi = torch.randint(-4, 5, (J, R), generator=g).float()
+    assert torch.equal(launch(Xi.to(DEV), Wi.to(DEV)).cpu(), Xi @ Wi.T)
+    X, W, b = rnd(I, R).to(DEV), rnd(J, R, seed=1).to(DEV), rnd(J, seed=2).to(DEV)
+    a = launch(X, W, epi=_lib.EPI_BIAS, bias=b)
+    for _ in range(5):
+        assert torch.equal(launch(X, W, epi=_lib.EPI_BIAS, bias=b), a)
+    # a row's result does not depend on which rows travel with it (no tile schedule in the sum order): the two halves of the
+    # batch computed alone equal the whole batch bit for bit
+    h = (I // 2) // 16 * 16 + 3
+    assert torch.equal(launch(X[:h], W, epi=_lib.EPI_BIAS, bias=b), a[:h])
+    assert torch.equal(launch(X[h:], W, epi=_lib.EPI_BIAS, bias=b), a[h:])
+
+
+def test_strided_operands_and_row_padding_untouched():
+    """ldx / ldc / ldr larger than the extents (the q/k/v buffer is one (M, 3 d) matrix): nothing outside [I][J] is written."""
+    I, J, R = 6272, 512, 512
+    Xb, W, b = rnd(I, 3 * R).to(DEV), rnd(J, R, seed=1, scale=0.05).to(DEV), rnd(J, seed=2).to(DEV)
+    Cb = torch.full((I + 4, 3 * J), 7.0, device=DEV)
+    rb = rnd(I, 2 * J, seed=4).to(DEV)
+    X, out, r = Xb[:, R:2 * R], Cb[:I, J:2 * J], rb[:, J:]
+    launch(X, W, epi=_lib.EPI_BIAS_RES, bias=b, res=r, out=out)
+    assert rel(out, X.double() @ W.double().T + b.double() + r.double()) < 2e-6
+    assert bool((Cb[:I, :J] == 7.0).all()) and bool((Cb[:I, 2 * J:] == 7.0).all()) and bool((Cb[I:] == 7.0).all())
+
+
+@pytest.mark.parametrize("I", [12544, 6277])
+def test_layernorm_fold_producer_and_consumer(I):
+    """row_stats_out (EPI_BIAS_RES) -> row_stats_in + ln_colsum (EPI_BIAS): LayerNorm(h) W^T + b without a LayerNorm pass
+    (hig_gemm_desc, include/hig.h); rows with a mean hundreds of times their spread keep their variance."""
+    d = 512
+    a, Wo, bo, hin = rnd(I, d).to(DEV), rnd(d, d, seed=1, scale=0.05).to(DEV), rnd(d, seed=2).to(DEV), rnd(I, d, seed=3).to(DEV)
+    hin[: I // 2] += 300.0
+    stats = torch.full((I, d // 64, 2), float("nan"), device=DEV)
+    h = launch(a, Wo, epi=_lib.EPI_BIAS_RES, bias=bo, res=hin, stats_out=stats)
+    href = a.double() @ Wo.double().T + bo.double() + hin.double()
+    assert rel(h, href) < 2e-6
+    hp = h.double().view(I, d // 64, 64)
+    assert rel(stats[:, :, 0], hp.sum(-1)) < 1e-6
+    assert rel(stats[:, :, 1], ((hp - hp.mean(-1, keepdim=True)) ** 2).sum(-1)) < 1e-5
+    gamma, beta = (1 + 0.1 * rnd(d, seed=5)).to(DEV), (0.1 * rnd(d, seed=6)).to(DEV)
+    for J in (512, 1536):
+        W, b = rnd(J, d, seed=7, scale=0.05).to(DEV), rnd(J, seed=8).to(DEV)
+        Wp = (W * gamma).contiguous()
+        colsum = Wp.double().sum(-1).float()
+        bp = (b.double() + W.double() @ beta.double()).float()
+        out = launch(h, Wp, epi=_lib.EPI_BIAS, bias=bp, stats_in=stats, colsum=colsum)
+        ref = F.linear(F.layer_norm(h.double(), (d,), gamma.double(), beta.double()), W.double(), b.double())
+        assert rel(out, ref) < 3e-5        # (the un-normalised product loses log2(|mean| / spread) bits: same bar as the tiled kernel's fold)
+        assert rel(out[I // 2:], ref[I // 2:]) < 3e-6
+
+
+def test_shapes_it_declines_still_run_on_the_tiled_kernel():
+    for I, J, R in [(1024, 512, 512), (6272, 512, 256), (6272, 520, 512)]:
+        X, W, b = rnd(I, R).to(DEV), rnd(J, R, seed=1, scale=0.05).to(DEV), rnd(J, seed=2).to(DEV)
+        assert rel(launch(X, W, epi=_lib.EPI_BIAS, bias=b, expect_wsp=False), X.double() @ W.double().T + b.double()) < 2e-6
