@@ -91,8 +91,66 @@ __device__ __forceinline__ void p32_store16(__amdgpu_buffer_rsrc_t rs, int byte_
   else __builtin_amdgcn_raw_buffer_store_b128(d, rs, byte_off, 0, 0);
 #endif
 }
+// LDS reads of the SERVICE waves, opaque to hipcc.  A C++ load from LDS behind a pending `buffer_load ... lds` makes the compiler
+// wait vmcnt(0) first (the DMA may alias the read): the epilogue then starts only after the X tile requested in the same iteration
+// has landed, and the service wave -- DMA issue, landing, epilogue, one after the other -- is late at every barrier (found in the
+// disassembly; profiles/r06_notes.md section 1).  What the epilogue reads was published by a barrier (hand-off) or by the counted
+// vmcnt of an earlier iteration (residual, statistics).  The wait names the loaded registers as operands, so no use moves above it.
+__device__ __forceinline__ f32x4 p32_lds16(unsigned addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t p32_lds8(unsigned addr) {
+  f32x2_t v;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7: below fp32 GELU rounding for |x| >~ 0.1, at most 1e-7 absolute elsewhere):
+// one exp, one rcp, ten other vector instructions instead of libm erff's ~40 with a branch -- the service waves issue a vector
+// instruction every 8-16 cycles next to their partner's MFMAs (tools/coissue32_probe.hip), so the epilogue's instruction count
+// is what makes them late at the tile barrier
+__device__ __forceinline__ float p32_erf_abs(float ax, float& ex) {   // erf(ax / sqrt 2), ex = exp(-ax^2 / 2), ax >= 0
+  const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  p *= t;
+  const float zz = ax * (0.70710678118654752440f * 1.2011224087864498f);   // ax / sqrt 2 * sqrt(log2 e)
+  ex = __builtin_amdgcn_exp2f(-(zz * zz));
+  return fmaf(-p, ex, 1.0f);
+}
+__device__ __forceinline__ float p32_gelu(float x) {
+  float ex;
+  const float e = p32_erf_abs(fabsf(x), ex);
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}
+__device__ __forceinline__ float p32_dgelu(float z) {   // Phi(z) + z phi(z)
+  float ex;
+  const float e = p32_erf_abs(fabsf(z), ex);
+  return fmaf(z * 0.39894228040143267794f, ex, 0.5f + copysignf(0.5f * e, z));
+}
 __host__ __device__ constexpr bool p32_has_bias(int e) { return e == HIG_EPI_BIAS || e == HIG_EPI_BIAS_GELU || e == HIG_EPI_BIAS_RES; }
 __host__ __device__ constexpr bool p32_has_res(int e) { return e == HIG_EPI_BIAS_RES || e == HIG_EPI_RES || e == HIG_EPI_DGELU; }
+
+// COUNT pieces of 1 KiB (piece n = first + STEP q: part n % PPR of row n / PPR) of the 16 rows [row0, row0 + 16) of a row-major
+// fp32 matrix -> an X-tile-shaped LDS buffer: LDS position p of row r receives the row's 16-byte chunk p ^ (r & 15).  Rows are
+// clamped to rmax (nothing is out of range).
+template <int PPR, int COUNT, int STEP>
+__device__ __forceinline__ void p32_dma_rows([[maybe_unused]] __amdgpu_buffer_rsrc_t rs, int ld, int row0, int rmax, [[maybe_unused]] char* dst, int first, int lane) {
+#pragma unroll
+  for (int q = 0; q < COUNT; ++q) {
+    const int n = first + STEP * q;              // scalar
+    const int r = n / PPR, part = n % PPR;
+    [[maybe_unused]] const int voff = 16 * (lane ^ (r & 15));
+    [[maybe_unused]] const int soff = min(row0 + r, rmax) * ld * 4 + part * 1024;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + n * 1024), 16, voff, soff, 0, 0);
+#endif
+  }
+}
 
 // KW: reduce extent (512 / 1024).  XT: 0 plain, 1 LayerNorm-fold producer (EPI_BIAS_RES: also writes the statistics of each
 // output row's 64-column panel), 2 consumer (EPI_BIAS: rows arrive un-normalised with their panel statistics) -- the formats of
@@ -296,22 +354,6 @@ __global__ __launch_bounds__(512, 2) void gemm_wsp32_kernel(const Wsp32Args a) {
   __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)(((int64_t)(a.I - 1) * a.ldc + a.J) * 4), 0x00020000);
   [[maybe_unused]] __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(AUX ? a.aux : a.C, 0, (int)(((int64_t)(a.I - 1) * (AUX ? a.ldaux : a.ldc) + a.J) * 4), 0x00020000);
   [[maybe_unused]] __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(HAS_RES ? a.res : a.X), 0, (int)(((int64_t)(a.I - 1) * (HAS_RES ? a.ldr : a.ldx) + (HAS_RES ? a.J : KW)) * 4), 0x00020000);
-  // 16 rows [row0, row0 + 16) of a row-major fp32 matrix with KW columns -> an X-tile-shaped buffer: 1 KiB per instruction
-  // (this wave: pieces sw, sw + 4, ...; piece n = part n % PPR of row n / PPR), LDS position p of row r receives the row's
-  // 16-byte chunk p ^ (r & 15)
-  auto dma_rows = [&]([[maybe_unused]] __amdgpu_buffer_rsrc_t rs, int ld, int row0, int rmax, [[maybe_unused]] char* dst) {
-#pragma unroll
-    for (int q = 0; q < NXI; ++q) {
-      const int n = sw + 4 * q;                  // scalar
-      const int r = n / PPR, part = n % PPR;
-      [[maybe_unused]] const int voff = 16 * (lane ^ (r & 15));
-      [[maybe_unused]] const int soff = min(row0 + r, rmax) * ld * 4 + part * 1024;
-#if defined(__HIP_DEVICE_COMPILE__)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + n * 1024), 16, voff, soff, 0, 0);
-#endif
-    }
-  };
-
   for (int seg = 0; seg < a.nseg; ++seg) {
     const int nps = a.seg_np[seg], G = 256 / nps;
     const int panel = a.seg_p0[seg] + w % nps, rg = w / nps;
@@ -326,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wsp32_kernel(const Wsp32Args a) {
     if constexpr (XT == 2) cs = *reinterpret_cast<const f32x4*>(a.colsum + j0 + 4 * cq);
     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), the other counters at their maximum
     asm volatile("" ::: "memory");
-    auto dma_x = [&](int t) { dma_rows(rsX, (int)a.ldx, (tb + t) * BM, a.I - 1, sX + ((t + NXB - 1) % NXB) * XBUF); };
+    auto dma_x = [&](int t) { p32_dma_rows<PPR, NXI, 4>(rsX, (int)a.ldx, (tb + t) * BM, a.I - 1, sX + ((t + NXB - 1) % NXB) * XBUF, sw, lane); };
     // residual tile t -> sR[t % 3]: this wave's KiB = its own four rows, every lane fetches the four columns it will finish
     auto dma_res = [&](int t) {
       if constexpr (HAS_RES) {
@@ -350,9 +392,9 @@ __global__ __launch_bounds__(512, 2) void gemm_wsp32_kernel(const Wsp32Args a) {
     p32_barrier();                               // S0
     // ---- the weight panel: all slices in flight at once; K = 512: X tile 0 behind them in ring slot 3 ----------------------
 #pragma unroll
-    for (int s = 0; s < NSL; ++s) dma_rows(rsW, (int)a.ldy, j0 + 16 * s, a.J - 1, wslice(s));
+    for (int s = 0; s < NSL; ++s) p32_dma_rows<PPR, NXI, 4>(rsW, (int)a.ldy, j0 + 16 * s, a.J - 1, wslice(s), sw, lane);   // (by all eight waves: slower, 9.3 K against 7.5 K cycles)
     int pre = 0;                                 // X tiles requested before the weights were read
-    if constexpr (W_BEHIND) { dma_x(0); pre = 1; asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NXI) : "memory"); }
+    if constexpr (W_BEHIND) { dma_x(0); pre = 1; asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NXI) : "memory"); }   // (this wave's weight pieces: landed)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     p32_barrier();                               // P1
     p32_barrier();                               // P2: the matrix waves hold their fragments
@@ -365,47 +407,58 @@ __global__ __launch_bounds__(512, 2) void gemm_wsp32_kernel(const Wsp32Args a) {
 
     // ---- epilogue of tile e from the hand-off -----------------------------------------------------------------------------
     constexpr int NST = 1 + (XT == 1 ? 1 : 0) + (AUX ? 1 : 0);   // vector-memory stores per wave and tile
+    const unsigned sh_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sH;
+    [[maybe_unused]] const unsigned sr_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sR;
+    [[maybe_unused]] const unsigned sl_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sL;
     auto epilogue = [&](int e) {
       const int row = 4 * sw + rsub;
-      const char* hp = sH + (e & 1) * HBUF + row * HROW + 16 * cq;
-      f32x4 v = *reinterpret_cast<const f32x4*>(hp);
+      const unsigned hp = sh_lds + (e & 1) * HBUF + row * HROW + 16 * cq;
+      f32x4 hh[NH];
 #pragma unroll
-      for (int p = 1; p < NH; ++p) v += *reinterpret_cast<const f32x4*>(hp + p * HPL);   // K parts in a fixed order
+      for (int p = 0; p < NH; ++p) hh[p] = p32_lds16(hp + p * HPL);
       [[maybe_unused]] f32x4 rr = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (HAS_RES) rr = *reinterpret_cast<const f32x4*>(sR + (e % NRB) * RBUF + sw * 1024 + lane * 16);
-      if constexpr (XT == 2) {
-        // mean / variance of the row from its R / 64 panel statistics (sum, centred sum of squares): pairwise merge (gemm.hip)
-        const char* lp = sL + (e % NRB) * LBUF + row * 64;
-        f32x4 ls[4];
+      if constexpr (HAS_RES) rr = p32_lds16(sr_lds + (e % NRB) * RBUF + sw * 1024 + lane * 16);
+      [[maybe_unused]] f32x2_t ps = {0.f, 0.f};
+      if constexpr (XT == 2) ps = p32_lds8(sl_lds + (e % NRB) * LBUF + row * 64 + 8 * (cq & 7));   // panel cq & 7 of the row: (sum, centred sum of squares)
+      if constexpr (NH == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(rr), "+v"(ps));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(hh[2]), "+v"(hh[3]), "+v"(rr), "+v"(ps));
+      float v[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) ls[p] = *reinterpret_cast<const f32x4*>(lp + 16 * p);
-        float tot = 0.f, m2 = 0.f;
+      for (int k = 0; k < 4; ++k) {              // K parts in a fixed order
+        v[k] = hh[0][k];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { tot += ls[p].x + ls[p].z; m2 += ls[p].y + ls[p].w; }
-        const float mean = tot * (1.0f / 512.0f);
-        float between = 0.f;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const float d0 = ls[p].x * (1.0f / 64.0f) - mean, d1 = ls[p].z * (1.0f / 64.0f) - mean;
-          between += d0 * d0 + d1 * d1;
-        }
-        const float rstd = rsqrtf((m2 + 64.0f * between) * (1.0f / 512.0f) + 1e-5f), mr = -mean * rstd;
-        v = f32x4{v.x * rstd + mr * cs.x, v.y * rstd + mr * cs.y, v.z * rstd + mr * cs.z, v.w * rstd + mr * cs.w};
+        for (int p = 1; p < NH; ++p) v[k] += hh[p][k];
       }
-      v += bq;
+      if constexpr (XT == 2) {
+        // mean / variance of the row from its 8 panel statistics, the merge of gemm.hip spread over the row's 16 lanes (one DPP
+        // row): lanes 0-7 hold one panel each, lanes 8-15 contribute nothing
+        const bool mine = cq < 8;
+        const float tot = row16_sum(mine ? ps.x : 0.f), m2 = row16_sum(mine ? ps.y : 0.f);
+        const float mean = tot * (1.0f / 512.0f);
+        const float d0 = fmaf(ps.x, 1.0f / 64.0f, -mean);
+        const float between = row16_sum(mine ? d0 * d0 : 0.f);
+        const float rstd = rsqrtf(fmaf(64.0f, between, m2) * (1.0f / 512.0f) + 1e-5f), mr = -mean * rstd;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaf(v[k], rstd, mr * cs[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += bq[k];
       const int ig = min((tb + e) * BM + row, a.I - 1);
-      if constexpr (AUX) { if (act && !(DIAG && (a.dbg & 4))) p32_store16<POL>(rsA, (ig * (int)a.ldaux + j0 + 4 * cq) * 4, v); }
-      if constexpr (EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_RES) v += rr;
-      if constexpr (EPI == HIG_EPI_BIAS_GELU) v = f32x4{hig_gelu(v.x), hig_gelu(v.y), hig_gelu(v.z), hig_gelu(v.w)};
-      if constexpr (EPI == HIG_EPI_DGELU) v = f32x4{v.x * hig_dgelu(rr.x), v.y * hig_dgelu(rr.y), v.z * hig_dgelu(rr.z), v.w * hig_dgelu(rr.w)};
-      if (DIAG && (a.dbg & 4)) { asm volatile("" ::"v"(v)); return; }
-      if (act) p32_store16<POL>(rsC, (ig * (int)a.ldc + j0 + 4 * cq) * 4, v);
+      if constexpr (AUX) { if (act && !(DIAG && (a.dbg & 4))) p32_store16<POL>(rsA, (ig * (int)a.ldaux + j0 + 4 * cq) * 4, f32x4{v[0], v[1], v[2], v[3]}); }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if constexpr (EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_RES) v[k] += rr[k];
+        if constexpr (EPI == HIG_EPI_BIAS_GELU) v[k] = p32_gelu(v[k]);
+        if constexpr (EPI == HIG_EPI_DGELU) v[k] *= p32_dgelu(rr[k]);
+      }
+      if (DIAG && (a.dbg & 4)) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }
+      if (act) p32_store16<POL>(rsC, (ig * (int)a.ldc + j0 + 4 * cq) * 4, f32x4{v[0], v[1], v[2], v[3]});
       if constexpr (XT == 1) {
         // LayerNorm fold, producer side: (sum, sum of squared deviations from the panel mean) of this row's 64 outputs; the 16
         // lanes of a row are one DPP row.  Every wave issues the store (lanes cq != 0 masked), so the counted waits hold.
-        const float sm = row16_sum((v.x + v.y) + (v.z + v.w));
+        const float sm = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
         const float pm = sm * (1.0f / 64.0f);
-        const float a0 = v.x - pm, a1 = v.y - pm, a2 = v.z - pm, a3 = v.w - pm;
+        const float a0 = v[0] - pm, a1 = v[1] - pm, a2 = v[2] - pm, a3 = v[3] - pm;
         const float qq = row16_sum((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3));
         if (cq == 0) *reinterpret_cast<float2*>(a.stats_out + ((int64_t)ig * (a.J >> 6) + panel) * 2) = make_float2(sm, qq);
       }
