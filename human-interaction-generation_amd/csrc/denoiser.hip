@@ -670,7 +670,12 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
   // side stream, forked after the per-sample prologue and joined before returning (events only: capturable).  An
   // in-order stream leaves the chip idle in every kernel's tail and ramp-up; two independent chains of the same
   // kernels fill those gaps (two whole forwards side by side: 5.85 ms each against 6.6 alone).
-  static const int split_env = getenv("HIG_FWD_SPLIT") ? atoi(getenv("HIG_FWD_SPLIT")) : 1;   // tuning knob
+  // (Round 6: with the exact-fp32 products on the weight-stationary kernel -- one workgroup per CU, every launch fills the chip
+  // by itself -- two half-batch chains no longer fit side by side, and each half pays the kernel's fixed cost on half the rows:
+  // B = 64 forward 5.85 ms split against 5.78 ms on one stream.  Unset, the split is therefore kept for the bf16 product modes
+  // and for chips where that kernel declines.)
+  static const int split_knob = getenv("HIG_FWD_SPLIT") ? atoi(getenv("HIG_FWD_SPLIT")) : -1;   // tuning knob
+  const int split_env = split_knob >= 0 ? split_knob : ((D.prec == HIG_PREC_F32 && hig_gemm_wsp32_active()) ? 0 : 1);
   // (M >= 8192: measured at B = 64.  Half batches run other tile schedules than the whole batch -- other split-tail
   // geometry, so sums in another order, last-bit differences (2e-7 rel-L2) -- and the B = 32 sampling step is expected to
   // equal its captured form bit for bit (tests/test_gpu_full_size.py), so small batches stay on one stream.)

@@ -1161,6 +1161,26 @@ int gemm_dispatch(const hig_gemm_desc& g, int splits, float* slabs, hipStream_t 
   if (splits <= 1 && !se.bias) {
     const int rc = hig_gemm_wsp32_try(g, st);
     if (rc != 1) return rc;
+    // K = 1536 / 2048 (the data gradient of the stacked q/k/v projection: dqkv (M, 3d) . Wqkv): that kernel's weight panel holds
+    // at most K = 1024, so the reduce range goes through it in passes -- C = X[:, :1024] W[:, :1024]^T (+ bias / res), then
+    // C += X[:, 1024:] W[:, 1024:]^T with C as its own residual (a lane re-reads exactly the element it stores two tiles later).
+    // 153 us for the two passes at M = 12 544 against 197 us on the tiled kernel.
+    if (hig_gemm_wsp32_active() && g.prec == HIG_PREC_F32 && !g.x_rs && !g.y_rs && g.xf == HIG_XF_NONE && !g.xcolsum && !g.row_stats_in &&
+        !g.row_stats_out && g.R > 1024 && g.R <= 2048 && g.R % 512 == 0 && g.I >= 2048 && g.J % 64 == 0 &&
+        (g.epi == HIG_EPI_NONE || g.epi == HIG_EPI_RES || g.epi == HIG_EPI_BIAS || g.epi == HIG_EPI_BIAS_RES)) {
+      hig_gemm_desc p1 = g;
+      p1.R = 1024;
+      const int rc1 = hig_gemm_wsp32_try(p1, st);
+      if (rc1 < 0) return rc1;
+      if (rc1 == HIG_OK) {
+        hig_gemm_desc p2 = g;
+        p2.X = g.X + 1024; p2.Y = g.Y + 1024; p2.R = g.R - 1024;
+        p2.epi = HIG_EPI_RES; p2.bias = nullptr; p2.res = g.C; p2.ldr = g.ldc;
+        const int rc2 = hig_gemm_wsp32_try(p2, st);
+        if (rc2 != 1) return rc2;
+        return hig_set_error(HIG_EHIP, "hig_gemm: second reduce pass declined after the first was launched");
+      }
+    }
   }
 #define CASE(xrs, yrs, xfv, ony, epiv)                                                   \
   if (g.x_rs == xrs && g.y_rs == yrs && g.xf == xfv && (g.xf == HIG_XF_NONE || g.xf_on_y == ony) && \

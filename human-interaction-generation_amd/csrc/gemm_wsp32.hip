@@ -528,11 +528,10 @@ int launch_p32(const hig_gemm_desc& g, hipStream_t st) {
   a.stats_in = g.row_stats_in;
   a.colsum = g.ln_colsum;
   a.stamps = g_p32_stamps;
-  static const int prio = getenv("HIG_F32_WSP_PRIO") ? atoi(getenv("HIG_F32_WSP_PRIO")) : 1;   // tuning knob
-  a.prio = prio;
+  a.prio = 1;   // (a tuning knob while the kernel was built: 0 -> +2 % on the seven forward shapes, 2 = 1; profiles/r06_notes.md section 1)
   static const int dbg = getenv("HIG_F32_WSP_DBG") ? atoi(getenv("HIG_F32_WSP_DBG")) : 0;   // timing ablations (never in a product run)
   a.dbg = dbg;
-  static const int pol = getenv("HIG_F32_WSP_POL") ? atoi(getenv("HIG_F32_WSP_POL")) : 0;       // tuning knob: 1 = sc1 output stores
+  constexpr int pol = 0;   // (a tuning knob while the kernel was built: sc1 write-through output stores changed nothing here)
   const bool wt = pol == 1 && !(g.res && g.res == g.C);
   const dim3 gr(256), bl(512);
   __atomic_fetch_add(&g_p32_launches, 1, __ATOMIC_RELAXED);
@@ -570,10 +569,13 @@ int dispatch_p32(const hig_gemm_desc& g, hipStream_t st) {
 
 // Returns HIG_OK when the launch was made, 1 when this kernel does not serve the call (the caller goes on to the tiled kernel
 // of gemm.hip), a negative HIG_E* code on error.
-int hig_gemm_wsp32_try(const hig_gemm_desc& g, hipStream_t st) {
+bool hig_gemm_wsp32_active() {
   static const int on = getenv("HIG_F32_WSP") ? atoi(getenv("HIG_F32_WSP")) : 1;                 // tuning knob: 0 = this kernel off
-  static const int min_rows = getenv("HIG_F32_WSP_ROWS") ? atoi(getenv("HIG_F32_WSP_ROWS")) : 2048;
-  if (!on || hig_chip_cus() != 256) return 1;
+  return on && hig_chip_cus() == 256;
+}
+int hig_gemm_wsp32_try(const hig_gemm_desc& g, hipStream_t st) {
+  constexpr int min_rows = 2048;   // below that a workgroup has < 4 tiles per segment to pay its weight phase with
+  if (!hig_gemm_wsp32_active()) return 1;
   if (g.prec != HIG_PREC_F32 || g.x_rs || g.y_rs || g.xf != HIG_XF_NONE || g.xcolsum) return 1;
   if (!(g.R == 512 || g.R == 1024) || g.I < min_rows) return 1;
   const int bn = g.R == 512 ? 64 : 32;

@@ -56,6 +56,7 @@ bool hig_gemm_ws16_lnfold_ok(int64_t rows, int d);
 // exact-fp32 weight-stationary kernel with specialised waves (gemm_wsp32.hip: K = 512 / 1024, reduce-contiguous aligned
 // operands, >= 2048 rows); same return codes
 int hig_gemm_wsp32_try(const hig_gemm_desc& g, hipStream_t st);
+bool hig_gemm_wsp32_active();   // that kernel is switched on and the chip has the 256 CUs its work split is written for
 
 namespace {
 

@@ -1,7 +1,8 @@
 """Every environment switch the library still reads ("Switches") is flipped ONCE, in a child process (they are read
 once per process), over a pass that touches every path they select between: the results must stay at the rounding level of the
 path -- a switch chooses between two implementations of the same arithmetic, never between two results.  The diagnostic
-switches whose builds are wrong by construction (HIG_BF16_DBG, HIG_BF16_WSP_DBG: timing ablations; HIG_POISON) are not flipped."""
+switches whose builds are wrong by construction (HIG_BF16_DBG, HIG_BF16_WSP_DBG, HIG_F32_WSP_DBG: timing ablations; HIG_POISON) are not
+flipped."""
 import json
 import os
 import subprocess
@@ -19,7 +20,7 @@ KNOBS = [
     ("HIG_GEMM_TILE", "128"), ("HIG_FEW_ROWS_SPLIT", "0"), ("HIG_FULLATTN_WAVES", "4"), ("HIG_FULLATTN_VALU", "1"),
     ("HIG_CTX16", "0"), ("HIG_FWD16_FORK", "0"), ("HIG_JOINT16", "0"), ("HIG_FUSE_APPLY", "0"), ("HIG_FUSE_OUT", "0"),
     ("HIG_EDGE16", "0"), ("HIG_BF16_TILE", "64"), ("HIG_BF16_FEWROW", "0"), ("HIG_BF16_WS", "0"), ("HIG_BF16_WSP", "0"),
-    ("HIG_BF16_WS_NWJ", "4"), ("HIG_BF16_WS_ROWS", "100000"), ("HIG_LNFOLD", "0"), ("HIG_LNFOLD1024", "0"), ("HIG_CHIP_CUS", "128"),
+    ("HIG_BF16_WS_NWJ", "4"), ("HIG_BF16_WS_ROWS", "100000"), ("HIG_LNFOLD", "0"), ("HIG_LNFOLD1024", "0"), ("HIG_CHIP_CUS", "128"), ("HIG_F32_WSP", "0"),
 ]
 
 
