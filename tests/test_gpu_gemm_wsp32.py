@@ -134,3 +134,25 @@ def test_shapes_it_declines_still_run_on_the_tiled_kernel():
     for I, J, R in [(1024, 512, 512), (6272, 512, 256), (6272, 520, 512)]:
         X, W, b = rnd(I, R).to(DEV), rnd(J, R, seed=1, scale=0.05).to(DEV), rnd(J, seed=2).to(DEV)
         assert rel(launch(X, W, epi=_lib.EPI_BIAS, bias=b, expect_wsp=False), X.double() @ W.double().T + b.double()) < 2e-6
+
+
+@pytest.mark.parametrize("I,J,R", [(12544, 512, 1536), (6272, 512, 2048), (2060, 1536, 1536)])
+def test_reduce_ranges_beyond_the_weight_panel_go_through_in_two_passes(I, J, R):
+    """K = 1536 / 2048 (data gradient of the stacked q/k/v projection): K = 1024 first, the rest added with C as its own residual."""
+    X, W, b, r = rnd(I, R).to(DEV), rnd(J, R, seed=1, scale=0.05).to(DEV), rnd(J, seed=2).to(DEV), rnd(I, J, seed=3).to(DEV)
+    prod = X.double() @ W.double().T
+    L = _lib.lib()
+    for epi, kw, ref in [(0, {}, prod), (_lib.EPI_BIAS, dict(bias=b), prod + b.double()), (_lib.EPI_RES, dict(res=r), prod + r.double()),
+                         (_lib.EPI_BIAS_RES, dict(bias=b, res=r), prod + b.double() + r.double())]:
+        out = torch.full((I, J), float("nan"), device=DEV)
+        d = _lib.GemmDesc()
+        d.X, d.ldx, d.Y, d.ldy, d.C, d.ldc, d.I, d.J, d.R, d.epi = X.data_ptr(), R, W.data_ptr(), R, out.data_ptr(), J, I, J, R, epi
+        if "bias" in kw:
+            d.bias = b.data_ptr()
+        if "res" in kw:
+            d.res, d.ldr = r.data_ptr(), J
+        before = L.hig_gemm_wsp32_launches()
+        _lib.check(L.hig_gemm(C.byref(d), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert L.hig_gemm_wsp32_launches() - before == 2
+        assert rel(out, ref) < 2e-6
