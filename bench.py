@@ -2,6 +2,7 @@
 """Benchmark of the hot path (BASELINE.json) on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          (spawns its own N ranks, one per GPU; or, equivalently:)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -401,6 +402,53 @@ def set_mode(model, mode):
         model.storage = "bf16" if mode == "bf16s" else "f32"
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes -- as the reference's launcher
+    spawns its own (tools/train.py:92-102, mp.spawn) -- BEFORE this process has made any GPU call (it never does: no HIP call,
+    no exec from a process that initialised the GPU), relay rank 0's JSON line, exit non-zero if any rank failed.  One rank per
+    GPU over RCCL; with fewer GPUs than ranks (a 1-GPU box: self-test only) the ranks share devices over gloo."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ndev = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ndev < n:
+        env.setdefault("HIG_DIST_BACKEND", "gloo")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    chunks, bad = [], None
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)   # (drains rank 0's pipe while it runs)
+    reader.start()
+    try:
+        while any(p.poll() is None for p in procs):
+            bad = next(((r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)), None)
+            if bad is not None:
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:                                       # a rank died: its peers would wait in a collective for ever
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    reader.join(timeout=10)
+    out = b"".join(c for c in chunks if c)
+    sys.stdout.write(out.decode(errors="replace"))
+    sys.stdout.flush()
+    if bad is None:
+        bad = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+    if bad is not None:
+        sys.exit("bench.py: rank %d exited with code %s" % bad)
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -415,9 +463,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
+    if a.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(a.gpus)                   # (does not return)
     ndev = torch.cuda.device_count()
     local = local % max(ndev, 1)   # (several ranks may share a GPU only in the gloo self-test below)
     torch.cuda.set_device(local)
@@ -496,13 +543,12 @@ def main():
             except Exception as e:       # noqa: BLE001  (reported in the line; every rank fails alike or the max below is inf)
                 probe.append(float("inf"))
                 print("bench: step form refused on rank %d: %s" % (rank, e), file=sys.stderr)
+        if trainer.fused_state().get("captured_form") != "one graph, exchange inside":
+            probe[2] = float("inf")            # (the trainer fell back to the split form -- on every rank alike, parallel.all_ranks_agree)
         pick = torch.tensor(probe, device=device, dtype=torch.float64)
-        dist.all_reduce(pick, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pick, op=dist.ReduceOp.MAX)      # (every rank sees the same vector, so every rank picks the same form)
         form_probe = {k: (round(pick[j].item() / 3 * 1e3, 3) if pick[j].item() != float("inf") else None)
                       for j, (_, _, k) in enumerate(forms)}
-        if trainer.fused_state().get("captured_form") != "one graph, exchange inside":
-            form_probe["one_graph_overlapped_ms"] = None            # (the trainer fell back to the split form)
-            pick[2] = float("inf")
         best = int(torch.argmin(pick).item())
         train_step, step_form = forms[best][0], forms[best][1]
         trainer.sync_replicas()

@@ -535,7 +535,7 @@ int launch_p32(const hig_gemm_desc& g, hipStream_t st) {
   const bool wt = pol == 1 && !(g.res && g.res == g.C);
   const dim3 gr(256), bl(512);
   __atomic_fetch_add(&g_p32_launches, 1, __ATOMIC_RELAXED);
-  if constexpr (KW == 512 && XT == 0 && !AUX && (EPI == HIG_EPI_NONE || EPI == HIG_EPI_BIAS_RES || EPI == HIG_EPI_BIAS_GELU)) {
+  if constexpr (KW == 512 && XT == 0 && !AUX && (EPI == HIG_EPI_NONE || EPI == HIG_EPI_BIAS_GELU)) {   // (with a residual the diagnostic instance would spill)
     if (a.stamps || dbg) {                       // diagnostic instances (tools/gemm_wsp32_stamps.py)
       hipLaunchKernelGGL((gemm_wsp32_kernel<KW, EPI, XT, AUX, 0, true>), gr, bl, 0, st, a);
       HIG_CHECK_LAUNCH();

@@ -75,7 +75,6 @@ class OverlappedGradAllReduce:
         self.wire = wire
         self.stream = None
         self.stage = None
-        self.works = []
 
     @staticmethod
     def active(group=None):
@@ -84,18 +83,21 @@ class OverlappedGradAllReduce:
     def begin(self, flat_grad, per_layer, tail):
         if self.stream is None or self.stream.device != flat_grad.device:
             self.stream = torch.cuda.Stream(device=flat_grad.device)
-        self.grad, self.per_layer, self.tail, self.works = flat_grad, per_layer, tail, []
+        self.grad, self.per_layer, self.tail = flat_grad, per_layer, tail
         if self.wire == "bf16" and (self.stage is None or self.stage.numel() != flat_grad.numel()
                                     or self.stage.device != flat_grad.device):
             self.stage = torch.empty(flat_grad.numel(), device=flat_grad.device, dtype=torch.bfloat16)
 
     def _reduce(self, ranges):
-        """Called with self.stream current."""
+        """Called with self.stream current.  Synchronous-style calls on purpose (no async_op, no Work handle kept): on the RCCL
+        backend that only makes self.stream wait for RCCL's internal stream -- the order the collectives run in anyway -- and no
+        Work object (with events recorded under a stream capture) outlives the call, so nothing the process group's watchdog
+        thread could query is left behind when the step is being captured."""
         for a, b in ranges:
             if b <= a:
                 continue
             if self.wire == "f32":
-                self.works.append(dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
                 continue
             from . import _lib
             sp = _lib.stream_ptr()
@@ -111,11 +113,37 @@ class OverlappedGradAllReduce:
         self.stream.wait_stream(torch.cuda.current_stream())     # the tail is final when the backward is
         with torch.cuda.stream(self.stream):
             self._reduce(list(self.tail) + list(extra))
-        for w in self.works:
-            w.wait()                                             # current stream waits for the exchange
-        torch.cuda.current_stream().wait_stream(self.stream)
-        self.works = []
+        torch.cuda.current_stream().wait_stream(self.stream)     # current stream waits for the exchange
         return dist.get_world_size(self.group)
+
+
+def drain_pending_collectives(group=None):
+    """Before a stream capture that contains collectives: every collective issued so far has finished on the GPU AND has been
+    retired by the process group's watchdog thread (it polls the completion events of in-flight work; a capture must not start
+    while it still holds any).  Deterministic replacement of the fixed sleep of round 5: ProcessGroupNCCL.waitForPendingWorks
+    returns when the watchdog's list is empty."""
+    torch.cuda.synchronize()
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    pg = group if group is not None else dist.distributed_c10d._get_default_group()
+    wait = getattr(pg, "_wait_for_pending_works", None)
+    if wait is not None:
+        wait()
+    else:                                      # (older torch: the watchdog polls every 100 ms)
+        import time
+        time.sleep(0.3)
+
+
+def all_ranks_agree(ok, device, group=None):
+    """True only if `ok` holds on EVERY rank (one eager MIN all-reduce; a group of one rank answers for itself).  A decision
+    that changes the sequence of collectives a rank will issue -- such as falling back from the captured exchange to the split
+    form -- has to be taken by all ranks alike, or their collective sequences stop matching."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                        device=device if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item())
 
 
 class ShardedSampler(torch.utils.data.Sampler):

@@ -423,6 +423,10 @@ class DDPMTrainer(object):
         fp = core.flat_params()
         n = self._fused_numel(clip_out is not None)
         ex = st["overlap"]
+        want = getattr(self.opt, "grad_wire", "f32")
+        if want != ex.wire:      # (the option is read when the fused state is built; changing it later used to be ignored silently)
+            raise RuntimeError("opt.grad_wire changed from %r to %r after the fused training state was created: set it before the "
+                               "first step (or drop the state: trainer._fused = None)" % (ex.wire, want))
         nsty = 4 if int(getattr(core.dims(1, 1, 1), "two_person", 0)) == 1 else 3   # stylization blocks per layer
         per_layer, tail = fp.layer_buckets(core.num_layers, nsty, core.latent_dim, core.time_embed_dim)
         assert per_layer[-1][1][1] - per_layer[0][1][0] == core.num_layers * nsty * 2 * core.latent_dim * core.time_embed_dim
@@ -581,19 +585,27 @@ class DDPMTrainer(object):
             # thread_local: other threads (the RCCL watchdog polls its events) may call into HIP while we capture
             ga, gb = torch.cuda.CUDAGraph(), None
             if in_graph:
-                # Let the process group's watchdog thread retire the warm-up's collectives before events are recorded under capture:
-                # once, under a loaded box, it queried an event "last recorded in a capturing stream" and took the process down
-                # (profiles/r05_notes.md section 5).  It polls every 100 ms; captures happen once per batch shape.
-                torch.cuda.synchronize()
-                time.sleep(0.3)
+                # The warm-up's collectives have finished AND the process group's watchdog thread has retired them before any
+                # event is recorded under capture (once, on a loaded box, it queried an event "last recorded in a capturing
+                # stream" and took the process down: profiles/r05_notes.md section 5).  Round 6: no Work handle of the exchange
+                # survives its call (parallel.OverlappedGradAllReduce._reduce) and the wait is the process group's own
+                # waitForPendingWorks instead of a sleep.
+                from ..parallel import all_ranks_agree, drain_pending_collectives
+                drain_pending_collectives()
+                err = None
                 try:
                     with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                         whole_step_with_exchange()
-                except Exception as e:      # RCCL refused the capture: fall back to graph A | eager all-reduce | graph B
+                except Exception as e:      # RCCL refused the capture
                     torch.cuda.synchronize()
-                    st["capture_exchange_error"] = "%s: %s" % (type(e).__name__, e)
+                    err = "%s: %s" % (type(e).__name__, e)
+                # The fallback changes the collectives a rank issues per step (one flat all-reduce instead of 2 L + 2 captured
+                # ones): every rank takes it, or none does.
+                if not all_ranks_agree(err is None, x_start.device):
+                    st.setdefault("capture_exchange_errors", {})[key] = err or "another rank could not capture the exchange"
+                    st["capture_exchange_error"] = st["capture_exchange_errors"][key]
                     in_graph = False
-                    ga = torch.cuda.CUDAGraph()
+                    ga = torch.cuda.CUDAGraph()     # graph A | eager all-reduce | graph B
                     restore()
             if not split:
                 with torch.cuda.graph(ga, capture_error_mode="thread_local"):
@@ -608,6 +620,7 @@ class DDPMTrainer(object):
             cap = st["graphs"][key] = (static, ga, gb)
             st["captured_form"] = "one graph" if not split else ("one graph, exchange inside" if in_graph
                                                                  else "graph A | all-reduce | graph B")
+            st.setdefault("captured_forms", {})[key] = st["captured_form"]      # (per graph; "captured_form" = the latest capture)
         static, ga, gb = cap
         with torch.no_grad():
             static["x0"].copy_(x_start)

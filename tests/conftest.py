@@ -56,6 +56,15 @@ def pytest_collection_finish(session):
         _spawn("dptrain", "dp_train_worker.py", 2)
     if "test_gpu_rccl.py::test_rccl_single_rank_exchange_is_the_identity" in wanted:
         _spawn("rccl", "rccl_worker.py", 1)
+    if "test_gpu_data_parallel.py::test_bench_spawns_its_own_ranks_when_started_without_a_launcher" in wanted:
+        # plain `python bench.py --gpus 2 ...`: no torchrun, no RANK / WORLD_SIZE in the environment
+        outdir = tempfile.mkdtemp(prefix="hig_benchspawn_")
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        out, log = open(os.path.join(outdir, "stdout.txt"), "wb"), open(os.path.join(outdir, "rank0.log"), "wb")
+        _DP["benchspawn"] = {"outdir": outdir, "n": 1, "procs": [subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline"],
+            env=env, stdout=out, stderr=log)]}
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -88,6 +97,11 @@ def dp_train_workers():
 @pytest.fixture(scope="session")
 def rccl_worker():
     return _finished("rccl", 900)
+
+
+@pytest.fixture(scope="session")
+def bench_spawn():
+    return _finished("benchspawn", 1200)
 
 
 @pytest.fixture(scope="session")

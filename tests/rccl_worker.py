@@ -89,6 +89,7 @@ def main():
         c, m, tr, gi, x0, noise = dp_worker.build_and_inputs("bf16")
         tr.opt.grad_wire = "bf16"
         r = steps(tr, m, gi, x0, noise)
+        r["wire"] = tr.fused_state()["overlap"].wire
         out["bf16/wire_bf16"] = r
         torch.save(out, os.path.join(outdir, "rccl.pt"))
 

@@ -78,3 +78,18 @@ def test_two_rank_epoch_loop_shards_checkpoints_and_resumes(dp_train_workers):
     # the resumed epoch started from the checkpoint, not from the fresh (different) models: it moved on from phase 1
     assert not torch.equal(got[0]["p1.params"], got[0]["p2.params"])
     assert (got[0]["p1.params"] - got[0]["p2.params"]).abs().max().item() < 0.05
+
+
+def test_bench_spawns_its_own_ranks_when_started_without_a_launcher(bench_spawn):
+    """`python bench.py --gpus 2 ...` with no torchrun and no RANK / WORLD_SIZE in the environment (how a driver may start
+    it): bench.py starts the two ranks itself before touching the GPU -- as the reference's launcher spawns its own ranks,
+    tools/train.py:92-102 -- and relays rank 0's ONE JSON line.  On this 1-GPU box the ranks share the device over gloo."""
+    import json
+    outdir, codes, logs = bench_spawn
+    assert codes == [0], "\n".join(logs)[-6000:]
+    lines = [l for l in open(os.path.join(outdir, "stdout.txt"), errors="replace").read().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1
+    assert r["value"] > 0 and r["ms_per_step"] > 0 and r["scaling"] == "weak"
+    assert "single_gpu_reference" in r and r["config"]["parallelism"].startswith("dp2")

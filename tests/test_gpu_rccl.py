@@ -55,6 +55,7 @@ def test_rccl_single_rank_exchange_is_the_identity(rccl_worker):
             # norm is a sum of 81 M squares: the roundings average out
             w = got["bf16/wire_bf16"]
             assert w["step"] == 6
+            assert w["wire"] == "bf16" and not torch.equal(w["flat"], ref["flat"])      # (the option really took effect)
             assert abs(w["gnorm"] - ref["gnorm"]) <= 2e-3 * abs(ref["gnorm"]), (w["gnorm"], ref["gnorm"])   # (after 6 steps)
             assert all(abs(a - b) <= 1e-3 * abs(b) for a, b in zip(w["losses"], ref["losses"])), (w["losses"], ref["losses"])
             d = (w["flat"] - ref["flat"]).double()

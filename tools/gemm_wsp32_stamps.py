@@ -1,6 +1,6 @@
 """Where a workgroup of the exact-fp32 weight-stationary GEMM (csrc/gemm_wsp32.hip) spends its time: s_memtime stamps of thread 0
 (matrix wave 0) and thread 256 (service wave 4), and the clock the chip held (stamp span against the HIP-event time).
-usage: python tools/gemm_wsp32_stamps.py [shape] [B] [hot]
+usage: python tools/gemm_wsp32_stamps.py [none|ffn1] [B] [hot]   (the diagnostic instances: no epilogue operand, bias + GELU)
 `hot`: the same operands every run, no cache flush in between (X served by the L2 / Infinity Cache instead of HBM)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
