@@ -360,14 +360,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wsp32_kernel(const Wsp32Args a) {
     const int tb = (int)((int64_t)rg * a.ntiles / G), te = (int)((int64_t)(rg + 1) * a.ntiles / G);
     const int nt = te - tb;
     const int j0 = panel * BN;
-    // bias (and the LayerNorm-fold column sums) of this lane's four columns, in registers for the segment.  Loaded and waited for
-    // (with a wait the compiler sees) BEFORE the first DMA goes out: hipcc then never guards their use with a vmcnt(0) of its
-    // own further down, where it would drain the DMA ring.
+    // bias (and the LayerNorm-fold column sums) of this lane's four columns, in registers for the segment: requested BEHIND the
+    // weight DMA (in front of it, a cold first load cost the whole workgroup its ~1 us before anything else was in flight) by
+    // loads hipcc does not see -- a C++ load pending beside the DMA would make it guard every use with a vmcnt(0) that drains
+    // the X ring -- and retired by the counted wait that retires the weight pieces, which names them as operands.
     f32x4 bq = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (p32_has_bias(EPI)) bq = *reinterpret_cast<const f32x4*>(a.bias + j0 + 4 * cq);
-    if constexpr (XT == 2) cs = *reinterpret_cast<const f32x4*>(a.colsum + j0 + 4 * cq);
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), the other counters at their maximum
-    asm volatile("" ::: "memory");
     auto dma_x = [&](int t) { p32_dma_rows<PPR, NXI, 4>(rsX, (int)a.ldx, (tb + t) * BM, a.I - 1, sX + ((t + NXB - 1) % NXB) * XBUF, sw, lane); };
     // residual tile t -> sR[t % 3]: this wave's KiB = its own four rows, every lane fetches the four columns it will finish
     auto dma_res = [&](int t) {
@@ -393,9 +390,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wsp32_kernel(const Wsp32Args a) {
     // ---- the weight panel: all slices in flight at once; K = 512: X tile 0 behind them in ring slot 3 ----------------------
 #pragma unroll
     for (int s = 0; s < NSL; ++s) p32_dma_rows<PPR, NXI, 4>(rsW, (int)a.ldy, j0 + 16 * s, a.J - 1, wslice(s), sw, lane);   // (by all eight waves: slower, 9.3 K against 7.5 K cycles)
+    if constexpr (p32_has_bias(EPI)) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq) : "v"(a.bias + j0 + 4 * cq) : "memory");
+    if constexpr (XT == 2) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cs) : "v"(a.colsum + j0 + 4 * cq) : "memory");
     int pre = 0;                                 // X tiles requested before the weights were read
-    if constexpr (W_BEHIND) { dma_x(0); pre = 1; asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NXI) : "memory"); }   // (this wave's weight pieces: landed)
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (W_BEHIND) { dma_x(0); pre = 1; asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bq), "+v"(cs) : "n"(NXI) : "memory"); }   // (this wave's weight pieces, bias: landed)
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq), "+v"(cs) :: "memory");
     p32_barrier();                               // P1
     p32_barrier();                               // P2: the matrix waves hold their fragments
     for (int t = pre; t < LOOK && t < nt; ++t) dma_x(t);

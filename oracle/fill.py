@@ -16,8 +16,28 @@ def _rs(name):
     return np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
 
 
+_CACHE, _CACHE_BYTES, _CACHE_CAP = {}, [0], 3 << 30
+
+
 def tensor_for(name, shape, dtype=torch.float32):
+    """Pure function of (name, shape): the large tensors are memoised (the test-suite rebuilds the same 81 M-parameter model
+    dozens of times; 3 GiB cap, oldest entries dropped) and handed out as copies."""
     shape = tuple(shape)
+    key = (name, shape, dtype)
+    if key in _CACHE:
+        return _CACHE[key].clone()
+    t = _tensor_for(name, shape, dtype)
+    if t.numel() >= 1 << 16:
+        _CACHE[key] = t
+        _CACHE_BYTES[0] += t.numel() * t.element_size()
+        while _CACHE_BYTES[0] > _CACHE_CAP:
+            old = _CACHE.pop(next(iter(_CACHE)))
+            _CACHE_BYTES[0] -= old.numel() * old.element_size()
+        return t.clone()
+    return t
+
+
+def _tensor_for(name, shape, dtype):
     n = _rs(name).standard_normal(shape)
     if name == "sequence_embedding":
         v = n

@@ -35,11 +35,11 @@ def run(env_extra):
 
 @pytest.fixture(scope="module")
 def digests():
-    """Every child once, four at a time (a child is mostly interpreter start-up and parameter generation on the host; the GPU
+    """Every child once, eight at a time (a child is mostly interpreter start-up and parameter generation on the host; the GPU
     passes are milliseconds): {"": default digest, switch: digest with that switch flipped}."""
     from concurrent.futures import ThreadPoolExecutor
     jobs = [("", {})] + [("%s=%s" % (k, v), {k: v}) for k, v in KNOBS]
-    with ThreadPoolExecutor(max_workers=4) as pool:
+    with ThreadPoolExecutor(max_workers=8) as pool:
         return dict(zip([j[0] for j in jobs], pool.map(lambda j: run(j[1]), jobs)))
 
 
