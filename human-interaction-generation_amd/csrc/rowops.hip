@@ -127,79 +127,6 @@ __global__ __launch_bounds__(256) void ln_mod_silu_kernel(
   }
 }
 
-// The same with RPW consecutive rows per wave, all of them requested before the first is used (round 6).  With one row per wave
-// a launch was 12 544 waves that each paid a full load -> reduce -> parameter load -> store chain for 4 KB (13.2 us at config 2,
-// 24 launches per forward): here a wave has RPW x 2 KB in flight, gamma / beta stay in registers for its rows, and the whole
-// launch is one round of resident waves (9.x us).  Same arithmetic in the same order: bit-identical to the kernel above.
-template <int NIT, int RPW>
-__global__ __launch_bounds__(256) void ln_mod_silu_rows_kernel(
-    const float* __restrict__ x, int64_t ldx, int64_t rows, int n, const float* __restrict__ gamma,
-    const float* __restrict__ beta, const float* __restrict__ ss, int64_t ss_ld, int shift_off,
-    int rows_per_sample, float* __restrict__ a, int64_t lda, float* __restrict__ stats) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * RPW;
-  if (row0 >= rows) return;
-  float4 v[RPW][NIT];
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    const float* xr = x + min(row0 + r, rows - 1) * ldx;       // (rows past the end: the last row again, never stored)
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int c = 4 * lane + 256 * it;
-      v[r][it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < n) v[r][it] = *reinterpret_cast<const float4*>(xr + c);
-    }
-  }
-  float4 g4[NIT], b4[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int c = 4 * lane + 256 * it;
-    g4[it] = b4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < n) {
-      g4[it] = *reinterpret_cast<const float4*>(gamma + c);
-      b4[it] = *reinterpret_cast<const float4*>(beta + c);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    const int64_t row = row0 + r;
-    if (row >= rows) break;
-    float s = 0.f;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) s += (v[r][it].x + v[r][it].y) + (v[r][it].z + v[r][it].w);
-    const float mean = wave_sum(s) / (float)n;
-    float q = 0.f;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int c = 4 * lane + 256 * it;
-      if (c < n) {
-        const float d0 = v[r][it].x - mean, d1 = v[r][it].y - mean, d2 = v[r][it].z - mean, d3 = v[r][it].w - mean;
-        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-      }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)n + 1e-5f);
-    if (lane == 0) {
-      stats[2 * row] = mean;
-      stats[2 * row + 1] = rstd;
-    }
-    const float* ssrow = ss + (row / rows_per_sample) * ss_ld;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int c = 4 * lane + 256 * it;
-      if (c < n) {
-        const float4 sc = *reinterpret_cast<const float4*>(ssrow + c);
-        const float4 sh = *reinterpret_cast<const float4*>(ssrow + shift_off + c);
-        float4 o;
-        o.x = hig_silu(((v[r][it].x - mean) * rstd * g4[it].x + b4[it].x) * (1.0f + sc.x) + sh.x);
-        o.y = hig_silu(((v[r][it].y - mean) * rstd * g4[it].y + b4[it].y) * (1.0f + sc.y) + sh.y);
-        o.z = hig_silu(((v[r][it].z - mean) * rstd * g4[it].z + b4[it].z) * (1.0f + sc.z) + sh.z);
-        o.w = hig_silu(((v[r][it].w - mean) * rstd * g4[it].w + b4[it].w) * (1.0f + sc.w) + sh.w);
-        *reinterpret_cast<float4*>(a + row * lda + c) = o;
-      }
-    }
-  }
-}
-
 // Backward of a = [silu](LN(x) * (1 + scale) + shift).  grid = (samples, splits); wave w of split
 // s owns rows s*4 + w, + 4*splits, ... of its sample.  NIT = ceil(n / 256) float4 per lane.
 template <int NIT, bool MOD_SILU>
@@ -928,20 +855,8 @@ extern "C" int hig_ln_mod_silu(const float* x, int64_t ldx, int64_t rows, int32_
   HIG_REQUIRE(n > 0 && n % 4 == 0 && n <= 1024 && ldx % 4 == 0 && lda % 4 == 0 && rows_per_sample > 0,
               "hig_ln_mod_silu: n must be a multiple of 4 and <= 1024 (got %d)", n);
   if (rows == 0) return HIG_OK;
-  const int nit = (n + 255) / 256;
-  if (rows >= 4096 && nit <= 2) {   // many rows: four rows per wave, one round of resident waves (see ln_mod_silu_rows_kernel)
-    constexpr int RPW = 4;
-    const dim3 grid4((unsigned)((rows + WAVES * RPW - 1) / (WAVES * RPW)));
-    if (nit == 1)
-      hipLaunchKernelGGL((ln_mod_silu_rows_kernel<1, RPW>), grid4, dim3(256), 0, hig_stream(stream), x, ldx, rows, n, gamma, beta, ss, ss_ld,
-                         ss_shift_off, rows_per_sample, a, lda, stats);
-    else
-      hipLaunchKernelGGL((ln_mod_silu_rows_kernel<2, RPW>), grid4, dim3(256), 0, hig_stream(stream), x, ldx, rows, n, gamma, beta, ss, ss_ld,
-                         ss_shift_off, rows_per_sample, a, lda, stats);
-    HIG_CHECK_LAUNCH();
-    return HIG_OK;
-  }
   const dim3 grid((unsigned)((rows + WAVES - 1) / WAVES));
+  const int nit = (n + 255) / 256;
 #define LMS(NITV)                                                                                      \
   hipLaunchKernelGGL((ln_mod_silu_kernel<NITV, true>), grid, dim3(256), 0, hig_stream(stream), x, ldx, rows, n, \
                      gamma, beta, ss, ss_ld, ss_shift_off, rows_per_sample, a, lda, stats)
