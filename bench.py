@@ -156,8 +156,9 @@ def ffn_gemm_roofline(c, device, reps=32):
     ach = flops / (ms * 1e-3) / 1e12
     traffic, src = pmc_traffic_bytes()
     return {"bound": "mfma",
-            "kernel": "gemm_f32_kernel<64,64,X_RS=0,Y_RS=0,XF_NONE,EPI_BIAS_GELU,FAST> (FFN linear1: M=%d K=%d N=%d; 12 whole "
-                      "rounds of 64x64 tiles + the last 64 tiles split 4-way along K, as in the forward)" % (M, K, Nn),
+            "kernel": "gemm_wsp32_kernel<KW=512,EPI_BIAS_GELU> (FFN linear1: M=%d K=%d N=%d; weight-stationary, 16 column panels x "
+                      "16 row groups of 49 tiles of 16 rows on the 256 CUs, as in the forward; HIG_F32_WSP=0: the tiled "
+                      "gemm_f32_kernel<64,64,...> of rounds 1-5)" % (M, K, Nn),
             "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
             "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "kernel_avg_us_rocprof": rocprof_kernel_avg_us(),

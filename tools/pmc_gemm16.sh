@@ -21,12 +21,12 @@ for name in ("fetch", "write", "sq", "lds", "tcc"):
     if not fs: continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[-1])):
-        if "gemm_bf16_kernel" in r["Kernel_Name"] or "gemm_ws16_kernel" in r["Kernel_Name"]:
+        if any(k in r["Kernel_Name"] for k in ("gemm_bf16_kernel", "gemm_ws16_kernel", "gemm_wsp16_kernel")):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items(): out[k] = sum(v) / len(v)
     ts = sorted(glob.glob("$O/%s/**/*kernel_trace.csv" % name, recursive=True))
     if ts:
-        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(ts[-1])) if "gemm_bf16_kernel" in r["Kernel_Name"] or "gemm_ws16_kernel" in r["Kernel_Name"]]
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(ts[-1])) if any(k in r["Kernel_Name"] for k in ("gemm_bf16_kernel", "gemm_ws16_kernel", "gemm_wsp16_kernel"))]
         if d: out["dur_us_" + name] = sum(d) / len(d) / 1e3
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     out["traffic_bytes"] = (2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024   # guide: FETCH_SIZE reads half on gfx950

@@ -12,6 +12,6 @@ python3 - <<PY
 import csv, glob, collections
 for name in ("pmc_fetch", "pmc_write"):
     f = sorted(glob.glob("$O/%s/**/*counter_collection.csv" % name, recursive=True))[-1]
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "gemm_f32_kernel" in r["Kernel_Name"]]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "gemm_f32_kernel" in r["Kernel_Name"] or "gemm_wsp32_kernel" in r["Kernel_Name"]]
     print(name, "launches", len(v), "mean", sum(v) / len(v), "min", min(v), "max", max(v))
 PY

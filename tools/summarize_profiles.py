@@ -58,7 +58,7 @@ if kt:
     if m1 and m2:
         lo, hi = m1[-1], m2[-1]
         durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows
-                if "gemm_f32_kernel" in r["Kernel_Name"] and lo < int(r["Start_Timestamp"]) < hi]
+                if ("gemm_f32_kernel" in r["Kernel_Name"] or "gemm_wsp32_kernel" in r["Kernel_Name"]) and lo < int(r["Start_Timestamp"]) < hi]
         if durs:
             avg = sum(durs) / len(durs) / 1e3
             flops = 2.0 * 12544 * 512 * 1024
@@ -89,7 +89,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
         continue
     by, dur = collections.defaultdict(list), {}
     for r in csv.DictReader(open(f)):
-        if "gemm_f32_kernel" in r["Kernel_Name"]:
+        if "gemm_f32_kernel" in r["Kernel_Name"] or "gemm_wsp32_kernel" in r["Kernel_Name"]:
             by[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     for k, v in by.items():
