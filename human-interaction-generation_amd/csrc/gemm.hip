@@ -996,7 +996,17 @@ int launch(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, hipSt
   }
   int gridx = hig_chip_cus() * per_cu;
   if (gridx > a.ntiles || forced_per_cu == 0) gridx = a.ntiles;   // 0: one workgroup per tile
-  if (a.ntiles > 0 && g.R >= 0) {
+  bool served = false;
+  if constexpr (X_RS && Y_RS && XF == HIG_XF_NONE && EPI == HIG_EPI_NONE) {
+    // weight gradients of the exact-fp32 step: the output-stationary kernel with specialised waves (wgrad_wsp32.hip) writes the
+    // same slabs (and per-split column sums) this function would
+    if (splits > 1 && a.g.C == slabs) {
+      const int rc = hig_wgrad_wsp32_try(g, splits, slabs, a.slab, a.xsum, a.xsum_stride, st);
+      if (rc < 0) return rc;
+      served = rc == HIG_OK;
+    }
+  }
+  if (!served && a.ntiles > 0 && g.R >= 0) {
     // the bf16 product modes exist for aligned reduce-contiguous operands; anything else
     // (F = 150 projections, reduce-slow dgrad / wgrad layouts) runs the exact fp32 kernel
     bool launched = false;

@@ -312,6 +312,13 @@ __global__ __launch_bounds__(512, 2) void gemm_wsp32_kernel(const Wsp32Args a) {
             }
           }
           if constexpr (TAIL) { if (s == (MAIN ? XS + 1 : XS - 1)) dump(); }
+          // the fragment this k-step multiplied stays "live" to its end: hipcc otherwise hands its registers -- free from the MFMA
+          // that read them last -- to this k-step's fragment read, and a write into an operand of an MFMA still in flight waits
+          // for it (see RS above); held to here, the read can only land in the slot the previous k-step released
+          {
+            const int cur = (s < XS ? NKS - XS + s : s - XS) % RS;      // (the loop is fully unrolled: a constant)
+            if ((s < XS && TAIL) || (s >= XS && MAIN)) asm volatile("" ::"v"(ring[cur]));
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         // every fragment read of tile i has been handed to the LDS: the add below is executed behind them (in order), so a

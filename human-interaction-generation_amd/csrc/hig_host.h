@@ -56,6 +56,9 @@ bool hig_gemm_ws16_lnfold_ok(int64_t rows, int d);
 // exact-fp32 weight-stationary kernel with specialised waves (gemm_wsp32.hip: K = 512 / 1024, reduce-contiguous aligned
 // operands, >= 2048 rows); same return codes
 int hig_gemm_wsp32_try(const hig_gemm_desc& g, hipStream_t st);
+// weight gradients dW = dC^T . act over >= 2048 rows, I and J multiples of 128, tiles x splits <= 256 (wgrad_wsp32.hip): writes
+// the split-R slabs (+ per-split column sums of dC) of hig_gemm_launch(splits > 1); same return codes
+int hig_wgrad_wsp32_try(const hig_gemm_desc& g, int splits, float* slabs, int64_t slab, float* xsum, int64_t xsum_stride, hipStream_t st);
 bool hig_gemm_wsp32_active();   // that kernel is switched on and the chip has the 256 CUs its work split is written for
 
 namespace {

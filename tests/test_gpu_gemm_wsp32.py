@@ -156,3 +156,37 @@ def test_reduce_ranges_beyond_the_weight_panel_go_through_in_two_passes(I, J, R)
         torch.cuda.synchronize()
         assert L.hig_gemm_wsp32_launches() - before == 2
         assert rel(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("I,J,R,splits", [(512, 512, 12544, 16), (1536, 512, 12544, 5), (512, 1024, 6272, 8), (1024, 512, 12539, 8),
+                                          (128, 256, 4099, 0), (512, 512, 2048, 0)])
+def test_weight_gradient_kernel_against_fp64(I, J, R, splits):
+    """wgrad_wsp32.hip through hig_gemm_split (the weight-gradient form of the fp32 backward: dW = dC^T . act over R rows in
+    `splits` slabs + the deterministic slab reduction, dbias = column sums of dC from the same pass): fp64 product, exact on
+    small integers, bitwise repeatable, row counts that are not a multiple of the 32-row stage."""
+    L = _lib.lib()
+    dC, act = rnd(R, I, seed=3).to(DEV), rnd(R, J, seed=4).to(DEV)
+    d = _lib.GemmDesc()
+    out, xs = torch.full((I, J), float("nan"), device=DEV), torch.full((I,), float("nan"), device=DEV)
+    d.X, d.ldx, d.x_rs, d.Y, d.ldy, d.y_rs = dC.data_ptr(), I, 1, act.data_ptr(), J, 1
+    d.C, d.ldc, d.I, d.J, d.R, d.xcolsum = out.data_ptr(), J, I, J, R, xs.data_ptr()
+    n = L.hig_gemm_split_scratch_floats(C.byref(d), splits)
+    slabs = torch.full((n,), float("nan"), device=DEV)
+
+    def run():
+        _lib.check(L.hig_gemm_split(C.byref(d), splits, slabs.data_ptr(), n, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        return out.clone(), xs.clone()
+    o, x = run()
+    assert rel(o, dC.double().t() @ act.double()) < 2e-6
+    assert rel(x, dC.double().sum(0)) < 2e-6
+    for _ in range(3):
+        slabs.fill_(float("nan"))
+        o2, x2 = run()
+        assert torch.equal(o2, o) and torch.equal(x2, x)
+    g = torch.Generator().manual_seed(5)
+    Ci, Ai = torch.randint(-3, 4, (R, I), generator=g).float(), torch.randint(-3, 4, (R, J), generator=g).float()
+    dC.copy_(Ci)
+    act.copy_(Ai)
+    o, x = run()
+    assert torch.equal(o.cpu(), Ci.t() @ Ai) and torch.equal(x.cpu(), Ci.sum(0))

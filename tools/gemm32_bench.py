@@ -78,3 +78,37 @@ if __name__ == "__main__":
         print("WSP=%s M=%d %-18s N=%4d K=%4d  %7.1f us  %6.1f TFLOP/s  frac %.3f" %
               (os.environ.get("HIG_F32_WSP", "1"), M, name, N, K, ms * 1e3, tf, tf / PEAK), flush=True)
     print("WSP=%s M=%d sum of the seven %.1f us" % (os.environ.get("HIG_F32_WSP", "1"), M, tot * 1e3))
+
+
+def run_wgrad(M, I, J, reps=20, warm=3):
+    """The weight-gradient form (hig_gemm_split, library's own split count): dW = dC^T . act over M rows + dbias."""
+    dev = "cuda"
+    L = _lib.lib()
+    dC, act = torch.randn(M, I, device=dev), torch.randn(M, J, device=dev)
+    out, xs = torch.empty(I, J, device=dev), torch.empty(I, device=dev)
+    d = _lib.GemmDesc()
+    d.X, d.ldx, d.x_rs, d.Y, d.ldy, d.y_rs = dC.data_ptr(), I, 1, act.data_ptr(), J, 1
+    d.C, d.ldc, d.I, d.J, d.R, d.xcolsum = out.data_ptr(), J, I, J, M, xs.data_ptr()
+    n = 64 << 20
+    slabs = torch.empty(n, device=dev)
+    for _ in range(warm):
+        _lib.check(L.hig_gemm_split(C.byref(d), 0, slabs.data_ptr(), n, _lib.stream_ptr()))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            _lib.check(L.hig_gemm_split(C.byref(d), 0, slabs.data_ptr(), n, _lib.stream_ptr()))
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / reps)
+    return best, 2.0 * M * I * J / best / 1e9
+
+
+if __name__ == "__main__" and os.environ.get("WGRAD", "1") != "0":
+    M = int(os.environ.get("M", 12544))
+    for name, I, J in [("sty-out / ca-q", 512, 512), ("q/k/v", 1536, 512), ("ffn1", 1024, 512), ("ffn2", 512, 1024)]:
+        ms, tf = run_wgrad(M, I, J)
+        print("WSP=%s M=%d wgrad %-15s dW %4d x %4d  %7.1f us (kernel + slab reduction)  %6.1f TFLOP/s  frac %.3f" %
+              (os.environ.get("HIG_F32_WSP", "1"), M, name, I, J, ms * 1e3, tf, tf / PEAK), flush=True)
