@@ -47,3 +47,14 @@ python3 $R/tools/gemm_wsp16_stamps.py qkv 64 2>&1 | grep -v amdgpu.ids | tail -1
 python3 $R/tools/wgrad_stamps.py 2>&1 | grep -v amdgpu.ids | tail -12 > $O/wgrad_stamps.txt
 python3 $R/tools/wgrad_time.py 2>&1 | grep -v amdgpu.ids | tail -8 > $O/wgrad_time.txt
 python3 $R/tools/two_person16_time.py 2>&1 | grep -v amdgpu.ids | tail -4 > $O/two_person16_time.txt
+
+# round 6: the exact-fp32 weight-stationary kernels (gemm_wsp32 / wgrad_wsp32): per-shape A/B against the tiled kernel, stamps of the
+# diagnostic instance, the micro-probes behind them, the steady-state counter pass, the capture soak
+{ HIG_F32_WSP=0 python3 $R/tools/gemm32_bench.py; HIG_F32_WSP=1 python3 $R/tools/gemm32_bench.py; M=50176 WGRAD=0 python3 $R/tools/gemm32_bench.py; } 2>&1 | grep "WSP=" > $O/gemm32_shapes.txt
+python3 $R/tools/gemm_wsp32_stamps.py none 64 hot 2>&1 | grep -v amdgpu.ids | grep -v "workgroup start" | tail -17 > $O/wsp32_stamps.txt
+python3 $R/tools/gemm_wsp32_stamps.py ffn1 64 cold 2>&1 | grep -v amdgpu.ids | grep -v "workgroup start" | tail -17 >> $O/wsp32_stamps.txt
+for p in coissue32_probe mfma32_stream_probe; do [ -x $R/tools/$p ] && $R/tools/$p > $O/$p.txt 2>&1; done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq_warm -- python3 $R/tools/ffn_gemm_pmc.py warm > $O/pmc_sq_warm.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/kt_warm -- python3 $R/tools/ffn_gemm_pmc.py warm > $O/kt_warm.log 2>&1
+python3 $R/tools/rowkernels_time.py 2>&1 | grep -v amdgpu.ids > $O/rowkernels_time.txt
+python3 $R/tools/capture_soak.py 50 > $O/capture_soak.json 2> $O/capture_soak.err

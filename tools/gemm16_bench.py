@@ -8,6 +8,7 @@ import sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from hig_amd import _lib
+if os.environ.get("HIG_LIB_ALT"): _lib.LIB_PATH = os.environ["HIG_LIB_ALT"]   # (A/B of a variant build)
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 M = B * 196
