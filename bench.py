@@ -134,8 +134,11 @@ def ffn_gemm_roofline(c, device, reps=32):
     L = _lib.lib()
     # the split-tail scratch hig_denoiser_fwd hands its GEMMs (hig_gemm_ws): same kernel, same tile schedule as in the forward
     tail = torch.zeros(L.hig_gemm_tail_ws_bytes(), dtype=torch.uint8, device=device)
-    for i in range(NB):
-        _lib.check(L.hig_gemm_ws(C.byref(descs[i]), tail.data_ptr(), tail.numel(), _lib.stream_ptr()))
+    # warm-up: 25 rounds over the operand sets (~25 ms).  A process that comes here from host-side work finds the chip's memory side
+    # idle: the first ~100 launches of a fresh process run 10-15 % slower than the steady state (tools/ffn_gemm_pmc.py warm: 120-124 us
+    # by kernel trace for the first 20 launches, 105 us for launches 300-400, at an unchanged shader clock)
+    for i in range(25 * NB):
+        _lib.check(L.hig_gemm_ws(C.byref(descs[i % NB]), tail.data_ptr(), tail.numel(), _lib.stream_ptr()))
     # 5 batches of `reps` launches, each bracketed by HIP events; the MEDIAN batch average is reported (one batch right
     # after the heavy training-step section read 7 % slow on some boxes while the in-situ rocprofv3 average of the same
     # kernel stayed at 0.122 ms: clock / thermal state, not the kernel)
@@ -163,8 +166,8 @@ def ffn_gemm_roofline(c, device, reps=32):
             "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
             "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "kernel_avg_us_rocprof": rocprof_kernel_avg_us(),
             "batch_avg_launch_ms": [round(v, 4) for v in batch_ms],
-            "how": "median of 5 batches of %d launches rotating over %d operand sets (HBM-resident activations), HIP events on "
-                   "the launch stream" % (reps, NB)}
+            "how": "median of 5 batches of %d launches rotating over %d operand sets (HBM-resident activations) after 200 warm-up "
+                   "launches, HIP events on the launch stream" % (reps, NB)}
 
 
 def ffn_gemm_bf16_roofline(c, device, reps=32):

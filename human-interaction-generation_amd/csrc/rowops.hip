@@ -157,9 +157,35 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       }
     }
   }
-  for (int rl = split * WAVES + wave; rl < rows_per_sample; rl += WAVES * nsplit) {
+  // The NEXT row of this wave is requested before the current one is touched (round 6): a wave walks ~6 rows, and with the loads
+  // at the top of each trip every row paid a full memory latency on its own (47 us per launch at config 2 = 1.6 TB/s; 24 launches
+  // per training step).  Rows past the end re-read the last row (never used).
+  const int rstep = WAVES * nsplit;
+  const int rl0 = split * WAVES + wave;
+  float4 pxv[NIT], pdav[NIT];
+  float pmean = 0.f, prstd = 0.f;
+  auto fetch = [&](int rl) {
+    const int64_t row = (int64_t)b * rows_per_sample + min(rl, rows_per_sample - 1);
+    pmean = stats[2 * row];
+    prstd = stats[2 * row + 1];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = 4 * lane + 256 * it;
+      pxv[it] = pdav[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < n) {
+        pxv[it] = *reinterpret_cast<const float4*>(x + row * ldx + c);
+        pdav[it] = *reinterpret_cast<const float4*>(da + row * ldda + c);
+      }
+    }
+  };
+  if (rl0 < rows_per_sample) fetch(rl0);
+  for (int rl = rl0; rl < rows_per_sample; rl += rstep) {
     const int64_t row = (int64_t)b * rows_per_sample + rl;
-    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const float mean = pmean, rstd = prstd;
+    float4 cxv[NIT], cdav[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) { cxv[it] = pxv[it]; cdav[it] = pdav[it]; }
+    fetch(rl + rstep);
     float4 xh[NIT], dxh[NIT];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -167,8 +193,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       const int c = 4 * lane + 256 * it;
       xh[it] = dxh[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c < n) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + row * ldx + c);
-        const float4 dav = *reinterpret_cast<const float4*>(da + row * ldda + c);
+        const float4 xv = cxv[it];
+        const float4 dav = cdav[it];
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dav.x, dav.y, dav.z, dav.w};
         const float gs[4] = {g4[it].x, g4[it].y, g4[it].z, g4[it].w};
         const float bs[4] = {b4[it].x, b4[it].y, b4[it].z, b4[it].w};
