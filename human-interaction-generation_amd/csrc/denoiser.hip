@@ -378,9 +378,15 @@ hipEvent_t& layer_event() {   // hig_denoiser_bwd_hooked: "layer l is enqueued" 
   return ev;
 }
 
+// HIG_BWD_OVERLAP, read once for every user below: -1 unset (each form's own default), 0 everything on the caller's stream,
+// 1 fork the weight gradients in every form (eager, captured, bf16 storage).
+int bwd_overlap_env() {
+  static const int v = getenv("HIG_BWD_OVERLAP") ? atoi(getenv("HIG_BWD_OVERLAP")) : -1;
+  return v;
+}
+
 SideStream* side_stream_for_current_device(hipStream_t caller) {
-  static const int enabled = getenv("HIG_BWD_OVERLAP") ? atoi(getenv("HIG_BWD_OVERLAP")) : 1;
-  if (!enabled) return nullptr;
+  if (bwd_overlap_env() == 0) return nullptr;
   SideStream* tab = side_stream_table();
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
@@ -1314,7 +1320,7 @@ extern "C" int hig_denoiser_bwd_hooked(const hig_dims* dims, const void* const* 
   // Eager launches: the weight gradients go to the second stream.  Under stream capture they stay on the caller's (unless
   // HIG_BWD_OVERLAP=1): the replayed graph did not turn the fork into overlap -- config 2, captured fp32 step 21.6-21.7 ms forked
   // against 21.2 on one stream, while eager launches gain a millisecond from it (20.4 against 21.3).
-  static const int fork_env = getenv("HIG_BWD_OVERLAP") ? atoi(getenv("HIG_BWD_OVERLAP")) : -1;
+  const int fork_env = bwd_overlap_env();
   hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cap_status) != hipSuccess) cap_status = hipStreamCaptureStatusNone;
   const bool want_fork = fork_env == 1 || (fork_env != 0 && cap_status == hipStreamCaptureStatusNone);
@@ -1990,7 +1996,7 @@ static int denoiser_bwd_bf16_impl(const hig_dims* dims, const void* const* param
   // share a CU, so a weight gradient on the second stream delays the workgroups of the data-gradient GEMM CU by CU instead of
   // filling idle slots -- config 2, captured step: 7.27 ms on one stream, 7.40 forked (7.72 with the LayerNorm reductions
   // forked as well).  The fp32 step keeps the fork (tiled kernels, several workgroups per CU: 20.4 vs 21.4 ms eager).
-  static const int fork16 = getenv("HIG_BWD_OVERLAP") ? atoi(getenv("HIG_BWD_OVERLAP")) : 0;
+  const int fork16 = bwd_overlap_env() == 1;
   WgradFork fork(fork16 ? side_stream_for_current_device(st) : nullptr, st);
   // dW[n][k] = sum_m dC[m][n] act[m][k] (+ the bias gradient = column sums of dC): both operands transposed to
   // reduce-contiguous bf16 (n_out x Mp), (k_in x Mp), then the split-R bf16 GEMM into the fp32 gradient.  Everything on the

@@ -278,3 +278,79 @@ def test_config3_captured_1000_step_loop_equals_eager_loop(mode):
     gd = _diffusion(1000)
     a = gd.p_sample_loop(m, x0.shape, noise=x0.clone(), clip_denoised=False, model_kwargs=kw)
     assert torch.isfinite(a).all() and rel(a, graph) > 1e-3
+
+
+def _single_person_trainer(c, m):
+    args = types.SimpleNamespace(device=torch.device(DEV), diffusion_steps=1000, is_train=True, lr=2e-4, batch_size=c["B"],
+                                 num_epochs=1, log_every=50, save_latest=500, save_every_e=5, is_continue=False, model_dir="/tmp")
+    return hig_amd.DDPMTrainer(args, m)
+
+
+def _backlog():
+    """About a quarter of a second of queued device work: what follows is enqueued onto a BUSY device."""
+    a = torch.randn(8192, 8192, device=DEV)
+    for _ in range(12):
+        a = (a @ a).mul_(1e-4)
+    return a
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_captured_single_person_step_does_not_depend_on_when_the_host_synchronises(storage):
+    """The round-5 two-person regression (tests/test_gpu_interaction.py) as a check of EVERY captured training form (VERDICT r05
+    item 8): the single-person step at BASELINE config 2's size, replayed (a) back to back, (b) onto an idle device after a
+    torch.cuda.synchronize() -- bench.py's timed() pattern -- and (c) behind a backlog of unrelated work.  A graph node that only
+    happens to be ordered by the host's enqueue timing shows as a different loss trajectory; the three must be bit-identical."""
+    import time
+    c = CONFIG2
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(c["B"], c["T"], c["F"], generator=g).to(DEV)
+    nz = torch.randn(c["B"], c["T"], c["F"], generator=g).to(DEV)
+    tt = torch.tensor(c["t"], device=DEV)
+    ln = torch.tensor(c["lengths"], device=DEV)
+    xp = torch.randn(c["B"], 4 * c["d"], generator=g).to(DEV)
+    xo = torch.randn(c["B"], c["N"], c["Lt"], generator=g).to(DEV)
+    runs = []
+    for pattern in ("back to back", "idle", "backlog"):
+        m = build(c, storage=storage).train()
+        tr = _single_person_trainer(c, m)
+        losses = []
+        for k in range(6):
+            if pattern == "backlog" and k >= 2:
+                _backlog()
+            tr.train_step_captured(x0, tt, ln, xp, xo, noise=nz)
+            losses.append(tr.fused_state()["loss"].clone())
+            if pattern == "idle" and k in (1, 3):
+                torch.cuda.synchronize()
+                time.sleep(0.05)
+        runs.append([v.item() for v in losses])
+        del tr, m
+    assert runs[0] == runs[1] == runs[2], runs
+    assert all(v == v and abs(v) < float("inf") for v in runs[0]), runs[0]
+    assert runs[0][-1] < runs[0][0]          # and it trains: same batch six times
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_captured_sampling_loop_replayed_onto_an_idle_device_equals_back_to_back(mode):
+    """The same check for the captured p_sample_loop (one hipGraph per step, replayed `steps` times): 50 steps at config 3's
+    batch with the noise draws zeroed, (a) right after capture, (b) again behind a backlog of unrelated device work, (c) again
+    onto an idle device after a synchronisation.  Bit-identical outputs."""
+    import time
+    c = dict(fill.CASES["width"], B=32)
+    m = build(c, precision=mode).eval()
+    with torch.no_grad():
+        m.out.weight.mul_(0.05)
+        m.out.bias.mul_(0.05)
+    g = torch.Generator().manual_seed(12)
+    kw = {"xf_proj": torch.randn(32, 4 * c["d"], generator=g).to(DEV),
+          "xf_out": torch.randn(32, c["N"], c["Lt"], generator=g).to(DEV),
+          "length": torch.tensor([196] * 20 + list(range(100, 196, 8)), device=DEV)}
+    x0 = torch.randn(32, 196, c["F"], generator=g).to(DEV)
+    gd = _diffusion(50)
+    first = _zero_noise_loop(m, gd, True, x0, kw).clone()
+    _backlog()
+    busy = _zero_noise_loop(m, gd, True, x0, kw).clone()
+    torch.cuda.synchronize()
+    time.sleep(0.05)
+    idle = _zero_noise_loop(m, gd, True, x0, kw).clone()
+    assert torch.isfinite(first).all()
+    assert torch.equal(first, busy) and torch.equal(first, idle)
