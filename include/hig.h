@@ -541,7 +541,7 @@ int hig_gemm_bf16(const hig_gemm16_desc* g, hig_stream_t stream);
  * slabs: >= hig_gemm_bf16_split_scratch_floats(g, splits) floats. */
 int64_t hig_gemm_bf16_split_scratch_floats(const hig_gemm16_desc* g, int32_t splits);
 int hig_gemm_bf16_split(const hig_gemm16_desc* g, int32_t splits, float* slabs, int64_t slab_floats, hig_stream_t stream);
-/* Diagnostics (tools/gemm16_stamps.py, tools/gemm_ws16_stamps.py): while buf != NULL, thread 0 of every workgroup of the
+/* Diagnostics (tools/gemm_ws16_stamps.py): while buf != NULL, thread 0 of every workgroup of the
  * tiled bf16 kernel (HIG_BF16_DBG & 16; buf[block * 8 + k], block < 4096) / of the weight-stationary kernel
  * (buf[block * 16 + k], 256 blocks) writes s_memtime stamps of its phases.  This pointer is the library's only mutable
  * global state besides what hig_shutdown() releases; it is NULL unless a tool sets it, and is never set during a timed run. */

@@ -57,4 +57,4 @@ for p in coissue32_probe mfma32_stream_probe; do [ -x $R/tools/$p ] && $R/tools/
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq_warm -- python3 $R/tools/ffn_gemm_pmc.py warm > $O/pmc_sq_warm.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $O/kt_warm -- python3 $R/tools/ffn_gemm_pmc.py warm > $O/kt_warm.log 2>&1
 python3 $R/tools/rowkernels_time.py 2>&1 | grep -v amdgpu.ids > $O/rowkernels_time.txt
-python3 $R/tools/capture_soak.py 50 > $O/capture_soak.json 2> $O/capture_soak.err
+python3 $R/tools/capture_soak.py 50 2> $O/capture_soak.err | grep "^{" > $O/capture_soak.json

@@ -33,7 +33,15 @@ for pattern, name in (("ws16_stamps.txt", "_ws16_stamps.txt"), ("apply16_stamps.
                       ("trace_train16/**/*kernel_stats.csv", "_kernel_stats_train_step_bf16s.csv"), ("train16_time.txt", "_train16_time.txt"),
                       ("train16_kernels_solo.txt", "_train16_kernels_solo.txt"), ("rccl_world1_probe.json", "_rccl_world1_probe.json"),
                       ("ws16_store_policy.txt", "_ws16_store_policy.txt"), ("fwd32_fold_textfork.txt", "_fwd32_fold_textfork.txt"),
-                      ("cfg5_time.txt", "_cfg5_time.txt")):
+                      ("cfg5_time.txt", "_cfg5_time.txt"),
+                      # round 5 / 6: probes, stamps and per-shape timings behind the specialised-wave kernels
+                      ("l2_fetch_probe.txt", "_l2_fetch_probe.txt"), ("coissue_probe.txt", "_coissue_probe.txt"),
+                      ("lds_read_probe.txt", "_lds_read_probe.txt"), ("wsp16_stamps.txt", "_wsp16_stamps.txt"),
+                      ("wgrad_stamps.txt", "_wgrad_stamps.txt"), ("wgrad_time.txt", "_wgrad_time.txt"),
+                      ("two_person16_time.txt", "_two_person16_time.txt"), ("gemm32_shapes.txt", "_gemm32_shapes.txt"),
+                      ("wsp32_stamps.txt", "_wsp32_stamps.txt"), ("coissue32_probe.txt", "_coissue32_probe.txt"),
+                      ("mfma32_stream_probe.txt", "_mfma32_stream_probe.txt"), ("rowkernels_time.txt", "_rowkernels_time.txt"),
+                      ("capture_soak.json", "_capture_soak.json"), ("overlap_forms.txt", "_train_step_fork_forms.txt")):
     f = one(pattern)
     if f:
         shutil.copy(f, os.path.join(dst, tag + name))
@@ -110,6 +118,43 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and "GRBM_GUI_ACTIVE" in vals:
     lines += ["", "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) = %.1f %%; "
               "clock under load = %.2f GHz" % (100 * util, clk)]
     vals["mfma_util"], vals["clock_ghz"] = util, clk
+
+# ---- round 6: the same kernel in its steady regime (tools/ffn_gemm_pmc.py warm: 400 launches back to back, the last 100) -------
+def last100(path, want_counters):
+    by, dur = collections.defaultdict(list), collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        if "gemm_wsp32_kernel" not in r["Kernel_Name"] and "gemm_f32_kernel" not in r["Kernel_Name"]:
+            continue
+        key = r.get("Dispatch_Id", str(len(dur)))
+        dur[key] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        if want_counters:
+            by[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    d = list(dur.values())[-100:]
+    return {k: sum(v[-100:]) / len(v[-100:]) for k, v in by.items()}, (sum(d) / len(d) / 1e3 if d else None)
+
+
+fw, kw = one("pmc_sq_warm/**/*counter_collection.csv"), one("kt_warm/**/*kernel_trace.csv")
+if fw and kw:
+    sq, dur_pmc = last100(fw, True)
+    _, dur_kt = last100(kw, False)
+    busy = sq.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024          # per SIMD
+    steady = {"what": "400 launches back to back over 8 operand sets (HBM-resident activations), the LAST 100 summarised (a fresh "
+                      "process finds the chip idle: its first ~100 launches run 15 % slower)",
+              "sq": sq, "dur_us_under_pmc": round(dur_pmc, 2), "dur_us_kernel_trace_only": round(dur_kt, 2),
+              "mfma_busy_cycles_per_simd": busy, "mfma_busy_check": "49 tiles x 128 MFMAs x 32 cycles = 200704"}
+    if "GRBM_GUI_ACTIVE" in sq:
+        steady["mfma_util_grbm"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (sq["GRBM_GUI_ACTIVE"] / 8 * 1024)
+        steady["grbm_clock_ghz_over_trace_duration"] = sq["GRBM_GUI_ACTIVE"] / 8 / (dur_kt * 1e-6) / 1e9
+        steady["grbm_note"] = ("a quotient above the 2.4 GHz maximum means the counter's window is wider than the ~0.1 ms dispatch "
+                               "(MI355X_MICROARCH.md: the quotient reads high below ~0.3 ms): MfmaUtil by GRBM under-reads here")
+    steady["mfma_util_lower_bound_at_2p4GHz"] = busy / (dur_kt * 1e-6 * 2.4e9)
+    steady["mfma_util_at_2p2GHz"] = busy / (dur_kt * 1e-6 * 2.2e9)
+    vals["steady_state"] = steady
+    lines += ["", "Steady state (last 100 of 400 back-to-back launches): %.1f us by kernel trace, MFMA busy %.0f cycles per SIMD -> "
+              "MfmaUtil >= %.3f (at the 2.4 GHz maximum clock), %.3f at 2.2 GHz; by GRBM_GUI_ACTIVE %.3f (window wider than the dispatch)" %
+              (dur_kt, busy, steady["mfma_util_lower_bound_at_2p4GHz"], steady["mfma_util_at_2p2GHz"], steady.get("mfma_util_grbm", float("nan")))]
+vals["kernel"] = "FFN linear1 GEMM (M=12544, K=512, N=1024, bias+GELU), tools/ffn_gemm_pmc.py, separate rocprofv3 --pmc passes"
+vals["algorithmic_bytes"] = 79.2e6
 json.dump(vals, open(os.path.join(dst, tag + "_ffn_gemm_pmc.json"), "w"), indent=1)
 open(os.path.join(dst, tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
