@@ -176,7 +176,7 @@ FwdLayout fwd_layout(const Dims& D, int training) {
 // Text context (floats): LN stats of xf_out (shared by all layers), then per layer the context
 // matrices + column-softmax stats, and the key/value projections (kept per layer for backward).
 struct TextLayout {
-  int64_t stt, cscr, layer0, lstride, Ac, kstc, kv, kv_stride, total;
+  int64_t stt, cscr, layer0, lstride, Ac, kstc, kv, kv_stride, xhat, kvall, total;
 };
 TextLayout text_layout(const Dims& D, int training) {
   TextLayout t;
@@ -195,6 +195,15 @@ TextLayout text_layout(const Dims& D, int training) {
   const bool keep = training || D.full;
   t.kv_stride = keep ? al(D.Mt * 2 * D.d) : 0;
   t.total = t.kv + (keep ? t.kv_stride * D.L : al(D.Mt * 2 * D.d));
+  // inference, linear attention, fp32 storage: room for the batched form of the text side (text_context_impl: the normalised
+  // text rows once, the key/value projections of ALL layers as one (Mt, L 2d) matrix)
+  t.xhat = t.kvall = -1;
+  if (!keep && !D.bf16) {
+    o = t.total;
+    t.xhat = take(D.Mt * D.Lt);
+    t.kvall = take(D.Mt * 2 * D.d * D.L);
+    t.total = o;
+  }
   return t;
 }
 
@@ -314,8 +323,8 @@ extern "C" int64_t hig_bwd_workspace_bytes(const hig_dims* dims) {
 
 namespace {
 struct SideStream;
-int text_context_impl(const Dims& D, const void* const* params, const float* xf_out, void* textctx, int training, hipStream_t st,
-                      hipEvent_t* layer_done);
+int text_context_impl(const Dims& D, const void* const* params, const void* const* derived32, const float* xf_out, void* textctx,
+                      int training, hipStream_t st, hipEvent_t* layer_done);
 }
 extern "C" int hig_text_context(const hig_dims* dims, const void* const* params, const float* xf_out,
                                 void* textctx, int training, hig_stream_t stream) {
@@ -323,17 +332,56 @@ extern "C" int hig_text_context(const hig_dims* dims, const void* const* params,
   HIG_TRY(check_dims(dims, D));
   HIG_REQUIRE(params && xf_out && textctx, "hig_text_context: null argument");
   HIG_REQUIRE(!D.bf16, "hig_text_context: bf16 storage goes through hig_text_context_bf16");
-  return text_context_impl(D, params, xf_out, textctx, training, hig_stream(stream), nullptr);
+  return text_context_impl(D, params, nullptr, xf_out, textctx, training, hig_stream(stream), nullptr);
 }
 namespace {
 // layer_done (nullable): event l is recorded on `st` behind layer l's launches (hig_denoiser_fwd_text waits for it in front of
 // layer l's cross-attention)
-int text_context_impl(const Dims& D, const void* const* params, const float* xf_out, void* textctx, int training, hipStream_t st,
-                      hipEvent_t* layer_done) {
+// Does the text side run in its batched form (one key/value GEMM + one context build for all layers)?  Inference, linear
+// attention, fp32 storage, and the caller's derived-operand table carries the stacked folded weights (entries 6 L .. 6 L + 3).
+bool text_batched(const Dims& D, const void* const* derived32, int training) {
+  static const int batch_env = getenv("HIG_TEXT_BATCH") ? atoi(getenv("HIG_TEXT_BATCH")) : 1;   // tuning knob
+  return batch_env && derived32 && !training && !D.full && !D.bf16 && derived32[6 * D.L] && derived32[6 * D.L + 1] &&
+         derived32[6 * D.L + 2] && derived32[6 * D.L + 3];
+}
+// derived32 (nullable): the caller's derived-operand table (hig_denoiser_fwd_x); entries [6 L .. 6 L + 3] select the BATCHED form
+int text_context_impl(const Dims& D, const void* const* params, const void* const* derived32, const float* xf_out, void* textctx,
+                      int training, hipStream_t st, hipEvent_t* layer_done) {
   hig_stream_t stream = reinterpret_cast<hig_stream_t>(st);
   const TextLayout tl = text_layout(D, training);
   float* base = static_cast<float*>(textctx);
   float* stt = base + tl.stt;
+  // Batched form (inference, linear attention): LN_text_l(x) = xhat gamma_l + beta_l with xhat = (x - mean) rstd the same for
+  // every layer, so [key_l; value_l](LN_text_l(x)) = xhat (gamma_l (.) W_l)^T + (W_l beta_l + b_l): with the folded weights of
+  // all layers stacked (derived per parameter version, models/transformer.py:_derived32) the L key/value GEMMs of B N rows
+  // x K = Lt are ONE product of L 2d columns -- 77 row tiles per workgroup of the weight-stationary kernel instead of 8 launches
+  // of 9.6 (K = 256: gemm_wsp32.hip), ~150 against ~300 us of chip time at config 2 (transformer.py:146,150).
+  if (text_batched(D, derived32, training)) {
+    float* xhat = base + tl.xhat;
+    float* kvall = base + tl.kvall;
+    const int64_t ldkv = (int64_t)D.L * 2 * D.d;
+    HIG_TRY(hig_layernorm(xf_out, D.Lt, D.Mt, D.Lt, static_cast<const float*>(derived32[6 * D.L + 2]),
+                          static_cast<const float*>(derived32[6 * D.L + 3]), xhat, D.Lt, stt, stream));
+    HIG_TRY(hig_gemm_launch(G(xhat, D.Lt, 0, static_cast<const float*>(derived32[6 * D.L]), D.Lt, 0, kvall, ldkv, D.Mt, ldkv, D.Lt)
+                                .epi(HIG_EPI_BIAS, static_cast<const float*>(derived32[6 * D.L + 1])).prec(D.prec).g, 1, nullptr, st));
+    // the stacked weights put all keys in front of all values ([K_0 .. K_{L-1} | V_0 .. V_{L-1}]): head l H + h of "L H heads"
+    // is layer l's head h, and ONE context-build launch serves every layer (4096 workgroups instead of 8 x 512)
+    const float* Kall = kvall;
+    const float* Vall = kvall + (int64_t)D.L * D.d;
+    int rc = hig_linattn_ctx_groups(Kall, Vall, ldkv, D.B, D.N, D.H, D.L, D.hd, base + tl.layer0 + tl.Ac, tl.lstride,
+                                    base + tl.layer0 + tl.kstc, tl.lstride, st);
+    if (rc < 0) return rc;
+    for (int l = 0; l < D.L; ++l) {
+      if (rc != HIG_OK) {   // (head dim not on the matrix-core kernels: one launch per layer)
+        float* Ac = base + tl.layer0 + tl.lstride * l + tl.Ac;
+        float* kstc = base + tl.layer0 + tl.lstride * l + tl.kstc;
+        HIG_TRY(hig_linattn_ctx(Kall + (int64_t)l * D.d, Vall + (int64_t)l * D.d, ldkv, D.B, D.N, D.H, D.hd, nullptr, Ac, kstc,
+                                base + tl.cscr, stream));
+      }
+      if (layer_done && hipEventRecord(layer_done[l], st) != hipSuccess) return hig_set_error(HIG_EHIP, "hipEventRecord failed");
+    }
+    return HIG_OK;
+  }
   HIG_TRY(hig_rowstats(xf_out, D.Lt, D.Mt, D.Lt, stt, stream));
   for (int l = 0; l < D.L; ++l) {
     float* kv = base + tl.kv + tl.kv_stride * l;
@@ -477,7 +525,9 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
   } text_join;
   if (xf_out_for_text) {
     static const int text_fork = getenv("HIG_TEXT_FORK") ? atoi(getenv("HIG_TEXT_FORK")) : 1;   // tuning knob
-    SideStream* ts = (text_fork && D.L <= kMaxTextLayers) ? side_stream_for_current_device(st) : nullptr;
+    // (the batched form is two whole-chip launches: next to the first layers' GEMMs -- one workgroup per CU each -- they only take
+    // turns with them, 6.04 ms forked against 5.98 in front at config 2; it runs first on the caller's stream)
+    SideStream* ts = (text_fork && D.L <= kMaxTextLayers && !text_batched(D, derived32, training)) ? side_stream_for_current_device(st) : nullptr;
     if (ts) {
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) ts = nullptr;
@@ -490,13 +540,13 @@ static int denoiser_fwd_impl(const hig_dims* dims, const void* const* params, co
       if (hipEventRecord(ts->ready, st) != hipSuccess || hipStreamWaitEvent(ts->s3, ts->ready, 0) != hipSuccess)
         return hig_set_error(HIG_EHIP, "text fork failed");
       hig_gemm_set_tail_scratch(ws + w.gtail3, HIG_GEMM_TAIL_BYTES);
-      const int rc = text_context_impl(D, params, xf_out_for_text, const_cast<void*>(textctx), training, ts->s3, ts->text_done);
+      const int rc = text_context_impl(D, params, derived32, xf_out_for_text, const_cast<void*>(textctx), training, ts->s3, ts->text_done);
       hig_gemm_set_tail_scratch(ws + w.gtail, HIG_GEMM_TAIL_BYTES);
       text_join.arm(ts->s3, ts->text_done[0], st);   // every error exit below joins the text stream first
       if (rc != HIG_OK) return rc;
       text_ev = ts->text_done;
     } else {
-      HIG_TRY(text_context_impl(D, params, xf_out_for_text, const_cast<void*>(textctx), training, st, nullptr));
+      HIG_TRY(text_context_impl(D, params, derived32, xf_out_for_text, const_cast<void*>(textctx), training, st, nullptr));
     }
   }
   // K0: emb = time_embed(timestep_embedding(t)) + xf_proj; all 3L scale/shift pairs in ONE GEMM

@@ -1,4 +1,4 @@
-// WEIGHT-STATIONARY exact-fp32 GEMM with SPECIALISED WAVES for gfx950 (MI355X), K = 512 or 1024:
+// WEIGHT-STATIONARY exact-fp32 GEMM with SPECIALISED WAVES for gfx950 (MI355X), K = 256, 512 or 1024:
 //   C[i][j] = epi( sum_r X[i][r] * W[j][r] ), fp32 in / out, v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate).
 // Serves the nn.Linear layers of the fp32 denoiser whose reduce extent is d = 512 or ff = 1024 and whose row count is the
 // frame count M = B.T (codes/models/transformer.py:81-85 stylization out, :108-114 q/k/v, :144 cross-attention query,
@@ -175,9 +175,9 @@ __global__ __launch_bounds__(512, 2) void gemm_wsp32_kernel(const Wsp32Args a) {
   // i + LOOK - NXB.  When that is tile i - 2 or older, its last fragment read completed before B_(i-1); when it is tile i - 1
   // (K = 1024: two slots), the matrix waves count their issued reads in LDS and the service waves poll that counter.
   constexpr bool NEED_CNT = NXB < LOOK + 2;
-  constexpr int NH = KW / 256;               // K parts (matrix waves per column block)
+  constexpr int NH = KW / 256;               // K parts (matrix waves per column block): 1 / 2 / 4
   constexpr int NC = 4 / NH;                 // blocks of 32 columns
-  constexpr int BN = 32 * NC;                // panel width: 64 / 32
+  constexpr int BN = 32 * NC;                // panel width: 128 / 64 / 32
   constexpr int NKS = 16;                    // k-steps (16 reduce elements) per wave and tile
   constexpr int XS = 3;                      // k-steps of X fragments read ahead; the last XS of a tile run behind the next barrier
   constexpr int RS = XS + 1;                 // fragment ring: the read of k-step s goes into the slot k-step s - RS left ONE k-step ago (a read
@@ -195,11 +195,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wsp32_kernel(const Wsp32Args a) {
   constexpr int NSL = BN / 16;               // weight slices of 16 columns (one X-tile-shaped buffer each): 4 / 2
   constexpr int PPR = ROWB / 1024;           // 1-KiB DMA pieces per row: 2 / 4
   constexpr int NXI = BM * PPR / 4;          // X DMA instructions per service wave and tile: 8 / 16
-  constexpr int QPR = BN / 4;                // float4 per output row: 16 / 8
+  constexpr int QPR = BN / 4;                // float4 per output row: 32 / 16 / 8
+  constexpr int RPP = QPR > 16 ? 64 / QPR : 4;   // rows of its four a service wave finishes per epilogue pass (K = 256: two passes)
+  constexpr int NPASS = 4 / RPP;
   constexpr bool HAS_RES = p32_has_res(EPI);
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static_assert(XT == 0 || (KW == 512 && ((XT == 1 && EPI == HIG_EPI_BIAS_RES) || (XT == 2 && EPI == HIG_EPI_BIAS))), "LayerNorm fold: K = 512, producer = BIAS_RES, consumer = BIAS");
   static_assert(!AUX || EPI == HIG_EPI_BIAS_GELU, "aux output: GELU epilogue only");
+  static_assert(KW != 256 || (!HAS_RES && XT == 0 && !AUX), "K = 256 (the text-side key/value projection): plain / bias epilogue only");
   static_assert(NKS % RS == 0, "the ring index of a k-step is its number modulo RS in every tile");
   __shared__ __attribute__((aligned(1024))) char smem[160 * 1024];
   char* const sX = smem;
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wsp32_kernel(const Wsp32Args a) {
   else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
   else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
   // epilogue: this lane owns columns [4 cq, 4 cq + 4) of row 4 sw + rsub of the tile (BN = 32: lanes 32-63 shadow lanes 0-31)
-  const int cq = lane & (QPR - 1), rsub = (lane / QPR) & 3;
+  const int cq = lane & (QPR - 1), rsub = (lane / QPR) % RPP;
   const bool act = lane < 4 * QPR;
   // raw (stride 0) buffer descriptors over the whole operands; rows are clamped, so nothing is out of range
   __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)(((int64_t)(a.I - 1) * a.ldx + KW) * 4), 0x00020000);
@@ -412,12 +415,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wsp32_kernel(const Wsp32Args a) {
     }
 
     // ---- epilogue of tile e from the hand-off -----------------------------------------------------------------------------
-    constexpr int NST = 1 + (XT == 1 ? 1 : 0) + (AUX ? 1 : 0);   // vector-memory stores per wave and tile
+    constexpr int NST = NPASS * (1 + (XT == 1 ? 1 : 0) + (AUX ? 1 : 0));   // vector-memory stores per wave and tile
     const unsigned sh_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sH;
     [[maybe_unused]] const unsigned sr_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sR;
     [[maybe_unused]] const unsigned sl_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sL;
     auto epilogue = [&](int e) {
-      const int row = 4 * sw + rsub;
+#pragma unroll
+     for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = 4 * sw + RPP * pass + rsub;
       const unsigned hp = sh_lds + (e & 1) * HBUF + row * HROW + 16 * cq;
       f32x4 hh[NH];
 #pragma unroll
@@ -426,7 +431,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wsp32_kernel(const Wsp32Args a) {
       if constexpr (HAS_RES) rr = p32_lds16(sr_lds + (e % NRB) * RBUF + sw * 1024 + lane * 16);
       [[maybe_unused]] f32x2_t ps = {0.f, 0.f};
       if constexpr (XT == 2) ps = p32_lds8(sl_lds + (e % NRB) * LBUF + row * 64 + 8 * (cq & 7));   // panel cq & 7 of the row: (sum, centred sum of squares)
-      if constexpr (NH == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(rr), "+v"(ps));
+      if constexpr (NH == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(rr), "+v"(ps));
+      else if constexpr (NH == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(rr), "+v"(ps));
       else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(hh[2]), "+v"(hh[3]), "+v"(rr), "+v"(ps));
       float v[4];
 #pragma unroll
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wsp32_kernel(const Wsp32Args a) {
         if constexpr (EPI == HIG_EPI_BIAS_GELU) v[k] = p32_gelu(v[k]);
         if constexpr (EPI == HIG_EPI_DGELU) v[k] *= p32_dgelu(rr[k]);
       }
-      if (DIAG && (a.dbg & 4)) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }
+      if (DIAG && (a.dbg & 4)) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
       if (act) p32_store16<POL>(rsC, (ig * (int)a.ldc + j0 + 4 * cq) * 4, f32x4{v[0], v[1], v[2], v[3]});
       if constexpr (XT == 1) {
         // LayerNorm fold, producer side: (sum, sum of squared deviations from the panel mean) of this row's 64 outputs; the 16
@@ -468,6 +474,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wsp32_kernel(const Wsp32Args a) {
         const float qq = row16_sum((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3));
         if (cq == 0) *reinterpret_cast<float2*>(a.stats_out + ((int64_t)ig * (a.J >> 6) + panel) * 2) = make_float2(sm, qq);
       }
+     }
     };
 
     // ---- main loop: iteration i (behind barrier B_i) requests residual / statistics of tile i and X(i + LOOK), finishes tile
@@ -510,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wsp32_kernel(const Wsp32Args a) {
 
 template <int KW, int EPI, int XT, bool AUX>
 int launch_p32(const hig_gemm_desc& g, hipStream_t st) {
-  constexpr int BN = KW == 512 ? 64 : 32;
+  constexpr int BN = 32 * (4 / (KW / 256));
   Wsp32Args a;
   a.X = g.X; a.ldx = g.ldx;
   a.W = g.Y; a.ldy = g.ldy;
@@ -556,6 +563,11 @@ int launch_p32(const hig_gemm_desc& g, hipStream_t st) {
 
 template <int KW>
 int dispatch_p32(const hig_gemm_desc& g, hipStream_t st) {
+  if constexpr (KW == 256) {   // the text side's key/value projection (transformer.py:146,150): plain / bias epilogue only
+    if (g.epi == HIG_EPI_NONE) return launch_p32<KW, HIG_EPI_NONE, 0, false>(g, st);
+    if (g.epi == HIG_EPI_BIAS && !g.row_stats_in) return launch_p32<KW, HIG_EPI_BIAS, 0, false>(g, st);
+    return 1;
+  } else {
   switch (g.epi) {
     case HIG_EPI_NONE: return launch_p32<KW, HIG_EPI_NONE, 0, false>(g, st);
     case HIG_EPI_BIAS:
@@ -568,6 +580,7 @@ int dispatch_p32(const hig_gemm_desc& g, hipStream_t st) {
     case HIG_EPI_RES: return launch_p32<KW, HIG_EPI_RES, 0, false>(g, st);
     case HIG_EPI_DGELU: return launch_p32<KW, HIG_EPI_DGELU, 0, false>(g, st);
     default: return 1;
+  }
   }
 }
 
@@ -583,8 +596,8 @@ int hig_gemm_wsp32_try(const hig_gemm_desc& g, hipStream_t st) {
   constexpr int min_rows = 2048;   // below that a workgroup has < 4 tiles per segment to pay its weight phase with
   if (!hig_gemm_wsp32_active()) return 1;
   if (g.prec != HIG_PREC_F32 || g.x_rs || g.y_rs || g.xf != HIG_XF_NONE || g.xcolsum) return 1;
-  if (!(g.R == 512 || g.R == 1024) || g.I < min_rows) return 1;
-  const int bn = g.R == 512 ? 64 : 32;
+  if (!(g.R == 256 || g.R == 512 || g.R == 1024) || g.I < min_rows) return 1;
+  const int bn = 32 * (4 / (g.R / 256));
   if (g.J % bn != 0 || g.J / bn > 256) return 1;
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if (!(g.ldx % 4 == 0 && g.ldy % 4 == 0 && g.ldc % 4 == 0 && al(g.X) && al(g.Y) && al(g.C))) return 1;
@@ -596,6 +609,7 @@ int hig_gemm_wsp32_try(const hig_gemm_desc& g, hipStream_t st) {
   if ((g.epi == HIG_EPI_DGELU || (g.epi == HIG_EPI_BIAS_GELU && g.aux)) && !(g.aux && g.ldaux % 4 == 0 && al(g.aux) && (int64_t)g.I * g.ldaux < lim)) return 1;
   if (g.row_stats_out && !(g.R == 512 && g.epi == HIG_EPI_BIAS_RES && !g.row_stats_in && (reinterpret_cast<uintptr_t>(g.row_stats_out) & 7) == 0)) return 1;
   if (g.row_stats_in && !(g.R == 512 && g.epi == HIG_EPI_BIAS && g.ln_colsum && al(g.row_stats_in) && al(g.ln_colsum))) return 1;
+  if (g.R == 256) return (g.row_stats_out || g.row_stats_in || g.aux) ? 1 : dispatch_p32<256>(g, st);
   return g.R == 512 ? dispatch_p32<512>(g, st) : dispatch_p32<1024>(g, st);
 }
 

@@ -53,7 +53,10 @@ int hig_gemm_ws16_try(const hig_gemm16_desc& g, hipStream_t st);
 // weight-stationary kernel with specialised matrix / service waves (gemm_wsp16.hip: K = 512, J % 128 == 0, >= 2048 rows); same codes
 int hig_gemm_wsp16_try(const hig_gemm16_desc& g, hipStream_t st);
 bool hig_gemm_ws16_lnfold_ok(int64_t rows, int d);
-// exact-fp32 weight-stationary kernel with specialised waves (gemm_wsp32.hip: K = 512 / 1024, reduce-contiguous aligned
+// linattn.hip: context build of G groups of H heads in one launch (the batched text side); 1 = shape not served
+int hig_linattn_ctx_groups(const float* K, const float* V, int64_t ld, int32_t B, int32_t rows, int32_t H, int32_t G, int32_t hd,
+                           float* A, int64_t a_gs, float* kstat, int64_t k_gs, hipStream_t st);
+// exact-fp32 weight-stationary kernel with specialised waves (gemm_wsp32.hip: K = 256 / 512 / 1024, reduce-contiguous aligned
 // operands, >= 2048 rows); same return codes
 int hig_gemm_wsp32_try(const hig_gemm_desc& g, hipStream_t st);
 // weight gradients dW = dC^T . act over >= 2048 rows, I and J multiples of 128, tiles x splits <= 256 (wgrad_wsp32.hip): writes

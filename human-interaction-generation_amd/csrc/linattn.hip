@@ -461,6 +461,10 @@ __global__ __launch_bounds__(256) void apply_mfma_kernel(const TIO* __restrict__
   }
 }
 
+struct CtxGroups {
+  int Hgrp;            // heads per output group
+  int64_t a_gs, k_gs;  // group strides of A / kstat in floats
+};
 // A[b,h][c][l] = sum_r softmax_r(K)[r,c] V[r,l]  (+ kstat): one workgroup per (sample, head) walks the row chunks
 // ONCE with a running column max (online softmax): when a chunk raises the max of channel c, the accumulator row c
 // and the running sum are rescaled by exp(m_old - m_new).  The next K / V tiles are prefetched into registers.
@@ -468,7 +472,7 @@ template <int HD, typename TIO>
 __global__ __launch_bounds__(256) void ctx_mfma_kernel(const TIO* __restrict__ K, const TIO* __restrict__ V,
                                                        int64_t ld, int rows, int H,
                                                        const int64_t* __restrict__ length, float* __restrict__ A,
-                                                       float* __restrict__ kstat, __bf16* __restrict__ At16) {
+                                                       float* __restrict__ kstat, __bf16* __restrict__ At16, const CtxGroups grp) {
   constexpr int LDP = HD + 4, TB = HD / 64, Q4 = HD / 4, NRG = 256 / Q4, PER = CH / NRG;
   __shared__ __attribute__((aligned(16))) float sP[CH * LDP];   // [r][c] = exp(K - running max)
   __shared__ __attribute__((aligned(16))) float sV[CH * LDP];   // [r][l]
@@ -477,6 +481,11 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const TIO* __restrict__ K
   __shared__ __attribute__((aligned(16))) float sscale[HD];     // exp(m_old - m_new) of the current chunk
   const int tid = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
+  // outputs: head h belongs to group h / Hgrp (the layers of the batched text side); a group's context matrices and column
+  // statistics are laid out (B, Hgrp, ...) at group strides -- Hgrp = H: one group, the plain (B, H, ...) layout
+  const int64_t oidx = (int64_t)b * grp.Hgrp + h % grp.Hgrp;
+  A += (h / grp.Hgrp) * grp.a_gs;
+  kstat += (h / grp.Hgrp) * grp.k_gs;
   int len = rows;
   if (length) len = (int)min<int64_t>(max<int64_t>(length[b], 0), rows);
   const TIO* Kb = K + (int64_t)b * rows * ld + h * HD;
@@ -574,7 +583,7 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const TIO* __restrict__ K
     float t = 0.f;
     for (int g2 = 0; g2 < NRG; ++g2) t += sred[g2 * HD + tid];
     sscale[tid] = t > 0.f ? 1.0f / t : 0.f;
-    float* st = kstat + ((int64_t)blockIdx.x * HD + tid) * 2;
+    float* st = kstat + (oidx * HD + tid) * 2;
     st[0] = len > 0 ? smax[tid] : 0.f;
     st[1] = len > 0 ? t : 1.f;
   }
@@ -583,7 +592,7 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const TIO* __restrict__ K
   for (int ti = 0; ti < TB; ++ti) {
     const int cc = wi * (HD / 2) + 32 * ti + lr;      // lane's context row (channel c)
     const float inv = sscale[cc];
-    float* ap = A + (int64_t)blockIdx.x * HD * HD + cc * HD + wj * (HD / 2) + 4 * lh;
+    float* ap = A + oidx * HD * HD + cc * HD + wj * (HD / 2) + 4 * lh;
 #pragma unroll
     for (int tj = 0; tj < TB; ++tj) store16(ap + 32 * tj, acc[ti][tj], inv);
     if (At16) {   // the same matrix transposed and rounded, At[l][c] = bf16(A[c][l]), in the fragment-major order of
@@ -593,7 +602,7 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const TIO* __restrict__ K
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int l = wj * (HD / 2) + 32 * tj + 8 * (e >> 2) + 4 * lh + (e & 3);
-          At16[(int64_t)blockIdx.x * HD * HD + hig_at16_offset(HD, l, cc)] = (__bf16)(acc[ti][tj][e] * inv);
+          At16[oidx * HD * HD + hig_at16_offset(HD, l, cc)] = (__bf16)(acc[ti][tj][e] * inv);
         }
     }
   }
@@ -1456,9 +1465,9 @@ int linattn_ctx_t(const TIO* K, const TIO* V, int64_t ld, int32_t B, int32_t row
     return HIG_OK;
   }
   if (hd == 64)
-    hipLaunchKernelGGL((ctx_mfma_kernel<64, TIO>), dim3(B * H), dim3(256), 0, st, K, V, ld, rows, H, length, A, kstat, At16);
+    hipLaunchKernelGGL((ctx_mfma_kernel<64, TIO>), dim3(B * H), dim3(256), 0, st, K, V, ld, rows, H, length, A, kstat, At16, CtxGroups{H, 0, 0});
   else
-    hipLaunchKernelGGL((ctx_mfma_kernel<128, TIO>), dim3(B * H), dim3(256), 0, st, K, V, ld, rows, H, length, A, kstat, At16);
+    hipLaunchKernelGGL((ctx_mfma_kernel<128, TIO>), dim3(B * H), dim3(256), 0, st, K, V, ld, rows, H, length, A, kstat, At16, CtxGroups{H, 0, 0});
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }
@@ -1492,6 +1501,23 @@ extern "C" int hig_linattn_ctx(const float* K, const float* V, int64_t ld, int32
   if (hd == 64 || hd == 128) return linattn_ctx_t<float>(K, V, ld, B, rows, H, hd, length, A, kstat, scratch, hig_stream(stream));
   HD_SWITCH(hd, hipLaunchKernelGGL((ctx_kernel<HDV>), dim3(B * H), dim3(256), 0, hig_stream(stream), K, V,
                                    ld, rows, H, length, A, kstat));
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+// The context build of G groups of H heads in ONE launch (the L layers of the batched text side, denoiser.hip): K / V hold
+// G H heads side by side (head g H + h at column (g H + h) hd), group g's outputs go to A + g a_gs / kstat + g k_gs in the
+// plain (B, H, ...) layout.  fp32 rows, head dim 64 / 128, no length mask; returns 1 when the shape is not served (the
+// caller loops over the groups instead).
+int hig_linattn_ctx_groups(const float* K, const float* V, int64_t ld, int32_t B, int32_t rows, int32_t H, int32_t G, int32_t hd,
+                           float* A, int64_t a_gs, float* kstat, int64_t k_gs, hipStream_t st) {
+  if (!(hd == 64 || hd == 128) || B <= 0 || rows <= 0 || H <= 0 || G <= 0) return 1;
+  if (hd == 64)
+    hipLaunchKernelGGL((ctx_mfma_kernel<64, float>), dim3(B * H * G), dim3(256), 0, st, K, V, ld, rows, H * G, nullptr, A, kstat,
+                       nullptr, CtxGroups{H, a_gs, k_gs});
+  else
+    hipLaunchKernelGGL((ctx_mfma_kernel<128, float>), dim3(B * H * G), dim3(256), 0, st, K, V, ld, rows, H * G, nullptr, A, kstat,
+                       nullptr, CtxGroups{H, a_gs, k_gs});
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

@@ -679,20 +679,32 @@ class MotionTransformer(nn.Module):
         """Operands of the fp32 inference forward derived from the parameters, rebuilt when they change (`derived32` of
         hig_denoiser_fwd_x): per layer the LayerNorm-folded projections k = 0 (self-attention q/k/v) and k = 1 (cross-attention
         query) as [W' = gamma (.) W, colsum = row sums of W', bias' = b + W beta] -- LayerNorm(x) W^T + b == rstd (x W'^T) - rstd
-        mean colsum + bias' (transformer.py:108-110,144), applied where the producer of x wrote its row statistics.  fp64
-        arithmetic for the derived vectors, fp32 storage; latent_dim % 128 == 0 only (NULL table otherwise)."""
+        mean colsum + bias' (transformer.py:108-110,144), applied where the producer of x wrote its row statistics; and
+        [6 L .. 6 L + 3] the text side's key/value weights of ALL layers with their text_norm folded in, stacked (L 2d, Lt: every
+        layer's key rows, then every layer's value rows), the
+        stacked bias', and a ones / zeros vector (the affine-free LayerNorm of the text rows) -- the per-call text side then runs
+        one GEMM instead of L (transformer.py:146,150).  fp64 arithmetic for the derived vectors, fp32 storage; latent_dim % 128
+        == 0 only (NULL table otherwise)."""
         d = self.latent_dim
         if d % 128 != 0 or d > 1024:
             return None
         ver = (self._param_version(), fp.flat.data_ptr())
         if getattr(self, "_derived_f32", None) is None or self._derived_f32[0] != ver:
             nl, ng, offs, L = _lib.NLAYER, _lib.NGLOBAL, fp.group_offsets, self.num_layers
-            arr, bufs = (C.c_void_p * (6 * L))(), []
+            arr, bufs = (C.c_void_p * (6 * L + 4))(), []
+            Lt = self.text_latent_dim
+            wt, bt = [], []
             with torch.no_grad():
                 for l in range(L):
                     def grp(idx, n):
                         o = offs[ng + l * nl + idx]
                         return fp.flat[o:o + n]
+                    # text side (transformer.py:146,150): [key; value](LN_text(xf)) = xhat (gamma (.) W)^T + (W beta + b) with
+                    # xhat = (xf - mean) rstd the same in every layer -- the folded weights of ALL layers stacked, one GEMM
+                    g_t, b_t = grp(10, Lt).double(), grp(11, Lt).double()
+                    Wkv, bkv = grp(14, 2 * d * Lt).view(2 * d, Lt).double(), grp(15, 2 * d).double()
+                    wt.append((Wkv * g_t[None, :]).float())         # rows [0, d): key, [d, 2 d): value
+                    bt.append((bkv + Wkv @ b_t).float())
                     for k, (nw, nb, wi, bi, rows) in enumerate(((0, 1, 2, 3, 3 * d), (8, 9, 12, 13, d))):
                         gamma, beta = grp(nw, d).double(), grp(nb, d).double()
                         W, b = grp(wi, rows * d).view(rows, d).double(), grp(bi, rows).double()
@@ -701,6 +713,13 @@ class MotionTransformer(nn.Module):
                         bp = (b + W @ beta).float().contiguous()
                         bufs += [Wp, cs, bp]
                         arr[6 * l + 3 * k], arr[6 * l + 3 * k + 1], arr[6 * l + 3 * k + 2] = Wp.data_ptr(), cs.data_ptr(), bp.data_ptr()
+                if not self.no_eff:
+                    # all keys in front of all values: [K_0 .. K_{L-1} | V_0 .. V_{L-1}] (one context-build launch for all layers)
+                    Wt = torch.cat([w[:d] for w in wt] + [w[d:] for w in wt], 0).contiguous()
+                    Bt = torch.cat([b[:d] for b in bt] + [b[d:] for b in bt], 0).contiguous()
+                    ones, zeros = torch.ones(Lt, device=Wt.device), torch.zeros(Lt, device=Wt.device)
+                    bufs += [Wt, Bt, ones, zeros]
+                    arr[6 * L], arr[6 * L + 1], arr[6 * L + 2], arr[6 * L + 3] = Wt.data_ptr(), Bt.data_ptr(), ones.data_ptr(), zeros.data_ptr()
             self._derived_f32 = (ver, arr, bufs)
         return self._derived_f32[1]
 

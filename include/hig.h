@@ -181,12 +181,18 @@ int hig_denoiser_fwd_text(const hig_dims* dims, const void* const* params, const
                           void* workspace, int training, hig_stream_t stream);
 
 /* The general fp32-storage forward.  xf_out (nullable): compute the text side in this call (hig_denoiser_fwd_text), else
- * `textctx` is an input.  derived32 (nullable; inference only): 6 L device pointers the caller derives from the parameters and
+ * `textctx` is an input.  derived32 (nullable; inference only): 6 L + 4 device pointers the caller derives from the parameters and
  * rebuilds when they change -- [6 l + 3 k + 0 .. 2], k = 0 self-attention q/k/v (3d rows), k = 1 cross-attention query (d rows):
  * W' (fp32, rows x d) = gamma (.) W of the LayerNorm in front of the projection, colsum (rows) = row sums of W', bias' (rows) =
  * b + W beta.  With them the LayerNorm launches in front of those projections disappear (d % 128 == 0): the stylization-out
  * GEMM that produces the residual stream writes its row statistics (hig_gemm_desc.row_stats_out), the projection applies them
- * in its epilogue (row_stats_in).  Any entry may be NULL (that projection then keeps its LayerNorm kernel). */
+ * in its epilogue (row_stats_in).  Any entry may be NULL (that projection then keeps its LayerNorm kernel).
+ * The table has 6 L + 4 entries: [6 L + 0 .. 3] (all four or none; linear attention only) = the text side's key/value weights of
+ * ALL layers with their text_norm folded in, stacked as one (L 2d, Lt) fp32 matrix [gamma_l (.) Wk_l, l = 0 .. L-1; gamma_l (.) Wv_l,
+ * l = 0 .. L-1] (every layer's key rows, then every layer's value rows), the bias' in the same order
+ * b_l + W_l beta_l (L 2d), a vector of Lt ones and one of Lt zeros: with xf_out given, the L key/value GEMMs of the per-call
+ * text side run as ONE product over the affine-free LayerNorm of the text rows (`textctx` must then have hig_textctx_bytes(dims,
+ * 0) bytes, which includes that form's staging).  HIG_TEXT_BATCH=0 keeps the per-layer form. */
 int hig_denoiser_fwd_x(const hig_dims* dims, const void* const* params, const void* const* derived32, const float* x,
                        const int64_t* t, const int64_t* length, const float* xf_proj, const float* xf_out, void* textctx,
                        float* out, void* workspace, int training, hig_stream_t stream);

@@ -40,6 +40,9 @@ with torch.no_grad():
     gi = inputs(big)
     m = build(big).eval()
     out["f32_fwd_rows9408"] = norm(m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"]))
+    m.cache_text_context = False      # the reference's per-call form: text side inside the call (forked / batched: HIG_TEXT_FORK, HIG_TEXT_BATCH)
+    out["f32_fwd_per_call_rows9408"] = norm(m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"]))
+    m.cache_text_context = True
     m.storage = "bf16"
     out["bf16_fwd_rows9408"] = norm(m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"]))
     del m

@@ -618,3 +618,37 @@ def test_workspaces_are_not_overrun(two_person):
     for kind, big, pad, n in guards:
         assert bool((big[:pad] == 0xA5).all()) and bool((big[pad + max(n, 16):] == 0xA5).all()), kind
     assert torch.isfinite(x.grad).all()
+
+
+@pytest.mark.parametrize("case,B", [("config1", 2), ("width", 2), ("width", 30)])
+def test_per_call_forward_with_the_batched_text_side_against_the_oracle_and_the_cached_form(case, B):
+    """The reference computes the cross-attention text side on every call (transformer.py:144-150).  The fp32 inference forward
+    does so in ONE key/value GEMM over the stacked, text_norm-folded weights of all layers and ONE context build
+    (hig_denoiser_fwd_x with the derived table of models/transformer.py:_derived32): against the CPU oracle at the fp32 gate,
+    against the cached form (per-layer GEMMs with a LayerNorm prologue: hig_text_context) to rounding, bitwise repeatable.
+    B x 77 text rows: 154 (tiled GEMM), 2310 (the K = 256 instance of the weight-stationary kernel)."""
+    c = dict(fill.CASES[case])
+    if B != c["B"]:
+        c.update(B=B, lengths=tuple(c["T"] - (7 * i) % (c["T"] - 1) for i in range(B)), t=tuple((37 * i) % 1000 for i in range(B)))
+    m = build(c).eval()
+    inp = fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"])
+    gi = {k: v.to(DEV) for k, v in inp.items()}
+
+    def fwd():
+        with torch.no_grad():
+            return m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+
+    cached = fwd()
+    m.cache_text_context = False
+    per_call = fwd()
+    torch.cuda.synchronize()
+    assert m._derived32(m.flat_params())[6 * c["L"]] is not None          # the stacked text weights exist: the batched form ran
+    assert torch.isfinite(per_call).all()
+    assert rel(per_call, cached) < 2e-6
+    for _ in range(3):
+        assert torch.equal(fwd(), per_call)
+    n = min(B, 2)
+    p = fill.core_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"])
+    with torch.no_grad():
+        ref = R.denoiser_forward(p, inp["x"][:n], inp["t"][:n], inp["length"][:n], inp["xf_proj"][:n], inp["xf_out"][:n], c["H"], c["L"])
+    assert rel(per_call[:n], ref) < 2e-5

@@ -190,3 +190,32 @@ def test_weight_gradient_kernel_against_fp64(I, J, R, splits):
     act.copy_(Ai)
     o, x = run()
     assert torch.equal(o.cpu(), Ci.t() @ Ai) and torch.equal(x.cpu(), Ci.sum(0))
+
+
+@pytest.mark.parametrize("I,J", [(4928, 8192), (4928, 1024), (2464, 4096), (4925, 384), (2050, 128)])
+def test_k256_instance_plain_and_bias(I, J):
+    """K = 256 (text_latent_dim): the cross-attention key/value projection of the text rows (transformer.py:146,150), all layers'
+    weights stacked in ONE launch (J = 2 d L) or one layer's (J = 2 d); 128-column panels, one K part per matrix wave, two
+    epilogue passes per service wave.  Other epilogues are declined at this K (the tiled kernel serves them)."""
+    R = 256
+    X, W, b = rnd(I, R).to(DEV), rnd(J, R, seed=1, scale=0.05).to(DEV), rnd(J, seed=2).to(DEV)
+    prod = X.double() @ W.double().T
+    assert rel(launch(X, W), prod) < 2e-6
+    o = launch(X, W, epi=_lib.EPI_BIAS, bias=b)
+    assert rel(o, prod + b.double()) < 2e-6
+    assert (o.double().cpu() - (prod + b.double()).cpu()).abs().max().item() < 1e-4
+    for _ in range(3):
+        assert torch.equal(launch(X, W, epi=_lib.EPI_BIAS, bias=b), o)
+    h = (I // 2) // 16 * 16 + 5
+    if h >= 2048:
+        assert torch.equal(launch(X[:h], W, epi=_lib.EPI_BIAS, bias=b), o[:h])
+    g = torch.Generator().manual_seed(6)
+    Xi, Wi = torch.randint(-4, 5, (I, R), generator=g).float(), torch.randint(-4, 5, (J, R), generator=g).float()
+    assert torch.equal(launch(Xi.to(DEV), Wi.to(DEV)).cpu(), Xi @ Wi.T)
+    r = rnd(I, J, seed=3).to(DEV)
+    assert rel(launch(X, W, epi=_lib.EPI_BIAS_RES, bias=b, res=r, expect_wsp=False), prod + b.double() + r.double()) < 2e-6
+    # strided output (one layer's slice of the stacked key/value buffer)
+    if J == 1024:
+        big = torch.full((I, 4 * J), 3.0, device=DEV)
+        launch(X, W, epi=_lib.EPI_BIAS, bias=b, out=big[:, J:2 * J])
+        assert torch.equal(big[:, J:2 * J], o) and bool((big[:, :J] == 3.0).all()) and bool((big[:, 2 * J:] == 3.0).all())
