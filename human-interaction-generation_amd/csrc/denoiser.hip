@@ -867,7 +867,7 @@ __global__ void tok0_bf16_kernel(__bf16* __restrict__ buf, int64_t sample_stride
 }
 
 struct Text16Layout {
-  int64_t xfn, kv, kv_stride, cscr, layer0, lstride, Ac, Atc, kstc, total;
+  int64_t xfn, kv, kv_stride, cscr, layer0, lstride, Ac, Atc, kstc, kvall, total;
 };
 Text16Layout text16_layout(const Dims& D) {
   Text16Layout t;
@@ -885,6 +885,13 @@ Text16Layout text16_layout(const Dims& D) {
   t.kstc = take((int64_t)D.B * D.d * 2 * 4);
   t.lstride = o;
   t.total = t.layer0 + t.lstride * D.L;
+  // linear attention: room for the batched form of the text side (key/value projections of ALL layers as one (Mt, L 2d) matrix)
+  t.kvall = -1;
+  if (!D.full) {
+    o = t.total;
+    t.kvall = take(D.Mt * 2 * D.d * D.L * 2);
+    t.total = o;
+  }
   return t;
 }
 
@@ -919,22 +926,54 @@ static int ctx16(const Dims& D, const void* K, const void* V, int64_t ld, int B,
 }
 
 // layer_done (nullable): event l is recorded on `st` behind layer l's launches (the forked form of hig_denoiser_fwd_bf16_x)
-static int text_context16_impl(const Dims& D, const void* const* params, const void* const* params16, const float* xf_out, void* textctx,
-                               hipStream_t st, hipEvent_t* layer_done);
+static int text_context16_impl(const Dims& D, const void* const* params, const void* const* params16, const void* const* derived,
+                               const float* xf_out, void* textctx, hipStream_t st, hipEvent_t* layer_done);
 extern "C" int hig_text_context_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
                                      const float* xf_out, void* textctx, hig_stream_t stream) {
   Dims D;
   HIG_TRY(check_dims(dims, D));
   HIG_REQUIRE(D.bf16, "hig_text_context_bf16: dims->storage must be HIG_STORE_BF16");
   HIG_REQUIRE(params && params16 && xf_out && textctx, "hig_text_context_bf16: null argument");
-  return text_context16_impl(D, params, params16, xf_out, textctx, hig_stream(stream), nullptr);
+  return text_context16_impl(D, params, params16, nullptr, xf_out, textctx, hig_stream(stream), nullptr);
 }
-static int text_context16_impl(const Dims& D, const void* const* params, const void* const* params16, const float* xf_out, void* textctx,
-                               hipStream_t st, hipEvent_t* layer_done) {
+// derived (nullable): the caller's derived-operand table of hig_denoiser_fwd_bf16_x; entries [13 L + 1 .. 13 L + 4] select the
+// BATCHED form (text_context_impl above: one key/value GEMM over the stacked text_norm-folded bf16 weights of all layers, one
+// context build over L H heads)
+static bool text16_batched(const Dims& D, const void* const* derived) {
+  static const int batch_env = getenv("HIG_TEXT_BATCH") ? atoi(getenv("HIG_TEXT_BATCH")) : 1;   // tuning knob
+  return batch_env && derived && !D.full && derived[13 * D.L + 1] && derived[13 * D.L + 2] && derived[13 * D.L + 3] && derived[13 * D.L + 4];
+}
+static int text_context16_impl(const Dims& D, const void* const* params, const void* const* params16, const void* const* derived,
+                               const float* xf_out, void* textctx, hipStream_t st, hipEvent_t* layer_done) {
   const Text16Layout tl = text16_layout(D);
   char* base = static_cast<char*>(textctx);
   hig_stream_t stream = reinterpret_cast<hig_stream_t>(st);
   void* xfn = base + tl.xfn;
+  if (text16_batched(D, derived) && tl.kvall >= 0) {
+    char* kvall = base + tl.kvall;
+    const int64_t ldkv = (int64_t)D.L * 2 * D.d;
+    HIG_TRY(hig_ln_bf16(xf_out, 1, D.Lt, D.Mt, D.Lt, static_cast<const float*>(derived[13 * D.L + 3]),
+                        static_cast<const float*>(derived[13 * D.L + 4]), nullptr, 0, 0, 0, xfn, D.Lt, stream));
+    HIG_TRY(hig_gemm16_launch(G16(xfn, D.Lt, derived[13 * D.L + 1], D.Lt, kvall, ldkv, D.Mt, ldkv, D.Lt)
+                                  .epi(HIG_EPI_BIAS, static_cast<const float*>(derived[13 * D.L + 2])).g, st));
+    const char* Kall = kvall;
+    const char* Vall = kvall + (int64_t)D.L * D.d * 2;
+    int rc = hig_linattn_ctx16_groups(Kall, Vall, ldkv, D.B, D.N, D.H, D.L, D.hd,
+                                      reinterpret_cast<float*>(base + tl.layer0 + tl.Ac), tl.lstride / 4,
+                                      reinterpret_cast<float*>(base + tl.layer0 + tl.kstc), tl.lstride / 4,
+                                      base + tl.layer0 + tl.Atc, tl.lstride / 2, st);
+    if (rc < 0) return rc;
+    for (int l = 0; l < D.L; ++l) {
+      if (rc != HIG_OK) {   // (head dim not on the bf16 matrix-core kernel: one launch per layer)
+        float* Ac = reinterpret_cast<float*>(base + tl.layer0 + tl.lstride * l + tl.Ac);
+        float* kstc = reinterpret_cast<float*>(base + tl.layer0 + tl.lstride * l + tl.kstc);
+        HIG_TRY(ctx16(D, Kall + (int64_t)l * D.d * 2, Vall + (int64_t)l * D.d * 2, ldkv, D.B, D.N, nullptr, Ac, kstc,
+                      reinterpret_cast<float*>(base + tl.cscr), base + tl.layer0 + tl.lstride * l + tl.Atc, stream));
+      }
+      if (layer_done && hipEventRecord(layer_done[l], st) != hipSuccess) return hig_set_error(HIG_EHIP, "hipEventRecord failed");
+    }
+    return HIG_OK;
+  }
   for (int l = 0; l < D.L; ++l) {
     char* kv = base + tl.kv + tl.kv_stride * l;
     float* Ac = reinterpret_cast<float*>(base + tl.layer0 + tl.lstride * l + tl.Ac);
@@ -996,7 +1035,10 @@ static int denoiser_fwd16_impl(const hig_dims* dims, const void* const* params, 
   // chain alone COSTS 2-6 % at config 2 (its 35 us of launches are shorter than the two event waits they add): it is forked
   // only when its modulation weight is large (>= 256 MB: the d = 1024 models).
   static const int fork_knob = getenv("HIG_FWD16_FORK") ? atoi(getenv("HIG_FWD16_FORK")) : -1;   // tuning knob: bit 0 embedding chain, bit 1 text side
-  const int fork_env = fork_knob >= 0 ? fork_knob : (2 | (((int64_t)E * ss_ld * 2 >= (256ll << 20)) ? 1 : 0));
+  // (round 6: the BATCHED text side -- three launches, two of them chip-wide -- is faster in front of the frame-row launches than
+  // next to them: B = 64 1.488 against 1.540 ms, per-layer form 1.539 forked / 1.603 in front; not forked by default)
+  const bool batched_text = xf_out_for_text && text16_batched(D, lnfold);
+  const int fork_env = fork_knob >= 0 ? fork_knob : ((batched_text ? 0 : 2) | (((int64_t)E * ss_ld * 2 >= (256ll << 20)) ? 1 : 0));
   SideStream* fs = (fork_env && D.L < kMaxTextLayers) ? side_stream_for_current_device(st) : nullptr;
   if (fs) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1031,7 +1073,7 @@ static int denoiser_fwd16_impl(const hig_dims* dims, const void* const* params, 
   if (fork_emb && hipEventRecord(emb_ev, se) != hipSuccess) return join_side(hig_set_error(HIG_EHIP, "hipEventRecord failed"));
   hipEvent_t* text_ev = nullptr;
   if (xf_out_for_text) {
-    HIG_TRY_SIDE(text_context16_impl(D, params, params16, xf_out_for_text, const_cast<void*>(textctx), fork_text ? fs->s3 : st,
+    HIG_TRY_SIDE(text_context16_impl(D, params, params16, lnfold, xf_out_for_text, const_cast<void*>(textctx), fork_text ? fs->s3 : st,
                                      fork_text ? fs->text_done : nullptr));
     if (fork_text) text_ev = fs->text_done;
   }

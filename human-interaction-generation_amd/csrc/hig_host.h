@@ -56,6 +56,8 @@ bool hig_gemm_ws16_lnfold_ok(int64_t rows, int d);
 // linattn.hip: context build of G groups of H heads in one launch (the batched text side); 1 = shape not served
 int hig_linattn_ctx_groups(const float* K, const float* V, int64_t ld, int32_t B, int32_t rows, int32_t H, int32_t G, int32_t hd,
                            float* A, int64_t a_gs, float* kstat, int64_t k_gs, hipStream_t st);
+int hig_linattn_ctx16_groups(const void* K, const void* V, int64_t ld, int32_t B, int32_t rows, int32_t H, int32_t G, int32_t hd,
+                             float* A, int64_t a_gs, float* kstat, int64_t k_gs, void* At16, int64_t at_gs, hipStream_t st);   // (linattn16.hip, bf16 rows)
 // exact-fp32 weight-stationary kernel with specialised waves (gemm_wsp32.hip: K = 256 / 512 / 1024, reduce-contiguous aligned
 // operands, >= 2048 rows); same return codes
 int hig_gemm_wsp32_try(const hig_gemm_desc& g, hipStream_t st);

@@ -465,11 +465,17 @@ __global__ __launch_bounds__(512) void rows_out16_kernel(const __bf16* __restric
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
+// Output groups: head h belongs to group h / Hgrp (the layers of the batched text side, denoiser.hip); a group's A / kstat / At16
+// are laid out (B, Hgrp, ...) at the group strides (elements).  Hgrp = H: one group, the plain (B, H, ...) layout.
+struct Ctx16Groups {
+  int Hgrp;
+  int64_t a_gs, k_gs, at_gs;
+};
 template <int HD, int NB>
 __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restrict__ K, const __bf16* __restrict__ V, int64_t ld,
                                                          int rows, int H, const int64_t* __restrict__ length,
                                                          float* __restrict__ A, float* __restrict__ kstat,
-                                                         __bf16* __restrict__ At16) {
+                                                         __bf16* __restrict__ At16, const Ctx16Groups grp) {
   static_assert(HD == 64 || HD == 128, "head dim 64 or 128");
   constexpr int CHK = 64;                       // rows per chunk
   constexpr int ROWB = HD * 2;                  // bytes per LDS row (128 / 256)
@@ -492,6 +498,10 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int64_t oidx = (int64_t)b * grp.Hgrp + h % grp.Hgrp;   // index inside the group's (B, Hgrp) outputs
+  A += (h / grp.Hgrp) * grp.a_gs;
+  kstat += (h / grp.Hgrp) * grp.k_gs;
+  if (At16) At16 += (h / grp.Hgrp) * grp.at_gs;
   int len = rows;
   if (length) len = (int)min<int64_t>(max<int64_t>(length[b], 0), rows);
   const __bf16* Kb = K + (int64_t)b * rows * ld + h * HD;
@@ -649,7 +659,7 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float t = sWmax[0][4 * c4 + c] + sWmax[1][4 * c4 + c] + sWmax[2][4 * c4 + c] + sWmax[3][4 * c4 + c];
-      float* st = kstat + ((int64_t)blockIdx.x * HD + 4 * c4 + c) * 2;
+      float* st = kstat + (oidx * HD + 4 * c4 + c) * 2;
       st[0] = len > 0 ? mrun[c] : 0.f;
       st[1] = len > 0 ? t : 1.f;
     }
@@ -662,7 +672,7 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
 #pragma unroll
     for (int bj = 0; bj < NBW; ++bj) {
       const int lbase = 32 * (NBW * wj + bj);
-      float* ap = A + (int64_t)blockIdx.x * HD * HD + cc * HD + lbase + 4 * lh;
+      float* ap = A + oidx * HD * HD + cc * HD + lbase + 4 * lh;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<f32x4*>(ap + 8 * q) = f32x4{acc[bi][bj][4 * q] * inv, acc[bi][bj][4 * q + 1] * inv, acc[bi][bj][4 * q + 2] * inv, acc[bi][bj][4 * q + 3] * inv};
@@ -670,7 +680,7 @@ __global__ __launch_bounds__(256) void ctx16_mfma_kernel(const __bf16* __restric
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int l = lbase + 8 * (e >> 2) + 4 * lh + (e & 3);
-          At16[(int64_t)blockIdx.x * HD * HD + hig_at16_offset(HD, l, cc)] = (__bf16)(acc[bi][bj][e] * inv);
+          At16[oidx * HD * HD + hig_at16_offset(HD, l, cc)] = (__bf16)(acc[bi][bj][e] * inv);
         }
       }
     }
@@ -816,13 +826,30 @@ extern "C" int hig_linattn_ctx_mm16(const void* K, const void* V, int64_t ld, in
   constexpr int nb2_from = 512;   // (a former tuning knob, fixed at the value that won its A/B): workgroups from which the ring has two buffers (0 = never)
   if (hd == 64 && nb2_from > 0 && B * H >= nb2_from)
     hipLaunchKernelGGL((ctx16_mfma_kernel<64, 2>), dim3(B * H), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(K),
-                       static_cast<const __bf16*>(V), ld, rows, H, length, A, kstat, static_cast<__bf16*>(At16));
+                       static_cast<const __bf16*>(V), ld, rows, H, length, A, kstat, static_cast<__bf16*>(At16), Ctx16Groups{H, 0, 0, 0});
   else if (hd == 64)
     hipLaunchKernelGGL((ctx16_mfma_kernel<64, 3>), dim3(B * H), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(K),
-                       static_cast<const __bf16*>(V), ld, rows, H, length, A, kstat, static_cast<__bf16*>(At16));
+                       static_cast<const __bf16*>(V), ld, rows, H, length, A, kstat, static_cast<__bf16*>(At16), Ctx16Groups{H, 0, 0, 0});
   else
     hipLaunchKernelGGL((ctx16_mfma_kernel<128, 3>), dim3(B * H), dim3(256), 0, hig_stream(stream), static_cast<const __bf16*>(K),
-                       static_cast<const __bf16*>(V), ld, rows, H, length, A, kstat, static_cast<__bf16*>(At16));
+                       static_cast<const __bf16*>(V), ld, rows, H, length, A, kstat, static_cast<__bf16*>(At16), Ctx16Groups{H, 0, 0, 0});
+  HIG_CHECK_LAUNCH();
+  return HIG_OK;
+}
+
+// The same for G groups of H heads in ONE launch (the L layers of the batched text side): K / V hold G H heads side by side, group
+// g's outputs go to A + g a_gs, kstat + g k_gs, At16 + g at_gs in the plain (B, H, ...) layout.  No length mask.
+int hig_linattn_ctx16_groups(const void* K, const void* V, int64_t ld, int32_t B, int32_t rows, int32_t H, int32_t G, int32_t hd,
+                             float* A, int64_t a_gs, float* kstat, int64_t k_gs, void* At16, int64_t at_gs, hipStream_t st) {
+  if (!(hd == 64 || hd == 128) || B <= 0 || rows <= 0 || H <= 0 || G <= 0 || ld % 8 != 0) return 1;
+  const Ctx16Groups grp{H, a_gs, k_gs, at_gs};
+  const int n = B * H * G;
+  if (hd == 64)
+    hipLaunchKernelGGL((ctx16_mfma_kernel<64, 2>), dim3(n), dim3(256), 0, st, static_cast<const __bf16*>(K), static_cast<const __bf16*>(V),
+                       ld, rows, H * G, nullptr, A, kstat, static_cast<__bf16*>(At16), grp);
+  else
+    hipLaunchKernelGGL((ctx16_mfma_kernel<128, 3>), dim3(n), dim3(256), 0, st, static_cast<const __bf16*>(K), static_cast<const __bf16*>(V),
+                       ld, rows, H * G, nullptr, A, kstat, static_cast<__bf16*>(At16), grp);
   HIG_CHECK_LAUNCH();
   return HIG_OK;
 }

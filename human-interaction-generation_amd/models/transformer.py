@@ -629,7 +629,7 @@ class MotionTransformer(nn.Module):
 
     def _derived16(self, fp):
         """Operands of the bf16-storage forward derived from the parameters, kept next to the bf16 shadow and rebuilt
-        when the parameters change (`derived` of hig_denoiser_fwd_bf16): 13 L + 1 device pointers, NULL where a piece does
+        when the parameters change (`derived` of hig_denoiser_fwd_bf16): 13 L + 5 device pointers, NULL where a piece does
         not apply (the library then runs its LayerNorm kernel / pads per call).
         [13 l + 3 k + 0 .. 2] (d = 512 or 1024): the LayerNorm-folded projection k of layer l -- k = 0 self-attention q/k/v, 1
         cross-attention query, 2 q/k/v of the person <-> person attention (two-person model) -- as [W' (bf16), colsum, bias']
@@ -638,12 +638,32 @@ class MotionTransformer(nn.Module):
         producer of x wrote its row statistics.
         [13 l + 9 + s] (d = 512): the stylization-out weight of the self- (s = 0) / cross- (1) / person <-> person (2) attention /
         FFN (3) block in matrix-core operand order (_frag16) for the fused kernels hig_attn_out16 / hig_rows_out16.
-        [13 L]: joint_embed weight (transformer.py:418) rounded to bf16 and padded to a multiple of 32 columns."""
+        [13 L]: joint_embed weight (transformer.py:418) rounded to bf16 and padded to a multiple of 32 columns.
+        [13 L + 1 .. 13 L + 4] (linear attention): the text side's key/value weights of ALL layers with their text_norm folded
+        in (gamma (.) W, every layer's key rows then every layer's value rows, bf16), the bias' b + W beta in the same order
+        (fp32), Lt ones, Lt zeros -- the per-call text side then runs ONE GEMM and ONE context build (transformer.py:146-152)."""
         ver = (self._param_version(), fp.flat.data_ptr())
         if getattr(self, "_derived", None) is None or self._derived[0] != ver:
             d, nl, ng, offs, L = self.latent_dim, _lib.NLAYER, _lib.NGLOBAL, fp.group_offsets, self.num_layers
-            arr, bufs = (C.c_void_p * (13 * L + 1))(), []
+            arr, bufs = (C.c_void_p * (13 * L + 5))(), []
+            Lt = self.text_latent_dim
+            wt, bt = [], []
             with torch.no_grad():
+                for l in range(0 if self.no_eff else L):
+                    def tgrp(idx, n):
+                        o = offs[ng + l * nl + idx]
+                        return fp.flat[o:o + n]
+                    # text side, batched (see _derived32): gamma (.) [Wk; Wv] rounded to bf16, bias' = b + W beta in fp32
+                    g_t, b_t = tgrp(10, Lt).double(), tgrp(11, Lt).double()
+                    Wkv, bkv = tgrp(14, 2 * d * Lt).view(2 * d, Lt).double(), tgrp(15, 2 * d).double()
+                    wt.append((Wkv * g_t[None, :]).float())
+                    bt.append((bkv + Wkv @ b_t).float())
+                if wt and Lt % 8 == 0:
+                    Wt = torch.cat([w[:d] for w in wt] + [w[d:] for w in wt], 0).to(torch.bfloat16).contiguous()
+                    Bt = torch.cat([b[:d] for b in bt] + [b[d:] for b in bt], 0).contiguous()
+                    ones, zeros = torch.ones(Lt, device=Wt.device), torch.zeros(Lt, device=Wt.device)
+                    bufs += [Wt, Bt, ones, zeros]
+                    arr[13 * L + 1], arr[13 * L + 2], arr[13 * L + 3], arr[13 * L + 4] = Wt.data_ptr(), Bt.data_ptr(), ones.data_ptr(), zeros.data_ptr()
                 for l in range(L if d in (512, 1024) else 0):
                     def grp(idx, n):
                         o = offs[ng + l * nl + idx]

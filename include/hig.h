@@ -204,7 +204,7 @@ int hig_denoiser_fwd_x(const hig_dims* dims, const void* const* params, const vo
  * Workspace / text-context sizes: hig_workspace_bytes / hig_textctx_bytes with the same dims (training = 0). */
 int hig_text_context_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
                           const float* xf_out, void* textctx, hig_stream_t stream);
-/* derived (nullable): 13 L + 1 device pointers the caller derives from the parameters and keeps next to the bf16 shadow
+/* derived (nullable): 13 L + 5 device pointers the caller derives from the parameters and keeps next to the bf16 shadow
  * (rebuilt when the parameters change); any entry may be NULL (the library then does that piece per call / unfused).
  * [13 l + 3 k + 0 .. 2], k = 0, 1, 2, d == 512 or 1024: W' (bf16, rows x d), colsum (fp32, rows), bias' (fp32, rows) of the LayerNorm +
  * Linear pair k of layer l -- k = 0 self-attention q/k/v (3d rows), k = 1 cross-attention query (d rows), k = 2 q/k/v of the
@@ -214,7 +214,12 @@ int hig_text_context_bf16(const hig_dims* dims, const void* const* params, const
  * projection applies them in its epilogue (hig_gemm16_desc).
  * [13 l + 9 + s], s = 0, 1, 2, 3: the stylization-out weight of the self- / cross- / person <-> person attention / FFN block
  * in matrix-core operand order (hig_weight_frag16) for hig_attn_out16 / hig_rows_out16.
- * [13 L]: joint_embed weight padded and rounded for hig_joint_embed_bf16_w ((d, Fp) bf16, Fp = F rounded up to 32). */
+ * [13 L]: joint_embed weight padded and rounded for hig_joint_embed_bf16_w ((d, Fp) bf16, Fp = F rounded up to 32).
+ * [13 L + 1 .. 13 L + 4] (all four or none; linear attention; read by hig_denoiser_fwd_bf16_x when it computes the text side):
+ * the key/value weights of ALL layers with their text_norm folded in, stacked as one (L 2d, Lt) bf16 matrix (every layer's key
+ * rows gamma_l (.) Wk_l, then every layer's value rows), bias' = b_l + W_l beta_l in the same order (fp32, L 2d), Lt ones and
+ * Lt zeros (fp32): the text side then runs ONE key/value GEMM over the affine-free LayerNorm of the text rows and ONE context
+ * build instead of L of each (`textctx`: hig_textctx_bytes covers that form's staging).  HIG_TEXT_BATCH=0: per-layer form. */
 int hig_denoiser_fwd_bf16(const hig_dims* dims, const void* const* params, const void* const* params16,
                           const void* const* derived, const float* x,
                           const int64_t* t, const int64_t* length, const float* xf_proj, const void* textctx,

@@ -658,8 +658,13 @@ def test_bf16_storage_sees_parameter_updates_and_refuses_unsupported_head_dims()
 def test_bf16_per_call_text_side_on_the_side_stream_equals_the_cached_form(case):
     """hig_denoiser_fwd_bf16_x with xf_out (the reference's per-call forward: text side and, for the d = 1024 models, the
     embedding chain on a library-owned stream next to the frame-row launches) against the text context built first on the
-    caller's stream (cache_text_context=True): same kernels and operands, so the same bits -- on every one of a run of
-    back-to-back calls with changing inputs (a missing join would show as a stale or half-written context)."""
+    caller's stream (cache_text_context=True), on every one of a run of back-to-back calls with changing inputs (a missing join
+    would show as a stale or half-written context: the inputs of consecutive calls differ by far more than the tolerance).
+    Linear attention: the per-call form is the BATCHED text side (one key/value GEMM over the stacked, text_norm-folded bf16
+    weights of all layers, one context build over L H heads; round 6) -- another rounding sequence of the same arithmetic, so
+    the two forms agree at the bf16 level (rel-L2 <= 2e-2: ~8e-3 measured at the config-2 width, where each form is ~1.3e-2
+    from the fp32 oracle), the per-call form is no further from the fp32 CPU oracle than the cached one (+ 10 %), and each is
+    bitwise repeatable."""
     c = CASES16[case]
     m = build(c, storage="bf16").eval()
     base = fill.inputs(c["B"], c["T"], c["F"], c["d"], c["N"], c["Lt"], c["lengths"], c["t"])
@@ -678,9 +683,28 @@ def test_bf16_per_call_text_side_on_the_side_stream_equals_the_cached_form(case)
                 res.append(m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"]))
         torch.cuda.synchronize()
         outs[cached] = res
+    errs = []
     for a, b in zip(outs[True], outs[False]):
-        assert torch.isfinite(b).all() and torch.equal(a, b)
-    assert not torch.equal(outs[False][0], outs[False][1])
+        assert torch.isfinite(b).all()
+        errs.append(rel(b, a))
+    print("bf16 per-call (batched text side) vs cached form, rel-L2 per call:", ["%.2e" % e for e in errs])
+    assert max(errs) < 2e-2, errs
+    if case != "config5":                                        # (the oracle at 8 x 300 rows x d = 1024 is minutes of host time)
+        n = min(c["B"], 2)
+        gk = torch.Generator().manual_seed(100)
+        xo = base["xf_out"] + 0.5 * torch.randn(base["xf_out"].shape, generator=gk)
+        xp = base["xf_proj"] + 0.5 * torch.randn(base["xf_proj"].shape, generator=gk)
+        with torch.no_grad():
+            p = fill.core_params(c["F"], c["d"], c["ff"], c["L"], c["Lt"], c["num_frames"])
+            ref = R.denoiser_forward(p, base["x"][:n], base["t"][:n], base["length"][:n], xp[:n], xo[:n], c["H"], c["L"])
+        e_call, e_cached = rel(outs[False][0][:n], ref), rel(outs[True][0][:n], ref)
+        print("vs the fp32 oracle: per-call (batched) %.3e, cached (per layer) %.3e" % (e_call, e_cached))
+        assert e_call < 3e-2 and e_call < 1.1 * e_cached + 1e-3, (e_call, e_cached)
+    assert rel(outs[False][0], outs[False][1]) > 5e-2          # consecutive calls really differ
+    m.cache_text_context = False                                # the last call again: same bits
+    with torch.no_grad():
+        again = m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=gi["xf_out"])
+    assert torch.equal(again, outs[False][-1])
     del g
 
 
