@@ -78,6 +78,11 @@ if __name__ == "__main__":
         print("WSP=%s M=%d %-18s N=%4d K=%4d  %7.1f us  %6.1f TFLOP/s  frac %.3f" %
               (os.environ.get("HIG_F32_WSP", "1"), M, name, N, K, ms * 1e3, tf, tf / PEAK), flush=True)
     print("WSP=%s M=%d sum of the seven %.1f us" % (os.environ.get("HIG_F32_WSP", "1"), M, tot * 1e3))
+    if M == 12544:   # the text side's key/value projection over the 64 x 77 text rows: one layer, and all eight stacked (round 6)
+        for name, N in (("text k/v, one layer", 1024), ("text k/v, 8 layers", 8192)):
+            ms, tf = run(4928, N, 256, _lib.EPI_BIAS, 0)
+            print("WSP=%s M=%d %-18s N=%4d K=%4d  %7.1f us  %6.1f TFLOP/s  frac %.3f" %
+                  (os.environ.get("HIG_F32_WSP", "1"), 4928, name, N, 256, ms * 1e3, tf, tf / PEAK), flush=True)
 
 
 def run_wgrad(M, I, J, reps=20, warm=3):
