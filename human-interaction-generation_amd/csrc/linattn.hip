@@ -461,6 +461,106 @@ __global__ __launch_bounds__(256) void apply_mfma_kernel(const TIO* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// apply, exact fp32, head dim 64, WAVE-AUTONOMOUS (round 6): Y tile (16 rows) = softmax_c(Q tile) . A[b,h] per wave, no LDS and no
+// barrier in the loop.  The chunk-walking kernel above is insensitive to everything one would tune -- LDS traffic, the padded last
+// chunk, the number of workgroups, the row stride (profiles/r06_notes.md section 5): its 1 024 workgroups move through
+// load / softmax / barrier / multiply / barrier / stage / barrier / store in step, and each phase leaves the other units idle.
+// Here a wave owns 16-row tiles from the load to the store, so the waves of a SIMD drift apart and one's MFMAs cover
+// another's loads, exponentials and stores:
+//   * v_mfma_f32_16x16x4_f32 with the roles chosen so that NOTHING needs a transpose: the A operand's row index is the OUTPUT
+//     column l, the B operand's column index the tile ROW r, and the reduce index of k-step s, lane group kq is channel
+//     c = 16 kq + s.  Lane (r, kq) therefore needs p[r][16 kq .. 16 kq + 15] -- 64 contiguous bytes of its row, loaded as four
+//     float4 straight into the registers the MFMAs read -- and the row softmax is a reduction over the lane's 16 values and the
+//     4 lane groups (two cross-lane exchanges).
+//   * output row index i = 4 q + e of column block blk stands for column l = 16 q + 4 blk + e: lane (r, q) ends up with the 16
+//     CONSECUTIVE columns 16 q .. 16 q + 15 of row r in its four accumulators -- four 16-byte stores, a row's 256 bytes from
+//     its four lanes.
+//     its four lanes (written through 4 KB of wave-private LDS as whole rows all the same: the stores of one instruction would
+//     otherwise be 64 pieces of 16 bytes).
+//   * A[b,h] (16 KB) is staged once per workgroup through LDS into 64 registers per lane (the only two barriers); four
+//     independent accumulator chains of 16 MFMAs per tile; the next tile's Q is requested before the current one's softmax.
+// T = 196: 13 tiles of 16 rows (6 % padding) instead of 4 chunks of 64 (31 %).  Measured (tools/attn_time.py, B = 64): 21.2 ->
+// 19.3 us warm, 24.7 -> 20.4 us on cold operands -- a tenth, not the factor of two the pipes' budgets (6.3 us of MFMA, 10 us of
+// HBM) promise: prefetching all of a wave's tiles, one wave per tile with the operands in LDS (16 waves per workgroup) and
+// two workgroups per (sample, head) all measured the same or worse (profiles/r06_notes.md section 5).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float la_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void apply_wave64_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ A,
+                                                           float* __restrict__ Y, int64_t ldy, int rows, int H) {
+  constexpr int HD = 64;
+  __shared__ __attribute__((aligned(16))) float sA[HD * HD];    // [c][l]; later the waves' output staging
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int r = lane & 15, kq = lane >> 4;
+  const int ntile = (rows + 15) >> 4;
+  const float* qb = Q + (int64_t)b * rows * ldq + h * HD + 16 * kq;
+  float4 cur[4], nxt[4];
+  auto fetch = [&](int tile, float4 (&v)[4]) {
+    const int row = min(tile * 16 + r, rows - 1);              // (rows past the end: a copy of the last row, never stored)
+    const float4* p = reinterpret_cast<const float4*>(qb + (int64_t)row * ldq);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = p[i];
+  };
+  if (wave < ntile) fetch(wave, cur);                          // (in flight while A is staged)
+  {
+    const float4* Ab = reinterpret_cast<const float4*>(A + (int64_t)blockIdx.x * HD * HD);
+#pragma unroll
+    for (int i = 0; i < HD * HD / 4 / 256; ++i) reinterpret_cast<float4*>(sA)[tid + 256 * i] = Ab[tid + 256 * i];
+  }
+  __syncthreads();
+  float aop[16][4];                                            // [k-step s][column block]: A[16 kq + s][16 (r >> 2) + 4 blk + (r & 3)]
+#pragma unroll
+  for (int s2 = 0; s2 < 16; ++s2)
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) aop[s2][blk] = sA[(16 * kq + s2) * HD + 16 * (r >> 2) + 4 * blk + (r & 3)];
+  __syncthreads();                                             // every wave holds its operands: sA becomes the waves' output staging
+  float* const so = sA + wave * (16 * HD);
+  for (int tile = wave; tile < ntile; tile += 4) {
+    if (tile + 4 < ntile) fetch(tile + 4, nxt);
+    // softmax over the row's 64 channels: 16 in this lane, the other 48 in lanes r + 16, r + 32, r + 48
+    float m = fmaxf(fmaxf(fmaxf(cur[0].x, cur[0].y), fmaxf(cur[0].z, cur[0].w)), fmaxf(fmaxf(cur[1].x, cur[1].y), fmaxf(cur[1].z, cur[1].w)));
+    m = fmaxf(m, fmaxf(fmaxf(fmaxf(cur[2].x, cur[2].y), fmaxf(cur[2].z, cur[2].w)), fmaxf(fmaxf(cur[3].x, cur[3].y), fmaxf(cur[3].z, cur[3].w))));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float p[16];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      p[4 * i] = __expf(cur[i].x - m); p[4 * i + 1] = __expf(cur[i].y - m); p[4 * i + 2] = __expf(cur[i].z - m); p[4 * i + 3] = __expf(cur[i].w - m);
+      sum += (p[4 * i] + p[4 * i + 1]) + (p[4 * i + 2] + p[4 * i + 3]);
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    la_f32x4 acc[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) acc[blk] = la_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const float ps = p[s2] * inv;
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[s2][blk], ps, acc[blk], 0, 0, 0);
+    }
+    // out through this wave's 4 KB of LDS as WHOLE rows (straight from the accumulators a store instruction is 64 pieces of 16
+    // bytes, 64 bytes apart: four L2 write requests per 64-byte segment through the write-through L1; 21.0 -> 20.4 us cold)
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+      *reinterpret_cast<float4*>(so + r * HD + ((16 * kq + 4 * blk) ^ (4 * (r & 12)))) = make_float4(acc[blk][0], acc[blk][1], acc[blk][2], acc[blk][3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (a wave reads back only what it wrote itself)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = 4 * i + kq, cc = 4 * r;                     // lane (r, kq): row 4 i + kq of the tile, columns 4 r .. 4 r + 3
+      const float4 v = *reinterpret_cast<const float4*>(so + rr * HD + (cc ^ (4 * (rr & 12))));
+      const int row = tile * 16 + rr;
+      if (row < rows) *reinterpret_cast<float4*>(Y + ((int64_t)b * rows + row) * ldy + h * HD + cc) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+  }
+}
+
 struct CtxGroups {
   int Hgrp;            // heads per output group
   int64_t a_gs, k_gs;  // group strides of A / kstat in floats
@@ -1479,6 +1579,18 @@ int linattn_apply_t(const TIO* Q, int64_t ldq, const float* A, TIO* Y, int64_t l
   const int nchunk_a = (rows + CH - 1) / CH;
   // (hd = 128 keeps 97 KB of LDS per workgroup = one per CU: fewer, longer-lived workgroups; measured with
   // tools/attn_time.py: 61 -> 47 us at config 5, neutral at hd = 64)
+  if constexpr (sizeof(TIO) == 4) {
+    // exact fp32, head dim 64: the wave-autonomous kernel (16-row tiles per wave, no barrier in the loop)
+    static const int wave_env = getenv("HIG_APPLY_WAVE") ? atoi(getenv("HIG_APPLY_WAVE")) : 1;   // tuning knob
+    // (short sequences keep the chunk-walking kernel: T = 91 has 6 tiles for 4 waves, 11.3 against 10.1 us at B = 64)
+    if (wave_env && hd == 64 && rows >= 128 && ldq % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
+      hipLaunchKernelGGL(apply_wave64_kernel, dim3(B * H), dim3(256), 0, st, reinterpret_cast<const float*>(Q), ldq, A,
+                         reinterpret_cast<float*>(Y), ldy, rows, H);
+      HIG_CHECK_LAUNCH();
+      return HIG_OK;
+    }
+  }
   constexpr int apply_target = 0;   // (a former tuning knob, fixed at the value that won its A/B)
   // (re-swept in round 2, profiles/r02_attn_sweep.md: hd = 128 at 256 / 512 / 1024 workgroups: 42.4 / 48.7 / 58.9 us)
   const int target = apply_target > 0 ? apply_target : (hd == 128 ? 1 : 4) * hig_chip_cus();

@@ -572,3 +572,32 @@ def test_gemm_wgrad_with_fused_column_sums(I, J, R):
     d.x_rs, d.ldx = 0, R                     # a reduce-contiguous X cannot provide the sums: loud error
     with pytest.raises(RuntimeError, match="xcolsum"):
         _lib.check(_lib.lib().hig_gemm(C.byref(d), _lib.stream_ptr()))
+
+
+@pytest.mark.parametrize("B,T,H", [(3, 128, 8), (2, 131, 4), (64, 196, 8), (2, 257, 8), (5, 300, 2)])
+def test_wave_autonomous_apply_kernel_fp32_hd64(B, T, H):
+    """hig_linattn_apply, exact fp32, head dim 64, >= 128 rows: the wave-autonomous kernel (16-row tiles per wave, MFMA operand
+    roles chosen so that neither q nor y is transposed, transformer.py:111,116-118) against the fp64 definition -- query rows
+    inside the stacked q/k/v buffer (row stride 3 d) and on their own (cross-attention, stride d), ragged last tile, nothing
+    written outside the (B T, d) output."""
+    hd = 64
+    d = H * hd
+    L = _lib.lib()
+    s = _lib.stream_ptr()
+    A = (rnd(B, H, hd, hd, seed=3) * 0.2).to(DEV)
+    for ldq in (3 * d, d):
+        qb = rnd(B * T, ldq, scale=1.5, seed=ldq).to(DEV)
+        q = qb[:, :d]
+        ybig = torch.full((B * T + 3, d + 8), 5.0, device=DEV)
+        y = ybig[:B * T, :d]
+        _lib.check(L.hig_linattn_apply(P(q), ldq, P(A), P(y), d + 8, B, T, H, hd, s))
+        torch.cuda.synchronize()
+        p = torch.softmax(q.double().view(B, T, H, hd), dim=-1)
+        ref = torch.einsum("bnhd,bhdl->bnhl", p, A.double()).reshape(B * T, d)
+        assert rel(y, ref) < 2e-6, (ldq, rel(y, ref))
+        assert (y.double() - ref).abs().max().item() < 2e-5
+        assert bool((ybig[:, d:] == 5.0).all()) and bool((ybig[B * T:] == 5.0).all())
+        y2 = torch.empty(B * T, d, device=DEV)
+        _lib.check(L.hig_linattn_apply(P(q), ldq, P(A), P(y2), d, B, T, H, hd, s))
+        torch.cuda.synchronize()
+        assert torch.equal(y2, y.contiguous())

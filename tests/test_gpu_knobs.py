@@ -21,7 +21,7 @@ KNOBS = [
     ("HIG_CTX16", "0"), ("HIG_FWD16_FORK", "0"), ("HIG_JOINT16", "0"), ("HIG_FUSE_APPLY", "0"), ("HIG_FUSE_OUT", "0"),
     ("HIG_EDGE16", "0"), ("HIG_BF16_TILE", "64"), ("HIG_BF16_FEWROW", "0"), ("HIG_BF16_WS", "0"), ("HIG_BF16_WSP", "0"),
     ("HIG_BF16_WS_NWJ", "4"), ("HIG_BF16_WS_ROWS", "100000"), ("HIG_LNFOLD", "0"), ("HIG_LNFOLD1024", "0"), ("HIG_CHIP_CUS", "128"), ("HIG_F32_WSP", "0"),
-    ("HIG_TEXT_BATCH", "0"),
+    ("HIG_TEXT_BATCH", "0"), ("HIG_APPLY_WAVE", "0"),
 ]
 
 
