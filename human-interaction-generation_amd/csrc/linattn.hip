@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256) void apply_mfma_kernel(const TIO* __restrict__
 // two workgroups per (sample, head) all measured the same or worse (profiles/r06_notes.md section 5).
 // ---------------------------------------------------------------------------------------------------------------------
 typedef float la_f32x4 __attribute__((ext_vector_type(4)));
+typedef int la_i32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void apply_wave64_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ A,
                                                            float* __restrict__ Y, int64_t ldy, int rows, int H) {
   constexpr int HD = 64;
@@ -495,14 +496,22 @@ __global__ __launch_bounds__(256) void apply_wave64_kernel(const float* __restri
   const int r = lane & 15, kq = lane >> 4;
   const int ntile = (rows + 15) >> 4;
   const float* qb = Q + (int64_t)b * rows * ldq + h * HD + 16 * kq;
-  float4 cur[4], nxt[4];
-  auto fetch = [&](int tile, float4 (&v)[4]) {
+  // The prefetch is written as loads hipcc does not see and a counted wait that names the loaded registers: as C++ loads it sank
+  // them to their use (register pressure), copied them early (a use: vmcnt(0) in the middle of the MFMAs) or -- with any of the
+  // loads / stores under an `if` -- lost count and waited vmcnt(0) for the write acknowledgements of the tile before as well;
+  // each of the three left a tile waiting a full memory latency (found in the disassembly).  Vector-memory operations of a wave
+  // retire in issue order (the counted waits of gemm_wsp32.hip rest on the same): behind a tile's four loads come the four
+  // stores of the tile in front of it and the four loads of the tile after it.
+  la_f32x4 q0[4], q1[4];
+  auto fetch = [&](int tile, la_f32x4 (&v)[4]) {
     const int row = min(tile * 16 + r, rows - 1);              // (rows past the end: a copy of the last row, never stored)
-    const float4* p = reinterpret_cast<const float4*>(qb + (int64_t)row * ldq);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = p[i];
+    const float* p = qb + (int64_t)row * ldq;
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p) : "memory");
   };
-  if (wave < ntile) fetch(wave, cur);                          // (in flight while A is staged)
+  fetch(min(wave, ntile - 1), q0);                             // (in flight while A is staged: the A loads behind it are C++ loads,
+                                                               //  waited for by hipcc before their LDS stores -- in order, so q0 has landed too)
   {
     const float4* Ab = reinterpret_cast<const float4*>(A + (int64_t)blockIdx.x * HD * HD);
 #pragma unroll
@@ -516,8 +525,10 @@ __global__ __launch_bounds__(256) void apply_wave64_kernel(const float* __restri
     for (int blk = 0; blk < 4; ++blk) aop[s2][blk] = sA[(16 * kq + s2) * HD + 16 * (r >> 2) + 4 * blk + (r & 3)];
   __syncthreads();                                             // every wave holds its operands: sA becomes the waves' output staging
   float* const so = sA + wave * (16 * HD);
-  for (int tile = wave; tile < ntile; tile += 4) {
-    if (tile + 4 < ntile) fetch(tile + 4, nxt);
+  __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(Y + (int64_t)b * rows * ldy, 0, (int)(((int64_t)(rows - 1) * ldy + H * HD) * 4), 0x00020000);
+  auto tile_out = [&](int tile, la_f32x4 (&cur)[4], auto younger) {
+    constexpr int YOUNGER = decltype(younger)::value;          // vector-memory operations issued behind this tile's loads
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : "n"(YOUNGER) : "memory");
     // softmax over the row's 64 channels: 16 in this lane, the other 48 in lanes r + 16, r + 32, r + 48
     float m = fmaxf(fmaxf(fmaxf(cur[0].x, cur[0].y), fmaxf(cur[0].z, cur[0].w)), fmaxf(fmaxf(cur[1].x, cur[1].y), fmaxf(cur[1].z, cur[1].w)));
     m = fmaxf(m, fmaxf(fmaxf(fmaxf(cur[2].x, cur[2].y), fmaxf(cur[2].z, cur[2].w)), fmaxf(fmaxf(cur[3].x, cur[3].y), fmaxf(cur[3].z, cur[3].w))));
@@ -543,7 +554,7 @@ __global__ __launch_bounds__(256) void apply_wave64_kernel(const float* __restri
       for (int blk = 0; blk < 4; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[s2][blk], ps, acc[blk], 0, 0, 0);
     }
     // out through this wave's 4 KB of LDS as WHOLE rows (straight from the accumulators a store instruction is 64 pieces of 16
-    // bytes, 64 bytes apart: four L2 write requests per 64-byte segment through the write-through L1; 21.0 -> 20.4 us cold)
+    // bytes, 64 bytes apart: four L2 write requests per 64-byte segment through the write-through L1)
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk)
       *reinterpret_cast<float4*>(so + r * HD + ((16 * kq + 4 * blk) ^ (4 * (r & 12)))) = make_float4(acc[blk][0], acc[blk][1], acc[blk][2], acc[blk][3]);
@@ -552,13 +563,31 @@ __global__ __launch_bounds__(256) void apply_wave64_kernel(const float* __restri
     for (int i = 0; i < 4; ++i) {
       const int rr = 4 * i + kq, cc = 4 * r;                     // lane (r, kq): row 4 i + kq of the tile, columns 4 r .. 4 r + 3
       const float4 v = *reinterpret_cast<const float4*>(so + rr * HD + (cc ^ (4 * (rr & 12))));
+      // UNCONDITIONAL stores through a buffer descriptor that ends with the sample's last row (rows past it are dropped by the
+      // range check), and unconditional (clamped) prefetches below: with either inside an `if`, hipcc cannot count the
+      // outstanding vector-memory operations and waits vmcnt(0) -- for the write acknowledgements of this tile AND the rows of
+      // the tile after next -- in the middle of the next tile's MFMAs (found in the disassembly: it made the prefetch worthless)
       const int row = tile * 16 + rr;
-      if (row < rows) *reinterpret_cast<float4*>(Y + ((int64_t)b * rows + row) * ldy + h * HD + cc) = v;
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(la_i32x4, v), rsY, (row * (int)ldy + h * HD + cc) * 4, 0, 0);
+#endif
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+  };
+  // two register sets alternate (no copies: a copy of the prefetched rows is a use, and hipcc schedules it -- and its wait -- early)
+  using I4 = std::integral_constant<int, 4>;
+  using I8 = std::integral_constant<int, 8>;
+  if (wave >= ntile) return;                                   // (never with >= 64 rows)
+  fetch(min(wave + 4, ntile - 1), q1);
+  tile_out(wave, q0, I4{});                                     // (behind q0: only the loads of q1 -- the A loads were waited for above)
+  for (int tile = wave + 4; tile < ntile; tile += 8) {
+    fetch(min(tile + 4, ntile - 1), q0);
+    tile_out(tile, q1, I8{});
+    if (tile + 4 >= ntile) break;
+    fetch(min(tile + 8, ntile - 1), q1);
+    tile_out(tile + 4, q0, I8{});
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (a clamped, unused prefetch may still be in flight)
 }
 
 struct CtxGroups {

@@ -150,22 +150,26 @@ def test_text_context_cache_follows_inplace_parameter_updates():
     m.temporal_decoder_blocks[0].ca_block.text_norm.weight.grad = torch.ones_like(m.temporal_decoder_blocks[0].ca_block.text_norm.weight)
     opt.step()
     assert not torch.equal(fwd(m), a)
-    # cache switched off: every forward recomputes the text side (hig_denoiser_fwd_text: forked onto the library's text stream
-    # and joined layer by layer), same numbers as the cached context, repeatably, also right after the inputs change
+    # cache switched off: every forward recomputes the text side inside the call (hig_denoiser_fwd_x; since round 6 in its batched
+    # form -- one key/value GEMM over the stacked text_norm-folded weights, another rounding order of the same arithmetic): the
+    # cached context's numbers to rounding, repeatably bit for bit, also right after the inputs change
+    def close(u, v):
+        return ((u - v).norm() / v.norm()).item() < 2e-6
+
     m.cache_text_context = True
     c0 = fwd(m)
     m.cache_text_context = False
     c1 = fwd(m)
-    assert torch.equal(c1, c0) and torch.equal(c1, fwd(m))
+    assert close(c1, c0) and torch.equal(c1, fwd(m))
     xo2 = gi["xf_out"] * 1.25
     with torch.no_grad():
         d1 = m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=xo2)
         m.cache_text_context = True
         d0 = m(gi["x"], gi["t"], length=gi["length"], xf_proj=gi["xf_proj"], xf_out=xo2)
-    assert torch.equal(d1, d0) and not torch.equal(d1, c1)
-    for _ in range(20):          # the text stream's events are reused call after call
+    assert close(d1, d0) and not torch.equal(d1, c1)        # (text_norm makes a rescaled xf_out an eps-level change: not equal, but close)
+    for _ in range(20):          # (the per-layer form's text-stream events, or the batched form's staging, are reused call after call)
         m.cache_text_context = False
-        assert torch.equal(fwd(m), c0)
+        assert torch.equal(fwd(m), c1)
 
 
 def test_captured_step_survives_rehoming_of_the_model():
