@@ -478,11 +478,11 @@ __global__ __launch_bounds__(256) void apply_mfma_kernel(const TIO* __restrict__
 //     its four lanes.
 //     its four lanes (written through 4 KB of wave-private LDS as whole rows all the same: the stores of one instruction would
 //     otherwise be 64 pieces of 16 bytes).
-//   * A[b,h] (16 KB) is staged once per workgroup through LDS into 64 registers per lane (the only two barriers); four
+//   * A[b,h] (16 KB) is staged once per workgroup through LDS (in operand order) into 64 registers per lane (the only barrier); four
 //     independent accumulator chains of 16 MFMAs per tile; the next tile's Q is requested before the current one's softmax.
 // T = 196: 13 tiles of 16 rows (6 % padding) instead of 4 chunks of 64 (31 %).  Measured (tools/attn_time.py, B = 64): 21.2 ->
-// 19.3 us warm, 24.7 -> 20.4 us on cold operands -- a tenth, not the factor of two the pipes' budgets (6.3 us of MFMA, 10 us of
-// HBM) promise: prefetching all of a wave's tiles, one wave per tile with the operands in LDS (16 waves per workgroup) and
+// 17.0 us warm -- a fifth, not the factor of two the pipes' budgets (6.3 us of MFMA, 10 us of
+// HBM) promise: the launch is short enough that every serial microsecond of its start shows (operand staging, above); prefetching all of a wave's tiles, one wave per tile with the operands in LDS (16 waves per workgroup) and
 // two workgroups per (sample, head) all measured the same or worse (profiles/r06_notes.md section 5).
 // ---------------------------------------------------------------------------------------------------------------------
 typedef float la_f32x4 __attribute__((ext_vector_type(4)));
@@ -490,7 +490,8 @@ typedef int la_i32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void apply_wave64_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ A,
                                                            float* __restrict__ Y, int64_t ldy, int rows, int H) {
   constexpr int HD = 64;
-  __shared__ __attribute__((aligned(16))) float sA[HD * HD];    // [c][l]; later the waves' output staging
+  __shared__ __attribute__((aligned(16))) float sA[HD * HD];    // A[b,h] in MFMA-operand order (below)
+  __shared__ __attribute__((aligned(16))) float sO[4 * 16 * HD]; // the waves' output staging
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int r = lane & 15, kq = lane >> 4;
@@ -513,18 +514,28 @@ __global__ __launch_bounds__(256) void apply_wave64_kernel(const float* __restri
   fetch(min(wave, ntile - 1), q0);                             // (in flight while A is staged: the A loads behind it are C++ loads,
                                                                //  waited for by hipcc before their LDS stores -- in order, so q0 has landed too)
   {
+    // staged in MFMA-operand order: float4 (c, r) = A[c][16 (r >> 2) + 4 blk + (r & 3)], blk = 0 .. 3 -- the four A operands of a
+    // k-step in ONE conflict-free ds_read_b128 per lane (read as 64 scalars from the row-major image, the eight waves of a CU's
+    // two workgroups spent ~2 us of its LDS pipe on four-way bank conflicts before their first MFMA: 19.0 -> 17.5 us)
     const float4* Ab = reinterpret_cast<const float4*>(A + (int64_t)blockIdx.x * HD * HD);
+    float4 areg[HD * HD / 4 / 256];
 #pragma unroll
-    for (int i = 0; i < HD * HD / 4 / 256; ++i) reinterpret_cast<float4*>(sA)[tid + 256 * i] = Ab[tid + 256 * i];
+    for (int i = 0; i < HD * HD / 4 / 256; ++i) areg[i] = Ab[tid + 256 * i];
+#pragma unroll
+    for (int i = 0; i < HD * HD / 4 / 256; ++i) {
+      const int f = tid + 256 * i, c = f >> 4, l = 4 * (f & 15);   // channel c, columns l .. l + 3: row index 4 (l >> 4) + e, block (l >> 2) & 3
+      float* dst = sA + ((c * 16) + 4 * (l >> 4)) * 4 + ((l >> 2) & 3);
+      dst[0] = areg[i].x; dst[4] = areg[i].y; dst[8] = areg[i].z; dst[12] = areg[i].w;
+    }
   }
   __syncthreads();
   float aop[16][4];                                            // [k-step s][column block]: A[16 kq + s][16 (r >> 2) + 4 blk + (r & 3)]
 #pragma unroll
-  for (int s2 = 0; s2 < 16; ++s2)
-#pragma unroll
-    for (int blk = 0; blk < 4; ++blk) aop[s2][blk] = sA[(16 * kq + s2) * HD + 16 * (r >> 2) + 4 * blk + (r & 3)];
-  __syncthreads();                                             // every wave holds its operands: sA becomes the waves' output staging
-  float* const so = sA + wave * (16 * HD);
+  for (int s2 = 0; s2 < 16; ++s2) {
+    const float4 a4 = reinterpret_cast<const float4*>(sA)[(16 * kq + s2) * 16 + r];
+    aop[s2][0] = a4.x; aop[s2][1] = a4.y; aop[s2][2] = a4.z; aop[s2][3] = a4.w;
+  }
+  float* const so = sO + wave * (16 * HD);                     // (its own 4 KB per wave: no second barrier before the first tile; 17.5 -> 17.0 us)
   __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(Y + (int64_t)b * rows * ldy, 0, (int)(((int64_t)(rows - 1) * ldy + H * HD) * 4), 0x00020000);
   auto tile_out = [&](int tile, la_f32x4 (&cur)[4], auto younger) {
     constexpr int YOUNGER = decltype(younger)::value;          // vector-memory operations issued behind this tile's loads
