@@ -68,14 +68,30 @@ __global__ __launch_bounds__(256) void ln_mod_silu_kernel(
   if (row >= rows) return;
   const float* xr = x + row * ldx;
   float4 v[NIT];
-  float s = 0.f;
+  // gamma / beta / scale / shift of this lane's columns are requested WITH the row, not behind its statistics: issued where they
+  // are used (inside `if (c < n)`, one slice after the other) every wave paid two more memory latencies in a row -- row, then
+  // the first slice's parameters, then the second's (disassembly; round 6)
+  float4 g4[NIT], b4[NIT], sc4[MOD ? NIT : 1], sh4[MOD ? NIT : 1];
+  const float* ssrow = MOD ? ss + (row / rows_per_sample) * ss_ld : nullptr;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int c = 4 * lane + 256 * it;
     v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < n) v[it] = *reinterpret_cast<const float4*>(xr + c);
-    s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+    g4[it] = b4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (MOD) sc4[it] = sh4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < n) {
+      v[it] = *reinterpret_cast<const float4*>(xr + c);
+      g4[it] = *reinterpret_cast<const float4*>(gamma + c);
+      b4[it] = *reinterpret_cast<const float4*>(beta + c);
+      if constexpr (MOD) {
+        sc4[it] = *reinterpret_cast<const float4*>(ssrow + c);
+        sh4[it] = *reinterpret_cast<const float4*>(ssrow + shift_off + c);
+      }
+    }
   }
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
   const float mean = wave_sum(s) / (float)n;
   float q = 0.f;
 #pragma unroll
@@ -96,32 +112,26 @@ __global__ __launch_bounds__(256) void ln_mod_silu_kernel(
     for (int it = 0; it < NIT; ++it) {
       const int c = 4 * lane + 256 * it;
       if (c < n) {
-        const float4 g4 = *reinterpret_cast<const float4*>(gamma + c);
-        const float4 b4 = *reinterpret_cast<const float4*>(beta + c);
         float4 o;
-        o.x = (v[it].x - mean) * rstd * g4.x + b4.x;
-        o.y = (v[it].y - mean) * rstd * g4.y + b4.y;
-        o.z = (v[it].z - mean) * rstd * g4.z + b4.z;
-        o.w = (v[it].w - mean) * rstd * g4.w + b4.w;
+        o.x = (v[it].x - mean) * rstd * g4[it].x + b4[it].x;
+        o.y = (v[it].y - mean) * rstd * g4[it].y + b4[it].y;
+        o.z = (v[it].z - mean) * rstd * g4[it].z + b4[it].z;
+        o.w = (v[it].w - mean) * rstd * g4[it].w + b4[it].w;
         *reinterpret_cast<float4*>(a + row * lda + c) = o;
       }
     }
     return;
   }
-  const float* ssrow = ss + (row / rows_per_sample) * ss_ld;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int c = 4 * lane + 256 * it;
     if (c < n) {
-      const float4 g4 = *reinterpret_cast<const float4*>(gamma + c);
-      const float4 b4 = *reinterpret_cast<const float4*>(beta + c);
-      const float4 sc = *reinterpret_cast<const float4*>(ssrow + c);
-      const float4 sh = *reinterpret_cast<const float4*>(ssrow + shift_off + c);
+      const float4 sc = sc4[MOD ? it : 0], sh = sh4[MOD ? it : 0];
       float4 o;
-      o.x = hig_silu(((v[it].x - mean) * rstd * g4.x + b4.x) * (1.0f + sc.x) + sh.x);
-      o.y = hig_silu(((v[it].y - mean) * rstd * g4.y + b4.y) * (1.0f + sc.y) + sh.y);
-      o.z = hig_silu(((v[it].z - mean) * rstd * g4.z + b4.z) * (1.0f + sc.z) + sh.z);
-      o.w = hig_silu(((v[it].w - mean) * rstd * g4.w + b4.w) * (1.0f + sc.w) + sh.w);
+      o.x = hig_silu(((v[it].x - mean) * rstd * g4[it].x + b4[it].x) * (1.0f + sc.x) + sh.x);
+      o.y = hig_silu(((v[it].y - mean) * rstd * g4[it].y + b4[it].y) * (1.0f + sc.y) + sh.y);
+      o.z = hig_silu(((v[it].z - mean) * rstd * g4[it].z + b4[it].z) * (1.0f + sc.z) + sh.z);
+      o.w = hig_silu(((v[it].w - mean) * rstd * g4[it].w + b4[it].w) * (1.0f + sc.w) + sh.w);
       *reinterpret_cast<float4*>(a + row * lda + c) = o;
     }
   }
