@@ -525,7 +525,14 @@ __global__ __launch_bounds__(256) void apply_wave64_kernel(const float* __restri
     for (int i = 0; i < HD * HD / 4 / 256; ++i) {
       const int f = tid + 256 * i, c = f >> 4, l = 4 * (f & 15);   // channel c, columns l .. l + 3: row index 4 (l >> 4) + e, block (l >> 2) & 3
       float* dst = sA + ((c * 16) + 4 * (l >> 4)) * 4 + ((l >> 2) & 3);
-      dst[0] = areg[i].x; dst[4] = areg[i].y; dst[8] = areg[i].z; dst[12] = areg[i].w;
+      // element e of the float4 goes to dst[4 e]; the four channels c of a wave write DIFFERENT elements in the same instruction
+      // (e = (j + c) & 3), so one scalar-store instruction touches all 32 banks instead of 8
+      const float el[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = (j + c) & 3;
+        dst[4 * e] = e == 0 ? el[0] : e == 1 ? el[1] : e == 2 ? el[2] : el[3];
+      }
     }
   }
   __syncthreads();
@@ -568,12 +575,12 @@ __global__ __launch_bounds__(256) void apply_wave64_kernel(const float* __restri
     // bytes, 64 bytes apart: four L2 write requests per 64-byte segment through the write-through L1)
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk)
-      *reinterpret_cast<float4*>(so + r * HD + ((16 * kq + 4 * blk) ^ (4 * (r & 12)))) = make_float4(acc[blk][0], acc[blk][1], acc[blk][2], acc[blk][3]);
+      *reinterpret_cast<float4*>(so + r * HD + ((16 * kq + 4 * blk) ^ (4 * r))) = make_float4(acc[blk][0], acc[blk][1], acc[blk][2], acc[blk][3]);   // (16-byte chunk q of row r at q ^ r: conflict-free both ways)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (a wave reads back only what it wrote itself)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rr = 4 * i + kq, cc = 4 * r;                     // lane (r, kq): row 4 i + kq of the tile, columns 4 r .. 4 r + 3
-      const float4 v = *reinterpret_cast<const float4*>(so + rr * HD + (cc ^ (4 * (rr & 12))));
+      const float4 v = *reinterpret_cast<const float4*>(so + rr * HD + (cc ^ (4 * rr)));
       // UNCONDITIONAL stores through a buffer descriptor that ends with the sample's last row (rows past it are dropped by the
       // range check), and unconditional (clamped) prefetches below: with either inside an `if`, hipcc cannot count the
       // outstanding vector-memory operations and waits vmcnt(0) -- for the write acknowledgements of this tile AND the rows of
