@@ -70,6 +70,25 @@ def soak16(name, c, layers=None):
                 assert torch.equal(a, b), (name, it, k, (a.float() - b.float()).abs().max().item())
     print("%s: %d identical iterations" % (name, n))
 
+# round 6: the fp32 per-call INFERENCE forward -- gemm_wsp32 / the batched text side (one K = 256 GEMM, one context build over L H
+# heads) / apply_wave64 with its opaque prefetch loads and counted waits -- with ragged lengths, back to back
+def soak32_inference(name, c):
+    m = bench.build_model(c, dev).eval()
+    m.cache_text_context = False
+    i = bench.make_inputs(c, dev, 0)
+    i["length"] = (torch.arange(c["B"], device=dev) * 37 % c["T"] + 1).long()
+    ref = None
+    with torch.no_grad():
+        for it in range(n):
+            out = m(i["x"], i["t"], length=i["length"], xf_proj=i["xf_proj"], xf_out=i["xf_out"]).clone()
+            if ref is None:
+                ref = out
+                assert torch.isfinite(out).all()
+            else:
+                assert torch.equal(out, ref), (name, it, (out - ref).abs().max().item())
+    print("%s: %d identical iterations" % (name, n))
+
+soak32_inference("fp32 per-call inference forward, config 2", dict(bench.CFG))
 soak16("bf16 storage, config 2 (training step + per-call inference forward)", bench.CFG)
 soak16("bf16 storage, config-5 width (B=32 T=300 d=1024 H=8, 3 layers)", dict(bench.CFG, B=32, T=300, d=1024, H=8, ff=1024), layers=3)
 
