@@ -622,7 +622,7 @@ def main():
         extra["fwd_f32_text_hoisted"] = {
             "frames_per_s": round(B * T * max(5, a.steps // 2) * world / el_h, 1),
             "ms_per_step": round(el_h / max(5, a.steps // 2) * 1e3, 3),
-            "what": "same forward with the cross-attention text context (8 K/V GEMMs + 8 context builds) computed once "
+            "what": "same forward with the cross-attention text context (key/value projections + context builds of the 8 layers) computed once "
                     "and cached -- what every step of p_sample_loop runs; NOT the headline"}
         model.cache_text_context = False
         # ---- same forward with the reduced-product GEMM modes (opt-in `precision=`) ----------
