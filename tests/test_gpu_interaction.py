@@ -136,10 +136,15 @@ BF16_TRAIN_CASES = {
     # weight-stationary GEMMs and the sliced weight-gradient kernel serve the step as they do at full size
     "rows2184": dict(B=12, T=91, F=263, d=512, H=8, L=2, ff=1024, N=77, Lt=256, num_frames=100,
                      lengths=(91, 40, 91, 2, 77, 91, 13, 91, 60, 91, 91, 5), t=(0, 999, 500, 250, 7, 650, 313, 900, 77, 42, 810, 123)),
+    # the BENCHMARKED two-person training shape (bench.py `two_person.pit_train_step_ms_bf16_storage`): 32 pairs
+    # = 64 model rows x 91 tokens x 263 features, d = 512, 8 heads, L = 8 -- 5 824 rows through every kernel of the bf16 step at
+    # its full-size work split, ragged lengths incl. near-empty samples
+    "bench64": dict(B=64, T=91, F=263, d=512, H=8, L=8, ff=1024, N=77, Lt=256, num_frames=196,
+                    lengths=tuple([91] * 40 + [2 + (11 * i) % 89 for i in range(24)]), t=tuple((37 * i + 5) % 1000 for i in range(64))),
 }
 
 
-@pytest.mark.parametrize("case,nocross", [("hd64", False), ("hd64", True), ("hd128", False), ("rows2184", False)])
+@pytest.mark.parametrize("case,nocross", [("hd64", False), ("hd64", True), ("hd128", False), ("rows2184", False), ("bench64", False)])
 def test_bf16_storage_two_person_backward_every_gradient_against_oracle_autograd(case, nocross):
     """storage='bf16' TRAINING of the two-person model (what the reference's tools/train.py trains: trainers/mul_ddpm_trainer.py
     :91-163 over models/interaction_transformer.py:167-207,334-367): forward with kept bf16 activations, backward through the
