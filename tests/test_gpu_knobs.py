@@ -54,3 +54,16 @@ def test_every_switch_selects_between_implementations_of_the_same_arithmetic(kno
         ref = default_digest[k]
         tol = 2e-2 if k.startswith("bf16") else 2e-4       # bf16 storage: another rounding sequence; fp32: another summation order
         assert abs(v - ref) <= tol * abs(ref), (knob, k, v, ref)
+
+
+def test_fused_and_unfused_attention_front_pass_the_same_gradient_gates_against_the_oracle():
+    """the bf16 training forward runs attention output + LayerNorm + modulation + SiLU as ONE kernel that normalises its
+    fp32 accumulators while the y it saves is rounded to bf16, so the backward recomputes the LayerNorm statistics from slightly
+    different values than the forward used (the unfused sequence, HIG_FUSE_APPLY=0, normalises exactly the bf16 y it saves).  Both
+    forms must pass the SAME gates against the fp32 oracle's autograd: the default runs in the suite
+    (tests/test_gpu_bf16_training.py), the unfused form here, in a child process (the switch is read once per process)."""
+    env = dict(os.environ, OMP_NUM_THREADS="16", HIG_FUSE_APPLY="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_bf16_training.py"),
+                        "-k", "every_gradient_against_oracle_autograd and width16"], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
